@@ -1,0 +1,135 @@
+/* yl_amd.h -- C ABI of the MI355X-native YOLO11 detect inference path (libyl_amd.so).
+ *
+ * The reference (dongyunjinyu/YOLO-Lite @ 2025-03-03) has no FFI / plugin interface: its boundary
+ * is the Python object API.  This header is the boundary underneath our
+ * Python mirror of that API; each entry point names the reference code it replaces (paths relative
+ * to /root/reference/yololite).  Plain pointers and sizes only -- no torch types.  Device pointers
+ * come from the caller (PyTorch-ROCm allocations); `stream` is a hipStream_t passed as void*.
+ *
+ * All functions return 0 on success and a negative code on failure; yl_last_error() returns a
+ * thread-local message.  Handles are not thread-safe individually (the reference predictor
+ * serialises calls with a lock, engine/predictor.py:65,159, and so does ours).
+ */
+#ifndef YL_AMD_H
+#define YL_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YL_ABI_VERSION 1
+
+/* element types */
+enum { YL_BF16 = 0, YL_F32 = 1, YL_F16 = 2, YL_U8 = 3 };
+
+/* op kinds of an engine program */
+enum {
+  YL_OP_CONV = 1,     /* dense 1x1 / 3x3, stride 1 / 2, +bias, optional SiLU, optional residual  */
+  YL_OP_DWCONV3 = 2,  /* depthwise 3x3 stride 1, +bias, optional SiLU, optional accumulate        */
+  YL_OP_SPPF_POOL = 3,/* three chained MaxPool2d(5,1,2): writes pool5/9/13 after the input slice  */
+  YL_OP_UPSAMPLE = 4, /* nearest upsample by `stride` (1 = plain copy) into a channel slice        */
+  YL_OP_ATTENTION = 5 /* softmax(q^T k * scale) applied to v, per head (C2PSA)                     */
+};
+
+/* A channel-slice view of an NHWC buffer inside the workspace arena. */
+typedef struct yl_view {
+  int64_t offset; /* byte offset from the workspace base; < 0 = absent                      */
+  int32_t H, W, C;/* logical dims per image                                                  */
+  int32_t pitch;  /* channels of the underlying buffer (elements between pixel starts)       */
+  int32_t coff;   /* first channel of this view inside the buffer                            */
+  int32_t dtype;  /* YL_BF16 or YL_F32                                                       */
+} yl_view;
+
+/* One op.  Weights are HOST pointers to BN-folded fp32 data; yl_engine_create packs them
+ * (bf16, MFMA fragment order) into device memory it owns.
+ *   conv   : weight [Cout][Cin][k][k], bias [Cout]      (reference nn/modules/conv.py:35-53 with
+ *            BN folded as utils/torch_utils.py:182-209; Bottleneck residual block.py:341-343)
+ *   dwconv : weight [C][1][3][3],   bias [C]            (conv.py:100-105)
+ *   pool   : nn/modules/block.py:180-184                 upsample: nn.Upsample in yolo11.yaml:31,35
+ *   attn   : nn/modules/block.py:905-913                 (in = qkv map, out = attended v)        */
+typedef struct yl_op {
+  int32_t kind;
+  int32_t k;          /* kernel size (1 or 3)                                        */
+  int32_t stride;     /* conv stride (1|2) or upsample factor (1|2)                  */
+  int32_t act;        /* 1 = SiLU                                                    */
+  int32_t accumulate; /* dwconv: out += result                                       */
+  int32_t heads, key_dim, head_dim; /* attention geometry                            */
+  float scale;        /* attention score scale                                       */
+  /* dwconv input channel map: in_channel(c) = (c / grp) * grp_stride + grp_off + c % grp;
+     grp == 0 means identity.  Used for Attention.pe on the v channels (block.py:913). */
+  int32_t grp, grp_stride, grp_off;
+  int32_t cin_weight; /* conv: input channels of `weight` if fewer than in.C (stem: 3 of 8); 0 = in.C */
+  yl_view in, out, res; /* res.offset < 0: no residual                               */
+  const float* weight;
+  const float* bias;
+} yl_op;
+
+/* Detect-level raw map: fp32 NHWC [B][H][W][64 + nc] (reference head.py:64-65 torch.cat(cv2, cv3)) */
+typedef struct yl_level {
+  int64_t offset;
+  int32_t H, W;
+  float stride;
+  int32_t reserved;
+} yl_level;
+
+typedef struct yl_engine yl_engine;
+
+const char* yl_last_error(void);
+int yl_abi_version(void);
+/* Number of visible HIP devices, or a negative code.  Does not create a context. */
+int yl_device_count(void);
+
+/* Build an engine for a fixed (batch, in_h, in_w): packs weights, picks kernel configs.
+ * Replaces nn/tasks.py:118-145 (BaseModel._predict_once layer loop) + nn/autobackend.py:34-124.
+ * `input_view` is where the converted NHWC bf16 input (channels padded to 8) is written. */
+int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h, int in_w,
+                     const yl_view* input_view, const yl_level* levels, int n_levels, int nc,
+                     int64_t workspace_bytes, yl_engine** out);
+void yl_engine_destroy(yl_engine* e);
+
+/* Network forward: input NCHW (YL_F32 / YL_F16 in [0,1], or YL_U8 in [0,255] which is divided by
+ * 255 as engine/predictor.py:82-84 does) -> raw level maps in the workspace -> y[B][4+nc][A] fp32
+ * decoded as nn/modules/head.py:95-126 (+ block.py:51-69 DFL, utils/tal.py:326-350).
+ * y may be NULL (raw maps only).  Enqueues on `stream`; no host sync. */
+int yl_engine_forward(yl_engine* e, const void* input, int in_dtype, void* workspace, float* y,
+                      void* stream);
+/* Same, replayed from a hipGraph captured on first use for this (input, workspace, y) triple. */
+int yl_engine_forward_graph(yl_engine* e, const void* input, int in_dtype, void* workspace,
+                            float* y, void* stream);
+/* Times each op with HIP events on `stream` (`iters` launches each, after one warm-up pass).
+ * ms[n_ops + 2]: [0] input conversion, [1..n_ops] ops, [n_ops+1] decode. Synchronises. */
+int yl_engine_profile(yl_engine* e, const void* input, int in_dtype, void* workspace, float* y,
+                      void* stream, int iters, float* ms);
+int yl_engine_num_ops(const yl_engine* e);
+/* Algorithmic work of op i: flops (2*MAC), bytes read+written once; name is a static string. */
+int yl_engine_op_info(const yl_engine* e, int i, double* flops, double* bytes, const char** kernel_name);
+
+/* Detect decode alone (device pointers): raw level maps -> y[B][4+nc][A].  head.py:95-126. */
+int yl_detect_decode(const void* workspace, const yl_level* levels, int n_levels, int batch, int nc,
+                     float* y, void* stream);
+
+/* Non-maximum suppression.  Replaces utils/ops.py:138-273 (single-label branch) including the
+ * torchvision.ops.nms call at ops.py:265, and optionally utils/ops.py:66-98 scale_boxes +
+ * ops.py:276-295 clip_boxes when `scale` is non-NULL.
+ *   pred      [B][4+nc][A] fp32 (cx, cy, w, h, class scores); NOT modified
+ *   classes   optional device int32[n_classes] filter (ops.py:247-248), NULL = all
+ *   scale     optional device float[B][5] = {pad_x, pad_y, gain, orig_w, orig_h}
+ *   out       [B][max_det][6] fp32 (x1, y1, x2, y2, conf, cls), score-descending
+ *   out_count [B] int32
+ *   work      device scratch of yl_nms_workspace_bytes(B, A, max_cand) bytes
+ * max_cand caps candidates per image (reference max_nms = 30000, ops.py:254-255; top scores kept). */
+int64_t yl_nms_workspace_bytes(int batch, int anchors, int max_cand);
+int yl_nms(const float* pred, int batch, int nc, int anchors, float conf_thres, float iou_thres,
+           int max_det, int agnostic, const int32_t* classes, int n_classes, int max_cand,
+           float max_wh, const float* scale, float* out, int32_t* out_count, void* work, void* stream);
+
+/* uint8 HWC BGR letterboxed images -> float NCHW RGB / 255 (engine/predictor.py:77-84). */
+int yl_preprocess_u8(const uint8_t* bgr_hwc, int batch, int h, int w, float* out_nchw, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YL_AMD_H */

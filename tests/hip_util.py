@@ -1,0 +1,75 @@
+"""Helpers for the -m gpu parity tests: build one-op engine programs around torch tensors."""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+
+from yololite_amd.nn.engine import HipEngine
+from yololite_amd.nn.lower import BF16, F32, OP_ATTENTION, OP_CONV, OP_DWCONV3, OP_SPPF_POOL, OP_UPSAMPLE, Program, TView, _Arena
+
+
+def bf16_round(t: torch.Tensor) -> torch.Tensor:
+    return t.to(torch.bfloat16).float()
+
+
+class Mini:
+    """A hand-built program: allocate buffers, add ops, upload NCHW tensors, run, read back."""
+
+    def __init__(self, batch: int, device):
+        self.batch = batch
+        self.device = device
+        self.ar = _Arena(batch)
+        self.prog = Program(batch, 32, 32, 80)
+        self.prog.input_view = self.ar.alloc(32, 32, 8)
+        self.fills = []
+        self.eng: Optional[HipEngine] = None
+
+    def buf(self, H, W, C, dtype=BF16) -> TView:
+        return self.ar.alloc(H, W, C, dtype)
+
+    def fill(self, view: TView, x_nchw: torch.Tensor):
+        self.fills.append((view, x_nchw))
+
+    def op(self, **kw):
+        kw.setdefault("res", None)
+        self.prog.ops.append(kw)
+
+    def run(self):
+        self.prog.ws_bytes = self.ar.top + 256
+        self.eng = HipEngine(self.prog, self.device)
+        ws = self.eng.workspace
+        ws.zero_()
+        for v, x in self.fills:
+            esz, dt = (4, torch.float32) if v.dtype == F32 else (2, torch.bfloat16)
+            n = self.batch * v.H * v.W * v.pitch
+            t = ws[v.offset: v.offset + esz * n].view(dt).view(self.batch, v.H, v.W, v.pitch)
+            t[..., v.coff: v.coff + v.C] = x.permute(0, 2, 3, 1).to(dt).to(self.device)
+        im = torch.zeros(self.batch, 3, 32, 32, device=self.device)
+        self.eng.forward(im, decode=False)
+        torch.cuda.synchronize()
+
+    def read(self, view: TView) -> torch.Tensor:
+        return self.eng.view_tensor(view).cpu()
+
+
+def run_conv(device, x, w, b, k, s, act, res=None, pitch_extra=(0, 0), out_f32=False, cin_weight=0):
+    """x (B,Cin,H,W) fp32 (already bf16-representable), w OIHW, b (Cout,) -> HIP conv output (fp32 NCHW)."""
+    B, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    p = k // 2
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    m = Mini(B, device)
+    xin = m.buf(H, W, Cin + pitch_extra[0]).slice(pitch_extra[0], Cin) if pitch_extra[0] else m.buf(H, W, Cin)
+    yb = m.buf(Ho, Wo, Cout + pitch_extra[1], F32 if out_f32 else BF16)
+    yv = yb.slice(pitch_extra[1], Cout) if pitch_extra[1] else yb
+    m.fill(xin, x)
+    rv = None
+    if res is not None:
+        rv = m.buf(Ho, Wo, Cout)
+        m.fill(rv, res)
+    m.op(kind=OP_CONV, name="t", k=k, stride=s, act=int(act), inp=xin, out=yv, res=rv,
+         weight=np.ascontiguousarray(w.numpy()), bias=np.ascontiguousarray(b.numpy()), cin_weight=cin_weight)
+    m.run()
+    return m.read(yv)

@@ -1,0 +1,176 @@
+"""-m gpu: each HIP kernel against a plain PyTorch fp32 reference of the same op.
+
+Inputs and weights are rounded to bf16 first, so the only differences left are fp32 accumulation
+order and the final bf16 rounding of the output (<= 2^-8 relative): tolerances below say so.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from hip_util import Mini, bf16_round, run_conv
+from yololite_amd.nn.lower import BF16, F32, OP_ATTENTION, OP_DWCONV3, OP_SPPF_POOL, OP_UPSAMPLE
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(g, *shape, scale=1.0):
+    return bf16_round(torch.randn(*shape, generator=g) * scale)
+
+
+def _assert_close_bf16(got, ref, what=""):
+    # output is bf16: half an ulp is 2^-9 relative; accumulation-order noise is far below that
+    tol = 2.0 ** -8 * ref.abs().clamp(min=1e-2) + 1e-3
+    err = (got - ref).abs()
+    bad = err > tol
+    assert not bad.any(), f"{what}: {int(bad.sum())} / {bad.numel()} off, max err {float(err.max()):.4g}"
+
+
+CONV_CASES = [
+    # Cin, Cout, k, s, H, W, act, res      (YOLO11 n/s/x shapes)
+    (8, 16, 3, 2, 64, 64, True, False),     # stem (Cin padded 3 -> 8)
+    (16, 32, 3, 2, 40, 40, True, False),
+    (16, 8, 3, 1, 40, 40, True, False),     # Bottleneck cv1 of layer 2 (Cout 8 -> half an MFMA tile)
+    (8, 16, 3, 1, 40, 40, True, True),      # Bottleneck cv2 + shortcut
+    (32, 32, 1, 1, 40, 40, True, False),
+    (48, 64, 1, 1, 40, 40, True, False),    # C3k2 cv2, Cin 48 (non-uniform K path)
+    (64, 64, 3, 2, 40, 40, True, False),
+    (64, 64, 3, 1, 20, 20, True, True),
+    (128, 128, 3, 2, 20, 20, True, False),
+    (128, 256, 3, 2, 20, 20, True, False),
+    (256, 64, 3, 1, 20, 20, True, False),   # Detect cv2[2][0], chunked Cin
+    (384, 128, 1, 1, 20, 20, True, False),
+    (512, 256, 1, 1, 10, 10, True, False),  # SPPF cv2
+    (80, 80, 1, 1, 20, 20, False, False),   # Detect class head (bias, no act)
+    (96, 128, 1, 1, 12, 20, True, False),
+    (48, 48, 3, 1, 12, 20, True, True),     # x-scale C3k bottleneck
+    (64, 64, 3, 1, 7, 9, True, False),      # ragged map
+    (32, 16, 3, 1, 33, 17, True, False),
+]
+
+
+@pytest.mark.parametrize("cin,cout,k,s,h,w,act,res", CONV_CASES)
+def test_conv_vs_torch(gpu_device, cin, cout, k, s, h, w, act, res):
+    g = torch.Generator().manual_seed(cin * 1000 + cout * 10 + k + s)
+    B = 3
+    x = _rand(g, B, cin, h, w)
+    wt = _rand(g, cout, cin, k, k, scale=1.0 / math.sqrt(cin * k * k))
+    b = torch.randn(cout, generator=g) * 0.5
+    ref = F.conv2d(x, wt, b, s, k // 2)
+    if act:
+        ref = F.silu(ref)
+    r = None
+    if res:
+        r = _rand(g, *ref.shape)
+        ref = ref + r
+    got = run_conv(gpu_device, x, wt, b, k, s, act, r)
+    _assert_close_bf16(got, ref, f"conv {cin}->{cout} k{k} s{s}")
+
+
+def test_conv_slices_and_f32_out(gpu_device):
+    """Reads a channel slice, writes a channel slice of an fp32 buffer (Detect head layout)."""
+    g = torch.Generator().manual_seed(7)
+    x = _rand(g, 2, 64, 20, 20)
+    wt = _rand(g, 80, 64, 1, 1, scale=0.125)
+    b = torch.randn(80, generator=g)
+    ref = F.conv2d(x, wt, b)
+    got = run_conv(gpu_device, x, wt, b, 1, 1, False, None, pitch_extra=(16, 64), out_f32=True)
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-4, atol=1e-4)  # fp32 out: order noise only
+
+
+def test_conv_stem_cin3(gpu_device):
+    g = torch.Generator().manual_seed(8)
+    x3 = bf16_round(torch.rand(2, 3, 64, 64, generator=g))
+    x = torch.cat([x3, torch.zeros(2, 5, 64, 64)], 1)
+    wt = _rand(g, 16, 3, 3, 3, scale=0.2)
+    b = torch.randn(16, generator=g) * 0.1
+    ref = F.silu(F.conv2d(x3, wt, b, 2, 1))
+    got = run_conv(gpu_device, x, wt, b, 3, 2, True, None, cin_weight=3)
+    _assert_close_bf16(got, ref, "stem")
+
+
+@pytest.mark.parametrize("c,h,w,act", [(64, 20, 20, True), (80, 13, 9, True), (128, 10, 10, False)])
+def test_dwconv_vs_torch(gpu_device, c, h, w, act):
+    g = torch.Generator().manual_seed(c)
+    x = _rand(g, 2, c, h, w)
+    wt = torch.randn(c, 1, 3, 3, generator=g) * 0.3
+    b = torch.randn(c, generator=g) * 0.2
+    ref = F.conv2d(x, wt, b, 1, 1, 1, c)
+    ref = F.silu(ref) if act else ref
+    m = Mini(2, gpu_device)
+    xin, out = m.buf(h, w, c), m.buf(h, w, c)
+    m.fill(xin, x)
+    m.op(kind=OP_DWCONV3, name="dw", k=3, stride=1, act=int(act), inp=xin, out=out, weight=wt.numpy(), bias=b.numpy())
+    m.run()
+    _assert_close_bf16(m.read(out), ref, "dwconv")
+
+
+def test_dwconv_headmap_accumulate(gpu_device):
+    """Attention.pe: depthwise conv on the v channels of the qkv map, added to the attention output."""
+    g = torch.Generator().manual_seed(3)
+    nh, kd, hd, h, w = 2, 32, 64, 6, 5
+    qkv = _rand(g, 2, nh * (2 * kd + hd), h, w)
+    prev = _rand(g, 2, nh * hd, h, w)
+    wt = torch.randn(nh * hd, 1, 3, 3, generator=g) * 0.3
+    b = torch.randn(nh * hd, generator=g) * 0.2
+    v = qkv.view(2, nh, 2 * kd + hd, h, w)[:, :, 2 * kd:].reshape(2, nh * hd, h, w)
+    ref = prev + F.conv2d(v, wt, b, 1, 1, 1, nh * hd)
+    m = Mini(2, gpu_device)
+    xin, out = m.buf(h, w, qkv.shape[1]), m.buf(h, w, nh * hd)
+    m.fill(xin, qkv)
+    m.fill(out, prev)
+    m.op(kind=OP_DWCONV3, name="pe", k=3, stride=1, act=0, accumulate=1, grp=hd, grp_stride=2 * kd + hd,
+         grp_off=2 * kd, inp=xin, out=out, weight=wt.numpy(), bias=b.numpy())
+    m.run()
+    _assert_close_bf16(m.read(out), ref, "pe")
+
+
+@pytest.mark.parametrize("c,h,w", [(128, 20, 20), (64, 5, 7), (256, 12, 20)])
+def test_sppf_pool_vs_torch(gpu_device, c, h, w):
+    g = torch.Generator().manual_seed(c + h)
+    x = _rand(g, 2, c, h, w)
+    m = Mini(2, gpu_device)
+    sbuf = m.buf(h, w, 4 * c)
+    m.fill(sbuf.slice(0, c), x)
+    m.op(kind=OP_SPPF_POOL, name="pool", inp=sbuf.slice(0, c), out=sbuf.slice(0, c))
+    m.run()
+    y1 = F.max_pool2d(x, 5, 1, 2)
+    y2 = F.max_pool2d(y1, 5, 1, 2)
+    y3 = F.max_pool2d(y2, 5, 1, 2)
+    np.testing.assert_array_equal(m.read(sbuf).numpy(), torch.cat([x, y1, y2, y3], 1).numpy())  # max is exact
+
+
+def test_upsample_and_copy(gpu_device):
+    g = torch.Generator().manual_seed(5)
+    x = _rand(g, 2, 64, 10, 7)
+    m = Mini(2, gpu_device)
+    xin, cat = m.buf(10, 7, 64), m.buf(20, 14, 96)
+    cp = m.buf(10, 7, 80)
+    m.fill(xin, x)
+    m.op(kind=OP_UPSAMPLE, name="up", stride=2, inp=xin, out=cat.slice(0, 64))
+    m.op(kind=OP_UPSAMPLE, name="cp", stride=1, inp=xin, out=cp.slice(16, 64))
+    m.run()
+    np.testing.assert_array_equal(m.read(cat.slice(0, 64)).numpy(), F.interpolate(x, scale_factor=2.0).numpy())
+    np.testing.assert_array_equal(m.read(cp.slice(16, 64)).numpy(), x.numpy())
+
+
+@pytest.mark.parametrize("nh,h,w", [(2, 20, 20), (1, 7, 5), (4, 20, 12), (2, 40, 40)])
+def test_attention_vs_torch(gpu_device, nh, h, w):
+    """reference nn/modules/block.py:905-912 on the per-head [q|k|v] channel layout."""
+    g = torch.Generator().manual_seed(nh * 100 + h)
+    kd, hd, B = 32, 64, 2
+    N = h * w
+    qkv = _rand(g, B, nh * (2 * kd + hd), h, w)
+    q, k, v = qkv.view(B, nh, 2 * kd + hd, N).split([kd, kd, hd], dim=2)
+    attn = ((q.transpose(-2, -1) @ k) * kd ** -0.5).softmax(-1)
+    ref = (v @ attn.transpose(-2, -1)).view(B, nh * hd, h, w)
+    m = Mini(B, gpu_device)
+    xin, out = m.buf(h, w, qkv.shape[1]), m.buf(h, w, nh * hd)
+    m.fill(xin, qkv)
+    m.op(kind=OP_ATTENTION, name="attn", heads=nh, key_dim=kd, head_dim=hd, scale=float(kd ** -0.5), inp=xin, out=out)
+    m.run()
+    got = m.read(out)
+    # fp32 math on bf16 inputs, bf16 output; __expf adds ~1e-6 relative
+    _assert_close_bf16(got, ref, "attention")

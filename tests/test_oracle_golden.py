@@ -1,0 +1,111 @@
+"""Pins oracle/yolo11_oracle.py against vectors computed by the reference itself
+(tests/golden/make_golden.py).  CPU only."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import yolo11_oracle as oracle
+from yololite_amd.nn.synth import synth_state_dict
+
+
+def _digest(sd):
+    h = hashlib.sha256()
+    for k in sorted(sd):
+        h.update(k.encode())
+        h.update(sd[k].detach().cpu().contiguous().numpy().tobytes())
+    return h.hexdigest()
+
+
+NETS = [("n", 64, 64, 0), ("n", 96, 128, 1), ("s", 64, 64, 2), ("m", 64, 64, 3), ("x", 64, 64, 4)]
+
+
+@pytest.mark.parametrize("scale,h,w,seed", NETS)
+def test_forward_matches_reference(golden, scale, h, w, seed):
+    tag = f"net_{scale}_{h}x{w}"
+    sd = synth_state_dict(scale, seed, cls_bias=list(golden[tag + "_bias"]), cls_gain=8.0)
+    assert _digest(sd) == bytes(golden[tag + "_sd"]).decode(), "weight synthesizer drifted from the fixture"
+    x = torch.from_numpy(golden[tag + "_x"])
+    with torch.inference_mode():
+        y, raw = oracle.forward(sd, x, scale)
+    # same fp32 ATen kernels in a different call order: tolerance covers summation-order noise only
+    for i, r in enumerate(raw):
+        np.testing.assert_allclose(r.numpy(), golden[f"{tag}_raw{i}"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(y.numpy(), golden[tag + "_y"], rtol=1e-4, atol=2e-4)
+
+
+def test_every_layer_matches_reference(golden):
+    sd = synth_state_dict("n", 0, cls_bias=list(golden["layers_n_bias"]), cls_gain=8.0)
+    x = torch.from_numpy(golden["layers_n_x"])
+    with torch.inference_mode():
+        y, raw, ys = oracle.forward(sd, x, "n", return_layers=True)
+    for i in range(23):
+        np.testing.assert_allclose(ys[i].numpy(), golden[f"layers_n_{i}"], rtol=1e-4, atol=1e-4, err_msg=f"layer {i}")
+    np.testing.assert_allclose(y.numpy(), golden["layers_n_y"], rtol=1e-4, atol=2e-4)
+
+
+def test_forward_640_subsample(golden):
+    sd = synth_state_dict("n", 0, cls_bias=list(golden["net_n_640_bias"]), cls_gain=8.0)
+    x = torch.rand(1, 3, 640, 640, generator=torch.Generator().manual_seed(300))
+    assert abs(x.double().sum().item() - golden["net_n_640_xsum"][0]) < 1e-6
+    with torch.inference_mode():
+        y, _ = oracle.forward(sd, x, "n")
+    np.testing.assert_allclose(y[:, :, ::37].numpy(), golden["net_n_640_ysub"], rtol=1e-4, atol=5e-4)
+    np.testing.assert_allclose(y.double().sum(2).numpy(), golden["net_n_640_ysum"], rtol=1e-5, atol=5e-2)
+    det = oracle.non_max_suppression(y, 0.25, 0.7, max_det=300)[0].numpy()
+    ref = golden["net_n_640_det0"]
+    assert det.shape == ref.shape
+    np.testing.assert_array_equal(det[:, 5], ref[:, 5])
+    np.testing.assert_allclose(det, ref, rtol=1e-4, atol=1e-3)
+
+
+NMS_CASES = ["sep", "twocls", "hiiou", "agnostic", "classes", "cls79", "empty", "trunc"]
+
+
+@pytest.mark.parametrize("name", NMS_CASES)
+def test_nms_matches_reference(golden, name):
+    pred = torch.from_numpy(golden[f"nms_{name}_pred"])
+    conf, iou, agn, max_det = golden[f"nms_{name}_kw"]
+    classes = golden[f"nms_{name}_classes"].tolist() or None
+    res = oracle.non_max_suppression(pred, float(conf), float(iou), classes=classes, agnostic=bool(agn),
+                                     max_det=int(max_det))
+    assert [len(r) for r in res] == golden[f"nms_{name}_n"].tolist()
+    got = np.concatenate([r.numpy() for r in res], 0) if sum(len(r) for r in res) else np.zeros((0, 6), np.float32)
+    np.testing.assert_array_equal(got, golden[f"nms_{name}_out"])  # bit-exact fp32
+
+
+def test_letterbox_geometry(golden):
+    for h0, w0, auto, nw, nh, top, bottom, left, right, oh, ow, val in golden["letterbox_geo"].tolist():
+        g = oracle.letterbox_geometry((h0, w0), (640, 640), auto=bool(auto), stride=32)
+        assert g["new_unpad"] == (nw, nh)
+        assert g["pads"] == (top, bottom, left, right)
+        assert g["out_shape"] == (oh, ow)
+        assert val == 114
+    # the survey's known answer for boats.jpg (1080x1920)
+    g = oracle.letterbox_geometry((1080, 1920), (640, 640), auto=True)
+    assert g["out_shape"] == (384, 640) and g["pads"] == (12, 12, 0, 0) and g["new_unpad"] == (640, 360)
+
+
+def test_scale_boxes(golden):
+    for bi, bo, (h1, w1, h0, w0) in zip(golden["scale_boxes_in"], golden["scale_boxes_out"],
+                                        golden["scale_boxes_shapes"].tolist()):
+        got = oracle.scale_boxes((h1, w1), torch.from_numpy(bi.copy()), (h0, w0)).numpy()
+        np.testing.assert_array_equal(got, bo)
+    b = torch.tensor([[10.0, 20.0, 630.0, 370.0]])
+    np.testing.assert_allclose(oracle.scale_boxes((384, 640), b, (1080, 1920)).numpy(), [[30, 24, 1890, 1074]])
+
+
+def test_known_answers(golden):
+    from yololite_amd.nn import arch
+
+    assert golden["ka_stride"].tolist() == [8.0, 16.0, 32.0]
+    assert golden["ka_save"].tolist() == [4, 6, 10, 13, 16, 19, 22]
+    assert golden["ka_params"].tolist() == [2624080, 9458752, 20114688, 25372160, 56966176]
+    ref_keys = bytes(golden["ka_sd_keys"]).decode().split("\n")
+    assert sorted(ref_keys) == sorted(synth_state_dict("n", 0).keys())
+    for s, n in zip("nsmlx", golden["ka_params"].tolist()):
+        specs, save = arch.parse_model(arch.yolo11_dict(s))
+        assert arch.count_parameters(specs) == n
+        assert save == [4, 6, 10, 13, 16, 19, 22]
+        assert len(oracle.plan(s)) == 24

@@ -1,0 +1,450 @@
+// Engine: a fixed (batch, H, W) program of ops over one workspace arena, all enqueued on a single
+// HIP stream (optionally replayed from a captured hipGraph).  Replaces the Python layer loop of the
+// reference (nn/tasks.py:118-145 BaseModel._predict_once, ~320 module calls per forward) and the
+// device plumbing of nn/autobackend.py:34-151.
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <tuple>
+
+#include "yl_internal.h"
+
+namespace yl {
+
+static thread_local std::string g_err;
+void set_error(const std::string& s) { g_err = s; }
+int fail(int code, const std::string& s) {
+  g_err = s;
+  return code;
+}
+
+struct OpRec {
+  yl_op op;
+  ConvConfig cfg{};
+  __bf16* d_wpk = nullptr;
+  float* d_w = nullptr;     // dwconv weights [9][C]
+  float* d_bias = nullptr;
+  double flops = 0, bytes = 0;
+  const char* name = "";
+};
+
+}  // namespace yl
+
+using namespace yl;
+
+struct yl_engine {
+  int batch = 0, in_h = 0, in_w = 0, nc = 0, A = 0;
+  int64_t ws_bytes = 0;
+  yl_view input_view{};
+  std::vector<yl_level> levels;
+  std::vector<OpRec> ops;
+  std::vector<void*> allocs;
+  struct GraphKey {
+    const void* in;
+    int dt;
+    void* ws;
+    float* y;
+    bool operator<(const GraphKey& o) const {
+      return std::tie(in, dt, ws, y) < std::tie(o.in, o.dt, o.ws, o.y);
+    }
+  };
+  std::map<GraphKey, hipGraphExec_t> graphs;
+};
+
+static int64_t view_elem_size(const yl_view& v) { return v.dtype == YL_F32 ? 4 : 2; }
+
+static int check_view(const yl_view& v, int batch, int64_t ws_bytes, const char* what) {
+  if (v.offset < 0) return fail(-1, std::string(what) + ": view is absent");
+  if (v.H <= 0 || v.W <= 0 || v.C <= 0 || v.pitch < v.coff + v.C || v.coff < 0)
+    return fail(-1, std::string(what) + ": inconsistent view");
+  const int64_t end = v.offset + (int64_t)batch * v.H * v.W * v.pitch * view_elem_size(v);
+  if (end > ws_bytes) return fail(-1, std::string(what) + ": view exceeds the workspace");
+  if (v.offset % 16) return fail(-1, std::string(what) + ": view offset must be 16-byte aligned");
+  return 0;
+}
+
+template <typename T>
+static int dev_upload(yl_engine* e, const std::vector<T>& h, T** d) {
+  void* p = nullptr;
+  YL_HIP(hipMalloc(&p, h.size() * sizeof(T) + 64));
+  e->allocs.push_back(p);
+  YL_HIP(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  *d = reinterpret_cast<T*>(p);
+  return 0;
+}
+
+extern "C" const char* yl_last_error(void) { return g_err.c_str(); }
+extern "C" int yl_abi_version(void) { return YL_ABI_VERSION; }
+extern "C" int yl_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return fail(-2, "hipGetDeviceCount failed");
+  return n;
+}
+
+extern "C" void yl_engine_destroy(yl_engine* e) {
+  if (!e) return;
+  for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
+  for (void* p : e->allocs) (void)hipFree(p);
+  delete e;
+}
+
+extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h, int in_w,
+                                const yl_view* input_view, const yl_level* levels, int n_levels, int nc,
+                                int64_t workspace_bytes, yl_engine** out) {
+  if (!ops || !out || !input_view || n_ops <= 0 || batch <= 0 || n_levels < 0 || n_levels > 8 ||
+      (n_levels > 0 && !levels))
+    return fail(-1, "yl_engine_create: bad arguments");
+  std::unique_ptr<yl_engine, void (*)(yl_engine*)> e(new yl_engine, yl_engine_destroy);
+  e->batch = batch;
+  e->in_h = in_h;
+  e->in_w = in_w;
+  e->nc = nc;
+  e->ws_bytes = workspace_bytes;
+  e->input_view = *input_view;
+  if (int rc = check_view(*input_view, batch, workspace_bytes, "input")) return rc;
+  if (input_view->C != 8 || input_view->pitch != 8 || input_view->H != in_h || input_view->W != in_w)
+    return fail(-1, "input view must be [H][W][8] bf16");
+  int a0 = 0;
+  for (int i = 0; i < n_levels; ++i) {
+    const yl_level& L = levels[i];
+    const int64_t end = L.offset + (int64_t)batch * L.H * L.W * (64 + nc) * 4;
+    if (L.offset < 0 || L.offset % 16 || end > workspace_bytes) return fail(-1, "level view exceeds the workspace");
+    e->levels.push_back(L);
+    a0 += L.H * L.W;
+  }
+  e->A = a0;
+
+  for (int i = 0; i < n_ops; ++i) {
+    OpRec r;
+    r.op = ops[i];
+    const yl_op& o = r.op;
+    const std::string tag = "op " + std::to_string(i);
+    if (int rc = check_view(o.in, batch, workspace_bytes, (tag + " in").c_str())) return rc;
+    if (int rc = check_view(o.out, batch, workspace_bytes, (tag + " out").c_str())) return rc;
+    const double px_in = (double)batch * o.in.H * o.in.W, px_out = (double)batch * o.out.H * o.out.W;
+    switch (o.kind) {
+      case YL_OP_CONV: {
+        if (!o.weight || !o.bias) return fail(-1, tag + ": conv needs weight and bias");
+        if (o.in.dtype != YL_BF16) return fail(-1, tag + ": conv input must be bf16");
+        const int pad = o.k / 2;
+        const int Ho = (o.in.H + 2 * pad - o.k) / o.stride + 1, Wo = (o.in.W + 2 * pad - o.k) / o.stride + 1;
+        if (Ho != o.out.H || Wo != o.out.W) return fail(-1, tag + ": conv output dims mismatch");
+        if (o.in.coff % 8 || o.in.pitch % 8) return fail(-1, tag + ": conv input slice must be 8-channel aligned");
+        if (o.res.offset >= 0) {
+          if (int rc = check_view(o.res, batch, workspace_bytes, (tag + " res").c_str())) return rc;
+          if (o.res.H != Ho || o.res.W != Wo || o.res.C != o.out.C || o.res.dtype != YL_BF16)
+            return fail(-1, tag + ": residual view mismatch");
+        }
+        // weight Cin may be smaller than the (padded) input view channels: stem 3 -> 8
+        const int cin_w = o.cin_weight > 0 ? o.cin_weight : o.in.C;
+        if (int rc = conv_choose(batch, o.in.C, o.out.C, o.k, o.stride, Ho, Wo, &r.cfg)) return rc;
+        std::vector<uint16_t> pk;
+        conv_pack_weights(o.weight, o.out.C, cin_w, o.in.C, o.k, r.cfg, &pk);
+        uint16_t* d = nullptr;
+        if (int rc = dev_upload(e.get(), pk, &d)) return rc;
+        r.d_wpk = reinterpret_cast<__bf16*>(d);
+        std::vector<float> bias((size_t)r.cfg.ncb * r.cfg.MT * 16 + 16, 0.f);
+        for (int c = 0; c < o.out.C; ++c) bias[c] = o.bias[c];
+        if (int rc = dev_upload(e.get(), bias, &r.d_bias)) return rc;
+        r.flops = 2.0 * px_out * o.out.C * cin_w * o.k * o.k;
+        r.bytes = px_in * o.in.C * 2 + px_out * o.out.C * view_elem_size(o.out) +
+                  (o.res.offset >= 0 ? px_out * o.out.C * 2 : 0) + (double)o.out.C * cin_w * o.k * o.k * 2;
+        r.name = r.cfg.name;
+        break;
+      }
+      case YL_OP_DWCONV3: {
+        if (!o.weight || !o.bias) return fail(-1, tag + ": dwconv needs weight and bias");
+        if (o.in.H != o.out.H || o.in.W != o.out.W) return fail(-1, tag + ": dwconv dims mismatch");
+        const int C = o.out.C;
+        std::vector<float> wt((size_t)9 * C);
+        for (int c = 0; c < C; ++c)
+          for (int t = 0; t < 9; ++t) wt[(size_t)t * C + c] = o.weight[(size_t)c * 9 + t];
+        if (int rc = dev_upload(e.get(), wt, &r.d_w)) return rc;
+        std::vector<float> bias(o.bias, o.bias + C);
+        if (int rc = dev_upload(e.get(), bias, &r.d_bias)) return rc;
+        r.flops = 2.0 * px_out * C * 9;
+        r.bytes = px_out * C * 2 * (o.accumulate ? 3 : 2);
+        r.name = "dwconv3x3";
+        break;
+      }
+      case YL_OP_SPPF_POOL:
+        if (o.out.pitch != o.in.pitch || o.out.offset != o.in.offset || o.in.pitch < o.in.coff + 4 * o.in.C)
+          return fail(-1, tag + ": sppf pool expects one buffer holding [x | p5 | p9 | p13]");
+        r.bytes = px_in * o.in.C * 2 * 4;
+        r.name = "sppf_maxpool";
+        break;
+      case YL_OP_UPSAMPLE:
+        if (o.stride != 1 && o.stride != 2) return fail(-1, tag + ": upsample factor must be 1 or 2");
+        if (o.out.H != o.in.H * o.stride || o.out.W != o.in.W * o.stride || o.out.C != o.in.C)
+          return fail(-1, tag + ": upsample dims mismatch");
+        r.bytes = px_in * o.in.C * 2 + px_out * o.out.C * 2;
+        r.name = "upsample_nearest";
+        break;
+      case YL_OP_ATTENTION:
+        if (o.key_dim != 32 || o.head_dim != 64)
+          return fail(-3, tag + ": attention supports key_dim 32 / head_dim 64 (every YOLO11 scale)");
+        if (o.in.C != o.heads * 128 || o.out.C != o.heads * 64) return fail(-1, tag + ": attention channel mismatch");
+        r.flops = 2.0 * batch * o.heads * (double)(o.in.H * o.in.W) * (o.in.H * o.in.W) * (32 + 64);
+        r.bytes = px_in * o.in.C * 2 + px_out * o.out.C * 2;
+        r.name = "attention";
+        break;
+      default:
+        return fail(-1, tag + ": unknown op kind");
+    }
+    e->ops.push_back(r);
+  }
+  *out = e.release();
+  return 0;
+}
+
+static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s) {
+  const yl_op& o = r.op;
+  const int B = e->batch;
+  switch (o.kind) {
+    case YL_OP_CONV: {
+      ConvArgs a{};
+      a.in = reinterpret_cast<const __bf16*>(ws + o.in.offset);
+      a.out = ws + o.out.offset;
+      a.res = o.res.offset >= 0 ? reinterpret_cast<const __bf16*>(ws + o.res.offset) : nullptr;
+      a.wpk = r.d_wpk;
+      a.bias = r.d_bias;
+      a.in_img = (long long)o.in.H * o.in.W * o.in.pitch;
+      a.out_img = (long long)o.out.H * o.out.W * o.out.pitch;
+      a.res_img = o.res.offset >= 0 ? (long long)o.res.H * o.res.W * o.res.pitch : 0;
+      a.H = o.in.H;
+      a.W = o.in.W;
+      a.Ho = o.out.H;
+      a.Wo = o.out.W;
+      a.in_pitch = o.in.pitch;
+      a.in_coff = o.in.coff;
+      a.out_pitch = o.out.pitch;
+      a.out_coff = o.out.coff;
+      a.res_pitch = o.res.offset >= 0 ? o.res.pitch : 0;
+      a.res_coff = o.res.offset >= 0 ? o.res.coff : 0;
+      a.Cin = o.in.C;
+      a.Cout = o.out.C;
+      a.stride = o.stride;
+      a.pad = o.k / 2;
+      a.act = o.act;
+      a.out_f32 = o.out.dtype == YL_F32;
+      return conv_launch(r.cfg, a, B, s);
+    }
+    case YL_OP_DWCONV3: {
+      DwArgs a{};
+      a.in = reinterpret_cast<const __bf16*>(ws + o.in.offset);
+      a.out = reinterpret_cast<__bf16*>(ws + o.out.offset);
+      a.w = r.d_w;
+      a.bias = r.d_bias;
+      a.in_img = (long long)o.in.H * o.in.W * o.in.pitch;
+      a.out_img = (long long)o.out.H * o.out.W * o.out.pitch;
+      a.H = o.out.H;
+      a.W = o.out.W;
+      a.C = o.out.C;
+      a.in_pitch = o.in.pitch;
+      a.in_coff = o.in.coff;
+      a.out_pitch = o.out.pitch;
+      a.out_coff = o.out.coff;
+      a.act = o.act;
+      a.accumulate = o.accumulate;
+      a.grp = o.grp;
+      a.grp_stride = o.grp_stride;
+      a.grp_off = o.grp_off;
+      a.batch = B;
+      return dwconv3_launch(a, s);
+    }
+    case YL_OP_SPPF_POOL: {
+      PoolArgs a{};
+      a.in = reinterpret_cast<const __bf16*>(ws + o.in.offset);
+      a.out = reinterpret_cast<__bf16*>(ws + o.in.offset);
+      a.img = (long long)o.in.H * o.in.W * o.in.pitch;
+      a.H = o.in.H;
+      a.W = o.in.W;
+      a.C = o.in.C;
+      a.pitch = o.in.pitch;
+      a.coff = o.in.coff;
+      a.batch = B;
+      return sppf_pool_launch(a, s);
+    }
+    case YL_OP_UPSAMPLE: {
+      UpArgs a{};
+      a.in = reinterpret_cast<const __bf16*>(ws + o.in.offset);
+      a.out = reinterpret_cast<__bf16*>(ws + o.out.offset);
+      a.in_img = (long long)o.in.H * o.in.W * o.in.pitch;
+      a.out_img = (long long)o.out.H * o.out.W * o.out.pitch;
+      a.H = o.in.H;
+      a.W = o.in.W;
+      a.C = o.in.C;
+      a.in_pitch = o.in.pitch;
+      a.in_coff = o.in.coff;
+      a.out_pitch = o.out.pitch;
+      a.out_coff = o.out.coff;
+      a.factor = o.stride;
+      a.batch = B;
+      return upsample_launch(a, s);
+    }
+    case YL_OP_ATTENTION: {
+      AttnArgs a{};
+      a.qkv = reinterpret_cast<const __bf16*>(ws + o.in.offset);
+      a.out = reinterpret_cast<__bf16*>(ws + o.out.offset);
+      a.in_img = (long long)o.in.H * o.in.W * o.in.pitch;
+      a.out_img = (long long)o.out.H * o.out.W * o.out.pitch;
+      a.N = o.in.H * o.in.W;
+      a.heads = o.heads;
+      a.in_pitch = o.in.pitch;
+      a.in_coff = o.in.coff;
+      a.out_pitch = o.out.pitch;
+      a.out_coff = o.out.coff;
+      a.batch = B;
+      a.scale = o.scale;
+      return attention_launch(a, s);
+    }
+  }
+  return fail(-1, "run_op: unknown kind");
+}
+
+static int run_convert(const yl_engine* e, const void* input, int in_dtype, char* ws, hipStream_t s) {
+  return convert_input_launch(input, in_dtype, reinterpret_cast<__bf16*>(ws + e->input_view.offset), e->batch,
+                              e->in_h, e->in_w, e->input_view.pitch,
+                              (long long)e->in_h * e->in_w * e->input_view.pitch, s);
+}
+
+static int run_decode(const yl_engine* e, const char* ws, float* y, hipStream_t s) {
+  DecodeLevel lv[8];
+  int a0 = 0;
+  for (size_t i = 0; i < e->levels.size(); ++i) {
+    lv[i].raw = reinterpret_cast<const float*>(ws + e->levels[i].offset);
+    lv[i].H = e->levels[i].H;
+    lv[i].W = e->levels[i].W;
+    lv[i].a0 = a0;
+    lv[i].stride = e->levels[i].stride;
+    a0 += lv[i].H * lv[i].W;
+  }
+  return decode_launch(lv, (int)e->levels.size(), e->batch, e->nc, e->A, y, s);
+}
+
+extern "C" int yl_engine_forward(yl_engine* e, const void* input, int in_dtype, void* workspace, float* y,
+                                 void* stream) {
+  if (!e || !input || !workspace) return fail(-1, "yl_engine_forward: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  char* ws = (char*)workspace;
+  if (int rc = run_convert(e, input, in_dtype, ws, s)) return rc;
+  for (const OpRec& r : e->ops)
+    if (int rc = run_op(e, r, ws, s)) return rc;
+  if (y) {
+    if (e->levels.empty()) return fail(-1, "yl_engine_forward: engine has no Detect levels to decode");
+    if (int rc = run_decode(e, ws, y, s)) return rc;
+  }
+  return 0;
+}
+
+extern "C" int yl_engine_forward_graph(yl_engine* e, const void* input, int in_dtype, void* workspace, float* y,
+                                       void* stream) {
+  if (!e || !input || !workspace) return fail(-1, "yl_engine_forward_graph: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  yl_engine::GraphKey key{input, in_dtype, workspace, y};
+  auto it = e->graphs.find(key);
+  if (it == e->graphs.end()) {
+    // run once eagerly so lazy one-time setup (function attributes) happens outside the capture
+    if (int rc = yl_engine_forward(e, input, in_dtype, workspace, y, stream)) return rc;
+    YL_HIP(hipStreamSynchronize(s));
+    hipGraph_t g = nullptr;
+    YL_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    int rc = yl_engine_forward(e, input, in_dtype, workspace, y, stream);
+    hipError_t ce = hipStreamEndCapture(s, &g);
+    if (rc) {
+      if (g) (void)hipGraphDestroy(g);
+      return rc;
+    }
+    if (ce != hipSuccess) return fail(-2, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
+    hipGraphExec_t ge = nullptr;
+    hipError_t ie = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (ie != hipSuccess) return fail(-2, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie));
+    it = e->graphs.emplace(key, ge).first;
+  }
+  YL_HIP(hipGraphLaunch(it->second, s));
+  return 0;
+}
+
+extern "C" int yl_engine_num_ops(const yl_engine* e) { return e ? (int)e->ops.size() : -1; }
+
+extern "C" int yl_engine_op_info(const yl_engine* e, int i, double* flops, double* bytes, const char** name) {
+  if (!e || i < 0 || i >= (int)e->ops.size()) return fail(-1, "yl_engine_op_info: bad index");
+  if (flops) *flops = e->ops[i].flops;
+  if (bytes) *bytes = e->ops[i].bytes;
+  if (name) *name = e->ops[i].name;
+  return 0;
+}
+
+extern "C" int yl_engine_profile(yl_engine* e, const void* input, int in_dtype, void* workspace, float* y,
+                                 void* stream, int iters, float* ms) {
+  if (!e || !input || !workspace || !ms || iters <= 0) return fail(-1, "yl_engine_profile: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  char* ws = (char*)workspace;
+  if (int rc = yl_engine_forward(e, input, in_dtype, workspace, y, stream)) return rc;
+  YL_HIP(hipStreamSynchronize(s));
+  hipEvent_t e0, e1;
+  YL_HIP(hipEventCreate(&e0));
+  YL_HIP(hipEventCreate(&e1));
+  const int n = (int)e->ops.size();
+  int rc = 0;
+  for (int i = 0; i < n + 2 && !rc; ++i) {
+    if (i == n + 1 && !y) {
+      ms[i] = 0.f;
+      continue;
+    }
+    (void)hipEventRecord(e0, s);
+    for (int it = 0; it < iters && !rc; ++it) {
+      if (i == 0) rc = run_convert(e, input, in_dtype, ws, s);
+      else if (i <= n) rc = run_op(e, e->ops[i - 1], ws, s);
+      else rc = run_decode(e, ws, y, s);
+    }
+    (void)hipEventRecord(e1, s);
+    if (hipEventSynchronize(e1) != hipSuccess) rc = fail(-2, "hipEventSynchronize failed");
+    float t = 0.f;
+    (void)hipEventElapsedTime(&t, e0, e1);
+    ms[i] = t / iters;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return rc;
+}
+
+extern "C" int yl_detect_decode(const void* workspace, const yl_level* levels, int n_levels, int batch, int nc,
+                                float* y, void* stream) {
+  if (!workspace || !levels || !y || n_levels <= 0 || n_levels > 8) return fail(-1, "yl_detect_decode: bad arguments");
+  DecodeLevel lv[8];
+  int a0 = 0;
+  for (int i = 0; i < n_levels; ++i) {
+    lv[i].raw = reinterpret_cast<const float*>((const char*)workspace + levels[i].offset);
+    lv[i].H = levels[i].H;
+    lv[i].W = levels[i].W;
+    lv[i].a0 = a0;
+    lv[i].stride = levels[i].stride;
+    a0 += lv[i].H * lv[i].W;
+  }
+  return decode_launch(lv, n_levels, batch, nc, a0, y, (hipStream_t)stream);
+}
+
+// engine/predictor.py:77-84: BGR HWC uint8 -> RGB CHW float / 255
+__global__ void preprocess_u8_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, int HW, long long total) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const long long b = i / HW;
+  const int p = (int)(i - b * HW);
+  const uint8_t* s = in + i * 3;
+  float* o = out + b * 3 * HW + p;
+  o[0] = (float)s[2] / 255.0f;
+  o[HW] = (float)s[1] / 255.0f;
+  o[2LL * HW] = (float)s[0] / 255.0f;
+}
+
+extern "C" int yl_preprocess_u8(const uint8_t* bgr_hwc, int batch, int h, int w, float* out_nchw, void* stream) {
+  if (!bgr_hwc || !out_nchw || batch <= 0 || h <= 0 || w <= 0) return fail(-1, "yl_preprocess_u8: bad arguments");
+  const long long total = (long long)batch * h * w;
+  hipLaunchKernelGGL(preprocess_u8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     bgr_hwc, out_nchw, h * w, total);
+  YL_HIP(hipGetLastError());
+  return 0;
+}

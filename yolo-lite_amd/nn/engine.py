@@ -1,0 +1,145 @@
+"""HipEngine: owns one lowered program + its workspace on a GPU and drives libyl_amd.so.
+
+PyTorch is used only for device memory (the workspace / IO tensors) and the current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .arch import LayerSpec
+from .lower import BF16, F32, Program, TView, lower
+
+_TORCH2YL = {torch.float32: _lib.YL_F32, torch.float16: _lib.YL_F16, torch.uint8: _lib.YL_U8}
+
+
+def _cview(v: Optional[TView]) -> _lib.View:
+    if v is None:
+        return _lib.View(-1, 0, 0, 0, 0, 0, 0)
+    return _lib.View(v.offset, v.H, v.W, v.C, v.pitch, v.coff, v.dtype)
+
+
+class HipEngine:
+    """A YOLO11 network instantiated for a fixed (batch, H, W) on one GPU."""
+
+    def __init__(self, prog: Program, device: torch.device):
+        if device.type != "cuda":
+            raise RuntimeError("HipEngine needs a GPU device (there is no CPU fallback for the HIP path)")
+        self.lib = _lib.lib()
+        self.device = device
+        self.batch, self.in_h, self.in_w = prog.batch, prog.in_h, prog.in_w
+        batch, in_h, in_w = prog.batch, prog.in_h, prog.in_w
+        self.prog = prog
+        self.nc = self.prog.nc
+        self.anchors = self.prog.anchors
+        ops = self.prog.ops
+        arr = (_lib.Op * len(ops))()
+        self._keep: List[np.ndarray] = []
+        for i, o in enumerate(ops):
+            c = arr[i]
+            c.kind = o["kind"]
+            c.k = o.get("k", 0)
+            c.stride = o.get("stride", 1)
+            c.act = o.get("act", 0)
+            c.accumulate = o.get("accumulate", 0)
+            c.heads, c.key_dim, c.head_dim = o.get("heads", 0), o.get("key_dim", 0), o.get("head_dim", 0)
+            c.scale = o.get("scale", 0.0)
+            c.grp, c.grp_stride, c.grp_off = o.get("grp", 0), o.get("grp_stride", 0), o.get("grp_off", 0)
+            c.cin_weight = o.get("cin_weight", 0)
+            c.inp, c.out, c.res = _cview(o["inp"]), _cview(o["out"]), _cview(o.get("res"))
+            if "weight" in o:
+                w = np.ascontiguousarray(o["weight"], dtype=np.float32)
+                b = np.ascontiguousarray(o["bias"], dtype=np.float32)
+                self._keep += [w, b]
+                c.weight, c.bias = w.ctypes.data, b.ctypes.data
+        lv = (_lib.Level * len(self.prog.levels))()
+        for i, L in enumerate(self.prog.levels):
+            lv[i] = _lib.Level(L["offset"], L["H"], L["W"], L["stride"], 0)
+        self._levels = lv
+        iv = _cview(self.prog.input_view)
+        handle = C.c_void_p()
+        with torch.cuda.device(device):
+            _lib.check(self.lib.yl_engine_create(arr, len(ops), batch, in_h, in_w, C.byref(iv), lv, len(lv), self.nc,
+                                                 self.prog.ws_bytes, C.byref(handle)), "yl_engine_create")
+            self.workspace = torch.empty(self.prog.ws_bytes, dtype=torch.uint8, device=device)
+        self._h = handle
+        self._keep.clear()  # weights were packed and uploaded by yl_engine_create
+
+    @classmethod
+    def from_model(cls, specs: Sequence[LayerSpec], state_dict: Dict[str, torch.Tensor], batch: int, in_h: int,
+                   in_w: int, device: torch.device, strides: Sequence[float] = (8.0, 16.0, 32.0)) -> "HipEngine":
+        return cls(lower(specs, state_dict, batch, in_h, in_w, strides), device)
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            try:
+                self.lib.yl_engine_destroy(h)
+            except Exception:
+                pass
+            self._h = None
+
+    # ------------------------------------------------------------------ forward
+    def _check_input(self, im: torch.Tensor):
+        if tuple(im.shape) != (self.batch, 3, self.in_h, self.in_w):
+            raise ValueError(f"engine built for {(self.batch, 3, self.in_h, self.in_w)}, got {tuple(im.shape)}")
+        if im.dtype not in _TORCH2YL:
+            raise TypeError(f"unsupported input dtype {im.dtype}")
+        if im.device != self.device or not im.is_contiguous():
+            raise ValueError("input must be a contiguous tensor on the engine's device")
+
+    def forward(self, im: torch.Tensor, y: Optional[torch.Tensor] = None, graph: bool = False,
+                decode: bool = True) -> Optional[torch.Tensor]:
+        """im (B,3,H,W) fp32/fp16 in [0,1] or uint8 -> y (B, 4+nc, A) fp32 (reference head.py:95-126)."""
+        self._check_input(im)
+        if decode and y is None:
+            y = torch.empty((self.batch, 4 + self.nc, self.anchors), dtype=torch.float32, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        fn = self.lib.yl_engine_forward_graph if graph else self.lib.yl_engine_forward
+        _lib.check(fn(self._h, im.data_ptr(), _TORCH2YL[im.dtype], self.workspace.data_ptr(),
+                      y.data_ptr() if decode else None, stream), "yl_engine_forward")
+        return y if decode else None
+
+    def raw_levels(self) -> List[torch.Tensor]:
+        """Zero-copy (B, 64+nc, H, W) fp32 views of the Detect level maps (reference head.py:64-65)."""
+        out = []
+        no = 64 + self.nc
+        for L in self.prog.levels:
+            n = self.batch * L["H"] * L["W"] * no
+            t = self.workspace[L["offset"]: L["offset"] + 4 * n].view(torch.float32)
+            out.append(t.view(self.batch, L["H"], L["W"], no).permute(0, 3, 1, 2))
+        return out
+
+    def view_tensor(self, v: TView) -> torch.Tensor:
+        """Copy of an arena view as an NCHW fp32 tensor (debug / per-layer parity tests)."""
+        esz, dt = (4, torch.float32) if v.dtype == F32 else (2, torch.bfloat16)
+        n = self.batch * v.H * v.W * v.pitch
+        t = self.workspace[v.offset: v.offset + esz * n].view(dt).view(self.batch, v.H, v.W, v.pitch)
+        return t[..., v.coff: v.coff + v.C].permute(0, 3, 1, 2).float().contiguous()
+
+    def layer_output(self, i: int) -> torch.Tensor:
+        return self.view_tensor(self.prog.layer_views[i])
+
+    def profile(self, im: torch.Tensor, iters: int = 20) -> List[dict]:
+        """Per-op HIP-event timings with algorithmic flops/bytes (see yl_engine_profile)."""
+        self._check_input(im)
+        n = self.lib.yl_engine_num_ops(self._h)
+        ms = (C.c_float * (n + 2))()
+        y = torch.empty((self.batch, 4 + self.nc, self.anchors), dtype=torch.float32, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self.lib.yl_engine_profile(self._h, im.data_ptr(), _TORCH2YL[im.dtype], self.workspace.data_ptr(),
+                                              y.data_ptr(), stream, iters, ms), "yl_engine_profile")
+        rows = [dict(name="input", kernel="convert_input", ms=ms[0], flops=0.0,
+                     bytes=float(im.numel() * im.element_size() + self.batch * self.in_h * self.in_w * 16))]
+        fl, by, nm = C.c_double(), C.c_double(), C.c_char_p()
+        for i in range(n):
+            self.lib.yl_engine_op_info(self._h, i, C.byref(fl), C.byref(by), C.byref(nm))
+            rows.append(dict(name=self.prog.ops[i].get("name", ""), kernel=nm.value.decode(), ms=ms[i + 1],
+                             flops=fl.value, bytes=by.value))
+        rows.append(dict(name="decode", kernel="detect_decode", ms=ms[n + 1], flops=0.0,
+                         bytes=float(self.batch * self.anchors * ((64 + self.nc) + (4 + self.nc)) * 4)))
+        return rows

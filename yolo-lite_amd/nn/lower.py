@@ -1,0 +1,256 @@
+"""Lowering of the YOLO11 layer list to a flat engine program over one workspace arena.
+
+Reference behaviour being lowered (all under /root/reference/yololite):
+``nn/tasks.py:118-145`` (layer loop and skip list), ``nn/modules/block.py`` (C3k2/C3k/Bottleneck/SPPF/
+C2PSA/PSABlock/Attention forward methods), ``nn/modules/head.py:59-69`` (Detect.forward) and
+``nn/modules/conv.py:321-331`` (Concat).  ``chunk``/``split``/``cat`` never move data here: producers
+write straight into channel slices of the consumer's buffer (NHWC, so a slice is a strided view),
+Conv+BN are folded with the formula of ``utils/torch_utils.py:182-209`` (eps 1e-3, ``:249``) and the
+Bottleneck / PSABlock residual adds run in the producing conv's epilogue.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from .arch import LayerSpec, detect_mid_channels
+
+BN_EPS = 1e-3
+BF16, F32 = 0, 1
+OP_CONV, OP_DWCONV3, OP_SPPF_POOL, OP_UPSAMPLE, OP_ATTENTION = 1, 2, 3, 4, 5
+
+
+@dataclass
+class TView:
+    offset: int
+    H: int
+    W: int
+    C: int
+    pitch: int
+    coff: int = 0
+    dtype: int = BF16
+
+    def slice(self, coff: int, C: int) -> "TView":
+        assert 0 <= coff and coff + C <= self.C, (coff, C, self.C)
+        return TView(self.offset, self.H, self.W, C, self.pitch, self.coff + coff, self.dtype)
+
+
+@dataclass
+class Program:
+    batch: int
+    in_h: int
+    in_w: int
+    nc: int
+    ops: List[dict] = field(default_factory=list)
+    ws_bytes: int = 0
+    input_view: Optional[TView] = None
+    levels: List[dict] = field(default_factory=list)
+    layer_views: Dict[int, TView] = field(default_factory=dict)
+    anchors: int = 0
+    strides: Tuple[float, ...] = ()
+
+
+class _Arena:
+    def __init__(self, batch: int):
+        self.batch = batch
+        self.top = 0
+
+    def alloc(self, H: int, W: int, C: int, dtype: int = BF16) -> TView:
+        esz = 4 if dtype == F32 else 2
+        off = self.top
+        self.top = (off + self.batch * H * W * C * esz + 255) // 256 * 256
+        return TView(off, H, W, C, C, 0, dtype)
+
+
+def fold_conv_bn(sd: Dict[str, torch.Tensor], name: str, bn: bool = True) -> Tuple[np.ndarray, np.ndarray]:
+    """BN-folded fp32 (weight OIHW, bias) of the Conv unit ``name`` (torch_utils.py:182-209)."""
+    if bn:
+        w = sd[name + ".conv.weight"].detach().float()
+        g, b = sd[name + ".bn.weight"].float(), sd[name + ".bn.bias"].float()
+        mu, var = sd[name + ".bn.running_mean"].float(), sd[name + ".bn.running_var"].float()
+        s = g / torch.sqrt(var + BN_EPS)
+        w = w * s.view(-1, 1, 1, 1)
+        bias = b - mu * s
+    else:
+        w = sd[name + ".weight"].detach().float()
+        bias = sd[name + ".bias"].detach().float()
+    return np.ascontiguousarray(w.numpy(), dtype=np.float32), np.ascontiguousarray(bias.numpy(), dtype=np.float32)
+
+
+def _out_hw(h: int, w: int, k: int, s: int) -> Tuple[int, int]:
+    p = k // 2
+    return (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+
+
+def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, in_h: int, in_w: int,
+          strides: Sequence[float] = (8.0, 16.0, 32.0)) -> Program:
+    det = specs[-1]
+    assert det.kind == "Detect"
+    prog = Program(batch, in_h, in_w, det.nc, strides=tuple(float(s) for s in strides))
+    ar = _Arena(batch)
+    ops = prog.ops
+
+    # ---- shapes of every layer output
+    shp: List[Tuple[int, int, int]] = []
+    for sp in specs[:-1]:
+        if isinstance(sp.f, int):
+            h, w, _ = (in_h, in_w, 3) if (sp.i == 0) else shp[sp.f if sp.f != -1 else sp.i - 1]
+        else:
+            h, w, _ = shp[sp.f[0] if sp.f[0] != -1 else sp.i - 1]
+        if sp.kind == "Conv":
+            h, w = _out_hw(h, w, sp.k, sp.s)
+        elif sp.kind == "Upsample":
+            h, w = 2 * h, 2 * w
+        shp.append((h, w, sp.c2))
+
+    # ---- Concat placement: each member gets a channel slice of the concat buffer
+    dest: Dict[int, TView] = {}
+    cat_buf: Dict[int, TView] = {}
+    late_copy: Dict[int, List[Tuple[int, TView]]] = {}
+    for sp in specs:
+        if sp.kind != "Concat":
+            continue
+        h, w, c = shp[sp.i]
+        buf = ar.alloc(h, w, c)
+        cat_buf[sp.i] = buf
+        coff = 0
+        for j, cj in zip(sp.f, sp.c1):
+            src = sp.i - 1 if j == -1 else j
+            sl = buf.slice(coff, cj)
+            if src in dest or specs[src].kind == "Concat":
+                late_copy.setdefault(sp.i, []).append((src, sl))
+            else:
+                dest[src] = sl
+            coff += cj
+
+    def out_view(i: int) -> TView:
+        if i in dest:
+            return dest[i]
+        h, w, c = shp[i]
+        return ar.alloc(h, w, c)
+
+    def conv(name, x: TView, y: TView, k=1, s=1, act=True, res: Optional[TView] = None, bn=True,
+             wb: Optional[Tuple[np.ndarray, np.ndarray]] = None, cin_weight=0):
+        w, b = wb if wb is not None else fold_conv_bn(sd, name, bn)
+        assert w.shape[0] == y.C and w.shape[2] == k, (name, w.shape, y.C)
+        assert (cin_weight or x.C) == w.shape[1], (name, w.shape, x.C)
+        ops.append(dict(kind=OP_CONV, name=name, k=k, stride=s, act=int(act), inp=x, out=y, res=res,
+                        weight=w, bias=b, cin_weight=cin_weight))
+
+    def dwconv(name, x: TView, y: TView, act=True, accumulate=False, grp=0, grp_stride=0, grp_off=0):
+        w, b = fold_conv_bn(sd, name, True)
+        assert w.shape[1] == 1 and w.shape[0] == y.C, (name, w.shape)
+        ops.append(dict(kind=OP_DWCONV3, name=name, k=3, stride=1, act=int(act), accumulate=int(accumulate),
+                        grp=grp, grp_stride=grp_stride, grp_off=grp_off, inp=x, out=y, res=None, weight=w, bias=b))
+
+    def bottleneck(p, x: TView, y: TView, c_mid: int, in_place_res: bool = True):
+        tmp = ar.alloc(x.H, x.W, c_mid)
+        conv(p + ".cv1", x, tmp, 3, 1)
+        conv(p + ".cv2", tmp, y, 3, 1, res=x if x.C == y.C else None)
+
+    def c3k_block(p, x: TView, y: TView):
+        c = x.C
+        c_ = int(c * 0.5)
+        u = ar.alloc(x.H, x.W, 2 * c_)
+        w1, b1 = fold_conv_bn(sd, p + ".cv1")
+        w2, b2 = fold_conv_bn(sd, p + ".cv2")
+        # C3.cv1 and C3.cv2 read the same input (block.py:259): one conv with stacked filters
+        conv(p + ".cv1+cv2", x, u, 1, 1, wb=(np.concatenate([w1, w2], 0), np.concatenate([b1, b2], 0)))
+        a = u.slice(0, c_)
+        for j in range(2):
+            bottleneck(f"{p}.m.{j}", a, a, c_)
+        conv(p + ".cv3", u, y, 1, 1)
+
+    views: Dict[int, TView] = {}
+    prog.input_view = ar.alloc(in_h, in_w, 8)
+    x = prog.input_view
+    for sp in specs[:-1]:
+        p = f"model.{sp.i}"
+        src = None
+        if isinstance(sp.f, int):
+            src = x if sp.f == -1 else views[sp.f]
+        if sp.kind == "Conv":
+            y = out_view(sp.i)
+            conv(p, src, y, sp.k, sp.s, cin_weight=3 if sp.i == 0 and src.C == 8 and sp.c1 == 3 else 0)
+        elif sp.kind == "C3k2":
+            y = out_view(sp.i)
+            c = int(sp.c2 * sp.e)
+            t = ar.alloc(src.H, src.W, (2 + sp.n) * c)
+            conv(p + ".cv1", src, t.slice(0, 2 * c), 1, 1)
+            for j in range(sp.n):
+                xin, xout = t.slice((1 + j) * c, c), t.slice((2 + j) * c, c)
+                if sp.c3k:
+                    c3k_block(f"{p}.m.{j}", xin, xout)
+                else:
+                    bottleneck(f"{p}.m.{j}", xin, xout, int(c * 0.5))
+            conv(p + ".cv2", t, y, 1, 1)
+        elif sp.kind == "SPPF":
+            y = out_view(sp.i)
+            c_ = sp.c1 // 2
+            sbuf = ar.alloc(src.H, src.W, 4 * c_)
+            conv(p + ".cv1", src, sbuf.slice(0, c_), 1, 1)
+            ops.append(dict(kind=OP_SPPF_POOL, name=p + ".m", inp=sbuf.slice(0, c_), out=sbuf.slice(0, c_), res=None))
+            conv(p + ".cv2", sbuf, y, 1, 1)
+        elif sp.kind == "C2PSA":
+            y = out_view(sp.i)
+            c = int(sp.c1 * 0.5)
+            nh = c // 64
+            hd = c // nh
+            kd = int(hd * 0.5)
+            u = ar.alloc(src.H, src.W, 2 * c)
+            conv(p + ".cv1", src, u, 1, 1)
+            b = u.slice(c, c)
+            for j in range(sp.n):
+                q = f"{p}.m.{j}"
+                qkv = ar.alloc(src.H, src.W, c + 2 * nh * kd)
+                conv(q + ".attn.qkv", b, qkv, 1, 1, act=False)
+                o = ar.alloc(src.H, src.W, c)
+                ops.append(dict(kind=OP_ATTENTION, name=q + ".attn", heads=nh, key_dim=kd, head_dim=hd,
+                                scale=float(kd ** -0.5), inp=qkv, out=o, res=None))
+                dwconv(q + ".attn.pe", qkv, o, act=False, accumulate=True, grp=hd, grp_stride=2 * kd + hd,
+                       grp_off=2 * kd)
+                conv(q + ".attn.proj", o, b, 1, 1, act=False, res=b)
+                f1 = ar.alloc(src.H, src.W, 2 * c)
+                conv(q + ".ffn.0", b, f1, 1, 1)
+                conv(q + ".ffn.1", f1, b, 1, 1, act=False, res=b)
+            conv(p + ".cv2", u, y, 1, 1)
+        elif sp.kind == "Upsample":
+            y = out_view(sp.i)
+            ops.append(dict(kind=OP_UPSAMPLE, name=p, stride=2, inp=src, out=y, res=None))
+        elif sp.kind == "Concat":
+            y = cat_buf[sp.i]
+            for s_i, sl in late_copy.get(sp.i, []):
+                ops.append(dict(kind=OP_UPSAMPLE, name=f"{p}.copy{s_i}", stride=1, inp=views[s_i], out=sl, res=None))
+        else:
+            raise NotImplementedError(sp.kind)
+        views[sp.i] = y
+        x = y
+
+    # ---- Detect (head.py:29-69): box branch cv2, class branch cv3, raw level maps in fp32
+    p = f"model.{det.i}"
+    c2, c3 = detect_mid_channels(det.c1, det.nc)
+    a_total = 0
+    for lvl, j in enumerate(det.f):
+        xin = views[j]
+        h, w = xin.H, xin.W
+        head = ar.alloc(h, w, 64 + det.nc, F32)
+        t1, t2 = ar.alloc(h, w, c2), ar.alloc(h, w, c2)
+        conv(f"{p}.cv2.{lvl}.0", xin, t1, 3, 1)
+        conv(f"{p}.cv2.{lvl}.1", t1, t2, 3, 1)
+        conv(f"{p}.cv2.{lvl}.2", t2, head.slice(0, 64), 1, 1, act=False, bn=False)
+        d1, e1 = ar.alloc(h, w, xin.C), ar.alloc(h, w, c3)
+        dwconv(f"{p}.cv3.{lvl}.0.0", xin, d1)
+        conv(f"{p}.cv3.{lvl}.0.1", d1, e1, 1, 1)
+        d2, e2 = ar.alloc(h, w, c3), ar.alloc(h, w, c3)
+        dwconv(f"{p}.cv3.{lvl}.1.0", e1, d2)
+        conv(f"{p}.cv3.{lvl}.1.1", d2, e2, 1, 1)
+        conv(f"{p}.cv3.{lvl}.2", e2, head.slice(64, det.nc), 1, 1, act=False, bn=False)
+        prog.levels.append(dict(offset=head.offset, H=h, W=w, stride=float(strides[lvl])))
+        a_total += h * w
+    prog.anchors = a_total
+    prog.layer_views = views
+    prog.ws_bytes = ar.top + 256
+    return prog

@@ -1,0 +1,92 @@
+"""Deterministic synthetic weights for YOLO11 (no checkpoints are available offline).
+
+Every tensor is a pure function of (key, shape, seed): the same call gives the same bytes in the
+build container (where the reference is imported to make golden vectors) and on the GPU box.
+BN statistics are randomised so that Conv+BN folding is exercised.  Keys and shapes follow the
+reference state dict (``model.<i>...{conv.weight,bn.*}``, ``model.23.dfl.conv.weight``).
+"""
+from __future__ import annotations
+
+import hashlib
+import math
+from typing import Dict, Optional, Sequence
+
+import torch
+
+from .arch import ConvUnit, conv_units, parse_model, yolo11_dict
+
+
+def _gen(key: str, seed: int) -> torch.Generator:
+    h = hashlib.sha256(f"{seed}:{key}".encode()).digest()
+    g = torch.Generator(device="cpu")
+    g.manual_seed(int.from_bytes(h[:8], "little") & 0x7FFFFFFFFFFFFFFF)
+    return g
+
+
+def _randn(key, seed, shape):
+    return torch.randn(shape, generator=_gen(key, seed), dtype=torch.float32)
+
+
+def _rand(key, seed, shape, lo, hi):
+    return torch.rand(shape, generator=_gen(key, seed), dtype=torch.float32) * (hi - lo) + lo
+
+
+def synth_state_dict(scale: str = "n", seed: int = 0, nc: int = 80,
+                     cls_bias: Optional[Sequence[float]] = None, cls_gain: float = 8.0,
+                     box_gain: float = 6.0, model_dict: Optional[dict] = None) -> Dict[str, torch.Tensor]:
+    """Random-init fp32 state dict of the YOLO11 architecture.
+
+    ``cls_bias``: optional per-level bias for the final class 1x1 convs (calibration, see
+    :func:`calibrate_cls_bias`); default is the reference ``Detect.bias_init`` value
+    ``log(5 / nc / (640 / stride)**2)`` (reference ``head.py:128-139``).
+    ``cls_gain`` / ``box_gain`` multiply the final class / box conv weights (spread the logits so
+    that scores and DFL distributions vary across anchors).  Gains of the BN'd convs are chosen so
+    activations stay O(1) through every scale n..x: sqrt(2/fan_in) before SiLU, 0.8/sqrt(fan_in)
+    for linear convs and 0.5/sqrt(fan_in) for convs whose output is added to a residual.
+    """
+    d = model_dict or yolo11_dict(scale, nc)
+    specs, _ = parse_model(d)
+    sd: Dict[str, torch.Tensor] = {}
+    det = specs[-1]
+    strides = (8.0, 16.0, 32.0)
+    for u in conv_units(specs):
+        fan_in = (u.c1 // u.g) * u.k * u.k
+        if u.bn:
+            n = u.name
+            is_res = (".m." in n and n.endswith(".cv2")) or n.endswith("attn.proj") or n.endswith("ffn.1")
+            std = (0.5 if is_res else (math.sqrt(2.0) if u.act else 0.8)) / math.sqrt(fan_in)
+            sd[u.name + ".conv.weight"] = _randn(u.name + ".conv.weight", seed, (u.c2, u.c1 // u.g, u.k, u.k)) * std
+            sd[u.name + ".bn.weight"] = _rand(u.name + ".bn.weight", seed, (u.c2,), 0.6, 1.4)
+            sd[u.name + ".bn.bias"] = _randn(u.name + ".bn.bias", seed, (u.c2,)) * 0.2
+            sd[u.name + ".bn.running_mean"] = _randn(u.name + ".bn.running_mean", seed, (u.c2,)) * 0.2
+            sd[u.name + ".bn.running_var"] = _rand(u.name + ".bn.running_var", seed, (u.c2,), 0.5, 1.5)
+            sd[u.name + ".bn.num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
+        else:
+            std = math.sqrt(1.0 / fan_in)
+            w = _randn(u.name + ".weight", seed, (u.c2, u.c1, u.k, u.k)) * std
+            is_cls = ".cv3." in u.name
+            lvl = int(u.name.split(".")[3])
+            if is_cls:
+                w = w * cls_gain
+                b0 = cls_bias[lvl] if cls_bias is not None else math.log(5 / det.nc / (640 / strides[lvl]) ** 2)
+                b = torch.full((u.c2,), float(b0), dtype=torch.float32)
+            else:
+                w = w * box_gain
+                b = torch.full((u.c2,), 1.0, dtype=torch.float32)
+            sd[u.name + ".weight"] = w
+            sd[u.name + ".bias"] = b
+    sd[f"model.{det.i}.dfl.conv.weight"] = torch.arange(16, dtype=torch.float32).view(1, 16, 1, 1)
+    return sd
+
+
+def calibrate_cls_bias(level_max_logits: Sequence[torch.Tensor], target_frac: float = 0.015,
+                       conf: float = 0.25) -> list:
+    """Per-level class bias such that about ``target_frac`` of anchors clear ``conf``.
+
+    ``level_max_logits[l]`` holds, for level ``l``, the per-anchor maximum class logit computed with
+    a zero class bias.  The (1 - target_frac) quantile over all levels is mapped to logit(conf).
+    """
+    allv = torch.cat([t.flatten().float().cpu() for t in level_max_logits])
+    q = torch.quantile(allv, 1.0 - target_frac).item()
+    shift = math.log(conf / (1.0 - conf)) - q
+    return [shift for _ in level_max_logits]
