@@ -50,6 +50,7 @@ struct yl_engine {
     }
   };
   std::map<GraphKey, hipGraphExec_t> graphs;
+  hipStream_t cap_stream = nullptr;
 };
 
 static int64_t view_elem_size(const yl_view& v) { return v.dtype == YL_F32 ? 4 : 2; }
@@ -85,6 +86,7 @@ extern "C" int yl_device_count(void) {
 extern "C" void yl_engine_destroy(yl_engine* e) {
   if (!e) return;
   for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
+  if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
   for (void* p : e->allocs) (void)hipFree(p);
   delete e;
 }
@@ -345,13 +347,20 @@ extern "C" int yl_engine_forward_graph(yl_engine* e, const void* input, int in_d
   yl_engine::GraphKey key{input, in_dtype, workspace, y};
   auto it = e->graphs.find(key);
   if (it == e->graphs.end()) {
+    if (e->graphs.size() >= 8) {  // pointers keep changing: drop the stale executables
+      for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
+      e->graphs.clear();
+    }
     // run once eagerly so lazy one-time setup (function attributes) happens outside the capture
     if (int rc = yl_engine_forward(e, input, in_dtype, workspace, y, stream)) return rc;
     YL_HIP(hipStreamSynchronize(s));
+    // Capture on a private stream (the caller's may be the legacy default stream, which cannot
+    // capture); the instantiated graph is then launched on the caller's stream.
+    if (!e->cap_stream) YL_HIP(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
     hipGraph_t g = nullptr;
-    YL_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    int rc = yl_engine_forward(e, input, in_dtype, workspace, y, stream);
-    hipError_t ce = hipStreamEndCapture(s, &g);
+    YL_HIP(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal));
+    int rc = yl_engine_forward(e, input, in_dtype, workspace, y, (void*)e->cap_stream);
+    hipError_t ce = hipStreamEndCapture(e->cap_stream, &g);
     if (rc) {
       if (g) (void)hipGraphDestroy(g);
       return rc;

@@ -1,0 +1,1 @@
+from .build import load_inference_source  # noqa: F401

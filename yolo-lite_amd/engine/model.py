@@ -1,0 +1,96 @@
+"""``YOLOLite`` / ``YOLO`` facade (reference ``yololite/engine/model.py:17-146``).
+
+``YOLOLite("yolo11n.yaml")`` builds from the architecture table, anything else loads a ``.pt``
+checkpoint; ``model(source)`` == ``model.predict(source)`` returns ``list[Results]``.
+Training and validation are outside the accelerated path and raise ``NotImplementedError``.
+"""
+from __future__ import annotations
+
+from pathlib import Path
+from typing import List, Union
+
+from ..cfg import DEFAULT_CFG_DICT
+from ..nn.tasks import DetectionModel, attempt_load_one_weight, yaml_model_load
+from .predictor import DetectionPredictor
+from .results import Results
+
+
+class YOLOLite:
+    def __init__(self, model: Union[str, Path] = "yolo11n.pt", task: str = None, verbose: bool = False) -> None:
+        self.callbacks = None
+        self.predictor = None
+        self.model = None
+        self.trainer = None
+        self.ckpt = None
+        self.cfg = None
+        self.ckpt_path = None
+        self.overrides = {}
+        self.metrics = None
+        self.task = task
+        model = str(model).strip()
+        if Path(model).suffix in {".yaml", ".yml"}:
+            self._new(model, task=task, verbose=verbose)
+        else:
+            self._load(model)
+
+    def __call__(self, source=None, stream: bool = False, **kwargs) -> list:
+        return self.predict(source, stream, **kwargs)
+
+    def _new(self, cfg: str, task=None, verbose=False) -> None:
+        cfg_dict = yaml_model_load(cfg)
+        self.cfg = cfg
+        self.task = task or "detect"
+        self.model = DetectionModel(cfg_dict, verbose=verbose)
+        self.overrides["model"] = self.cfg
+        self.overrides["task"] = self.task
+        self.model.args = {**DEFAULT_CFG_DICT, **self.overrides}
+        self.model.task = self.task
+        self.model_name = cfg
+
+    def _load(self, weights: str) -> None:
+        self.model, self.ckpt = attempt_load_one_weight(weights)
+        self.task = self.model.args.get("task", "detect")
+        self.overrides = self.model.args = {k: v for k, v in self.model.args.items()
+                                            if k in {"imgsz", "data", "task", "single_cls"}}
+        self.ckpt_path = self.model.pt_path
+        self.overrides["model"] = weights
+        self.overrides["task"] = self.task
+        self.model_name = weights
+
+    def predict(self, source=None, stream: bool = False, **kwargs) -> List[Results]:
+        """Same argument merge as reference model.py:95-98 (conf 0.25, batch 1, save True, mode predict).
+
+        Unlike the reference, the predictor (and its engines / captured graphs) is reused across calls
+        when the arguments are unchanged; the reference rebuilds it every call (model.py:97-98).
+        """
+        custom = {"conf": 0.25, "batch": 1, "save": True, "mode": "predict"}
+        keep = kwargs.pop("keep_orig_img", False)
+        args = {**self.overrides, **custom, **kwargs}
+        if self.predictor is None or getattr(self, "_pred_args", None) != (args, keep):
+            backend = self.predictor.model if self.predictor is not None else None
+            self.predictor = DetectionPredictor(overrides=args, keep_orig_img=keep)
+            if backend is not None and backend.model is self.model and str(args.get("device")) == str(
+                    (getattr(self, "_pred_args", None) or ({},))[0].get("device")):
+                self.predictor.model = backend  # keep built engines
+                self.predictor.device = backend.device
+                self.predictor.args.half = backend.fp16
+            else:
+                self.predictor.setup_model(model=self.model)
+            self._pred_args = (dict(args), keep)
+        return self.predictor(source=source, stream=stream)
+
+    def val(self, **kwargs):
+        raise NotImplementedError("validation is not part of the MI355X predict path (SURVEY.md section 8f-2)")
+
+    def train(self, **kwargs):
+        raise NotImplementedError("training is not part of the MI355X predict path")
+
+    def info(self):
+        return self.model.info()
+
+    @property
+    def names(self):
+        return self.model.names
+
+
+YOLO = YOLOLite  # Ultralytics-style alias

@@ -1,0 +1,173 @@
+"""DetectionPredictor: preprocess -> inference -> postprocess with the reference's hooks
+(``yololite/engine/predictor.py:21-246``).
+
+Differences from the reference, all deliberate and documented in DESIGN.md:
+* ``inference`` runs the HIP engine (bf16 activations, fp32 accumulate/decode), not ``nn.Module`` s.
+* ``postprocess`` keeps results on the device and fuses ``scale_boxes`` + clip into the NMS kernel's
+  output stage; one host sync (the per-image counts) per batch instead of three ``synchronize`` s.
+* for tensor sources the uint8 host copy of the input (``convert_torch2numpy_batch``,
+  predictor.py:120-121) is only made when ``keep_orig_img=True``; ``Results.orig_shape`` is always set.
+* saving / plotting / showing are result sinks outside the accelerated path: ``save=True`` is
+  accepted (the reference's ``predict`` forces it) but nothing is drawn; ``save_txt`` works.
+"""
+from __future__ import annotations
+
+import threading
+from pathlib import Path
+from typing import List
+
+import numpy as np
+import torch
+
+from ..cfg import DEFAULT_CFG, get_cfg, get_save_dir
+from ..data import load_inference_source
+from ..data.augment import LetterBox
+from ..nn.autobackend import AutoBackend
+from ..utils import LOGGER, ops
+from ..utils.checks import check_imgsz
+from ..utils.torch_utils import select_device, smart_inference_mode
+from .results import Results
+
+
+class DetectionPredictor:
+    def __init__(self, cfg=DEFAULT_CFG, overrides=None, keep_orig_img: bool = False):
+        self.args = get_cfg(cfg, overrides)
+        self._save_dir = None
+        if self.args.conf is None:
+            self.args.conf = 0.25
+        self.done_warmup = False
+        self.model = None
+        self.data = self.args.data
+        self.imgsz = None
+        self.device = None
+        self.dataset = None
+        self.source_type = None
+        self.seen = 0
+        self.batch = None
+        self.results = None
+        self.txt_path = None
+        self.keep_orig_img = keep_orig_img
+        self.last_preds = None
+        self._lock = threading.Lock()
+
+    @property
+    def save_dir(self) -> Path:
+        if self._save_dir is None:
+            self._save_dir = get_save_dir(self.args)
+        return self._save_dir
+
+    # ------------------------------------------------------------------ hooks
+    def preprocess(self, im):
+        """BCHW tensor passthrough, or list of HWC BGR uint8 -> letterbox -> RGB CHW /255
+        (reference predictor.py:67-85)."""
+        not_tensor = not isinstance(im, torch.Tensor)
+        if not_tensor:
+            im = np.stack(self.pre_transform(im))
+            im = im[..., ::-1].transpose((0, 3, 1, 2))
+            im = torch.from_numpy(np.ascontiguousarray(im))
+        im = im.to(self.device)
+        if not_tensor:
+            return im  # uint8: the engine's input kernel divides by 255 (predictor.py:82-84)
+        return im if im.dtype in (torch.float16, torch.float32, torch.uint8) else im.float()
+
+    def pre_transform(self, im: List[np.ndarray]):
+        same_shapes = len({x.shape for x in im}) == 1
+        letterbox = LetterBox(self.imgsz, auto=same_shapes and self.model.pt, stride=self.model.stride)
+        return [letterbox(image=x) for x in im]
+
+    def inference(self, im, *args, **kwargs):
+        if self.args.visualize or self.args.augment or self.args.embed:
+            raise NotImplementedError("visualize / augment / embed are outside the accelerated predict path")
+        return self.model(im, *args, **kwargs)
+
+    def postprocess(self, preds, img, orig_imgs):
+        """NMS + rescale to the original image + Results (reference predictor.py:110-127)."""
+        pred = preds[0] if isinstance(preds, (list, tuple)) else preds
+        self.last_preds = pred
+        B = pred.shape[0]
+        if isinstance(orig_imgs, torch.Tensor):
+            shapes = [tuple(orig_imgs.shape[2:])] * B
+            imgs = ops.convert_torch2numpy_batch(orig_imgs) if self.keep_orig_img else [None] * B
+        else:
+            shapes = [tuple(o.shape[:2]) for o in orig_imgs]
+            imgs = orig_imgs
+        sc = []
+        for h0, w0 in shapes:
+            gain, pad = ops.scale_boxes_params(tuple(img.shape[2:]), (h0, w0))
+            sc.append([pad[0], pad[1], gain, w0, h0])
+        scale = torch.tensor(sc, dtype=torch.float32, device=pred.device)
+        out, cnt = ops.nms_padded(pred, self.args.conf, self.args.iou, classes=self.args.classes,
+                                  agnostic=self.args.agnostic_nms, max_det=self.args.max_det, scale=scale)
+        counts = cnt.tolist()
+        return [Results(imgs[i], path=self.batch[0][i], names=self.model.names, boxes=out[i, : counts[i]],
+                        orig_shape=shapes[i]) for i in range(B)]
+
+    # ------------------------------------------------------------------ driver
+    def __call__(self, source=None, model=None, stream=False, *args, **kwargs):
+        self.stream = stream
+        if stream:
+            return self.stream_inference(source, model, *args, **kwargs)
+        return list(self.stream_inference(source, model, *args, **kwargs))
+
+    def setup_source(self, source):
+        self.imgsz = check_imgsz(self.args.imgsz, stride=self.model.stride, min_dim=2)
+        self.dataset = load_inference_source(source=source, batch=self.args.batch, vid_stride=self.args.vid_stride,
+                                             buffer=self.args.stream_buffer)
+        self.source_type = self.dataset.source_type
+
+    def setup_model(self, model, verbose=True):
+        self.model = AutoBackend(weights=model or self.args.model,
+                                 device=select_device(self.args.device, verbose=verbose and self.args.verbose),
+                                 dnn=self.args.dnn, data=self.args.data, fp16=self.args.half, batch=self.args.batch,
+                                 fuse=True, verbose=verbose)
+        self.device = self.model.device
+        self.args.half = self.model.fp16
+        self.model.eval()
+
+    @smart_inference_mode()
+    def stream_inference(self, source=None, model=None, *args, **kwargs):
+        if not self.model:
+            self.setup_model(model)
+        with self._lock:
+            self.setup_source(source if source is not None else self.args.source)
+            if self.args.save_txt:
+                (self.save_dir / "labels").mkdir(parents=True, exist_ok=True)
+            self.seen, self.batch = 0, None
+            profilers = (ops.Profile(device=self.device), ops.Profile(device=self.device),
+                         ops.Profile(device=self.device))
+            im = None
+            for self.batch in self.dataset:
+                paths, im0s, s = self.batch
+                with profilers[0]:
+                    im = self.preprocess(im0s)
+                with profilers[1]:
+                    preds = self.inference(im, *args, **kwargs)
+                with profilers[2]:
+                    self.results = self.postprocess(preds, im, im0s)
+                n = len(im0s)
+                for i in range(n):
+                    self.seen += 1
+                    self.results[i].speed = {"preprocess": profilers[0].dt * 1e3 / n,
+                                             "inference": profilers[1].dt * 1e3 / n,
+                                             "postprocess": profilers[2].dt * 1e3 / n}
+                    if self.args.verbose or self.args.save_txt:
+                        s[i] += self.write_results(i, Path(paths[i]), im, s)
+                if self.args.verbose:
+                    LOGGER.info("\n".join(s))
+                yield from self.results
+        if self.args.verbose and self.seen and im is not None:
+            t = tuple(x.t / self.seen * 1e3 for x in profilers)
+            LOGGER.info("Speed: %.1fms preprocess, %.1fms inference, %.1fms postprocess per image at shape "
+                        f"{(min(self.args.batch, self.seen), 3, *im.shape[2:])}" % t)
+
+    def write_results(self, i, p, im, s):
+        """Log line (and optional labels/*.txt) for image i (reference predictor.py:248-285)."""
+        string = f"{i}: " if (self.source_type.from_img or self.source_type.tensor) else ""
+        string += "{:g}x{:g} ".format(*im.shape[2:])
+        result = self.results[i]
+        string += f"{result.verbose()}{result.speed['inference']:.1f}ms"
+        if self.args.save_txt:
+            self.txt_path = self.save_dir / "labels" / p.stem
+            result.save_dir = str(self.save_dir)
+            result.save_txt(f"{self.txt_path}.txt", save_conf=self.args.save_conf)
+        return string

@@ -1,0 +1,197 @@
+"""Result containers with the reference's accessors (``yololite/engine/results.py:13-101, 443-580``).
+
+``plot`` / ``save_crop`` (cv2 drawing) are result sinks outside the accelerated path; ``save_txt``,
+``summary``, ``to_json`` / ``tojson`` and ``verbose`` are plain Python and are provided.
+"""
+from __future__ import annotations
+
+import json
+from pathlib import Path
+
+import numpy as np
+import torch
+
+from ..utils import SimpleClass, ops
+
+
+class BaseTensor(SimpleClass):
+    def __init__(self, data, orig_shape) -> None:
+        assert isinstance(data, (torch.Tensor, np.ndarray)), "data must be torch.Tensor or np.ndarray"
+        self.data = data
+        self.orig_shape = orig_shape
+
+    @property
+    def shape(self):
+        return self.data.shape
+
+    def cpu(self):
+        return self if isinstance(self.data, np.ndarray) else self.__class__(self.data.cpu(), self.orig_shape)
+
+    def numpy(self):
+        return self if isinstance(self.data, np.ndarray) else self.__class__(self.data.cpu().numpy(), self.orig_shape)
+
+    def cuda(self):
+        return self.__class__(torch.as_tensor(self.data).cuda(), self.orig_shape)
+
+    def to(self, *args, **kwargs):
+        return self.__class__(torch.as_tensor(self.data).to(*args, **kwargs), self.orig_shape)
+
+    def __len__(self):
+        return len(self.data)
+
+    def __getitem__(self, idx):
+        return self.__class__(self.data[idx], self.orig_shape)
+
+
+class Boxes(BaseTensor):
+    """(n, 6) detections [x1, y1, x2, y2, conf, cls] in original-image pixels."""
+
+    def __init__(self, boxes, orig_shape) -> None:
+        if boxes.ndim == 1:
+            boxes = boxes[None, :]
+        n = boxes.shape[-1]
+        assert n in {6, 7}, f"expected 6 or 7 values but got {n}"
+        super().__init__(boxes, orig_shape)
+        self.orig_shape = orig_shape
+
+    @property
+    def xyxy(self):
+        return self.data[:, :4]
+
+    @property
+    def conf(self):
+        return self.data[:, -2]
+
+    @property
+    def cls(self):
+        return self.data[:, -1]
+
+    @property
+    def id(self):
+        return None
+
+    @property
+    def xywh(self):
+        return ops.xyxy2xywh(self.xyxy)
+
+    @property
+    def xyxyn(self):
+        xyxy = self.xyxy.clone() if isinstance(self.xyxy, torch.Tensor) else np.copy(self.xyxy)
+        xyxy[..., [0, 2]] /= self.orig_shape[1]
+        xyxy[..., [1, 3]] /= self.orig_shape[0]
+        return xyxy
+
+    @property
+    def xywhn(self):
+        xywh = ops.xyxy2xywh(self.xyxy)
+        xywh[..., [0, 2]] /= self.orig_shape[1]
+        xywh[..., [1, 3]] /= self.orig_shape[0]
+        return xywh
+
+
+class Results(SimpleClass):
+    """Per-image inference result: ``boxes``, ``names``, ``path``, ``orig_img``/``orig_shape``, ``speed``.
+
+    ``orig_img`` may be ``None`` on the tensor fast path (the reference rebuilds a uint8 copy of the
+    input on the host, predictor.py:120-121, which costs a full D2H transfer; pass
+    ``keep_orig_img=True`` to the predictor to get it); ``orig_shape`` is always set.
+    """
+
+    def __init__(self, orig_img, path, names, boxes=None, speed=None, orig_shape=None) -> None:
+        self.orig_img = orig_img
+        self.orig_shape = tuple(orig_img.shape[:2]) if orig_img is not None else tuple(orig_shape)
+        self.boxes = Boxes(boxes, self.orig_shape) if boxes is not None else None
+        self.speed = speed if speed is not None else {"preprocess": None, "inference": None, "postprocess": None}
+        self.names = names
+        self.path = path
+        self.save_dir = None
+        self._keys = ("boxes",)
+
+    def __getitem__(self, idx):
+        return self._apply("__getitem__", idx)
+
+    def __len__(self):
+        for k in self._keys:
+            v = getattr(self, k)
+            if v is not None:
+                return len(v)
+        return 0
+
+    def update(self, boxes=None):
+        if boxes is not None:
+            self.boxes = Boxes(ops.clip_boxes(boxes, self.orig_shape), self.orig_shape)
+
+    def _apply(self, fn, *args, **kwargs):
+        r = self.new()
+        for k in self._keys:
+            v = getattr(self, k)
+            if v is not None:
+                setattr(r, k, getattr(v, fn)(*args, **kwargs))
+        return r
+
+    def cpu(self):
+        return self._apply("cpu")
+
+    def numpy(self):
+        return self._apply("numpy")
+
+    def cuda(self):
+        return self._apply("cuda")
+
+    def to(self, *args, **kwargs):
+        return self._apply("to", *args, **kwargs)
+
+    def new(self):
+        return Results(orig_img=self.orig_img, path=self.path, names=self.names, speed=self.speed,
+                       orig_shape=self.orig_shape)
+
+    def verbose(self) -> str:
+        """'3 persons, 1 boat, ' style summary (reference results.py:246-263)."""
+        s = ""
+        boxes = self.boxes
+        if boxes is not None and len(boxes):
+            cls = boxes.cls if isinstance(boxes.cls, torch.Tensor) else torch.as_tensor(boxes.cls)
+            for c in cls.unique():
+                n = int((cls == c).sum())
+                s += f"{n} {self.names[int(c)]}{'s' * (n > 1)}, "
+        return s
+
+    def summary(self, normalize=False, decimals=5):
+        """List of dicts {name, class, confidence, box{x1,y1,x2,y2}} (reference results.py:319-352)."""
+        out = []
+        if self.boxes is None:
+            return out
+        data = self.boxes.data.cpu().numpy() if isinstance(self.boxes.data, torch.Tensor) else self.boxes.data
+        h, w = self.orig_shape if normalize else (1, 1)
+        for row in data:
+            cid = int(row[5])
+            out.append({"name": self.names[cid], "class": cid, "confidence": round(float(row[4]), decimals),
+                        "box": {"x1": round(float(row[0]) / w, decimals), "y1": round(float(row[1]) / h, decimals),
+                                "x2": round(float(row[2]) / w, decimals), "y2": round(float(row[3]) / h, decimals)}})
+        return out
+
+    def to_json(self, normalize=False, decimals=5):
+        return json.dumps(self.summary(normalize=normalize, decimals=decimals), indent=2)
+
+    tojson = to_json
+
+    def save_txt(self, txt_file, save_conf=False):
+        """Append 'cls cx cy w h [conf]' lines, normalised (reference results.py:265-290)."""
+        boxes = self.boxes
+        texts = []
+        if boxes is not None:
+            for d in boxes:
+                c, conf = int(d.cls), float(d.conf)
+                line = (c, *(float(v) for v in d.xywhn.reshape(-1)))
+                line += (conf,) * save_conf
+                texts.append(("%g " * len(line)).rstrip() % line)
+        if texts:
+            Path(txt_file).parent.mkdir(parents=True, exist_ok=True)
+            with open(txt_file, "a") as f:
+                f.writelines(t + "\n" for t in texts)
+
+    def plot(self, *args, **kwargs):
+        raise NotImplementedError("Results.plot draws with cv2; result sinks are outside the accelerated path")
+
+    def save_crop(self, *args, **kwargs):
+        raise NotImplementedError("Results.save_crop is outside the accelerated path")

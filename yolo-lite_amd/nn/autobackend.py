@@ -1,0 +1,106 @@
+"""AutoBackend: device placement and forward dispatch (reference ``yololite/nn/autobackend.py``).
+
+The backend is always the HIP engine.  Engines are built lazily per (batch, H, W) because all
+buffer offsets, tilings and the captured graph are shape-specialised; the most recent few are cached.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from pathlib import Path
+from typing import Optional
+
+import torch
+
+from .engine import HipEngine
+from .tasks import DetectionModel, attempt_load_weights
+
+
+def default_class_names(data=None):
+    if data:
+        try:
+            import yaml
+
+            with open(data, errors="ignore", encoding="utf-8") as f:
+                return yaml.safe_load(f)["names"]
+        except Exception:
+            pass
+    return {i: f"class{i}" for i in range(999)}
+
+
+class AutoBackend:
+    """``AutoBackend(weights, device, fp16, fuse)`` with ``.forward(im)``, ``.warmup(imgsz)`` and the
+    attributes the predictor reads: ``pt fp16 stride names device`` (reference autobackend.py:124)."""
+
+    MAX_ENGINES = 4
+
+    def __init__(self, weights="yolo11n.pt", device=torch.device("cpu"), dnn=False, data=None, fp16=False, batch=1,
+                 fuse=True, verbose=True):
+        w = weights[0] if isinstance(weights, (list, tuple)) else weights
+        if isinstance(w, DetectionModel):
+            model = w
+        else:
+            # reference bug not inherited: `w.split('.')[1] == 'pt'` (autobackend.py:63) breaks on './x.pt'
+            if Path(str(w)).suffix != ".pt":
+                raise TypeError(f"model='{w}' is not a supported model format (only *.pt / in-memory models)")
+            model = attempt_load_weights(str(w), device=device, inplace=True, fuse=fuse)
+        if fuse:
+            model = model.fuse(verbose=verbose)
+        self.model = model
+        self.device = device if isinstance(device, torch.device) else torch.device(device)
+        self.fp16 = bool(fp16)  # accepted for API compatibility; the engine computes in bf16 / fp32 accumulate
+        self.pt = True
+        self.nn_module = isinstance(w, DetectionModel)
+        self.jit = False
+        self.triton = False
+        self.stride = max(int(model.stride.max()), 32)
+        self.names = model.names if model.names else default_class_names(data)
+        self.task = "detect"
+        self.batch = batch
+        self._engines: "OrderedDict[tuple, HipEngine]" = OrderedDict()
+
+    def eval(self):
+        return self
+
+    def engine_for(self, b: int, h: int, w: int) -> HipEngine:
+        key = (b, h, w, self.model._version)
+        eng = self._engines.get(key)
+        if eng is None:
+            if self.device.type != "cuda":
+                raise RuntimeError("the YOLO11 network runs on the GPU only (HIP kernels; no CPU fallback): "
+                                   "pass device=0 / 'cuda:0'")
+            eng = HipEngine.from_model(self.model.specs, self.model.state_dict(), b, h, w, self.device,
+                                       strides=self.model.stride.tolist())
+            self._engines[key] = eng
+            while len(self._engines) > self.MAX_ENGINES:
+                self._engines.popitem(last=False)
+        else:
+            self._engines.move_to_end(key)
+        return eng
+
+    def forward(self, im: torch.Tensor, augment=False, visualize=False, embed=None, graph: bool = False):
+        """(B,3,H,W) in [0,1] -> [y (B, 4+nc, A) fp32, [raw level maps (B, 64+nc, H_l, W_l)]]
+        like ``Detect.forward`` in eval mode (reference head.py:59-69, autobackend.py:126-151)."""
+        if augment or visualize or embed:
+            raise NotImplementedError("augment / visualize / embed are outside the accelerated predict path")
+        if im.device != self.device:
+            im = im.to(self.device)
+        if im.dtype == torch.float64 or im.dtype == torch.bfloat16:
+            im = im.float()
+        im = im.contiguous()
+        b, _, h, w = im.shape
+        eng = self.engine_for(b, h, w)
+        y = eng.forward(im, graph=graph)
+        return [y, eng.raw_levels()]
+
+    __call__ = forward
+
+    def from_numpy(self, x):
+        import numpy as np
+
+        return torch.tensor(x).to(self.device) if isinstance(x, np.ndarray) else x
+
+    def warmup(self, imgsz=(1, 3, 640, 640)):
+        """One dummy forward on GPU devices (reference autobackend.py:157-165, minus its `self.jit` bug)."""
+        if self.device.type != "cpu":
+            im = torch.zeros(*imgsz, dtype=torch.float32, device=self.device)
+            self.forward(im, graph=False)

@@ -97,7 +97,13 @@ class HipEngine:
         """im (B,3,H,W) fp32/fp16 in [0,1] or uint8 -> y (B, 4+nc, A) fp32 (reference head.py:95-126)."""
         self._check_input(im)
         if decode and y is None:
-            y = torch.empty((self.batch, 4 + self.nc, self.anchors), dtype=torch.float32, device=self.device)
+            if graph:  # graphs bake pointers: reuse one output buffer (valid until the next graph call)
+                if getattr(self, "_y_static", None) is None:
+                    self._y_static = torch.empty((self.batch, 4 + self.nc, self.anchors), dtype=torch.float32,
+                                                 device=self.device)
+                y = self._y_static
+            else:
+                y = torch.empty((self.batch, 4 + self.nc, self.anchors), dtype=torch.float32, device=self.device)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         fn = self.lib.yl_engine_forward_graph if graph else self.lib.yl_engine_forward
         _lib.check(fn(self._h, im.data_ptr(), _TORCH2YL[im.dtype], self.workspace.data_ptr(),
