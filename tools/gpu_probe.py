@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Development probe: times the pieces of the hot path separately on the GPU (not part of the bench contract)."""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import torch  # noqa: E402
+
+from bench import build_model  # noqa: E402
+from yololite_amd.utils import ops as hops  # noqa: E402
+
+
+def timeit(fn, n=30, warm=5):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n, (time.perf_counter() - t0) * 1e3 / n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--scale", default="n")
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--imgsz", type=int, default=640)
+    ap.add_argument("--top", type=int, default=25)
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    B, H = a.batch, a.imgsz
+    x = torch.rand(B, 3, H, H, generator=torch.Generator().manual_seed(0)).to(dev)
+    specs, sd, eng = build_model(a.scale, dev, B, H, H, x)
+    y = eng.forward(x, graph=True)
+    print("forward graph   (gpu ms, wall ms):", timeit(lambda: eng.forward(x, graph=True)))
+    print("forward eager   (gpu ms, wall ms):", timeit(lambda: eng.forward(x, graph=False)))
+    print("forward nodecode(gpu ms, wall ms):", timeit(lambda: eng.forward(x, graph=False, decode=False)))
+    print("nms             (gpu ms, wall ms):", timeit(lambda: hops.nms_padded(y, 0.25, 0.7)))
+    out, cnt = hops.nms_padded(y, 0.25, 0.7)
+    cands = (y[:, 4:].amax(1) > 0.25).sum(1).float()
+    print("candidates/img mean", cands.mean().item(), "max", cands.max().item(), "dets/img", cnt.float().mean().item())
+    print("e2e             (gpu ms, wall ms):", timeit(lambda: hops.nms_padded(eng.forward(x, graph=True), 0.25, 0.7)))
+    rows = eng.profile(x, iters=20)
+    tot = sum(r["ms"] for r in rows)
+    print(f"sum of per-op times {tot:.3f} ms over {len(rows)} launches")
+    rows.sort(key=lambda r: -r["ms"])
+    for r in rows[: a.top]:
+        print(f"{r['name']:26s} {r['kernel']:16s} {r['ms'] * 1e3:8.1f} us {r['flops'] / max(r['ms'], 1e-9) / 1e9:7.1f} TF/s "
+              f"{r['bytes'] / max(r['ms'], 1e-9) / 1e6:8.1f} GB/s")
+
+
+if __name__ == "__main__":
+    main()

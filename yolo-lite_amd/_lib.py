@@ -67,6 +67,11 @@ def lib() -> C.CDLL:
         if not LIB_PATH.exists():
             raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "(there is no CPU fallback for the HIP path)")
+    # PyTorch-ROCm bundles its own libamdhip64 (same SONAME as /opt/rocm's).  Import torch first so
+    # that libyl_amd.so binds to the HIP runtime torch already initialised: two runtimes in one
+    # process cannot share device pointers or streams ("no ROCm-capable device is detected").
+    import torch  # noqa: F401
+
     L = C.CDLL(str(LIB_PATH))
     vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
     L.yl_last_error.restype = C.c_char_p

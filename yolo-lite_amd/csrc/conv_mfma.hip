@@ -9,10 +9,20 @@
 //   A (16 x 32)  = packed weights, row = output channel, k = (tap, cin) in groups of 8
 //   B (32 x 16)  = activations,    col = output pixel,   read from an LDS halo tile [pixel][cch]
 //   D (16 x 16)  : lane holds 4 consecutive output channels of ONE pixel -> 8-byte NHWC stores.
-// One workgroup = 4 waves = TH x TW output pixels (4*NT*16) x MT*16 output channels.
+// One workgroup = 4 waves; a tile = TH x TW output pixels (4*NT*16) x MT*16 output channels.
+//
+// Two kernels share the k-loop and the epilogue:
+//   conv_ws_kernel   weight-stationary + persistent: the block's whole filter slab is staged into
+//                    LDS once, then the block walks its tiles; the next (tile, channel-chunk) halo
+//                    is prefetched global->registers while the current one is multiplied out of
+//                    LDS (two halo buffers, one barrier per stage).
+//   conv_tile_kernel fallback when the slab does not fit LDS: one tile per block, the filter
+//                    chunk is restaged with every channel chunk.
 #include "yl_internal.h"
 
 namespace yl {
+
+constexpr int MAXPRE = 12;  // 16-byte prefetch registers per thread (halo stage)
 
 __device__ __forceinline__ int fastdiv(int x, int d, unsigned magic) {
   return d == 1 ? x : (int)__umulhi((unsigned)x, magic);
@@ -20,30 +30,10 @@ __device__ __forceinline__ int fastdiv(int x, int d, unsigned magic) {
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
 
-template <int KS, int MT, int NT, bool UNIFORM>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int g = lane >> 4, n = lane & 15;
-
-  // XCD-aware, bijective block remap: blocks that share halo rows / weights land on one L2.
-  int bid = blockIdx.x;
-  {
-    const int q = a.nblocks >> 3, r = a.nblocks & 7, xcd = bid & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  const int cb = bid % a.ncb;
-  int t = bid / a.ncb;
-  const int tx_i = t % a.tiles_x;
-  t /= a.tiles_x;
-  const int ty_i = t % a.tiles_y;
-  const int b = t / a.tiles_y;
-  const int oy0 = ty_i * a.TH, ox0 = tx_i * a.TW;
-  const int iy0 = oy0 * a.stride - a.pad, ix0 = ox0 * a.stride - a.pad;
-
-  // Per-lane output pixels (one per pixel tile) and their halo offsets in LDS.
-  int pixoff[NT];
-  int opix[NT];  // oy*Wo+ox or -1
+// Per-lane output pixels of the wave's NT pixel tiles: LDS halo offset and output pixel index.
+template <int NT>
+__device__ __forceinline__ void lane_pixels(const ConvArgs& a, int wave, int n, int oy0, int ox0, int (&pixoff)[NT],
+                                            int (&opix)[NT]) {
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int idx = (wave * NT + nt) * 16 + n;
@@ -56,73 +46,53 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     pixoff[nt] = ((ty * a.stride) * a.HW + tx * a.stride) * a.pp;
     opix[nt] = valid ? oy * a.Wo + ox : -1;
   }
+}
 
-  f32x4 acc[MT][NT];
+// Halo stage, split in two so the global loads fly during the previous stage's MFMAs.
+__device__ __forceinline__ void stage_load(const ConvArgs& a, const __bf16* src /* image + coff + chunk */, int iy0,
+                                           int ix0, int sg, int sp0, int ppass, int HP, bf16x8 (&pre)[MAXPRE]) {
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int HP = a.HH * a.HW;
-  const int ppass = 256 >> a.lg2;
-  const int sg = tid & ((1 << a.lg2) - 1), sp0 = tid >> a.lg2;
-  const __bf16* inb = a.in + (long long)b * a.in_img + a.in_coff;
-
-  for (int chunk = 0; chunk < a.nchunks; ++chunk) {
-    if (chunk) __syncthreads();
-    // ---- stage the halo tile of this channel chunk: global NHWC -> LDS [pixel][cch] (+16 B pad)
-    if (sg < a.cg) {
-      for (int pix = sp0; pix < HP; pix += ppass) {
-        const int hy = fastdiv(pix, a.HW, a.magic_hw);
-        const int hx = pix - hy * a.HW;
-        const int iy = iy0 + hy, ix = ix0 + hx;
-        bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
-          v = *reinterpret_cast<const bf16x8*>(inb + (long long)(iy * a.W + ix) * a.in_pitch +
-                                               chunk * a.cch + sg * 8);
-        *reinterpret_cast<bf16x8*>(smem + pix * a.pp + sg * 16) = v;
-      }
+  for (int j = 0; j < MAXPRE; ++j) {
+    const int pix = sp0 + j * ppass;
+    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (pix < HP && sg < a.cg) {
+      const int hy = fastdiv(pix, a.HW, a.magic_hw);
+      const int hx = pix - hy * a.HW;
+      const int iy = iy0 + hy, ix = ix0 + hx;
+      if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+        v = *reinterpret_cast<const bf16x8*>(src + (long long)(iy * a.W + ix) * a.in_pitch + sg * 8);
     }
-    __syncthreads();
+    pre[j] = v;
+  }
+}
 
-    const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.wpk) +
-                       ((size_t)(cb * a.nchunks + chunk) * a.ksteps) * MT * 64 + lane;
-    if (UNIFORM) {
-      const int kkn = a.cg >> 2;
-      int ks = 0;
+__device__ __forceinline__ void stage_store(const ConvArgs& a, unsigned char* dst, int sg, int sp0, int ppass, int HP,
+                                            const bf16x8 (&pre)[MAXPRE]) {
+  if (sg >= a.cg) return;
 #pragma unroll
-      for (int tap = 0; tap < KS * KS; ++tap) {
-        const int tapoff = ((tap / KS) * a.HW + (tap % KS)) * a.pp + g * 16;
-        for (int kk = 0; kk < kkn; ++kk, ++ks) {
-          bf16x8 wa[MT], xb[NT];
+  for (int j = 0; j < MAXPRE; ++j) {
+    const int pix = sp0 + j * ppass;
+    if (pix < HP) *reinterpret_cast<bf16x8*>(dst + pix * a.pp + sg * 16) = pre[j];
+  }
+}
+
+// K loop of one channel chunk: both operands from LDS.
+template <int KS, int MT, int NT, bool UNIFORM>
+__device__ __forceinline__ void kloop(const ConvArgs& a, const unsigned char* halo, const bf16x8* wl /* + lane */,
+                                      int g, const int (&pixoff)[NT], f32x4 (&acc)[MT][NT]) {
+  if (UNIFORM) {
+    const int kkn = a.cg >> 2;
+    int ks = 0;
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) wa[mt] = wp[(ks * MT + mt) * 64];
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-            xb[nt] = *reinterpret_cast<const bf16x8*>(smem + pixoff[nt] + tapoff + kk * 64);
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[mt], xb[nt], acc[mt][nt], 0, 0, 0);
-        }
-      }
-    } else {
-      for (int ks = 0; ks < a.ksteps; ++ks) {
-        const int k8 = ks * 4 + g;
-        int tap = fastdiv(k8, a.cg, a.magic_cg);
-        int c8 = k8 - tap * a.cg;
-        if (tap >= KS * KS) {  // zero-weight padding group: read any valid finite data
-          tap = KS * KS - 1;
-          c8 = 0;
-        }
-        const int kh = (tap * 11) >> 5, kw = tap - 3 * ((tap * 11) >> 5);
-        const int off = (KS == 1 ? 0 : (kh * a.HW + kw) * a.pp) + c8 * 16;
+    for (int tap = 0; tap < KS * KS; ++tap) {
+      const int tapoff = ((tap / KS) * a.HW + (tap % KS)) * a.pp + g * 16;
+      for (int kk = 0; kk < kkn; ++kk, ++ks) {
         bf16x8 wa[MT], xb[NT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) wa[mt] = wp[(ks * MT + mt) * 64];
+        for (int mt = 0; mt < MT; ++mt) wa[mt] = wl[(ks * MT + mt) * 64];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) xb[nt] = *reinterpret_cast<const bf16x8*>(smem + pixoff[nt] + off);
+        for (int nt = 0; nt < NT; ++nt)
+          xb[nt] = *reinterpret_cast<const bf16x8*>(halo + pixoff[nt] + tapoff + kk * 64);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -130,9 +100,35 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[mt], xb[nt], acc[mt][nt], 0, 0, 0);
       }
     }
+  } else {
+    for (int ks = 0; ks < a.ksteps; ++ks) {
+      const int k8 = ks * 4 + g;
+      int tap = fastdiv(k8, a.cg, a.magic_cg);
+      int c8 = k8 - tap * a.cg;
+      if (tap >= KS * KS) {  // zero-weight padding group: read any valid finite data
+        tap = KS * KS - 1;
+        c8 = 0;
+      }
+      const int kh = (tap * 11) >> 5, kw = tap - 3 * ((tap * 11) >> 5);
+      const int off = (KS == 1 ? 0 : (kh * a.HW + kw) * a.pp) + c8 * 16;
+      bf16x8 wa[MT], xb[NT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) wa[mt] = wl[(ks * MT + mt) * 64];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) xb[nt] = *reinterpret_cast<const bf16x8*>(halo + pixoff[nt] + off);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[mt], xb[nt], acc[mt][nt], 0, 0, 0);
+    }
   }
+}
 
-  // ---- epilogue: + bias, SiLU, + residual, store 4 consecutive channels of one pixel
+// + bias, SiLU, + residual, store 4 consecutive channels of one pixel.
+template <int MT, int NT>
+__device__ __forceinline__ void epilogue(const ConvArgs& a, int cb, int b, int g, const int (&opix)[NT],
+                                         const f32x4 (&acc)[MT][NT]) {
   const bool vec = ((a.Cout | a.out_pitch | a.out_coff | a.res_pitch | a.res_coff) & 3) == 0;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -182,86 +178,248 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
   }
 }
 
+// XCD-aware, bijective block remap: blocks that share halo rows / weights land on one L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+  const int q = nblocks >> 3, r = nblocks & 7, xcd = bid & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+struct TilePos {
+  int b, oy0, ox0;
+};
+__device__ __forceinline__ TilePos tile_pos(const ConvArgs& a, int t) {
+  TilePos p;
+  const int tx_i = t % a.tiles_x;
+  t /= a.tiles_x;
+  const int ty_i = t % a.tiles_y;
+  p.b = t / a.tiles_y;
+  p.oy0 = ty_i * a.TH;
+  p.ox0 = tx_i * a.TW;
+  return p;
+}
+
+// ------------------------------------------------------------ weight-stationary persistent kernel
+template <int KS, int MT, int NT, bool UNIFORM>
+__global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, n = lane & 15;
+  const int bid = xcd_remap(blockIdx.x, a.nblocks);
+  const int cb = bid % a.ncb;
+  const int slot = bid / a.ncb;  // this block walks tiles slot, slot + gws, ...
+  const int ntiles = a.ntiles;
+  const int mine = (ntiles - slot + a.gws - 1) / a.gws;
+  if (mine <= 0) return;
+  const int nitems = mine * a.nchunks;
+
+  const int HP = a.HH * a.HW;
+  const int ppass = 256 >> a.lg2;
+  const int sg = tid & ((1 << a.lg2) - 1), sp0 = tid >> a.lg2;
+  unsigned char* hbuf[2] = {smem + a.halo_lds_off, smem + a.halo_lds_off + a.halo_bytes};
+  const bf16x8* wl = reinterpret_cast<const bf16x8*>(smem) + lane;
+  const int wstride = a.ksteps * MT * 64;  // bf16x8 units per chunk
+
+  bf16x8 pre[MAXPRE];
+  // ---- prologue: first halo stage in flight, whole filter slab -> LDS, then publish both
+  TilePos cur = tile_pos(a, slot);
+  {
+    const __bf16* src = a.in + (long long)cur.b * a.in_img + a.in_coff;
+    stage_load(a, src, cur.oy0 * a.stride - a.pad, cur.ox0 * a.stride - a.pad, sg, sp0, ppass, HP, pre);
+    const bf16x8* wsrc = reinterpret_cast<const bf16x8*>(a.wpk) + (size_t)cb * a.nchunks * wstride;
+    bf16x8* wdst = reinterpret_cast<bf16x8*>(smem);
+    const int nw = a.nchunks * wstride;
+    for (int i = tid; i < nw; i += 256) wdst[i] = wsrc[i];
+    stage_store(a, hbuf[0], sg, sp0, ppass, HP, pre);
+  }
+  __syncthreads();
+
+  int pixoff[NT], opix[NT];
+  f32x4 acc[MT][NT];
+  int chunk = 0, tcount = 0;
+  TilePos nxt = cur;
+  for (int it = 0; it < nitems; ++it) {
+    if (chunk == 0) {
+      lane_pixels<NT>(a, wave, n, cur.oy0, cur.ox0, pixoff, opix);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // ---- prefetch the next (tile, chunk) halo into registers
+    const bool more = it + 1 < nitems;
+    int nchunk = chunk + 1;
+    if (nchunk == a.nchunks) {
+      nchunk = 0;
+      if (more) nxt = tile_pos(a, slot + (tcount + 1) * a.gws);
+    }
+    if (more) {
+      const __bf16* src = a.in + (long long)nxt.b * a.in_img + a.in_coff + nchunk * a.cch;
+      stage_load(a, src, nxt.oy0 * a.stride - a.pad, nxt.ox0 * a.stride - a.pad, sg, sp0, ppass, HP, pre);
+    }
+    // ---- multiply the current stage out of LDS
+    kloop<KS, MT, NT, UNIFORM>(a, hbuf[it & 1], wl + (size_t)chunk * wstride, g, pixoff, acc);
+    if (chunk == a.nchunks - 1) epilogue<MT, NT>(a, cb, cur.b, g, opix, acc);
+    if (more) stage_store(a, hbuf[(it + 1) & 1], sg, sp0, ppass, HP, pre);
+    __syncthreads();
+    if (nchunk == 0) {
+      cur = nxt;
+      ++tcount;
+    }
+    chunk = nchunk;
+  }
+}
+
+// ------------------------------------------------------------------- one-tile-per-block fallback
+template <int KS, int MT, int NT, bool UNIFORM>
+__global__ __launch_bounds__(256) void conv_tile_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, n = lane & 15;
+  const int bid = xcd_remap(blockIdx.x, a.nblocks);
+  const int cb = bid % a.ncb;
+  const TilePos tp = tile_pos(a, bid / a.ncb);
+  const int iy0 = tp.oy0 * a.stride - a.pad, ix0 = tp.ox0 * a.stride - a.pad;
+
+  int pixoff[NT], opix[NT];
+  lane_pixels<NT>(a, wave, n, tp.oy0, tp.ox0, pixoff, opix);
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int HP = a.HH * a.HW;
+  const int ppass = 256 >> a.lg2;
+  const int sg = tid & ((1 << a.lg2) - 1), sp0 = tid >> a.lg2;
+  const __bf16* inb = a.in + (long long)tp.b * a.in_img + a.in_coff;
+  unsigned char* halo = smem + a.halo_lds_off;
+  const int wstride = a.ksteps * MT * 64;
+  bf16x8 pre[MAXPRE];
+  for (int chunk = 0; chunk < a.nchunks; ++chunk) {
+    if (chunk) __syncthreads();
+    stage_load(a, inb + chunk * a.cch, iy0, ix0, sg, sp0, ppass, HP, pre);
+    {
+      const bf16x8* wsrc = reinterpret_cast<const bf16x8*>(a.wpk) + ((size_t)cb * a.nchunks + chunk) * wstride;
+      bf16x8* wdst = reinterpret_cast<bf16x8*>(smem);
+      for (int i = tid; i < wstride; i += 256) wdst[i] = wsrc[i];
+    }
+    stage_store(a, halo, sg, sp0, ppass, HP, pre);
+    __syncthreads();
+    kloop<KS, MT, NT, UNIFORM>(a, halo, reinterpret_cast<const bf16x8*>(smem) + lane, g, pixoff, acc);
+  }
+  epilogue<MT, NT>(a, cb, tp.b, g, opix, acc);
+}
+
 // ------------------------------------------------------------------------------------ host
 static unsigned magic_of(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull / (unsigned)d) + 1ull); }
+
+static const size_t LDS_MAX = 160 * 1024;     // per CU and per workgroup on gfx950
+static const size_t W_STATIONARY_MAX = 80 * 1024;
+static const int NUM_CU = 256;
 
 int conv_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, ConvConfig* c) {
   if ((k != 1 && k != 3) || (stride != 1 && stride != 2) || Cin % 8 || Cin <= 0 || Cout <= 0)
     return fail(-3, "conv: unsupported geometry (k in {1,3}, stride in {1,2}, Cin % 8 == 0)");
   const int cout16 = (Cout + 15) / 16;
-  int MT = 1;
-  if (cout16 % 4 == 0) MT = 4;
-  else if (cout16 % 5 == 0) MT = 5;
-  else if (cout16 % 2 == 0) MT = 2;
-  c->MT = MT;
-  c->ncb = cout16 / MT;
+  const int ntaps = k * k;
+  c->ntaps = ntaps;
   const long long pixels = (long long)batch * Ho * Wo;
-  // 256-pixel tiles when that still gives >= ~4 blocks per CU, else 128.
-  int NT = (pixels / 256) * c->ncb >= 1024 ? 4 : 2;
-  if (MT == 5 && NT == 4) NT = 2;  // keep accumulators <= 64 VGPRs
-  c->NT = NT;
-  const int P = 4 * NT * 16;
-  c->ntaps = k * k;
-  const int pad = k / 2;
-  (void)pad;
-  // channel chunk
-  int cch;
-  if (Cin <= 128) cch = Cin;
-  else if (Cin % 64 == 0) cch = 64;
-  else if (Cin % 32 == 0) cch = 32;
-  else if (Cin % 16 == 0) cch = 16;
-  else cch = 8;
-  // tile search: minimise staged halo pixels per output pixel, then the block count
   auto halo = [&](int th, int tw, int* hh, int* hw) {
     *hh = (th - 1) * stride + k;
     *hw = (tw - 1) * stride + k;
   };
-  for (;;) {
-    double best = 1e30;
-    int bth = 0, btw = 0;
-    for (int tw = 4; tw <= P && tw <= ((Wo + 3) / 4) * 4 + 12; ++tw) {
-      int th = P / tw;
-      if (th < 1) break;
-      if (th > Ho) th = Ho;
-      int hh, hw;
-      halo(th, tw, &hh, &hw);
-      const size_t lds = (size_t)hh * hw * (cch * 2 + 16);
-      if (lds > 64 * 1024) continue;
-      const long long tiles = (long long)((Ho + th - 1) / th) * ((Wo + tw - 1) / tw);
-      // cost: staged pixels + a penalty for idle MFMA slots (P per tile regardless of use)
-      const double cost = (double)tiles * ((double)hh * hw * (k == 1 ? 1.0 : 1.0) + 0.75 * P);
-      if (cost < best) {
-        best = cost;
-        bth = th;
-        btw = tw;
+  // channel-chunk candidates: divisors of Cin that are multiples of 8, at most 128, largest first;
+  // multiples of 32 first (wave-uniform tap per k-step), then the rest
+  std::vector<int> cands;
+  for (int pass = 0; pass < 2; ++pass)
+    for (int d = Cin < 128 ? Cin : 128; d >= 8; d -= 8)
+      if (Cin % d == 0 && ((d % 32 == 0) == (pass == 0))) cands.push_back(d);
+  if (Cin <= 128 && Cin % 32) cands.insert(cands.begin(), Cin);  // small odd Cin: a single chunk
+
+  int mts[4], nmt = 0;
+  if (cout16 % 4 == 0) mts[nmt++] = 4;
+  if (cout16 % 5 == 0) mts[nmt++] = 5;
+  if (cout16 % 2 == 0) mts[nmt++] = 2;
+  mts[nmt++] = 1;
+
+  // mode 1: weight-stationary (slab of all chunks <= W_STATIONARY_MAX), mode 0: per-chunk restaging
+  for (int ws = 1; ws >= 0; --ws) {
+    for (int mi = 0; mi < nmt; ++mi) {
+      const int MT = mts[mi];
+      const int ncb = cout16 / MT;
+      int NT0 = 1;
+      if ((pixels / 256) * ncb >= 2 * NUM_CU) NT0 = 4;
+      else if ((pixels / 128) * ncb >= 2 * NUM_CU) NT0 = 2;
+      if (MT == 5 && NT0 == 4) NT0 = 2;
+      for (int NT = NT0; NT >= 1; NT >>= 1) {
+        const int P = 4 * NT * 16;
+        for (int cch : cands) {
+          const int cg = cch / 8, nchunks = Cin / cch;
+          int lg2 = 0;
+          while ((1 << lg2) < cg) ++lg2;
+          const int ksteps = (ntaps * cg + 3) / 4;
+          const size_t wchunk = (size_t)ksteps * MT * 1024;
+          const size_t wbytes = ws ? wchunk * nchunks : wchunk;
+          if (ws && wbytes > W_STATIONARY_MAX) continue;
+          if (!ws && wbytes > 64 * 1024) continue;
+          const int pp = cch * 2 + 16;
+          double best = 1e30;
+          int bth = 0, btw = 0;
+          for (int tw = 4; tw <= P && tw <= ((Wo + 3) / 4) * 4 + 12; ++tw) {
+            int th = P / tw;
+            if (th < 1) break;
+            if (th > Ho) th = Ho;
+            int hh, hw;
+            halo(th, tw, &hh, &hw);
+            const size_t hb = ((size_t)hh * hw * pp + 15) & ~(size_t)15;
+            if (wbytes + (ws ? 2 : 1) * hb > LDS_MAX - 1024) continue;
+            if ((hh * hw + (256 >> lg2) - 1) / (256 >> lg2) > MAXPRE) continue;
+            const long long tiles = (long long)((Ho + th - 1) / th) * ((Wo + tw - 1) / tw);
+            const double cost = (double)tiles * ((double)hh * hw + 0.75 * P);
+            if (cost < best) {
+              best = cost;
+              bth = th;
+              btw = tw;
+            }
+          }
+          if (!bth) continue;
+          c->ws = ws;
+          c->MT = MT;
+          c->ncb = ncb;
+          c->NT = NT;
+          c->TH = bth;
+          c->TW = btw;
+          halo(c->TH, c->TW, &c->HH, &c->HW);
+          c->tiles_x = (Wo + c->TW - 1) / c->TW;
+          c->tiles_y = (Ho + c->TH - 1) / c->TH;
+          c->cch = cch;
+          c->cg = cg;
+          c->lg2 = lg2;
+          c->nchunks = nchunks;
+          c->uniform = (cch % 32 == 0);
+          c->ksteps = ksteps;
+          c->pp = pp;
+          c->halo_bytes = (int)(((size_t)c->HH * c->HW * pp + 15) & ~(size_t)15);
+          c->halo_lds_off = (int)wbytes;
+          c->lds_bytes = wbytes + (size_t)(ws ? 2 : 1) * c->halo_bytes;
+          c->wpk_elems = (size_t)ncb * nchunks * ksteps * MT * 64 * 8;
+          c->ntiles = batch * c->tiles_x * c->tiles_y;
+          if (ws) {
+            const int bpc = (int)(LDS_MAX / c->lds_bytes) >= 2 ? 2 : 1;
+            int cap = NUM_CU * bpc / ncb;
+            if (cap < 1) cap = 1;
+            const int rounds = (c->ntiles + cap - 1) / cap;
+            c->gws = (c->ntiles + rounds - 1) / rounds;
+          } else {
+            c->gws = c->ntiles;
+          }
+          c->name = k == 3 ? (stride == 2 ? "conv3x3s2_mfma" : "conv3x3_mfma") : "conv1x1_mfma";
+          return 0;
+        }
       }
     }
-    if (bth) {
-      c->TH = bth;
-      c->TW = btw;
-      break;
-    }
-    // does not fit: halve the chunk (must still divide Cin and be a multiple of 8)
-    int nc = cch / 2;
-    while (nc >= 8 && (Cin % nc || nc % 8)) nc -= 8;
-    if (nc < 8) return fail(-3, "conv: no tile fits LDS");
-    cch = nc;
   }
-  halo(c->TH, c->TW, &c->HH, &c->HW);
-  c->tiles_x = (Wo + c->TW - 1) / c->TW;
-  c->tiles_y = (Ho + c->TH - 1) / c->TH;
-  c->cch = cch;
-  c->cg = cch / 8;
-  c->lg2 = 0;
-  while ((1 << c->lg2) < c->cg) ++c->lg2;
-  c->nchunks = Cin / cch;
-  c->uniform = (cch % 32 == 0);
-  c->ksteps = (c->ntaps * c->cg + 3) / 4;
-  c->pp = cch * 2 + 16;
-  c->lds_bytes = (size_t)c->HH * c->HW * c->pp;
-  c->wpk_elems = (size_t)c->ncb * c->nchunks * c->ksteps * c->MT * 64 * 8;
-  c->name = k == 3 ? (stride == 2 ? "conv3x3s2_mfma" : "conv3x3_mfma") : "conv1x1_mfma";
-  return 0;
+  return fail(-3, "conv: no tiling fits LDS");
 }
 
 static inline uint16_t f2bf(float f) {
@@ -297,16 +455,25 @@ void conv_pack_weights(const float* w, int Cout, int Cin_w, int Cin_pad, int k, 
 
 template <int KS, int MT, int NT, bool U>
 static int launch_t(const ConvConfig& cfg, const ConvArgs& a, hipStream_t s) {
-  auto kern = conv_mfma_kernel<KS, MT, NT, U>;
-  if (cfg.lds_bytes > 48 * 1024) {
-    static bool done = false;  // per instantiation
-    if (!done) {
+  if (cfg.ws) {
+    auto kern = conv_ws_kernel<KS, MT, NT, U>;
+    static size_t attr = 0;  // per instantiation: largest dynamic LDS size enabled so far
+    if (cfg.lds_bytes > attr) {
       YL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 64 * 1024));
-      done = true;
+                                 (int)LDS_MAX));
+      attr = LDS_MAX;
     }
+    hipLaunchKernelGGL(kern, dim3(a.nblocks), dim3(256), cfg.lds_bytes, s, a);
+  } else {
+    auto kern = conv_tile_kernel<KS, MT, NT, U>;
+    static size_t attr = 0;
+    if (cfg.lds_bytes > attr) {
+      YL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)LDS_MAX));
+      attr = LDS_MAX;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.nblocks), dim3(256), cfg.lds_bytes, s, a);
   }
-  hipLaunchKernelGGL(kern, dim3(a.nblocks), dim3(256), cfg.lds_bytes, s, a);
   YL_HIP(hipGetLastError());
   return 0;
 }
@@ -318,7 +485,8 @@ static int launch_u(const ConvConfig& cfg, const ConvArgs& a, hipStream_t s) {
 
 template <int KS, int MT>
 static int launch_n(const ConvConfig& cfg, const ConvArgs& a, hipStream_t s) {
-  return cfg.NT == 4 ? launch_u<KS, MT, 4>(cfg, a, s) : launch_u<KS, MT, 2>(cfg, a, s);
+  return cfg.NT == 4 ? launch_u<KS, MT, 4>(cfg, a, s)
+                     : cfg.NT == 2 ? launch_u<KS, MT, 2>(cfg, a, s) : launch_u<KS, MT, 1>(cfg, a, s);
 }
 
 template <int KS>
@@ -327,12 +495,13 @@ static int launch_m(const ConvConfig& cfg, const ConvArgs& a, hipStream_t s) {
     case 1: return launch_n<KS, 1>(cfg, a, s);
     case 2: return launch_n<KS, 2>(cfg, a, s);
     case 4: return launch_n<KS, 4>(cfg, a, s);
-    case 5: return launch_u<KS, 5, 2>(cfg, a, s);
+    case 5: return cfg.NT == 1 ? launch_u<KS, 5, 1>(cfg, a, s) : launch_u<KS, 5, 2>(cfg, a, s);
   }
   return fail(-3, "conv: bad MT");
 }
 
 int conv_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s) {
+  (void)batch;
   a.TH = cfg.TH;
   a.TW = cfg.TW;
   a.tiles_x = cfg.tiles_x;
@@ -347,10 +516,14 @@ int conv_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s) {
   a.ksteps = cfg.ksteps;
   a.pp = cfg.pp;
   a.ntaps = cfg.ntaps;
+  a.halo_lds_off = cfg.halo_lds_off;
+  a.halo_bytes = cfg.halo_bytes;
+  a.ntiles = cfg.ntiles;
+  a.gws = cfg.gws;
   a.magic_hw = magic_of(cfg.HW);
   a.magic_tw = magic_of(cfg.TW);
   a.magic_cg = magic_of(cfg.cg);
-  a.nblocks = batch * cfg.tiles_x * cfg.tiles_y * cfg.ncb;
+  a.nblocks = cfg.gws * cfg.ncb;
   return cfg.ntaps == 9 ? launch_m<3>(cfg, a, s) : launch_m<1>(cfg, a, s);
 }
 

@@ -18,9 +18,10 @@ __global__ void convert_input_kernel(const T* __restrict__ in, __bf16* __restric
   const int p = (int)(i - (long long)b * HW);
   const T* src = in + (long long)b * 3 * HW + p;
   bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-  v[0] = (__bf16)((float)src[0] * mul);
-  v[1] = (__bf16)((float)src[HW] * mul);
-  v[2] = (__bf16)((float)src[2 * (long long)HW] * mul);
+  // `div` is 255 for uint8 sources: a true fp32 division like `im /= 255` (predictor.py:84)
+  v[0] = (__bf16)((float)src[0] / mul);
+  v[1] = (__bf16)((float)src[HW] / mul);
+  v[2] = (__bf16)((float)src[2 * (long long)HW] / mul);
   *reinterpret_cast<bf16x8*>(out + (long long)b * out_img + (long long)p * pitch) = v;
 }
 
@@ -37,7 +38,7 @@ int convert_input_launch(const void* in, int in_dtype, __bf16* out, int batch, i
                        H * W, out_img, pitch, 1.0f, total);
   else if (in_dtype == YL_U8)
     hipLaunchKernelGGL(convert_input_kernel<uint8_t>, dim3(blocks), dim3(256), 0, s, (const uint8_t*)in, out, H * W,
-                       out_img, pitch, 1.0f / 255.0f, total);
+                       out_img, pitch, 255.0f, total);
   else
     return fail(-3, "convert_input: unsupported input dtype");
   YL_HIP(hipGetLastError());

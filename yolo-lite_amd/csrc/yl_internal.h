@@ -41,14 +41,16 @@ struct ConvArgs {
   int HH, HW;                           // halo dims
   int cch, cg, lg2, nchunks, ksteps, pp;  // chunk channels, groups of 8, log2(pow2>=cg), ...
   int ntaps;
+  int halo_lds_off, halo_bytes;  // LDS: [filter slab][halo buffer(s)]
+  int ntiles, gws;               // pixel tiles in total / blocks per output-channel block
   unsigned magic_hw, magic_tw, magic_cg;  // ceil(2^32 / x) for small-number division
   int nblocks;
 };
 
 struct ConvConfig {
-  int MT, NT, uniform;
+  int MT, NT, uniform, ws;
   int TH, TW, tiles_x, tiles_y, ncb;
-  int HH, HW, cch, cg, lg2, nchunks, ksteps, pp, ntaps;
+  int HH, HW, cch, cg, lg2, nchunks, ksteps, pp, ntaps, halo_lds_off, halo_bytes, ntiles, gws;
   size_t lds_bytes;
   size_t wpk_elems;  // packed weight elements
   const char* name;
