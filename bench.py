@@ -147,8 +147,8 @@ def main():
     specs, sd, eng = build_model(args.scale, dev, B, H, W, x)
 
     def hot_path(im):
-        y = eng.forward(im, graph=True)
-        return hops.nms_padded(y, conf, iou, max_det=max_det)
+        # network (hipGraph replay) + fused Detect decode / candidate filter / NMS, all on-device
+        return eng.detect(im, conf, iou, max_det=max_det, graph=True)
 
     def sync_all():
         torch.cuda.synchronize(dev)

@@ -126,6 +126,15 @@ int yl_nms(const float* pred, int batch, int nc, int anchors, float conf_thres, 
            int max_det, int agnostic, const int32_t* classes, int n_classes, int max_cand,
            float max_wh, const float* scale, float* out, int32_t* out_count, void* work, void* stream);
 
+/* Fused Detect decode + NMS straight from the raw level maps in the workspace: identical results
+ * to yl_detect_decode followed by yl_nms (same decode arithmetic, same candidate order), but
+ * y[B][4+nc][A] (reference head.py:126) is never written or re-read.  `work` must hold
+ * yl_nms_workspace_bytes(B, A, max_cand) bytes with A = sum of level H*W. */
+int yl_decode_nms(const void* workspace, const yl_level* levels, int n_levels, int batch, int nc,
+                  float conf_thres, float iou_thres, int max_det, int agnostic, const int32_t* classes,
+                  int n_classes, int max_cand, float max_wh, const float* scale, float* out,
+                  int32_t* out_count, void* work, void* stream);
+
 /* uint8 HWC BGR letterboxed images -> float NCHW RGB / 255 (engine/predictor.py:77-84). */
 int yl_preprocess_u8(const uint8_t* bgr_hwc, int batch, int h, int w, float* out_nchw, void* stream);
 

@@ -172,5 +172,10 @@ def test_attention_vs_torch(gpu_device, nh, h, w):
     m.op(kind=OP_ATTENTION, name="attn", heads=nh, key_dim=kd, head_dim=hd, scale=float(kd ** -0.5), inp=xin, out=out)
     m.run()
     got = m.read(out)
-    # fp32 math on bf16 inputs, bf16 output; __expf adds ~1e-6 relative
-    _assert_close_bf16(got, ref, "attention")
+    # The kernel rounds the probabilities to bf16 before the P.V MFMA (like any bf16 flash kernel):
+    # each term p_j*v_j carries up to 2^-9 relative error, so the bound scales with sum_j p_j*|v_j|,
+    # plus the bf16 rounding of the output itself.
+    bound = (v.abs() @ attn.transpose(-2, -1)).view(B, nh * hd, h, w)
+    err = (got - ref).abs()
+    tol = 2.0 ** -8 * bound + 2.0 ** -8 * ref.abs() + 1e-3
+    assert not (err > tol).any(), f"attention: max err {float(err.max()):.4g}, worst ratio {float((err / tol).max()):.2f}"

@@ -235,3 +235,25 @@ def match_detections(det, ref, conf_thres, iou_thres, band=SCORE_ATOL, iou_match
             near = max(((_iou(r[:4], d[:4]), float(r[4]), float(r[5])) for r in ref), default=None)
             print("unexplained det", [round(float(v), 3) for v in d], "nearest ref (iou, conf, cls)", near)
     return st
+
+
+@pytest.mark.parametrize("kw", [dict(conf=0.25, iou=0.7), dict(conf=0.25, iou=0.7, classes=[1, 27, 40]),
+                                dict(conf=0.3, iou=0.5, agnostic=True, max_det=10)])
+def test_fused_decode_nms_equals_unfused(gpu_device, golden, kw):
+    """yl_decode_nms (no (B, 84, A) tensor) must reproduce decode -> NMS bit for bit."""
+    sd = synth_state_dict("n", 1, cls_bias=list(golden["net_n_96x128_bias"]), cls_gain=8.0)
+    x = torch.from_numpy(golden["net_n_96x128_x"]).to(gpu_device)
+    eng = _engine("n", sd, 2, 96, 128, gpu_device)
+    y = eng.forward(x)
+    if "classes" in kw:  # filter on classes that actually occur
+        o0, c0 = hops.nms_padded(y, kw["conf"], kw["iou"])
+        kw = dict(kw, classes=sorted({int(v) for v in o0[0, : int(c0[0]), 5].tolist()})[:2] or [0])
+    ref_out, ref_cnt = hops.nms_padded(y, kw["conf"], kw["iou"], classes=kw.get("classes"),
+                                       agnostic=kw.get("agnostic", False), max_det=kw.get("max_det", 300))
+    out, cnt = eng.detect(x, graph=False, **kw)
+    assert torch.equal(cnt, ref_cnt)
+    assert int(cnt.sum()) > 0
+    for i in range(2):
+        assert torch.equal(out[i, : int(cnt[i])], ref_out[i, : int(cnt[i])])
+    out2, cnt2 = eng.detect(x, graph=True, **kw)
+    assert torch.equal(cnt2, cnt) and torch.equal(out2[0, : int(cnt[0])], out[0, : int(cnt[0])])

@@ -47,7 +47,8 @@ def main():
     out, cnt = hops.nms_padded(y, 0.25, 0.7)
     cands = (y[:, 4:].amax(1) > 0.25).sum(1).float()
     print("candidates/img mean", cands.mean().item(), "max", cands.max().item(), "dets/img", cnt.float().mean().item())
-    print("e2e             (gpu ms, wall ms):", timeit(lambda: hops.nms_padded(eng.forward(x, graph=True), 0.25, 0.7)))
+    print("e2e unfused     (gpu ms, wall ms):", timeit(lambda: hops.nms_padded(eng.forward(x, graph=True), 0.25, 0.7)))
+    print("e2e fused detect(gpu ms, wall ms):", timeit(lambda: eng.detect(x, 0.25, 0.7, graph=True)))
     rows = eng.profile(x, iters=20)
     tot = sum(r["ms"] for r in rows)
     print(f"sum of per-op times {tot:.3f} ms over {len(rows)} launches")

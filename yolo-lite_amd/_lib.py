@@ -18,7 +18,8 @@ OP_CONV, OP_DWCONV3, OP_SPPF_POOL, OP_UPSAMPLE, OP_ATTENTION = 1, 2, 3, 4, 5
 EXPORTS = (
     "yl_last_error", "yl_abi_version", "yl_device_count", "yl_engine_create", "yl_engine_destroy",
     "yl_engine_forward", "yl_engine_forward_graph", "yl_engine_profile", "yl_engine_num_ops",
-    "yl_engine_op_info", "yl_detect_decode", "yl_nms_workspace_bytes", "yl_nms", "yl_preprocess_u8",
+    "yl_engine_op_info", "yl_detect_decode", "yl_nms_workspace_bytes", "yl_nms", "yl_decode_nms",
+    "yl_preprocess_u8",
 )
 
 
@@ -99,6 +100,9 @@ def lib() -> C.CDLL:
     L.yl_nms_workspace_bytes.argtypes = [i32, i32, i32]
     L.yl_nms.restype = i32
     L.yl_nms.argtypes = [vp, i32, i32, i32, f32, f32, i32, i32, vp, i32, i32, f32, vp, vp, vp, vp, vp]
+    L.yl_decode_nms.restype = i32
+    L.yl_decode_nms.argtypes = [vp, C.POINTER(Level), i32, i32, i32, f32, f32, i32, i32, vp, i32, i32, f32, vp, vp, vp,
+                                vp, vp]
     L.yl_preprocess_u8.restype = i32
     L.yl_preprocess_u8.argtypes = [vp, i32, i32, i32, vp, vp]
     if L.yl_abi_version() != 1:

@@ -11,13 +11,14 @@
 //   D (16 x 16)  : lane holds 4 consecutive output channels of ONE pixel -> 8-byte NHWC stores.
 // One workgroup = 4 waves; a tile = TH x TW output pixels (4*NT*16) x MT*16 output channels.
 //
-// Two kernels share the k-loop and the epilogue:
-//   conv_ws_kernel   weight-stationary + persistent: the block's whole filter slab is staged into
-//                    LDS once, then the block walks its tiles; the next (tile, channel-chunk) halo
-//                    is prefetched global->registers while the current one is multiplied out of
-//                    LDS (two halo buffers, one barrier per stage).
-//   conv_tile_kernel fallback when the slab does not fit LDS: one tile per block, the filter
-//                    chunk is restaged with every channel chunk.
+// Two kernels share the epilogue:
+//   conv_direct_kernel  the block's whole filter slab is staged into LDS once; activations are
+//                       fetched as MFMA fragments straight from global memory / L1 (no halo
+//                       staging, no barrier in the pixel loop).  Used whenever the slab fits.
+//   conv_tile_kernel    fallback for huge filters: one LDS halo tile per block, the filter chunk
+//                       is restaged with every channel chunk.
+// (A persistent weight-stationary LDS-halo variant was measured slower than both at batch 32 --
+//  one workgroup per CU cannot hide HBM latency -- and was dropped; see DESIGN.md.)
 #include "yl_internal.h"
 
 namespace yl {
@@ -125,54 +126,102 @@ __device__ __forceinline__ void kloop(const ConvArgs& a, const unsigned char* ha
   }
 }
 
-// + bias, SiLU, + residual, store 4 consecutive channels of one pixel.
+// Output-channel order inside a block of MT*16 channels.  The MFMA leaves lane (pixel n, quad g)
+// with rows g*4+r of every 16-row tile; the filter rows are permuted at pack time so that one lane's
+// rows of two adjacent tiles are 8 CONSECUTIVE channels: 16-byte NHWC stores (64 contiguous bytes
+// per pixel per store instruction) instead of 8-byte ones.
+__host__ __device__ inline int chan_in_block(int MT, int mt, int g, int r) {
+  const int even = MT & ~1;
+  return mt < even ? ((((mt >> 1) * 4 + g) * 2 + (mt & 1)) * 4 + r) : (even * 16 + g * 4 + r);
+}
+
+template <int W>
+__device__ __forceinline__ void store_group(const ConvArgs& a, int b, int pix, int co, float (&v)[W]) {
+  // W = 8 or 4 consecutive channels starting at co, all < Cout when `vec` alignment holds
+  const bool vec = ((a.Cout | a.out_pitch | a.out_coff | a.res_pitch | a.res_coff) & (W - 1)) == 0;
+  if (vec) {
+    if (a.res) {
+      const __bf16* rp = a.res + (long long)b * a.res_img + (long long)pix * a.res_pitch + a.res_coff + co;
+      if (W == 8) {
+        const bf16x8 rv = *reinterpret_cast<const bf16x8*>(rp);
+#pragma unroll
+        for (int r = 0; r < W; ++r) v[r] += (float)rv[r];
+      } else {
+        const bf16x4 rv = *reinterpret_cast<const bf16x4*>(rp);
+#pragma unroll
+        for (int r = 0; r < W; ++r) v[r] += (float)rv[r];
+      }
+    }
+    const long long o = (long long)b * a.out_img + (long long)pix * a.out_pitch + a.out_coff + co;
+    if (a.out_f32) {
+      float* op = reinterpret_cast<float*>(a.out) + o;
+#pragma unroll
+      for (int q = 0; q < W; q += 4) *reinterpret_cast<f32x4*>(op + q) = f32x4{v[q], v[q + 1], v[q + 2], v[q + 3]};
+    } else {
+      __bf16* op = reinterpret_cast<__bf16*>(a.out) + o;
+      if (W == 8) {
+        bf16x8 t;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t[r] = (__bf16)v[r];
+        *reinterpret_cast<bf16x8*>(op) = t;
+      } else {
+        *reinterpret_cast<bf16x4*>(op) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+      }
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < W; ++r) {
+      if (co + r >= a.Cout) continue;
+      float x = v[r];
+      if (a.res) x += (float)a.res[(long long)b * a.res_img + (long long)pix * a.res_pitch + a.res_coff + co + r];
+      const long long o = (long long)b * a.out_img + (long long)pix * a.out_pitch + a.out_coff + co + r;
+      if (a.out_f32)
+        reinterpret_cast<float*>(a.out)[o] = x;
+      else
+        reinterpret_cast<__bf16*>(a.out)[o] = (__bf16)x;
+    }
+  }
+}
+
+// + bias, SiLU, + residual, NHWC store.
 template <int MT, int NT>
 __device__ __forceinline__ void epilogue(const ConvArgs& a, int cb, int b, int g, const int (&opix)[NT],
                                          const f32x4 (&acc)[MT][NT]) {
-  const bool vec = ((a.Cout | a.out_pitch | a.out_coff | a.res_pitch | a.res_coff) & 3) == 0;
+  const int cbase = cb * MT * 16;
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int co = (cb * MT + mt) * 16 + g * 4;
+  for (int p = 0; p < MT / 2; ++p) {
+    const int co = cbase + (p * 4 + g) * 8;
     if (co >= a.Cout) continue;
-    const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + co);
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias + co);
+    const f32x4 b1 = *reinterpret_cast<const f32x4*>(a.bias + co + 4);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       if (opix[nt] < 0) continue;
-      float v[4];
+      float v[8];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float x = acc[mt][nt][r] + bv[r];
-        v[r] = a.act ? silu_f(x) : x;
+        const float x0 = acc[2 * p][nt][r] + b0[r], x1 = acc[2 * p + 1][nt][r] + b1[r];
+        v[r] = a.act ? silu_f(x0) : x0;
+        v[4 + r] = a.act ? silu_f(x1) : x1;
       }
-      if (vec) {
-        if (a.res) {
-          const bf16x4 rv = *reinterpret_cast<const bf16x4*>(
-              a.res + (long long)b * a.res_img + (long long)opix[nt] * a.res_pitch + a.res_coff + co);
+      store_group<8>(a, b, opix[nt], co, v);
+    }
+  }
+  if (MT & 1) {
+    constexpr int mt = MT - 1;
+    const int co = cbase + (MT & ~1) * 16 + g * 4;
+    if (co < a.Cout) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + co);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
-        }
-        if (a.out_f32) {
-          float* op = reinterpret_cast<float*>(a.out) + (long long)b * a.out_img +
-                      (long long)opix[nt] * a.out_pitch + a.out_coff + co;
-          *reinterpret_cast<f32x4*>(op) = f32x4{v[0], v[1], v[2], v[3]};
-        } else {
-          __bf16* op = reinterpret_cast<__bf16*>(a.out) + (long long)b * a.out_img +
-                       (long long)opix[nt] * a.out_pitch + a.out_coff + co;
-          *reinterpret_cast<bf16x4*>(op) = bf16x4{(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
-        }
-      } else {
+      for (int nt = 0; nt < NT; ++nt) {
+        if (opix[nt] < 0) continue;
+        float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          if (co + r >= a.Cout) continue;
-          float x = v[r];
-          if (a.res)
-            x += (float)a.res[(long long)b * a.res_img + (long long)opix[nt] * a.res_pitch + a.res_coff + co + r];
-          const long long o = (long long)b * a.out_img + (long long)opix[nt] * a.out_pitch + a.out_coff + co + r;
-          if (a.out_f32)
-            reinterpret_cast<float*>(a.out)[o] = x;
-          else
-            reinterpret_cast<__bf16*>(a.out)[o] = (__bf16)x;
+          const float x = acc[mt][nt][r] + bv[r];
+          v[r] = a.act ? silu_f(x) : x;
         }
+        store_group<4>(a, b, opix[nt], co, v);
       }
     }
   }
@@ -198,74 +247,121 @@ __device__ __forceinline__ TilePos tile_pos(const ConvArgs& a, int t) {
   return p;
 }
 
-// ------------------------------------------------------------ weight-stationary persistent kernel
-template <int KS, int MT, int NT, bool UNIFORM>
-__global__ __launch_bounds__(256) void conv_ws_kernel(ConvArgs a) {
+// ------------------------------------------------------------------ direct (LDS-free activations)
+// Every wave owns a 2*NT x 8 pixel patch and MT*16 output channels.  Its B fragments (activations)
+// come straight from global memory / L1 -- 16 contiguous bytes per lane, the tap shift is just an
+// address offset and the zero padding a per-lane predicate -- so there is no halo staging, no
+// barrier in the pixel loop and many independent loads in flight per wave.  Only the block's
+// filter slab lives in LDS (staged once, fragment order, conflict-free reads).  K = (tap, cin)
+// flattened; the next k-step's operands are fetched while the current one is multiplied.
+template <int KS, int NT>
+__device__ __forceinline__ void fetch_b(const ConvArgs& a, const __bf16* img, int ks, int g, const int (&base)[NT],
+                                        const unsigned (&mask)[NT], bf16x8 (&xb)[NT]) {
+  const int k8 = ks * 4 + g;
+  const int tap = KS == 1 ? 0 : fastdiv(k8, a.cg, a.magic_cg);
+  const int c8 = k8 - tap * a.cg;
+  const bool kvalid = KS == 1 ? (k8 < a.cg) : (tap < KS * KS);
+  const int kh = (tap * 11) >> 5;
+  const int dy = KS == 1 ? 0 : kh - 1, dx = KS == 1 ? 0 : tap - 3 * kh - 1;
+  const int off = (dy * a.W + dx) * a.in_pitch + c8 * 8;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (kvalid && ((mask[nt] >> tap) & 1u)) v = *reinterpret_cast<const bf16x8*>(img + base[nt] + off);
+    xb[nt] = v;
+  }
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void mma_step(const bf16x8 (&wa)[MT], const bf16x8 (&xb)[NT], f32x4 (&acc)[MT][NT]) {
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[mt], xb[nt], acc[mt][nt], 0, 0, 0);
+}
+
+template <int KS, int MT, int NT>
+__global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, n = lane & 15;
   const int bid = xcd_remap(blockIdx.x, a.nblocks);
   const int cb = bid % a.ncb;
-  const int slot = bid / a.ncb;  // this block walks tiles slot, slot + gws, ...
-  const int ntiles = a.ntiles;
-  const int mine = (ntiles - slot + a.gws - 1) / a.gws;
-  if (mine <= 0) return;
-  const int nitems = mine * a.nchunks;
-
-  const int HP = a.HH * a.HW;
-  const int ppass = 256 >> a.lg2;
-  const int sg = tid & ((1 << a.lg2) - 1), sp0 = tid >> a.lg2;
-  unsigned char* hbuf[2] = {smem + a.halo_lds_off, smem + a.halo_lds_off + a.halo_bytes};
-  const bf16x8* wl = reinterpret_cast<const bf16x8*>(smem) + lane;
-  const int wstride = a.ksteps * MT * 64;  // bf16x8 units per chunk
-
-  bf16x8 pre[MAXPRE];
-  // ---- prologue: first halo stage in flight, whole filter slab -> LDS, then publish both
-  TilePos cur = tile_pos(a, slot);
+  const int pblk = bid / a.ncb;
   {
-    const __bf16* src = a.in + (long long)cur.b * a.in_img + a.in_coff;
-    stage_load(a, src, cur.oy0 * a.stride - a.pad, cur.ox0 * a.stride - a.pad, sg, sp0, ppass, HP, pre);
-    const bf16x8* wsrc = reinterpret_cast<const bf16x8*>(a.wpk) + (size_t)cb * a.nchunks * wstride;
+    const bf16x8* wsrc = reinterpret_cast<const bf16x8*>(a.wpk) + (size_t)cb * a.ksteps * MT * 64;
     bf16x8* wdst = reinterpret_cast<bf16x8*>(smem);
-    const int nw = a.nchunks * wstride;
+    const int nw = a.ksteps * MT * 64;
     for (int i = tid; i < nw; i += 256) wdst[i] = wsrc[i];
-    stage_store(a, hbuf[0], sg, sp0, ppass, HP, pre);
   }
   __syncthreads();
+  const bf16x8* wl = reinterpret_cast<const bf16x8*>(smem) + lane;
+  constexpr int PH = 2 * NT;  // patch = PH x 8 pixels
 
-  int pixoff[NT], opix[NT];
-  f32x4 acc[MT][NT];
-  int chunk = 0, tcount = 0;
-  TilePos nxt = cur;
-  for (int it = 0; it < nitems; ++it) {
-    if (chunk == 0) {
-      lane_pixels<NT>(a, wave, n, cur.oy0, cur.ox0, pixoff, opix);
+  for (int pp = 0; pp < a.ppw; ++pp) {
+    int patch = (pblk * a.ppw + pp) * 4 + wave;
+    if (patch >= a.npatches) break;
+    const int px_i = patch % a.tiles_x;
+    patch /= a.tiles_x;
+    const int py_i = patch % a.tiles_y;
+    const int b = patch / a.tiles_y;
+    const int oy0 = py_i * PH, ox0 = px_i * 8;
+    const __bf16* img = a.in + (long long)b * a.in_img + a.in_coff;
+
+    int base[NT], opix[NT];
+    unsigned mask[NT];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+    for (int nt = 0; nt < NT; ++nt) {
+      const int idx = nt * 16 + n;
+      const int oy = oy0 + (idx >> 3), ox = ox0 + (idx & 7);
+      const bool valid = oy < a.Ho && ox < a.Wo;
+      const int cy = oy * a.stride, cx = ox * a.stride;
+      base[nt] = (cy * a.W + cx) * a.in_pitch;
+      unsigned m = 0;
+      if (valid) {
+        if (KS == 1) {
+          m = 1u;
+        } else {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+          for (int t = 0; t < 9; ++t) {
+            const int iy = cy + t / 3 - 1, ix = cx + t % 3 - 1;
+            if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) m |= 1u << t;
+          }
+        }
+      }
+      mask[nt] = m;
+      opix[nt] = valid ? oy * a.Wo + ox : -1;
     }
-    // ---- prefetch the next (tile, chunk) halo into registers
-    const bool more = it + 1 < nitems;
-    int nchunk = chunk + 1;
-    if (nchunk == a.nchunks) {
-      nchunk = 0;
-      if (more) nxt = tile_pos(a, slot + (tcount + 1) * a.gws);
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    bf16x8 x0[NT], x1[NT], w0[MT], w1[MT];
+    fetch_b<KS, NT>(a, img, 0, g, base, mask, x0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) w0[mt] = wl[mt * 64];
+    for (int ks = 0; ks < a.ksteps; ks += 2) {
+      const bool has1 = ks + 1 < a.ksteps;
+      if (has1) {
+        fetch_b<KS, NT>(a, img, ks + 1, g, base, mask, x1);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) w1[mt] = wl[((ks + 1) * MT + mt) * 64];
+      }
+      mma_step<MT, NT>(w0, x0, acc);
+      if (has1) {
+        if (ks + 2 < a.ksteps) {
+          fetch_b<KS, NT>(a, img, ks + 2, g, base, mask, x0);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) w0[mt] = wl[((ks + 2) * MT + mt) * 64];
+        }
+        mma_step<MT, NT>(w1, x1, acc);
+      }
     }
-    if (more) {
-      const __bf16* src = a.in + (long long)nxt.b * a.in_img + a.in_coff + nchunk * a.cch;
-      stage_load(a, src, nxt.oy0 * a.stride - a.pad, nxt.ox0 * a.stride - a.pad, sg, sp0, ppass, HP, pre);
-    }
-    // ---- multiply the current stage out of LDS
-    kloop<KS, MT, NT, UNIFORM>(a, hbuf[it & 1], wl + (size_t)chunk * wstride, g, pixoff, acc);
-    if (chunk == a.nchunks - 1) epilogue<MT, NT>(a, cb, cur.b, g, opix, acc);
-    if (more) stage_store(a, hbuf[(it + 1) & 1], sg, sp0, ppass, HP, pre);
-    __syncthreads();
-    if (nchunk == 0) {
-      cur = nxt;
-      ++tcount;
-    }
-    chunk = nchunk;
+    epilogue<MT, NT>(a, cb, b, g, opix, acc);
   }
 }
 
@@ -342,8 +438,56 @@ int conv_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo,
   if (cout16 % 2 == 0) mts[nmt++] = 2;
   mts[nmt++] = 1;
 
-  // mode 1: weight-stationary (slab of all chunks <= W_STATIONARY_MAX), mode 0: per-chunk restaging
-  for (int ws = 1; ws >= 0; --ws) {
+  // ---- preferred: direct kernel (activations straight from global/L1, filter slab in LDS)
+  {
+    static const char* env = getenv("YL_CONV_MODE");  // "tile" forces the LDS-halo kernel (A/B tests)
+    const size_t slab_max = getenv("YL_CONV_SLAB_KB") ? (size_t)atoi(getenv("YL_CONV_SLAB_KB")) * 1024 : 72 * 1024;
+    const int cg = Cin / 8;
+    const int ksteps = (ntaps * cg + 3) / 4;
+    for (int mi = 0; mi < nmt && !(env && !strcmp(env, "tile")); ++mi) {
+      const int MT = mts[mi];
+      if ((size_t)ksteps * MT * 1024 > slab_max) continue;
+      const int ncb = cout16 / MT;
+      auto npatches = [&](int nt) { return (long long)batch * ((Ho + 2 * nt - 1) / (2 * nt)) * ((Wo + 7) / 8); };
+      int NT = 1;
+      if (npatches(4) * ncb / 4 >= 4 * NUM_CU) NT = 4;
+      else if (npatches(2) * ncb / 4 >= 2 * NUM_CU) NT = 2;
+      if (MT == 5 && NT == 4) NT = 2;
+      c->ws = 2;  // direct
+      c->MT = MT;
+      c->ncb = ncb;
+      c->NT = NT;
+      c->TH = 2 * NT;
+      c->TW = 8;
+      c->HH = c->HW = 0;
+      c->tiles_x = (Wo + 7) / 8;
+      c->tiles_y = (Ho + 2 * NT - 1) / (2 * NT);
+      c->cch = Cin;
+      c->cg = cg;
+      c->lg2 = 0;
+      c->nchunks = 1;
+      c->uniform = 0;
+      c->ksteps = ksteps;
+      c->pp = 0;
+      c->halo_bytes = 0;
+      c->halo_lds_off = 0;
+      c->lds_bytes = (size_t)ksteps * MT * 1024;
+      c->wpk_elems = (size_t)ncb * ksteps * MT * 64 * 8;
+      c->ntiles = (int)npatches(NT);
+      // patches per wave: amortise the slab load while keeping >= ~8 blocks per CU in the grid
+      long long blocks1 = ((long long)c->ntiles + 3) / 4 * ncb;
+      int ppw = (int)(blocks1 / (8 * NUM_CU));
+      if (ppw < 1) ppw = 1;
+      if (ppw > 8) ppw = 8;
+      c->ppw = ppw;
+      c->gws = (int)(((long long)c->ntiles + 4 * ppw - 1) / (4 * ppw));
+      c->name = k == 3 ? (stride == 2 ? "conv3x3s2_mfma" : "conv3x3_mfma") : "conv1x1_mfma";
+      return 0;
+    }
+  }
+
+  // ---- fallback: LDS-halo tile kernel with per-chunk filter restaging
+  for (int ws = 0; ws >= 0; --ws) {
     for (int mi = 0; mi < nmt; ++mi) {
       const int MT = mts[mi];
       const int ncb = cout16 / MT;
@@ -440,7 +584,7 @@ void conv_pack_weights(const float* w, int Cout, int Cin_w, int Cin_pad, int k, 
       for (int ks = 0; ks < c.ksteps; ++ks)
         for (int mt = 0; mt < c.MT; ++mt)
           for (int lane = 0; lane < 64; ++lane) {
-            const int co = (cb * c.MT + mt) * 16 + (lane & 15);
+            const int co = cb * c.MT * 16 + chan_in_block(c.MT, mt, (lane & 15) >> 2, lane & 3);
             const int k8 = ks * 4 + (lane >> 4);
             const int tap = k8 / c.cg, c8 = k8 % c.cg;
             for (int j = 0; j < 8; ++j, ++o) {
@@ -455,8 +599,9 @@ void conv_pack_weights(const float* w, int Cout, int Cin_w, int Cin_pad, int k, 
 
 template <int KS, int MT, int NT, bool U>
 static int launch_t(const ConvConfig& cfg, const ConvArgs& a, hipStream_t s) {
-  if (cfg.ws) {
-    auto kern = conv_ws_kernel<KS, MT, NT, U>;
+  if (cfg.ws == 2) {
+    if (U) return fail(-3, "conv: direct kernel has no uniform variant");
+    auto kern = conv_direct_kernel<KS, MT, NT>;
     static size_t attr = 0;  // per instantiation: largest dynamic LDS size enabled so far
     if (cfg.lds_bytes > attr) {
       YL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -519,6 +664,8 @@ int conv_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s) {
   a.halo_lds_off = cfg.halo_lds_off;
   a.halo_bytes = cfg.halo_bytes;
   a.ntiles = cfg.ntiles;
+  a.npatches = cfg.ntiles;
+  a.ppw = cfg.ppw;
   a.gws = cfg.gws;
   a.magic_hw = magic_of(cfg.HW);
   a.magic_tw = magic_of(cfg.TW);

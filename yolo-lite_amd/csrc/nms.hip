@@ -23,6 +23,7 @@ struct NmsWs {
   float* conf;          // [B][M]
   int32_t* cls;         // [B][M]
   unsigned long long* mask;  // [B][M][MW]
+  float4* cbox;         // [B][A] (cx, cy, w, h) of candidate anchors (fused decode path only)
   int KP, M, MW;
 };
 
@@ -45,8 +46,10 @@ static int64_t nms_layout(int B, int A, int max_cand, char* base, NmsWs* w) {
   };
   const int64_t o_count = take(4LL * B), o_nf = take(4LL * B), o_keys = take(8LL * B * KP),
                 o_clsof = take(4LL * B * A), o_boff = take(16LL * B * M), o_braw = take(16LL * B * M),
-                o_conf = take(4LL * B * M), o_cls = take(4LL * B * M), o_mask = take(8LL * B * M * MW);
+                o_conf = take(4LL * B * M), o_cls = take(4LL * B * M), o_mask = take(8LL * B * M * MW),
+                o_cbox = take(16LL * B * A);
   if (w) {
+    w->cbox = (float4*)(base + o_cbox);
     w->count = (int32_t*)(base + o_count);
     w->nfinal = (int32_t*)(base + o_nf);
     w->keys = (unsigned long long*)(base + o_keys);
@@ -132,13 +135,19 @@ __global__ __launch_bounds__(1024) void nms_sort_kernel(const float* __restrict_
   if (n > 1) bitonic_sort(k, np, tid, 1024);
   const int nf = n < w.M ? n : w.M;  // keep the top max_cand by score (ops.py:254-255)
   if (tid == 0) w.nfinal[b] = nf;
-  const float* pb = pred + (long long)b * (4 + nc) * A;
+  const float* pb = pred ? pred + (long long)b * (4 + nc) * A : nullptr;
   for (int i = tid; i < nf; i += 1024) {
     const unsigned long long key = k[i];
     const int a = (int)(key & 0xffffffffu);
     const float score = __uint_as_float(~(unsigned)(key >> 32));
     const int cls = w.cls_of[(long long)b * A + a];
-    const float cx = pb[a], cy = pb[A + a], bw = pb[2LL * A + a], bh = pb[3LL * A + a];
+    float cx, cy, bw, bh;
+    if (pb) {
+      cx = pb[a], cy = pb[A + a], bw = pb[2LL * A + a], bh = pb[3LL * A + a];
+    } else {
+      const float4 t = w.cbox[(long long)b * A + a];
+      cx = t.x, cy = t.y, bw = t.z, bh = t.w;
+    }
     const float hw = __fdiv_rn(bw, 2.0f), hh = __fdiv_rn(bh, 2.0f);  // ops.py:386
     const float x1 = __fsub_rn(cx, hw), y1 = __fsub_rn(cy, hh), x2 = __fadd_rn(cx, hw), y2 = __fadd_rn(cy, hh);
     const float c = __fmul_rn((float)cls, agnostic ? 0.0f : max_wh);  // ops.py:258
@@ -288,6 +297,154 @@ extern "C" int yl_nms(const float* pred, int batch, int nc, int anchors, float c
   hipLaunchKernelGGL(nms_candidates_kernel, dim3((anchors + 255) / 256, batch), dim3(256), 0, s, pred, nc, anchors,
                      conf_thres, classes, classes ? n_classes : 0, w);
   hipLaunchKernelGGL(nms_sort_kernel, dim3(batch), dim3(1024), 0, s, pred, nc, anchors, agnostic, max_wh, w);
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(64, batch), dim3(256), 0, s, iou_thres, w);
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(batch), dim3(64), 0, s, max_det, scale, out, out_count, w);
+  YL_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---------------------------------------------------------------- fused Detect decode + candidates
+// Same arithmetic as decode_kernel (shared device functions), but instead of materialising
+// y[B][4+nc][A] (reference head.py:126, 90 MB at batch 32) only the anchors whose best class score
+// clears the threshold are kept: key + class + (cx, cy, w, h).  One workgroup = 64 anchors.
+namespace yl {
+constexpr int DC_ANCH = 64;
+struct DecCandArgs {
+  DecodeLevel lv[8];
+  int blk0[9];
+  int n_levels, batch, nc, A;
+  float conf_thres;
+  const int32_t* classes;
+  int n_classes;
+};
+
+__global__ __launch_bounds__(256) void decode_candidates_kernel(DecCandArgs a, NmsWs w) {
+  extern __shared__ __attribute__((aligned(16))) float sraw[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nb_img = a.blk0[a.n_levels];
+  const int b = blockIdx.x / nb_img;
+  const int k = blockIdx.x - b * nb_img;
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < 8; ++i)
+    if (i < a.n_levels && k >= a.blk0[i]) l = i;
+  const DecodeLevel L = a.lv[l];
+  const int HW = L.H * L.W;
+  const int p0 = (k - a.blk0[l]) * DC_ANCH;
+  const int nv = min(DC_ANCH, HW - p0);
+  const int no = 64 + a.nc, pitch = no + 1;
+  float* sdist = sraw + DC_ANCH * pitch;       // [4][64]
+  float* sbest = sdist + 4 * DC_ANCH;          // [4][64] best score per wave
+  int* sbidx = reinterpret_cast<int*>(sbest + 4 * DC_ANCH);  // [4][64]
+  const float* raw = L.raw + ((long long)b * HW + p0) * no;
+  if ((no & 3) == 0) {  // the chunk is one contiguous run: 16-byte loads
+    const int n4 = nv * no / 4;
+    for (int i = tid; i < n4; i += 256) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(raw + 4LL * i);
+      const int e = 4 * i, r = e / no, c = e - r * no;
+      float* d = sraw + r * pitch + c;
+      d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+    }
+  } else {
+    for (int r = wave; r < nv; r += 4)
+      for (int c = lane; c < no; c += 64) sraw[r * pitch + c] = raw[(long long)r * no + c];
+  }
+  __syncthreads();
+  float dist = 0.f;
+  if (lane < nv) dist = dfl_expect(sraw + lane * pitch + wave * 16);
+  sdist[wave * DC_ANCH + lane] = dist;
+  // best class among c = wave, wave + 4, ...: strict '>' keeps the first maximum (ops.py:243)
+  float best = -1.f;
+  int bi = 0x7fffffff;
+  if (lane < nv)
+    for (int c = wave; c < a.nc; c += 4) {
+      const float sc = sigmoid_score(sraw[lane * pitch + 64 + c]);
+      if (sc > best) {
+        best = sc;
+        bi = c;
+      }
+    }
+  sbest[wave * DC_ANCH + lane] = best;
+  sbidx[wave * DC_ANCH + lane] = bi;
+  __syncthreads();
+  if (wave == 0 && lane < nv) {
+#pragma unroll
+    for (int q = 1; q < 4; ++q) {
+      const float s2 = sbest[q * DC_ANCH + lane];
+      const int i2 = sbidx[q * DC_ANCH + lane];
+      if (s2 > best || (s2 == best && i2 < bi)) {
+        best = s2;
+        bi = i2;
+      }
+    }
+    bool keep = best > a.conf_thres;
+    if (keep && a.classes) {
+      bool ok = false;
+      for (int i = 0; i < a.n_classes; ++i) ok |= (a.classes[i] == bi);
+      keep = ok;
+    }
+    if (keep) {
+      const int p = p0 + lane, an = L.a0 + p;
+      const float ax = (float)(p % L.W) + 0.5f, ay = (float)(p / L.W) + 0.5f;
+      const float4 bx = box_xywh(ax, ay, sdist[lane], sdist[DC_ANCH + lane], sdist[2 * DC_ANCH + lane],
+                                 sdist[3 * DC_ANCH + lane], L.stride);
+      const int slot = atomicAdd(&w.count[b], 1);
+      w.keys[(long long)b * w.KP + slot] = ((unsigned long long)(~__float_as_uint(best)) << 32) | (unsigned)an;
+      w.cls_of[(long long)b * a.A + an] = bi;
+      w.cbox[(long long)b * a.A + an] = bx;
+    }
+  }
+}
+}  // namespace yl
+
+extern "C" int yl_decode_nms(const void* workspace, const yl_level* levels, int n_levels, int batch, int nc,
+                             float conf_thres, float iou_thres, int max_det, int agnostic, const int32_t* classes,
+                             int n_classes, int max_cand, float max_wh, const float* scale, float* out,
+                             int32_t* out_count, void* work, void* stream) {
+  if (!workspace || !levels || !out || !out_count || !work) return fail(-1, "yl_decode_nms: null pointer");
+  if (batch <= 0 || nc <= 0 || n_levels <= 0 || n_levels > 8 || max_det <= 0 || max_cand <= 0)
+    return fail(-1, "yl_decode_nms: bad sizes");
+  if (!(conf_thres >= 0.f && conf_thres <= 1.f) || !(iou_thres >= 0.f && iou_thres <= 1.f))
+    return fail(-4, "yl_decode_nms: thresholds must lie in [0, 1]");
+  DecCandArgs a;
+  int nb = 0, A = 0;
+  for (int i = 0; i < n_levels; ++i) {
+    a.lv[i].raw = reinterpret_cast<const float*>((const char*)workspace + levels[i].offset);
+    a.lv[i].H = levels[i].H;
+    a.lv[i].W = levels[i].W;
+    a.lv[i].a0 = A;
+    a.lv[i].stride = levels[i].stride;
+    a.blk0[i] = nb;
+    nb += (levels[i].H * levels[i].W + DC_ANCH - 1) / DC_ANCH;
+    A += levels[i].H * levels[i].W;
+  }
+  for (int i = n_levels; i < 8; ++i) {
+    a.lv[i] = DecodeLevel{nullptr, 0, 0, 1 << 30, 0.f};
+    a.blk0[i] = 1 << 30;
+  }
+  a.blk0[n_levels] = nb;
+  a.n_levels = n_levels;
+  a.batch = batch;
+  a.nc = nc;
+  a.A = A;
+  a.conf_thres = conf_thres;
+  a.classes = classes;
+  a.n_classes = classes ? n_classes : 0;
+  NmsWs w;
+  nms_layout(batch, A, max_cand, (char*)work, &w);
+  if (w.M > 64 * 64 * SCAN_T) return fail(-3, "yl_decode_nms: max_cand above 32768 is not supported");
+  const size_t lds = ((size_t)DC_ANCH * (64 + nc + 1) + 12 * DC_ANCH) * sizeof(float);
+  if (lds > 150 * 1024) return fail(-3, "yl_decode_nms: nc too large");
+  static size_t attr = 0;
+  if (lds > attr) {
+    YL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decode_candidates_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr = 160 * 1024;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  YL_HIP(hipMemsetAsync(w.count, 0, 4 * (size_t)batch, s));
+  hipLaunchKernelGGL(decode_candidates_kernel, dim3(batch * nb), dim3(256), lds, s, a, w);
+  hipLaunchKernelGGL(nms_sort_kernel, dim3(batch), dim3(1024), 0, s, (const float*)nullptr, nc, A, agnostic, max_wh, w);
   hipLaunchKernelGGL(nms_mask_kernel, dim3(64, batch), dim3(256), 0, s, iou_thres, w);
   hipLaunchKernelGGL(nms_scan_kernel, dim3(batch), dim3(64), 0, s, max_det, scale, out, out_count, w);
   YL_HIP(hipGetLastError());

@@ -158,10 +158,81 @@ __global__ void sppf_pool_kernel(PoolArgs a) {
   *reinterpret_cast<bf16x8*>(op + 3 * a.C) = o13;
 }
 
+// LDS version: one workgroup = one image x 8 channels; the H x W map is staged once (16 bytes per
+// pixel), row maxima for the 5/9/13 windows are built from it, then column maxima of those.
+// 13 + 27 LDS reads per pixel instead of 169 global loads.
+__device__ __forceinline__ bf16x8 max8(bf16x8 a, bf16x8 b) {
+  bf16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (float)a[j] > (float)b[j] ? a[j] : b[j];
+  return o;
+}
+
+__global__ __launch_bounds__(256) void sppf_pool_lds_kernel(PoolArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
+  const int HW = a.H * a.W;
+  bf16x8* sx = reinterpret_cast<bf16x8*>(psm);  // [HW] input
+  bf16x8* sh = sx + HW;                         // [3][HW] horizontal maxima
+  const int cg = a.C >> 3;
+  const int b = blockIdx.x / cg, g8 = blockIdx.x % cg;
+  const __bf16* inb = a.in + (long long)b * a.img + a.coff + g8 * 8;
+  for (int p = threadIdx.x; p < HW; p += 256) sx[p] = *reinterpret_cast<const bf16x8*>(inb + (long long)p * a.pitch);
+  __syncthreads();
+  for (int p = threadIdx.x; p < HW; p += 256) {
+    const int y = p / a.W, x = p - y * a.W;
+    bf16x8 m = sx[p];
+    bf16x8 m5 = m, m9 = m, m13 = m;
+#pragma unroll
+    for (int d = 1; d <= 6; ++d) {
+      bf16x8 t = m;
+      if (x - d >= 0) t = max8(t, sx[p - d]);
+      if (x + d < a.W) t = max8(t, sx[p + d]);
+      m13 = max8(m13, t);
+      if (d <= 4) m9 = max8(m9, t);
+      if (d <= 2) m5 = max8(m5, t);
+    }
+    sh[p] = m5;
+    sh[HW + p] = m9;
+    sh[2 * HW + p] = m13;
+  }
+  __syncthreads();
+  __bf16* ob = a.out + (long long)b * a.img + a.coff + g8 * 8;
+  for (int p = threadIdx.x; p < HW; p += 256) {
+    const int y = p / a.W;
+    bf16x8 o[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int r = 2 + 2 * k;
+      const bf16x8* hk = sh + k * HW;
+      bf16x8 m = hk[p];
+      for (int d = 1; d <= r; ++d) {
+        if (y - d >= 0) m = max8(m, hk[p - d * a.W]);
+        if (y + d < a.H) m = max8(m, hk[p + d * a.W]);
+      }
+      o[k] = m;
+    }
+    __bf16* op = ob + (long long)p * a.pitch;
+    *reinterpret_cast<bf16x8*>(op + a.C) = o[0];
+    *reinterpret_cast<bf16x8*>(op + 2 * a.C) = o[1];
+    *reinterpret_cast<bf16x8*>(op + 3 * a.C) = o[2];
+  }
+}
+
 int sppf_pool_launch(const PoolArgs& a, hipStream_t s) {
   if (a.C % 8 || a.pitch % 8 || a.coff % 8) return fail(-3, "sppf_pool: channels must be multiples of 8");
-  const long long total = (long long)a.batch * a.H * a.W * (a.C / 8);
-  hipLaunchKernelGGL(sppf_pool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+  const size_t lds = (size_t)a.H * a.W * 16 * 4;
+  if (lds <= 150 * 1024) {
+    static size_t attr = 0;
+    if (lds > attr) {
+      YL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sppf_pool_lds_kernel),
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr = 160 * 1024;
+    }
+    hipLaunchKernelGGL(sppf_pool_lds_kernel, dim3(a.batch * (a.C / 8)), dim3(256), lds, s, a);
+  } else {
+    const long long total = (long long)a.batch * a.H * a.W * (a.C / 8);
+    hipLaunchKernelGGL(sppf_pool_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+  }
   YL_HIP(hipGetLastError());
   return 0;
 }
@@ -199,126 +270,142 @@ int upsample_launch(const UpArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------------------- attention
 // nn/modules/block.py:905-912: per head, attn = softmax((q^T k) * scale) over keys;
 // out[:, i] = sum_j v[:, j] * attn[i, j].  qkv channel layout per head: [q(32) | k(32) | v(64)].
-// One workgroup = 64 queries of one (image, head); 4 waves split the keys (online softmax each)
-// and are merged through LDS.  K/V rows are read as LDS broadcasts.  fp32 VALU (about 1 % of the
-// network's MACs); the MFMA version is future work.
-constexpr int AT_KD = 32, AT_HD = 64, AT_KT = 256;  // key tile staged per pass
+//
+// MFMA flash-style kernel (v_mfma_f32_16x16x32_bf16), one workgroup per (image, head, query half):
+//   S^T tile  = K_tile (16 keys x 32) . Q^T (32 x 16 queries)   -> lane holds 4 keys of ITS query
+//   O^T tile += V^T (16 d x 32 keys) . P^T (32 keys x 16 queries)
+// The S^T accumulators of two 16-key tiles are, after exp(), exactly the B fragment of the second
+// product when MFMA k-slot 8g+j is read as key (j<4 ? 4g+j : 16+4g+j-4); V^T is staged in LDS with
+// the keys contiguous so the matching A fragment is two 8-byte LDS reads.  Online softmax per
+// query column: the running max is shared by the 4 lanes of a column through two shuffles.
+constexpr int AT_KD = 32, AT_HD = 64;
+constexpr int AT_STAGE = 512;          // keys resident in LDS at a time
+constexpr int AT_KP = AT_KD + 8;       // K row pitch (elements): 80-byte rows
+constexpr int AT_VP = AT_STAGE + 8;    // V^T row pitch (elements)
+constexpr int AT_QSPLIT = 2;           // workgroups per (image, head)
 
 __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) __bf16 sk[AT_KT * AT_KD];
-  __shared__ __attribute__((aligned(16))) __bf16 sv[AT_KT * AT_HD];
-  __shared__ float sm[4][64], sl[4][64];
-  const int tid = threadIdx.x, lane = tid & 63, part = tid >> 6;
-  const int qblocks = (a.N + 63) / 64;
+  extern __shared__ __attribute__((aligned(16))) unsigned char asm_[];
+  __bf16* sK = reinterpret_cast<__bf16*>(asm_);   // [AT_STAGE][AT_KP]
+  __bf16* sVt = sK + AT_STAGE * AT_KP;            // [64][AT_VP]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, n = lane & 15;
   int bid = blockIdx.x;
-  const int qb = bid % qblocks;
-  bid /= qblocks;
+  const int qs = bid % AT_QSPLIT;
+  bid /= AT_QSPLIT;
   const int head = bid % a.heads;
   const int b = bid / a.heads;
   const int hstride = 2 * AT_KD + AT_HD;
   const __bf16* base = a.qkv + (long long)b * a.in_img + a.in_coff + head * hstride;
-  const int q = qb * 64 + lane;
-  const bool qv = q < a.N;
-  float qr[AT_KD];
-  {
-    const __bf16* qp = base + (long long)(qv ? q : 0) * a.in_pitch;
-#pragma unroll
-    for (int c = 0; c < AT_KD; c += 8) {
-      const bf16x8 v = *reinterpret_cast<const bf16x8*>(qp + c);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) qr[c + j] = (float)v[j] * a.scale;
-    }
-  }
-  float m = -__builtin_huge_valf(), l = 0.f;
-  float acc[AT_HD];
-#pragma unroll
-  for (int d = 0; d < AT_HD; ++d) acc[d] = 0.f;
+  const int nqt = (a.N + 15) / 16;                       // query tiles
+  const int nstage = (a.N + AT_STAGE - 1) / AT_STAGE;
+  const int wslot = qs * 4 + wave;                       // this wave takes q tiles wslot, wslot + 8, ...
+  const int rounds = (nqt + 4 * AT_QSPLIT - 1) / (4 * AT_QSPLIT);
+  const float ninf = -__builtin_huge_valf();
 
-  for (int k0 = 0; k0 < a.N; k0 += AT_KT) {
-    const int kn = min(AT_KT, a.N - k0);
-    __syncthreads();
-    // stage K [kn][32] and V [kn][64]
-    for (int i = tid; i < kn * (AT_KD / 8); i += 256) {
-      const int key = i / (AT_KD / 8), c8 = i % (AT_KD / 8);
-      *reinterpret_cast<bf16x8*>(sk + key * AT_KD + c8 * 8) =
-          *reinterpret_cast<const bf16x8*>(base + (long long)(k0 + key) * a.in_pitch + AT_KD + c8 * 8);
-    }
-    for (int i = tid; i < kn * (AT_HD / 8); i += 256) {
-      const int key = i / (AT_HD / 8), c8 = i % (AT_HD / 8);
-      *reinterpret_cast<bf16x8*>(sv + key * AT_HD + c8 * 8) =
-          *reinterpret_cast<const bf16x8*>(base + (long long)(k0 + key) * a.in_pitch + 2 * AT_KD + c8 * 8);
-    }
-    __syncthreads();
-    for (int key = part; key < kn; key += 4) {
-      float s = 0.f;
+  for (int rd = 0; rd < rounds; ++rd) {
+    const int qt = wslot + rd * 4 * AT_QSPLIT;
+    const bool active = qt < nqt;
+    const int q = qt * 16 + n;
+    bf16x8 qf = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (active && q < a.N) qf = *reinterpret_cast<const bf16x8*>(base + (long long)q * a.in_pitch + g * 8);
+    float m = ninf, l = 0.f;
+    f32x4 acc[4];
 #pragma unroll
-      for (int c = 0; c < AT_KD; c += 8) {
-        const bf16x8 kv = *reinterpret_cast<const bf16x8*>(sk + key * AT_KD + c);
+    for (int dt = 0; dt < 4; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int st = 0; st < nstage; ++st) {
+      const int k0s = st * AT_STAGE;
+      const int nk = min(AT_STAGE, a.N - k0s);
+      const int nk32 = (nk + 31) & ~31;
+      if (nstage > 1 || rd == 0) {
+        __syncthreads();  // previous users of the stage buffers are done
+        for (int i = tid; i < nk32 * 4; i += 256) {
+          const int key = i >> 2, c8 = i & 3;
+          bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+          if (key < nk)
+            v = *reinterpret_cast<const bf16x8*>(base + (long long)(k0s + key) * a.in_pitch + AT_KD + c8 * 8);
+          *reinterpret_cast<bf16x8*>(sK + key * AT_KP + c8 * 8) = v;
+        }
+        for (int i = tid; i < nk32 * 8; i += 256) {
+          const int key = i >> 3, c8 = i & 7;
+          bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+          if (key < nk)
+            v = *reinterpret_cast<const bf16x8*>(base + (long long)(k0s + key) * a.in_pitch + 2 * AT_KD + c8 * 8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s += qr[c + j] * (float)kv[j];
+          for (int j = 0; j < 8; ++j) sVt[(c8 * 8 + j) * AT_VP + key] = v[j];
+        }
+        __syncthreads();
       }
-      const float mn = fmaxf(m, s);
-      const float alpha = __expf(m - mn);
-      const float pexp = __expf(s - mn);
-      l = l * alpha + pexp;
-      m = mn;
+      if (!active) continue;
+      for (int k0 = 0; k0 < nk32; k0 += 32) {
+        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(sK + (k0 + n) * AT_KP + g * 8);
+        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(sK + (k0 + 16 + n) * AT_KP + g * 8);
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, qf, z, 0, 0, 0);
+        const f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf, z, 0, 0, 0);
+        float v[8];
 #pragma unroll
-      for (int d = 0; d < AT_HD; d += 8) {
-        const bf16x8 vv = *reinterpret_cast<const bf16x8*>(sv + key * AT_HD + d);
+        for (int r = 0; r < 4; ++r) {
+          v[r] = (k0 + 4 * g + r < nk) ? s0[r] * a.scale : ninf;
+          v[4 + r] = (k0 + 16 + 4 * g + r < nk) ? s1[r] * a.scale : ninf;
+        }
+        float lm = v[0];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[d + j] = acc[d + j] * alpha + pexp * (float)vv[j];
+        for (int j = 1; j < 8; ++j) lm = fmaxf(lm, v[j]);
+        lm = fmaxf(lm, __shfl_xor(lm, 16));
+        lm = fmaxf(lm, __shfl_xor(lm, 32));
+        const float mn = fmaxf(m, lm);  // finite: every processed step has at least one real key
+        const float alpha = __expf(m - mn);
+        float ps = 0.f;
+        bf16x8 pb;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float e = __expf(v[j] - mn);
+          ps += e;
+          pb[j] = (__bf16)e;
+        }
+        l = l * alpha + ps;
+        m = mn;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          const __bf16* vr = sVt + (dt * 16 + n) * AT_VP + k0 + 4 * g;
+          const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vr);
+          const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vr + 16);
+          const bf16x8 av = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[dt][r] *= alpha;
+          acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, pb, acc[dt], 0, 0, 0);
+        }
       }
     }
-  }
-  // merge the 4 key partitions
-  sm[part][lane] = m;
-  __syncthreads();
-  const float mg = fmaxf(fmaxf(sm[0][lane], sm[1][lane]), fmaxf(sm[2][lane], sm[3][lane]));
-  const float f = (m == -__builtin_huge_valf()) ? 0.f : __expf(m - mg);
-  sl[part][lane] = l * f;
-  __syncthreads();
-  const float lg = sl[0][lane] + sl[1][lane] + sl[2][lane] + sl[3][lane];
-  // reuse sv as fp32 scratch [4][64 q][64 d] = 64 KB? too large: reduce in 4 rounds through sk/sv
-  float* red = reinterpret_cast<float*>(sv);  // 256*64*2 B = 32 KB = 8192 floats = [2][64][64]
-  __syncthreads();
-  for (int round = 0; round < 2; ++round) {
-    // parts (2*round, 2*round+1) deposit, everybody accumulates afterwards
-    if ((part >> 1) == round) {
-      float* dst = red + ((part & 1) * 64 + lane) * AT_HD;
+    if (active) {
+      l += __shfl_xor(l, 16);
+      l += __shfl_xor(l, 32);
+      if (q < a.N) {
+        const float inv = 1.0f / l;
+        __bf16* op = a.out + (long long)b * a.out_img + (long long)q * a.out_pitch + a.out_coff + head * AT_HD;
 #pragma unroll
-      for (int d = 0; d < AT_HD; ++d) dst[(d + lane) & (AT_HD - 1)] = acc[d] * f;  // skewed: conflict-free
-    }
-    __syncthreads();
-    if (part == 0) {
-      if (round == 0) {
-#pragma unroll
-        for (int d = 0; d < AT_HD; ++d) acc[d] = 0.f;
+        for (int dt = 0; dt < 4; ++dt)
+          *reinterpret_cast<bf16x4*>(op + dt * 16 + 4 * g) =
+              bf16x4{(__bf16)(acc[dt][0] * inv), (__bf16)(acc[dt][1] * inv), (__bf16)(acc[dt][2] * inv),
+                     (__bf16)(acc[dt][3] * inv)};
       }
-      const float* s0 = red + lane * AT_HD;
-      const float* s1 = red + (64 + lane) * AT_HD;
-#pragma unroll
-      for (int d = 0; d < AT_HD; ++d) acc[d] += s0[(d + lane) & (AT_HD - 1)] + s1[(d + lane) & (AT_HD - 1)];
-    }
-    __syncthreads();
-  }
-  if (part == 0 && qv) {
-    const float inv = 1.0f / lg;
-    __bf16* op = a.out + (long long)b * a.out_img + (long long)q * a.out_pitch + a.out_coff + head * AT_HD;
-#pragma unroll
-    for (int d = 0; d < AT_HD; d += 8) {
-      bf16x8 o;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = (__bf16)(acc[d + j] * inv);
-      *reinterpret_cast<bf16x8*>(op + d) = o;
     }
   }
 }
 
 int attention_launch(const AttnArgs& a, hipStream_t s) {
-  if (a.in_pitch % 8 || a.in_coff % 8 || a.out_pitch % 8 || a.out_coff % 8)
+  if (a.in_pitch % 8 || a.in_coff % 8 || a.out_pitch % 4 || a.out_coff % 4)
     return fail(-3, "attention: channel offsets must be multiples of 8");
-  const int qblocks = (a.N + 63) / 64;
-  hipLaunchKernelGGL(attention_kernel, dim3(a.batch * a.heads * qblocks), dim3(256), 0, s, a);
+  const size_t lds = ((size_t)AT_STAGE * AT_KP + (size_t)AT_HD * AT_VP) * 2;
+  static bool attr = false;
+  if (!attr) {
+    YL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr = true;
+  }
+  hipLaunchKernelGGL(attention_kernel, dim3(a.batch * a.heads * AT_QSPLIT), dim3(256), lds, s, a);
   YL_HIP(hipGetLastError());
   return 0;
 }
@@ -328,73 +415,86 @@ int attention_launch(const AttnArgs& a, hipStream_t s) {
 // dist2bbox xywh (utils/tal.py:341-350) on anchors (x+0.5, y+0.5) (tal.py:326-338), times stride,
 // and sigmoid of the class logits.  fp32 in, fp32 out: y[B][4+nc][A].
 constexpr int MAX_LEVELS = 8;
+constexpr int DEC_ANCH = 64;  // anchors per workgroup
 struct DecodeArgs {
   DecodeLevel lv[MAX_LEVELS];
+  int blk0[MAX_LEVELS + 1];  // first block of each level inside one image
   int n_levels, batch, nc, A;
   float* y;
 };
 
-__global__ void decode_kernel(DecodeArgs a) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long long)a.batch * a.A) return;
-  const int b = (int)(i / a.A);
-  const int an = (int)(i - (long long)b * a.A);
+// One workgroup = 64 consecutive anchors of one level of one image.  Their raw rows are one
+// contiguous run of 64 x (64+nc) floats: staged through LDS with coalesced loads (row pitch no+1
+// words -> conflict-free column reads), then every output row of y is written as 256-byte runs.
+__global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sraw[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nb_img = a.blk0[a.n_levels];
+  const int b = blockIdx.x / nb_img;
+  const int k = blockIdx.x - b * nb_img;
   int l = 0;
 #pragma unroll
-  for (int k = 1; k < MAX_LEVELS; ++k)
-    if (k < a.n_levels && an >= a.lv[k].a0) l = k;
+  for (int i = 1; i < MAX_LEVELS; ++i)
+    if (i < a.n_levels && k >= a.blk0[i]) l = i;
   const DecodeLevel L = a.lv[l];
-  const int p = an - L.a0;
-  const int no = 64 + a.nc;
-  const float* raw = L.raw + ((long long)b * L.H * L.W + p) * no;
-  float dist[4];
-#pragma unroll
-  for (int side = 0; side < 4; ++side) {
-    float v[16];
-    float mx = -__builtin_huge_valf();
-    if ((no & 3) == 0) {
-#pragma unroll
-      for (int k = 0; k < 16; k += 4) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(raw + side * 16 + k);
-        v[k] = t[0]; v[k + 1] = t[1]; v[k + 2] = t[2]; v[k + 3] = t[3];
-      }
-    } else {
-#pragma unroll
-      for (int k = 0; k < 16; ++k) v[k] = raw[side * 16 + k];
-    }
-#pragma unroll
-    for (int k = 0; k < 16; ++k) mx = fmaxf(mx, v[k]);
-    float sum = 0.f, ws = 0.f;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const float e = expf(v[k] - mx);
-      sum += e;
-      ws += e * (float)k;
-    }
-    dist[side] = ws / sum;
+  const int HW = L.H * L.W;
+  const int p0 = (k - a.blk0[l]) * DEC_ANCH;
+  const int nv = min(DEC_ANCH, HW - p0);
+  const int no = 64 + a.nc, pitch = no + 1;
+  float* sdist = sraw + DEC_ANCH * pitch;  // [4][64]
+  const float* raw = L.raw + ((long long)b * HW + p0) * no;
+  for (int r = wave; r < nv; r += 4)
+    for (int c = lane; c < no; c += 64) sraw[r * pitch + c] = raw[(long long)r * no + c];
+  __syncthreads();
+  // DFL: thread = (anchor, side)
+  {
+    const int an = lane, side = wave;
+    float dist = 0.f;
+    if (an < nv) dist = dfl_expect(sraw + an * pitch + side * 16);
+    sdist[side * DEC_ANCH + an] = dist;
   }
-  const float ax = (float)(p % L.W) + 0.5f, ay = (float)(p / L.W) + 0.5f;
-  const float x1 = ax - dist[0], y1 = ay - dist[1], x2 = ax + dist[2], y2 = ay + dist[3];
-  float* yb = a.y + (long long)b * (4 + a.nc) * a.A + an;
-  yb[0] = ((x1 + x2) / 2.0f) * L.stride;
-  yb[(long long)a.A] = ((y1 + y2) / 2.0f) * L.stride;
-  yb[2LL * a.A] = (x2 - x1) * L.stride;
-  yb[3LL * a.A] = (y2 - y1) * L.stride;
-  for (int c = 0; c < a.nc; ++c) yb[(long long)(4 + c) * a.A] = 1.0f / (1.0f + expf(-raw[64 + c]));
+  __syncthreads();
+  float* yb = a.y + (long long)b * (4 + a.nc) * a.A + L.a0 + p0;
+  if (lane < nv) {
+    const int p = p0 + lane;
+    const float ax = (float)(p % L.W) + 0.5f, ay = (float)(p / L.W) + 0.5f;
+    const float4 bx = box_xywh(ax, ay, sdist[lane], sdist[DEC_ANCH + lane], sdist[2 * DEC_ANCH + lane],
+                               sdist[3 * DEC_ANCH + lane], L.stride);
+    const float o = wave == 0 ? bx.x : wave == 1 ? bx.y : wave == 2 ? bx.z : bx.w;
+    yb[(long long)wave * a.A + lane] = o;
+    for (int c = wave; c < a.nc; c += 4)
+      yb[(long long)(4 + c) * a.A + lane] = sigmoid_score(sraw[lane * pitch + 64 + c]);
+  }
 }
 
 int decode_launch(const DecodeLevel* lv, int n_levels, int batch, int nc, int A, float* y, hipStream_t s) {
   if (n_levels > MAX_LEVELS) return fail(-3, "decode: too many levels");
   DecodeArgs a;
-  for (int i = 0; i < n_levels; ++i) a.lv[i] = lv[i];
-  for (int i = n_levels; i < MAX_LEVELS; ++i) a.lv[i] = DecodeLevel{nullptr, 0, 0, 1 << 30, 0.f};
+  int nb = 0;
+  for (int i = 0; i < n_levels; ++i) {
+    a.lv[i] = lv[i];
+    a.blk0[i] = nb;
+    nb += (lv[i].H * lv[i].W + DEC_ANCH - 1) / DEC_ANCH;
+  }
+  for (int i = n_levels; i < MAX_LEVELS; ++i) {
+    a.lv[i] = DecodeLevel{nullptr, 0, 0, 1 << 30, 0.f};
+    a.blk0[i] = 1 << 30;
+  }
+  a.blk0[n_levels] = nb;
   a.n_levels = n_levels;
   a.batch = batch;
   a.nc = nc;
   a.A = A;
   a.y = y;
-  const long long total = (long long)batch * A;
-  hipLaunchKernelGGL(decode_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+  const size_t lds = ((size_t)DEC_ANCH * (64 + nc + 1) + 4 * DEC_ANCH) * sizeof(float);
+  if (lds > 150 * 1024) return fail(-3, "decode: nc too large for the LDS-staged decode");
+  static size_t attr = 0;
+  if (lds > attr) {
+    YL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decode_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr = 160 * 1024;
+  }
+  hipLaunchKernelGGL(decode_kernel, dim3((unsigned)(batch * nb)), dim3(256), lds, s, a);
   YL_HIP(hipGetLastError());
   return 0;
 }

@@ -43,6 +43,7 @@ struct ConvArgs {
   int ntaps;
   int halo_lds_off, halo_bytes;  // LDS: [filter slab][halo buffer(s)]
   int ntiles, gws;               // pixel tiles in total / blocks per output-channel block
+  int npatches, ppw;             // direct kernel: wave patches in total / patches per wave
   unsigned magic_hw, magic_tw, magic_cg;  // ceil(2^32 / x) for small-number division
   int nblocks;
 };
@@ -50,7 +51,7 @@ struct ConvArgs {
 struct ConvConfig {
   int MT, NT, uniform, ws;
   int TH, TW, tiles_x, tiles_y, ncb;
-  int HH, HW, cch, cg, lg2, nchunks, ksteps, pp, ntaps, halo_lds_off, halo_bytes, ntiles, gws;
+  int HH, HW, cch, cg, lg2, nchunks, ksteps, pp, ntaps, halo_lds_off, halo_bytes, ntiles, gws, ppw;
   size_t lds_bytes;
   size_t wpk_elems;  // packed weight elements
   const char* name;
@@ -110,5 +111,27 @@ struct DecodeLevel {
   float stride;
 };
 int decode_launch(const DecodeLevel* lv, int n_levels, int batch, int nc, int A, float* y, hipStream_t s);
+
+// Decode arithmetic shared by the plain decode kernel and the fused decode+candidate kernel, so both
+// produce bit-identical boxes and scores (head.py:95-126, block.py:66-69, tal.py:341-350).
+__device__ __forceinline__ float dfl_expect(const float* v) {  // softmax over 16 bins, expectation
+  float mx = v[0];
+#pragma unroll
+  for (int j = 1; j < 16; ++j) mx = fmaxf(mx, v[j]);
+  float sum = 0.f, ws = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const float e = expf(v[j] - mx);
+    sum += e;
+    ws += e * (float)j;
+  }
+  return ws / sum;
+}
+__device__ __forceinline__ float4 box_xywh(float ax, float ay, float dl, float dt, float dr, float db, float stride) {
+  const float x1 = ax - dl, y1 = ay - dt, x2 = ax + dr, y2 = ay + db;
+  return make_float4(((x1 + x2) / 2.0f) * stride, ((y1 + y2) / 2.0f) * stride, (x2 - x1) * stride,
+                     (y2 - y1) * stride);
+}
+__device__ __forceinline__ float sigmoid_score(float logit) { return 1.0f / (1.0f + expf(-logit)); }
 
 }  // namespace yl

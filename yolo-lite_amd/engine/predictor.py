@@ -47,6 +47,7 @@ class DetectionPredictor:
         self.results = None
         self.txt_path = None
         self.keep_orig_img = keep_orig_img
+        self.fuse_postprocess = True  # set False to run the reference's three separate stages
         self.last_preds = None
         self._lock = threading.Lock()
 
@@ -102,6 +103,39 @@ class DetectionPredictor:
         return [Results(imgs[i], path=self.batch[0][i], names=self.model.names, boxes=out[i, : counts[i]],
                         orig_shape=shapes[i]) for i in range(B)]
 
+    # ------------------------------------------------------------------ fused fast path
+    def _can_fuse(self) -> bool:
+        """The fused path is used when the hooks are not overridden and nobody asked for ``last_preds``."""
+        cls = type(self)
+        return (self.fuse_postprocess and cls.inference is DetectionPredictor.inference
+                and cls.postprocess is DetectionPredictor.postprocess
+                and not (self.args.visualize or self.args.augment or self.args.embed))
+
+    def _shapes_and_scale(self, img, orig_imgs, B, device):
+        if isinstance(orig_imgs, torch.Tensor):
+            shapes = [tuple(orig_imgs.shape[2:])] * B
+            imgs = ops.convert_torch2numpy_batch(orig_imgs) if self.keep_orig_img else [None] * B
+        else:
+            shapes = [tuple(o.shape[:2]) for o in orig_imgs]
+            imgs = orig_imgs
+        sc = []
+        for h0, w0 in shapes:
+            gain, pad = ops.scale_boxes_params(tuple(img.shape[2:]), (h0, w0))
+            sc.append([pad[0], pad[1], gain, w0, h0])
+        return shapes, imgs, torch.tensor(sc, dtype=torch.float32, device=device)
+
+    def _detect_fused(self, im, orig_imgs):
+        """inference + postprocess in one pass: the (B, 4+nc, A) tensor is never materialised."""
+        b, _, h, w = im.shape
+        eng = self.model.engine_for(b, h, w)
+        shapes, imgs, scale = self._shapes_and_scale(im, orig_imgs, b, im.device)
+        out, cnt = eng.detect(im.contiguous(), self.args.conf, self.args.iou, max_det=self.args.max_det,
+                              classes=self.args.classes, agnostic=self.args.agnostic_nms, scale=scale, graph=False)
+        counts = cnt.tolist()
+        self.last_preds = None
+        return [Results(imgs[i], path=self.batch[0][i], names=self.model.names, boxes=out[i, : counts[i]],
+                        orig_shape=shapes[i]) for i in range(b)]
+
     # ------------------------------------------------------------------ driver
     def __call__(self, source=None, model=None, stream=False, *args, **kwargs):
         self.stream = stream
@@ -140,10 +174,15 @@ class DetectionPredictor:
                 paths, im0s, s = self.batch
                 with profilers[0]:
                     im = self.preprocess(im0s)
-                with profilers[1]:
-                    preds = self.inference(im, *args, **kwargs)
-                with profilers[2]:
-                    self.results = self.postprocess(preds, im, im0s)
+                if self._can_fuse():
+                    with profilers[1]:  # network + fused decode / NMS / box rescale, one host sync
+                        self.results = self._detect_fused(im, im0s)
+                    profilers[2].dt = 0.0
+                else:
+                    with profilers[1]:
+                        preds = self.inference(im, *args, **kwargs)
+                    with profilers[2]:
+                        self.results = self.postprocess(preds, im, im0s)
                 n = len(im0s)
                 for i in range(n):
                     self.seen += 1

@@ -110,6 +110,33 @@ class HipEngine:
                       y.data_ptr() if decode else None, stream), "yl_engine_forward")
         return y if decode else None
 
+    def detect(self, im: torch.Tensor, conf: float = 0.25, iou: float = 0.7, max_det: int = 300,
+               classes=None, agnostic: bool = False, max_nms: int = 30000, max_wh: float = 7680.0,
+               scale: Optional[torch.Tensor] = None, graph: bool = True):
+        """Network + fused Detect decode + NMS; returns padded (out[B, max_det, 6], count[B]).
+
+        Bit-identical to ``forward`` followed by ``utils.ops.nms_padded`` but the (B, 4+nc, A) tensor
+        of the reference (head.py:126) is never materialised.  No host synchronisation."""
+        from ..utils import ops as _ops
+
+        self.forward(im, graph=graph, decode=False)
+        max_cand = min(int(max_nms), self.anchors)
+        work = _ops._nms_workspace(self.device, self.batch, self.anchors, max_cand)
+        out = torch.empty((self.batch, max_det, 6), dtype=torch.float32, device=self.device)
+        cnt = torch.empty((self.batch,), dtype=torch.int32, device=self.device)
+        cls_t = None
+        if classes is not None:
+            cls_t = torch.as_tensor(list(np.atleast_1d(classes)), dtype=torch.int32, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        rc = self.lib.yl_decode_nms(self.workspace.data_ptr(), self._levels, len(self._levels), self.batch, self.nc,
+                                    float(conf), float(iou), int(max_det), int(bool(agnostic)),
+                                    cls_t.data_ptr() if cls_t is not None else None,
+                                    int(cls_t.numel()) if cls_t is not None else 0, max_cand, float(max_wh),
+                                    scale.data_ptr() if scale is not None else None, out.data_ptr(), cnt.data_ptr(),
+                                    work.data_ptr(), stream)
+        _lib.check(rc, "yl_decode_nms")
+        return out, cnt
+
     def raw_levels(self) -> List[torch.Tensor]:
         """Zero-copy (B, 64+nc, H, W) fp32 views of the Detect level maps (reference head.py:64-65)."""
         out = []
