@@ -1,0 +1,58 @@
+"""CPU: lowering of the YOLO11 graph to the engine program (no GPU needed)."""
+import pytest
+
+from yololite_amd.nn import arch
+from yololite_amd.nn.lower import OP_ATTENTION, OP_CONV, OP_DWCONV3, OP_SPPF_POOL, OP_UPSAMPLE, lower
+from yololite_amd.nn.synth import synth_state_dict
+
+
+def _prog(scale, b=2, h=640, w=640):
+    specs, _ = arch.parse_model(arch.yolo11_dict(scale))
+    return lower(specs, synth_state_dict(scale, 0), b, h, w)
+
+
+def _conv_gflop(prog):
+    f = 0.0
+    for o in prog.ops:
+        if o["kind"] in (OP_CONV, OP_DWCONV3):
+            w = o["weight"]
+            f += 2.0 * o["out"].H * o["out"].W * w.shape[0] * w.shape[1] * w.shape[2] * w.shape[3]
+    return f / 1e9
+
+
+@pytest.mark.parametrize("scale,gflop,nconv", [("n", 6.4811, 88), ("s", 21.4669, 88), ("x", 194.9038, 174)])
+def test_algorithmic_flops_match_survey(scale, gflop, nconv):
+    """2*MAC over all nn.Conv2d calls per image at 640x640 (DFL conv excluded
+    here: it is 16*4*8400 MACs = 0.0011 GFLOP, folded into the decode kernel)."""
+    p = _prog(scale, 1)
+    got = _conv_gflop(p) + 2 * 16 * 4 * p.anchors / 1e9
+    assert abs(got - gflop) < 2e-3 * gflop
+    # C3k cv1+cv2 pairs are merged into one launch: count reference Conv2d calls
+    calls = sum(2 if o.get("name", "").endswith("cv1+cv2") else 1 for o in p.ops if o["kind"] in (OP_CONV, OP_DWCONV3))
+    assert calls + 1 == nconv  # + the DFL conv
+
+
+def test_views_inside_workspace_and_aligned():
+    p = _prog("n", 3, 96, 128)
+    assert p.anchors == 12 * 16 + 6 * 8 + 3 * 4
+    for o in p.ops:
+        for key in ("inp", "out", "res"):
+            v = o.get(key)
+            if v is None:
+                continue
+            esz = 4 if v.dtype == 1 else 2
+            assert v.offset % 256 == 0 and v.coff + v.C <= v.pitch
+            assert v.offset + p.batch * v.H * v.W * v.pitch * esz <= p.ws_bytes
+            if o["kind"] != OP_CONV or key == "inp":
+                assert v.coff % 8 == 0 or v.dtype == 1
+    kinds = [o["kind"] for o in p.ops]
+    assert kinds.count(OP_SPPF_POOL) == 1 and kinds.count(OP_ATTENTION) == 1 and kinds.count(OP_UPSAMPLE) == 2
+
+
+def test_concat_members_are_slices_of_one_buffer():
+    """Concat never copies: layer 6 and the upsampled layer 10 share layer 12's buffer."""
+    p = _prog("n", 1)
+    v6, v11, v12 = p.layer_views[6], p.layer_views[11], p.layer_views[12]
+    assert v6.offset == v12.offset == v11.offset
+    assert (v11.coff, v11.C, v6.coff, v6.C, v12.C) == (0, 256, 256, 128, 384)
+    assert not any(o.get("name", "").endswith(".copy") for o in p.ops)

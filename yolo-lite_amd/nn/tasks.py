@@ -128,6 +128,8 @@ _ALLOWED = {
 
 
 def _allowed_global(module: str, name: str):
+    if module == "__builtin__":  # protocol-2 pickles (torch.save default) use the Python 2 module name
+        module = "builtins"
     if (module, name) in _ALLOWED:
         return _ALLOWED[(module, name)]
     if module == "torch._utils" and name in {"_rebuild_tensor_v2", "_rebuild_parameter", "_rebuild_tensor",
