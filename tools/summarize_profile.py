@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Turn a gpurun_out/rNN directory (rocprofv3 kernel trace + PMC passes + bench JSON) into the
+tracked summaries under profiles/.
+
+    python tools/summarize_profile.py gpurun_out/r01 profiles r01
+
+HBM traffic per launch follows MI355X_MICROARCH.md (HBM section): FETCH_SIZE / WRITE_SIZE are in KiB
+and collected in separate passes; on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced
+reads, so the read side is doubled.
+"""
+import csv
+import glob
+import json
+import shutil
+import sys
+from collections import defaultdict
+from pathlib import Path
+
+
+def short(name):
+    n = name.split("(")[0].replace("void ", "").replace("yl::", "")
+    return n[:60]
+
+
+def pmc(dirpath, counter):
+    out = defaultdict(lambda: [0.0, 0])
+    for f in glob.glob(str(Path(dirpath) / "**" / "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter:
+                a = out[short(r["Kernel_Name"])]
+                a[0] += float(r["Counter_Value"])
+                a[1] += 1
+    return {k: v[0] / v[1] for k, v in out.items() if v[1]}
+
+
+def main():
+    src, dst, tag = Path(sys.argv[1]), Path(sys.argv[2]), sys.argv[3]
+    dst.mkdir(parents=True, exist_ok=True)
+    stats = glob.glob(str(src / "trace" / "**" / "*kernel_stats.csv"), recursive=True)
+    rows = list(csv.DictReader(open(stats[0]))) if stats else []
+    if stats:
+        shutil.copy(stats[0], dst / f"{tag}_kernel_stats.csv")
+    fetch = pmc(src / "pmc_fetch", "FETCH_SIZE")
+    write = pmc(src / "pmc_write", "WRITE_SIZE")
+    bench = None
+    if (src / "bench.json").exists():
+        txt = (src / "bench.json").read_text().strip().splitlines()
+        bench = json.loads(txt[-1]) if txt else None
+        (dst / f"{tag}_bench.json").write_text(json.dumps(bench, indent=1))
+    if (src / "per_op.json").exists():
+        shutil.copy(src / "per_op.json", dst / f"{tag}_per_op.json")
+    lines = [f"# {tag}: rocprofv3 --kernel-trace --stats of `python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline`", ""]
+    if bench:
+        lines += [f"bench (un-profiled run): **{bench['value']} {bench['unit']}**, {bench['ms_per_step']} ms/step, "
+                  f"roofline {json.dumps(bench.get('roofline'))}", ""]
+    lines += ["| kernel | calls | avg us | total % | HBM read MB/launch (2 x FETCH_SIZE) | HBM write MB/launch |",
+              "|---|---|---|---|---|---|"]
+    for r in rows:
+        if float(r["Percentage"]) < 0.05:
+            continue
+        k = short(r["Name"])
+        rd = fetch.get(k)
+        wr = write.get(k)
+        lines.append(f"| `{k}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} | "
+                     f"{'' if rd is None else f'{2 * rd * 1024 / 1e6:.1f}'} | {'' if wr is None else f'{wr * 1024 / 1e6:.1f}'} |")
+    (dst / f"{tag}_summary.md").write_text("\n".join(lines) + "\n")
+    print("\n".join(lines[:40]))
+
+
+if __name__ == "__main__":
+    main()
