@@ -23,9 +23,9 @@ SCORE_ATOL = 0.08
 BOX_ATOL_STRIDES = 0.35  # box coordinate error allowed, in units of the level stride
 
 
-def _engine(scale, sd, b, h, w, dev):
+def _engine(scale, sd, b, h, w, dev, keep_layers=False):
     specs, _ = arch.parse_model(arch.yolo11_dict(scale))
-    return HipEngine.from_model(specs, sd, b, h, w, dev)
+    return HipEngine.from_model(specs, sd, b, h, w, dev, keep_layers=keep_layers)
 
 
 def _stride_per_anchor(h, w):
@@ -38,7 +38,7 @@ def _stride_per_anchor(h, w):
 def test_every_layer_vs_golden(gpu_device, golden):
     sd = synth_state_dict("n", 0, cls_bias=list(golden["layers_n_bias"]), cls_gain=8.0)
     x = torch.from_numpy(golden["layers_n_x"])
-    eng = _engine("n", sd, 1, 64, 64, gpu_device)
+    eng = _engine("n", sd, 1, 64, 64, gpu_device, keep_layers=True)
     eng.forward(x.to(gpu_device))
     torch.cuda.synchronize()
     worst = 0.0

@@ -49,9 +49,29 @@ def test_views_inside_workspace_and_aligned():
     assert kinds.count(OP_SPPF_POOL) == 1 and kinds.count(OP_ATTENTION) == 1 and kinds.count(OP_UPSAMPLE) == 2
 
 
+def _prog_noreuse(scale, b=1, h=640, w=640):
+    specs, _ = arch.parse_model(arch.yolo11_dict(scale))
+    return lower(specs, synth_state_dict(scale, 0), b, h, w, reuse=False)
+
+
+@pytest.mark.parametrize("scale", ["n", "x"])
+def test_arena_reuse_never_overlaps_live_buffers(scale):
+    """Buffers whose lifetimes [first op, last op] intersect must occupy disjoint byte ranges."""
+    p = _prog(scale, 2, 96, 128)
+    q = _prog_noreuse(scale, 2, 96, 128)
+    assert p.ws_bytes < 0.6 * q.ws_bytes
+    t = sorted(p.alloc_table, key=lambda r: r[2])
+    for i, (f1, l1, o1, s1) in enumerate(t):
+        assert o1 % 256 == 0 and o1 + s1 <= p.ws_bytes
+        for f2, l2, o2, s2 in t[i + 1:]:
+            if o2 >= o1 + s1:
+                break
+            assert l1 < f2 or l2 < f1, f"live buffers overlap: {(f1, l1, o1, s1)} vs {(f2, l2, o2, s2)}"
+
+
 def test_concat_members_are_slices_of_one_buffer():
     """Concat never copies: layer 6 and the upsampled layer 10 share layer 12's buffer."""
-    p = _prog("n", 1)
+    p = _prog_noreuse("n", 1)
     v6, v11, v12 = p.layer_views[6], p.layer_views[11], p.layer_views[12]
     assert v6.offset == v12.offset == v11.offset
     assert (v11.coff, v11.C, v6.coff, v6.C, v12.C) == (0, 256, 256, 128, 384)

@@ -52,6 +52,12 @@ def main():
     rows = eng.profile(x, iters=20)
     tot = sum(r["ms"] for r in rows)
     print(f"sum of per-op times {tot:.3f} ms over {len(rows)} launches")
+    agg = {}
+    for r in rows:
+        a_ = agg.setdefault(r["kernel"], [0.0, 0])
+        a_[0] += r["ms"]
+        a_[1] += 1
+    print("by kernel:", ", ".join(f"{k} {v[0] * 1e3:.0f}us x{v[1]}" for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])))
     rows.sort(key=lambda r: -r["ms"])
     for r in rows[: a.top]:
         print(f"{r['name']:26s} {r['kernel']:16s} {r['ms'] * 1e3:8.1f} us {r['flops'] / max(r['ms'], 1e-9) / 1e9:7.1f} TF/s "

@@ -29,7 +29,12 @@ __device__ __forceinline__ int fastdiv(int x, int d, unsigned magic) {
   return d == 1 ? x : (int)__umulhi((unsigned)x, magic);
 }
 
-__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+// SiLU with the hardware exp2 / reciprocal (v_exp_f32, v_rcp_f32; ~1 ulp each, far inside bf16 output
+// rounding): an IEEE divide here costs ~10 VALU instructions per element and made the epilogue, not
+// memory, the bottleneck of the streaming layers (measured: 32->32 1x1 @160^2 43 us -> see DESIGN.md).
+__device__ __forceinline__ float silu_f(float v) {
+  return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * v));
+}
 
 // Per-lane output pixels of the wave's NT pixel tiles: LDS halo offset and output pixel index.
 template <int NT>
@@ -201,8 +206,8 @@ __device__ __forceinline__ void epilogue(const ConvArgs& a, int cb, int b, int g
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float x0 = acc[2 * p][nt][r] + b0[r], x1 = acc[2 * p + 1][nt][r] + b1[r];
-        v[r] = a.act ? silu_f(x0) : x0;
-        v[4 + r] = a.act ? silu_f(x1) : x1;
+        v[r] = (a.act && !(a.dbg & 8)) ? silu_f(x0) : x0;
+        v[4 + r] = (a.act && !(a.dbg & 8)) ? silu_f(x1) : x1;
       }
       store_group<8>(a, b, opix[nt], co, v);
     }
@@ -248,28 +253,116 @@ __device__ __forceinline__ TilePos tile_pos(const ConvArgs& a, int t) {
 }
 
 // ------------------------------------------------------------------ direct (LDS-free activations)
-// Every wave owns a 2*NT x 8 pixel patch and MT*16 output channels.  Its B fragments (activations)
-// come straight from global memory / L1 -- 16 contiguous bytes per lane, the tap shift is just an
-// address offset and the zero padding a per-lane predicate -- so there is no halo staging, no
-// barrier in the pixel loop and many independent loads in flight per wave.  Only the block's
-// filter slab lives in LDS (staged once, fragment order, conflict-free reads).  K = (tap, cin)
-// flattened; the next k-step's operands are fetched while the current one is multiplied.
+// Every wave owns a run of NT*16 CONSECUTIVE output pixels (row-major over the whole batch, so a
+// patch is one contiguous run of NHWC memory: long DRAM bursts for the loads of a 1x1 conv and for
+// every store) and MT*16 output channels.  Its B fragments (activations) come straight from global
+// memory / L1 -- 16 contiguous bytes per lane, the tap shift is an address offset, the zero padding
+// a per-lane predicate -- so there is no halo staging and no barrier in the pixel loop.  Only the
+// block's filter slab lives in LDS (staged once, fragment order, conflict-free reads).
+// K = (tap, cin) flattened in groups of 8 channels.
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+// Buffer addressing (raw_buffer_load/store with a 32-bit byte offset): an offset beyond the
+// descriptor's size makes a load return zeros and a store vanish, so zero padding, ragged patches
+// and channel tails need no branches and no zero-fill moves -- just a select on the offset.
+constexpr unsigned OOB = 0x80000000u;
+
+template <int NT>
+struct Patch {
+  unsigned base[NT];  // byte offset of the (stride-scaled) centre pixel inside the input slice
+  int gp[NT];         // global output pixel index, -1 if outside the tensor
+  unsigned mask[NT];  // bit t: tap t of this pixel lies inside the image
+};
+
 template <int KS, int NT>
-__device__ __forceinline__ void fetch_b(const ConvArgs& a, const __bf16* img, int ks, int g, const int (&base)[NT],
-                                        const unsigned (&mask)[NT], bf16x8 (&xb)[NT]) {
-  const int k8 = ks * 4 + g;
-  const int tap = KS == 1 ? 0 : fastdiv(k8, a.cg, a.magic_cg);
-  const int c8 = k8 - tap * a.cg;
-  const bool kvalid = KS == 1 ? (k8 < a.cg) : (tap < KS * KS);
-  const int kh = (tap * 11) >> 5;
-  const int dy = KS == 1 ? 0 : kh - 1, dx = KS == 1 ? 0 : tap - 3 * kh - 1;
-  const int off = (dy * a.W + dx) * a.in_pitch + c8 * 8;
+__device__ __forceinline__ void patch_setup(const ConvArgs& a, int patch, int n, Patch<NT>& P) {
+  const int first = patch * (16 * NT);  // wave-uniform
+  const int hw = a.Ho * a.Wo;
+  const int b0 = first / hw;
+  const int rem = first - b0 * hw;
+  const int oy0 = rem / a.Wo;
+  const int ox0 = rem - oy0 * a.Wo;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (kvalid && ((mask[nt] >> tap) & 1u)) v = *reinterpret_cast<const bf16x8*>(img + base[nt] + off);
-    xb[nt] = v;
+    const int t = ox0 + nt * 16 + n;
+    const int q = fastdiv(t, a.Wo, a.magic_wo);
+    const int ox = t - q * a.Wo;
+    const int oyt = oy0 + q;
+    const int qb = fastdiv(oyt, a.Ho, a.magic_ho);
+    const int oy = oyt - qb * a.Ho;
+    const int b = b0 + qb;
+    const int gp = first + nt * 16 + n;
+    const bool valid = gp < a.npix;
+    const int cy = oy * a.stride, cx = ox * a.stride;
+    P.base[nt] = (unsigned)(((b * a.H + cy) * a.W + cx) * a.in_pitch) * 2u;
+    unsigned m = 0;
+    if (KS == 1) {
+      m = valid ? 1u : 0u;
+    } else {
+#pragma unroll
+      for (int tp = 0; tp < 9; ++tp) {
+        const int iy = cy + tp / 3 - 1, ix = cx + tp % 3 - 1;
+        m |= ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) ? (1u << tp) : 0u;
+      }
+      m = valid ? m : 0u;
+    }
+    P.mask[nt] = m;
+    P.gp[nt] = valid ? gp : -1;
   }
+}
+
+// Fetch cursor: walks the k-steps in order.  In the UNIFORM case (Cin % 32 == 0) a k-step lies
+// inside one tap, so tap / channel block / tap offset are wave-uniform scalars and the per-lane
+// work is an add, a bit test and a select per load; otherwise (tap, channel group) are per lane.
+struct KCursor {
+  int ks, tap, kk, off;  // off: byte offset of the current tap
+};
+
+template <int KS>
+__device__ __forceinline__ int tap_offset(const ConvArgs& a, int tap) {  // bytes
+  if (KS == 1) return 0;
+  const int kh = (tap * 11) >> 5;
+  return ((kh - 1) * a.W + (tap - 3 * kh - 1)) * a.in_pitch * 2;
+}
+
+template <int KS, int NT, bool UNIFORM>
+__device__ __forceinline__ void fetch_b(const ConvArgs& a, __amdgpu_buffer_rsrc_t rin, KCursor& c, int g,
+                                        const Patch<NT>& P, bf16x8 (&xb)[NT]) {
+  if (UNIFORM) {
+    const unsigned off = (unsigned)(c.off + c.kk * 64 + g * 16);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const unsigned vo = ((P.mask[nt] >> c.tap) & 1u) ? P.base[nt] + off : OOB;
+      xb[nt] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rin, vo, 0, 0));
+    }
+    if (++c.kk == (a.cg >> 2)) {
+      c.kk = 0;
+      ++c.tap;
+      c.off = tap_offset<KS>(a, c.tap);
+    }
+  } else {
+    const int k8 = c.ks * 4 + g;
+    const int tap = KS == 1 ? 0 : fastdiv(k8, a.cg, a.magic_cg);
+    const int c8 = k8 - tap * a.cg;
+    const bool kvalid = KS == 1 ? (k8 < a.cg) : (tap < KS * KS);
+    const unsigned off = (unsigned)(tap_offset<KS>(a, tap) + c8 * 16);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const unsigned vo = (kvalid && ((P.mask[nt] >> tap) & 1u)) ? P.base[nt] + off : OOB;
+      xb[nt] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rin, vo, 0, 0));
+    }
+  }
+  ++c.ks;
+}
+
+template <int KS>
+__device__ __forceinline__ KCursor cursor_begin(const ConvArgs& a) {
+  KCursor c;
+  c.ks = 0;
+  c.tap = 0;
+  c.kk = 0;
+  c.off = tap_offset<KS>(a, 0);
+  return c;
 }
 
 template <int MT, int NT>
@@ -281,7 +374,110 @@ __device__ __forceinline__ void mma_step(const bf16x8 (&wa)[MT], const bf16x8 (&
       acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[mt], xb[nt], acc[mt][nt], 0, 0, 0);
 }
 
-template <int KS, int MT, int NT>
+// Global -> LDS copy of a packed filter slab: 8 independent 16-byte loads per thread are issued
+// before the first LDS store, so the copy costs one memory round trip per 32 KB, not one per 4 KB.
+__device__ __forceinline__ void copy_slab(const bf16x8* __restrict__ src, bf16x8* dst, int n16, int tid) {
+  for (int i0 = tid; i0 < n16; i0 += 256 * 8) {
+    bf16x8 t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * 256;
+      if (i < n16) t[u] = src[i];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * 256;
+      if (i < n16) dst[i] = t[u];
+    }
+  }
+}
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  const bf16x2 t = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(unsigned, t);
+}
+
+// Epilogue of the direct kernel (the accumulators already contain the bias): SiLU, residual, 16-byte
+// buffer stores.  Requires every channel count / pitch / offset to be a multiple of 8 (host-checked,
+// otherwise the generic epilogue is used).
+template <int MT, int NT>
+__device__ __forceinline__ void epilogue_buf(const ConvArgs& a, __amdgpu_buffer_rsrc_t rout,
+                                             __amdgpu_buffer_rsrc_t rres, int cb, int g, const int (&gp)[NT],
+                                             f32x4 (&acc)[MT][NT]) {
+  const int cbase = cb * MT * 16;
+  const unsigned esz = a.out_f32 ? 4u : 2u;
+  if (a.act && !(a.dbg & 8)) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[mt][nt][r] = silu_f(acc[mt][nt][r]);
+  }
+#pragma unroll
+  for (int p = 0; p < MT / 2; ++p) {
+    const int co = cbase + (p * 4 + g) * 8;
+    const bool cok = co < a.Cout;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const bool ok = cok && gp[nt] >= 0;
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[2 * p][nt][r];
+        v[4 + r] = acc[2 * p + 1][nt][r];
+      }
+      if (a.res) {
+        const unsigned ro = ok ? (unsigned)gp[nt] * (unsigned)(a.res_pitch * 2) + (unsigned)((a.res_coff + co) * 2) : OOB;
+        const bf16x8 rv = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rres, ro, 0, 0));
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += (float)rv[r];
+      }
+      const unsigned vo = ok ? (unsigned)gp[nt] * ((unsigned)a.out_pitch * esz) + (unsigned)(a.out_coff + co) * esz : OOB;
+      if (a.out_f32) {
+        __builtin_amdgcn_raw_buffer_store_b128(
+            u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, rout,
+            vo, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(
+            u32x4{__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])}, rout,
+            ok ? vo + 16u : OOB, 0, 0);
+      } else {
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]),
+                                                     pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])},
+                                               rout, vo, 0, 0);
+      }
+    }
+  }
+  if (MT & 1) {
+    constexpr int mt = MT - 1;
+    const int co = cbase + (MT & ~1) * 16 + g * 4;
+    const bool cok = co < a.Cout;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const bool ok = cok && gp[nt] >= 0;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[mt][nt][r];
+      if (a.res) {
+        const unsigned ro = ok ? (unsigned)gp[nt] * (unsigned)(a.res_pitch * 2) + (unsigned)((a.res_coff + co) * 2) : OOB;
+        const u32x2 rw = __builtin_amdgcn_raw_buffer_load_b64(rres, ro, 0, 0);
+        const bf16x4 rv = __builtin_bit_cast(bf16x4, rw);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+      }
+      const unsigned vo = ok ? (unsigned)gp[nt] * ((unsigned)a.out_pitch * esz) + (unsigned)(a.out_coff + co) * esz : OOB;
+      if (a.out_f32)
+        __builtin_amdgcn_raw_buffer_store_b128(
+            u32x4{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])}, rout,
+            vo, 0, 0);
+      else
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])}, rout, vo, 0, 0);
+    }
+  }
+}
+
+template <int KS, int MT, int NT, bool UNIFORM>
 __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -289,79 +485,75 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs a) {
   const int bid = xcd_remap(blockIdx.x, a.nblocks);
   const int cb = bid % a.ncb;
   const int pblk = bid / a.ncb;
-  {
-    const bf16x8* wsrc = reinterpret_cast<const bf16x8*>(a.wpk) + (size_t)cb * a.ksteps * MT * 64;
-    bf16x8* wdst = reinterpret_cast<bf16x8*>(smem);
-    const int nw = a.ksteps * MT * 64;
-    for (int i = tid; i < nw; i += 256) wdst[i] = wsrc[i];
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.in + a.in_coff), (short)0, (a.dbg & 1) ? 0 : a.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rout =
+      __builtin_amdgcn_make_buffer_rsrc(a.out, (short)0, (a.dbg & 2) ? 0 : a.out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rres =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.res, (short)0, a.res ? a.res_bytes : 0, 0x00020000);
+  // Activation fragments ride a ring of D k-steps (D*NT = 8 sixteen-byte loads in flight per lane,
+  // refilled right after the MFMAs that consumed a slot); filter fragments come from LDS one step
+  // ahead.  The first ring fill of a patch is issued BEFORE the filter slab is staged (first patch)
+  // or before the previous patch's epilogue stores, so its latency is always covered.
+  constexpr int D = NT >= 4 ? 2 : (NT == 2 ? 4 : 8);
+  bf16x8 xr[D][NT], wv[2][MT];
+  Patch<NT> P;
+  KCursor cur;
+  int patch = pblk * a.ppw * 4 + wave;
+  bool live = patch < a.npatches;
+  if (live) {
+    patch_setup<KS, NT>(a, patch, n, P);
+    cur = cursor_begin<KS>(a);
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+      if (d < a.ksteps) fetch_b<KS, NT, UNIFORM>(a, rin, cur, g, P, xr[d]);
   }
+  // per-lane bias of its 4 rows of every channel tile (the accumulators start from it)
+  f32x4 bias_r[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+    bias_r[mt] = *reinterpret_cast<const f32x4*>(a.bias + cb * MT * 16 + chan_in_block(MT, mt, g, 0));
+  if (!(a.dbg & 4))
+    copy_slab(reinterpret_cast<const bf16x8*>(a.wpk) + (size_t)cb * a.ksteps * MT * 64,
+              reinterpret_cast<bf16x8*>(smem), a.ksteps * MT * 64, tid);
   __syncthreads();
   const bf16x8* wl = reinterpret_cast<const bf16x8*>(smem) + lane;
-  constexpr int PH = 2 * NT;  // patch = PH x 8 pixels
-
-  for (int pp = 0; pp < a.ppw; ++pp) {
-    int patch = (pblk * a.ppw + pp) * 4 + wave;
-    if (patch >= a.npatches) break;
-    const int px_i = patch % a.tiles_x;
-    patch /= a.tiles_x;
-    const int py_i = patch % a.tiles_y;
-    const int b = patch / a.tiles_y;
-    const int oy0 = py_i * PH, ox0 = px_i * 8;
-    const __bf16* img = a.in + (long long)b * a.in_img + a.in_coff;
-
-    int base[NT], opix[NT];
-    unsigned mask[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int idx = nt * 16 + n;
-      const int oy = oy0 + (idx >> 3), ox = ox0 + (idx & 7);
-      const bool valid = oy < a.Ho && ox < a.Wo;
-      const int cy = oy * a.stride, cx = ox * a.stride;
-      base[nt] = (cy * a.W + cx) * a.in_pitch;
-      unsigned m = 0;
-      if (valid) {
-        if (KS == 1) {
-          m = 1u;
-        } else {
-#pragma unroll
-          for (int t = 0; t < 9; ++t) {
-            const int iy = cy + t / 3 - 1, ix = cx + t % 3 - 1;
-            if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) m |= 1u << t;
-          }
-        }
-      }
-      mask[nt] = m;
-      opix[nt] = valid ? oy * a.Wo + ox : -1;
-    }
-
+  for (int pp = 0; pp < a.ppw && live; ++pp) {
     f32x4 acc[MT][NT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    bf16x8 x0[NT], x1[NT], w0[MT], w1[MT];
-    fetch_b<KS, NT>(a, img, 0, g, base, mask, x0);
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = bias_r[mt];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) w0[mt] = wl[mt * 64];
-    for (int ks = 0; ks < a.ksteps; ks += 2) {
-      const bool has1 = ks + 1 < a.ksteps;
-      if (has1) {
-        fetch_b<KS, NT>(a, img, ks + 1, g, base, mask, x1);
+    for (int mt = 0; mt < MT; ++mt) wv[0][mt] = wl[mt * 64];
+    for (int ks0 = 0; ks0 < a.ksteps; ks0 += D) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) w1[mt] = wl[((ks + 1) * MT + mt) * 64];
-      }
-      mma_step<MT, NT>(w0, x0, acc);
-      if (has1) {
-        if (ks + 2 < a.ksteps) {
-          fetch_b<KS, NT>(a, img, ks + 2, g, base, mask, x0);
+      for (int d = 0; d < D; ++d) {
+        const int ks = ks0 + d;
+        if (ks < a.ksteps) {
+          if (ks + 1 < a.ksteps) {
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) w0[mt] = wl[((ks + 2) * MT + mt) * 64];
+            for (int mt = 0; mt < MT; ++mt) wv[(d + 1) & 1][mt] = wl[((ks + 1) * MT + mt) * 64];
+          }
+          mma_step<MT, NT>(wv[d & 1], xr[d], acc);
+          if (ks + D < a.ksteps) fetch_b<KS, NT, UNIFORM>(a, rin, cur, g, P, xr[d]);
         }
-        mma_step<MT, NT>(w1, x1, acc);
       }
     }
-    epilogue<MT, NT>(a, cb, b, g, opix, acc);
+    // next patch: descriptors + first ring fill go out before this patch's stores
+    int opix[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) opix[nt] = P.gp[nt];
+    patch += 4;
+    live = (pp + 1 < a.ppw) && patch < a.npatches;
+    if (live) {
+      patch_setup<KS, NT>(a, patch, n, P);
+      cur = cursor_begin<KS>(a);
+#pragma unroll
+      for (int d = 0; d < D; ++d)
+        if (d < a.ksteps) fetch_b<KS, NT, UNIFORM>(a, rin, cur, g, P, xr[d]);
+    }
+    epilogue_buf<MT, NT>(a, rout, rres, cb, g, opix, acc);
   }
 }
 
@@ -394,11 +586,8 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(ConvArgs a) {
   for (int chunk = 0; chunk < a.nchunks; ++chunk) {
     if (chunk) __syncthreads();
     stage_load(a, inb + chunk * a.cch, iy0, ix0, sg, sp0, ppass, HP, pre);
-    {
-      const bf16x8* wsrc = reinterpret_cast<const bf16x8*>(a.wpk) + ((size_t)cb * a.nchunks + chunk) * wstride;
-      bf16x8* wdst = reinterpret_cast<bf16x8*>(smem);
-      for (int i = tid; i < wstride; i += 256) wdst[i] = wsrc[i];
-    }
+    copy_slab(reinterpret_cast<const bf16x8*>(a.wpk) + ((size_t)cb * a.nchunks + chunk) * wstride,
+              reinterpret_cast<bf16x8*>(smem), wstride, tid);
     stage_store(a, halo, sg, sp0, ppass, HP, pre);
     __syncthreads();
     kloop<KS, MT, NT, UNIFORM>(a, halo, reinterpret_cast<const bf16x8*>(smem) + lane, g, pixoff, acc);
@@ -413,7 +602,7 @@ static const size_t LDS_MAX = 160 * 1024;     // per CU and per workgroup on gfx
 static const size_t W_STATIONARY_MAX = 80 * 1024;
 static const int NUM_CU = 256;
 
-int conv_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, ConvConfig* c) {
+int conv_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, int aligned8, ConvConfig* c) {
   if ((k != 1 && k != 3) || (stride != 1 && stride != 2) || Cin % 8 || Cin <= 0 || Cout <= 0)
     return fail(-3, "conv: unsupported geometry (k in {1,3}, stride in {1,2}, Cin % 8 == 0)");
   const int cout16 = (Cout + 15) / 16;
@@ -444,11 +633,14 @@ int conv_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo,
     const size_t slab_max = getenv("YL_CONV_SLAB_KB") ? (size_t)atoi(getenv("YL_CONV_SLAB_KB")) * 1024 : 72 * 1024;
     const int cg = Cin / 8;
     const int ksteps = (ntaps * cg + 3) / 4;
-    for (int mi = 0; mi < nmt && !(env && !strcmp(env, "tile")); ++mi) {
+    // the direct kernel stores 16 bytes per lane: every channel count / pitch / offset must be a
+    // multiple of 8 (true for all YOLO11 scales unless nc is odd-sized); otherwise the tile kernel runs
+    for (int mi = 0; mi < nmt && aligned8 && !(env && !strcmp(env, "tile")); ++mi) {
       const int MT = mts[mi];
       if ((size_t)ksteps * MT * 1024 > slab_max) continue;
       const int ncb = cout16 / MT;
-      auto npatches = [&](int nt) { return (long long)batch * ((Ho + 2 * nt - 1) / (2 * nt)) * ((Wo + 7) / 8); };
+      const long long npix = (long long)batch * Ho * Wo;
+      auto npatches = [&](int nt) { return (npix + 16 * nt - 1) / (16 * nt); };
       int NT = 1;
       if (npatches(4) * ncb / 4 >= 4 * NUM_CU) NT = 4;
       else if (npatches(2) * ncb / 4 >= 2 * NUM_CU) NT = 2;
@@ -457,16 +649,15 @@ int conv_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo,
       c->MT = MT;
       c->ncb = ncb;
       c->NT = NT;
-      c->TH = 2 * NT;
-      c->TW = 8;
+      c->TH = 1;
+      c->TW = 16 * NT;
       c->HH = c->HW = 0;
-      c->tiles_x = (Wo + 7) / 8;
-      c->tiles_y = (Ho + 2 * NT - 1) / (2 * NT);
+      c->tiles_x = c->tiles_y = 0;
       c->cch = Cin;
       c->cg = cg;
       c->lg2 = 0;
       c->nchunks = 1;
-      c->uniform = 0;
+      c->uniform = (cg % 4 == 0);
       c->ksteps = ksteps;
       c->pp = 0;
       c->halo_bytes = 0;
@@ -476,9 +667,10 @@ int conv_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo,
       c->ntiles = (int)npatches(NT);
       // patches per wave: amortise the slab load while keeping >= ~8 blocks per CU in the grid
       long long blocks1 = ((long long)c->ntiles + 3) / 4 * ncb;
-      int ppw = (int)(blocks1 / (8 * NUM_CU));
+      static const int ppw_div = getenv("YL_CONV_BPC") ? atoi(getenv("YL_CONV_BPC")) : 8;  // target blocks per CU
+      int ppw = (int)(blocks1 / (ppw_div * NUM_CU));
       if (ppw < 1) ppw = 1;
-      if (ppw > 8) ppw = 8;
+      if (ppw > 32) ppw = 32;
       c->ppw = ppw;
       c->gws = (int)(((long long)c->ntiles + 4 * ppw - 1) / (4 * ppw));
       c->name = k == 3 ? (stride == 2 ? "conv3x3s2_mfma" : "conv3x3_mfma") : "conv1x1_mfma";
@@ -600,8 +792,7 @@ void conv_pack_weights(const float* w, int Cout, int Cin_w, int Cin_pad, int k, 
 template <int KS, int MT, int NT, bool U>
 static int launch_t(const ConvConfig& cfg, const ConvArgs& a, hipStream_t s) {
   if (cfg.ws == 2) {
-    if (U) return fail(-3, "conv: direct kernel has no uniform variant");
-    auto kern = conv_direct_kernel<KS, MT, NT>;
+    auto kern = conv_direct_kernel<KS, MT, NT, U>;
     static size_t attr = 0;  // per instantiation: largest dynamic LDS size enabled so far
     if (cfg.lds_bytes > attr) {
       YL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -646,7 +837,6 @@ static int launch_m(const ConvConfig& cfg, const ConvArgs& a, hipStream_t s) {
 }
 
 int conv_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s) {
-  (void)batch;
   a.TH = cfg.TH;
   a.TW = cfg.TW;
   a.tiles_x = cfg.tiles_x;
@@ -670,7 +860,24 @@ int conv_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s) {
   a.magic_hw = magic_of(cfg.HW);
   a.magic_tw = magic_of(cfg.TW);
   a.magic_cg = magic_of(cfg.cg);
+  a.magic_wo = magic_of(a.Wo);
+  a.magic_ho = magic_of(a.Ho);
+  a.npix = batch * a.Ho * a.Wo;
+  {
+    const long long inb = ((long long)batch * a.in_img - a.in_coff) * 2;
+    const long long outb = (long long)batch * a.out_img * (a.out_f32 ? 4 : 2);
+    const long long resb = (long long)batch * a.res_img * 2;
+    if (cfg.ws == 2 && (inb >= (1LL << 31) || outb >= (1LL << 31) || resb >= (1LL << 31)))
+      return fail(-3, "conv: tensor too large for 32-bit buffer offsets");
+    a.in_bytes = (unsigned)inb;
+    a.out_bytes = (unsigned)outb;
+    a.res_bytes = (unsigned)resb;
+  }
   a.nblocks = cfg.gws * cfg.ncb;
+  {
+    static const int dbg = getenv("YL_CONV_DBG") ? atoi(getenv("YL_CONV_DBG")) : 0;  // ablation, dev only
+    a.dbg = dbg;
+  }
   return cfg.ntaps == 9 ? launch_m<3>(cfg, a, s) : launch_m<1>(cfg, a, s);
 }
 

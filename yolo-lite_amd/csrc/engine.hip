@@ -140,7 +140,9 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
         }
         // weight Cin may be smaller than the (padded) input view channels: stem 3 -> 8
         const int cin_w = o.cin_weight > 0 ? o.cin_weight : o.in.C;
-        if (int rc = conv_choose(batch, o.in.C, o.out.C, o.k, o.stride, Ho, Wo, &r.cfg)) return rc;
+        const int al8 = ((o.out.C | o.out.pitch | o.out.coff) & 7) == 0 &&
+                        (o.res.offset < 0 || ((o.res.pitch | o.res.coff) & 7) == 0);
+        if (int rc = conv_choose(batch, o.in.C, o.out.C, o.k, o.stride, Ho, Wo, al8, &r.cfg)) return rc;
         std::vector<uint16_t> pk;
         conv_pack_weights(o.weight, o.out.C, cin_w, o.in.C, o.k, r.cfg, &pk);
         uint16_t* d = nullptr;

@@ -5,7 +5,9 @@
 
 namespace yl {
 
-__device__ __forceinline__ float silu_g(float v) { return v / (1.0f + __expf(-v)); }
+__device__ __forceinline__ float silu_g(float v) {  // hardware exp2 / rcp, see conv_mfma.hip
+  return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * v));
+}
 
 // ------------------------------------------------------------------ input NCHW -> NHWC bf16 (C=8)
 // engine/predictor.py:67-85 (preprocess: .float(), /255 for uint8 sources); channels 3..7 are zero.
@@ -48,60 +50,91 @@ int convert_input_launch(const void* in, int in_dtype, __bf16* out, int batch, i
 // ------------------------------------------------------------------------------ depthwise 3x3
 // nn/modules/conv.py:100-105 (DWConv, groups = C) with folded BN; optional SiLU; optional
 // accumulate (x = attn_out + pe(v), nn/modules/block.py:913) and the per-head v channel map.
-__global__ void dwconv3_kernel(DwArgs a) {
+// One thread = 8 channels x 4 consecutive output pixels of a row: the 3 x 6 input window and the
+// 9 x 8 filter taps are loaded once and reused (9 sixteen-byte loads per output instead of 27).
+constexpr int DW_PX = 4;
+__global__ __launch_bounds__(256) void dwconv3_kernel(DwArgs a) {
   const int cg = a.C >> 3;
-  const long long total = (long long)a.batch * a.H * a.W * cg;
+  const int wq = (a.W + DW_PX - 1) / DW_PX;
+  const long long total = (long long)a.batch * a.H * wq * cg;
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
   const int g8 = (int)(i % cg);
   long long p = i / cg;
-  const int x = (int)(p % a.W);
-  p /= a.W;
+  const int x0 = (int)(p % wq) * DW_PX;
+  p /= wq;
   const int y = (int)(p % a.H);
   const int b = (int)(p / a.H);
   const int c = g8 * 8;
   const int cin = a.grp ? (c / a.grp) * a.grp_stride + a.grp_off + (c % a.grp) : c;
   const __bf16* inb = a.in + (long long)b * a.in_img + a.in_coff + cin;
-  float acc[8];
+  float acc[DW_PX][8];
+  {
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias + c), b1 = *reinterpret_cast<const f32x4*>(a.bias + c + 4);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) acc[j] = a.bias[c + j];
+    for (int q = 0; q < DW_PX; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[q][j] = b0[j];
+        acc[q][4 + j] = b1[j];
+      }
+  }
 #pragma unroll
   for (int kh = 0; kh < 3; ++kh) {
     const int iy = y + kh - 1;
     if ((unsigned)iy >= (unsigned)a.H) continue;
+    float wrow[3][8];
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) {
-      const int ix = x + kw - 1;
-      if ((unsigned)ix >= (unsigned)a.W) continue;
-      const bf16x8 v = *reinterpret_cast<const bf16x8*>(inb + (long long)(iy * a.W + ix) * a.in_pitch);
       const float* wp = a.w + (kh * 3 + kw) * a.C + c;
-      const f32x4 w0 = *reinterpret_cast<const f32x4*>(wp);
-      const f32x4 w1 = *reinterpret_cast<const f32x4*>(wp + 4);
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(wp), w1 = *reinterpret_cast<const f32x4*>(wp + 4);
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        acc[j] += (float)v[j] * w0[j];
-        acc[4 + j] += (float)v[4 + j] * w1[j];
+        wrow[kw][j] = w0[j];
+        wrow[kw][4 + j] = w1[j];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < DW_PX + 2; ++t) {  // input column x0 - 1 + t feeds outputs q = t - kw
+      const int ix = x0 - 1 + t;
+      if ((unsigned)ix >= (unsigned)a.W) continue;
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(inb + (long long)(iy * a.W + ix) * a.in_pitch);
+      float f[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = (float)v[j];
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int q = t - kw;
+        if (q >= 0 && q < DW_PX) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[q][j] += f[j] * wrow[kw][j];
+        }
       }
     }
   }
-  __bf16* op = a.out + (long long)b * a.out_img + (long long)(y * a.W + x) * a.out_pitch + a.out_coff + c;
-  bf16x8 o;
-  if (a.accumulate) {
-    const bf16x8 prev = *reinterpret_cast<const bf16x8*>(op);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (__bf16)((a.act ? silu_g(acc[j]) : acc[j]) + (float)prev[j]);
-  } else {
+  for (int q = 0; q < DW_PX; ++q) {
+    const int x = x0 + q;
+    if (x >= a.W) break;
+    __bf16* op = a.out + (long long)b * a.out_img + (long long)(y * a.W + x) * a.out_pitch + a.out_coff + c;
+    bf16x8 o;
+    if (a.accumulate) {
+      const bf16x8 prev = *reinterpret_cast<const bf16x8*>(op);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (__bf16)(a.act ? silu_g(acc[j]) : acc[j]);
+      for (int j = 0; j < 8; ++j) o[j] = (__bf16)((a.act ? silu_g(acc[q][j]) : acc[q][j]) + (float)prev[j]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (__bf16)(a.act ? silu_g(acc[q][j]) : acc[q][j]);
+    }
+    *reinterpret_cast<bf16x8*>(op) = o;
   }
-  *reinterpret_cast<bf16x8*>(op) = o;
 }
 
 int dwconv3_launch(const DwArgs& a, hipStream_t s) {
   if (a.C % 8 || a.in_pitch % 8 || a.in_coff % 8 || a.out_pitch % 8 || a.out_coff % 8 ||
       (a.grp && (a.grp % 8 || a.grp_stride % 8 || a.grp_off % 8)))
     return fail(-3, "dwconv3: channels/pitches must be multiples of 8");
-  const long long total = (long long)a.batch * a.H * a.W * (a.C / 8);
+  const long long total = (long long)a.batch * a.H * ((a.W + DW_PX - 1) / DW_PX) * (a.C / 8);
   hipLaunchKernelGGL(dwconv3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
   YL_HIP(hipGetLastError());
   return 0;
@@ -443,8 +476,18 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
   const int no = 64 + a.nc, pitch = no + 1;
   float* sdist = sraw + DEC_ANCH * pitch;  // [4][64]
   const float* raw = L.raw + ((long long)b * HW + p0) * no;
-  for (int r = wave; r < nv; r += 4)
-    for (int c = lane; c < no; c += 64) sraw[r * pitch + c] = raw[(long long)r * no + c];
+  if ((no & 3) == 0) {  // the chunk is one contiguous run: 16-byte loads
+    const int n4 = nv * no / 4;
+    for (int i = tid; i < n4; i += 256) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(raw + 4LL * i);
+      const int e = 4 * i, r = e / no, c = e - r * no;
+      float* d = sraw + r * pitch + c;
+      d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+    }
+  } else {
+    for (int r = wave; r < nv; r += 4)
+      for (int c = lane; c < no; c += 64) sraw[r * pitch + c] = raw[(long long)r * no + c];
+  }
   __syncthreads();
   // DFL: thread = (anchor, side)
   {

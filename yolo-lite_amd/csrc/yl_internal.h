@@ -44,8 +44,11 @@ struct ConvArgs {
   int halo_lds_off, halo_bytes;  // LDS: [filter slab][halo buffer(s)]
   int ntiles, gws;               // pixel tiles in total / blocks per output-channel block
   int npatches, ppw;             // direct kernel: wave patches in total / patches per wave
-  unsigned magic_hw, magic_tw, magic_cg;  // ceil(2^32 / x) for small-number division
+  unsigned magic_hw, magic_tw, magic_cg, magic_wo, magic_ho;  // ceil(2^32 / x) for small-number division
+  int npix;                      // direct kernel: batch * Ho * Wo
+  unsigned in_bytes, out_bytes, res_bytes;  // buffer-descriptor sizes (bytes past the base pointers)
   int nblocks;
+  int dbg;  // development ablation flags (YL_CONV_DBG), 0 in production
 };
 
 struct ConvConfig {
@@ -58,7 +61,7 @@ struct ConvConfig {
 };
 
 // Chooses the tiling for one conv; returns <0 when unsupported.
-int conv_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, ConvConfig* cfg);
+int conv_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, int aligned8, ConvConfig* cfg);
 // Packs folded fp32 OIHW weights into the fragment order cfg describes (host).
 void conv_pack_weights(const float* w_oihw, int Cout, int Cin_w, int Cin_pad, int k, const ConvConfig& cfg,
                        std::vector<uint16_t>* out);

@@ -71,8 +71,11 @@ class HipEngine:
 
     @classmethod
     def from_model(cls, specs: Sequence[LayerSpec], state_dict: Dict[str, torch.Tensor], batch: int, in_h: int,
-                   in_w: int, device: torch.device, strides: Sequence[float] = (8.0, 16.0, 32.0)) -> "HipEngine":
-        return cls(lower(specs, state_dict, batch, in_h, in_w, strides), device)
+                   in_w: int, device: torch.device, strides: Sequence[float] = (8.0, 16.0, 32.0),
+                   keep_layers: bool = False) -> "HipEngine":
+        """``keep_layers=True`` gives every layer its own buffer (debug: ``layer_output``); the default
+        recycles dead buffers so consecutive layers hand tensors over through the Infinity Cache."""
+        return cls(lower(specs, state_dict, batch, in_h, in_w, strides, reuse=not keep_layers), device)
 
     def __del__(self):
         h = getattr(self, "_h", None)
