@@ -311,13 +311,10 @@ __device__ __forceinline__ void patch_setup(const ConvArgs& a, int patch, int n,
   }
 }
 
-// Fetch cursor: walks the k-steps in order.  In the UNIFORM case (Cin % 32 == 0) a k-step lies
-// inside one tap, so tap / channel block / tap offset are wave-uniform scalars and the per-lane
-// work is an add, a bit test and a select per load; otherwise (tap, channel group) are per lane.
-struct KCursor {
-  int ks, tap, kk, off;  // off: byte offset of the current tap
-};
-
+// B-fragment fetch of k-step `ks` (wave-uniform).  In the UNIFORM case (Cin % 32 == 0) a k-step lies
+// inside one tap, so tap / channel block / tap byte offset are scalars and the per-lane work is a bit
+// test, a select and an add per load; otherwise (tap, channel group) are derived per lane.  K-steps
+// past the end (ring refills, padding) select the out-of-range offset and return zeros.
 template <int KS>
 __device__ __forceinline__ int tap_offset(const ConvArgs& a, int tap) {  // bytes
   if (KS == 1) return 0;
@@ -326,22 +323,19 @@ __device__ __forceinline__ int tap_offset(const ConvArgs& a, int tap) {  // byte
 }
 
 template <int KS, int NT, bool UNIFORM>
-__device__ __forceinline__ void fetch_b(const ConvArgs& a, __amdgpu_buffer_rsrc_t rin, KCursor& c, int g,
+__device__ __forceinline__ void fetch_b(const ConvArgs& a, __amdgpu_buffer_rsrc_t rin, int ks, int g,
                                         const Patch<NT>& P, bf16x8 (&xb)[NT]) {
   if (UNIFORM) {
-    const unsigned off = (unsigned)(c.off + c.kk * 64 + g * 16);
+    const int tap = fastdiv(ks, a.kkn, a.magic_kkn);
+    const int kk = ks - tap * a.kkn;
+    const unsigned off = (unsigned)(tap_offset<KS>(a, tap) + kk * 64) + (unsigned)(g * 16);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const unsigned vo = ((P.mask[nt] >> c.tap) & 1u) ? P.base[nt] + off : OOB;
+      const unsigned vo = ((P.mask[nt] >> tap) & 1u) ? P.base[nt] + off : OOB;
       xb[nt] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rin, vo, 0, 0));
     }
-    if (++c.kk == (a.cg >> 2)) {
-      c.kk = 0;
-      ++c.tap;
-      c.off = tap_offset<KS>(a, c.tap);
-    }
   } else {
-    const int k8 = c.ks * 4 + g;
+    const int k8 = ks * 4 + g;
     const int tap = KS == 1 ? 0 : fastdiv(k8, a.cg, a.magic_cg);
     const int c8 = k8 - tap * a.cg;
     const bool kvalid = KS == 1 ? (k8 < a.cg) : (tap < KS * KS);
@@ -352,17 +346,6 @@ __device__ __forceinline__ void fetch_b(const ConvArgs& a, __amdgpu_buffer_rsrc_
       xb[nt] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rin, vo, 0, 0));
     }
   }
-  ++c.ks;
-}
-
-template <int KS>
-__device__ __forceinline__ KCursor cursor_begin(const ConvArgs& a) {
-  KCursor c;
-  c.ks = 0;
-  c.tap = 0;
-  c.kk = 0;
-  c.off = tap_offset<KS>(a, 0);
-  return c;
 }
 
 template <int MT, int NT>
@@ -498,15 +481,13 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs a) {
   constexpr int D = NT >= 4 ? 2 : (NT == 2 ? 4 : 8);
   bf16x8 xr[D][NT], wv[2][MT];
   Patch<NT> P;
-  KCursor cur;
-  int patch = pblk * a.ppw * 4 + wave;
+  // wave-uniform values are forced into SGPRs so the k-loop bookkeeping stays on the scalar unit
+  int patch = __builtin_amdgcn_readfirstlane(pblk * a.ppw * 4 + wave);
   bool live = patch < a.npatches;
   if (live) {
     patch_setup<KS, NT>(a, patch, n, P);
-    cur = cursor_begin<KS>(a);
 #pragma unroll
-    for (int d = 0; d < D; ++d)
-      if (d < a.ksteps) fetch_b<KS, NT, UNIFORM>(a, rin, cur, g, P, xr[d]);
+    for (int d = 0; d < D; ++d) fetch_b<KS, NT, UNIFORM>(a, rin, d, g, P, xr[d]);
   }
   // per-lane bias of its 4 rows of every channel tile (the accumulators start from it)
   f32x4 bias_r[MT];
@@ -518,6 +499,7 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs a) {
               reinterpret_cast<bf16x8*>(smem), a.ksteps * MT * 64, tid);
   __syncthreads();
   const bf16x8* wl = reinterpret_cast<const bf16x8*>(smem) + lane;
+
   for (int pp = 0; pp < a.ppw && live; ++pp) {
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -526,18 +508,31 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs a) {
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = bias_r[mt];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) wv[0][mt] = wl[mt * 64];
-    for (int ks0 = 0; ks0 < a.ksteps; ks0 += D) {
+    // Branch-free main loop over whole groups of D k-steps: ring refills past the end resolve to
+    // out-of-range offsets (zeros, no memory access) and the `ks + 1` filter prefetch is clamped, so
+    // the body is straight-line code and the compiler keeps counted vmcnt waits (the D-deep ring
+    // really stays in flight).  The < D leftover steps run in a predicated tail.
+    const int klast = a.ksteps - 1;
+    int ks0 = 0;
+    for (; ks0 + D <= a.ksteps; ks0 += D) {
 #pragma unroll
       for (int d = 0; d < D; ++d) {
         const int ks = ks0 + d;
-        if (ks < a.ksteps) {
-          if (ks + 1 < a.ksteps) {
+        const int kn = min(ks + 1, klast);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) wv[(d + 1) & 1][mt] = wl[((ks + 1) * MT + mt) * 64];
-          }
-          mma_step<MT, NT>(wv[d & 1], xr[d], acc);
-          if (ks + D < a.ksteps) fetch_b<KS, NT, UNIFORM>(a, rin, cur, g, P, xr[d]);
-        }
+        for (int mt = 0; mt < MT; ++mt) wv[(d + 1) & 1][mt] = wl[(kn * MT + mt) * 64];
+        mma_step<MT, NT>(wv[d & 1], xr[d], acc);
+        fetch_b<KS, NT, UNIFORM>(a, rin, ks + D, g, P, xr[d]);
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d) {
+      const int ks = ks0 + d;
+      if (ks < a.ksteps) {
+        const int kn = min(ks + 1, klast);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) wv[(d + 1) & 1][mt] = wl[(kn * MT + mt) * 64];
+        mma_step<MT, NT>(wv[d & 1], xr[d], acc);
       }
     }
     // next patch: descriptors + first ring fill go out before this patch's stores
@@ -548,10 +543,8 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs a) {
     live = (pp + 1 < a.ppw) && patch < a.npatches;
     if (live) {
       patch_setup<KS, NT>(a, patch, n, P);
-      cur = cursor_begin<KS>(a);
 #pragma unroll
-      for (int d = 0; d < D; ++d)
-        if (d < a.ksteps) fetch_b<KS, NT, UNIFORM>(a, rin, cur, g, P, xr[d]);
+      for (int d = 0; d < D; ++d) fetch_b<KS, NT, UNIFORM>(a, rin, d, g, P, xr[d]);
     }
     epilogue_buf<MT, NT>(a, rout, rres, cb, g, opix, acc);
   }
@@ -658,12 +651,13 @@ int conv_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo,
       c->lg2 = 0;
       c->nchunks = 1;
       c->uniform = (cg % 4 == 0);
+      c->kloop = ksteps;
       c->ksteps = ksteps;
       c->pp = 0;
       c->halo_bytes = 0;
       c->halo_lds_off = 0;
-      c->lds_bytes = (size_t)ksteps * MT * 1024;
-      c->wpk_elems = (size_t)ncb * ksteps * MT * 64 * 8;
+      c->lds_bytes = (size_t)c->ksteps * MT * 1024;
+      c->wpk_elems = (size_t)ncb * c->ksteps * MT * 64 * 8;
       c->ntiles = (int)npatches(NT);
       // patches per wave: amortise the slab load while keeping >= ~8 blocks per CU in the grid
       long long blocks1 = ((long long)c->ntiles + 3) / 4 * ncb;
@@ -849,6 +843,9 @@ int conv_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s) {
   a.lg2 = cfg.lg2;
   a.nchunks = cfg.nchunks;
   a.ksteps = cfg.ksteps;
+  a.kloop = cfg.kloop;
+  a.kkn = cfg.cg >> 2;
+  a.magic_kkn = magic_of(cfg.cg >> 2);
   a.pp = cfg.pp;
   a.ntaps = cfg.ntaps;
   a.halo_lds_off = cfg.halo_lds_off;

@@ -44,6 +44,8 @@ struct ConvArgs {
   int halo_lds_off, halo_bytes;  // LDS: [filter slab][halo buffer(s)]
   int ntiles, gws;               // pixel tiles in total / blocks per output-channel block
   int npatches, ppw;             // direct kernel: wave patches in total / patches per wave
+  int kloop, kkn;                // direct kernel: padded k-step count of the main loop, k-steps per tap
+  unsigned magic_kkn;
   unsigned magic_hw, magic_tw, magic_cg, magic_wo, magic_ho;  // ceil(2^32 / x) for small-number division
   int npix;                      // direct kernel: batch * Ho * Wo
   unsigned in_bytes, out_bytes, res_bytes;  // buffer-descriptor sizes (bytes past the base pointers)
@@ -54,7 +56,7 @@ struct ConvArgs {
 struct ConvConfig {
   int MT, NT, uniform, ws;
   int TH, TW, tiles_x, tiles_y, ncb;
-  int HH, HW, cch, cg, lg2, nchunks, ksteps, pp, ntaps, halo_lds_off, halo_bytes, ntiles, gws, ppw;
+  int HH, HW, cch, cg, lg2, nchunks, ksteps, pp, ntaps, halo_lds_off, halo_bytes, ntiles, gws, ppw, kloop;
   size_t lds_bytes;
   size_t wpk_elems;  // packed weight elements
   const char* name;
