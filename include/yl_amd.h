@@ -62,6 +62,9 @@ typedef struct yl_op {
      grp == 0 means identity.  Used for Attention.pe on the v channels (block.py:913). */
   int32_t grp, grp_stride, grp_off;
   int32_t cin_weight; /* conv: input channels of `weight` if fewer than in.C (stem: 3 of 8); 0 = in.C */
+  int32_t lane;       /* 0 = main stream.  k > 0: side lane k -- the op starts once every earlier op of the
+                         program has finished, runs concurrently with LATER main-lane ops and is joined
+                         before the decode (the three Detect levels' box / class branches)          */
   yl_view in, out, res; /* res.offset < 0: no residual                               */
   const float* weight;
   const float* bias;

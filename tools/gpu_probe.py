@@ -58,10 +58,26 @@ def main():
         a_[0] += r["ms"]
         a_[1] += 1
     print("by kernel:", ", ".join(f"{k} {v[0] * 1e3:.0f}us x{v[1]}" for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])))
+    excess_table(rows, a.top)
     rows.sort(key=lambda r: -r["ms"])
-    for r in rows[: a.top]:
+    for r in rows[: 0]:
         print(f"{r['name']:26s} {r['kernel']:16s} {r['ms'] * 1e3:8.1f} us {r['flops'] / max(r['ms'], 1e-9) / 1e9:7.1f} TF/s "
               f"{r['bytes'] / max(r['ms'], 1e-9) / 1e6:8.1f} GB/s")
+
+
+
+
+def excess_table(rows, top=40):
+    """ops ranked by time above an optimistic roofline (5 TB/s, 1.25 PFLOP/s)."""
+    out = []
+    for r in rows:
+        ideal = max(r["bytes"] / 5e12, r["flops"] / 1.25e15) * 1e3
+        out.append((r["ms"] - ideal, r["ms"], ideal, r["name"], r["kernel"]))
+    out.sort(reverse=True)
+    tot = sum(o[0] for o in out)
+    print(f"total excess over roofline: {tot * 1e3:.0f} us")
+    for ex, ms, ideal, name, k in out[:top]:
+        print(f"  {name:26s} {k:16s} {ms * 1e3:7.1f} us  ideal {ideal * 1e3:6.1f}  excess {ex * 1e3:6.1f}")
 
 
 if __name__ == "__main__":

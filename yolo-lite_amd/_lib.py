@@ -33,6 +33,7 @@ class Op(C.Structure):
                 ("accumulate", C.c_int32), ("heads", C.c_int32), ("key_dim", C.c_int32),
                 ("head_dim", C.c_int32), ("scale", C.c_float), ("grp", C.c_int32),
                 ("grp_stride", C.c_int32), ("grp_off", C.c_int32), ("cin_weight", C.c_int32),
+                ("lane", C.c_int32),
                 ("inp", View), ("out", View), ("res", View),
                 ("weight", C.c_void_p), ("bias", C.c_void_p)]
 

@@ -51,6 +51,10 @@ struct yl_engine {
   };
   std::map<GraphKey, hipGraphExec_t> graphs;
   hipStream_t cap_stream = nullptr;
+  // side lanes (yl_op.lane > 0): one non-blocking stream each + a pool of fork/join events
+  std::vector<hipStream_t> lanes;
+  std::vector<hipEvent_t> events;
+  int max_lane = 0;
 };
 
 static int64_t view_elem_size(const yl_view& v) { return v.dtype == YL_F32 ? 4 : 2; }
@@ -87,6 +91,9 @@ extern "C" void yl_engine_destroy(yl_engine* e) {
   if (!e) return;
   for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
   if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
+  for (hipStream_t st : e->lanes)
+    if (st) (void)hipStreamDestroy(st);
+  for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
   for (void* p : e->allocs) (void)hipFree(p);
   delete e;
 }
@@ -196,6 +203,8 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
       default:
         return fail(-1, tag + ": unknown op kind");
     }
+    if (o.lane < 0 || o.lane > 64) return fail(-1, tag + ": bad lane");
+    if (o.lane > e->max_lane) e->max_lane = o.lane;
     e->ops.push_back(r);
   }
   *out = e.release();
@@ -327,14 +336,52 @@ static int run_decode(const yl_engine* e, const char* ws, float* y, hipStream_t 
   return decode_launch(lv, (int)e->levels.size(), e->batch, e->nc, e->A, y, s);
 }
 
+// Side lanes: an op with lane k > 0 is launched on its own stream.  A fork event recorded on the
+// main stream at the op's program position makes it start only after EVERY earlier op (main lane
+// in order; earlier ops of the same lane by stream order), which covers its data dependencies and
+// the recycling of arena memory; it then overlaps with later main-lane ops.  All lanes are joined
+// back into the main stream before the decode.  The same calls are legal under stream capture, where
+// they become fork/join edges of the graph.
+static int lane_resources(yl_engine* e, size_t n_events) {
+  while ((int)e->lanes.size() <= e->max_lane) e->lanes.push_back(nullptr);
+  for (int k = 1; k <= e->max_lane; ++k)
+    if (!e->lanes[k]) YL_HIP(hipStreamCreateWithFlags(&e->lanes[k], hipStreamNonBlocking));
+  while (e->events.size() < n_events) {
+    hipEvent_t ev;
+    YL_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    e->events.push_back(ev);
+  }
+  return 0;
+}
+
 extern "C" int yl_engine_forward(yl_engine* e, const void* input, int in_dtype, void* workspace, float* y,
                                  void* stream) {
   if (!e || !input || !workspace) return fail(-1, "yl_engine_forward: null pointer");
   hipStream_t s = (hipStream_t)stream;
   char* ws = (char*)workspace;
+  if (e->max_lane > 0)
+    if (int rc = lane_resources(e, e->ops.size() + e->max_lane + 1)) return rc;
   if (int rc = run_convert(e, input, in_dtype, ws, s)) return rc;
-  for (const OpRec& r : e->ops)
-    if (int rc = run_op(e, r, ws, s)) return rc;
+  size_t nev = 0;
+  std::vector<char> used((size_t)e->max_lane + 1, 0);
+  for (const OpRec& r : e->ops) {
+    const int lane = r.op.lane;
+    if (lane == 0) {
+      if (int rc = run_op(e, r, ws, s)) return rc;
+    } else {
+      hipEvent_t ev = e->events[nev++];
+      YL_HIP(hipEventRecord(ev, s));
+      YL_HIP(hipStreamWaitEvent(e->lanes[lane], ev, 0));
+      if (int rc = run_op(e, r, ws, e->lanes[lane])) return rc;
+      used[lane] = 1;
+    }
+  }
+  for (int k = 1; k <= e->max_lane; ++k)
+    if (used[k]) {
+      hipEvent_t ev = e->events[nev++];
+      YL_HIP(hipEventRecord(ev, e->lanes[k]));
+      YL_HIP(hipStreamWaitEvent(s, ev, 0));
+    }
   if (y) {
     if (e->levels.empty()) return fail(-1, "yl_engine_forward: engine has no Detect levels to decode");
     if (int rc = run_decode(e, ws, y, s)) return rc;

@@ -50,6 +50,7 @@ class HipEngine:
             c.scale = o.get("scale", 0.0)
             c.grp, c.grp_stride, c.grp_off = o.get("grp", 0), o.get("grp_stride", 0), o.get("grp_off", 0)
             c.cin_weight = o.get("cin_weight", 0)
+            c.lane = o.get("lane", 0)
             c.inp, c.out, c.res = _cview(o["inp"]), _cview(o["out"]), _cview(o.get("res"))
             if "weight" in o:
                 w = np.ascontiguousarray(o["weight"], dtype=np.float32)

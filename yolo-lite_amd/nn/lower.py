@@ -92,6 +92,8 @@ def compact_arena(prog: "Program", sizes: Dict[int, int]) -> int:
     for i, o in enumerate(prog.ops):
         for k in ("inp", "out", "res"):
             touch(o.get(k), i)
+            if o.get("lane", 0):  # side lanes run concurrently with later ops: alive until the join
+                touch(o.get(k), n)
     for L in prog.levels:  # raw level maps are read by the decode after the last op
         first[L["offset"]] = min(first.get(L["offset"], n), n)
         last[L["offset"]] = n
@@ -172,7 +174,7 @@ def _out_hw(h: int, w: int, k: int, s: int) -> Tuple[int, int]:
 
 
 def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, in_h: int, in_w: int,
-          strides: Sequence[float] = (8.0, 16.0, 32.0), reuse: bool = True) -> Program:
+          strides: Sequence[float] = (8.0, 16.0, 32.0), reuse: bool = True, side_lanes: bool = True) -> Program:
     det = specs[-1]
     assert det.kind == "Detect"
     prog = Program(batch, in_h, in_w, det.nc, strides=tuple(float(s) for s in strides))
@@ -250,6 +252,37 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
             bottleneck(f"{p}.m.{j}", a, a, c_)
         conv(p + ".cv3", u, y, 1, 1)
 
+    # ---- Detect (head.py:29-69): box branch cv2, class branch cv3, raw level maps in fp32.
+    # Each level's two branches are emitted right after the layer that feeds them, on side lanes:
+    # they only depend on that layer, so the engine runs them concurrently with the rest of the
+    # neck (whose 20x20 / 40x40 layers cannot fill the chip by themselves).
+    dp = f"model.{det.i}"
+    c2, c3 = detect_mid_channels(det.c1, det.nc)
+    level_of = {j: lvl for lvl, j in enumerate(det.f)}
+    level_rec: Dict[int, dict] = {}
+
+    def emit_level(lvl: int, xin: TView):
+        h, w = xin.H, xin.W
+        head = ar.alloc(h, w, 64 + det.nc, F32)
+        n0 = len(ops)
+        t1, t2 = ar.alloc(h, w, c2), ar.alloc(h, w, c2)
+        conv(f"{dp}.cv2.{lvl}.0", xin, t1, 3, 1)
+        conv(f"{dp}.cv2.{lvl}.1", t1, t2, 3, 1)
+        conv(f"{dp}.cv2.{lvl}.2", t2, head.slice(0, 64), 1, 1, act=False, bn=False)
+        for o in ops[n0:]:
+            o["lane"] = 1 + 2 * lvl if side_lanes else 0
+        n1 = len(ops)
+        d1, e1 = ar.alloc(h, w, xin.C), ar.alloc(h, w, c3)
+        dwconv(f"{dp}.cv3.{lvl}.0.0", xin, d1)
+        conv(f"{dp}.cv3.{lvl}.0.1", d1, e1, 1, 1)
+        d2, e2 = ar.alloc(h, w, c3), ar.alloc(h, w, c3)
+        dwconv(f"{dp}.cv3.{lvl}.1.0", e1, d2)
+        conv(f"{dp}.cv3.{lvl}.1.1", d2, e2, 1, 1)
+        conv(f"{dp}.cv3.{lvl}.2", e2, head.slice(64, det.nc), 1, 1, act=False, bn=False)
+        for o in ops[n1:]:
+            o["lane"] = 2 + 2 * lvl if side_lanes else 0
+        level_rec[lvl] = dict(offset=head.offset, H=h, W=w, stride=float(strides[lvl]))
+
     views: Dict[int, TView] = {}
     prog.input_view = ar.alloc(in_h, in_w, 8)
     x = prog.input_view
@@ -314,28 +347,13 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
             raise NotImplementedError(sp.kind)
         views[sp.i] = y
         x = y
+        if sp.i in level_of:
+            emit_level(level_of[sp.i], y)
 
-    # ---- Detect (head.py:29-69): box branch cv2, class branch cv3, raw level maps in fp32
-    p = f"model.{det.i}"
-    c2, c3 = detect_mid_channels(det.c1, det.nc)
     a_total = 0
-    for lvl, j in enumerate(det.f):
-        xin = views[j]
-        h, w = xin.H, xin.W
-        head = ar.alloc(h, w, 64 + det.nc, F32)
-        t1, t2 = ar.alloc(h, w, c2), ar.alloc(h, w, c2)
-        conv(f"{p}.cv2.{lvl}.0", xin, t1, 3, 1)
-        conv(f"{p}.cv2.{lvl}.1", t1, t2, 3, 1)
-        conv(f"{p}.cv2.{lvl}.2", t2, head.slice(0, 64), 1, 1, act=False, bn=False)
-        d1, e1 = ar.alloc(h, w, xin.C), ar.alloc(h, w, c3)
-        dwconv(f"{p}.cv3.{lvl}.0.0", xin, d1)
-        conv(f"{p}.cv3.{lvl}.0.1", d1, e1, 1, 1)
-        d2, e2 = ar.alloc(h, w, c3), ar.alloc(h, w, c3)
-        dwconv(f"{p}.cv3.{lvl}.1.0", e1, d2)
-        conv(f"{p}.cv3.{lvl}.1.1", d2, e2, 1, 1)
-        conv(f"{p}.cv3.{lvl}.2", e2, head.slice(64, det.nc), 1, 1, act=False, bn=False)
-        prog.levels.append(dict(offset=head.offset, H=h, W=w, stride=float(strides[lvl])))
-        a_total += h * w
+    for lvl in range(len(det.f)):
+        prog.levels.append(level_rec[lvl])
+        a_total += level_rec[lvl]["H"] * level_rec[lvl]["W"]
     prog.anchors = a_total
     prog.layer_views = views
     prog.ws_bytes = (compact_arena(prog, ar.sizes) if reuse else ar.top) + 256
