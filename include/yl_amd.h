@@ -31,7 +31,10 @@ enum {
   YL_OP_DWCONV3 = 2,  /* depthwise 3x3 stride 1, +bias, optional SiLU, optional accumulate        */
   YL_OP_SPPF_POOL = 3,/* three chained MaxPool2d(5,1,2): writes pool5/9/13 after the input slice  */
   YL_OP_UPSAMPLE = 4, /* nearest upsample by `stride` (1 = plain copy) into a channel slice        */
-  YL_OP_ATTENTION = 5 /* softmax(q^T k * scale) applied to v, per head (C2PSA)                     */
+  YL_OP_ATTENTION = 5,/* softmax(q^T k * scale) applied to v, per head (C2PSA)                     */
+  YL_OP_STEM = 6      /* first layer fused with the input conversion: 3x3 stride-2 conv on the 3-channel
+                         NCHW network input (fp32 / fp16 / uint8, /255 for uint8) -> NHWC bf16; must be
+                         op 0; weight [Cout][3][3][3]                                              */
 };
 
 /* A channel-slice view of an NHWC buffer inside the workspace arena. */

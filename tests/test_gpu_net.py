@@ -72,6 +72,33 @@ def test_net_output_vs_golden(gpu_device, golden, scale, h, w, seed):
         assert rel < LAYER_REL_L2, f"raw level {i}: rel L2 {rel:.4f}"
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.uint8])
+def test_fused_stem_vs_generic_conv_and_torch(gpu_device, dtype):
+    """Layer 0 fused with the input conversion (YL_OP_STEM) against (a) the convert + generic MFMA
+    conv route and (b) torch fp32 on bf16-rounded operands (conv.py:35-53)."""
+    from yololite_amd.nn.lower import fold_conv_bn, lower
+
+    specs, _ = arch.parse_model(arch.yolo11_dict("n"))
+    sd = synth_state_dict("n", 5)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randint(0, 256, (2, 3, 64, 96), generator=g, dtype=torch.uint8)
+    xin = x if dtype == torch.uint8 else x.float() / 255
+    outs = []
+    for fused in (True, False):
+        eng = HipEngine(lower(specs, sd, 2, 64, 96, reuse=False, fused_stem=fused), gpu_device)
+        eng.forward(xin.to(gpu_device))
+        torch.cuda.synchronize()
+        outs.append(eng.layer_output(0).cpu())
+    w, b = fold_conv_bn(sd, "model.0")
+    w = torch.as_tensor(w).bfloat16().float()
+    xr = (x.float() / 255).bfloat16().float()
+    ref = torch.nn.functional.silu(torch.nn.functional.conv2d(xr, w, torch.as_tensor(b), stride=2, padding=1))
+    # bf16 output rounding (2^-8 relative) + fp32 summation-order differences
+    tol = 2.0 ** -7 * ref.abs() + 1e-3
+    assert bool(((outs[0] - ref).abs() <= tol).all())
+    assert bool(((outs[0] - outs[1]).abs() <= tol).all())
+
+
 def test_graph_replay_matches_eager(gpu_device, golden):
     sd = synth_state_dict("n", 0, cls_bias=list(golden["net_n_64x64_bias"]), cls_gain=8.0)
     x = torch.from_numpy(golden["net_n_64x64_x"]).to(gpu_device)

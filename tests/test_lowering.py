@@ -2,7 +2,7 @@
 import pytest
 
 from yololite_amd.nn import arch
-from yololite_amd.nn.lower import OP_ATTENTION, OP_CONV, OP_DWCONV3, OP_SPPF_POOL, OP_UPSAMPLE, lower
+from yololite_amd.nn.lower import OP_ATTENTION, OP_CONV, OP_DWCONV3, OP_SPPF_POOL, OP_STEM, OP_UPSAMPLE, lower
 from yololite_amd.nn.synth import synth_state_dict
 
 
@@ -14,7 +14,7 @@ def _prog(scale, b=2, h=640, w=640):
 def _conv_gflop(prog):
     f = 0.0
     for o in prog.ops:
-        if o["kind"] in (OP_CONV, OP_DWCONV3):
+        if o["kind"] in (OP_CONV, OP_DWCONV3, OP_STEM):
             w = o["weight"]
             f += 2.0 * o["out"].H * o["out"].W * w.shape[0] * w.shape[1] * w.shape[2] * w.shape[3]
     return f / 1e9
@@ -28,7 +28,7 @@ def test_algorithmic_flops_match_survey(scale, gflop, nconv):
     got = _conv_gflop(p) + 2 * 16 * 4 * p.anchors / 1e9
     assert abs(got - gflop) < 2e-3 * gflop
     # C3k cv1+cv2 pairs are merged into one launch: count reference Conv2d calls
-    calls = sum(2 if o.get("name", "").endswith("cv1+cv2") else 1 for o in p.ops if o["kind"] in (OP_CONV, OP_DWCONV3))
+    calls = sum(2 if o.get("name", "").endswith("cv1+cv2") else 1 for o in p.ops if o["kind"] in (OP_CONV, OP_DWCONV3, OP_STEM))
     assert calls + 1 == nconv  # + the DFL conv
 
 

@@ -13,7 +13,7 @@ _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "libyl_amd.so"
 
 YL_BF16, YL_F32, YL_F16, YL_U8 = 0, 1, 2, 3
-OP_CONV, OP_DWCONV3, OP_SPPF_POOL, OP_UPSAMPLE, OP_ATTENTION = 1, 2, 3, 4, 5
+OP_CONV, OP_DWCONV3, OP_SPPF_POOL, OP_UPSAMPLE, OP_ATTENTION, OP_STEM = 1, 2, 3, 4, 5, 6
 
 EXPORTS = (
     "yl_last_error", "yl_abi_version", "yl_device_count", "yl_engine_create", "yl_engine_destroy",

@@ -179,6 +179,28 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
         r.name = "dwconv3x3";
         break;
       }
+      case YL_OP_STEM: {
+        if (i != 0) return fail(-1, tag + ": the stem must be op 0");
+        if (!o.weight || !o.bias) return fail(-1, tag + ": stem needs weight and bias");
+        if (o.out.H != (in_h + 2 - 3) / 2 + 1 || o.out.W != (in_w + 2 - 3) / 2 + 1 || o.out.dtype != YL_BF16)
+          return fail(-1, tag + ": stem output dims mismatch");
+        if (o.out.C % 16 || o.out.pitch % 4 || o.out.coff % 4) return fail(-1, tag + ": stem needs Cout % 16 == 0");
+        std::vector<float> wt((size_t)o.out.C * 27);
+        for (size_t q = 0; q < wt.size(); ++q) {  // round to bf16 like every other conv filter
+          uint32_t u;
+          memcpy(&u, &o.weight[q], 4);
+          u += 0x7fffu + ((u >> 16) & 1u);
+          u &= 0xffff0000u;
+          memcpy(&wt[q], &u, 4);
+        }
+        if (int rc = dev_upload(e.get(), wt, &r.d_w)) return rc;
+        std::vector<float> bias(o.bias, o.bias + o.out.C);
+        if (int rc = dev_upload(e.get(), bias, &r.d_bias)) return rc;
+        r.flops = 2.0 * px_out * o.out.C * 27;
+        r.bytes = (double)batch * 3 * in_h * in_w * 4 + px_out * o.out.C * 2;
+        r.name = "stem_conv3x3s2";
+        break;
+      }
       case YL_OP_SPPF_POOL:
         if (o.out.pitch != o.in.pitch || o.out.offset != o.in.offset || o.in.pitch < o.in.coff + 4 * o.in.C)
           return fail(-1, tag + ": sppf pool expects one buffer holding [x | p5 | p9 | p13]");
@@ -211,7 +233,8 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
   return 0;
 }
 
-static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s) {
+static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s, const void* input = nullptr,
+                  int in_dtype = 0) {
   const yl_op& o = r.op;
   const int B = e->batch;
   switch (o.kind) {
@@ -242,6 +265,25 @@ static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s) {
       a.act = o.act;
       a.out_f32 = o.out.dtype == YL_F32;
       return conv_launch(r.cfg, a, B, s);
+    }
+    case YL_OP_STEM: {
+      if (!input) return fail(-1, "run_op: the stem needs the network input");
+      StemArgs a{};
+      a.in = input;
+      a.out = reinterpret_cast<__bf16*>(ws + o.out.offset);
+      a.w = r.d_w;
+      a.bias = r.d_bias;
+      a.out_img = (long long)o.out.H * o.out.W * o.out.pitch;
+      a.B = B;
+      a.H = e->in_h;
+      a.W = e->in_w;
+      a.Ho = o.out.H;
+      a.Wo = o.out.W;
+      a.Cout = o.out.C;
+      a.out_pitch = o.out.pitch;
+      a.out_coff = o.out.coff;
+      a.act = o.act;
+      return stem_launch(a, in_dtype, s);
     }
     case YL_OP_DWCONV3: {
       DwArgs a{};
@@ -361,13 +403,15 @@ extern "C" int yl_engine_forward(yl_engine* e, const void* input, int in_dtype, 
   char* ws = (char*)workspace;
   if (e->max_lane > 0)
     if (int rc = lane_resources(e, e->ops.size() + e->max_lane + 1)) return rc;
-  if (int rc = run_convert(e, input, in_dtype, ws, s)) return rc;
+  const bool stem = !e->ops.empty() && e->ops[0].op.kind == YL_OP_STEM;
+  if (!stem)
+    if (int rc = run_convert(e, input, in_dtype, ws, s)) return rc;
   size_t nev = 0;
   std::vector<char> used((size_t)e->max_lane + 1, 0);
   for (const OpRec& r : e->ops) {
     const int lane = r.op.lane;
     if (lane == 0) {
-      if (int rc = run_op(e, r, ws, s)) return rc;
+      if (int rc = run_op(e, r, ws, s, input, in_dtype)) return rc;
     } else {
       hipEvent_t ev = e->events[nev++];
       YL_HIP(hipEventRecord(ev, s));
@@ -452,10 +496,10 @@ extern "C" int yl_engine_profile(yl_engine* e, const void* input, int in_dtype, 
   int rc = 0;
   for (int it = 0; it < iters && !rc; ++it) {
     (void)hipEventRecord(ev[0], s);
-    rc = run_convert(e, input, in_dtype, ws, s);
+    if (e->ops[0].op.kind != YL_OP_STEM) rc = run_convert(e, input, in_dtype, ws, s);
     (void)hipEventRecord(ev[1], s);
     for (int i = 0; i < n && !rc; ++i) {
-      rc = run_op(e, e->ops[i], ws, s);
+      rc = run_op(e, e->ops[i], ws, s, input, in_dtype);
       (void)hipEventRecord(ev[i + 2], s);
     }
     if (y && !e->levels.empty() && !rc) rc = run_decode(e, ws, y, s);

@@ -47,6 +47,155 @@ int convert_input_launch(const void* in, int in_dtype, __bf16* out, int batch, i
   return 0;
 }
 
+// --------------------------------------------------------------------------------- fused stem
+// Layer 0 of yolo11.yaml (Conv 3 -> c, k 3, s 2; conv.py:35-53) fused with the predictor's input
+// conversion (predictor.py:67-85): reads the NCHW network input directly (fp32 / fp16 / uint8) and
+// writes NHWC bf16, so the 8-channel padded NHWC copy of the input is never written or re-read.
+//
+// One workgroup = one output row segment of one image (up to 64 pixels per wave).
+//   load   : the 3 channels x 3 input rows the segment needs are read as contiguous element PAIRS
+//            (ix = 2ox, 2ox+1: fully coalesced; stride-2 dword loads run at about one lane per clock on
+//            this TA), rounded to bf16 and parked in LDS with the left halo column and zero padding.
+//   compute: implicit GEMM on v_mfma_f32_16x16x32_bf16 with K = 27 taps padded to 32: A = filters
+//            (rows = 16 output channels), B = im2col patch gathered from LDS (cols = 16 pixels).
+//   store  : D gives each lane 4 consecutive channels of one pixel -> 8-byte stores, 512 contiguous
+//            bytes per instruction.
+// Numerics as the generic MFMA conv (bf16 operands, fp32 accumulate).  Bandwidth bound: 157 MB in,
+// 105 MB out at batch 32 x 640^2 (fp32 input, 16 channels).
+constexpr int STEM_MAXW = 8;  // waves per workgroup -> up to 512 output pixels per row segment
+
+template <typename T>
+struct StemPair;
+template <>
+struct StemPair<float> {
+  typedef __attribute__((ext_vector_type(2))) float type;
+};
+template <>
+struct StemPair<_Float16> {
+  typedef __attribute__((ext_vector_type(2))) _Float16 type;
+};
+template <>
+struct StemPair<uint8_t> {
+  typedef __attribute__((ext_vector_type(2))) uint8_t type;
+};
+
+template <typename T>
+__device__ __forceinline__ float stem_cvt(T v) {
+  float f = (float)v;
+  if constexpr (sizeof(T) == 1) f = f / 255.0f;  // true division, as predictor.py:84
+  return f;
+}
+
+template <typename T>
+__global__ __launch_bounds__(64 * STEM_MAXW) void stem_kernel(StemArgs a, __bf16* __restrict__ out,
+                                                              const float* __restrict__ w,
+                                                              const float* __restrict__ bias) {
+  extern __shared__ __align__(16) unsigned char stem_smem[];
+  __bf16* tile = reinterpret_cast<__bf16*>(stem_smem);  // [9 (c,kh)][row] ; col' = ix - 2*ox0 + 2
+  typedef typename StemPair<T>::type pair_t;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const int row = 2 * nthr + 8;  // bf16 elements per LDS row (even)
+  const int seg = blockIdx.x % a.nseg;
+  const int oy = (blockIdx.x / a.nseg) % a.Ho;
+  const int b = blockIdx.x / (a.nseg * a.Ho);
+  const int ox0 = seg * nthr;
+  const T* in = reinterpret_cast<const T*>(a.in) + (long long)b * 3 * a.H * a.W;
+
+  // ---- load phase: 9 coalesced pair loads per thread, then the halo column
+  {
+    const int ix0 = 2 * (ox0 + tid);
+    const bool pair_ok = ((a.W & 1) == 0) && ix0 + 1 < a.W;
+    pair_t v[9];
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+      const int c = r / 3, kh = r % 3;
+      const int iy = 2 * oy + kh - 1;
+      const T* rp = in + ((long long)c * a.H + iy) * a.W;
+      pair_t q = {(T)0, (T)0};
+      if ((unsigned)iy < (unsigned)a.H) {
+        if (pair_ok) {
+          q = *reinterpret_cast<const pair_t*>(rp + ix0);
+        } else {
+          if (ix0 < a.W) q[0] = rp[ix0];
+          if (ix0 + 1 < a.W) q[1] = rp[ix0 + 1];
+        }
+      }
+      v[r] = q;
+    }
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+      typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+      const bf16x2 o = {(__bf16)stem_cvt<T>(v[r][0]), (__bf16)stem_cvt<T>(v[r][1])};
+      *reinterpret_cast<bf16x2*>(tile + r * row + 2 * tid + 2) = o;
+    }
+    if (tid < 9) {
+      const int c = tid / 3, kh = tid % 3;
+      const int iy = 2 * oy + kh - 1, ix = 2 * ox0 - 1;
+      float f = 0.f;
+      if ((unsigned)iy < (unsigned)a.H && ix >= 0) f = stem_cvt<T>(in[((long long)c * a.H + iy) * a.W + ix]);
+      tile[tid * row + 1] = (__bf16)f;
+    }
+  }
+  __syncthreads();
+
+  // ---- compute phase
+  const int lane = tid & 63, wave = tid >> 6;
+  const int p = lane & 15, kg = lane >> 4;
+  int toff[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = kg * 8 + j;
+    const int c = k / 9, kh = (k % 9) / 3, kw = k % 3;
+    toff[j] = k < 27 ? (c * 3 + kh) * row + kw + 1 : 2;  // k >= 27: any initialised (finite) element, the filter is 0
+  }
+  for (int mb = 0; mb < a.Cout; mb += 16) {
+    bf16x8 af;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = kg * 8 + j;
+      af[j] = (__bf16)(k < 27 ? w[(mb + p) * 27 + k] : 0.f);
+    }
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + mb + kg * 4);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int px = wave * 64 + g * 16 + p;  // pixel within the segment
+      bf16x8 bf;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bf[j] = tile[toff[j] + 2 * px];
+      f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, bv, 0, 0, 0);
+      const int ox = ox0 + px;
+      if (ox < a.Wo) {
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (__bf16)(a.act ? silu_g(acc[r]) : acc[r]);
+        __bf16* op = out + (long long)b * a.out_img + (long long)(oy * a.Wo + ox) * a.out_pitch + a.out_coff + mb + kg * 4;
+        *reinterpret_cast<bf16x4*>(op) = o;
+      }
+    }
+  }
+}
+
+int stem_launch(const StemArgs& a0, int in_dtype, hipStream_t s) {
+  if (a0.Cout % 16 || a0.out_pitch % 4 || a0.out_coff % 4)
+    return fail(-3, "stem: output channels must be a multiple of 16");
+  StemArgs a = a0;
+  const int waves = std::min(STEM_MAXW, (a.Wo + 63) / 64);
+  const int nthr = 64 * waves;
+  a.nseg = (a.Wo + nthr - 1) / nthr;
+  const unsigned blocks = (unsigned)(a.B * a.Ho * a.nseg);
+  const size_t lds = (size_t)9 * (2 * nthr + 8) * sizeof(__bf16);
+  if (in_dtype == YL_F32)
+    hipLaunchKernelGGL(stem_kernel<float>, dim3(blocks), dim3(nthr), lds, s, a, a.out, a.w, a.bias);
+  else if (in_dtype == YL_F16)
+    hipLaunchKernelGGL(stem_kernel<_Float16>, dim3(blocks), dim3(nthr), lds, s, a, a.out, a.w, a.bias);
+  else if (in_dtype == YL_U8)
+    hipLaunchKernelGGL(stem_kernel<uint8_t>, dim3(blocks), dim3(nthr), lds, s, a, a.out, a.w, a.bias);
+  else
+    return fail(-3, "stem: unsupported input dtype");
+  YL_HIP(hipGetLastError());
+  return 0;
+}
+
 // ------------------------------------------------------------------------------ depthwise 3x3
 // nn/modules/conv.py:100-105 (DWConv, groups = C) with folded BN; optional SiLU; optional
 // accumulate (x = attn_out + pe(v), nn/modules/block.py:913) and the per-head v channel map.

@@ -107,6 +107,16 @@ struct AttnArgs {
 };
 int attention_launch(const AttnArgs& a, hipStream_t s);
 
+struct StemArgs {
+  const void* in;     // NCHW [B][3][H][W]
+  __bf16* out;
+  const float* w;     // [Cout][27] (bf16-rounded values)
+  const float* bias;
+  long long out_img;
+  int B, H, W, Ho, Wo, Cout, out_pitch, out_coff, act, nseg;
+};
+int stem_launch(const StemArgs& a, int in_dtype, hipStream_t s);
+
 int convert_input_launch(const void* in, int in_dtype, __bf16* out, int batch, int H, int W, int pitch,
                          long long out_img, hipStream_t s);
 

@@ -20,7 +20,7 @@ from .arch import LayerSpec, detect_mid_channels
 
 BN_EPS = 1e-3
 BF16, F32 = 0, 1
-OP_CONV, OP_DWCONV3, OP_SPPF_POOL, OP_UPSAMPLE, OP_ATTENTION = 1, 2, 3, 4, 5
+OP_CONV, OP_DWCONV3, OP_SPPF_POOL, OP_UPSAMPLE, OP_ATTENTION, OP_STEM = 1, 2, 3, 4, 5, 6
 
 
 @dataclass
@@ -174,7 +174,8 @@ def _out_hw(h: int, w: int, k: int, s: int) -> Tuple[int, int]:
 
 
 def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, in_h: int, in_w: int,
-          strides: Sequence[float] = (8.0, 16.0, 32.0), reuse: bool = True, side_lanes: bool = True) -> Program:
+          strides: Sequence[float] = (8.0, 16.0, 32.0), reuse: bool = True, side_lanes: bool = True,
+          fused_stem: bool = True) -> Program:
     det = specs[-1]
     assert det.kind == "Detect"
     prog = Program(batch, in_h, in_w, det.nc, strides=tuple(float(s) for s in strides))
@@ -291,7 +292,12 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
         src = None
         if isinstance(sp.f, int):
             src = x if sp.f == -1 else views[sp.f]
-        if sp.kind == "Conv":
+        if sp.kind == "Conv" and sp.i == 0 and sp.c1 == 3 and sp.k == 3 and sp.s == 2 and sp.c2 % 16 == 0 and fused_stem:
+            # layer 0 reads the NCHW network input directly (no converted NHWC copy of the input)
+            y = out_view(sp.i)
+            w, b = fold_conv_bn(sd, p)
+            ops.append(dict(kind=OP_STEM, name=p, k=3, stride=2, act=1, inp=src, out=y, res=None, weight=w, bias=b))
+        elif sp.kind == "Conv":
             y = out_view(sp.i)
             conv(p, src, y, sp.k, sp.s, cin_weight=3 if sp.i == 0 and src.C == 8 and sp.c1 == 3 else 0)
         elif sp.kind == "C3k2":
