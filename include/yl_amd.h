@@ -37,11 +37,22 @@ enum {
                          op 0; weight [Cout][3][3][3]                                              */
 };
 
-/* A channel-slice view of an NHWC buffer inside the workspace arena. */
+/* A channel-slice view of a buffer inside the workspace arena.
+ *   YL_F32  : NHWC, buffer[B][H][W][pitch] (the Detect level maps).
+ *   YL_BF16 : "C8-planar, guarded": buffer[pitch / 8][plane_px][8] -- one plane per 8 channels, and
+ *             inside a plane the whole batch as one array of rows, every row followed by one zero
+ *             guard pixel, every image by one zero guard row (plus one guard row in front):
+ *                 pixel(b, y, x) = g0 + b * (H + 1) * (W + 1) + y * (W + 1) + x,   g0 = W + 2
+ *                 plane_px = (g0 + B * (H + 1) * (W + 1) + 1) rounded up to a multiple of 16
+ *             so a 3x3 tap is a constant offset that lands on data or on a zero, and the 16 pixels x
+ *             4 channel groups of an MFMA B fragment are 4 runs of 256 contiguous bytes.
+ *             C, pitch and coff must be multiples of 8; a view is the plane range
+ *             [coff / 8, (coff + C) / 8).  Guards are cleared by yl_engine_prepare_workspace and are
+ *             never written by any kernel; buffers must not overlap. */
 typedef struct yl_view {
-  int64_t offset; /* byte offset from the workspace base; < 0 = absent                      */
+  int64_t offset; /* byte offset of the buffer from the workspace base; < 0 = absent        */
   int32_t H, W, C;/* logical dims per image                                                  */
-  int32_t pitch;  /* channels of the underlying buffer (elements between pixel starts)       */
+  int32_t pitch;  /* channels of the underlying buffer                                       */
   int32_t coff;   /* first channel of this view inside the buffer                            */
   int32_t dtype;  /* YL_BF16 or YL_F32                                                       */
 } yl_view;
@@ -68,7 +79,7 @@ typedef struct yl_op {
   int32_t lane;       /* 0 = main stream.  k > 0: side lane k -- the op starts once every earlier op of the
                          program has finished, runs concurrently with LATER main-lane ops and is joined
                          before the decode (the three Detect levels' box / class branches)          */
-  yl_view in, out, res; /* res.offset < 0: no residual                               */
+  yl_view in, out, res; /* res.offset < 0: no residual; res has the geometry of out           */
   const float* weight;
   const float* bias;
 } yl_op;
@@ -90,11 +101,17 @@ int yl_device_count(void);
 
 /* Build an engine for a fixed (batch, in_h, in_w): packs weights, picks kernel configs.
  * Replaces nn/tasks.py:118-145 (BaseModel._predict_once layer loop) + nn/autobackend.py:34-124.
- * `input_view` is where the converted NHWC bf16 input (channels padded to 8) is written. */
+ * `input_view` is where the converted bf16 input (one plane, channels padded to 8) is written when
+ * op 0 is not YL_OP_STEM. */
 int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h, int in_w,
                      const yl_view* input_view, const yl_level* levels, int n_levels, int nc,
                      int64_t workspace_bytes, yl_engine** out);
 void yl_engine_destroy(yl_engine* e);
+
+/* Clears a workspace (all guard pixels must read as zero) and remembers its address; forward calls
+ * do this themselves the first time they see a workspace pointer.  Call it again after anything
+ * else has written to the workspace. */
+int yl_engine_prepare_workspace(yl_engine* e, void* workspace, void* stream);
 
 /* Network forward: input NCHW (YL_F32 / YL_F16 in [0,1], or YL_U8 in [0,255] which is divided by
  * 255 as engine/predictor.py:82-84 does) -> raw level maps in the workspace -> y[B][4+nc][A] fp32

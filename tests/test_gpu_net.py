@@ -85,7 +85,7 @@ def test_fused_stem_vs_generic_conv_and_torch(gpu_device, dtype):
     xin = x if dtype == torch.uint8 else x.float() / 255
     outs = []
     for fused in (True, False):
-        eng = HipEngine(lower(specs, sd, 2, 64, 96, reuse=False, fused_stem=fused), gpu_device)
+        eng = HipEngine(lower(specs, sd, 2, 64, 96, fused_stem=fused), gpu_device)
         eng.forward(xin.to(gpu_device))
         torch.cuda.synchronize()
         outs.append(eng.layer_output(0).cpu())

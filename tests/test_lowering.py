@@ -2,7 +2,7 @@
 import pytest
 
 from yololite_amd.nn import arch
-from yololite_amd.nn.lower import OP_ATTENTION, OP_CONV, OP_DWCONV3, OP_SPPF_POOL, OP_STEM, OP_UPSAMPLE, lower
+from yololite_amd.nn.lower import OP_ATTENTION, OP_CONV, OP_DWCONV3, OP_SPPF_POOL, OP_STEM, OP_UPSAMPLE, lower, plane_pixels, view_bytes
 from yololite_amd.nn.synth import synth_state_dict
 
 
@@ -40,33 +40,45 @@ def test_views_inside_workspace_and_aligned():
             v = o.get(key)
             if v is None:
                 continue
-            esz = 4 if v.dtype == 1 else 2
             assert v.offset % 256 == 0 and v.coff + v.C <= v.pitch
-            assert v.offset + p.batch * v.H * v.W * v.pitch * esz <= p.ws_bytes
-            if o["kind"] != OP_CONV or key == "inp":
-                assert v.coff % 8 == 0 or v.dtype == 1
+            assert v.offset + view_bytes(p.batch, v) <= p.ws_bytes
+            if v.dtype == 0:  # bf16 views are plane ranges: everything in units of 8 channels
+                assert v.C % 8 == 0 and v.pitch % 8 == 0 and v.coff % 8 == 0
     kinds = [o["kind"] for o in p.ops]
     assert kinds.count(OP_SPPF_POOL) == 1 and kinds.count(OP_ATTENTION) == 1 and kinds.count(OP_UPSAMPLE) == 2
 
 
-def _prog_noreuse(scale, b=1, h=640, w=640):
-    specs, _ = arch.parse_model(arch.yolo11_dict(scale))
-    return lower(specs, synth_state_dict(scale, 0), b, h, w, reuse=False)
+def test_plane_geometry_known_answers():
+    """pixel(b, y, x) = g0 + b*(H+1)*(W+1) + y*(W+1) + x must leave room for every 3x3 tap."""
+    for B, H, W in [(1, 2, 2), (3, 20, 20), (32, 80, 80), (2, 3, 4)]:
+        pp = plane_pixels(B, H, W)
+        g0, w1, img = W + 2, W + 1, (H + 1) * (W + 1)
+        first = g0 - w1 - 1                                   # tap (-1, -1) of pixel (0, 0, 0)
+        last = g0 + (B - 1) * img + (H - 1) * w1 + (W - 1) + w1 + 1  # tap (+1, +1) of the last pixel
+        assert first == 0 and last < pp and pp % 16 == 0
+    assert plane_pixels(1, 2, 2) == 16 and plane_pixels(32, 80, 80) == (82 + 32 * 81 * 81 + 1 + 15) // 16 * 16
 
 
 @pytest.mark.parametrize("scale", ["n", "x"])
-def test_arena_reuse_never_overlaps_live_buffers(scale):
-    """Buffers whose lifetimes [first op, last op] intersect must occupy disjoint byte ranges."""
+def test_buffers_never_overlap(scale):
+    """No recycling: the guard pixels of a buffer are zeroed once and must never be overwritten."""
     p = _prog(scale, 2, 96, 128)
-    q = _prog_noreuse(scale, 2, 96, 128)
-    assert p.ws_bytes < 0.6 * q.ws_bytes
-    t = sorted(p.alloc_table, key=lambda r: r[2])
-    for i, (f1, l1, o1, s1) in enumerate(t):
-        assert o1 % 256 == 0 and o1 + s1 <= p.ws_bytes
-        for f2, l2, o2, s2 in t[i + 1:]:
-            if o2 >= o1 + s1:
-                break
-            assert l1 < f2 or l2 < f1, f"live buffers overlap: {(f1, l1, o1, s1)} vs {(f2, l2, o2, s2)}"
+    spans = {}
+    for o in p.ops:
+        for key in ("inp", "out", "res"):
+            v = o.get(key)
+            if v is not None:
+                spans[v.offset] = max(spans.get(v.offset, 0), view_bytes(p.batch, v))
+    for L in p.levels:
+        spans[L["offset"]] = p.batch * L["H"] * L["W"] * (64 + p.nc) * 4
+    t = sorted(spans.items())
+    for (o1, s1), (o2, _) in zip(t, t[1:]):
+        assert o1 + s1 <= o2
+    assert t[-1][0] + t[-1][1] <= p.ws_bytes
+
+
+def _prog_noreuse(scale, b=1, h=640, w=640):
+    return _prog(scale, b, h, w)
 
 
 def test_concat_members_are_slices_of_one_buffer():

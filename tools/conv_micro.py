@@ -28,7 +28,8 @@ for r in range(NREP):
     prog.ops.append(dict(kind=OP_CONV, name=f"c{r}", k=k, stride=s, act=1, inp=x, out=y, res=None, weight=w, bias=b))
 prog.ws_bytes = ar.top + 256
 eng = HipEngine(prog, dev)
-eng.workspace.view(torch.bfloat16).normal_()
+for o in prog.ops:
+    eng.write_view(o['inp'], torch.randn(B, cin, H, W))
 im = torch.zeros(B, 3, 32, 32, device=dev)
 for _ in range(3):
     eng.forward(im, decode=False)
@@ -42,5 +43,6 @@ e1.record()
 torch.cuda.synchronize()
 us = e0.elapsed_time(e1) / (N * NREP) * 1e3
 byt = B * (H * W * cin + Ho * Wo * cout) * 2
+torch.cuda.synchronize()
 fl = 2.0 * B * Ho * Wo * cout * cin * k * k
 print(f"dbg={os.environ.get('YL_CONV_DBG', '0'):>2s} {cin}->{cout} k{k} s{s} @{H}x{W}: {us:7.1f} us  {byt / us / 1e6:6.2f} TB/s  {fl / us / 1e6:7.1f} TF/s")

@@ -17,7 +17,7 @@ OP_CONV, OP_DWCONV3, OP_SPPF_POOL, OP_UPSAMPLE, OP_ATTENTION, OP_STEM = 1, 2, 3,
 
 EXPORTS = (
     "yl_last_error", "yl_abi_version", "yl_device_count", "yl_engine_create", "yl_engine_destroy",
-    "yl_engine_forward", "yl_engine_forward_graph", "yl_engine_profile", "yl_engine_num_ops",
+    "yl_engine_prepare_workspace", "yl_engine_forward", "yl_engine_forward_graph", "yl_engine_profile", "yl_engine_num_ops",
     "yl_engine_op_info", "yl_detect_decode", "yl_nms_workspace_bytes", "yl_nms", "yl_decode_nms",
     "yl_preprocess_u8",
 )
@@ -85,6 +85,8 @@ def lib() -> C.CDLL:
                                    i64, C.POINTER(vp)]
     L.yl_engine_destroy.restype = None
     L.yl_engine_destroy.argtypes = [vp]
+    L.yl_engine_prepare_workspace.restype = i32
+    L.yl_engine_prepare_workspace.argtypes = [vp, vp, vp]
     for name in ("yl_engine_forward", "yl_engine_forward_graph"):
         f = getattr(L, name)
         f.restype = i32

@@ -55,18 +55,38 @@ struct yl_engine {
   std::vector<hipStream_t> lanes;
   std::vector<hipEvent_t> events;
   int max_lane = 0;
+  std::vector<void*> zeroed;  // workspaces whose guard pixels this engine has already cleared
 };
 
 static int64_t view_elem_size(const yl_view& v) { return v.dtype == YL_F32 ? 4 : 2; }
 
+// bf16 views are plane ranges of a C8-planar guarded buffer (yl_internal.h); fp32 views are NHWC.
 static int check_view(const yl_view& v, int batch, int64_t ws_bytes, const char* what) {
   if (v.offset < 0) return fail(-1, std::string(what) + ": view is absent");
   if (v.H <= 0 || v.W <= 0 || v.C <= 0 || v.pitch < v.coff + v.C || v.coff < 0)
     return fail(-1, std::string(what) + ": inconsistent view");
-  const int64_t end = v.offset + (int64_t)batch * v.H * v.W * v.pitch * view_elem_size(v);
+  int64_t end;
+  if (v.dtype == YL_F32) {
+    end = v.offset + (int64_t)batch * v.H * v.W * v.pitch * 4;
+  } else {
+    if ((v.C | v.pitch | v.coff) & 7)
+      return fail(-3, std::string(what) + ": bf16 channel counts / offsets must be multiples of 8 (planar layout)");
+    end = v.offset + (int64_t)(v.pitch / 8) * plane_bytes(geo_of(batch, v.H, v.W));
+  }
   if (end > ws_bytes) return fail(-1, std::string(what) + ": view exceeds the workspace");
   if (v.offset % 16) return fail(-1, std::string(what) + ": view offset must be 16-byte aligned");
   return 0;
+}
+
+static PView pview(char* ws, const yl_view& v, int batch) {
+  const Geo g = geo_of(batch, v.H, v.W);
+  PView p;
+  p.base = reinterpret_cast<__bf16*>(ws + v.offset + (int64_t)(v.coff / 8) * plane_bytes(g));
+  p.plane = (long long)g.plane_px * 8;
+  p.W1 = g.W1;
+  p.img = g.img;
+  p.g0 = g.g0;
+  return p;
 }
 
 template <typename T>
@@ -112,8 +132,9 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
   e->ws_bytes = workspace_bytes;
   e->input_view = *input_view;
   if (int rc = check_view(*input_view, batch, workspace_bytes, "input")) return rc;
-  if (input_view->C != 8 || input_view->pitch != 8 || input_view->H != in_h || input_view->W != in_w)
-    return fail(-1, "input view must be [H][W][8] bf16");
+  if (input_view->C != 8 || input_view->pitch != 8 || input_view->H != in_h || input_view->W != in_w ||
+      input_view->dtype != YL_BF16)
+    return fail(-1, "input view must be one bf16 plane [H][W][8]");
   int a0 = 0;
   for (int i = 0; i < n_levels; ++i) {
     const yl_level& L = levels[i];
@@ -139,7 +160,6 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
         const int pad = o.k / 2;
         const int Ho = (o.in.H + 2 * pad - o.k) / o.stride + 1, Wo = (o.in.W + 2 * pad - o.k) / o.stride + 1;
         if (Ho != o.out.H || Wo != o.out.W) return fail(-1, tag + ": conv output dims mismatch");
-        if (o.in.coff % 8 || o.in.pitch % 8) return fail(-1, tag + ": conv input slice must be 8-channel aligned");
         if (o.res.offset >= 0) {
           if (int rc = check_view(o.res, batch, workspace_bytes, (tag + " res").c_str())) return rc;
           if (o.res.H != Ho || o.res.W != Wo || o.res.C != o.out.C || o.res.dtype != YL_BF16)
@@ -147,11 +167,9 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
         }
         // weight Cin may be smaller than the (padded) input view channels: stem 3 -> 8
         const int cin_w = o.cin_weight > 0 ? o.cin_weight : o.in.C;
-        const int al8 = ((o.out.C | o.out.pitch | o.out.coff) & 7) == 0 &&
-                        (o.res.offset < 0 || ((o.res.pitch | o.res.coff) & 7) == 0);
-        if (int rc = conv_choose(batch, o.in.C, o.out.C, o.k, o.stride, Ho, Wo, al8, &r.cfg)) return rc;
+        if (int rc = conv_choose(batch, o.in.C, o.out.C, o.k, o.stride, Ho, Wo, &r.cfg)) return rc;
         std::vector<uint16_t> pk;
-        conv_pack_weights(o.weight, o.out.C, cin_w, o.in.C, o.k, r.cfg, &pk);
+        conv_pack_weights(o.weight, o.out.C, cin_w, o.k, r.cfg, &pk);
         uint16_t* d = nullptr;
         if (int rc = dev_upload(e.get(), pk, &d)) return rc;
         r.d_wpk = reinterpret_cast<__bf16*>(d);
@@ -166,7 +184,8 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
       }
       case YL_OP_DWCONV3: {
         if (!o.weight || !o.bias) return fail(-1, tag + ": dwconv needs weight and bias");
-        if (o.in.H != o.out.H || o.in.W != o.out.W) return fail(-1, tag + ": dwconv dims mismatch");
+        if (o.in.H != o.out.H || o.in.W != o.out.W || o.in.dtype != YL_BF16 || o.out.dtype != YL_BF16)
+          return fail(-1, tag + ": dwconv dims mismatch");
         const int C = o.out.C;
         std::vector<float> wt((size_t)9 * C);
         for (int c = 0; c < C; ++c)
@@ -184,7 +203,7 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
         if (!o.weight || !o.bias) return fail(-1, tag + ": stem needs weight and bias");
         if (o.out.H != (in_h + 2 - 3) / 2 + 1 || o.out.W != (in_w + 2 - 3) / 2 + 1 || o.out.dtype != YL_BF16)
           return fail(-1, tag + ": stem output dims mismatch");
-        if (o.out.C % 16 || o.out.pitch % 4 || o.out.coff % 4) return fail(-1, tag + ": stem needs Cout % 16 == 0");
+        if (o.out.C % 16) return fail(-1, tag + ": stem needs Cout % 16 == 0");
         std::vector<float> wt((size_t)o.out.C * 27);
         for (size_t q = 0; q < wt.size(); ++q) {  // round to bf16 like every other conv filter
           uint32_t u;
@@ -240,66 +259,63 @@ static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s, c
   switch (o.kind) {
     case YL_OP_CONV: {
       ConvArgs a{};
-      a.in = reinterpret_cast<const __bf16*>(ws + o.in.offset);
-      a.out = ws + o.out.offset;
-      a.res = o.res.offset >= 0 ? reinterpret_cast<const __bf16*>(ws + o.res.offset) : nullptr;
+      const Geo gi = geo_of(B, o.in.H, o.in.W), go = geo_of(B, o.out.H, o.out.W);
+      a.in = pview(ws, o.in, B).base;
+      a.in_plane = (unsigned)plane_bytes(gi);
+      a.in_w1 = gi.W1;
+      a.in_img = gi.img;
+      a.in_g0 = gi.g0;
+      a.out_f32 = o.out.dtype == YL_F32;
+      if (a.out_f32) {
+        a.out = ws + o.out.offset;
+        a.out_pitch = o.out.pitch;
+        a.out_coff = o.out.coff;
+      } else {
+        a.out = pview(ws, o.out, B).base;
+        a.out_plane = (unsigned)plane_bytes(go);
+      }
+      a.out_w1 = go.W1;
+      a.out_img = go.img;
+      a.out_g0 = go.g0;
+      if (o.res.offset >= 0) {
+        a.res = pview(ws, o.res, B).base;
+        a.res_plane = (unsigned)plane_bytes(go);
+      }
       a.wpk = r.d_wpk;
       a.bias = r.d_bias;
-      a.in_img = (long long)o.in.H * o.in.W * o.in.pitch;
-      a.out_img = (long long)o.out.H * o.out.W * o.out.pitch;
-      a.res_img = o.res.offset >= 0 ? (long long)o.res.H * o.res.W * o.res.pitch : 0;
-      a.H = o.in.H;
-      a.W = o.in.W;
       a.Ho = o.out.H;
       a.Wo = o.out.W;
-      a.in_pitch = o.in.pitch;
-      a.in_coff = o.in.coff;
-      a.out_pitch = o.out.pitch;
-      a.out_coff = o.out.coff;
-      a.res_pitch = o.res.offset >= 0 ? o.res.pitch : 0;
-      a.res_coff = o.res.offset >= 0 ? o.res.coff : 0;
       a.Cin = o.in.C;
       a.Cout = o.out.C;
       a.stride = o.stride;
-      a.pad = o.k / 2;
       a.act = o.act;
-      a.out_f32 = o.out.dtype == YL_F32;
       return conv_launch(r.cfg, a, B, s);
     }
     case YL_OP_STEM: {
       if (!input) return fail(-1, "run_op: the stem needs the network input");
       StemArgs a{};
       a.in = input;
-      a.out = reinterpret_cast<__bf16*>(ws + o.out.offset);
+      a.out = pview(ws, o.out, B);
       a.w = r.d_w;
       a.bias = r.d_bias;
-      a.out_img = (long long)o.out.H * o.out.W * o.out.pitch;
       a.B = B;
       a.H = e->in_h;
       a.W = e->in_w;
       a.Ho = o.out.H;
       a.Wo = o.out.W;
       a.Cout = o.out.C;
-      a.out_pitch = o.out.pitch;
-      a.out_coff = o.out.coff;
       a.act = o.act;
       return stem_launch(a, in_dtype, s);
     }
     case YL_OP_DWCONV3: {
       DwArgs a{};
-      a.in = reinterpret_cast<const __bf16*>(ws + o.in.offset);
-      a.out = reinterpret_cast<__bf16*>(ws + o.out.offset);
+      a.in = pview(ws, o.in, B);
+      a.out = pview(ws, o.out, B);
       a.w = r.d_w;
       a.bias = r.d_bias;
-      a.in_img = (long long)o.in.H * o.in.W * o.in.pitch;
-      a.out_img = (long long)o.out.H * o.out.W * o.out.pitch;
       a.H = o.out.H;
       a.W = o.out.W;
       a.C = o.out.C;
-      a.in_pitch = o.in.pitch;
-      a.in_coff = o.in.coff;
-      a.out_pitch = o.out.pitch;
-      a.out_coff = o.out.coff;
       a.act = o.act;
       a.accumulate = o.accumulate;
       a.grp = o.grp;
@@ -310,46 +326,32 @@ static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s, c
     }
     case YL_OP_SPPF_POOL: {
       PoolArgs a{};
-      a.in = reinterpret_cast<const __bf16*>(ws + o.in.offset);
-      a.out = reinterpret_cast<__bf16*>(ws + o.in.offset);
-      a.img = (long long)o.in.H * o.in.W * o.in.pitch;
+      a.v = pview(ws, o.in, B);
       a.H = o.in.H;
       a.W = o.in.W;
       a.C = o.in.C;
-      a.pitch = o.in.pitch;
-      a.coff = o.in.coff;
       a.batch = B;
       return sppf_pool_launch(a, s);
     }
     case YL_OP_UPSAMPLE: {
       UpArgs a{};
-      a.in = reinterpret_cast<const __bf16*>(ws + o.in.offset);
-      a.out = reinterpret_cast<__bf16*>(ws + o.out.offset);
-      a.in_img = (long long)o.in.H * o.in.W * o.in.pitch;
-      a.out_img = (long long)o.out.H * o.out.W * o.out.pitch;
+      a.in = pview(ws, o.in, B);
+      a.out = pview(ws, o.out, B);
       a.H = o.in.H;
       a.W = o.in.W;
       a.C = o.in.C;
-      a.in_pitch = o.in.pitch;
-      a.in_coff = o.in.coff;
-      a.out_pitch = o.out.pitch;
-      a.out_coff = o.out.coff;
       a.factor = o.stride;
       a.batch = B;
       return upsample_launch(a, s);
     }
     case YL_OP_ATTENTION: {
       AttnArgs a{};
-      a.qkv = reinterpret_cast<const __bf16*>(ws + o.in.offset);
-      a.out = reinterpret_cast<__bf16*>(ws + o.out.offset);
-      a.in_img = (long long)o.in.H * o.in.W * o.in.pitch;
-      a.out_img = (long long)o.out.H * o.out.W * o.out.pitch;
+      a.in = pview(ws, o.in, B);
+      a.out = pview(ws, o.out, B);
+      a.H = o.in.H;
+      a.W = o.in.W;
       a.N = o.in.H * o.in.W;
       a.heads = o.heads;
-      a.in_pitch = o.in.pitch;
-      a.in_coff = o.in.coff;
-      a.out_pitch = o.out.pitch;
-      a.out_coff = o.out.coff;
       a.batch = B;
       a.scale = o.scale;
       return attention_launch(a, s);
@@ -359,9 +361,20 @@ static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s, c
 }
 
 static int run_convert(const yl_engine* e, const void* input, int in_dtype, char* ws, hipStream_t s) {
-  return convert_input_launch(input, in_dtype, reinterpret_cast<__bf16*>(ws + e->input_view.offset), e->batch,
-                              e->in_h, e->in_w, e->input_view.pitch,
-                              (long long)e->in_h * e->in_w * e->input_view.pitch, s);
+  return convert_input_launch(input, in_dtype, pview(ws, e->input_view, e->batch), e->batch, e->in_h, e->in_w, s);
+}
+
+// The guard pixels of the planar layout must read as zero.  Nothing ever writes them, so clearing a
+// workspace once, the first time this engine sees its address, is enough.
+static int prepare_workspace(yl_engine* e, char* ws, hipStream_t s) {
+  for (void* p : e->zeroed)
+    if (p == ws) return 0;
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  (void)hipStreamIsCapturing(s, &st);
+  if (st != hipStreamCaptureStatusNone) return fail(-1, "workspace must be prepared before stream capture");
+  YL_HIP(hipMemsetAsync(ws, 0, (size_t)e->ws_bytes, s));
+  e->zeroed.push_back(ws);
+  return 0;
 }
 
 static int run_decode(const yl_engine* e, const char* ws, float* y, hipStream_t s) {
@@ -396,11 +409,17 @@ static int lane_resources(yl_engine* e, size_t n_events) {
   return 0;
 }
 
+extern "C" int yl_engine_prepare_workspace(yl_engine* e, void* workspace, void* stream) {
+  if (!e || !workspace) return fail(-1, "yl_engine_prepare_workspace: null pointer");
+  return prepare_workspace(e, (char*)workspace, (hipStream_t)stream);
+}
+
 extern "C" int yl_engine_forward(yl_engine* e, const void* input, int in_dtype, void* workspace, float* y,
                                  void* stream) {
   if (!e || !input || !workspace) return fail(-1, "yl_engine_forward: null pointer");
   hipStream_t s = (hipStream_t)stream;
   char* ws = (char*)workspace;
+  if (int rc = prepare_workspace(e, ws, s)) return rc;
   if (e->max_lane > 0)
     if (int rc = lane_resources(e, e->ops.size() + e->max_lane + 1)) return rc;
   const bool stem = !e->ops.empty() && e->ops[0].op.kind == YL_OP_STEM;

@@ -1,6 +1,7 @@
-// Bandwidth-bound NHWC bf16 kernels of the YOLO11 path: input conversion, depthwise 3x3, SPPF
-// max-pool chain, nearest upsample / slice copy, C2PSA attention and the Detect decode.
-// Every thread moves 16-byte (8 x bf16) channel groups so that global accesses are coalesced.
+// Bandwidth-bound bf16 kernels of the YOLO11 path over the C8-planar guarded layout (yl_internal.h):
+// input conversion, fused stem, depthwise 3x3, SPPF max-pool chain, nearest upsample / slice copy,
+// C2PSA attention, and the Detect decode.  Every thread moves 16-byte pixels (8 x bf16 of one plane)
+// and neighbouring lanes touch neighbouring pixels of the same plane.
 #include "yl_internal.h"
 
 namespace yl {
@@ -9,38 +10,43 @@ __device__ __forceinline__ float silu_g(float v) {  // hardware exp2 / rcp, see 
   return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * v));
 }
 
-// ------------------------------------------------------------------ input NCHW -> NHWC bf16 (C=8)
+__device__ __forceinline__ int pv_pix(const PView& v, int b, int y, int x) { return v.g0 + b * v.img + y * v.W1 + x; }
+__device__ __forceinline__ __bf16* pv_ptr(const PView& v, int c8, int pix) {
+  return v.base + (long long)c8 * v.plane + (long long)pix * 8;
+}
+
+// ---------------------------------------------------------- input NCHW -> one bf16 plane (C = 8)
 // engine/predictor.py:67-85 (preprocess: .float(), /255 for uint8 sources); channels 3..7 are zero.
+// Only used when layer 0 is not the standard 3x3 stride-2 stem (otherwise see stem_kernel).
 template <typename T>
-__global__ void convert_input_kernel(const T* __restrict__ in, __bf16* __restrict__ out, int HW, long long out_img,
-                                     int pitch, float mul, long long total) {
+__global__ void convert_input_kernel(const T* __restrict__ in, PView out, int H, int W, float mul, long long total) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= total) return;
+  const int HW = H * W;
   const int b = (int)(i / HW);
   const int p = (int)(i - (long long)b * HW);
+  const int y = p / W, x = p - y * W;
   const T* src = in + (long long)b * 3 * HW + p;
   bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-  // `div` is 255 for uint8 sources: a true fp32 division like `im /= 255` (predictor.py:84)
+  // `mul` is 255 for uint8 sources: a true fp32 division like `im /= 255` (predictor.py:84)
   v[0] = (__bf16)((float)src[0] / mul);
   v[1] = (__bf16)((float)src[HW] / mul);
   v[2] = (__bf16)((float)src[2 * (long long)HW] / mul);
-  *reinterpret_cast<bf16x8*>(out + (long long)b * out_img + (long long)p * pitch) = v;
+  *reinterpret_cast<bf16x8*>(pv_ptr(out, 0, pv_pix(out, b, y, x))) = v;
 }
 
-int convert_input_launch(const void* in, int in_dtype, __bf16* out, int batch, int H, int W, int pitch,
-                         long long out_img, hipStream_t s) {
+int convert_input_launch(const void* in, int in_dtype, const PView& out, int batch, int H, int W, hipStream_t s) {
   const long long total = (long long)batch * H * W;
   const int blocks = (int)((total + 255) / 256);
-  if (pitch != 8) return fail(-3, "convert_input: input view pitch must be 8");
   if (in_dtype == YL_F32)
-    hipLaunchKernelGGL(convert_input_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)in, out, H * W,
-                       out_img, pitch, 1.0f, total);
+    hipLaunchKernelGGL(convert_input_kernel<float>, dim3(blocks), dim3(256), 0, s, (const float*)in, out, H, W, 1.0f,
+                       total);
   else if (in_dtype == YL_F16)
-    hipLaunchKernelGGL(convert_input_kernel<_Float16>, dim3(blocks), dim3(256), 0, s, (const _Float16*)in, out,
-                       H * W, out_img, pitch, 1.0f, total);
+    hipLaunchKernelGGL(convert_input_kernel<_Float16>, dim3(blocks), dim3(256), 0, s, (const _Float16*)in, out, H, W,
+                       1.0f, total);
   else if (in_dtype == YL_U8)
-    hipLaunchKernelGGL(convert_input_kernel<uint8_t>, dim3(blocks), dim3(256), 0, s, (const uint8_t*)in, out, H * W,
-                       out_img, pitch, 255.0f, total);
+    hipLaunchKernelGGL(convert_input_kernel<uint8_t>, dim3(blocks), dim3(256), 0, s, (const uint8_t*)in, out, H, W,
+                       255.0f, total);
   else
     return fail(-3, "convert_input: unsupported input dtype");
   YL_HIP(hipGetLastError());
@@ -58,8 +64,8 @@ int convert_input_launch(const void* in, int in_dtype, __bf16* out, int batch, i
 //            this TA), rounded to bf16 and parked in LDS with the left halo column and zero padding.
 //   compute: implicit GEMM on v_mfma_f32_16x16x32_bf16 with K = 27 taps padded to 32: A = filters
 //            (rows = 16 output channels), B = im2col patch gathered from LDS (cols = 16 pixels).
-//   store  : D gives each lane 4 consecutive channels of one pixel -> 8-byte stores, 512 contiguous
-//            bytes per instruction.
+//   store  : D gives each lane 4 consecutive channels of one pixel -> 8-byte stores; the two lane
+//            quads of a plane fill whole 16-byte pixels, 256 contiguous bytes per plane.
 // Numerics as the generic MFMA conv (bf16 operands, fp32 accumulate).  Bandwidth bound: 157 MB in,
 // 105 MB out at batch 32 x 640^2 (fp32 input, 16 channels).
 constexpr int STEM_MAXW = 8;  // waves per workgroup -> up to 512 output pixels per row segment
@@ -87,8 +93,7 @@ __device__ __forceinline__ float stem_cvt(T v) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(64 * STEM_MAXW) void stem_kernel(StemArgs a, __bf16* __restrict__ out,
-                                                              const float* __restrict__ w,
+__global__ __launch_bounds__(64 * STEM_MAXW) void stem_kernel(StemArgs a, const float* __restrict__ w,
                                                               const float* __restrict__ bias) {
   extern __shared__ __align__(16) unsigned char stem_smem[];
   __bf16* tile = reinterpret_cast<__bf16*>(stem_smem);  // [9 (c,kh)][row] ; col' = ix - 2*ox0 + 2
@@ -168,16 +173,15 @@ __global__ __launch_bounds__(64 * STEM_MAXW) void stem_kernel(StemArgs a, __bf16
         bf16x4 o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = (__bf16)(a.act ? silu_g(acc[r]) : acc[r]);
-        __bf16* op = out + (long long)b * a.out_img + (long long)(oy * a.Wo + ox) * a.out_pitch + a.out_coff + mb + kg * 4;
-        *reinterpret_cast<bf16x4*>(op) = o;
+        const int ch = mb + kg * 4;
+        *reinterpret_cast<bf16x4*>(pv_ptr(a.out, ch >> 3, pv_pix(a.out, b, oy, ox)) + (ch & 7)) = o;
       }
     }
   }
 }
 
 int stem_launch(const StemArgs& a0, int in_dtype, hipStream_t s) {
-  if (a0.Cout % 16 || a0.out_pitch % 4 || a0.out_coff % 4)
-    return fail(-3, "stem: output channels must be a multiple of 16");
+  if (a0.Cout % 16) return fail(-3, "stem: output channels must be a multiple of 16");
   StemArgs a = a0;
   const int waves = std::min(STEM_MAXW, (a.Wo + 63) / 64);
   const int nthr = 64 * waves;
@@ -185,11 +189,11 @@ int stem_launch(const StemArgs& a0, int in_dtype, hipStream_t s) {
   const unsigned blocks = (unsigned)(a.B * a.Ho * a.nseg);
   const size_t lds = (size_t)9 * (2 * nthr + 8) * sizeof(__bf16);
   if (in_dtype == YL_F32)
-    hipLaunchKernelGGL(stem_kernel<float>, dim3(blocks), dim3(nthr), lds, s, a, a.out, a.w, a.bias);
+    hipLaunchKernelGGL(stem_kernel<float>, dim3(blocks), dim3(nthr), lds, s, a, a.w, a.bias);
   else if (in_dtype == YL_F16)
-    hipLaunchKernelGGL(stem_kernel<_Float16>, dim3(blocks), dim3(nthr), lds, s, a, a.out, a.w, a.bias);
+    hipLaunchKernelGGL(stem_kernel<_Float16>, dim3(blocks), dim3(nthr), lds, s, a, a.w, a.bias);
   else if (in_dtype == YL_U8)
-    hipLaunchKernelGGL(stem_kernel<uint8_t>, dim3(blocks), dim3(nthr), lds, s, a, a.out, a.w, a.bias);
+    hipLaunchKernelGGL(stem_kernel<uint8_t>, dim3(blocks), dim3(nthr), lds, s, a, a.w, a.bias);
   else
     return fail(-3, "stem: unsupported input dtype");
   YL_HIP(hipGetLastError());
@@ -199,24 +203,26 @@ int stem_launch(const StemArgs& a0, int in_dtype, hipStream_t s) {
 // ------------------------------------------------------------------------------ depthwise 3x3
 // nn/modules/conv.py:100-105 (DWConv, groups = C) with folded BN; optional SiLU; optional
 // accumulate (x = attn_out + pe(v), nn/modules/block.py:913) and the per-head v channel map.
-// One thread = 8 channels x 4 consecutive output pixels of a row: the 3 x 6 input window and the
-// 9 x 8 filter taps are loaded once and reused (9 sixteen-byte loads per output instead of 27).
+// One thread = one plane (8 channels) x 4 consecutive output pixels of a row: the 3 x 6 input window
+// and the 9 x 8 filter taps are loaded once and reused (4.5 sixteen-byte loads per output instead of
+// 9).  The zero padding comes from the guard pixels of the layout: no bounds tests on the taps.
+// Thread order: pixel runs fastest, planes slowest -> a wave reads contiguous memory.
 constexpr int DW_PX = 4;
 __global__ __launch_bounds__(256) void dwconv3_kernel(DwArgs a) {
   const int cg = a.C >> 3;
   const int wq = (a.W + DW_PX - 1) / DW_PX;
-  const long long total = (long long)a.batch * a.H * wq * cg;
+  const long long per_plane = (long long)a.batch * a.H * wq;
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int g8 = (int)(i % cg);
-  long long p = i / cg;
+  if (i >= per_plane * cg) return;
+  const int g8 = (int)(i / per_plane);
+  long long p = i - g8 * per_plane;
   const int x0 = (int)(p % wq) * DW_PX;
   p /= wq;
   const int y = (int)(p % a.H);
   const int b = (int)(p / a.H);
   const int c = g8 * 8;
   const int cin = a.grp ? (c / a.grp) * a.grp_stride + a.grp_off + (c % a.grp) : c;
-  const __bf16* inb = a.in + (long long)b * a.in_img + a.in_coff + cin;
+  const __bf16* inb = pv_ptr(a.in, cin >> 3, pv_pix(a.in, b, y, x0));
   float acc[DW_PX][8];
   {
     const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias + c), b1 = *reinterpret_cast<const f32x4*>(a.bias + c + 4);
@@ -230,8 +236,6 @@ __global__ __launch_bounds__(256) void dwconv3_kernel(DwArgs a) {
   }
 #pragma unroll
   for (int kh = 0; kh < 3; ++kh) {
-    const int iy = y + kh - 1;
-    if ((unsigned)iy >= (unsigned)a.H) continue;
     float wrow[3][8];
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) {
@@ -245,9 +249,8 @@ __global__ __launch_bounds__(256) void dwconv3_kernel(DwArgs a) {
     }
 #pragma unroll
     for (int t = 0; t < DW_PX + 2; ++t) {  // input column x0 - 1 + t feeds outputs q = t - kw
-      const int ix = x0 - 1 + t;
-      if ((unsigned)ix >= (unsigned)a.W) continue;
-      const bf16x8 v = *reinterpret_cast<const bf16x8*>(inb + (long long)(iy * a.W + ix) * a.in_pitch);
+      if (x0 - 1 + t > a.W) continue;      // beyond the guard column (ragged last run only)
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(inb + ((kh - 1) * a.in.W1 + t - 1) * 8);
       float f[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) f[j] = (float)v[j];
@@ -256,16 +259,16 @@ __global__ __launch_bounds__(256) void dwconv3_kernel(DwArgs a) {
         const int q = t - kw;
         if (q >= 0 && q < DW_PX) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) acc[q][j] += f[j] * wrow[kw][j];
+          for (int j = 0; j < 8; ++j) acc[q][j] = __builtin_fmaf(f[j], wrow[kw][j], acc[q][j]);
         }
       }
     }
   }
+  __bf16* ob = pv_ptr(a.out, g8, pv_pix(a.out, b, y, x0));
 #pragma unroll
   for (int q = 0; q < DW_PX; ++q) {
-    const int x = x0 + q;
-    if (x >= a.W) break;
-    __bf16* op = a.out + (long long)b * a.out_img + (long long)(y * a.W + x) * a.out_pitch + a.out_coff + c;
+    if (x0 + q >= a.W) break;
+    __bf16* op = ob + q * 8;
     bf16x8 o;
     if (a.accumulate) {
       const bf16x8 prev = *reinterpret_cast<const bf16x8*>(op);
@@ -280,9 +283,8 @@ __global__ __launch_bounds__(256) void dwconv3_kernel(DwArgs a) {
 }
 
 int dwconv3_launch(const DwArgs& a, hipStream_t s) {
-  if (a.C % 8 || a.in_pitch % 8 || a.in_coff % 8 || a.out_pitch % 8 || a.out_coff % 8 ||
-      (a.grp && (a.grp % 8 || a.grp_stride % 8 || a.grp_off % 8)))
-    return fail(-3, "dwconv3: channels/pitches must be multiples of 8");
+  if (a.C % 8 || (a.grp && (a.grp % 8 || a.grp_stride % 8 || a.grp_off % 8)))
+    return fail(-3, "dwconv3: channel counts must be multiples of 8");
   const long long total = (long long)a.batch * a.H * ((a.W + DW_PX - 1) / DW_PX) * (a.C / 8);
   hipLaunchKernelGGL(dwconv3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
   YL_HIP(hipGetLastError());
@@ -291,19 +293,20 @@ int dwconv3_launch(const DwArgs& a, hipStream_t s) {
 
 // ------------------------------------------------------------------------- SPPF pooling chain
 // nn/modules/block.py:180-184: y1 = m(x), y2 = m(y1), y3 = m(y2) with m = MaxPool2d(5,1,2).
-// Chained 5x5 max pools with -inf padding equal single 5/9/13 windows clipped to the image.
+// Chained 5x5 max pools with -inf padding equal single 5/9/13 windows clipped to the image (the zero
+// guards must NOT take part: SiLU outputs can be negative).  Pool k of plane g8 goes to plane
+// k * C/8 + g8 of the same buffer.
 __global__ void sppf_pool_kernel(PoolArgs a) {
   const int cg = a.C >> 3;
-  const long long total = (long long)a.batch * a.H * a.W * cg;
+  const long long per_plane = (long long)a.batch * a.H * a.W;
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int g8 = (int)(i % cg);
-  long long p = i / cg;
+  if (i >= per_plane * cg) return;
+  const int g8 = (int)(i / per_plane);
+  long long p = i - g8 * per_plane;
   const int x = (int)(p % a.W);
   p /= a.W;
   const int y = (int)(p % a.H);
   const int b = (int)(p / a.H);
-  const __bf16* inb = a.in + (long long)b * a.img + a.coff + g8 * 8;
   const float ninf = -__builtin_huge_valf();
   float m5[8], m9[8], m13[8];
 #pragma unroll
@@ -317,7 +320,7 @@ __global__ void sppf_pool_kernel(PoolArgs a) {
       if ((unsigned)ix >= (unsigned)a.W) continue;
       const int adx = dx < 0 ? -dx : dx;
       const int r = ady > adx ? ady : adx;
-      const bf16x8 v = *reinterpret_cast<const bf16x8*>(inb + (long long)(iy * a.W + ix) * a.pitch);
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(pv_ptr(a.v, g8, pv_pix(a.v, b, iy, ix)));
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float f = (float)v[j];
@@ -327,7 +330,7 @@ __global__ void sppf_pool_kernel(PoolArgs a) {
       }
     }
   }
-  __bf16* op = a.out + (long long)b * a.img + (long long)(y * a.W + x) * a.pitch + a.coff + g8 * 8;
+  const int po = pv_pix(a.v, b, y, x);
   bf16x8 o5, o9, o13;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -335,12 +338,12 @@ __global__ void sppf_pool_kernel(PoolArgs a) {
     o9[j] = (__bf16)m9[j];
     o13[j] = (__bf16)m13[j];
   }
-  *reinterpret_cast<bf16x8*>(op + a.C) = o5;
-  *reinterpret_cast<bf16x8*>(op + 2 * a.C) = o9;
-  *reinterpret_cast<bf16x8*>(op + 3 * a.C) = o13;
+  *reinterpret_cast<bf16x8*>(pv_ptr(a.v, cg + g8, po)) = o5;
+  *reinterpret_cast<bf16x8*>(pv_ptr(a.v, 2 * cg + g8, po)) = o9;
+  *reinterpret_cast<bf16x8*>(pv_ptr(a.v, 3 * cg + g8, po)) = o13;
 }
 
-// LDS version: one workgroup = one image x 8 channels; the H x W map is staged once (16 bytes per
+// LDS version: one workgroup = one image x one plane; the H x W map is staged once (16 bytes per
 // pixel), row maxima for the 5/9/13 windows are built from it, then column maxima of those.
 // 13 + 27 LDS reads per pixel instead of 169 global loads.
 __device__ __forceinline__ bf16x8 max8(bf16x8 a, bf16x8 b) {
@@ -357,8 +360,10 @@ __global__ __launch_bounds__(256) void sppf_pool_lds_kernel(PoolArgs a) {
   bf16x8* sh = sx + HW;                         // [3][HW] horizontal maxima
   const int cg = a.C >> 3;
   const int b = blockIdx.x / cg, g8 = blockIdx.x % cg;
-  const __bf16* inb = a.in + (long long)b * a.img + a.coff + g8 * 8;
-  for (int p = threadIdx.x; p < HW; p += 256) sx[p] = *reinterpret_cast<const bf16x8*>(inb + (long long)p * a.pitch);
+  for (int p = threadIdx.x; p < HW; p += 256) {
+    const int y = p / a.W, x = p - y * a.W;
+    sx[p] = *reinterpret_cast<const bf16x8*>(pv_ptr(a.v, g8, pv_pix(a.v, b, y, x)));
+  }
   __syncthreads();
   for (int p = threadIdx.x; p < HW; p += 256) {
     const int y = p / a.W, x = p - y * a.W;
@@ -378,9 +383,8 @@ __global__ __launch_bounds__(256) void sppf_pool_lds_kernel(PoolArgs a) {
     sh[2 * HW + p] = m13;
   }
   __syncthreads();
-  __bf16* ob = a.out + (long long)b * a.img + a.coff + g8 * 8;
   for (int p = threadIdx.x; p < HW; p += 256) {
-    const int y = p / a.W;
+    const int y = p / a.W, x = p - y * a.W;
     bf16x8 o[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -393,15 +397,14 @@ __global__ __launch_bounds__(256) void sppf_pool_lds_kernel(PoolArgs a) {
       }
       o[k] = m;
     }
-    __bf16* op = ob + (long long)p * a.pitch;
-    *reinterpret_cast<bf16x8*>(op + a.C) = o[0];
-    *reinterpret_cast<bf16x8*>(op + 2 * a.C) = o[1];
-    *reinterpret_cast<bf16x8*>(op + 3 * a.C) = o[2];
+    const int po = pv_pix(a.v, b, y, x);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) *reinterpret_cast<bf16x8*>(pv_ptr(a.v, (k + 1) * cg + g8, po)) = o[k];
   }
 }
 
 int sppf_pool_launch(const PoolArgs& a, hipStream_t s) {
-  if (a.C % 8 || a.pitch % 8 || a.coff % 8) return fail(-3, "sppf_pool: channels must be multiples of 8");
+  if (a.C % 8) return fail(-3, "sppf_pool: channels must be a multiple of 8");
   const size_t lds = (size_t)a.H * a.W * 16 * 4;
   if (lds <= 150 * 1024) {
     static size_t attr = 0;
@@ -424,25 +427,22 @@ int sppf_pool_launch(const PoolArgs& a, hipStream_t s) {
 __global__ void upsample_kernel(UpArgs a) {
   const int cg = a.C >> 3;
   const int Ho = a.H * a.factor, Wo = a.W * a.factor;
-  const long long total = (long long)a.batch * Ho * Wo * cg;
+  const long long per_plane = (long long)a.batch * Ho * Wo;
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= total) return;
-  const int g8 = (int)(i % cg);
-  long long p = i / cg;
+  if (i >= per_plane * cg) return;
+  const int g8 = (int)(i / per_plane);
+  long long p = i - g8 * per_plane;
   const int x = (int)(p % Wo);
   p /= Wo;
   const int y = (int)(p % Ho);
   const int b = (int)(p / Ho);
-  const int iy = y / a.factor, ix = x / a.factor;
-  const bf16x8 v = *reinterpret_cast<const bf16x8*>(a.in + (long long)b * a.in_img +
-                                                    (long long)(iy * a.W + ix) * a.in_pitch + a.in_coff + g8 * 8);
-  *reinterpret_cast<bf16x8*>(a.out + (long long)b * a.out_img + (long long)(y * Wo + x) * a.out_pitch + a.out_coff +
-                             g8 * 8) = v;
+  const bf16x8 v =
+      *reinterpret_cast<const bf16x8*>(pv_ptr(a.in, g8, pv_pix(a.in, b, y / a.factor, x / a.factor)));
+  *reinterpret_cast<bf16x8*>(pv_ptr(a.out, g8, pv_pix(a.out, b, y, x))) = v;
 }
 
 int upsample_launch(const UpArgs& a, hipStream_t s) {
-  if (a.C % 8 || a.in_pitch % 8 || a.in_coff % 8 || a.out_pitch % 8 || a.out_coff % 8)
-    return fail(-3, "upsample: channels must be multiples of 8");
+  if (a.C % 8) return fail(-3, "upsample: channels must be a multiple of 8");
   const long long total = (long long)a.batch * a.H * a.factor * a.W * a.factor * (a.C / 8);
   hipLaunchKernelGGL(upsample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
   YL_HIP(hipGetLastError());
@@ -478,7 +478,12 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
   const int head = bid % a.heads;
   const int b = bid / a.heads;
   const int hstride = 2 * AT_KD + AT_HD;
-  const __bf16* base = a.qkv + (long long)b * a.in_img + a.in_coff + head * hstride;
+  const int hplane = head * hstride / 8;  // first plane of this head's [q | k | v] block
+  // token t of image b -> pixel index inside a plane
+  auto tok = [&](int t) {
+    const int y = t / a.W;
+    return pv_pix(a.in, b, y, t - y * a.W);
+  };
   const int nqt = (a.N + 15) / 16;                       // query tiles
   const int nstage = (a.N + AT_STAGE - 1) / AT_STAGE;
   const int wslot = qs * 4 + wave;                       // this wave takes q tiles wslot, wslot + 8, ...
@@ -490,7 +495,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
     const bool active = qt < nqt;
     const int q = qt * 16 + n;
     bf16x8 qf = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (active && q < a.N) qf = *reinterpret_cast<const bf16x8*>(base + (long long)q * a.in_pitch + g * 8);
+    if (active && q < a.N) qf = *reinterpret_cast<const bf16x8*>(pv_ptr(a.in, hplane + g, tok(q)));
     float m = ninf, l = 0.f;
     f32x4 acc[4];
 #pragma unroll
@@ -506,14 +511,14 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
           const int key = i >> 2, c8 = i & 3;
           bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
           if (key < nk)
-            v = *reinterpret_cast<const bf16x8*>(base + (long long)(k0s + key) * a.in_pitch + AT_KD + c8 * 8);
+            v = *reinterpret_cast<const bf16x8*>(pv_ptr(a.in, hplane + AT_KD / 8 + c8, tok(k0s + key)));
           *reinterpret_cast<bf16x8*>(sK + key * AT_KP + c8 * 8) = v;
         }
         for (int i = tid; i < nk32 * 8; i += 256) {
           const int key = i >> 3, c8 = i & 7;
           bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
           if (key < nk)
-            v = *reinterpret_cast<const bf16x8*>(base + (long long)(k0s + key) * a.in_pitch + 2 * AT_KD + c8 * 8);
+            v = *reinterpret_cast<const bf16x8*>(pv_ptr(a.in, hplane + 2 * AT_KD / 8 + c8, tok(k0s + key)));
 #pragma unroll
           for (int j = 0; j < 8; ++j) sVt[(c8 * 8 + j) * AT_VP + key] = v[j];
         }
@@ -566,10 +571,11 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
       l += __shfl_xor(l, 32);
       if (q < a.N) {
         const float inv = 1.0f / l;
-        __bf16* op = a.out + (long long)b * a.out_img + (long long)q * a.out_pitch + a.out_coff + head * AT_HD;
+        const int qy = q / a.W;
+        const int po = pv_pix(a.out, b, qy, q - qy * a.W);
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt)
-          *reinterpret_cast<bf16x4*>(op + dt * 16 + 4 * g) =
+          *reinterpret_cast<bf16x4*>(pv_ptr(a.out, (head * AT_HD + dt * 16 + 4 * g) >> 3, po) + ((4 * g) & 7)) =
               bf16x4{(__bf16)(acc[dt][0] * inv), (__bf16)(acc[dt][1] * inv), (__bf16)(acc[dt][2] * inv),
                      (__bf16)(acc[dt][3] * inv)};
       }
@@ -578,8 +584,6 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
 }
 
 int attention_launch(const AttnArgs& a, hipStream_t s) {
-  if (a.in_pitch % 8 || a.in_coff % 8 || a.out_pitch % 4 || a.out_coff % 4)
-    return fail(-3, "attention: channel offsets must be multiples of 8");
   const size_t lds = ((size_t)AT_STAGE * AT_KP + (size_t)AT_HD * AT_VP) * 2;
   static bool attr = false;
   if (!attr) {

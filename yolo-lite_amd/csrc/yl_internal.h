@@ -24,101 +24,120 @@ int fail(int code, const std::string& s);
       return ::yl::fail(-2, std::string(#expr) + ": " + hipGetErrorString(_e));              \
   } while (0)
 
+// ------------------------------------------------------------------- activation layout in HBM
+// bf16 activations are "C8-planar, guarded":  buffer[C/8][plane_px][8]
+//   * one PLANE per group of 8 channels; a pixel of a plane is 16 bytes (one MFMA k-group), so the 16
+//     pixels x 4 k-groups a wave fetches as a B fragment are 4 runs of 256 contiguous bytes -- the
+//     texture addresser serves that at its full 64 B/clk, whereas NHWC (pixels C*2 bytes apart) costs
+//     one clock per lane, 4x slower (measured: tools/micro/ta_rate.hip);
+//   * inside a plane the whole batch is one array of rows, each row followed by one zero GUARD pixel,
+//     each image followed by one zero guard row (plus one guard row in front):
+//         pixel(b, y, x) = g0 + b * img + y * W1 + x,   W1 = W + 1, img = (H + 1) * W1, g0 = W1 + 1
+//     so every 3x3 tap of every pixel is a plain offset (dy * W1 + dx) that lands on real data or on a
+//     zero guard: no per-tap predicates, no halo staging.  Guards are zeroed when a workspace is first
+//     used and never written afterwards (buffers are not recycled between tensors).
+// A channel-slice view (torch.chunk / torch.cat / Concat) is a sub-range of planes.
+// fp32 Detect level maps stay NHWC [B][H][W][64 + nc].
+struct Geo {
+  int W1, img, g0;
+  unsigned plane_px;  // pixels per plane (multiple of 16)
+};
+inline Geo geo_of(int batch, int H, int W) {
+  Geo g;
+  g.W1 = W + 1;
+  g.img = (H + 1) * g.W1;
+  g.g0 = g.W1 + 1;
+  const long long n = (long long)g.g0 + (long long)batch * g.img + 1;
+  g.plane_px = (unsigned)((n + 15) & ~15LL);
+  return g;
+}
+inline long long plane_bytes(const Geo& g) { return (long long)g.plane_px * 16; }
+
 // ----------------------------------------------------------------------------- conv (MFMA)
-// Implicit-GEMM view: rows = output channels (A operand, packed weights), columns = output
-// pixels (B operand, LDS-staged NHWC halo tile), K = taps x input channels in groups of 8.
+// Implicit-GEMM view: rows = output channels (A operand, packed weights staged in LDS), columns =
+// output pixels (B operand, fetched straight from the planes), K = taps x input channels in groups of 8.
 struct ConvArgs {
-  const __bf16* in;
-  void* out;
-  const __bf16* res;   // nullptr: none
-  const __bf16* wpk;   // [cb][chunk][kstep][MT][64 lanes][8]
+  const __bf16* in;    // first plane of the input slice
+  void* out;           // bf16: first plane of the output slice; fp32: NHWC buffer base
+  const __bf16* res;   // first plane of the residual slice, nullptr: none
+  const __bf16* wpk;   // [cb][kstep][MT][64 lanes][8]
   const float* bias;   // padded to ncb*MT*16
-  long long in_img, out_img, res_img;  // elements per image in the underlying buffers
-  int H, W, Ho, Wo;
-  int in_pitch, in_coff, out_pitch, out_coff, res_pitch, res_coff;
-  int Cin, Cout, stride, pad, act, out_f32;
-  int TH, TW, tiles_x, tiles_y, ncb;   // output tile / grid decomposition
-  int HH, HW;                           // halo dims
-  int cch, cg, lg2, nchunks, ksteps, pp;  // chunk channels, groups of 8, log2(pow2>=cg), ...
-  int ntaps;
-  int halo_lds_off, halo_bytes;  // LDS: [filter slab][halo buffer(s)]
-  int ntiles, gws;               // pixel tiles in total / blocks per output-channel block
-  int npatches, ppw;             // direct kernel: wave patches in total / patches per wave
-  int kloop, kkn;                // direct kernel: padded k-step count of the main loop, k-steps per tap
-  unsigned magic_kkn;
-  unsigned magic_hw, magic_tw, magic_cg, magic_wo, magic_ho;  // ceil(2^32 / x) for small-number division
-  int npix;                      // direct kernel: batch * Ho * Wo
+  unsigned in_plane, out_plane, res_plane;  // bytes per plane
+  int Ho, Wo;
+  int in_w1, in_img, in_g0, out_w1, out_img, out_g0;  // guarded geometry (pixels); res shares the output's
+  int out_pitch, out_coff;                  // fp32 NHWC output only
+  int Cin, Cout, stride, act, out_f32;
+  int ncb, cg, ksteps, kchunk, ntaps;       // k-steps in total / per LDS slab
+  int npatches, ppw;                        // wave patches in total / patches per wave
+  int kkn;                                  // k-steps per tap (uniform case)
+  unsigned magic_kkn, magic_cg, magic_wo, magic_ho;  // ceil(2^32 / x) for small-number division
+  int npix;                                 // batch * Ho * Wo
   unsigned in_bytes, out_bytes, res_bytes;  // buffer-descriptor sizes (bytes past the base pointers)
   int nblocks;
   int dbg;  // development ablation flags (YL_CONV_DBG), 0 in production
 };
 
 struct ConvConfig {
-  int MT, NT, uniform, ws;
-  int TH, TW, tiles_x, tiles_y, ncb;
-  int HH, HW, cch, cg, lg2, nchunks, ksteps, pp, ntaps, halo_lds_off, halo_bytes, ntiles, gws, ppw, kloop;
+  int MT, NT, uniform, ncb, cg, ksteps, kchunk, ntaps, npatches, gws, ppw;
   size_t lds_bytes;
   size_t wpk_elems;  // packed weight elements
   const char* name;
 };
 
 // Chooses the tiling for one conv; returns <0 when unsupported.
-int conv_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, int aligned8, ConvConfig* cfg);
+int conv_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, ConvConfig* cfg);
 // Packs folded fp32 OIHW weights into the fragment order cfg describes (host).
-void conv_pack_weights(const float* w_oihw, int Cout, int Cin_w, int Cin_pad, int k, const ConvConfig& cfg,
+void conv_pack_weights(const float* w_oihw, int Cout, int Cin_w, int k, const ConvConfig& cfg,
                        std::vector<uint16_t>* out);
 int conv_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s);
 
 // ------------------------------------------------------------------------ elementwise-ish
+// PView: a channel slice of a planar buffer as the kernels see it.
+struct PView {
+  __bf16* base;     // first plane of the slice
+  long long plane;  // elements per plane
+  int W1, img, g0;
+};
+
 struct DwArgs {
-  const __bf16* in;
-  __bf16* out;
+  PView in, out;
   const float* w;     // [9][C]
   const float* bias;  // [C]
-  long long in_img, out_img;
-  int H, W, C, in_pitch, in_coff, out_pitch, out_coff;
+  int H, W, C;
   int act, accumulate, grp, grp_stride, grp_off;
   int batch;
 };
 int dwconv3_launch(const DwArgs& a, hipStream_t s);
 
 struct PoolArgs {
-  const __bf16* in;  // slice 0 (cv1 output) -- the buffer also receives the three pools
-  __bf16* out;       // same buffer base, slices 1..3 follow at coff + C, +2C, +3C
-  long long img;
-  int H, W, C, pitch, coff, batch;
+  PView v;  // slice 0 (cv1 output); the three pools are written to the C/8 planes after each other
+  int H, W, C, batch;
 };
 int sppf_pool_launch(const PoolArgs& a, hipStream_t s);
 
 struct UpArgs {
-  const __bf16* in;
-  __bf16* out;
-  long long in_img, out_img;
-  int H, W, C, in_pitch, in_coff, out_pitch, out_coff, factor, batch;  // H, W = input dims
+  PView in, out;
+  int H, W, C, factor, batch;  // H, W = input dims
 };
 int upsample_launch(const UpArgs& a, hipStream_t s);
 
 struct AttnArgs {
-  const __bf16* qkv;
-  __bf16* out;
-  long long in_img, out_img;
-  int N, heads, in_pitch, in_coff, out_pitch, out_coff, batch;
+  PView in, out;
+  int H, W, N, heads, batch;
   float scale;
 };
 int attention_launch(const AttnArgs& a, hipStream_t s);
 
 struct StemArgs {
   const void* in;     // NCHW [B][3][H][W]
-  __bf16* out;
+  PView out;
   const float* w;     // [Cout][27] (bf16-rounded values)
   const float* bias;
-  long long out_img;
-  int B, H, W, Ho, Wo, Cout, out_pitch, out_coff, act, nseg;
+  int B, H, W, Ho, Wo, Cout, act, nseg;
 };
 int stem_launch(const StemArgs& a, int in_dtype, hipStream_t s);
 
-int convert_input_launch(const void* in, int in_dtype, __bf16* out, int batch, int H, int W, int pitch,
-                         long long out_img, hipStream_t s);
+int convert_input_launch(const void* in, int in_dtype, const PView& out, int batch, int H, int W, hipStream_t s);
 
 struct DecodeLevel {
   const float* raw;  // [B][H][W][64+nc]

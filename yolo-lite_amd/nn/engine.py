@@ -12,7 +12,7 @@ import torch
 
 from .. import _lib
 from .arch import LayerSpec
-from .lower import BF16, F32, Program, TView, lower
+from .lower import BF16, F32, Program, TView, lower, plane_pixels
 
 _TORCH2YL = {torch.float32: _lib.YL_F32, torch.float16: _lib.YL_F16, torch.uint8: _lib.YL_U8}
 
@@ -67,16 +67,20 @@ class HipEngine:
             _lib.check(self.lib.yl_engine_create(arr, len(ops), batch, in_h, in_w, C.byref(iv), lv, len(lv), self.nc,
                                                  self.prog.ws_bytes, C.byref(handle)), "yl_engine_create")
             self.workspace = torch.empty(self.prog.ws_bytes, dtype=torch.uint8, device=device)
+            # zero the guard pixels of the planar layout once; no kernel ever writes them
+            _lib.check(self.lib.yl_engine_prepare_workspace(handle, self.workspace.data_ptr(),
+                                                            torch.cuda.current_stream(device).cuda_stream),
+                       "yl_engine_prepare_workspace")
         self._h = handle
         self._keep.clear()  # weights were packed and uploaded by yl_engine_create
 
     @classmethod
     def from_model(cls, specs: Sequence[LayerSpec], state_dict: Dict[str, torch.Tensor], batch: int, in_h: int,
                    in_w: int, device: torch.device, strides: Sequence[float] = (8.0, 16.0, 32.0),
-                   keep_layers: bool = False) -> "HipEngine":
-        """``keep_layers=True`` gives every layer its own buffer (debug: ``layer_output``); the default
-        recycles dead buffers so consecutive layers hand tensors over through the Infinity Cache."""
-        return cls(lower(specs, state_dict, batch, in_h, in_w, strides, reuse=not keep_layers), device)
+                   keep_layers: bool = True) -> "HipEngine":
+        """Every layer keeps its own buffer (``layer_output`` works on any engine); ``keep_layers`` is
+        accepted for compatibility and ignored."""
+        return cls(lower(specs, state_dict, batch, in_h, in_w, strides), device)
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -151,12 +155,33 @@ class HipEngine:
             out.append(t.view(self.batch, L["H"], L["W"], no).permute(0, 3, 1, 2))
         return out
 
+    def _planes(self, v: TView) -> torch.Tensor:
+        """The guarded planes of a bf16 view as a (C/8, B, H+1, W+1, 8) tensor aliasing the workspace
+        (index [..., :H, :W, :] is the data, the rest are guard pixels)."""
+        pp = plane_pixels(self.batch, v.H, v.W)
+        n = (v.pitch // 8) * pp * 8
+        t = self.workspace[v.offset: v.offset + 2 * n].view(torch.bfloat16).view(v.pitch // 8, pp, 8)
+        t = t[v.coff // 8: (v.coff + v.C) // 8, v.W + 2: v.W + 2 + self.batch * (v.H + 1) * (v.W + 1)]
+        return t.view(v.C // 8, self.batch, v.H + 1, v.W + 1, 8)
+
     def view_tensor(self, v: TView) -> torch.Tensor:
         """Copy of an arena view as an NCHW fp32 tensor (debug / per-layer parity tests)."""
-        esz, dt = (4, torch.float32) if v.dtype == F32 else (2, torch.bfloat16)
-        n = self.batch * v.H * v.W * v.pitch
-        t = self.workspace[v.offset: v.offset + esz * n].view(dt).view(self.batch, v.H, v.W, v.pitch)
-        return t[..., v.coff: v.coff + v.C].permute(0, 3, 1, 2).float().contiguous()
+        if v.dtype == F32:
+            n = self.batch * v.H * v.W * v.pitch
+            t = self.workspace[v.offset: v.offset + 4 * n].view(torch.float32).view(self.batch, v.H, v.W, v.pitch)
+            return t[..., v.coff: v.coff + v.C].permute(0, 3, 1, 2).contiguous()
+        t = self._planes(v)[:, :, : v.H, : v.W]  # (C/8, B, H, W, 8)
+        return t.permute(1, 0, 4, 2, 3).reshape(self.batch, v.C, v.H, v.W).float().contiguous()
+
+    def write_view(self, v: TView, x: torch.Tensor) -> None:
+        """Store an NCHW tensor into a bf16 arena view (tests / micro-benchmarks)."""
+        t = x.to(self.device, torch.bfloat16).view(self.batch, v.C // 8, 8, v.H, v.W).permute(1, 0, 3, 4, 2)
+        self._planes(v)[:, :, : v.H, : v.W] = t
+
+    def guards_are_zero(self, v: TView) -> bool:
+        """True if no kernel has written a guard pixel of this view (layout invariant, tests)."""
+        t = self._planes(v)
+        return bool((t[:, :, v.H, :] == 0).all()) and bool((t[:, :, :, v.W] == 0).all())
 
     def layer_output(self, i: int) -> torch.Tensor:
         return self.view_tensor(self.prog.layer_views[i])

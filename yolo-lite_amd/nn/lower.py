@@ -4,7 +4,8 @@ Reference behaviour being lowered (all under /root/reference/yololite):
 ``nn/tasks.py:118-145`` (layer loop and skip list), ``nn/modules/block.py`` (C3k2/C3k/Bottleneck/SPPF/
 C2PSA/PSABlock/Attention forward methods), ``nn/modules/head.py:59-69`` (Detect.forward) and
 ``nn/modules/conv.py:321-331`` (Concat).  ``chunk``/``split``/``cat`` never move data here: producers
-write straight into channel slices of the consumer's buffer (NHWC, so a slice is a strided view),
+write straight into channel slices of the consumer's buffer (activations are stored as planes of 8
+channels -- see ``plane_pixels`` -- so a slice is a range of planes),
 Conv+BN are folded with the formula of ``utils/torch_utils.py:182-209`` (eps 1e-3, ``:249``) and the
 Bottleneck / PSABlock residual adds run in the producing conv's epilogue.
 """
@@ -51,106 +52,41 @@ class Program:
     layer_views: Dict[int, TView] = field(default_factory=dict)
     anchors: int = 0
     strides: Tuple[float, ...] = ()
-    alloc_table: List[tuple] = field(default_factory=list)
+
+
+def plane_pixels(batch: int, H: int, W: int) -> int:
+    """Pixels per plane of the C8-planar guarded bf16 layout (mirror of ``geo_of`` in csrc/yl_internal.h).
+
+    buffer[C/8][plane_pixels][8]: one plane per 8 channels; inside a plane the whole batch is one array
+    of rows, each row followed by a zero guard pixel and each image by a zero guard row, so that every
+    3x3 tap of every pixel is a constant offset that lands on data or on a zero:
+    ``pixel(b, y, x) = g0 + b * (H + 1) * (W + 1) + y * (W + 1) + x`` with ``g0 = W + 2``.
+    """
+    n = (W + 2) + batch * (H + 1) * (W + 1) + 1
+    return (n + 15) // 16 * 16
+
+
+def view_bytes(batch: int, v: "TView") -> int:
+    """Bytes of the whole buffer underneath a view."""
+    if v.dtype == F32:
+        return batch * v.H * v.W * v.pitch * 4
+    return (v.pitch // 8) * plane_pixels(batch, v.H, v.W) * 16
 
 
 class _Arena:
+    """Bump allocator.  Buffers are never recycled: the guard pixels of the planar layout are zeroed
+    once per workspace and must stay untouched (capacity is not a concern with 288 GB of HBM)."""
+
     def __init__(self, batch: int):
         self.batch = batch
         self.top = 0
-        self.sizes: Dict[int, int] = {}  # buffer (identified by its bump offset) -> bytes
 
     def alloc(self, H: int, W: int, C: int, dtype: int = BF16) -> TView:
-        esz = 4 if dtype == F32 else 2
-        off = self.top
-        nbytes = (self.batch * H * W * C * esz + 255) // 256 * 256
-        self.sizes[off] = nbytes
-        self.top = off + nbytes
-        return TView(off, H, W, C, C, 0, dtype)
-
-
-def compact_arena(prog: "Program", sizes: Dict[int, int]) -> int:
-    """Re-assign buffer offsets by liveness so that the working set of consecutive layers stays small.
-
-    Every buffer lives from the first op that touches it to the last; dead buffers are recycled
-    (address-ordered first fit with coalescing).  The point is not capacity (288 GB) but locality:
-    a layer's output lands in memory that was read moments ago, so at batch 32 the ~50-100 MB
-    producer/consumer hand-offs stay inside the 256 MB Infinity Cache instead of streaming 1.9 GB
-    of distinct addresses through HBM.  Returns the new arena size.
-    """
-    n = len(prog.ops)
-    first: Dict[int, int] = {}
-    last: Dict[int, int] = {}
-
-    def touch(v: Optional[TView], i: int):
-        if v is None:
-            return
-        first[v.offset] = min(first.get(v.offset, i), i)
-        last[v.offset] = max(last.get(v.offset, i), i)
-
-    touch(prog.input_view, -1)
-    for i, o in enumerate(prog.ops):
-        for k in ("inp", "out", "res"):
-            touch(o.get(k), i)
-            if o.get("lane", 0):  # side lanes run concurrently with later ops: alive until the join
-                touch(o.get(k), n)
-    for L in prog.levels:  # raw level maps are read by the decode after the last op
-        first[L["offset"]] = min(first.get(L["offset"], n), n)
-        last[L["offset"]] = n
-    free: List[List[int]] = []  # [start, end) sorted by start
-    top = 0
-    newoff: Dict[int, int] = {}
-    by_first: Dict[int, List[int]] = {}
-    by_last: Dict[int, List[int]] = {}
-    for b in first:
-        by_first.setdefault(first[b], []).append(b)
-        by_last.setdefault(last[b], []).append(b)
-
-    def take(nbytes: int) -> int:
-        nonlocal top
-        for iv in free:
-            if iv[1] - iv[0] >= nbytes:
-                st = iv[0]
-                iv[0] += nbytes
-                if iv[0] == iv[1]:
-                    free.remove(iv)
-                return st
-        st = top
-        top += nbytes
-        return st
-
-    def give(st: int, nbytes: int):
-        free.append([st, st + nbytes])
-        free.sort()
-        merged: List[List[int]] = []
-        for iv in free:
-            if merged and merged[-1][1] == iv[0]:
-                merged[-1][1] = iv[1]
-            else:
-                merged.append(iv)
-        free[:] = merged
-
-    for i in range(-1, n + 1):
-        for b in sorted(by_first.get(i, []), key=lambda x: -sizes[x]):
-            newoff[b] = take(sizes[b])
-        for b in by_last.get(i, []):
-            give(newoff[b], sizes[b])
-    seen = set()
-
-    def remap(v: Optional[TView]):
-        if v is not None and id(v) not in seen:
-            seen.add(id(v))
-            v.offset = newoff[v.offset]
-
-    remap(prog.input_view)
-    for o in prog.ops:
-        for k in ("inp", "out", "res"):
-            remap(o.get(k))
-    for L in prog.levels:
-        L["offset"] = newoff[L["offset"]]
-    prog.layer_views = {}  # intermediate layers are no longer all alive at the end
-    prog.alloc_table = [(first[b], last[b], newoff[b], sizes[b]) for b in first]  # for the overlap test
-    return top
+        if dtype != F32 and C % 8:
+            raise NotImplementedError(f"bf16 activations need channel counts that are multiples of 8, got {C}")
+        v = TView(self.top, H, W, C, C, 0, dtype)
+        self.top += (view_bytes(self.batch, v) + 255) // 256 * 256
+        return v
 
 
 def fold_conv_bn(sd: Dict[str, torch.Tensor], name: str, bn: bool = True) -> Tuple[np.ndarray, np.ndarray]:
@@ -174,7 +110,7 @@ def _out_hw(h: int, w: int, k: int, s: int) -> Tuple[int, int]:
 
 
 def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, in_h: int, in_w: int,
-          strides: Sequence[float] = (8.0, 16.0, 32.0), reuse: bool = True, side_lanes: bool = True,
+          strides: Sequence[float] = (8.0, 16.0, 32.0), side_lanes: bool = True,
           fused_stem: bool = True) -> Program:
     det = specs[-1]
     assert det.kind == "Detect"
@@ -362,5 +298,5 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
         a_total += level_rec[lvl]["H"] * level_rec[lvl]["W"]
     prog.anchors = a_total
     prog.layer_views = views
-    prog.ws_bytes = (compact_arena(prog, ar.sizes) if reuse else ar.top) + 256
+    prog.ws_bytes = ar.top + 256
     return prog
