@@ -207,22 +207,30 @@ int stem_launch(const StemArgs& a0, int in_dtype, hipStream_t s) {
 // and the 9 x 8 filter taps are loaded once and reused (4.5 sixteen-byte loads per output instead of
 // 9).  The zero padding comes from the guard pixels of the layout: no bounds tests on the taps.
 // Thread order: pixel runs fastest, planes slowest -> a wave reads contiguous memory.
-constexpr int DW_PX = 4;
+template <int DW_PX>
 __global__ __launch_bounds__(256) void dwconv3_kernel(DwArgs a) {
-  const int cg = a.C >> 3;
-  const int wq = (a.W + DW_PX - 1) / DW_PX;
-  const long long per_plane = (long long)a.batch * a.H * wq;
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= per_plane * cg) return;
-  const int g8 = (int)(i / per_plane);
-  long long p = i - g8 * per_plane;
-  const int x0 = (int)(p % wq) * DW_PX;
-  p /= wq;
-  const int y = (int)(p % a.H);
-  const int b = (int)(p / a.H);
+  const unsigned wq = (unsigned)(a.W + DW_PX - 1) / DW_PX;
+  const unsigned per_plane = (unsigned)a.batch * a.H * wq;  // < 2^31 (host-checked)
+  unsigned p = blockIdx.x * 256u + threadIdx.x;
+  if (p >= per_plane) return;
+  const int g8 = blockIdx.y;  // plane: wave-uniform, so the filter / bias loads are scalar
+  const unsigned row = p / wq;
+  const int x0 = (int)(p - row * wq) * DW_PX;
+  const int b = (int)(row / (unsigned)a.H);
+  const int y = (int)(row - (unsigned)b * a.H);
   const int c = g8 * 8;
   const int cin = a.grp ? (c / a.grp) * a.grp_stride + a.grp_off + (c % a.grp) : c;
   const __bf16* inb = pv_ptr(a.in, cin >> 3, pv_pix(a.in, b, y, x0));
+  // all 3 x (DW_PX + 2) input pixels are requested before the first use: one memory round trip
+  bf16x8 v[3][DW_PX + 2];
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+    for (int t = 0; t < DW_PX + 2; ++t) {
+      // columns beyond the guard (ragged last run only) are clamped onto the guard: zeros
+      const int dx = min(t - 1, a.W - x0);
+      v[kh][t] = *reinterpret_cast<const bf16x8*>(inb + ((kh - 1) * a.in.W1 + dx) * 8);
+    }
   float acc[DW_PX][8];
   {
     const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias + c), b1 = *reinterpret_cast<const f32x4*>(a.bias + c + 4);
@@ -249,11 +257,9 @@ __global__ __launch_bounds__(256) void dwconv3_kernel(DwArgs a) {
     }
 #pragma unroll
     for (int t = 0; t < DW_PX + 2; ++t) {  // input column x0 - 1 + t feeds outputs q = t - kw
-      if (x0 - 1 + t > a.W) continue;      // beyond the guard column (ragged last run only)
-      const bf16x8 v = *reinterpret_cast<const bf16x8*>(inb + ((kh - 1) * a.in.W1 + t - 1) * 8);
       float f[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) f[j] = (float)v[j];
+      for (int j = 0; j < 8; ++j) f[j] = (float)v[kh][t][j];
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
         const int q = t - kw;
@@ -282,11 +288,20 @@ __global__ __launch_bounds__(256) void dwconv3_kernel(DwArgs a) {
   }
 }
 
+template <int PX>
+static void dw_launch_px(const DwArgs& a, hipStream_t s) {
+  const long long per_plane = (long long)a.batch * a.H * ((a.W + PX - 1) / PX);
+  hipLaunchKernelGGL(dwconv3_kernel<PX>, dim3((unsigned)((per_plane + 255) / 256), a.C / 8), dim3(256), 0, s, a);
+}
+
 int dwconv3_launch(const DwArgs& a, hipStream_t s) {
   if (a.C % 8 || (a.grp && (a.grp % 8 || a.grp_stride % 8 || a.grp_off % 8)))
     return fail(-3, "dwconv3: channel counts must be multiples of 8");
-  const long long total = (long long)a.batch * a.H * ((a.W + DW_PX - 1) / DW_PX) * (a.C / 8);
-  hipLaunchKernelGGL(dwconv3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+  if ((long long)a.batch * a.H * a.W >= (1LL << 31) || a.C / 8 > 65535) return fail(-3, "dwconv3: tensor too large");
+  static const int px = getenv("YL_DW_PX") ? atoi(getenv("YL_DW_PX")) : 2;
+  if (px == 1) dw_launch_px<1>(a, s);
+  else if (px == 2) dw_launch_px<2>(a, s);
+  else dw_launch_px<4>(a, s);
   YL_HIP(hipGetLastError());
   return 0;
 }
@@ -425,17 +440,15 @@ int sppf_pool_launch(const PoolArgs& a, hipStream_t s) {
 // -------------------------------------------------------------- nearest upsample / slice copy
 // nn.Upsample(None, 2, "nearest") of yolo11.yaml:31,35 written straight into the Concat buffer.
 __global__ void upsample_kernel(UpArgs a) {
-  const int cg = a.C >> 3;
-  const int Ho = a.H * a.factor, Wo = a.W * a.factor;
-  const long long per_plane = (long long)a.batch * Ho * Wo;
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= per_plane * cg) return;
-  const int g8 = (int)(i / per_plane);
-  long long p = i - g8 * per_plane;
-  const int x = (int)(p % Wo);
-  p /= Wo;
-  const int y = (int)(p % Ho);
-  const int b = (int)(p / Ho);
+  const unsigned Ho = a.H * a.factor, Wo = a.W * a.factor;
+  const unsigned per_plane = (unsigned)a.batch * Ho * Wo;  // < 2^31 (host-checked)
+  const unsigned p = blockIdx.x * 256u + threadIdx.x;
+  if (p >= per_plane) return;
+  const int g8 = blockIdx.y;
+  const unsigned row = p / Wo;
+  const int x = (int)(p - row * Wo);
+  const int b = (int)(row / Ho);
+  const int y = (int)(row - (unsigned)b * Ho);
   const bf16x8 v =
       *reinterpret_cast<const bf16x8*>(pv_ptr(a.in, g8, pv_pix(a.in, b, y / a.factor, x / a.factor)));
   *reinterpret_cast<bf16x8*>(pv_ptr(a.out, g8, pv_pix(a.out, b, y, x))) = v;
@@ -443,8 +456,9 @@ __global__ void upsample_kernel(UpArgs a) {
 
 int upsample_launch(const UpArgs& a, hipStream_t s) {
   if (a.C % 8) return fail(-3, "upsample: channels must be a multiple of 8");
-  const long long total = (long long)a.batch * a.H * a.factor * a.W * a.factor * (a.C / 8);
-  hipLaunchKernelGGL(upsample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+  const long long per_plane = (long long)a.batch * a.H * a.factor * a.W * a.factor;
+  if (per_plane >= (1LL << 31) || a.C / 8 > 65535) return fail(-3, "upsample: tensor too large");
+  hipLaunchKernelGGL(upsample_kernel, dim3((unsigned)((per_plane + 255) / 256), a.C / 8), dim3(256), 0, s, a);
   YL_HIP(hipGetLastError());
   return 0;
 }
