@@ -198,6 +198,26 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
     level_of = {j: lvl for lvl, j in enumerate(det.f)}
     level_rec: Dict[int, dict] = {}
 
+    # Lane policy.  side_lanes=True: the class branch of the first (largest) level runs on side lane 1,
+    # everything else on the main stream (measured best on MI355X among ~15 maps: cross-stream edges
+    # inside a hipGraph cost 5-60 us each, so only the longest chain -- five 80x80 kernels that overlap
+    # the 80x80 box branch and the 40x40 neck -- is worth a fork; 1.37 -> 1.21 ms end to end).
+    # YL_LANES="b0c0b1c1b2c2" (one lane digit per level and branch) overrides it for experiments.
+    import os
+    nlv = len(det.f)
+    lanes = [0] * (2 * nlv)
+    if side_lanes and nlv > 1:
+        lanes[1] = 1
+    env = os.environ.get("YL_LANES", "")
+    if len(env) == 2 * nlv and env.isdigit():
+        lanes = [int(ch) for ch in env]
+
+    def box_lane(lvl: int) -> int:
+        return lanes[2 * lvl]
+
+    def cls_lane(lvl: int) -> int:
+        return lanes[2 * lvl + 1]
+
     def emit_level(lvl: int, xin: TView):
         h, w = xin.H, xin.W
         head = ar.alloc(h, w, 64 + det.nc, F32)
@@ -207,7 +227,7 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
         conv(f"{dp}.cv2.{lvl}.1", t1, t2, 3, 1)
         conv(f"{dp}.cv2.{lvl}.2", t2, head.slice(0, 64), 1, 1, act=False, bn=False)
         for o in ops[n0:]:
-            o["lane"] = 1 + 2 * lvl if side_lanes else 0
+            o["lane"] = box_lane(lvl)
         n1 = len(ops)
         d1, e1 = ar.alloc(h, w, xin.C), ar.alloc(h, w, c3)
         dwconv(f"{dp}.cv3.{lvl}.0.0", xin, d1)
@@ -217,7 +237,7 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
         conv(f"{dp}.cv3.{lvl}.1.1", d2, e2, 1, 1)
         conv(f"{dp}.cv3.{lvl}.2", e2, head.slice(64, det.nc), 1, 1, act=False, bn=False)
         for o in ops[n1:]:
-            o["lane"] = 2 + 2 * lvl if side_lanes else 0
+            o["lane"] = cls_lane(lvl)
         level_rec[lvl] = dict(offset=head.offset, H=h, W=w, stride=float(strides[lvl]))
 
     views: Dict[int, TView] = {}
