@@ -158,6 +158,15 @@ int yl_decode_nms(const void* workspace, const yl_level* levels, int n_levels, i
                   int n_classes, int max_cand, float max_wh, const float* scale, float* out,
                   int32_t* out_count, void* work, void* stream);
 
+/* The whole hot path -- yl_engine_forward (raw maps only) followed by yl_decode_nms -- replayed from
+ * one hipGraph captured on first use for this exact argument tuple (every pointer and threshold is
+ * baked in; the contents of input / classes / scale may change between calls).  One launch, no host
+ * round trip between the network and the NMS. */
+int yl_engine_detect_graph(yl_engine* e, const void* input, int in_dtype, void* workspace,
+                           float conf_thres, float iou_thres, int max_det, int agnostic,
+                           const int32_t* classes, int n_classes, int max_cand, float max_wh,
+                           const float* scale, float* out, int32_t* out_count, void* work, void* stream);
+
 /* uint8 HWC BGR letterboxed images -> float NCHW RGB / 255 (engine/predictor.py:77-84). */
 int yl_preprocess_u8(const uint8_t* bgr_hwc, int batch, int h, int w, float* out_nchw, void* stream);
 

@@ -18,7 +18,7 @@ OP_CONV, OP_DWCONV3, OP_SPPF_POOL, OP_UPSAMPLE, OP_ATTENTION, OP_STEM = 1, 2, 3,
 EXPORTS = (
     "yl_last_error", "yl_abi_version", "yl_device_count", "yl_engine_create", "yl_engine_destroy",
     "yl_engine_prepare_workspace", "yl_engine_forward", "yl_engine_forward_graph", "yl_engine_profile", "yl_engine_num_ops",
-    "yl_engine_op_info", "yl_detect_decode", "yl_nms_workspace_bytes", "yl_nms", "yl_decode_nms",
+    "yl_engine_op_info", "yl_engine_detect_graph", "yl_detect_decode", "yl_nms_workspace_bytes", "yl_nms", "yl_decode_nms",
     "yl_preprocess_u8",
 )
 
@@ -106,6 +106,8 @@ def lib() -> C.CDLL:
     L.yl_decode_nms.restype = i32
     L.yl_decode_nms.argtypes = [vp, C.POINTER(Level), i32, i32, i32, f32, f32, i32, i32, vp, i32, i32, f32, vp, vp, vp,
                                 vp, vp]
+    L.yl_engine_detect_graph.restype = i32
+    L.yl_engine_detect_graph.argtypes = [vp, vp, i32, vp, f32, f32, i32, i32, vp, i32, i32, f32, vp, vp, vp, vp, vp]
     L.yl_preprocess_u8.restype = i32
     L.yl_preprocess_u8.argtypes = [vp, i32, i32, i32, vp, vp]
     if L.yl_abi_version() != 1:

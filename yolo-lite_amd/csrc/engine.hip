@@ -50,6 +50,11 @@ struct yl_engine {
     }
   };
   std::map<GraphKey, hipGraphExec_t> graphs;
+  // whole hot path (network + fused decode + NMS) as one graph, keyed by every baked-in argument
+  typedef std::tuple<const void*, int, void*, float, float, int, int, const void*, int, int, float, const void*, void*,
+                     void*, void*>
+      DetectKey;
+  std::map<DetectKey, hipGraphExec_t> dgraphs;
   hipStream_t cap_stream = nullptr;
   // side lanes (yl_op.lane > 0): one non-blocking stream each + a pool of fork/join events
   std::vector<hipStream_t> lanes;
@@ -110,6 +115,7 @@ extern "C" int yl_device_count(void) {
 extern "C" void yl_engine_destroy(yl_engine* e) {
   if (!e) return;
   for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
+  for (auto& kv : e->dgraphs) (void)hipGraphExecDestroy(kv.second);
   if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
   for (hipStream_t st : e->lanes)
     if (st) (void)hipStreamDestroy(st);
@@ -483,6 +489,57 @@ extern "C" int yl_engine_forward_graph(yl_engine* e, const void* input, int in_d
     (void)hipGraphDestroy(g);
     if (ie != hipSuccess) return fail(-2, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie));
     it = e->graphs.emplace(key, ge).first;
+  }
+  YL_HIP(hipGraphLaunch(it->second, s));
+  return 0;
+}
+
+static int detect_eager(yl_engine* e, const void* input, int in_dtype, void* workspace, float conf_thres,
+                        float iou_thres, int max_det, int agnostic, const int32_t* classes, int n_classes,
+                        int max_cand, float max_wh, const float* scale, float* out, int32_t* out_count, void* work,
+                        void* stream) {
+  if (int rc = yl_engine_forward(e, input, in_dtype, workspace, nullptr, stream)) return rc;
+  return yl_decode_nms(workspace, e->levels.data(), (int)e->levels.size(), e->batch, e->nc, conf_thres, iou_thres,
+                       max_det, agnostic, classes, n_classes, max_cand, max_wh, scale, out, out_count, work, stream);
+}
+
+extern "C" int yl_engine_detect_graph(yl_engine* e, const void* input, int in_dtype, void* workspace,
+                                      float conf_thres, float iou_thres, int max_det, int agnostic,
+                                      const int32_t* classes, int n_classes, int max_cand, float max_wh,
+                                      const float* scale, float* out, int32_t* out_count, void* work, void* stream) {
+  if (!e || !input || !workspace || !out || !out_count || !work)
+    return fail(-1, "yl_engine_detect_graph: null pointer");
+  if (e->levels.empty()) return fail(-1, "yl_engine_detect_graph: engine has no Detect levels");
+  hipStream_t s = (hipStream_t)stream;
+  yl_engine::DetectKey key(input, in_dtype, workspace, conf_thres, iou_thres, max_det, agnostic, classes, n_classes,
+                           max_cand, max_wh, scale, out, out_count, work);
+  auto it = e->dgraphs.find(key);
+  if (it == e->dgraphs.end()) {
+    if (e->dgraphs.size() >= 8) {
+      for (auto& kv : e->dgraphs) (void)hipGraphExecDestroy(kv.second);
+      e->dgraphs.clear();
+    }
+    // eager first: argument checks, workspace preparation and lazy function attributes happen here
+    if (int rc = detect_eager(e, input, in_dtype, workspace, conf_thres, iou_thres, max_det, agnostic, classes,
+                              n_classes, max_cand, max_wh, scale, out, out_count, work, stream))
+      return rc;
+    YL_HIP(hipStreamSynchronize(s));
+    if (!e->cap_stream) YL_HIP(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
+    hipGraph_t g = nullptr;
+    YL_HIP(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal));
+    int rc = detect_eager(e, input, in_dtype, workspace, conf_thres, iou_thres, max_det, agnostic, classes, n_classes,
+                          max_cand, max_wh, scale, out, out_count, work, (void*)e->cap_stream);
+    hipError_t ce = hipStreamEndCapture(e->cap_stream, &g);
+    if (rc) {
+      if (g) (void)hipGraphDestroy(g);
+      return rc;
+    }
+    if (ce != hipSuccess) return fail(-2, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
+    hipGraphExec_t ge = nullptr;
+    hipError_t ie = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (ie != hipSuccess) return fail(-2, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie));
+    it = e->dgraphs.emplace(key, ge).first;
   }
   YL_HIP(hipGraphLaunch(it->second, s));
   return 0;

@@ -124,25 +124,48 @@ class HipEngine:
         """Network + fused Detect decode + NMS; returns padded (out[B, max_det, 6], count[B]).
 
         Bit-identical to ``forward`` followed by ``utils.ops.nms_padded`` but the (B, 4+nc, A) tensor
-        of the reference (head.py:126) is never materialised.  No host synchronisation."""
+        of the reference (head.py:126) is never materialised.  No host synchronisation.  With
+        ``graph=True`` the whole path is ONE hipGraph launch and the returned tensors are engine-owned
+        buffers that stay valid until the next ``detect`` call with the same ``max_det``."""
         from ..utils import ops as _ops
 
-        self.forward(im, graph=graph, decode=False)
+        self._check_input(im)
         max_cand = min(int(max_nms), self.anchors)
         work = _ops._nms_workspace(self.device, self.batch, self.anchors, max_cand)
-        out = torch.empty((self.batch, max_det, 6), dtype=torch.float32, device=self.device)
-        cnt = torch.empty((self.batch,), dtype=torch.int32, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        st = self.__dict__.setdefault("_det_static", {})
+        if graph:
+            if max_det not in st:
+                st[max_det] = (torch.empty((self.batch, max_det, 6), dtype=torch.float32, device=self.device),
+                               torch.empty((self.batch,), dtype=torch.int32, device=self.device))
+            out, cnt = st[max_det]
+        else:
+            out = torch.empty((self.batch, max_det, 6), dtype=torch.float32, device=self.device)
+            cnt = torch.empty((self.batch,), dtype=torch.int32, device=self.device)
         cls_t = None
         if classes is not None:
-            cls_t = torch.as_tensor(list(np.atleast_1d(classes)), dtype=torch.int32, device=self.device)
-        stream = torch.cuda.current_stream(self.device).cuda_stream
-        rc = self.lib.yl_decode_nms(self.workspace.data_ptr(), self._levels, len(self._levels), self.batch, self.nc,
-                                    float(conf), float(iou), int(max_det), int(bool(agnostic)),
-                                    cls_t.data_ptr() if cls_t is not None else None,
-                                    int(cls_t.numel()) if cls_t is not None else 0, max_cand, float(max_wh),
-                                    scale.data_ptr() if scale is not None else None, out.data_ptr(), cnt.data_ptr(),
-                                    work.data_ptr(), stream)
-        _lib.check(rc, "yl_decode_nms")
+            ck = ("cls", tuple(int(c) for c in np.atleast_1d(classes)))
+            if ck not in st:  # graphs bake the pointer: one device copy per distinct class filter
+                st[ck] = torch.as_tensor(list(ck[1]), dtype=torch.int32, device=self.device)
+            cls_t = st[ck]
+        if scale is not None and graph:
+            if "scale" not in st:
+                st["scale"] = torch.empty((self.batch, 5), dtype=torch.float32, device=self.device)
+            st["scale"].copy_(scale.reshape(self.batch, 5))
+            scale = st["scale"]
+        args = (float(conf), float(iou), int(max_det), int(bool(agnostic)),
+                cls_t.data_ptr() if cls_t is not None else None, int(cls_t.numel()) if cls_t is not None else 0,
+                max_cand, float(max_wh), scale.data_ptr() if scale is not None else None, out.data_ptr(),
+                cnt.data_ptr(), work.data_ptr(), stream)
+        if graph:
+            rc = self.lib.yl_engine_detect_graph(self._h, im.data_ptr(), _TORCH2YL[im.dtype],
+                                                 self.workspace.data_ptr(), *args)
+            _lib.check(rc, "yl_engine_detect_graph")
+        else:
+            self.forward(im, graph=False, decode=False)
+            rc = self.lib.yl_decode_nms(self.workspace.data_ptr(), self._levels, len(self._levels), self.batch,
+                                        self.nc, *args)
+            _lib.check(rc, "yl_decode_nms")
         return out, cnt
 
     def raw_levels(self) -> List[torch.Tensor]:
