@@ -1,0 +1,20 @@
+#!/bin/bash
+# Collects the round's profile on the GPU box into gpurun_out/$1 (kernel trace + stats, HBM counters in
+# separate passes as MI355X_MICROARCH.md prescribes, the un-profiled bench line and the per-op table).
+#   gpurun --timeout 1500 -- 'bash tools/profile_round.sh r01'
+# then:  python tools/summarize_profile.py gpurun_out/r01 profiles r01
+set -u
+TAG=${1:-r01}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+python3 $R/bench.py --steps 50 --warmup 10 --profile-out $OUT/per_op.json > $OUT/bench.json 2> $OUT/bench.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/trace.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
+# keep only the small CSVs
+find $OUT -name "*.db" -delete
+find $OUT -name "*kernel_trace.csv" -size +20M -delete
+ls -la $OUT $OUT/trace/* | head -30
+tail -1 $OUT/bench.json
