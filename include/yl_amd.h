@@ -84,7 +84,9 @@ typedef struct yl_op {
   const float* bias;
 } yl_op;
 
-/* Detect-level raw map: fp32 NHWC [B][H][W][64 + nc] (reference head.py:64-65 torch.cat(cv2, cv3)) */
+/* Detect-level raw map (reference head.py:64-65 torch.cat(cv2, cv3)), fp32, stored as two NHWC blocks
+ * back to back: box logits [B][H][W][64] at `offset`, class logits [B][H][W][nc] right behind them
+ * (the NMS front end streams only the class block and touches box rows of surviving anchors). */
 typedef struct yl_level {
   int64_t offset;
   int32_t H, W;

@@ -131,10 +131,13 @@ def test_decode_vs_oracle(gpu_device):
     ref = oracle.detect_decode(raw, (8.0, 16.0, 32.0))
     sd = synth_state_dict("n", 0)
     eng = _engine("n", sd, 2, 96, 128, gpu_device)
-    for r, L in zip(raw, eng.prog.levels):
-        n = 2 * L["H"] * L["W"] * 144
-        eng.workspace[L["offset"]: L["offset"] + 4 * n].view(torch.float32).copy_(
-            r.permute(0, 2, 3, 1).contiguous().flatten().to(gpu_device))
+    for r, L in zip(raw, eng.prog.levels):  # level map = box block [B][H][W][64] + class block [B][H][W][80]
+        px = 2 * L["H"] * L["W"]
+        nhwc = r.permute(0, 2, 3, 1)
+        eng.workspace[L["offset"]: L["offset"] + 4 * px * 64].view(torch.float32).copy_(
+            nhwc[..., :64].contiguous().flatten().to(gpu_device))
+        eng.workspace[L["offset"] + 4 * px * 64: L["offset"] + 4 * px * 144].view(torch.float32).copy_(
+            nhwc[..., 64:].contiguous().flatten().to(gpu_device))
     import ctypes as C
     y = torch.empty(2, 84, eng.anchors, device=gpu_device)
     rc = eng.lib.yl_detect_decode(eng.workspace.data_ptr(), eng._levels, 3, 2, 80, y.data_ptr(),

@@ -387,11 +387,7 @@ static int run_decode(const yl_engine* e, const char* ws, float* y, hipStream_t 
   DecodeLevel lv[8];
   int a0 = 0;
   for (size_t i = 0; i < e->levels.size(); ++i) {
-    lv[i].raw = reinterpret_cast<const float*>(ws + e->levels[i].offset);
-    lv[i].H = e->levels[i].H;
-    lv[i].W = e->levels[i].W;
-    lv[i].a0 = a0;
-    lv[i].stride = e->levels[i].stride;
+    lv[i] = decode_level(ws, e->levels[i], e->batch, a0);
     a0 += lv[i].H * lv[i].W;
   }
   return decode_launch(lv, (int)e->levels.size(), e->batch, e->nc, e->A, y, s);
@@ -598,11 +594,7 @@ extern "C" int yl_detect_decode(const void* workspace, const yl_level* levels, i
   DecodeLevel lv[8];
   int a0 = 0;
   for (int i = 0; i < n_levels; ++i) {
-    lv[i].raw = reinterpret_cast<const float*>((const char*)workspace + levels[i].offset);
-    lv[i].H = levels[i].H;
-    lv[i].W = levels[i].W;
-    lv[i].a0 = a0;
-    lv[i].stride = levels[i].stride;
+    lv[i] = decode_level(workspace, levels[i], batch, a0);
     a0 += lv[i].H * lv[i].W;
   }
   return decode_launch(lv, n_levels, batch, nc, a0, y, (hipStream_t)stream);

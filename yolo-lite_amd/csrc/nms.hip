@@ -9,12 +9,22 @@
 // __f*_rn intrinsics stop the compiler from contracting mul+add into FMAs.  Equal scores are
 // ordered by anchor index (the reference leaves ties to the sort implementation).
 // The reference's wall-clock bail-out (ops.py:269-271) is a load-dependent defect and is not kept.
+#include <cmath>
+
 #include "yl_internal.h"
 
 namespace yl {
 
+constexpr int NSUB = 16;
+
 struct NmsWs {
   int32_t* count;       // [B]
+  // fused decode path: anchors that passed the logit pre-filter, in NSUB sub-lists per image (same-address
+  // atomics serialise at ~0.3 us each in L2: one counter per image made both kernels atomic-bound)
+  int32_t* pre_count;   // [B][NSUB]
+  int32_t* pre_list;    // [B][NSUB][sub_cap] anchor indices, unordered
+  int sub_cap;          // = slots per sub-list, also the stride of the sub-lists inside keys[b][]
+  int fused;            // 1: keys live in the sub-list slots (sentinel ~0 = rejected by the exact test)
   int32_t* nfinal;      // [B]
   unsigned long long* keys;  // [B][KP]   KP = pow2 >= A
   int32_t* cls_of;      // [B][A]
@@ -37,20 +47,26 @@ static int pow2_ge(int x) {
 static int64_t nms_layout(int B, int A, int max_cand, char* base, NmsWs* w) {
   const int M = max_cand < A ? max_cand : A;
   const int MW = (M + 63) / 64;
-  const int KP = pow2_ge(A);
+  const int KP = pow2_ge(A + 128 * NSUB);  // >= NSUB * sub_cap
   int64_t o = 0;
   auto take = [&](int64_t bytes) {
     int64_t r = o;
     o += align256(bytes);
     return r;
   };
-  const int64_t o_count = take(4LL * B), o_nf = take(4LL * B), o_keys = take(8LL * B * KP),
+  const int sub_cap = (A / (64 * NSUB) + 2) * 64;  // >= 64 * (64-anchor workgroups per sub-list)
+  const int64_t o_count = take(4LL * B * (1 + NSUB)), o_nf = take(4LL * B),
+                o_pre = take(4LL * B * NSUB * sub_cap), o_keys = take(8LL * B * KP),
                 o_clsof = take(4LL * B * A), o_boff = take(16LL * B * M), o_braw = take(16LL * B * M),
                 o_conf = take(4LL * B * M), o_cls = take(4LL * B * M), o_mask = take(8LL * B * M * MW),
                 o_cbox = take(16LL * B * A);
   if (w) {
     w->cbox = (float4*)(base + o_cbox);
     w->count = (int32_t*)(base + o_count);
+    w->pre_count = w->count + B;  // cleared by the same memset
+    w->pre_list = (int32_t*)(base + o_pre);
+    w->sub_cap = sub_cap;
+    w->fused = 0;
     w->nfinal = (int32_t*)(base + o_nf);
     w->keys = (unsigned long long*)(base + o_keys);
     w->cls_of = (int32_t*)(base + o_clsof);
@@ -119,20 +135,59 @@ __device__ __forceinline__ void bitonic_sort(unsigned long long* k, int np, int 
 __global__ __launch_bounds__(1024) void nms_sort_kernel(const float* __restrict__ pred, int nc, int A, int agnostic,
                                                          float max_wh, NmsWs w) {
   __shared__ unsigned long long sk[SORT_LDS_KEYS];
+  __shared__ int s_nvalid;
   const int b = blockIdx.x, tid = threadIdx.x;
-  int n = w.count[b];
-  if (n > A) n = A;
-  int np = 64;
-  while (np < n) np <<= 1;
   unsigned long long* gk = w.keys + (long long)b * w.KP;
-  unsigned long long* k = (np <= SORT_LDS_KEYS) ? sk : gk;
-  if (k == sk) {
-    for (int i = tid; i < np; i += 1024) sk[i] = i < n ? gk[i] : ~0ull;
+  int n, np = 64;
+  unsigned long long* k;
+  if (w.fused) {
+    // keys sit in NSUB sub-lists (slot j of sub-list s at gk[s * sub_cap + j]); rejected anchors left ~0
+    int pre[NSUB + 1];
+    pre[0] = 0;
+#pragma unroll
+    for (int q = 0; q < NSUB; ++q) pre[q + 1] = pre[q] + w.pre_count[b * NSUB + q];
+    n = pre[NSUB];
+    while (np < n) np <<= 1;
+    if (np <= SORT_LDS_KEYS) {
+      k = sk;
+      for (int i = tid; i < np; i += 1024) {
+        unsigned long long v = ~0ull;
+        if (i < n) {
+          int q = 0;
+#pragma unroll
+          for (int t = 1; t < NSUB; ++t) q += (i >= pre[t]);
+          v = gk[q * w.sub_cap + (i - pre[q])];
+        }
+        sk[i] = v;
+      }
+    } else {  // too many for the LDS sort: sort the whole slot range in place (sentinels fill unused slots)
+      k = gk;
+      n = NSUB * w.sub_cap;
+      np = 64;
+      while (np < n) np <<= 1;
+      for (int q = 0; q < NSUB; ++q)
+        for (int i = w.pre_count[b * NSUB + q] + tid; i < w.sub_cap; i += 1024) gk[q * w.sub_cap + i] = ~0ull;
+      for (int i = n + tid; i < np; i += 1024) gk[i] = ~0ull;
+    }
   } else {
-    for (int i = n + tid; i < np; i += 1024) gk[i] = ~0ull;
+    n = w.count[b];
+    if (n > A) n = A;
+    while (np < n) np <<= 1;
+    k = (np <= SORT_LDS_KEYS) ? sk : gk;
+    if (k == sk) {
+      for (int i = tid; i < np; i += 1024) sk[i] = i < n ? gk[i] : ~0ull;
+    } else {
+      for (int i = n + tid; i < np; i += 1024) gk[i] = ~0ull;
+    }
   }
+  if (tid == 0) s_nvalid = 0;
   __syncthreads();
   if (n > 1) bitonic_sort(k, np, tid, 1024);
+  // sentinels (fused path: anchors the exact test rejected) sort last: count the real keys
+  for (int i = tid; i < n; i += 1024)
+    if (k[i] != ~0ull && (i + 1 == n || k[i + 1] == ~0ull)) s_nvalid = i + 1;
+  __syncthreads();
+  n = s_nvalid;
   const int nf = n < w.M ? n : w.M;  // keep the top max_cand by score (ops.py:254-255)
   if (tid == 0) w.nfinal[b] = nf;
   const float* pb = pred ? pred + (long long)b * (4 + nc) * A : nullptr;
@@ -193,6 +248,30 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(float iou_thres, NmsWs w)
 // ---- 4. greedy scan over the sorted candidates, 64 at a time, one wavefront per image
 constexpr int SCAN_T = 8;  // words per lane -> up to 64*64*8 = 32768 candidates
 
+// one kept detection -> out[b][slot] (ops.py:66-98 scale_boxes + ops.py:276-295 clip_boxes when scaled)
+__device__ __forceinline__ void scan_emit(const NmsWs& w, int b, int i, int slot, int max_det, bool scaled, float padx,
+                                          float pady, float gain, float w0, float h0, float* out) {
+  const long long o = (long long)b * w.M + i;
+  float4 bx = w.box_raw[o];
+  if (scaled) {
+    bx.x = __fdiv_rn(__fsub_rn(bx.x, padx), gain);
+    bx.y = __fdiv_rn(__fsub_rn(bx.y, pady), gain);
+    bx.z = __fdiv_rn(__fsub_rn(bx.z, padx), gain);
+    bx.w = __fdiv_rn(__fsub_rn(bx.w, pady), gain);
+    bx.x = fminf(fmaxf(bx.x, 0.f), w0);
+    bx.y = fminf(fmaxf(bx.y, 0.f), h0);
+    bx.z = fminf(fmaxf(bx.z, 0.f), w0);
+    bx.w = fminf(fmaxf(bx.w, 0.f), h0);
+  }
+  float* op = out + ((long long)b * max_det + slot) * 6;
+  op[0] = bx.x;
+  op[1] = bx.y;
+  op[2] = bx.z;
+  op[3] = bx.w;
+  op[4] = w.conf[o];
+  op[5] = (float)w.cls[o];
+}
+
 __global__ __launch_bounds__(64) void nms_scan_kernel(int max_det, const float* __restrict__ scale, float* out,
                                                        int32_t* out_count, NmsWs w) {
   const int b = blockIdx.x, lane = threadIdx.x;
@@ -211,6 +290,59 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(int max_det, const float* 
     h0 = scale[b * 5 + 4];
   }
   int total = 0;
+  if (nwords <= SCAN_T) {
+    // Fast path (up to 512 candidates -- every realistic conf >= 0.05 case): the pending-suppression
+    // words are wave-uniform scalars, each lane keeps its own mask row in registers (one batch of loads
+    // per 64 candidates), the diagonal word is resolved with readlane, and the rows of the kept
+    // candidates are OR-ed across the wave with shuffles instead of one dependent global load each.
+    unsigned long long remw[SCAN_T];
+#pragma unroll
+    for (int t = 0; t < SCAN_T; ++t) remw[t] = 0ull;
+    for (int blk = 0; blk < nwords && total < max_det; ++blk) {
+      const int i = blk * 64 + lane;
+      unsigned long long d[SCAN_T];
+#pragma unroll
+      for (int t = 0; t < SCAN_T; ++t) d[t] = (t >= blk && t < nwords && i < n) ? mask[(long long)i * w.MW + t] : 0ull;
+      unsigned long long dcur = 0ull, cur = 0ull;
+#pragma unroll
+      for (int t = 0; t < SCAN_T; ++t)
+        if (t == blk) {
+          dcur = d[t];
+          cur = remw[t];
+        }
+      const int nvalid = n - blk * 64;
+      const unsigned long long vmask = nvalid >= 64 ? ~0ull : ((1ull << nvalid) - 1ull);
+      unsigned long long alive = ~cur & vmask;
+      unsigned long long kept = 0ull;
+      int room = max_det - total;
+      while (alive && room > 0) {
+        const int bit = __builtin_amdgcn_readfirstlane(__builtin_ctzll(alive));
+        kept |= 1ull << bit;
+        --room;
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)dcur, bit);
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(dcur >> 32), bit);
+        alive &= ~(((unsigned long long)hi << 32) | lo);
+        alive &= ~(1ull << bit);
+      }
+      const bool mine = (kept >> lane) & 1ull;
+#pragma unroll
+      for (int t = 0; t < SCAN_T; ++t)
+        if (t > blk && t < nwords) {
+          unsigned lo = mine ? (unsigned)d[t] : 0u, hi = mine ? (unsigned)(d[t] >> 32) : 0u;
+#pragma unroll
+          for (int off = 32; off >= 1; off >>= 1) {
+            lo |= __shfl_xor(lo, off);
+            hi |= __shfl_xor(hi, off);
+          }
+          remw[t] |= ((unsigned long long)hi << 32) | lo;
+        }
+      if (mine) scan_emit(w, b, i, total + __popcll(kept & ((1ull << lane) - 1ull)), max_det, scale != nullptr, padx, pady,
+                          gain, w0, h0, out);
+      total += __popcll(kept);
+    }
+    if (lane == 0) out_count[b] = total;
+    return;
+  }
   for (int blk = 0; blk < nwords && total < max_det; ++blk) {
     unsigned long long own = 0ull;
 #pragma unroll
@@ -245,28 +377,9 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(int max_det, const float* 
       }
     }
     // emit: lane `bit` writes its own detection at rank order
-    if ((kept >> lane) & 1ull) {
-      const int slot = total + __popcll(kept & ((1ull << lane) - 1ull));
-      const long long o = (long long)b * w.M + i;
-      float4 bx = w.box_raw[o];
-      if (scale) {  // ops.py:66-98 scale_boxes + ops.py:276-295 clip_boxes
-        bx.x = __fdiv_rn(__fsub_rn(bx.x, padx), gain);
-        bx.y = __fdiv_rn(__fsub_rn(bx.y, pady), gain);
-        bx.z = __fdiv_rn(__fsub_rn(bx.z, padx), gain);
-        bx.w = __fdiv_rn(__fsub_rn(bx.w, pady), gain);
-        bx.x = fminf(fmaxf(bx.x, 0.f), w0);
-        bx.y = fminf(fmaxf(bx.y, 0.f), h0);
-        bx.z = fminf(fmaxf(bx.z, 0.f), w0);
-        bx.w = fminf(fmaxf(bx.w, 0.f), h0);
-      }
-      float* op = out + ((long long)b * max_det + slot) * 6;
-      op[0] = bx.x;
-      op[1] = bx.y;
-      op[2] = bx.z;
-      op[3] = bx.w;
-      op[4] = w.conf[o];
-      op[5] = (float)w.cls[o];
-    }
+    if ((kept >> lane) & 1ull)
+      scan_emit(w, b, i, total + __popcll(kept & ((1ull << lane) - 1ull)), max_det, scale != nullptr, padx, pady, gain, w0,
+                h0, out);
     total += __popcll(kept);
   }
   if (lane == 0) out_count[b] = total;
@@ -314,49 +427,75 @@ struct DecCandArgs {
   int blk0[9];
   int n_levels, batch, nc, A;
   float conf_thres;
+  float logit_lo;  // sparse kernel: anchors whose best LOGIT is below this cannot clear conf_thres
   const int32_t* classes;
   int n_classes;
 };
 
-__global__ __launch_bounds__(256) void decode_candidates_kernel(DecCandArgs a, NmsWs w) {
-  extern __shared__ __attribute__((aligned(16))) float sraw[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+struct DcBlock {
+  DecodeLevel L;
+  int b, p0, nv, HW;
+};
+__device__ __forceinline__ DcBlock dc_block(const DecCandArgs& a) {
+  DcBlock d;
   const int nb_img = a.blk0[a.n_levels];
-  const int b = blockIdx.x / nb_img;
-  const int k = blockIdx.x - b * nb_img;
+  d.b = blockIdx.x / nb_img;
+  const int k = blockIdx.x - d.b * nb_img;
   int l = 0;
 #pragma unroll
   for (int i = 1; i < 8; ++i)
     if (i < a.n_levels && k >= a.blk0[i]) l = i;
-  const DecodeLevel L = a.lv[l];
-  const int HW = L.H * L.W;
-  const int p0 = (k - a.blk0[l]) * DC_ANCH;
-  const int nv = min(DC_ANCH, HW - p0);
+  d.L = a.lv[l];
+  d.HW = d.L.H * d.L.W;
+  d.p0 = (k - a.blk0[l]) * DC_ANCH;
+  d.nv = min(DC_ANCH, d.HW - d.p0);
+  return d;
+}
+
+// the reference's candidate test and bookkeeping for one anchor (ops.py:203,243-248)
+// key_slot < 0: append with an atomic (dense kernel); else the key goes to that slot of keys[b][] and a
+// rejected anchor leaves the sentinel ~0 there (sparse path: no atomics).
+__device__ __forceinline__ void dc_emit(const DecCandArgs& a, const NmsWs& w, const DcBlock& d, int an_local,
+                                        float best, int bi, float dl, float dt, float dr, float db,
+                                        int key_slot = -1) {
+  bool keep = best > a.conf_thres;
+  if (keep && a.classes) {
+    bool ok = false;
+    for (int i = 0; i < a.n_classes; ++i) ok |= (a.classes[i] == bi);
+    keep = ok;
+  }
+  if (!keep) {
+    if (key_slot >= 0) w.keys[(long long)d.b * w.KP + key_slot] = ~0ull;
+    return;
+  }
+  const int p = d.p0 + an_local, an = d.L.a0 + p;
+  const float ax = (float)(p % d.L.W) + 0.5f, ay = (float)(p / d.L.W) + 0.5f;
+  const float4 bx = box_xywh(ax, ay, dl, dt, dr, db, d.L.stride);
+  const int slot = key_slot >= 0 ? key_slot : atomicAdd(&w.count[d.b], 1);
+  w.keys[(long long)d.b * w.KP + slot] = ((unsigned long long)(~__float_as_uint(best)) << 32) | (unsigned)an;
+  w.cls_of[(long long)d.b * a.A + an] = bi;
+  w.cbox[(long long)d.b * a.A + an] = bx;
+}
+
+// Dense variant (low thresholds, e.g. validation at conf 0.001): every anchor is decoded.
+__global__ __launch_bounds__(256) void decode_candidates_dense_kernel(DecCandArgs a, NmsWs w) {
+  extern __shared__ __attribute__((aligned(16))) float sraw[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const DcBlock d = dc_block(a);
   const int no = 64 + a.nc, pitch = no + 1;
   float* sdist = sraw + DC_ANCH * pitch;       // [4][64]
   float* sbest = sdist + 4 * DC_ANCH;          // [4][64] best score per wave
   int* sbidx = reinterpret_cast<int*>(sbest + 4 * DC_ANCH);  // [4][64]
-  const float* raw = L.raw + ((long long)b * HW + p0) * no;
-  if ((no & 3) == 0) {  // the chunk is one contiguous run: 16-byte loads
-    const int n4 = nv * no / 4;
-    for (int i = tid; i < n4; i += 256) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(raw + 4LL * i);
-      const int e = 4 * i, r = e / no, c = e - r * no;
-      float* d = sraw + r * pitch + c;
-      d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
-    }
-  } else {
-    for (int r = wave; r < nv; r += 4)
-      for (int c = lane; c < no; c += 64) sraw[r * pitch + c] = raw[(long long)r * no + c];
-  }
+  stage_rows(sraw, pitch, 0, d.L.box + ((long long)d.b * d.HW + d.p0) * 64, 64, d.nv, tid);
+  stage_rows(sraw, pitch, 64, d.L.cls + ((long long)d.b * d.HW + d.p0) * a.nc, a.nc, d.nv, tid);
   __syncthreads();
   float dist = 0.f;
-  if (lane < nv) dist = dfl_expect(sraw + lane * pitch + wave * 16);
+  if (lane < d.nv) dist = dfl_expect(sraw + lane * pitch + wave * 16);
   sdist[wave * DC_ANCH + lane] = dist;
   // best class among c = wave, wave + 4, ...: strict '>' keeps the first maximum (ops.py:243)
   float best = -1.f;
   int bi = 0x7fffffff;
-  if (lane < nv)
+  if (lane < d.nv)
     for (int c = wave; c < a.nc; c += 4) {
       const float sc = sigmoid_score(sraw[lane * pitch + 64 + c]);
       if (sc > best) {
@@ -367,7 +506,7 @@ __global__ __launch_bounds__(256) void decode_candidates_kernel(DecCandArgs a, N
   sbest[wave * DC_ANCH + lane] = best;
   sbidx[wave * DC_ANCH + lane] = bi;
   __syncthreads();
-  if (wave == 0 && lane < nv) {
+  if (wave == 0 && lane < d.nv) {
 #pragma unroll
     for (int q = 1; q < 4; ++q) {
       const float s2 = sbest[q * DC_ANCH + lane];
@@ -377,22 +516,93 @@ __global__ __launch_bounds__(256) void decode_candidates_kernel(DecCandArgs a, N
         bi = i2;
       }
     }
-    bool keep = best > a.conf_thres;
-    if (keep && a.classes) {
-      bool ok = false;
-      for (int i = 0; i < a.n_classes; ++i) ok |= (a.classes[i] == bi);
-      keep = ok;
+    dc_emit(a, w, d, lane, best, bi, sdist[lane], sdist[DC_ANCH + lane], sdist[2 * DC_ANCH + lane],
+            sdist[3 * DC_ANCH + lane]);
+  }
+}
+
+// Sparse variant (the usual case: ~1-2 % of the anchors clear conf 0.25).  Only the class block is
+// streamed (nc of 64+nc floats per anchor); the best LOGIT of every anchor is a pre-filter with a safety
+// margin, and the exact reference arithmetic -- 80 sigmoids, first-max class, DFL of the 64 box logits
+// read straight from global memory -- runs for the few survivors only (decode_exact_kernel).  Identical results to the dense kernel: the pre-filter only drops
+// anchors whose best score is far below the threshold, everything kept is recomputed exactly.
+__global__ __launch_bounds__(256) void decode_candidates_sparse_kernel(DecCandArgs a, NmsWs w) {
+  extern __shared__ __attribute__((aligned(16))) float scls[];  // [64][nc + 1]
+  __shared__ float smax[4][DC_ANCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const DcBlock d = dc_block(a);
+  const int pitch = a.nc + 1;
+  stage_rows(scls, pitch, 0, d.L.cls + ((long long)d.b * d.HW + d.p0) * a.nc, a.nc, d.nv, tid);
+  __syncthreads();
+  float m = -__builtin_huge_valf();
+  if (lane < d.nv)
+    for (int c = wave; c < a.nc; c += 4) m = fmaxf(m, scls[lane * pitch + c]);
+  smax[wave][lane] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(smax[0][lane], smax[1][lane]), fmaxf(smax[2][lane], smax[3][lane]));
+  // survivors go to a per-image list; decode_exact_kernel deals them out evenly (object-rich image
+  // regions would otherwise serialise inside the few workgroups that own them)
+  if (wave == 0 && lane < d.nv && m > a.logit_lo) {
+    const int sub = d.b * NSUB + (blockIdx.x & (NSUB - 1));
+    const int slot = atomicAdd(&w.pre_count[sub], 1);
+    w.pre_list[(long long)sub * w.sub_cap + slot] = d.L.a0 + d.p0 + lane;
+  }
+}
+
+// One wavefront per surviving anchor: 64 lanes = its 64 box logits = classes lane, lane + 64, ...
+constexpr int DX_BLOCKS = 4;  // workgroups per sub-list (4 waves each)
+__global__ __launch_bounds__(256) void decode_exact_kernel(DecCandArgs a, NmsWs w) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.z, sub = blockIdx.y;
+  const int n = w.pre_count[b * NSUB + sub];
+  for (int j = blockIdx.x * 4 + wave; j < n; j += DX_BLOCKS * 4) {
+    const int an = w.pre_list[(long long)(b * NSUB + sub) * w.sub_cap + j];
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < 8; ++i)
+      if (i < a.n_levels && an >= a.lv[i].a0) l = i;
+    DcBlock d;
+    d.L = a.lv[l];
+    d.b = b;
+    d.HW = d.L.H * d.L.W;
+    d.p0 = an - d.L.a0;
+    d.nv = 1;
+    const long long row = (long long)b * d.HW + d.p0;
+    // DFL (block.py:66-69): exponentials in parallel, sums in the reference's sequential order
+    const float v = d.L.box[row * 64 + lane];
+    float mx = v;
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    const float e = expf(v - mx);
+    // class scores: per-lane strict '>' in increasing c keeps the first maximum (ops.py:243)
+    float best = -1.f;
+    int bi = 0x7fffffff;
+    for (int c = lane; c < a.nc; c += 64) {
+      const float sc = sigmoid_score(d.L.cls[row * a.nc + c]);
+      if (sc > best) {
+        best = sc;
+        bi = c;
+      }
     }
-    if (keep) {
-      const int p = p0 + lane, an = L.a0 + p;
-      const float ax = (float)(p % L.W) + 0.5f, ay = (float)(p / L.W) + 0.5f;
-      const float4 bx = box_xywh(ax, ay, sdist[lane], sdist[DC_ANCH + lane], sdist[2 * DC_ANCH + lane],
-                                 sdist[3 * DC_ANCH + lane], L.stride);
-      const int slot = atomicAdd(&w.count[b], 1);
-      w.keys[(long long)b * w.KP + slot] = ((unsigned long long)(~__float_as_uint(best)) << 32) | (unsigned)an;
-      w.cls_of[(long long)b * a.A + an] = bi;
-      w.cbox[(long long)b * a.A + an] = bx;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const float s2 = __shfl_xor(best, off);
+      const int i2 = __shfl_xor(bi, off);
+      if (s2 > best || (s2 == best && i2 < bi)) {
+        best = s2;
+        bi = i2;
+      }
     }
+    float sum = 0.f, ws = 0.f;  // every lane sums the side it belongs to
+#pragma unroll
+    for (int j2 = 0; j2 < 16; ++j2) {
+      const float ej = __shfl(e, (lane & 48) + j2);
+      sum += ej;
+      ws += ej * (float)j2;
+    }
+    const float dist = ws / sum;
+    const float dl = __shfl(dist, 0), dt = __shfl(dist, 16), dr = __shfl(dist, 32), db = __shfl(dist, 48);
+    if (lane == 0) dc_emit(a, w, d, 0, best, bi, dl, dt, dr, db, sub * w.sub_cap + j);
   }
 }
 }  // namespace yl
@@ -409,17 +619,13 @@ extern "C" int yl_decode_nms(const void* workspace, const yl_level* levels, int 
   DecCandArgs a;
   int nb = 0, A = 0;
   for (int i = 0; i < n_levels; ++i) {
-    a.lv[i].raw = reinterpret_cast<const float*>((const char*)workspace + levels[i].offset);
-    a.lv[i].H = levels[i].H;
-    a.lv[i].W = levels[i].W;
-    a.lv[i].a0 = A;
-    a.lv[i].stride = levels[i].stride;
+    a.lv[i] = decode_level(workspace, levels[i], batch, A);
     a.blk0[i] = nb;
     nb += (levels[i].H * levels[i].W + DC_ANCH - 1) / DC_ANCH;
     A += levels[i].H * levels[i].W;
   }
   for (int i = n_levels; i < 8; ++i) {
-    a.lv[i] = DecodeLevel{nullptr, 0, 0, 1 << 30, 0.f};
+    a.lv[i] = DecodeLevel{nullptr, nullptr, 0, 0, 1 << 30, 0.f};
     a.blk0[i] = 1 << 30;
   }
   a.blk0[n_levels] = nb;
@@ -433,17 +639,29 @@ extern "C" int yl_decode_nms(const void* workspace, const yl_level* levels, int 
   NmsWs w;
   nms_layout(batch, A, max_cand, (char*)work, &w);
   if (w.M > 64 * 64 * SCAN_T) return fail(-3, "yl_decode_nms: max_cand above 32768 is not supported");
-  const size_t lds = ((size_t)DC_ANCH * (64 + nc + 1) + 12 * DC_ANCH) * sizeof(float);
+  // Sparse kernel unless the threshold keeps a large share of the anchors (validation at conf 0.001).
+  // logit(conf) - 0.05: the exact test `1 / (1 + expf(-x)) > conf` cannot pass below it.
+  const bool sparse = conf_thres >= 0.05f;
+  a.logit_lo = conf_thres >= 1.f ? __builtin_huge_valf()
+                                 : (float)(std::log((double)conf_thres / (1.0 - (double)conf_thres)) - 0.05);
+  const size_t lds = sparse ? (size_t)DC_ANCH * (nc + 1) * sizeof(float)
+                            : ((size_t)DC_ANCH * (64 + nc + 1) + 12 * DC_ANCH) * sizeof(float);
   if (lds > 150 * 1024) return fail(-3, "yl_decode_nms: nc too large");
-  static size_t attr = 0;
-  if (lds > attr) {
-    YL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decode_candidates_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr = 160 * 1024;
+  static size_t attr[2] = {48 * 1024, 48 * 1024};  // dynamic LDS enabled so far (dense, sparse)
+  if (lds > attr[sparse]) {
+    YL_HIP(hipFuncSetAttribute(sparse ? reinterpret_cast<const void*>(decode_candidates_sparse_kernel)
+                                      : reinterpret_cast<const void*>(decode_candidates_dense_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr[sparse] = lds;
   }
   hipStream_t s = (hipStream_t)stream;
-  YL_HIP(hipMemsetAsync(w.count, 0, 4 * (size_t)batch, s));
-  hipLaunchKernelGGL(decode_candidates_kernel, dim3(batch * nb), dim3(256), lds, s, a, w);
+  YL_HIP(hipMemsetAsync(w.count, 0, 4 * (size_t)batch * (1 + NSUB), s));  // count + pre_count
+  if (sparse) {
+    w.fused = 1;
+    hipLaunchKernelGGL(decode_candidates_sparse_kernel, dim3(batch * nb), dim3(256), lds, s, a, w);
+    hipLaunchKernelGGL(decode_exact_kernel, dim3(DX_BLOCKS, NSUB, batch), dim3(256), 0, s, a, w);
+  } else
+    hipLaunchKernelGGL(decode_candidates_dense_kernel, dim3(batch * nb), dim3(256), lds, s, a, w);
   hipLaunchKernelGGL(nms_sort_kernel, dim3(batch), dim3(1024), 0, s, (const float*)nullptr, nc, A, agnostic, max_wh, w);
   hipLaunchKernelGGL(nms_mask_kernel, dim3(64, batch), dim3(256), 0, s, iou_thres, w);
   hipLaunchKernelGGL(nms_scan_kernel, dim3(batch), dim3(64), 0, s, max_det, scale, out, out_count, w);

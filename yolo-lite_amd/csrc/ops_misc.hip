@@ -616,6 +616,7 @@ int attention_launch(const AttnArgs& a, hipStream_t s) {
 // and sigmoid of the class logits.  fp32 in, fp32 out: y[B][4+nc][A].
 constexpr int MAX_LEVELS = 8;
 constexpr int DEC_ANCH = 64;  // anchors per workgroup
+
 struct DecodeArgs {
   DecodeLevel lv[MAX_LEVELS];
   int blk0[MAX_LEVELS + 1];  // first block of each level inside one image
@@ -623,9 +624,10 @@ struct DecodeArgs {
   float* y;
 };
 
-// One workgroup = 64 consecutive anchors of one level of one image.  Their raw rows are one
-// contiguous run of 64 x (64+nc) floats: staged through LDS with coalesced loads (row pitch no+1
-// words -> conflict-free column reads), then every output row of y is written as 256-byte runs.
+// One workgroup = 64 consecutive anchors of one level of one image.  Their box rows (64 x 64 floats)
+// and class rows (64 x nc floats) are two contiguous runs: staged through LDS with coalesced loads
+// (row pitch 64+nc+1 words -> conflict-free column reads), then every output row of y is written as
+// 256-byte runs.
 __global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sraw[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -642,19 +644,8 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
   const int nv = min(DEC_ANCH, HW - p0);
   const int no = 64 + a.nc, pitch = no + 1;
   float* sdist = sraw + DEC_ANCH * pitch;  // [4][64]
-  const float* raw = L.raw + ((long long)b * HW + p0) * no;
-  if ((no & 3) == 0) {  // the chunk is one contiguous run: 16-byte loads
-    const int n4 = nv * no / 4;
-    for (int i = tid; i < n4; i += 256) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(raw + 4LL * i);
-      const int e = 4 * i, r = e / no, c = e - r * no;
-      float* d = sraw + r * pitch + c;
-      d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
-    }
-  } else {
-    for (int r = wave; r < nv; r += 4)
-      for (int c = lane; c < no; c += 64) sraw[r * pitch + c] = raw[(long long)r * no + c];
-  }
+  stage_rows(sraw, pitch, 0, L.box + ((long long)b * HW + p0) * 64, 64, nv, tid);
+  stage_rows(sraw, pitch, 64, L.cls + ((long long)b * HW + p0) * a.nc, a.nc, nv, tid);
   __syncthreads();
   // DFL: thread = (anchor, side)
   {
@@ -687,7 +678,7 @@ int decode_launch(const DecodeLevel* lv, int n_levels, int batch, int nc, int A,
     nb += (lv[i].H * lv[i].W + DEC_ANCH - 1) / DEC_ANCH;
   }
   for (int i = n_levels; i < MAX_LEVELS; ++i) {
-    a.lv[i] = DecodeLevel{nullptr, 0, 0, 1 << 30, 0.f};
+    a.lv[i] = DecodeLevel{nullptr, nullptr, 0, 0, 1 << 30, 0.f};
     a.blk0[i] = 1 << 30;
   }
   a.blk0[n_levels] = nb;

@@ -140,11 +140,57 @@ int stem_launch(const StemArgs& a, int in_dtype, hipStream_t s);
 int convert_input_launch(const void* in, int in_dtype, const PView& out, int batch, int H, int W, hipStream_t s);
 
 struct DecodeLevel {
-  const float* raw;  // [B][H][W][64+nc]
+  const float* box;  // [B][H][W][64]  DFL logits (head.py:64 cv2)
+  const float* cls;  // [B][H][W][nc]  class logits (cv3); stored right behind the box block
   int H, W, a0;      // a0: first anchor index of this level
   float stride;
 };
+inline DecodeLevel decode_level(const void* workspace, const yl_level& L, int batch, int a0) {
+  DecodeLevel d;
+  d.box = reinterpret_cast<const float*>((const char*)workspace + L.offset);
+  d.cls = d.box + (long long)batch * L.H * L.W * 64;
+  d.H = L.H;
+  d.W = L.W;
+  d.a0 = a0;
+  d.stride = L.stride;
+  return d;
+}
 int decode_launch(const DecodeLevel* lv, int n_levels, int batch, int nc, int A, float* y, hipStream_t s);
+
+// nrows contiguous rows of `n` floats -> LDS rows of `pitch` words starting at column c0 (256 threads).
+// Loads are issued in batches of 8 per thread before the first LDS write: one memory round trip per
+// 32 KB instead of one per 4 KB.
+__device__ __forceinline__ void stage_rows(float* dst, int pitch, int c0, const float* __restrict__ src, int n,
+                                           int nrows, int tid) {
+  if ((n & 3) == 0) {  // 16-byte loads over the whole run
+    const int n4 = nrows * n / 4;
+    for (int i0 = tid; i0 < n4; i0 += 256 * 8) {
+      f32x4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * 256;
+        if (i < n4) v[u] = *reinterpret_cast<const f32x4*>(src + 4LL * i);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * 256;
+        if (i < n4) {
+          const int e = 4 * i, r = e / n, c = e - r * n;
+          float* d = dst + r * pitch + c0 + c;
+          d[0] = v[u][0];
+          d[1] = v[u][1];
+          d[2] = v[u][2];
+          d[3] = v[u][3];
+        }
+      }
+    }
+  } else {
+    for (int i = tid; i < nrows * n; i += 256) {
+      const int r = i / n, c = i - r * n;
+      dst[r * pitch + c0 + c] = src[i];
+    }
+  }
+}
 
 // Decode arithmetic shared by the plain decode kernel and the fused decode+candidate kernel, so both
 // produce bit-identical boxes and scores (head.py:95-126, block.py:66-69, tal.py:341-350).

@@ -169,13 +169,15 @@ class HipEngine:
         return out, cnt
 
     def raw_levels(self) -> List[torch.Tensor]:
-        """Zero-copy (B, 64+nc, H, W) fp32 views of the Detect level maps (reference head.py:64-65)."""
+        """(B, 64+nc, H, W) fp32 copies of the Detect level maps (reference head.py:64-65 ``cat(cv2, cv3)``);
+        in the workspace a level is a box block [B][H][W][64] followed by a class block [B][H][W][nc]."""
         out = []
-        no = 64 + self.nc
         for L in self.prog.levels:
-            n = self.batch * L["H"] * L["W"] * no
-            t = self.workspace[L["offset"]: L["offset"] + 4 * n].view(torch.float32)
-            out.append(t.view(self.batch, L["H"], L["W"], no).permute(0, 3, 1, 2))
+            px = self.batch * L["H"] * L["W"]
+            box = self.workspace[L["offset"]: L["offset"] + 4 * px * 64].view(torch.float32)
+            cls = self.workspace[L["offset"] + 4 * px * 64: L["offset"] + 4 * px * (64 + self.nc)].view(torch.float32)
+            t = torch.cat([box.view(self.batch, L["H"], L["W"], 64), cls.view(self.batch, L["H"], L["W"], self.nc)], 3)
+            out.append(t.permute(0, 3, 1, 2))
         return out
 
     def _planes(self, v: TView) -> torch.Tensor:

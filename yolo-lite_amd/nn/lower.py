@@ -220,12 +220,15 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
 
     def emit_level(lvl: int, xin: TView):
         h, w = xin.H, xin.W
-        head = ar.alloc(h, w, 64 + det.nc, F32)
+        # raw level map: fp32 box block [B][H][W][64] immediately followed by the class block [B][H][W][nc]
+        head_box = ar.alloc(h, w, 64, F32)
+        assert ar.top == head_box.offset + batch * h * w * 64 * 4  # 256 bytes per pixel: no padding
+        head_cls = ar.alloc(h, w, det.nc, F32)
         n0 = len(ops)
         t1, t2 = ar.alloc(h, w, c2), ar.alloc(h, w, c2)
         conv(f"{dp}.cv2.{lvl}.0", xin, t1, 3, 1)
         conv(f"{dp}.cv2.{lvl}.1", t1, t2, 3, 1)
-        conv(f"{dp}.cv2.{lvl}.2", t2, head.slice(0, 64), 1, 1, act=False, bn=False)
+        conv(f"{dp}.cv2.{lvl}.2", t2, head_box, 1, 1, act=False, bn=False)
         for o in ops[n0:]:
             o["lane"] = box_lane(lvl)
         n1 = len(ops)
@@ -235,10 +238,10 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
         d2, e2 = ar.alloc(h, w, c3), ar.alloc(h, w, c3)
         dwconv(f"{dp}.cv3.{lvl}.1.0", e1, d2)
         conv(f"{dp}.cv3.{lvl}.1.1", d2, e2, 1, 1)
-        conv(f"{dp}.cv3.{lvl}.2", e2, head.slice(64, det.nc), 1, 1, act=False, bn=False)
+        conv(f"{dp}.cv3.{lvl}.2", e2, head_cls, 1, 1, act=False, bn=False)
         for o in ops[n1:]:
             o["lane"] = cls_lane(lvl)
-        level_rec[lvl] = dict(offset=head.offset, H=h, W=w, stride=float(strides[lvl]))
+        level_rec[lvl] = dict(offset=head_box.offset, H=h, W=w, stride=float(strides[lvl]))
 
     views: Dict[int, TView] = {}
     prog.input_view = ar.alloc(in_h, in_w, 8)
