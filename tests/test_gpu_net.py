@@ -268,7 +268,8 @@ def match_detections(det, ref, conf_thres, iou_thres, band=SCORE_ATOL, iou_match
 
 
 @pytest.mark.parametrize("kw", [dict(conf=0.25, iou=0.7), dict(conf=0.25, iou=0.7, classes=[1, 27, 40]),
-                                dict(conf=0.3, iou=0.5, agnostic=True, max_det=10)])
+                                dict(conf=0.3, iou=0.5, agnostic=True, max_det=10),
+                                dict(conf=0.01, iou=0.6)])  # low threshold: the dense candidate kernel
 def test_fused_decode_nms_equals_unfused(gpu_device, golden, kw):
     """yl_decode_nms (no (B, 84, A) tensor) must reproduce decode -> NMS bit for bit."""
     sd = synth_state_dict("n", 1, cls_bias=list(golden["net_n_96x128_bias"]), cls_gain=8.0)

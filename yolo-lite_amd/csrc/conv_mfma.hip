@@ -44,12 +44,6 @@ __host__ __device__ inline int chan_in_block(int MT, int mt, int g, int r) {
   return mt < even ? ((((mt >> 1) * 4 + g) * 2 + (mt & 1)) * 4 + r) : (even * 16 + g * 4 + r);
 }
 
-// XCD-aware, bijective block remap: blocks that share rows / weights land on one L2.
-__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
-  const int q = nblocks >> 3, r = nblocks & 7, xcd = bid & 7;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-}
-
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 // Buffer addressing (raw_buffer_load/store with a 32-bit byte offset): an offset beyond the

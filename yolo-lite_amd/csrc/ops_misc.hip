@@ -100,32 +100,52 @@ __global__ __launch_bounds__(64 * STEM_MAXW) void stem_kernel(StemArgs a, const 
   typedef typename StemPair<T>::type pair_t;
   const int tid = threadIdx.x, nthr = blockDim.x;
   const int row = 2 * nthr + 8;  // bf16 elements per LDS row (even)
-  const int seg = blockIdx.x % a.nseg;
-  const int oy = (blockIdx.x / a.nseg) % a.Ho;
-  const int b = blockIdx.x / (a.nseg * a.Ho);
+  // XCD remap: neighbouring output rows share an input row -- keep them on one L2 (measured with
+  // FETCH_SIZE: 1.5x the algorithmic reads when consecutive rows were dealt to different XCDs)
+  const int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int seg = bid % a.nseg;
+  const int oy = (bid / a.nseg) % a.Ho;
+  const int b = bid / (a.nseg * a.Ho);
   const int ox0 = seg * nthr;
   const T* in = reinterpret_cast<const T*>(a.in) + (long long)b * 3 * a.H * a.W;
 
   // ---- load phase: 9 coalesced pair loads per thread, then the halo column
   {
     const int ix0 = 2 * (ox0 + tid);
-    const bool pair_ok = ((a.W & 1) == 0) && ix0 + 1 < a.W;
     pair_t v[9];
+    const long long img_bytes = 3LL * a.H * a.W * (long long)sizeof(T);
+    if ((a.W & 1) == 0 && img_bytes < (1LL << 30)) {
+      // usual case: branch-free buffer loads; rows above / below the image and pairs right of it
+      // resolve to out-of-range offsets (zeros)
+      const __amdgpu_buffer_rsrc_t rs =
+          __builtin_amdgcn_make_buffer_rsrc((void*)in, (short)0, (int)img_bytes, 0x00020000);
+      const unsigned lane_off = ix0 < a.W ? (unsigned)ix0 * (unsigned)sizeof(T) : 0x80000000u;
 #pragma unroll
-    for (int r = 0; r < 9; ++r) {
-      const int c = r / 3, kh = r % 3;
-      const int iy = 2 * oy + kh - 1;
-      const T* rp = in + ((long long)c * a.H + iy) * a.W;
-      pair_t q = {(T)0, (T)0};
-      if ((unsigned)iy < (unsigned)a.H) {
-        if (pair_ok) {
-          q = *reinterpret_cast<const pair_t*>(rp + ix0);
-        } else {
+      for (int r = 0; r < 9; ++r) {
+        const int c = r / 3, kh = r % 3;
+        const int iy = 2 * oy + kh - 1;  // block-uniform
+        const unsigned row_off =
+            (unsigned)iy < (unsigned)a.H ? (unsigned)((c * a.H + iy) * a.W) * (unsigned)sizeof(T) : 0x40000000u;
+        if constexpr (sizeof(T) == 4)
+          v[r] = __builtin_bit_cast(pair_t, __builtin_amdgcn_raw_buffer_load_b64(rs, row_off + lane_off, 0, 0));
+        else if constexpr (sizeof(T) == 2)
+          v[r] = __builtin_bit_cast(pair_t, __builtin_amdgcn_raw_buffer_load_b32(rs, row_off + lane_off, 0, 0));
+        else
+          v[r] = __builtin_bit_cast(pair_t, __builtin_amdgcn_raw_buffer_load_b16(rs, row_off + lane_off, 0, 0));
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 9; ++r) {
+        const int c = r / 3, kh = r % 3;
+        const int iy = 2 * oy + kh - 1;
+        const T* rp = in + ((long long)c * a.H + iy) * a.W;
+        pair_t q = {(T)0, (T)0};
+        if ((unsigned)iy < (unsigned)a.H) {
           if (ix0 < a.W) q[0] = rp[ix0];
           if (ix0 + 1 < a.W) q[1] = rp[ix0 + 1];
         }
+        v[r] = q;
       }
-      v[r] = q;
     }
 #pragma unroll
     for (int r = 0; r < 9; ++r) {
@@ -146,13 +166,19 @@ __global__ __launch_bounds__(64 * STEM_MAXW) void stem_kernel(StemArgs a, const 
   // ---- compute phase
   const int lane = tid & 63, wave = tid >> 6;
   const int p = lane & 15, kg = lane >> 4;
-  int toff[8];
+  const int px0 = wave * 64 + p;  // this lane's pixel in n-tile 0; n-tile g adds 16 pixels
+  // LDS element of tap k for pixel px0 (k = (c*3 + kh)*3 + kw; k / 3 = (k * 11) >> 5 for k < 32);
+  // k >= 27 reads any initialised (finite) element, its filter value is 0.  The n-tile offset is a
+  // constant, so the eight gathers of a tile are ds_read_u16 with immediate offsets.
+  const __bf16* tp[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int k = kg * 8 + j;
-    const int c = k / 9, kh = (k % 9) / 3, kw = k % 3;
-    toff[j] = k < 27 ? (c * 3 + kh) * row + kw + 1 : 2;  // k >= 27: any initialised (finite) element, the filter is 0
+    const int r = (k * 11) >> 5;
+    tp[j] = tile + (k < 27 ? r * row + (k - 3 * r) + 1 : 2) + 2 * px0;
   }
+  const int ox_lane = ox0 + px0;
+  const int pix0 = pv_pix(a.out, b, oy, ox_lane);
   for (int mb = 0; mb < a.Cout; mb += 16) {
     bf16x8 af;
 #pragma unroll
@@ -161,20 +187,19 @@ __global__ __launch_bounds__(64 * STEM_MAXW) void stem_kernel(StemArgs a, const 
       af[j] = (__bf16)(k < 27 ? w[(mb + p) * 27 + k] : 0.f);
     }
     const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + mb + kg * 4);
+    const int ch = mb + kg * 4;
+    __bf16* op0 = pv_ptr(a.out, ch >> 3, pix0) + (ch & 7);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int px = wave * 64 + g * 16 + p;  // pixel within the segment
       bf16x8 bf;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) bf[j] = tile[toff[j] + 2 * px];
+      for (int j = 0; j < 8; ++j) bf[j] = tp[j][32 * g];
       f32x4 acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf, bv, 0, 0, 0);
-      const int ox = ox0 + px;
-      if (ox < a.Wo) {
+      if (ox_lane + 16 * g < a.Wo) {
         bf16x4 o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = (__bf16)(a.act ? silu_g(acc[r]) : acc[r]);
-        const int ch = mb + kg * 4;
-        *reinterpret_cast<bf16x4*>(pv_ptr(a.out, ch >> 3, pv_pix(a.out, b, oy, ox)) + (ch & 7)) = o;
+        *reinterpret_cast<bf16x4*>(op0 + 128 * g) = o;
       }
     }
   }

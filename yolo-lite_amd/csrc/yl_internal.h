@@ -53,6 +53,13 @@ inline Geo geo_of(int batch, int H, int W) {
 }
 inline long long plane_bytes(const Geo& g) { return (long long)g.plane_px * 16; }
 
+// XCD-aware, bijective block remap: consecutive work items (blocks that share input rows / filters)
+// land on one XCD and therefore one L2; hardware deals workgroups to the 8 XCDs round-robin.
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+  const int q = nblocks >> 3, r = nblocks & 7, xcd = bid & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
 // ----------------------------------------------------------------------------- conv (MFMA)
 // Implicit-GEMM view: rows = output channels (A operand, packed weights staged in LDS), columns =
 // output pixels (B operand, fetched straight from the planes), K = taps x input channels in groups of 8.
