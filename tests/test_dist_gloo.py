@@ -46,6 +46,20 @@ def _worker(rank, world, port, steps, q):
             outs, cnts = last
             ref_out, ref_cnt = _fake_compute(batches[(steps - 1) % 3])
             assert torch.equal(torch.cat(outs), ref_out) and torch.equal(torch.cat(cnts), ref_cnt)
+        # resident shards (what bench.py runs for N > 1): no per-step collective, one gather at the end
+        from yololite_amd.dist import run_resident
+
+        gl = torch.Generator().manual_seed(77 + rank)
+        local = [torch.randint(0, 256, (per, 3, 8, 8), generator=gl, dtype=torch.uint8) for _ in range(2)]
+        got = run_resident(_fake_compute, local, steps)
+        if rank == 0:
+            refs = []
+            for r in range(world):
+                gr = torch.Generator().manual_seed(77 + r)
+                lr = [torch.randint(0, 256, (per, 3, 8, 8), generator=gr, dtype=torch.uint8) for _ in range(2)]
+                refs.append(_fake_compute(lr[(steps - 1) % 2]))
+            assert torch.equal(torch.cat(got[0]), torch.cat([r[0] for r in refs]))
+            assert torch.equal(torch.cat(got[1]), torch.cat([r[1] for r in refs]))
         q.put((rank, "ok"))
     except Exception as e:  # pragma: no cover
         q.put((rank, repr(e)))

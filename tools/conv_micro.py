@@ -32,13 +32,13 @@ for o in prog.ops:
     eng.write_view(o['inp'], torch.randn(B, cin, H, W))
 im = torch.zeros(B, 3, 32, 32, device=dev)
 for _ in range(3):
-    eng.forward(im, decode=False)
+    eng.forward(im, decode=False, graph=True)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-N = 10
+N = 20
 for _ in range(N):
-    eng.forward(im, decode=False)
+    eng.forward(im, decode=False, graph=True)
 e1.record()
 torch.cuda.synchronize()
 us = e0.elapsed_time(e1) / (N * NREP) * 1e3

@@ -60,7 +60,7 @@ def main():
     print("by kernel:", ", ".join(f"{k} {v[0] * 1e3:.0f}us x{v[1]}" for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])))
     excess_table(rows, a.top)
     rows.sort(key=lambda r: -r["ms"])
-    for r in rows[: 0]:
+    for r in rows[: (a.top if os.environ.get('YL_PROBE_LIST') else 0)]:
         print(f"{r['name']:26s} {r['kernel']:16s} {r['ms'] * 1e3:8.1f} us {r['flops'] / max(r['ms'], 1e-9) / 1e9:7.1f} TF/s "
               f"{r['bytes'] / max(r['ms'], 1e-9) / 1e6:8.1f} GB/s")
 

@@ -236,7 +236,8 @@ template <int DW_PX>
 __global__ __launch_bounds__(256) void dwconv3_kernel(DwArgs a) {
   const unsigned wq = (unsigned)(a.W + DW_PX - 1) / DW_PX;
   const unsigned per_plane = (unsigned)a.batch * a.H * wq;  // < 2^31 (host-checked)
-  unsigned p = blockIdx.x * 256u + threadIdx.x;
+  // XCD remap: neighbouring row runs (which share input rows) stay on one L2
+  unsigned p = (unsigned)xcd_remap(blockIdx.x, gridDim.x) * 256u + threadIdx.x;
   if (p >= per_plane) return;
   const int g8 = blockIdx.y;  // plane: wave-uniform, so the filter / bias loads are scalar
   const unsigned row = p / wq;
@@ -503,7 +504,7 @@ constexpr int AT_KD = 32, AT_HD = 64;
 constexpr int AT_STAGE = 512;          // keys resident in LDS at a time
 constexpr int AT_KP = AT_KD + 8;       // K row pitch (elements): 80-byte rows
 constexpr int AT_VP = AT_STAGE + 8;    // V^T row pitch (elements)
-constexpr int AT_QSPLIT = 2;           // workgroups per (image, head)
+constexpr int AT_QSPLIT = 4;           // workgroups per (image, head)
 
 __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char asm_[];
@@ -546,20 +547,40 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
       const int nk32 = (nk + 31) & ~31;
       if (nstage > 1 || rd == 0) {
         __syncthreads();  // previous users of the stage buffers are done
-        for (int i = tid; i < nk32 * 4; i += 256) {
-          const int key = i >> 2, c8 = i & 3;
-          bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-          if (key < nk)
-            v = *reinterpret_cast<const bf16x8*>(pv_ptr(a.in, hplane + AT_KD / 8 + c8, tok(k0s + key)));
-          *reinterpret_cast<bf16x8*>(sK + key * AT_KP + c8 * 8) = v;
-        }
-        for (int i = tid; i < nk32 * 8; i += 256) {
-          const int key = i >> 3, c8 = i & 7;
-          bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-          if (key < nk)
-            v = *reinterpret_cast<const bf16x8*>(pv_ptr(a.in, hplane + 2 * AT_KD / 8 + c8, tok(k0s + key)));
+        // loads are issued in batches of 8 per thread before the first LDS write (one memory round
+        // trip per batch instead of one per vector)
+        for (int i0 = tid; i0 < nk32 * 4; i0 += 256 * 8) {
+          bf16x8 v[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) sVt[(c8 * 8 + j) * AT_VP + key] = v[j];
+          for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * 256, key = i >> 2, c8 = i & 3;
+            v[u] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (i < nk32 * 4 && key < nk)
+              v[u] = *reinterpret_cast<const bf16x8*>(pv_ptr(a.in, hplane + AT_KD / 8 + c8, tok(k0s + key)));
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * 256, key = i >> 2, c8 = i & 3;
+            if (i < nk32 * 4) *reinterpret_cast<bf16x8*>(sK + key * AT_KP + c8 * 8) = v[u];
+          }
+        }
+        for (int i0 = tid; i0 < nk32 * 8; i0 += 256 * 8) {
+          bf16x8 v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * 256, key = i >> 3, c8 = i & 7;
+            v[u] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (i < nk32 * 8 && key < nk)
+              v[u] = *reinterpret_cast<const bf16x8*>(pv_ptr(a.in, hplane + 2 * AT_KD / 8 + c8, tok(k0s + key)));
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u * 256, key = i >> 3, c8 = i & 7;
+            if (i < nk32 * 8) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) sVt[(c8 * 8 + j) * AT_VP + key] = v[u][j];
+            }
+          }
         }
         __syncthreads();
       }

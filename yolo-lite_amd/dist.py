@@ -50,6 +50,18 @@ def gather_results(out: torch.Tensor, cnt: torch.Tensor, dst: int = 0, async_op:
     return outs, cnts, (w1, w2)
 
 
+def run_resident(compute: Callable[[torch.Tensor], Tuple[torch.Tensor, torch.Tensor]], local_batches: List[torch.Tensor],
+                 steps: int, dst: int = 0):
+    """Every rank works on image shards that already live in its own HBM: ``steps`` passes of the hot
+    path with no data-path collective at all (the path partitions by image), then ONE
+    gather of the last step's result records to ``dst``.  Returns the gathered (outs, cnts) on ``dst``."""
+    out = cnt = None
+    for k in range(steps):
+        out, cnt = compute(local_batches[k % len(local_batches)])
+    outs, cnts, _ = gather_results(out.clone(), cnt.clone(), dst, async_op=False)
+    return outs, cnts
+
+
 class ShardedRunner:
     """Pipelined scatter -> compute -> gather loop.
 
@@ -81,6 +93,9 @@ class ShardedRunner:
             if k + 1 < steps:
                 pending = scatter_images(batches[(k + 1) % nb], self.bufs[(k + 1) % 2], self.src, async_op=True)
             out, cnt = self.compute(cur)
+            # the hot path may hand out engine-owned buffers that its next call overwrites: the
+            # asynchronous gather gets private copies
+            out, cnt = out.clone(), cnt.clone()
             outs, cnts, works = gather_results(out, cnt, self.src, async_op=True)
             tail.append(works)
             if len(tail) > 2:  # bound the number of in-flight gathers
