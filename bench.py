@@ -193,7 +193,7 @@ def main():
         ms_step = dt / args.steps * 1e3
         value = world * B * args.steps / dt
         res = {
-            "metric": "images/sec end-to-end (incl. NMS), YOLO11n 640x640 batch=32",
+            "metric": f"images/sec end-to-end (incl. NMS), YOLO11{args.scale} {H}x{W} batch={B}",
             "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
