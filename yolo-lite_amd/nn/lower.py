@@ -218,6 +218,16 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
     def cls_lane(lvl: int) -> int:
         return lanes[2 * lvl + 1]
 
+    # Emission order = issue order on the main stream.  With side lanes the (large, bandwidth-heavy) box
+    # branch of level 0 is issued after the 20x20 / 40x40 tail of the network: the side lane's large
+    # class-branch kernels then overlap the small latency-bound kernels instead of the other large branch
+    # (measured 1.124 -> 1.077 ms end to end; pairing two large branches makes both slower).
+    # YL_BOX_DEFER="<level digits>" overrides the set of deferred box branches ("-" = none).
+    deferred: List[dict] = []
+    defer_box = {0} if (side_lanes and nlv > 1) else set()
+    if "YL_BOX_DEFER" in os.environ:
+        defer_box = {int(ch) for ch in os.environ["YL_BOX_DEFER"] if ch.isdigit()}
+
     def emit_level(lvl: int, xin: TView):
         h, w = xin.H, xin.W
         # raw level map: fp32 box block [B][H][W][64] immediately followed by the class block [B][H][W][nc]
@@ -231,6 +241,9 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
         conv(f"{dp}.cv2.{lvl}.2", t2, head_box, 1, 1, act=False, bn=False)
         for o in ops[n0:]:
             o["lane"] = box_lane(lvl)
+        if lvl in defer_box:  # run this box branch after the rest of the network (see below)
+            deferred.extend(ops[n0:])
+            del ops[n0:]
         n1 = len(ops)
         d1, e1 = ar.alloc(h, w, xin.C), ar.alloc(h, w, c3)
         dwconv(f"{dp}.cv3.{lvl}.0.0", xin, d1)
@@ -315,6 +328,7 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
         if sp.i in level_of:
             emit_level(level_of[sp.i], y)
 
+    ops.extend(deferred)
     a_total = 0
     for lvl in range(len(det.f)):
         prog.levels.append(level_rec[lvl])
