@@ -288,3 +288,30 @@ def test_fused_decode_nms_equals_unfused(gpu_device, golden, kw):
         assert torch.equal(out[i, : int(cnt[i])], ref_out[i, : int(cnt[i])])
     out2, cnt2 = eng.detect(x, graph=True, **kw)
     assert torch.equal(cnt2, cnt) and torch.equal(out2[0, : int(cnt[0])], out[0, : int(cnt[0])])
+
+
+def test_slots_in_flight_on_two_streams(gpu_device, golden):
+    """Batches in flight on different HIP streams use different workspace slots of one engine; their
+    results must equal the one-at-a-time results bit for bit."""
+    sd = synth_state_dict("n", 1, cls_bias=list(golden["net_n_96x128_bias"]), cls_gain=8.0)
+    x0 = torch.from_numpy(golden["net_n_96x128_x"]).to(gpu_device)
+    x1 = x0.flip(3).contiguous()
+    eng = _engine("n", sd, 2, 96, 128, gpu_device)
+    ref = []
+    for x in (x0, x1):
+        o, c = eng.detect(x, 0.25, 0.7, graph=False)
+        ref.append((o.clone(), c.clone()))
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    got = [None, None]
+    for rep in range(4):
+        for j, x in enumerate((x0, x1)):
+            with torch.cuda.stream(streams[j]):
+                got[j] = eng.detect(x, 0.25, 0.7, graph=True, slot=j)
+    torch.cuda.synchronize()
+    for j in range(2):
+        assert torch.equal(got[j][1], ref[j][1])
+        for i in range(2):
+            n = int(ref[j][1][i])
+            assert torch.equal(got[j][0][i, :n], ref[j][0][i, :n])
+    assert int(ref[0][1].sum()) > 0

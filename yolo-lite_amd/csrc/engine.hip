@@ -55,10 +55,16 @@ struct yl_engine {
                      void*, void*>
       DetectKey;
   std::map<DetectKey, hipGraphExec_t> dgraphs;
-  hipStream_t cap_stream = nullptr;
-  // side lanes (yl_op.lane > 0): one non-blocking stream each + a pool of fork/join events
-  std::vector<hipStream_t> lanes;
-  std::vector<hipEvent_t> events;
+  // Per workspace (= per batch in flight): a private capture stream, one non-blocking stream per side
+  // lane (yl_op.lane > 0) and a pool of fork/join events.  Batches that are in flight on different
+  // caller streams use different workspaces; giving each its own lane streams keeps their graphs from
+  // sharing (and serialising on) one hardware queue.
+  struct StreamSet {
+    hipStream_t cap = nullptr;
+    std::vector<hipStream_t> lanes;
+    std::vector<hipEvent_t> events;
+  };
+  std::map<void*, StreamSet> sets;
   int max_lane = 0;
   std::vector<void*> zeroed;  // workspaces whose guard pixels this engine has already cleared
 };
@@ -116,10 +122,12 @@ extern "C" void yl_engine_destroy(yl_engine* e) {
   if (!e) return;
   for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
   for (auto& kv : e->dgraphs) (void)hipGraphExecDestroy(kv.second);
-  if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
-  for (hipStream_t st : e->lanes)
-    if (st) (void)hipStreamDestroy(st);
-  for (hipEvent_t ev : e->events) (void)hipEventDestroy(ev);
+  for (auto& kv : e->sets) {
+    if (kv.second.cap) (void)hipStreamDestroy(kv.second.cap);
+    for (hipStream_t st : kv.second.lanes)
+      if (st) (void)hipStreamDestroy(st);
+    for (hipEvent_t ev : kv.second.events) (void)hipEventDestroy(ev);
+  }
   for (void* p : e->allocs) (void)hipFree(p);
   delete e;
 }
@@ -399,15 +407,22 @@ static int run_decode(const yl_engine* e, const char* ws, float* y, hipStream_t 
 // the recycling of arena memory; it then overlaps with later main-lane ops.  All lanes are joined
 // back into the main stream before the decode.  The same calls are legal under stream capture, where
 // they become fork/join edges of the graph.
-static int lane_resources(yl_engine* e, size_t n_events) {
-  while ((int)e->lanes.size() <= e->max_lane) e->lanes.push_back(nullptr);
+static int lane_resources(yl_engine* e, yl_engine::StreamSet& ss, size_t n_events) {
+  while ((int)ss.lanes.size() <= e->max_lane) ss.lanes.push_back(nullptr);
   for (int k = 1; k <= e->max_lane; ++k)
-    if (!e->lanes[k]) YL_HIP(hipStreamCreateWithFlags(&e->lanes[k], hipStreamNonBlocking));
-  while (e->events.size() < n_events) {
+    if (!ss.lanes[k]) YL_HIP(hipStreamCreateWithFlags(&ss.lanes[k], hipStreamNonBlocking));
+  while (ss.events.size() < n_events) {
     hipEvent_t ev;
     YL_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    e->events.push_back(ev);
+    ss.events.push_back(ev);
   }
+  return 0;
+}
+
+static int capture_stream(yl_engine* e, void* workspace, hipStream_t* out) {
+  yl_engine::StreamSet& ss = e->sets[workspace];
+  if (!ss.cap) YL_HIP(hipStreamCreateWithFlags(&ss.cap, hipStreamNonBlocking));
+  *out = ss.cap;
   return 0;
 }
 
@@ -422,8 +437,9 @@ extern "C" int yl_engine_forward(yl_engine* e, const void* input, int in_dtype, 
   hipStream_t s = (hipStream_t)stream;
   char* ws = (char*)workspace;
   if (int rc = prepare_workspace(e, ws, s)) return rc;
+  yl_engine::StreamSet& ss = e->sets[workspace];
   if (e->max_lane > 0)
-    if (int rc = lane_resources(e, e->ops.size() + e->max_lane + 1)) return rc;
+    if (int rc = lane_resources(e, ss, e->ops.size() + e->max_lane + 1)) return rc;
   const bool stem = !e->ops.empty() && e->ops[0].op.kind == YL_OP_STEM;
   if (!stem)
     if (int rc = run_convert(e, input, in_dtype, ws, s)) return rc;
@@ -434,17 +450,17 @@ extern "C" int yl_engine_forward(yl_engine* e, const void* input, int in_dtype, 
     if (lane == 0) {
       if (int rc = run_op(e, r, ws, s, input, in_dtype)) return rc;
     } else {
-      hipEvent_t ev = e->events[nev++];
+      hipEvent_t ev = ss.events[nev++];
       YL_HIP(hipEventRecord(ev, s));
-      YL_HIP(hipStreamWaitEvent(e->lanes[lane], ev, 0));
-      if (int rc = run_op(e, r, ws, e->lanes[lane])) return rc;
+      YL_HIP(hipStreamWaitEvent(ss.lanes[lane], ev, 0));
+      if (int rc = run_op(e, r, ws, ss.lanes[lane])) return rc;
       used[lane] = 1;
     }
   }
   for (int k = 1; k <= e->max_lane; ++k)
     if (used[k]) {
-      hipEvent_t ev = e->events[nev++];
-      YL_HIP(hipEventRecord(ev, e->lanes[k]));
+      hipEvent_t ev = ss.events[nev++];
+      YL_HIP(hipEventRecord(ev, ss.lanes[k]));
       YL_HIP(hipStreamWaitEvent(s, ev, 0));
     }
   if (y) {
@@ -470,11 +486,12 @@ extern "C" int yl_engine_forward_graph(yl_engine* e, const void* input, int in_d
     YL_HIP(hipStreamSynchronize(s));
     // Capture on a private stream (the caller's may be the legacy default stream, which cannot
     // capture); the instantiated graph is then launched on the caller's stream.
-    if (!e->cap_stream) YL_HIP(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
+    hipStream_t cap = nullptr;
+    if (int rc = capture_stream(e, workspace, &cap)) return rc;
     hipGraph_t g = nullptr;
-    YL_HIP(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal));
-    int rc = yl_engine_forward(e, input, in_dtype, workspace, y, (void*)e->cap_stream);
-    hipError_t ce = hipStreamEndCapture(e->cap_stream, &g);
+    YL_HIP(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
+    int rc = yl_engine_forward(e, input, in_dtype, workspace, y, (void*)cap);
+    hipError_t ce = hipStreamEndCapture(cap, &g);
     if (rc) {
       if (g) (void)hipGraphDestroy(g);
       return rc;
@@ -520,12 +537,13 @@ extern "C" int yl_engine_detect_graph(yl_engine* e, const void* input, int in_dt
                               n_classes, max_cand, max_wh, scale, out, out_count, work, stream))
       return rc;
     YL_HIP(hipStreamSynchronize(s));
-    if (!e->cap_stream) YL_HIP(hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking));
+    hipStream_t cap = nullptr;
+    if (int rc = capture_stream(e, workspace, &cap)) return rc;
     hipGraph_t g = nullptr;
-    YL_HIP(hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal));
+    YL_HIP(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
     int rc = detect_eager(e, input, in_dtype, workspace, conf_thres, iou_thres, max_det, agnostic, classes, n_classes,
-                          max_cand, max_wh, scale, out, out_count, work, (void*)e->cap_stream);
-    hipError_t ce = hipStreamEndCapture(e->cap_stream, &g);
+                          max_cand, max_wh, scale, out, out_count, work, (void*)cap);
+    hipError_t ce = hipStreamEndCapture(cap, &g);
     if (rc) {
       if (g) (void)hipGraphDestroy(g);
       return rc;

@@ -51,13 +51,17 @@ def gather_results(out: torch.Tensor, cnt: torch.Tensor, dst: int = 0, async_op:
 
 
 def run_resident(compute: Callable[[torch.Tensor], Tuple[torch.Tensor, torch.Tensor]], local_batches: List[torch.Tensor],
-                 steps: int, dst: int = 0):
+                 steps: int, dst: int = 0, finish: Optional[Callable[[], None]] = None):
     """Every rank works on image shards that already live in its own HBM: ``steps`` passes of the hot
     path with no data-path collective at all (the path partitions by image), then ONE
-    gather of the last step's result records to ``dst``.  Returns the gathered (outs, cnts) on ``dst``."""
+    gather of the last step's result records to ``dst``.  Returns the gathered (outs, cnts) on ``dst``.
+    ``compute`` may pipeline steps over several streams; ``finish`` (e.g. a device synchronise) is then
+    called once after the last step, before the gather reads its outputs."""
     out = cnt = None
     for k in range(steps):
         out, cnt = compute(local_batches[k % len(local_batches)])
+    if finish is not None:
+        finish()
     outs, cnts, _ = gather_results(out.clone(), cnt.clone(), dst, async_op=False)
     return outs, cnts
 

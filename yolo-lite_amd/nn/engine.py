@@ -66,13 +66,24 @@ class HipEngine:
         with torch.cuda.device(device):
             _lib.check(self.lib.yl_engine_create(arr, len(ops), batch, in_h, in_w, C.byref(iv), lv, len(lv), self.nc,
                                                  self.prog.ws_bytes, C.byref(handle)), "yl_engine_create")
-            self.workspace = torch.empty(self.prog.ws_bytes, dtype=torch.uint8, device=device)
-            # zero the guard pixels of the planar layout once; no kernel ever writes them
-            _lib.check(self.lib.yl_engine_prepare_workspace(handle, self.workspace.data_ptr(),
-                                                            torch.cuda.current_stream(device).cuda_stream),
-                       "yl_engine_prepare_workspace")
         self._h = handle
+        self._slots: List[dict] = []
+        self.workspace = self._slot(0)["ws"]
         self._keep.clear()  # weights were packed and uploaded by yl_engine_create
+
+    def _slot(self, i: int) -> dict:
+        """Slot i = one workspace (+ NMS scratch and static outputs): batches in flight on different HIP
+        streams use different slots of ONE engine (shared packed weights), e.g. bench.py pipelines two."""
+        while len(self._slots) <= i:
+            with torch.cuda.device(self.device):
+                ws = torch.empty(self.prog.ws_bytes, dtype=torch.uint8, device=self.device)
+                # zero the guard pixels of the planar layout once; no kernel ever writes them
+                _lib.check(self.lib.yl_engine_prepare_workspace(self._h, ws.data_ptr(),
+                                                                torch.cuda.current_stream(self.device).cuda_stream),
+                           "yl_engine_prepare_workspace")
+                torch.cuda.current_stream(self.device).synchronize()
+            self._slots.append(dict(ws=ws, static={}))
+        return self._slots[i]
 
     @classmethod
     def from_model(cls, specs: Sequence[LayerSpec], state_dict: Dict[str, torch.Tensor], batch: int, in_h: int,
@@ -101,39 +112,44 @@ class HipEngine:
             raise ValueError("input must be a contiguous tensor on the engine's device")
 
     def forward(self, im: torch.Tensor, y: Optional[torch.Tensor] = None, graph: bool = False,
-                decode: bool = True) -> Optional[torch.Tensor]:
+                decode: bool = True, slot: int = 0) -> Optional[torch.Tensor]:
         """im (B,3,H,W) fp32/fp16 in [0,1] or uint8 -> y (B, 4+nc, A) fp32 (reference head.py:95-126)."""
         self._check_input(im)
+        sl = self._slot(slot)
         if decode and y is None:
             if graph:  # graphs bake pointers: reuse one output buffer (valid until the next graph call)
-                if getattr(self, "_y_static", None) is None:
-                    self._y_static = torch.empty((self.batch, 4 + self.nc, self.anchors), dtype=torch.float32,
-                                                 device=self.device)
-                y = self._y_static
+                if "y" not in sl["static"]:
+                    sl["static"]["y"] = torch.empty((self.batch, 4 + self.nc, self.anchors), dtype=torch.float32,
+                                                    device=self.device)
+                y = sl["static"]["y"]
             else:
                 y = torch.empty((self.batch, 4 + self.nc, self.anchors), dtype=torch.float32, device=self.device)
         stream = torch.cuda.current_stream(self.device).cuda_stream
         fn = self.lib.yl_engine_forward_graph if graph else self.lib.yl_engine_forward
-        _lib.check(fn(self._h, im.data_ptr(), _TORCH2YL[im.dtype], self.workspace.data_ptr(),
+        _lib.check(fn(self._h, im.data_ptr(), _TORCH2YL[im.dtype], sl["ws"].data_ptr(),
                       y.data_ptr() if decode else None, stream), "yl_engine_forward")
         return y if decode else None
 
     def detect(self, im: torch.Tensor, conf: float = 0.25, iou: float = 0.7, max_det: int = 300,
                classes=None, agnostic: bool = False, max_nms: int = 30000, max_wh: float = 7680.0,
-               scale: Optional[torch.Tensor] = None, graph: bool = True):
+               scale: Optional[torch.Tensor] = None, graph: bool = True, slot: int = 0):
         """Network + fused Detect decode + NMS; returns padded (out[B, max_det, 6], count[B]).
 
         Bit-identical to ``forward`` followed by ``utils.ops.nms_padded`` but the (B, 4+nc, A) tensor
         of the reference (head.py:126) is never materialised.  No host synchronisation.  With
         ``graph=True`` the whole path is ONE hipGraph launch and the returned tensors are engine-owned
-        buffers that stay valid until the next ``detect`` call with the same ``max_det``."""
-        from ..utils import ops as _ops
-
+        buffers that stay valid until the next ``detect`` call with the same ``max_det`` and ``slot``.
+        Calls with different ``slot`` values may be in flight on different streams at the same time."""
         self._check_input(im)
         max_cand = min(int(max_nms), self.anchors)
-        work = _ops._nms_workspace(self.device, self.batch, self.anchors, max_cand)
+        sl = self._slot(slot)
+        st = sl["static"]
+        wk = ("work", max_cand)
+        if wk not in st:  # NMS scratch belongs to the slot: two batches in flight must not share it
+            nbytes = int(self.lib.yl_nms_workspace_bytes(self.batch, self.anchors, max_cand))
+            st[wk] = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        work = st[wk]
         stream = torch.cuda.current_stream(self.device).cuda_stream
-        st = self.__dict__.setdefault("_det_static", {})
         if graph:
             if max_det not in st:
                 st[max_det] = (torch.empty((self.batch, max_det, 6), dtype=torch.float32, device=self.device),
@@ -158,13 +174,13 @@ class HipEngine:
                 max_cand, float(max_wh), scale.data_ptr() if scale is not None else None, out.data_ptr(),
                 cnt.data_ptr(), work.data_ptr(), stream)
         if graph:
-            rc = self.lib.yl_engine_detect_graph(self._h, im.data_ptr(), _TORCH2YL[im.dtype],
-                                                 self.workspace.data_ptr(), *args)
+            rc = self.lib.yl_engine_detect_graph(self._h, im.data_ptr(), _TORCH2YL[im.dtype], sl["ws"].data_ptr(),
+                                                 *args)
             _lib.check(rc, "yl_engine_detect_graph")
         else:
-            self.forward(im, graph=False, decode=False)
-            rc = self.lib.yl_decode_nms(self.workspace.data_ptr(), self._levels, len(self._levels), self.batch,
-                                        self.nc, *args)
+            self.forward(im, graph=False, decode=False, slot=slot)
+            rc = self.lib.yl_decode_nms(sl["ws"].data_ptr(), self._levels, len(self._levels), self.batch, self.nc,
+                                        *args)
             _lib.check(rc, "yl_decode_nms")
         return out, cnt
 
