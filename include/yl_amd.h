@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define YL_ABI_VERSION 1
+#define YL_ABI_VERSION 2
 
 /* element types */
 enum { YL_BF16 = 0, YL_F32 = 1, YL_F16 = 2, YL_U8 = 3 };
@@ -82,6 +82,14 @@ typedef struct yl_op {
   yl_view in, out, res; /* res.offset < 0: no residual; res has the geometry of out           */
   const float* weight;
   const float* bias;
+  /* conv only: a 1x1 stride-1 conv fused behind this one (its only consumer), applied in the epilogue
+     so that the intermediate tensor never exists.  post_cin = output channels of THIS conv (32 or 64,
+     `weight` is [post_cin][Cin][k][k]); post_weight [out.C][post_cin], post_bias [out.C]; `act` belongs
+     to this conv, post_act to the fused one; out is the fused conv's output; no residual.
+     post_weight == NULL: plain conv. */
+  int32_t post_cin, post_act;
+  const float* post_weight;
+  const float* post_bias;
 } yl_op;
 
 /* Detect-level raw map (reference head.py:64-65 torch.cat(cv2, cv3)), fp32, stored as two NHWC blocks

@@ -17,6 +17,8 @@ def _conv_gflop(prog):
         if o["kind"] in (OP_CONV, OP_DWCONV3, OP_STEM):
             w = o["weight"]
             f += 2.0 * o["out"].H * o["out"].W * w.shape[0] * w.shape[1] * w.shape[2] * w.shape[3]
+            if "post_weight" in o:  # a 1x1 conv fused into this conv's epilogue
+                f += 2.0 * o["out"].H * o["out"].W * o["post_weight"].shape[0] * o["post_weight"].shape[1]
     return f / 1e9
 
 
@@ -28,7 +30,8 @@ def test_algorithmic_flops_match_survey(scale, gflop, nconv):
     got = _conv_gflop(p) + 2 * 16 * 4 * p.anchors / 1e9
     assert abs(got - gflop) < 2e-3 * gflop
     # C3k cv1+cv2 pairs are merged into one launch: count reference Conv2d calls
-    calls = sum(2 if o.get("name", "").endswith("cv1+cv2") else 1 for o in p.ops if o["kind"] in (OP_CONV, OP_DWCONV3, OP_STEM))
+    calls = sum((2 if o.get("name", "").endswith("cv1+cv2") else 1) + len(o.get("fused_names", []))
+                for o in p.ops if o["kind"] in (OP_CONV, OP_DWCONV3, OP_STEM))
     assert calls + 1 == nconv  # + the DFL conv
 
 

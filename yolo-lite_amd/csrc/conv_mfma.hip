@@ -277,7 +277,11 @@ __device__ __forceinline__ void run_ksteps(const ConvArgs& a, __amdgpu_buffer_rs
   }
 }
 
-template <int KS, int MT, int NT, bool UNIFORM>
+// POST (MT even, all MT*16 channels of the first conv in this wave, i.e. ncb == 1): a 1x1 conv that
+// consumes ONLY this conv's output is applied in the epilogue.  After bias + SiLU + bf16 rounding the
+// accumulators of tile pair p ARE the B fragment of k-step p of that 1x1 conv (same channel permutation
+// that makes the stores 16 bytes wide), so the intermediate tensor is never written or read.
+template <int KS, int MT, int NT, bool UNIFORM, bool POST>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -331,6 +335,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
       if (multi || first) {
         if (!first) __syncthreads();  // every wave is done with the previous slab
         if (!(a.dbg & 4)) copy_slab(wsrc + (size_t)kc * MT * 64, reinterpret_cast<bf16x8*>(smem), nk * MT * 64, tid);
+        if (POST && first)  // the follow-up 1x1's filter: MT/2 k-steps x MT tiles, right behind the slab
+          copy_slab(reinterpret_cast<const bf16x8*>(a.wpk2),
+                    reinterpret_cast<bf16x8*>(smem) + min(a.kchunk, a.ksteps) * MT * 64, (MT / 2) * MT * 64, tid);
         __syncthreads();
         first = false;
       }
@@ -348,7 +355,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
 #pragma unroll
       for (int d = 0; d < D; ++d) fetch_b<KS, NT, UNIFORM>(a, rin, d, g, P, xr[d]);
     }
-    epilogue<MT, NT>(a, rout, rres, cb, g, opix, acc);
+    if constexpr (POST) {
+      static_assert(!POST || (MT % 2 == 0), "POST needs an even tile count");
+      // epilogue of the first conv in registers, then the 1x1 on the packed fragments
+      bf16x8 xb2[MT / 2][NT];
+#pragma unroll
+      for (int p = 0; p < MT / 2; ++p)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          float v[8];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = acc[2 * p][nt][r];
+            v[4 + r] = acc[2 * p + 1][nt][r];
+          }
+          if (a.act) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = silu_f(v[r]);
+          }
+#pragma unroll
+          for (int r = 0; r < 8; ++r) xb2[p][nt][r] = (__bf16)v[r];
+        }
+      const bf16x8* wl2 = wl + min(a.kchunk, a.ksteps) * MT * 64;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const f32x4 b2 = *reinterpret_cast<const f32x4*>(a.bias2 + chan_in_block(MT, mt, g, 0));
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = b2;
+      }
+#pragma unroll
+      for (int p = 0; p < MT / 2; ++p)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const bf16x8 w2 = wl2[(p * MT + mt) * 64];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2, xb2[p][nt], acc[mt][nt], 0, 0, 0);
+        }
+      ConvArgs a2 = a;
+      a2.Cout = a.post_cout;
+      a2.act = a.post_act;
+      epilogue<MT, NT>(a2, rout, rres, cb, g, opix, acc);
+    } else {
+      epilogue<MT, NT>(a, rout, rres, cb, g, opix, acc);
+    }
   }
 }
 
@@ -358,7 +408,7 @@ static unsigned magic_of(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ul
 static const size_t LDS_MAX = 160 * 1024;  // per CU and per workgroup on gfx950
 static const int NUM_CU = 256;
 
-int conv_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, ConvConfig* c) {
+int conv_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, int post, ConvConfig* c) {
   if ((k != 1 && k != 3) || (stride != 1 && stride != 2) || Cin % 8 || Cin <= 0 || Cout <= 0)
     return fail(-3, "conv: unsupported geometry (k in {1,3}, stride in {1,2}, Cin % 8 == 0)");
   const int cout16 = (Cout + 15) / 16;
@@ -405,6 +455,13 @@ int conv_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo,
   c->ksteps = ksteps;
   c->kchunk = kchunk;
   c->lds_bytes = (size_t)(kchunk < ksteps ? kchunk : ksteps) * MT * 1024;
+  c->post = post;
+  if (post) {
+    // follow-up 1x1 in the epilogue: this wave must hold every channel of the first conv
+    if (ncb != 1 || (MT != 2 && MT != 4) || Cout != MT * 16)
+      return fail(-3, "conv: a fused follow-up 1x1 needs Cout in {32, 64} of the first conv");
+    c->lds_bytes += (size_t)(MT / 2) * MT * 1024;
+  }
   c->wpk_elems = (size_t)ncb * ksteps * MT * 64 * 8;
   c->npatches = (int)npatches(NT);
   // patches per wave: amortise the slab load while keeping >= ~8 blocks per CU in the grid
@@ -448,9 +505,9 @@ void conv_pack_weights(const float* w, int Cout, int Cin_w, int k, const ConvCon
         }
 }
 
-template <int KS, int MT, int NT, bool U>
-static int launch_t(const ConvConfig& cfg, const ConvArgs& a, hipStream_t s) {
-  auto kern = conv_kernel<KS, MT, NT, U>;
+template <int KS, int MT, int NT, bool U, bool POST>
+static int launch_p(const ConvConfig& cfg, const ConvArgs& a, hipStream_t s) {
+  auto kern = conv_kernel<KS, MT, NT, U, POST>;
   static size_t attr = 0;  // per instantiation: largest dynamic LDS size enabled so far
   if (cfg.lds_bytes > attr) {
     YL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -460,6 +517,15 @@ static int launch_t(const ConvConfig& cfg, const ConvArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(kern, dim3(a.nblocks), dim3(256), cfg.lds_bytes, s, a);
   YL_HIP(hipGetLastError());
   return 0;
+}
+
+template <int KS, int MT, int NT, bool U>
+static int launch_t(const ConvConfig& cfg, const ConvArgs& a, hipStream_t s) {
+  if constexpr (MT == 2 || MT == 4) {
+    if (cfg.post) return launch_p<KS, MT, NT, U, true>(cfg, a, s);
+  }
+  if (cfg.post) return fail(-3, "conv: fused follow-up conv needs MT in {2, 4}");
+  return launch_p<KS, MT, NT, U, false>(cfg, a, s);
 }
 
 template <int KS, int MT, int NT>
@@ -502,8 +568,9 @@ int conv_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s) {
   {
     const long long lim = 1LL << 30;
     const long long inb = (long long)cfg.cg * a.in_plane;
-    const long long outb = a.out_f32 ? (long long)a.npix * a.out_pitch * 4 : (long long)((a.Cout + 7) / 8) * a.out_plane;
-    const long long resb = a.res ? (long long)((a.Cout + 7) / 8) * a.res_plane : 0;
+    const int cout_out = a.wpk2 ? a.post_cout : a.Cout;  // channels of the tensor that is actually stored
+    const long long outb = a.out_f32 ? (long long)a.npix * a.out_pitch * 4 : (long long)((cout_out + 7) / 8) * a.out_plane;
+    const long long resb = a.res ? (long long)((cout_out + 7) / 8) * a.res_plane : 0;
     if (inb > lim || outb > lim || resb > lim)
       return fail(-3, "conv: a tensor slice exceeds 1 GiB (32-bit buffer offsets); lower the batch size");
     a.in_bytes = (unsigned)inb;

@@ -23,6 +23,8 @@ struct OpRec {
   yl_op op;
   ConvConfig cfg{};
   __bf16* d_wpk = nullptr;
+  __bf16* d_wpk2 = nullptr;  // fused follow-up 1x1
+  float* d_bias2 = nullptr;
   float* d_w = nullptr;     // dwconv weights [9][C]
   float* d_bias = nullptr;
   double flops = 0, bytes = 0;
@@ -181,18 +183,38 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
         }
         // weight Cin may be smaller than the (padded) input view channels: stem 3 -> 8
         const int cin_w = o.cin_weight > 0 ? o.cin_weight : o.in.C;
-        if (int rc = conv_choose(batch, o.in.C, o.out.C, o.k, o.stride, Ho, Wo, &r.cfg)) return rc;
+        const bool post = o.post_weight != nullptr;
+        const int cout1 = post ? o.post_cin : o.out.C;  // channels the main GEMM produces
+        if (post && (!o.post_bias || o.res.offset >= 0 || o.out.C > o.post_cin))
+          return fail(-1, tag + ": fused follow-up conv needs a bias, no residual and out.C <= post_cin");
+        if (int rc = conv_choose(batch, o.in.C, cout1, o.k, o.stride, Ho, Wo, post, &r.cfg)) return rc;
         std::vector<uint16_t> pk;
-        conv_pack_weights(o.weight, o.out.C, cin_w, o.k, r.cfg, &pk);
+        conv_pack_weights(o.weight, cout1, cin_w, o.k, r.cfg, &pk);
+        if (post) {
+          ConvConfig c2 = r.cfg;  // same tile count; K = post_cin channels, one tap
+          c2.ncb = 1;
+          c2.cg = o.post_cin / 8;
+          c2.ksteps = r.cfg.MT / 2;
+          c2.ntaps = 1;
+          c2.wpk_elems = (size_t)c2.ksteps * c2.MT * 64 * 8;
+          std::vector<uint16_t> pk2;
+          conv_pack_weights(o.post_weight, o.out.C, o.post_cin, 1, c2, &pk2);
+          uint16_t* d2 = nullptr;
+          if (int rc = dev_upload(e.get(), pk2, &d2)) return rc;
+          r.d_wpk2 = reinterpret_cast<__bf16*>(d2);
+          std::vector<float> b2((size_t)r.cfg.MT * 16 + 16, 0.f);
+          for (int c = 0; c < o.out.C; ++c) b2[c] = o.post_bias[c];
+          if (int rc = dev_upload(e.get(), b2, &r.d_bias2)) return rc;
+        }
         uint16_t* d = nullptr;
         if (int rc = dev_upload(e.get(), pk, &d)) return rc;
         r.d_wpk = reinterpret_cast<__bf16*>(d);
         std::vector<float> bias((size_t)r.cfg.ncb * r.cfg.MT * 16 + 16, 0.f);
-        for (int c = 0; c < o.out.C; ++c) bias[c] = o.bias[c];
+        for (int c = 0; c < cout1; ++c) bias[c] = o.bias[c];
         if (int rc = dev_upload(e.get(), bias, &r.d_bias)) return rc;
-        r.flops = 2.0 * px_out * o.out.C * cin_w * o.k * o.k;
+        r.flops = 2.0 * px_out * cout1 * cin_w * o.k * o.k + (post ? 2.0 * px_out * o.out.C * o.post_cin : 0.0);
         r.bytes = px_in * o.in.C * 2 + px_out * o.out.C * view_elem_size(o.out) +
-                  (o.res.offset >= 0 ? px_out * o.out.C * 2 : 0) + (double)o.out.C * cin_w * o.k * o.k * 2;
+                  (o.res.offset >= 0 ? px_out * o.out.C * 2 : 0) + (double)cout1 * cin_w * o.k * o.k * 2;
         r.name = r.cfg.name;
         break;
       }
@@ -297,10 +319,14 @@ static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s, c
       }
       a.wpk = r.d_wpk;
       a.bias = r.d_bias;
+      a.wpk2 = r.d_wpk2;
+      a.bias2 = r.d_bias2;
+      a.post_cout = o.out.C;
+      a.post_act = o.post_act;
       a.Ho = o.out.H;
       a.Wo = o.out.W;
       a.Cin = o.in.C;
-      a.Cout = o.out.C;
+      a.Cout = r.d_wpk2 ? o.post_cin : o.out.C;
       a.stride = o.stride;
       a.act = o.act;
       return conv_launch(r.cfg, a, B, s);

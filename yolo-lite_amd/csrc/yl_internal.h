@@ -68,6 +68,9 @@ struct ConvArgs {
   void* out;           // bf16: first plane of the output slice; fp32: NHWC buffer base
   const __bf16* res;   // first plane of the residual slice, nullptr: none
   const __bf16* wpk;   // [cb][kstep][MT][64 lanes][8]
+  const __bf16* wpk2;  // fused follow-up 1x1: [MT/2 k-steps][MT][64 lanes][8], nullptr: none
+  const float* bias2;  // its bias, padded to MT*16
+  int post_cout, post_act;
   const float* bias;   // padded to ncb*MT*16
   unsigned in_plane, out_plane, res_plane;  // bytes per plane
   int Ho, Wo;
@@ -85,14 +88,14 @@ struct ConvArgs {
 };
 
 struct ConvConfig {
-  int MT, NT, uniform, ncb, cg, ksteps, kchunk, ntaps, npatches, gws, ppw;
+  int MT, NT, uniform, post, ncb, cg, ksteps, kchunk, ntaps, npatches, gws, ppw;
   size_t lds_bytes;
   size_t wpk_elems;  // packed weight elements
   const char* name;
 };
 
 // Chooses the tiling for one conv; returns <0 when unsupported.
-int conv_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, ConvConfig* cfg);
+int conv_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, int post, ConvConfig* cfg);
 // Packs folded fp32 OIHW weights into the fragment order cfg describes (host).
 void conv_pack_weights(const float* w_oihw, int Cout, int Cin_w, int k, const ConvConfig& cfg,
                        std::vector<uint16_t>* out);

@@ -57,6 +57,12 @@ class HipEngine:
                 b = np.ascontiguousarray(o["bias"], dtype=np.float32)
                 self._keep += [w, b]
                 c.weight, c.bias = w.ctypes.data, b.ctypes.data
+            if "post_weight" in o:
+                w2 = np.ascontiguousarray(o["post_weight"], dtype=np.float32).reshape(o["post_weight"].shape[0], -1)
+                b2 = np.ascontiguousarray(o["post_bias"], dtype=np.float32)
+                self._keep += [w2, b2]
+                c.post_weight, c.post_bias = w2.ctypes.data, b2.ctypes.data
+                c.post_cin, c.post_act = int(w2.shape[1]), int(o.get("post_act", 0))
         lv = (_lib.Level * len(self.prog.levels))()
         for i, L in enumerate(self.prog.levels):
             lv[i] = _lib.Level(L["offset"], L["H"], L["W"], L["stride"], 0)
@@ -88,10 +94,10 @@ class HipEngine:
     @classmethod
     def from_model(cls, specs: Sequence[LayerSpec], state_dict: Dict[str, torch.Tensor], batch: int, in_h: int,
                    in_w: int, device: torch.device, strides: Sequence[float] = (8.0, 16.0, 32.0),
-                   keep_layers: bool = True) -> "HipEngine":
-        """Every layer keeps its own buffer (``layer_output`` works on any engine); ``keep_layers`` is
-        accepted for compatibility and ignored."""
-        return cls(lower(specs, state_dict, batch, in_h, in_w, strides), device)
+                   keep_layers: bool = False) -> "HipEngine":
+        """``keep_layers=True`` (debug: ``layer_output`` of every layer) disables the fusions that make
+        intermediate tensors disappear; pass False for the production program."""
+        return cls(lower(specs, state_dict, batch, in_h, in_w, strides, fuse_post=not keep_layers), device)
 
     def __del__(self):
         h = getattr(self, "_h", None)

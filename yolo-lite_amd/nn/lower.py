@@ -89,6 +89,56 @@ class _Arena:
         return v
 
 
+def fuse_follow_up_convs(ops: List[dict]) -> List[dict]:
+    """Conv A -> 1x1 stride-1 conv B, where B is the ONLY reader of A's output and A produces 32 or 64
+    channels: B is applied in A's epilogue (``yl_op.post_*``), the tensor between them disappears.
+    In YOLO11n: layer 1 -> C3k2.cv1 of layer 2, layer 3 -> C3k2.cv1 of layer 4, and the last two convs
+    of every Detect box branch (cv2[i][1] -> cv2[i][2]).  Saves 0.23 GB of HBM traffic per batch of 32
+    at 640x640 and five launches."""
+
+    def key(v: TView):
+        return (v.offset, v.coff, v.C)
+
+    def planes(v: TView):
+        return {(v.offset, p) for p in range(v.coff // 8, (v.coff + v.C) // 8)} if v.dtype == BF16 else set()
+
+    readers: Dict[tuple, List[int]] = {}
+    for i, o in enumerate(ops):
+        for k in ("inp", "res"):
+            v = o.get(k)
+            if v is not None and v.dtype == BF16:
+                for pl in planes(v):
+                    readers.setdefault(pl, []).append(i)
+        if o.get("accumulate"):  # reads its own output
+            for pl in planes(o["out"]):
+                readers.setdefault(pl, []).append(i)
+    drop = set()
+    for i, a in enumerate(ops):
+        if a["kind"] != OP_CONV or i in drop or "post_weight" in a or a.get("res") is not None:
+            continue
+        y = a["out"]
+        if y.dtype != BF16 or y.C not in (32, 64) or a.get("cin_weight", 0):
+            continue
+        rd = {j for pl in planes(y) for j in readers.get(pl, [])}
+        if len(rd) != 1:
+            continue
+        j = next(iter(rd))
+        b = ops[j]
+        if (j <= i or b["kind"] != OP_CONV or b.get("k") != 1 or b.get("stride", 1) != 1 or b.get("res") is not None
+                or key(b["inp"]) != key(y) or b.get("lane", 0) != a.get("lane", 0) or b["out"].C > y.C
+                or "post_weight" in b or b.get("cin_weight", 0)):
+            continue
+        # nothing between them may write A's output again (in-place updates): A is the only writer by construction
+        a["post_weight"] = b["weight"].reshape(b["weight"].shape[0], -1)
+        a["post_bias"] = b["bias"]
+        a["post_act"] = b.get("act", 0)
+        a["out"] = b["out"]
+        a["name"] = f"{a.get('name', '')}+{b.get('name', '').split('.')[-1] if '.' in b.get('name', '') else b.get('name', '')}"
+        a["fused_names"] = [b.get("name", "")]
+        drop.add(j)
+    return [o for i, o in enumerate(ops) if i not in drop]
+
+
 def fold_conv_bn(sd: Dict[str, torch.Tensor], name: str, bn: bool = True) -> Tuple[np.ndarray, np.ndarray]:
     """BN-folded fp32 (weight OIHW, bias) of the Conv unit ``name`` (torch_utils.py:182-209)."""
     if bn:
@@ -110,7 +160,7 @@ def _out_hw(h: int, w: int, k: int, s: int) -> Tuple[int, int]:
 
 
 def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, in_h: int, in_w: int,
-          strides: Sequence[float] = (8.0, 16.0, 32.0), side_lanes: bool = True,
+          strides: Sequence[float] = (8.0, 16.0, 32.0), side_lanes: bool = True, fuse_post: bool = True,
           fused_stem: bool = True) -> Program:
     det = specs[-1]
     assert det.kind == "Detect"
@@ -329,6 +379,8 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
             emit_level(level_of[sp.i], y)
 
     ops.extend(deferred)
+    if fuse_post and os.environ.get("YL_FUSE_POST", "1") != "0":
+        ops[:] = fuse_follow_up_convs(ops)
     a_total = 0
     for lvl in range(len(det.f)):
         prog.levels.append(level_rec[lvl])
