@@ -30,7 +30,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.View) == 32       # int64 + 6 x int32
     assert ctypes.sizeof(_lib.Level) == 24
     # yl_op: 13 x int32/float (52) + pad to 8 (56) + 3 views (96) + 2 pointers (16)
-    assert ctypes.sizeof(_lib.Op) == 56 + 96 + 16
+    assert ctypes.sizeof(_lib.Op) == 56 + 96 + 16 + 8 + 16  # + post_cin, post_act, post_weight, post_bias
 
 
 def test_no_gpu_calls_fail_loudly():
