@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define YL_ABI_VERSION 2
+#define YL_ABI_VERSION 3
 
 /* element types */
 enum { YL_BF16 = 0, YL_F32 = 1, YL_F16 = 2, YL_U8 = 3 };
@@ -90,6 +90,12 @@ typedef struct yl_op {
   int32_t post_cin, post_act;
   const float* post_weight;
   const float* post_bias;
+  /* 1x1 stride-1 conv only: in2.offset >= 0 makes the conv read cat(upsample_nearest(in2, up), in) along the
+     channels (yolo11.yaml:31-36 nn.Upsample + Concat) without that tensor existing: the first in2.C input
+     channels come from in2 at pixel (y / up, x / up).  up must be 2; in2.C and in.C multiples of 32;
+     `weight` is [Cout][in2.C + in.C]. */
+  yl_view in2;
+  int32_t up, reserved;
 } yl_op;
 
 /* Detect-level raw map (reference head.py:64-65 torch.cat(cv2, cv3)), fp32, stored as two NHWC blocks

@@ -11,7 +11,7 @@ import torch
 import torch.nn.functional as F
 
 from hip_util import Mini, bf16_round, run_conv
-from yololite_amd.nn.lower import BF16, F32, OP_ATTENTION, OP_DWCONV3, OP_SPPF_POOL, OP_UPSAMPLE
+from yololite_amd.nn.lower import BF16, F32, OP_ATTENTION, OP_CONV, OP_DWCONV3, OP_SPPF_POOL, OP_UPSAMPLE
 
 pytestmark = pytest.mark.gpu
 
@@ -78,6 +78,36 @@ def test_conv_slices_and_f32_out(gpu_device):
     ref = F.conv2d(x, wt, b)
     got = run_conv(gpu_device, x, wt, b, 1, 1, False, None, pitch_extra=(16, 64), out_f32=True)
     np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=1e-4, atol=1e-4)  # fp32 out: order noise only
+
+
+@pytest.mark.parametrize("cin,cmid,cout,k,s,h,w,act2,f32", [(16, 32, 32, 3, 2, 40, 40, True, False),
+                                                             (64, 64, 64, 3, 1, 20, 24, False, True),
+                                                             (32, 64, 48, 1, 1, 13, 9, True, False)])
+def test_conv_with_fused_follow_up_1x1(gpu_device, cin, cmid, cout, k, s, h, w, act2, f32):
+    """conv -> SiLU -> (bf16) -> 1x1 conv in ONE launch (yl_op.post_*): the intermediate tensor only
+    exists in registers, rounded to bf16 exactly like a stored activation would be."""
+    g = torch.Generator().manual_seed(cin + cmid + cout)
+    x = _rand(g, 2, cin, h, w)
+    w1 = _rand(g, cmid, cin, k, k, scale=1.0 / math.sqrt(cin * k * k))
+    b1 = torch.randn(cmid, generator=g) * 0.5
+    w2 = _rand(g, cout, cmid, 1, 1, scale=1.0 / math.sqrt(cmid))
+    b2 = torch.randn(cout, generator=g) * 0.5
+    mid = bf16_round(F.silu(F.conv2d(x, w1, b1, s, k // 2)))
+    ref = F.conv2d(mid, w2, b2)
+    if act2:
+        ref = F.silu(ref)
+    m = Mini(2, gpu_device)
+    xin = m.buf(h, w, cin)
+    yo = m.buf(ref.shape[2], ref.shape[3], cout, F32 if f32 else BF16)
+    m.fill(xin, x)
+    m.op(kind=OP_CONV, name="t", k=k, stride=s, act=1, inp=xin, out=yo, weight=np.ascontiguousarray(w1.numpy()),
+         bias=np.ascontiguousarray(b1.numpy()), post_weight=np.ascontiguousarray(w2.numpy().reshape(cout, cmid)),
+         post_bias=np.ascontiguousarray(b2.numpy()), post_act=int(act2))
+    m.run()
+    got = m.read(yo)
+    # the intermediate's bf16 rounding can flip by one ulp (accumulation order): |w2| * 2^-8 * |mid| headroom
+    tol = 2.0 ** -7 * ref.abs() + 2.0 ** -7 * F.conv2d(mid.abs(), w2.abs()) + 1e-3
+    assert bool(((got - ref).abs() <= tol).all()), float(((got - ref).abs() - tol).max())
 
 
 def test_conv_stem_cin3(gpu_device):

@@ -39,7 +39,7 @@ def test_views_inside_workspace_and_aligned():
     p = _prog("n", 3, 96, 128)
     assert p.anchors == 12 * 16 + 6 * 8 + 3 * 4
     for o in p.ops:
-        for key in ("inp", "out", "res"):
+        for key in ("inp", "out", "res", "inp2"):
             v = o.get(key)
             if v is None:
                 continue
@@ -48,7 +48,12 @@ def test_views_inside_workspace_and_aligned():
             if v.dtype == 0:  # bf16 views are plane ranges: everything in units of 8 channels
                 assert v.C % 8 == 0 and v.pitch % 8 == 0 and v.coff % 8 == 0
     kinds = [o["kind"] for o in p.ops]
-    assert kinds.count(OP_SPPF_POOL) == 1 and kinds.count(OP_ATTENTION) == 1 and kinds.count(OP_UPSAMPLE) == 2
+    assert kinds.count(OP_SPPF_POOL) == 1 and kinds.count(OP_ATTENTION) == 1
+    # both nn.Upsample layers are read through by the 1x1 conv behind their Concat (yl_op.in2)
+    assert kinds.count(OP_UPSAMPLE) == 0 and sum("inp2" in o for o in p.ops) == 2
+    specs, _ = arch.parse_model(arch.yolo11_dict("n"))
+    q = lower(specs, synth_state_dict("n", 0), 3, 96, 128, fuse_post=False)
+    assert [o["kind"] for o in q.ops].count(OP_UPSAMPLE) == 2 and not any("inp2" in o or "post_weight" in o for o in q.ops)
 
 
 def test_plane_geometry_known_answers():

@@ -37,7 +37,8 @@ class Op(C.Structure):
                 ("inp", View), ("out", View), ("res", View),
                 ("weight", C.c_void_p), ("bias", C.c_void_p),
                 ("post_cin", C.c_int32), ("post_act", C.c_int32),
-                ("post_weight", C.c_void_p), ("post_bias", C.c_void_p)]
+                ("post_weight", C.c_void_p), ("post_bias", C.c_void_p),
+                ("inp2", View), ("up", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Level(C.Structure):
@@ -112,7 +113,7 @@ def lib() -> C.CDLL:
     L.yl_engine_detect_graph.argtypes = [vp, vp, i32, vp, f32, f32, i32, i32, vp, i32, i32, f32, vp, vp, vp, vp, vp]
     L.yl_preprocess_u8.restype = i32
     L.yl_preprocess_u8.argtypes = [vp, i32, i32, i32, vp, vp]
-    if L.yl_abi_version() != 2:
+    if L.yl_abi_version() != 3:
         raise RuntimeError("libyl_amd.so ABI version mismatch; rebuild it")
     _lib = L
     return L

@@ -56,11 +56,13 @@ constexpr unsigned OOB_K = 0x40000000u;
 template <int NT>
 struct Patch {
   unsigned base[NT];  // byte offset of the (stride-scaled) centre pixel in the lane's first input plane
+  unsigned base2[NT]; // UP only: the same for the low-resolution source (pixel (y/2, x/2))
   int opix[NT];       // output pixel: guarded plane index (bf16) or linear NHWC index (fp32); -1 = none
 };
 
-template <int NT>
-__device__ __forceinline__ void patch_setup(const ConvArgs& a, int patch, int n, unsigned lane_off, Patch<NT>& P) {
+template <int NT, bool UP = false>
+__device__ __forceinline__ void patch_setup(const ConvArgs& a, int patch, int n, unsigned lane_off, Patch<NT>& P,
+                                            unsigned lane_off2 = 0) {
   const int first = patch * (16 * NT);  // wave-uniform
   const int hw = a.Ho * a.Wo;
   const int b0 = first / hw;
@@ -81,6 +83,10 @@ __device__ __forceinline__ void patch_setup(const ConvArgs& a, int patch, int n,
     const int pi = a.in_g0 + b * a.in_img + oy * a.stride * a.in_w1 + ox * a.stride;
     const int po = a.out_f32 ? gp : a.out_g0 + b * a.out_img + oy * a.out_w1 + ox;
     P.base[nt] = valid ? (unsigned)pi * 16u + lane_off : OOB_LANE;
+    if (UP) {
+      const int pi2 = a.in2_g0 + b * a.in2_img + (oy >> 1) * a.in2_w1 + (ox >> 1);
+      P.base2[nt] = valid ? (unsigned)pi2 * 16u + lane_off2 : OOB_LANE;
+    }
     P.opix[nt] = valid ? po : -1;
   }
 }
@@ -96,9 +102,29 @@ __device__ __forceinline__ int tap_offset(const ConvArgs& a, int tap) {  // byte
 // inside one tap: tap, channel block and byte offset are scalars (the lane's k-group plane is already
 // in Patch::base) and the per-lane work is ONE add per load; otherwise (tap, channel group) are derived
 // per lane.  K-steps past the end (ring refills) resolve to the out-of-range offset and return zeros.
-template <int KS, int NT, bool UNIFORM>
+// UP (1x1 convs reading a Concat whose first channels are a nearest-upsampled low-resolution map,
+// yolo11.yaml:31-36): k-steps below ks_split read the low-resolution source itself at pixel (y/2, x/2),
+// so the 4x larger upsampled copy is never written or read.
+template <int KS, int NT, bool UNIFORM, bool UP = false>
 __device__ __forceinline__ void fetch_b(const ConvArgs& a, __amdgpu_buffer_rsrc_t rin, int ks, int g,
-                                        const Patch<NT>& P, bf16x8 (&xb)[NT]) {
+                                        const Patch<NT>& P, bf16x8 (&xb)[NT],
+                                        __amdgpu_buffer_rsrc_t rin2 = __amdgpu_buffer_rsrc_t()) {
+  if constexpr (UP) {
+    static_assert(!UP || (KS == 1 && UNIFORM), "UP is a 1x1, Cin % 32 == 0 feature");
+    if (ks < a.ks_split) {
+      const unsigned off2 = (unsigned)(ks * 4) * a.in2_plane;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        xb[nt] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rin2, P.base2[nt] + off2, 0, 0));
+      return;
+    }
+    ks -= a.ks_split;  // k-step within the full-resolution source
+    const unsigned off1 = ks < a.ksteps - a.ks_split ? (unsigned)(ks * 4) * a.in_plane : OOB_K;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      xb[nt] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rin, P.base[nt] + off1, 0, 0));
+    return;
+  }
   unsigned off;
   if (UNIFORM) {
     const int tap = fastdiv(ks, a.kkn, a.magic_kkn);
@@ -245,10 +271,11 @@ __device__ __forceinline__ void epilogue(const ConvArgs& a, __amdgpu_buffer_rsrc
 // out-of-range offsets (zeros, no memory access) and the filter prefetch is clamped, so the body is
 // straight-line code and the compiler keeps counted vmcnt waits (the ring really stays in flight).
 // kbeg must be a multiple of D.
-template <int KS, int MT, int NT, bool UNIFORM, int D>
+template <int KS, int MT, int NT, bool UNIFORM, int D, bool UP = false>
 __device__ __forceinline__ void run_ksteps(const ConvArgs& a, __amdgpu_buffer_rsrc_t rin, int g, const Patch<NT>& P,
                                            const bf16x8* wl, int kbeg, int nk, bf16x8 (&xr)[D][NT],
-                                           f32x4 (&acc)[MT][NT]) {
+                                           f32x4 (&acc)[MT][NT],
+                                           __amdgpu_buffer_rsrc_t rin2 = __amdgpu_buffer_rsrc_t()) {
   bf16x8 wv[2][MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) wv[0][mt] = wl[mt * 64];
@@ -262,7 +289,7 @@ __device__ __forceinline__ void run_ksteps(const ConvArgs& a, __amdgpu_buffer_rs
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) wv[(d + 1) & 1][mt] = wl[(in_ * MT + mt) * 64];
       mma_step<MT, NT>(wv[d & 1], xr[d], acc);
-      fetch_b<KS, NT, UNIFORM>(a, rin, kbeg + i + D, g, P, xr[d]);
+      fetch_b<KS, NT, UNIFORM, UP>(a, rin, kbeg + i + D, g, P, xr[d], rin2);
     }
   }
 #pragma unroll
@@ -281,7 +308,7 @@ __device__ __forceinline__ void run_ksteps(const ConvArgs& a, __amdgpu_buffer_rs
 // consumes ONLY this conv's output is applied in the epilogue.  After bias + SiLU + bf16 rounding the
 // accumulators of tile pair p ARE the B fragment of k-step p of that 1x1 conv (same channel permutation
 // that makes the stores 16 bytes wide), so the intermediate tensor is never written or read.
-template <int KS, int MT, int NT, bool UNIFORM, bool POST>
+template <int KS, int MT, int NT, bool UNIFORM, bool POST, bool UP = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -295,19 +322,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
       __builtin_amdgcn_make_buffer_rsrc(a.out, (short)0, (a.dbg & 2) ? 0 : a.out_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rres =
       __builtin_amdgcn_make_buffer_rsrc((void*)a.res, (short)0, a.res ? a.res_bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rin2 =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.in2, (short)0, UP ? a.in2_bytes : 0, 0x00020000);
   constexpr int D = NT >= 4 ? 2 : (NT == 2 ? 4 : 8);
   bf16x8 xr[D][NT];
   Patch<NT> P;
   const unsigned lane_off = UNIFORM ? (unsigned)g * a.in_plane : 0u;
+  const unsigned lane_off2 = UP ? (unsigned)g * a.in2_plane : 0u;
   // wave-uniform values are forced into SGPRs so the k-loop bookkeeping stays on the scalar unit
   int patch = __builtin_amdgcn_readfirstlane(pblk * a.ppw * 4 + wave);
   bool live = patch < a.npatches;
   // The first ring fill of a patch is issued BEFORE the filter slab is staged (first patch) or before
   // the previous patch's epilogue stores, so its latency is always covered.
   if (live) {
-    patch_setup<NT>(a, patch, n, lane_off, P);
+    patch_setup<NT, UP>(a, patch, n, lane_off, P, lane_off2);
 #pragma unroll
-    for (int d = 0; d < D; ++d) fetch_b<KS, NT, UNIFORM>(a, rin, d, g, P, xr[d]);
+    for (int d = 0; d < D; ++d) fetch_b<KS, NT, UNIFORM, UP>(a, rin, d, g, P, xr[d], rin2);
   }
   // per-lane bias of its 4 rows of every channel tile (the accumulators start from it)
   f32x4 bias_r[MT];
@@ -341,7 +371,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
         __syncthreads();
         first = false;
       }
-      if (live) run_ksteps<KS, MT, NT, UNIFORM, D>(a, rin, g, P, wl, kc, nk, xr, acc);
+      if (live) run_ksteps<KS, MT, NT, UNIFORM, D, UP>(a, rin, g, P, wl, kc, nk, xr, acc, rin2);
     }
     if (!live) break;
     // next patch: addresses + first ring fill go out before this patch's stores
@@ -351,9 +381,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     patch += 4;
     live = (pp + 1 < a.ppw) && patch < a.npatches;
     if (live) {
-      patch_setup<NT>(a, patch, n, lane_off, P);
+      patch_setup<NT, UP>(a, patch, n, lane_off, P, lane_off2);
 #pragma unroll
-      for (int d = 0; d < D; ++d) fetch_b<KS, NT, UNIFORM>(a, rin, d, g, P, xr[d]);
+      for (int d = 0; d < D; ++d) fetch_b<KS, NT, UNIFORM, UP>(a, rin, d, g, P, xr[d], rin2);
     }
     if constexpr (POST) {
       static_assert(!POST || (MT % 2 == 0), "POST needs an even tile count");
@@ -519,8 +549,29 @@ static int launch_p(const ConvConfig& cfg, const ConvArgs& a, hipStream_t s) {
   return 0;
 }
 
+template <int MT, int NT>
+static int launch_up(const ConvConfig& cfg, const ConvArgs& a, hipStream_t s) {
+  auto kern = conv_kernel<1, MT, NT, true, false, true>;
+  static size_t attr = 0;
+  if (cfg.lds_bytes > attr) {
+    YL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)LDS_MAX));
+    attr = LDS_MAX;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.nblocks), dim3(256), cfg.lds_bytes, s, a);
+  YL_HIP(hipGetLastError());
+  return 0;
+}
+
 template <int KS, int MT, int NT, bool U>
 static int launch_t(const ConvConfig& cfg, const ConvArgs& a, hipStream_t s) {
+  if (a.in2) {
+    if constexpr (KS == 1 && U) {
+      if (cfg.post) return fail(-3, "conv: upsampled second input and fused follow-up conv cannot be combined");
+      return launch_up<MT, NT>(cfg, a, s);
+    }
+    return fail(-3, "conv: an upsampled second input needs a 1x1 conv with Cin % 32 == 0");
+  }
   if constexpr (MT == 2 || MT == 4) {
     if (cfg.post) return launch_p<KS, MT, NT, U, true>(cfg, a, s);
   }
@@ -567,12 +618,17 @@ int conv_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s) {
   a.npix = batch * a.Ho * a.Wo;
   {
     const long long lim = 1LL << 30;
-    const long long inb = (long long)cfg.cg * a.in_plane;
+    const long long inb = (long long)(cfg.cg - (a.in2 ? a.ks_split * 4 : 0)) * a.in_plane;
     const int cout_out = a.wpk2 ? a.post_cout : a.Cout;  // channels of the tensor that is actually stored
     const long long outb = a.out_f32 ? (long long)a.npix * a.out_pitch * 4 : (long long)((cout_out + 7) / 8) * a.out_plane;
     const long long resb = a.res ? (long long)((cout_out + 7) / 8) * a.res_plane : 0;
     if (inb > lim || outb > lim || resb > lim)
       return fail(-3, "conv: a tensor slice exceeds 1 GiB (32-bit buffer offsets); lower the batch size");
+    if (a.in2) {
+      const long long in2b = (long long)(a.ks_split * 4) * a.in2_plane;
+      if (in2b > lim) return fail(-3, "conv: a tensor slice exceeds 1 GiB (32-bit buffer offsets); lower the batch size");
+      a.in2_bytes = (unsigned)in2b;
+    }
     a.in_bytes = (unsigned)inb;
     a.out_bytes = (unsigned)outb;
     a.res_bytes = (unsigned)resb;

@@ -181,13 +181,21 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
           if (o.res.H != Ho || o.res.W != Wo || o.res.C != o.out.C || o.res.dtype != YL_BF16)
             return fail(-1, tag + ": residual view mismatch");
         }
+        const bool up = o.in2.offset >= 0;
+        if (up) {
+          if (int rc = check_view(o.in2, batch, workspace_bytes, (tag + " in2").c_str())) return rc;
+          if (o.up != 2 || o.k != 1 || o.stride != 1 || o.in2.dtype != YL_BF16 || o.in2.H * 2 != o.in.H ||
+              o.in2.W * 2 != o.in.W || o.in2.C % 32 || o.in.C % 32 || o.cin_weight || o.post_weight)
+            return fail(-1, tag + ": upsampled second input needs a plain 1x1 conv, up == 2, channel counts % 32 == 0");
+        }
+        const int cin_total = o.in.C + (up ? o.in2.C : 0);
         // weight Cin may be smaller than the (padded) input view channels: stem 3 -> 8
-        const int cin_w = o.cin_weight > 0 ? o.cin_weight : o.in.C;
+        const int cin_w = o.cin_weight > 0 ? o.cin_weight : cin_total;
         const bool post = o.post_weight != nullptr;
         const int cout1 = post ? o.post_cin : o.out.C;  // channels the main GEMM produces
         if (post && (!o.post_bias || o.res.offset >= 0 || o.out.C > o.post_cin))
           return fail(-1, tag + ": fused follow-up conv needs a bias, no residual and out.C <= post_cin");
-        if (int rc = conv_choose(batch, o.in.C, cout1, o.k, o.stride, Ho, Wo, post, &r.cfg)) return rc;
+        if (int rc = conv_choose(batch, cin_total, cout1, o.k, o.stride, Ho, Wo, post, &r.cfg)) return rc;
         std::vector<uint16_t> pk;
         conv_pack_weights(o.weight, cout1, cin_w, o.k, r.cfg, &pk);
         if (post) {
@@ -213,7 +221,7 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
         for (int c = 0; c < cout1; ++c) bias[c] = o.bias[c];
         if (int rc = dev_upload(e.get(), bias, &r.d_bias)) return rc;
         r.flops = 2.0 * px_out * cout1 * cin_w * o.k * o.k + (post ? 2.0 * px_out * o.out.C * o.post_cin : 0.0);
-        r.bytes = px_in * o.in.C * 2 + px_out * o.out.C * view_elem_size(o.out) +
+        r.bytes = px_in * o.in.C * 2 + (up ? px_in / 4 * o.in2.C * 2 : 0.0) + px_out * o.out.C * view_elem_size(o.out) +
                   (o.res.offset >= 0 ? px_out * o.out.C * 2 : 0) + (double)cout1 * cin_w * o.k * o.k * 2;
         r.name = r.cfg.name;
         break;
@@ -317,6 +325,15 @@ static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s, c
         a.res = pview(ws, o.res, B).base;
         a.res_plane = (unsigned)plane_bytes(go);
       }
+      if (o.in2.offset >= 0) {
+        const Geo g2 = geo_of(B, o.in2.H, o.in2.W);
+        a.in2 = pview(ws, o.in2, B).base;
+        a.in2_plane = (unsigned)plane_bytes(g2);
+        a.in2_w1 = g2.W1;
+        a.in2_img = g2.img;
+        a.in2_g0 = g2.g0;
+        a.ks_split = o.in2.C / 32;
+      }
       a.wpk = r.d_wpk;
       a.bias = r.d_bias;
       a.wpk2 = r.d_wpk2;
@@ -325,7 +342,7 @@ static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s, c
       a.post_act = o.post_act;
       a.Ho = o.out.H;
       a.Wo = o.out.W;
-      a.Cin = o.in.C;
+      a.Cin = o.in.C + (o.in2.offset >= 0 ? o.in2.C : 0);
       a.Cout = r.d_wpk2 ? o.post_cin : o.out.C;
       a.stride = o.stride;
       a.act = o.act;

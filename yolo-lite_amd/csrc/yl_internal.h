@@ -67,6 +67,9 @@ struct ConvArgs {
   const __bf16* in;    // first plane of the input slice
   void* out;           // bf16: first plane of the output slice; fp32: NHWC buffer base
   const __bf16* res;   // first plane of the residual slice, nullptr: none
+  const __bf16* in2;   // 1x1 only: low-resolution source of the first ks_split*32 input channels (nearest x2), or nullptr
+  unsigned in2_plane, in2_bytes;
+  int in2_w1, in2_img, in2_g0, ks_split;
   const __bf16* wpk;   // [cb][kstep][MT][64 lanes][8]
   const __bf16* wpk2;  // fused follow-up 1x1: [MT/2 k-steps][MT][64 lanes][8], nullptr: none
   const float* bias2;  // its bias, padded to MT*16

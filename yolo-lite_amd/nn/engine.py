@@ -52,6 +52,7 @@ class HipEngine:
             c.cin_weight = o.get("cin_weight", 0)
             c.lane = o.get("lane", 0)
             c.inp, c.out, c.res = _cview(o["inp"]), _cview(o["out"]), _cview(o.get("res"))
+            c.inp2, c.up = _cview(o.get("inp2")), int(o.get("up", 0))
             if "weight" in o:
                 w = np.ascontiguousarray(o["weight"], dtype=np.float32)
                 b = np.ascontiguousarray(o["bias"], dtype=np.float32)

@@ -139,6 +139,44 @@ def fuse_follow_up_convs(ops: List[dict]) -> List[dict]:
     return [o for i, o in enumerate(ops) if i not in drop]
 
 
+def fuse_upsample_into_convs(ops: List[dict]) -> List[dict]:
+    """nn.Upsample(2, nearest) -> Concat -> 1x1 conv (yolo11.yaml:31-36): when that conv is the only
+    reader of the upsampled planes, it reads the low-resolution map itself at pixel (y/2, x/2)
+    (``yl_op.in2``); the 4x larger copy is never written or read and the upsample launch disappears."""
+
+    def planes(v: TView):
+        return {(v.offset, p) for p in range(v.coff // 8, (v.coff + v.C) // 8)}
+
+    drop = set()
+    for i, u in enumerate(ops):
+        if u["kind"] != OP_UPSAMPLE or u.get("stride") != 2 or u.get("lane", 0):
+            continue
+        s_out = u["out"]
+        up_planes = planes(s_out)
+        rd = []
+        for j, o in enumerate(ops):
+            for k in ("inp", "res", "inp2"):
+                v = o.get(k)
+                if v is not None and v.dtype == BF16 and planes(v) & up_planes:
+                    rd.append(j)
+            if o.get("accumulate") and planes(o["out"]) & up_planes:
+                rd.append(j)
+        if len(rd) != 1:
+            continue
+        r = ops[rd[0]]
+        v = r["inp"]
+        if (r["kind"] != OP_CONV or r.get("k") != 1 or r.get("stride", 1) != 1 or "post_weight" in r or "inp2" in r
+                or r.get("cin_weight", 0) or r.get("lane", 0) or v.offset != s_out.offset or v.coff != s_out.coff
+                or v.C <= s_out.C or s_out.C % 32 or (v.C - s_out.C) % 32):
+            continue
+        r["inp2"] = u["inp"]
+        r["up"] = 2
+        r["inp"] = TView(v.offset, v.H, v.W, v.C - s_out.C, v.pitch, v.coff + s_out.C, v.dtype)
+        r["fused_upsample"] = u.get("name", "")
+        drop.add(i)
+    return [o for i, o in enumerate(ops) if i not in drop]
+
+
 def fold_conv_bn(sd: Dict[str, torch.Tensor], name: str, bn: bool = True) -> Tuple[np.ndarray, np.ndarray]:
     """BN-folded fp32 (weight OIHW, bias) of the Conv unit ``name`` (torch_utils.py:182-209)."""
     if bn:
@@ -381,6 +419,8 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
     ops.extend(deferred)
     if fuse_post and os.environ.get("YL_FUSE_POST", "1") != "0":
         ops[:] = fuse_follow_up_convs(ops)
+    if fuse_post and os.environ.get("YL_FUSE_UP", "1") != "0":
+        ops[:] = fuse_upsample_into_convs(ops)
     a_total = 0
     for lvl in range(len(det.f)):
         prog.levels.append(level_rec[lvl])
