@@ -110,6 +110,24 @@ def test_conv_with_fused_follow_up_1x1(gpu_device, cin, cmid, cout, k, s, h, w, 
     assert bool(((got - ref).abs() <= tol).all()), float(((got - ref).abs() - tol).max())
 
 
+def test_conv_reads_through_upsample_concat(gpu_device):
+    """1x1 conv over cat(upsample(lo), skip): the conv reads `lo` itself (yl_op.in2); bit-identical to the
+    conv over a materialised concat buffer."""
+    g = torch.Generator().manual_seed(99)
+    lo, skip = _rand(g, 2, 64, 5, 7), _rand(g, 2, 32, 10, 14)
+    wt = _rand(g, 48, 96, 1, 1, scale=0.1)
+    b = torch.randn(48, generator=g) * 0.3
+    ref = F.silu(F.conv2d(torch.cat([F.interpolate(lo, scale_factor=2.0), skip], 1), wt, b))
+    m = Mini(2, gpu_device)
+    vlo, cat, out = m.buf(5, 7, 64), m.buf(10, 14, 96), m.buf(10, 14, 48)
+    m.fill(vlo, lo)
+    m.fill(cat.slice(64, 32), skip)
+    m.op(kind=OP_CONV, name="t", k=1, stride=1, act=1, inp=cat.slice(64, 32), inp2=vlo, up=2, out=out,
+         weight=np.ascontiguousarray(wt.numpy()), bias=np.ascontiguousarray(b.numpy()))
+    m.run()
+    _assert_close_bf16(m.read(out), ref, "conv over upsample+concat")
+
+
 def test_conv_stem_cin3(gpu_device):
     g = torch.Generator().manual_seed(8)
     x3 = bf16_round(torch.rand(2, 3, 64, 64, generator=g))
