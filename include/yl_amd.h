@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define YL_ABI_VERSION 3
+#define YL_ABI_VERSION 4
 
 /* element types */
 enum { YL_BF16 = 0, YL_F32 = 1, YL_F16 = 2, YL_U8 = 3 };
@@ -33,12 +33,12 @@ enum {
   YL_OP_UPSAMPLE = 4, /* nearest upsample by `stride` (1 = plain copy) into a channel slice        */
   YL_OP_ATTENTION = 5,/* softmax(q^T k * scale) applied to v, per head (C2PSA)                     */
   YL_OP_STEM = 6      /* first layer fused with the input conversion: 3x3 stride-2 conv on the 3-channel
-                         NCHW network input (fp32 / fp16 / uint8, /255 for uint8) -> NHWC bf16; must be
+                         NCHW network input (fp32 / fp16 / uint8, /255 for uint8) -> bf16 planes; must be
                          op 0; weight [Cout][3][3][3]                                              */
 };
 
 /* A channel-slice view of a buffer inside the workspace arena.
- *   YL_F32  : NHWC, buffer[B][H][W][pitch] (the Detect level maps).
+ *   YL_F32  : NHWC, buffer[B][H][W][pitch] (conv output option; not used by the YOLO11 lowering).
  *   YL_BF16 : "C8-planar, guarded": buffer[pitch / 8][plane_px][8] -- one plane per 8 channels, and
  *             inside a plane the whole batch as one array of rows, every row followed by one zero
  *             guard pixel, every image by one zero guard row (plus one guard row in front):
@@ -98,14 +98,16 @@ typedef struct yl_op {
   int32_t up, reserved;
 } yl_op;
 
-/* Detect-level raw map (reference head.py:64-65 torch.cat(cv2, cv3)), fp32, stored as two NHWC blocks
- * back to back: box logits [B][H][W][64] at `offset`, class logits [B][H][W][nc] right behind them
- * (the NMS front end streams only the class block and touches box rows of surviving anchors). */
+/* Detect-level raw maps (reference head.py:64-65 torch.cat(cv2, cv3)): two bf16 buffers in the planar
+ * guarded activation layout (see yl_view) -- the 64 DFL logits at `offset` (8 planes) and the class
+ * logits at `offset_cls` (nc8 / 8 planes; nc8 = nc rounded up to a multiple of 8, the padding channels
+ * hold large negative logits).  Decode and NMS read them as fp32 (bf16 -> fp32 is exact). */
 typedef struct yl_level {
   int64_t offset;
+  int64_t offset_cls;
   int32_t H, W;
   float stride;
-  int32_t reserved;
+  int32_t nc8;
 } yl_level;
 
 typedef struct yl_engine yl_engine;
@@ -130,7 +132,7 @@ void yl_engine_destroy(yl_engine* e);
 int yl_engine_prepare_workspace(yl_engine* e, void* workspace, void* stream);
 
 /* Network forward: input NCHW (YL_F32 / YL_F16 in [0,1], or YL_U8 in [0,255] which is divided by
- * 255 as engine/predictor.py:82-84 does) -> raw level maps in the workspace -> y[B][4+nc][A] fp32
+ * 255 as engine/predictor.py:82-84 does) -> raw level maps in the workspace (bf16) -> y[B][4+nc][A] fp32
  * decoded as nn/modules/head.py:95-126 (+ block.py:51-69 DFL, utils/tal.py:326-350).
  * y may be NULL (raw maps only).  Enqueues on `stream`; no host sync. */
 int yl_engine_forward(yl_engine* e, const void* input, int in_dtype, void* workspace, float* y,

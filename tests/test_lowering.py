@@ -77,9 +77,8 @@ def test_buffers_never_overlap(scale):
             v = o.get(key)
             if v is not None:
                 spans[v.offset] = max(spans.get(v.offset, 0), view_bytes(p.batch, v))
-    for L in p.levels:  # a level map = box block + class block, back to back
-        px = p.batch * L["H"] * L["W"]
-        assert spans[L["offset"]] == px * 64 * 4 and spans[L["offset"] + px * 256] == px * p.nc * 4
+    for L in p.levels:  # a level = two ordinary planar buffers: 64 box logits, nc8 class logits
+        assert L["offset"] in spans and L["offset_cls"] in spans and L["nc8"] % 8 == 0 and L["nc8"] >= p.nc
     t = sorted(spans.items())
     for (o1, s1), (o2, _) in zip(t, t[1:]):
         assert o1 + s1 <= o2

@@ -7,6 +7,7 @@ set -u
 TAG=${1:-r01}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
+rm -rf $OUT
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py --steps 50 --warmup 10 --profile-out $OUT/per_op.json > $OUT/bench.json 2> $OUT/bench.err

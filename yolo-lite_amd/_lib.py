@@ -42,8 +42,8 @@ class Op(C.Structure):
 
 
 class Level(C.Structure):
-    _fields_ = [("offset", C.c_int64), ("H", C.c_int32), ("W", C.c_int32), ("stride", C.c_float),
-                ("reserved", C.c_int32)]
+    _fields_ = [("offset", C.c_int64), ("offset_cls", C.c_int64), ("H", C.c_int32), ("W", C.c_int32),
+                ("stride", C.c_float), ("nc8", C.c_int32)]
 
 
 _lib = None
@@ -113,7 +113,7 @@ def lib() -> C.CDLL:
     L.yl_engine_detect_graph.argtypes = [vp, vp, i32, vp, f32, f32, i32, i32, vp, i32, i32, f32, vp, vp, vp, vp, vp]
     L.yl_preprocess_u8.restype = i32
     L.yl_preprocess_u8.argtypes = [vp, i32, i32, i32, vp, vp]
-    if L.yl_abi_version() != 3:
+    if L.yl_abi_version() != 4:
         raise RuntimeError("libyl_amd.so ABI version mismatch; rebuild it")
     _lib = L
     return L

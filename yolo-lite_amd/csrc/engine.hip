@@ -154,8 +154,11 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
   int a0 = 0;
   for (int i = 0; i < n_levels; ++i) {
     const yl_level& L = levels[i];
-    const int64_t end = L.offset + (int64_t)batch * L.H * L.W * (64 + nc) * 4;
-    if (L.offset < 0 || L.offset % 16 || end > workspace_bytes) return fail(-1, "level view exceeds the workspace");
+    const int64_t pb = plane_bytes(geo_of(batch, L.H, L.W));
+    if (L.nc8 < nc || L.nc8 % 8) return fail(-1, "level nc8 must be nc rounded up to a multiple of 8");
+    if (L.offset < 0 || L.offset % 16 || L.offset + 8 * pb > workspace_bytes || L.offset_cls < 0 || L.offset_cls % 16 ||
+        L.offset_cls + (L.nc8 / 8) * pb > workspace_bytes)
+      return fail(-1, "level view exceeds the workspace");
     e->levels.push_back(L);
     a0 += L.H * L.W;
   }

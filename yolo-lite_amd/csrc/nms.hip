@@ -419,45 +419,41 @@ extern "C" int yl_nms(const float* pred, int batch, int nc, int anchors, float c
 // ---------------------------------------------------------------- fused Detect decode + candidates
 // Same arithmetic as decode_kernel (shared device functions), but instead of materialising
 // y[B][4+nc][A] (reference head.py:126, 90 MB at batch 32) only the anchors whose best class score
-// clears the threshold are kept: key + class + (cx, cy, w, h).  One workgroup = 64 anchors.
+// clears the threshold are kept: key + class + (cx, cy, w, h).
 namespace yl {
-constexpr int DC_ANCH = 64;
 struct DecCandArgs {
   DecodeLevel lv[8];
-  int blk0[9];
   int n_levels, batch, nc, A;
   float conf_thres;
-  float logit_lo;  // sparse kernel: anchors whose best LOGIT is below this cannot clear conf_thres
+  float logit_lo;  // sparse path: anchors whose best LOGIT is below this cannot clear conf_thres
   const int32_t* classes;
   int n_classes;
 };
 
-struct DcBlock {
+struct DcAnchor {
   DecodeLevel L;
-  int b, p0, nv, HW;
+  int b, p, px, py, pix;  // level-local anchor index, its coordinates, guarded pixel index
 };
-__device__ __forceinline__ DcBlock dc_block(const DecCandArgs& a) {
-  DcBlock d;
-  const int nb_img = a.blk0[a.n_levels];
-  d.b = blockIdx.x / nb_img;
-  const int k = blockIdx.x - d.b * nb_img;
+__device__ __forceinline__ DcAnchor dc_anchor(const DecCandArgs& a, int b, int an) {
+  DcAnchor d;
   int l = 0;
 #pragma unroll
   for (int i = 1; i < 8; ++i)
-    if (i < a.n_levels && k >= a.blk0[i]) l = i;
+    if (i < a.n_levels && an >= a.lv[i].a0) l = i;
   d.L = a.lv[l];
-  d.HW = d.L.H * d.L.W;
-  d.p0 = (k - a.blk0[l]) * DC_ANCH;
-  d.nv = min(DC_ANCH, d.HW - d.p0);
+  d.b = b;
+  d.p = an - d.L.a0;
+  d.py = d.p / d.L.W;
+  d.px = d.p - d.py * d.L.W;
+  d.pix = d.L.box.g0 + b * d.L.box.img + d.py * d.L.box.W1 + d.px;
   return d;
 }
 
-// the reference's candidate test and bookkeeping for one anchor (ops.py:203,243-248)
+// the reference's candidate test and bookkeeping for one anchor (ops.py:203,243-248).
 // key_slot < 0: append with an atomic (dense kernel); else the key goes to that slot of keys[b][] and a
 // rejected anchor leaves the sentinel ~0 there (sparse path: no atomics).
-__device__ __forceinline__ void dc_emit(const DecCandArgs& a, const NmsWs& w, const DcBlock& d, int an_local,
-                                        float best, int bi, float dl, float dt, float dr, float db,
-                                        int key_slot = -1) {
+__device__ __forceinline__ void dc_emit(const DecCandArgs& a, const NmsWs& w, const DcAnchor& d, float best, int bi,
+                                        float dl, float dt, float dr, float db, int key_slot = -1) {
   bool keep = best > a.conf_thres;
   if (keep && a.classes) {
     bool ok = false;
@@ -468,88 +464,78 @@ __device__ __forceinline__ void dc_emit(const DecCandArgs& a, const NmsWs& w, co
     if (key_slot >= 0) w.keys[(long long)d.b * w.KP + key_slot] = ~0ull;
     return;
   }
-  const int p = d.p0 + an_local, an = d.L.a0 + p;
-  const float ax = (float)(p % d.L.W) + 0.5f, ay = (float)(p / d.L.W) + 0.5f;
-  const float4 bx = box_xywh(ax, ay, dl, dt, dr, db, d.L.stride);
+  const int an = d.L.a0 + d.p;
+  const float4 bx = box_xywh((float)d.px + 0.5f, (float)d.py + 0.5f, dl, dt, dr, db, d.L.stride);
   const int slot = key_slot >= 0 ? key_slot : atomicAdd(&w.count[d.b], 1);
   w.keys[(long long)d.b * w.KP + slot] = ((unsigned long long)(~__float_as_uint(best)) << 32) | (unsigned)an;
   w.cls_of[(long long)d.b * a.A + an] = bi;
   w.cbox[(long long)d.b * a.A + an] = bx;
 }
 
-// Dense variant (low thresholds, e.g. validation at conf 0.001): every anchor is decoded.
+// Dense variant (low thresholds, e.g. validation at conf 0.001): every anchor is decoded, one thread each.
 __global__ __launch_bounds__(256) void decode_candidates_dense_kernel(DecCandArgs a, NmsWs w) {
-  extern __shared__ __attribute__((aligned(16))) float sraw[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const DcBlock d = dc_block(a);
-  const int no = 64 + a.nc, pitch = no + 1;
-  float* sdist = sraw + DC_ANCH * pitch;       // [4][64]
-  float* sbest = sdist + 4 * DC_ANCH;          // [4][64] best score per wave
-  int* sbidx = reinterpret_cast<int*>(sbest + 4 * DC_ANCH);  // [4][64]
-  stage_rows(sraw, pitch, 0, d.L.box + ((long long)d.b * d.HW + d.p0) * 64, 64, d.nv, tid);
-  stage_rows(sraw, pitch, 64, d.L.cls + ((long long)d.b * d.HW + d.p0) * a.nc, a.nc, d.nv, tid);
-  __syncthreads();
-  float dist = 0.f;
-  if (lane < d.nv) dist = dfl_expect(sraw + lane * pitch + wave * 16);
-  sdist[wave * DC_ANCH + lane] = dist;
-  // best class among c = wave, wave + 4, ...: strict '>' keeps the first maximum (ops.py:243)
+  const int an = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (an >= a.A) return;
+  const DcAnchor d = dc_anchor(a, b, an);
+  // best class: strict '>' in increasing c keeps the first maximum (ops.py:243)
   float best = -1.f;
   int bi = 0x7fffffff;
-  if (lane < d.nv)
-    for (int c = wave; c < a.nc; c += 4) {
-      const float sc = sigmoid_score(sraw[lane * pitch + 64 + c]);
-      if (sc > best) {
-        best = sc;
-        bi = c;
-      }
-    }
-  sbest[wave * DC_ANCH + lane] = best;
-  sbidx[wave * DC_ANCH + lane] = bi;
-  __syncthreads();
-  if (wave == 0 && lane < d.nv) {
+  for (int c8 = 0; c8 * 8 < a.nc; ++c8) {
+    float v[8];
+    level_load8(d.L.cls, c8, d.pix, v);
 #pragma unroll
-    for (int q = 1; q < 4; ++q) {
-      const float s2 = sbest[q * DC_ANCH + lane];
-      const int i2 = sbidx[q * DC_ANCH + lane];
-      if (s2 > best || (s2 == best && i2 < bi)) {
-        best = s2;
-        bi = i2;
+    for (int j = 0; j < 8; ++j) {
+      const float sc = sigmoid_score(v[j]);
+      if (c8 * 8 + j < a.nc && sc > best) {
+        best = sc;
+        bi = c8 * 8 + j;
       }
     }
-    dc_emit(a, w, d, lane, best, bi, sdist[lane], sdist[DC_ANCH + lane], sdist[2 * DC_ANCH + lane],
-            sdist[3 * DC_ANCH + lane]);
   }
+  if (!(best > a.conf_thres)) return;
+  float dist[4];
+#pragma unroll
+  for (int side = 0; side < 4; ++side) {
+    float v[16], lo[8], hi[8];
+    level_load8(d.L.box, 2 * side, d.pix, lo);
+    level_load8(d.L.box, 2 * side + 1, d.pix, hi);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      v[j] = lo[j];
+      v[8 + j] = hi[j];
+    }
+    dist[side] = dfl_expect(v);
+  }
+  dc_emit(a, w, d, best, bi, dist[0], dist[1], dist[2], dist[3]);
 }
 
-// Sparse variant (the usual case: ~1-2 % of the anchors clear conf 0.25).  Only the class block is
-// streamed (nc of 64+nc floats per anchor); the best LOGIT of every anchor is a pre-filter with a safety
-// margin, and the exact reference arithmetic -- 80 sigmoids, first-max class, DFL of the 64 box logits
-// read straight from global memory -- runs for the few survivors only (decode_exact_kernel).  Identical results to the dense kernel: the pre-filter only drops
-// anchors whose best score is far below the threshold, everything kept is recomputed exactly.
-__global__ __launch_bounds__(256) void decode_candidates_sparse_kernel(DecCandArgs a, NmsWs w) {
-  extern __shared__ __attribute__((aligned(16))) float scls[];  // [64][nc + 1]
-  __shared__ float smax[4][DC_ANCH];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const DcBlock d = dc_block(a);
-  const int pitch = a.nc + 1;
-  stage_rows(scls, pitch, 0, d.L.cls + ((long long)d.b * d.HW + d.p0) * a.nc, a.nc, d.nv, tid);
-  __syncthreads();
+// Sparse variant (the usual case: ~1-2 % of the anchors clear conf 0.25), two kernels.
+// 1. pre-filter: only the class planes are streamed (one thread per anchor, nc8/8 sixteen-byte loads,
+//    coalesced per plane); anchors whose best LOGIT could clear the threshold (safety margin, see the
+//    host code) are appended to one of NSUB per-image lists.
+__global__ __launch_bounds__(256) void decode_candidates_sparse_kernel(DecCandArgs a, NmsWs w, int nc8) {
+  const int an = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (an >= a.A) return;
+  const DcAnchor d = dc_anchor(a, b, an);
   float m = -__builtin_huge_valf();
-  if (lane < d.nv)
-    for (int c = wave; c < a.nc; c += 4) m = fmaxf(m, scls[lane * pitch + c]);
-  smax[wave][lane] = m;
-  __syncthreads();
-  m = fmaxf(fmaxf(smax[0][lane], smax[1][lane]), fmaxf(smax[2][lane], smax[3][lane]));
-  // survivors go to a per-image list; decode_exact_kernel deals them out evenly (object-rich image
-  // regions would otherwise serialise inside the few workgroups that own them)
-  if (wave == 0 && lane < d.nv && m > a.logit_lo) {
-    const int sub = d.b * NSUB + (blockIdx.x & (NSUB - 1));
+  for (int c8 = 0; c8 < nc8 / 8; ++c8) {
+    float v[8];
+    level_load8(d.L.cls, c8, d.pix, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m = fmaxf(m, v[j]);
+  }
+  if (m > a.logit_lo) {
+    const int sub = b * NSUB + ((an >> 6) & (NSUB - 1));
     const int slot = atomicAdd(&w.pre_count[sub], 1);
-    w.pre_list[(long long)sub * w.sub_cap + slot] = d.L.a0 + d.p0 + lane;
+    w.pre_list[(long long)sub * w.sub_cap + slot] = an;
   }
 }
 
-// One wavefront per surviving anchor: 64 lanes = its 64 box logits = classes lane, lane + 64, ...
+// 2. exact decode of the survivors, one wavefront per anchor: the reference arithmetic -- nc sigmoids,
+//    first-max class, DFL of the 64 box logits (exponentials in parallel, sums in the reference's
+//    sequential order) -- so the results are identical to the dense kernel's.
 constexpr int DX_BLOCKS = 4;  // workgroups per sub-list (4 waves each)
 __global__ __launch_bounds__(256) void decode_exact_kernel(DecCandArgs a, NmsWs w) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -557,19 +543,9 @@ __global__ __launch_bounds__(256) void decode_exact_kernel(DecCandArgs a, NmsWs 
   const int n = w.pre_count[b * NSUB + sub];
   for (int j = blockIdx.x * 4 + wave; j < n; j += DX_BLOCKS * 4) {
     const int an = w.pre_list[(long long)(b * NSUB + sub) * w.sub_cap + j];
-    int l = 0;
-#pragma unroll
-    for (int i = 1; i < 8; ++i)
-      if (i < a.n_levels && an >= a.lv[i].a0) l = i;
-    DcBlock d;
-    d.L = a.lv[l];
-    d.b = b;
-    d.HW = d.L.H * d.L.W;
-    d.p0 = an - d.L.a0;
-    d.nv = 1;
-    const long long row = (long long)b * d.HW + d.p0;
-    // DFL (block.py:66-69): exponentials in parallel, sums in the reference's sequential order
-    const float v = d.L.box[row * 64 + lane];
+    const DcAnchor d = dc_anchor(a, b, an);
+    // lane = box channel lane: plane lane >> 3, element lane & 7
+    const float v = (float)d.L.box.base[(long long)(lane >> 3) * d.L.box.plane + (long long)d.pix * 8 + (lane & 7)];
     float mx = v;
 #pragma unroll
     for (int off = 8; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
@@ -578,7 +554,8 @@ __global__ __launch_bounds__(256) void decode_exact_kernel(DecCandArgs a, NmsWs 
     float best = -1.f;
     int bi = 0x7fffffff;
     for (int c = lane; c < a.nc; c += 64) {
-      const float sc = sigmoid_score(d.L.cls[row * a.nc + c]);
+      const float lg = (float)d.L.cls.base[(long long)(c >> 3) * d.L.cls.plane + (long long)d.pix * 8 + (c & 7)];
+      const float sc = sigmoid_score(lg);
       if (sc > best) {
         best = sc;
         bi = c;
@@ -602,7 +579,7 @@ __global__ __launch_bounds__(256) void decode_exact_kernel(DecCandArgs a, NmsWs 
     }
     const float dist = ws / sum;
     const float dl = __shfl(dist, 0), dt = __shfl(dist, 16), dr = __shfl(dist, 32), db = __shfl(dist, 48);
-    if (lane == 0) dc_emit(a, w, d, 0, best, bi, dl, dt, dr, db, sub * w.sub_cap + j);
+    if (lane == 0) dc_emit(a, w, d, best, bi, dl, dt, dr, db, sub * w.sub_cap + j);
   }
 }
 }  // namespace yl
@@ -617,18 +594,16 @@ extern "C" int yl_decode_nms(const void* workspace, const yl_level* levels, int 
   if (!(conf_thres >= 0.f && conf_thres <= 1.f) || !(iou_thres >= 0.f && iou_thres <= 1.f))
     return fail(-4, "yl_decode_nms: thresholds must lie in [0, 1]");
   DecCandArgs a;
-  int nb = 0, A = 0;
+  int A = 0;
   for (int i = 0; i < n_levels; ++i) {
+    if (levels[i].nc8 < nc || levels[i].nc8 % 8) return fail(-1, "yl_decode_nms: level nc8 must be nc rounded up to 8");
     a.lv[i] = decode_level(workspace, levels[i], batch, A);
-    a.blk0[i] = nb;
-    nb += (levels[i].H * levels[i].W + DC_ANCH - 1) / DC_ANCH;
     A += levels[i].H * levels[i].W;
   }
   for (int i = n_levels; i < 8; ++i) {
-    a.lv[i] = DecodeLevel{nullptr, nullptr, 0, 0, 1 << 30, 0.f};
-    a.blk0[i] = 1 << 30;
+    a.lv[i] = a.lv[0];
+    a.lv[i].a0 = 1 << 30;
   }
-  a.blk0[n_levels] = nb;
   a.n_levels = n_levels;
   a.batch = batch;
   a.nc = nc;
@@ -639,29 +614,21 @@ extern "C" int yl_decode_nms(const void* workspace, const yl_level* levels, int 
   NmsWs w;
   nms_layout(batch, A, max_cand, (char*)work, &w);
   if (w.M > 64 * 64 * SCAN_T) return fail(-3, "yl_decode_nms: max_cand above 32768 is not supported");
-  // Sparse kernel unless the threshold keeps a large share of the anchors (validation at conf 0.001).
+  // Sparse path unless the threshold keeps a large share of the anchors (validation at conf 0.001).
   // logit(conf) - 0.05: the exact test `1 / (1 + expf(-x)) > conf` cannot pass below it.
   const bool sparse = conf_thres >= 0.05f;
   a.logit_lo = conf_thres >= 1.f ? __builtin_huge_valf()
                                  : (float)(std::log((double)conf_thres / (1.0 - (double)conf_thres)) - 0.05);
-  const size_t lds = sparse ? (size_t)DC_ANCH * (nc + 1) * sizeof(float)
-                            : ((size_t)DC_ANCH * (64 + nc + 1) + 12 * DC_ANCH) * sizeof(float);
-  if (lds > 150 * 1024) return fail(-3, "yl_decode_nms: nc too large");
-  static size_t attr[2] = {48 * 1024, 48 * 1024};  // dynamic LDS enabled so far (dense, sparse)
-  if (lds > attr[sparse]) {
-    YL_HIP(hipFuncSetAttribute(sparse ? reinterpret_cast<const void*>(decode_candidates_sparse_kernel)
-                                      : reinterpret_cast<const void*>(decode_candidates_dense_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr[sparse] = lds;
-  }
   hipStream_t s = (hipStream_t)stream;
   YL_HIP(hipMemsetAsync(w.count, 0, 4 * (size_t)batch * (1 + NSUB), s));  // count + pre_count
+  const dim3 grid((unsigned)((A + 255) / 256), batch);
   if (sparse) {
     w.fused = 1;
-    hipLaunchKernelGGL(decode_candidates_sparse_kernel, dim3(batch * nb), dim3(256), lds, s, a, w);
+    hipLaunchKernelGGL(decode_candidates_sparse_kernel, grid, dim3(256), 0, s, a, w, levels[0].nc8);
     hipLaunchKernelGGL(decode_exact_kernel, dim3(DX_BLOCKS, NSUB, batch), dim3(256), 0, s, a, w);
-  } else
-    hipLaunchKernelGGL(decode_candidates_dense_kernel, dim3(batch * nb), dim3(256), lds, s, a, w);
+  } else {
+    hipLaunchKernelGGL(decode_candidates_dense_kernel, grid, dim3(256), 0, s, a, w);
+  }
   hipLaunchKernelGGL(nms_sort_kernel, dim3(batch), dim3(1024), 0, s, (const float*)nullptr, nc, A, agnostic, max_wh, w);
   hipLaunchKernelGGL(nms_mask_kernel, dim3(64, batch), dim3(256), 0, s, iou_thres, w);
   hipLaunchKernelGGL(nms_scan_kernel, dim3(batch), dim3(64), 0, s, max_det, scale, out, out_count, w);

@@ -659,89 +659,70 @@ int attention_launch(const AttnArgs& a, hipStream_t s) {
 // ---------------------------------------------------------------------------- Detect decode
 // nn/modules/head.py:95-126 (_inference): DFL (block.py:66-69: softmax over 16 bins, expectation),
 // dist2bbox xywh (utils/tal.py:341-350) on anchors (x+0.5, y+0.5) (tal.py:326-338), times stride,
-// and sigmoid of the class logits.  fp32 in, fp32 out: y[B][4+nc][A].
+// and sigmoid of the class logits.  Level maps are bf16 planes (yl_level); arithmetic and output are
+// fp32: y[B][4+nc][A].  One thread = one anchor: its logits are 8 + nc8/8 sixteen-byte pixels, lanes of
+// a wave read neighbouring pixels of one plane and write neighbouring columns of one row of y.
 constexpr int MAX_LEVELS = 8;
-constexpr int DEC_ANCH = 64;  // anchors per workgroup
-
 struct DecodeArgs {
   DecodeLevel lv[MAX_LEVELS];
-  int blk0[MAX_LEVELS + 1];  // first block of each level inside one image
   int n_levels, batch, nc, A;
   float* y;
 };
 
-// One workgroup = 64 consecutive anchors of one level of one image.  Their box rows (64 x 64 floats)
-// and class rows (64 x nc floats) are two contiguous runs: staged through LDS with coalesced loads
-// (row pitch 64+nc+1 words -> conflict-free column reads), then every output row of y is written as
-// 256-byte runs.
 __global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float sraw[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int nb_img = a.blk0[a.n_levels];
-  const int b = blockIdx.x / nb_img;
-  const int k = blockIdx.x - b * nb_img;
+  const int an = blockIdx.x * 256 + threadIdx.x;  // anchor inside the image
+  const int b = blockIdx.y;
+  if (an >= a.A) return;
   int l = 0;
 #pragma unroll
   for (int i = 1; i < MAX_LEVELS; ++i)
-    if (i < a.n_levels && k >= a.blk0[i]) l = i;
+    if (i < a.n_levels && an >= a.lv[i].a0) l = i;
   const DecodeLevel L = a.lv[l];
-  const int HW = L.H * L.W;
-  const int p0 = (k - a.blk0[l]) * DEC_ANCH;
-  const int nv = min(DEC_ANCH, HW - p0);
-  const int no = 64 + a.nc, pitch = no + 1;
-  float* sdist = sraw + DEC_ANCH * pitch;  // [4][64]
-  stage_rows(sraw, pitch, 0, L.box + ((long long)b * HW + p0) * 64, 64, nv, tid);
-  stage_rows(sraw, pitch, 64, L.cls + ((long long)b * HW + p0) * a.nc, a.nc, nv, tid);
-  __syncthreads();
-  // DFL: thread = (anchor, side)
-  {
-    const int an = lane, side = wave;
-    float dist = 0.f;
-    if (an < nv) dist = dfl_expect(sraw + an * pitch + side * 16);
-    sdist[side * DEC_ANCH + an] = dist;
+  const int p = an - L.a0, py = p / L.W, px = p - py * L.W;
+  const int pix = pv_pix(L.box, b, py, px);
+  float dist[4];
+#pragma unroll
+  for (int side = 0; side < 4; ++side) {
+    float v[16];
+    float lo[8], hi[8];
+    level_load8(L.box, 2 * side, pix, lo);
+    level_load8(L.box, 2 * side + 1, pix, hi);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      v[j] = lo[j];
+      v[8 + j] = hi[j];
+    }
+    dist[side] = dfl_expect(v);
   }
-  __syncthreads();
-  float* yb = a.y + (long long)b * (4 + a.nc) * a.A + L.a0 + p0;
-  if (lane < nv) {
-    const int p = p0 + lane;
-    const float ax = (float)(p % L.W) + 0.5f, ay = (float)(p / L.W) + 0.5f;
-    const float4 bx = box_xywh(ax, ay, sdist[lane], sdist[DEC_ANCH + lane], sdist[2 * DEC_ANCH + lane],
-                               sdist[3 * DEC_ANCH + lane], L.stride);
-    const float o = wave == 0 ? bx.x : wave == 1 ? bx.y : wave == 2 ? bx.z : bx.w;
-    yb[(long long)wave * a.A + lane] = o;
-    for (int c = wave; c < a.nc; c += 4)
-      yb[(long long)(4 + c) * a.A + lane] = sigmoid_score(sraw[lane * pitch + 64 + c]);
+  const float4 bx = box_xywh((float)px + 0.5f, (float)py + 0.5f, dist[0], dist[1], dist[2], dist[3], L.stride);
+  float* yb = a.y + (long long)b * (4 + a.nc) * a.A + an;
+  yb[0] = bx.x;
+  yb[(long long)a.A] = bx.y;
+  yb[2LL * a.A] = bx.z;
+  yb[3LL * a.A] = bx.w;
+  for (int c8 = 0; c8 * 8 < a.nc; ++c8) {
+    float v[8];
+    level_load8(L.cls, c8, pix, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (c8 * 8 + j < a.nc) yb[(long long)(4 + c8 * 8 + j) * a.A] = sigmoid_score(v[j]);
   }
 }
 
 int decode_launch(const DecodeLevel* lv, int n_levels, int batch, int nc, int A, float* y, hipStream_t s) {
   if (n_levels > MAX_LEVELS) return fail(-3, "decode: too many levels");
   DecodeArgs a;
-  int nb = 0;
-  for (int i = 0; i < n_levels; ++i) {
-    a.lv[i] = lv[i];
-    a.blk0[i] = nb;
-    nb += (lv[i].H * lv[i].W + DEC_ANCH - 1) / DEC_ANCH;
-  }
+  for (int i = 0; i < n_levels; ++i) a.lv[i] = lv[i];
   for (int i = n_levels; i < MAX_LEVELS; ++i) {
-    a.lv[i] = DecodeLevel{nullptr, nullptr, 0, 0, 1 << 30, 0.f};
-    a.blk0[i] = 1 << 30;
+    a.lv[i] = lv[0];
+    a.lv[i].a0 = 1 << 30;
   }
-  a.blk0[n_levels] = nb;
   a.n_levels = n_levels;
   a.batch = batch;
   a.nc = nc;
   a.A = A;
   a.y = y;
-  const size_t lds = ((size_t)DEC_ANCH * (64 + nc + 1) + 4 * DEC_ANCH) * sizeof(float);
-  if (lds > 150 * 1024) return fail(-3, "decode: nc too large for the LDS-staged decode");
-  static size_t attr = 0;
-  if (lds > attr) {
-    YL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(decode_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr = 160 * 1024;
-  }
-  hipLaunchKernelGGL(decode_kernel, dim3((unsigned)(batch * nb)), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(decode_kernel, dim3((unsigned)((A + 255) / 256), batch), dim3(256), 0, s, a);
   YL_HIP(hipGetLastError());
   return 0;
 }

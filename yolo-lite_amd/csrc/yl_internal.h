@@ -37,7 +37,8 @@ int fail(int code, const std::string& s);
 //     zero guard: no per-tap predicates, no halo staging.  Guards are zeroed when a workspace is first
 //     used and never written afterwards (buffers are not recycled between tensors).
 // A channel-slice view (torch.chunk / torch.cat / Concat) is a sub-range of planes.
-// fp32 Detect level maps stay NHWC [B][H][W][64 + nc].
+// The Detect level maps are ordinary planar buffers (yl_level); fp32 NHWC conv output still exists as
+// an epilogue option (yl_view dtype YL_F32) but the lowering no longer uses it.
 struct Geo {
   int W1, img, g0;
   unsigned plane_px;  // pixels per plane (multiple of 16)
@@ -153,20 +154,36 @@ int stem_launch(const StemArgs& a, int in_dtype, hipStream_t s);
 int convert_input_launch(const void* in, int in_dtype, const PView& out, int batch, int H, int W, hipStream_t s);
 
 struct DecodeLevel {
-  const float* box;  // [B][H][W][64]  DFL logits (head.py:64 cv2)
-  const float* cls;  // [B][H][W][nc]  class logits (cv3); stored right behind the box block
-  int H, W, a0;      // a0: first anchor index of this level
+  PView box;     // 8 planes: DFL logits (head.py:64 cv2)
+  PView cls;     // nc8 / 8 planes: class logits (cv3); padding channels hold large negative values
+  int H, W, a0;  // a0: first anchor index of this level
   float stride;
 };
+inline PView level_view(const void* workspace, int64_t offset, int batch, int H, int W) {
+  const Geo g = geo_of(batch, H, W);
+  PView p;
+  p.base = reinterpret_cast<__bf16*>((char*)workspace + offset);
+  p.plane = (long long)g.plane_px * 8;
+  p.W1 = g.W1;
+  p.img = g.img;
+  p.g0 = g.g0;
+  return p;
+}
 inline DecodeLevel decode_level(const void* workspace, const yl_level& L, int batch, int a0) {
   DecodeLevel d;
-  d.box = reinterpret_cast<const float*>((const char*)workspace + L.offset);
-  d.cls = d.box + (long long)batch * L.H * L.W * 64;
+  d.box = level_view(workspace, L.offset, batch, L.H, L.W);
+  d.cls = level_view(workspace, L.offset_cls, batch, L.H, L.W);
   d.H = L.H;
   d.W = L.W;
   d.a0 = a0;
   d.stride = L.stride;
   return d;
+}
+// 8 consecutive channels of plane c8 at pixel pix, as fp32
+__device__ __forceinline__ void level_load8(const PView& v, int c8, int pix, float (&o)[8]) {
+  const bf16x8 t = *reinterpret_cast<const bf16x8*>(v.base + (long long)c8 * v.plane + (long long)pix * 8);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (float)t[j];
 }
 int decode_launch(const DecodeLevel* lv, int n_levels, int batch, int nc, int A, float* y, hipStream_t s);
 

@@ -66,7 +66,7 @@ class HipEngine:
                 c.post_cin, c.post_act = int(w2.shape[1]), int(o.get("post_act", 0))
         lv = (_lib.Level * len(self.prog.levels))()
         for i, L in enumerate(self.prog.levels):
-            lv[i] = _lib.Level(L["offset"], L["H"], L["W"], L["stride"], 0)
+            lv[i] = _lib.Level(L["offset"], L["offset_cls"], L["H"], L["W"], L["stride"], L["nc8"])
         self._levels = lv
         iv = _cview(self.prog.input_view)
         handle = C.c_void_p()
@@ -191,16 +191,18 @@ class HipEngine:
             _lib.check(rc, "yl_decode_nms")
         return out, cnt
 
+    def level_views(self, i: int):
+        """(box, cls) arena views of Detect level i (bf16 planar buffers of 64 and nc8 channels)."""
+        L = self.prog.levels[i]
+        return (TView(L["offset"], L["H"], L["W"], 64, 64, 0, BF16),
+                TView(L["offset_cls"], L["H"], L["W"], L["nc8"], L["nc8"], 0, BF16))
+
     def raw_levels(self) -> List[torch.Tensor]:
-        """(B, 64+nc, H, W) fp32 copies of the Detect level maps (reference head.py:64-65 ``cat(cv2, cv3)``);
-        in the workspace a level is a box block [B][H][W][64] followed by a class block [B][H][W][nc]."""
+        """(B, 64+nc, H, W) fp32 copies of the Detect level maps (reference head.py:64-65 ``cat(cv2, cv3)``)."""
         out = []
-        for L in self.prog.levels:
-            px = self.batch * L["H"] * L["W"]
-            box = self.workspace[L["offset"]: L["offset"] + 4 * px * 64].view(torch.float32)
-            cls = self.workspace[L["offset"] + 4 * px * 64: L["offset"] + 4 * px * (64 + self.nc)].view(torch.float32)
-            t = torch.cat([box.view(self.batch, L["H"], L["W"], 64), cls.view(self.batch, L["H"], L["W"], self.nc)], 3)
-            out.append(t.permute(0, 3, 1, 2))
+        for i in range(len(self.prog.levels)):
+            vb, vc = self.level_views(i)
+            out.append(torch.cat([self.view_tensor(vb), self.view_tensor(vc)[:, : self.nc]], 1))
         return out
 
     def _planes(self, v: TView) -> torch.Tensor:

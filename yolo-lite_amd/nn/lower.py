@@ -277,7 +277,7 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
             bottleneck(f"{p}.m.{j}", a, a, c_)
         conv(p + ".cv3", u, y, 1, 1)
 
-    # ---- Detect (head.py:29-69): box branch cv2, class branch cv3, raw level maps in fp32.
+    # ---- Detect (head.py:29-69): box branch cv2, class branch cv3, raw level maps as bf16 planes.
     # Each level's two branches are emitted right after the layer that feeds them, on side lanes:
     # they only depend on that layer, so the engine runs them concurrently with the rest of the
     # neck (whose 20x20 / 40x40 layers cannot fill the chip by themselves).
@@ -318,10 +318,11 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
 
     def emit_level(lvl: int, xin: TView):
         h, w = xin.H, xin.W
-        # raw level map: fp32 box block [B][H][W][64] immediately followed by the class block [B][H][W][nc]
-        head_box = ar.alloc(h, w, 64, F32)
-        assert ar.top == head_box.offset + batch * h * w * 64 * 4  # 256 bytes per pixel: no padding
-        head_cls = ar.alloc(h, w, det.nc, F32)
+        # raw level maps: ordinary bf16 planar buffers, 64 DFL logits and nc8 class logits (nc padded to a
+        # multiple of 8 with zero filters and a -1e4 bias: such a channel can never be the best class)
+        nc8 = (det.nc + 7) // 8 * 8
+        head_box = ar.alloc(h, w, 64)
+        head_cls = ar.alloc(h, w, nc8)
         n0 = len(ops)
         t1, t2 = ar.alloc(h, w, c2), ar.alloc(h, w, c2)
         conv(f"{dp}.cv2.{lvl}.0", xin, t1, 3, 1)
@@ -339,10 +340,15 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
         d2, e2 = ar.alloc(h, w, c3), ar.alloc(h, w, c3)
         dwconv(f"{dp}.cv3.{lvl}.1.0", e1, d2)
         conv(f"{dp}.cv3.{lvl}.1.1", d2, e2, 1, 1)
-        conv(f"{dp}.cv3.{lvl}.2", e2, head_cls, 1, 1, act=False, bn=False)
+        wc, bc = fold_conv_bn(sd, f"{dp}.cv3.{lvl}.2", bn=False)
+        if nc8 != det.nc:
+            wc = np.concatenate([wc, np.zeros((nc8 - det.nc, *wc.shape[1:]), np.float32)], 0)
+            bc = np.concatenate([bc, np.full(nc8 - det.nc, -1e4, np.float32)], 0)
+        conv(f"{dp}.cv3.{lvl}.2", e2, head_cls, 1, 1, act=False, wb=(wc, bc))
         for o in ops[n1:]:
             o["lane"] = cls_lane(lvl)
-        level_rec[lvl] = dict(offset=head_box.offset, H=h, W=w, stride=float(strides[lvl]))
+        level_rec[lvl] = dict(offset=head_box.offset, offset_cls=head_cls.offset, nc8=nc8, H=h, W=w,
+                              stride=float(strides[lvl]))
 
     views: Dict[int, TView] = {}
     prog.input_view = ar.alloc(in_h, in_w, 8)
