@@ -14,6 +14,9 @@ Prints ONE JSON line on rank 0.
 from __future__ import annotations
 
 import argparse
+import os
+
+os.environ.setdefault("DEBUG_HIP_FORCE_GRAPH_QUEUES", "2")  # see yololite_amd/_lib.py; before HIP initialises
 import json
 import os
 import sys

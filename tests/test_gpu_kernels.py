@@ -128,6 +128,32 @@ def test_conv_reads_through_upsample_concat(gpu_device):
     _assert_close_bf16(m.read(out), ref, "conv over upsample+concat")
 
 
+@pytest.mark.parametrize("c,cout,h,w,act2", [(64, 80, 20, 20, True), (80, 80, 13, 9, True), (32, 32, 40, 40, False)])
+def test_depthwise_pointwise_fused(gpu_device, c, cout, h, w, act2):
+    """DWConv 3x3 + SiLU -> 1x1 conv in one launch (Detect class branch); the depthwise result only exists
+    in LDS, rounded to bf16 like a stored activation."""
+    g = torch.Generator().manual_seed(c * 7 + cout)
+    x = _rand(g, 2, c, h, w)
+    wd = torch.randn(c, 1, 3, 3, generator=g) * 0.3
+    bd = torch.randn(c, generator=g) * 0.2
+    wp = _rand(g, cout, c, 1, 1, scale=1.0 / math.sqrt(c))
+    bp = torch.randn(cout, generator=g) * 0.3
+    mid = bf16_round(F.silu(F.conv2d(x, wd, bd, 1, 1, 1, c)))
+    ref = F.conv2d(mid, wp, bp)
+    if act2:
+        ref = F.silu(ref)
+    m = Mini(2, gpu_device)
+    xin, out = m.buf(h, w, c), m.buf(h, w, cout)
+    m.fill(xin, x)
+    m.op(kind=OP_DWCONV3, name="t", act=1, inp=xin, out=out, weight=np.ascontiguousarray(wd.numpy()),
+         bias=np.ascontiguousarray(bd.numpy()), post_weight=np.ascontiguousarray(wp.numpy().reshape(cout, c)),
+         post_bias=np.ascontiguousarray(bp.numpy()), post_act=int(act2))
+    m.run()
+    got = m.read(out)
+    tol = 2.0 ** -7 * ref.abs() + 2.0 ** -7 * F.conv2d(mid.abs(), wp.abs()) + 1e-3
+    assert bool(((got - ref).abs() <= tol).all()), float(((got - ref).abs() - tol).max())
+
+
 def test_conv_stem_cin3(gpu_device):
     g = torch.Generator().manual_seed(8)
     x3 = bf16_round(torch.rand(2, 3, 64, 64, generator=g))

@@ -9,6 +9,12 @@ import ctypes as C
 import os
 from pathlib import Path
 
+# The hot path replays as a hipGraph with exactly two parallel branches (network trunk + the 80x80 class
+# branch).  With the runtime's default graph-queue heuristic the branch often ends up serialised behind the
+# trunk (measured: 27.0 k vs 33.3 k images/s) -- two forced graph queues make the mapping deterministic.
+# Must be in the environment before the HIP runtime initialises, hence at import time.
+os.environ.setdefault("DEBUG_HIP_FORCE_GRAPH_QUEUES", "2")
+
 _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "libyl_amd.so"
 

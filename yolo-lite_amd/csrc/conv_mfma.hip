@@ -432,6 +432,98 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
   }
 }
 
+// ------------------------------------------------------- depthwise 3x3 -> pointwise 1x1 in one launch
+// The Detect class branch is Sequential(DWConv(c, c, 3), Conv(c, c3, 1)) twice (head.py:41-48).  The
+// depthwise output is consumed by that 1x1 conv only, so a workgroup computes it for its 64*NT pixels
+// straight into LDS (bf16, [plane][pixel][8] = MFMA B-fragment order) and runs the 1x1 GEMM from there:
+// the intermediate tensor is never written to or read from HBM.  Same arithmetic and operation order as
+// dwconv3_kernel followed by conv_kernel (bit-identical results).  Needs all output channels in one
+// workgroup (Cout <= 80 here: MT <= 5, ncb == 1).
+template <int MT, int NT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void dwpw_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int P = 64 * NT;  // pixels per workgroup
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, n = lane & 15;
+  const int pblk = xcd_remap(blockIdx.x, gridDim.x);
+  const int C = a.Cin;
+  bf16x8* slab = reinterpret_cast<bf16x8*>(smem);
+  bf16x8* tile = slab + a.ksteps * MT * 64;                       // [cg][P]
+  float* dww = reinterpret_cast<float*>(tile + a.cg * P);         // [9][C] filter taps, then [C] bias
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, (short)0, a.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.out, (short)0, a.out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc((void*)nullptr, (short)0, 0, 0x00020000);
+
+  copy_slab(reinterpret_cast<const bf16x8*>(a.wpk), slab, a.ksteps * MT * 64, tid);
+  for (int i = tid; i < 10 * C; i += 256) dww[i] = i < 9 * C ? a.dw_w[i] : a.dw_b[i - 9 * C];
+  __syncthreads();
+
+  // ---- depthwise 3x3 + bias + SiLU of the workgroup's pixels, every plane
+  const unsigned hw = (unsigned)(a.Ho * a.Wo);
+  for (int item = tid; item < P * a.cg; item += 256) {
+    const int px = item & (P - 1), c8 = item / P;
+    const unsigned gp = (unsigned)pblk * P + px;
+    const unsigned b = gp / hw, rem = gp - b * hw;
+    const unsigned y = rem / (unsigned)a.Wo, x = rem - y * a.Wo;
+    const unsigned pix = a.in_g0 + b * a.in_img + y * a.in_w1 + x;
+    const unsigned vo = gp < (unsigned)a.npix ? pix * 16u + (unsigned)c8 * a.in_plane : OOB_LANE;
+    bf16x8 v[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+      v[t] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                                            rin, vo + (unsigned)(((t / 3 - 1) * a.in_w1 + (t % 3 - 1)) * 16), 0, 0));
+    float acc[8];
+    {
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(dww + 9 * C + c8 * 8);
+      const f32x4 b1 = *reinterpret_cast<const f32x4*>(dww + 9 * C + c8 * 8 + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[j] = b0[j];
+        acc[4 + j] = b1[j];
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(dww + t * C + c8 * 8);
+      const f32x4 w1 = *reinterpret_cast<const f32x4*>(dww + t * C + c8 * 8 + 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[j] = __builtin_fmaf((float)v[t][j], w0[j], acc[j]);
+        acc[4 + j] = __builtin_fmaf((float)v[t][4 + j], w1[j], acc[4 + j]);
+      }
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (__bf16)(a.dw_act ? silu_f(acc[j]) : acc[j]);
+    tile[c8 * P + px] = o;
+  }
+  __syncthreads();
+
+  // ---- 1x1 GEMM from LDS
+  const int patch = pblk * 4 + wave;
+  if (patch >= a.npatches) return;
+  Patch<NT> Pp;
+  patch_setup<NT>(a, patch, n, 0u, Pp);
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias + chan_in_block(MT, mt, g, 0));
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = bv;
+  }
+  const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int ks = 0; ks < a.ksteps; ++ks) {
+    bf16x8 wa[MT], xb[NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) wa[mt] = slab[(ks * MT + mt) * 64 + lane];
+    const int k8 = ks * 4 + g;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) xb[nt] = k8 < a.cg ? tile[k8 * P + wave * 16 * NT + nt * 16 + n] : zero;
+    mma_step<MT, NT>(wa, xb, acc);
+  }
+  epilogue<MT, NT>(a, rout, rres, 0, g, Pp.opix, acc);
+}
+
 // ------------------------------------------------------------------------------------ host
 static unsigned magic_of(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull / (unsigned)d) + 1ull); }
 
@@ -599,6 +691,57 @@ static int launch_m(const ConvConfig& cfg, const ConvArgs& a, hipStream_t s) {
     case 5: return cfg.NT == 1 ? launch_u<KS, 5, 1>(cfg, a, s) : launch_u<KS, 5, 2>(cfg, a, s);
   }
   return fail(-3, "conv: bad MT");
+}
+
+template <int MT, int NT>
+static int launch_dwpw(const ConvConfig& cfg, const ConvArgs& a, size_t lds, hipStream_t s) {
+  auto kern = dwpw_kernel<MT, NT>;
+  static size_t attr = 0;
+  if (lds > attr) {
+    YL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)LDS_MAX));
+    attr = LDS_MAX;
+  }
+  const int blocks = (cfg.npatches + 3) / 4;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), lds, s, a);
+  YL_HIP(hipGetLastError());
+  return 0;
+}
+
+// depthwise 3x3 + pointwise 1x1 (see dwpw_kernel); cfg from conv_choose(Cin = C, k = 1)
+int dwpw_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s) {
+  if (cfg.ncb != 1 || cfg.kchunk < cfg.ksteps || cfg.NT > 2)
+    return fail(-3, "dwpw: needs all output channels in one workgroup and NT <= 2");
+  a.ncb = 1;
+  a.cg = cfg.cg;
+  a.ksteps = cfg.ksteps;
+  a.kchunk = cfg.kchunk;
+  a.ntaps = 1;
+  a.magic_wo = magic_of(a.Wo);
+  a.magic_ho = magic_of(a.Ho);
+  a.npatches = cfg.npatches;
+  a.ppw = 1;
+  a.npix = batch * a.Ho * a.Wo;
+  const long long lim = 1LL << 30;
+  const long long inb = (long long)cfg.cg * a.in_plane, outb = (long long)((a.Cout + 7) / 8) * a.out_plane;
+  if (inb > lim || outb > lim) return fail(-3, "dwpw: a tensor slice exceeds 1 GiB; lower the batch size");
+  a.in_bytes = (unsigned)inb;
+  a.out_bytes = (unsigned)outb;
+  a.nblocks = (cfg.npatches + 3) / 4;
+  a.dbg = 0;
+  const size_t lds = (size_t)cfg.ksteps * cfg.MT * 1024 + (size_t)cfg.cg * 64 * cfg.NT * 16 + (size_t)10 * a.Cin * 4;
+  if (lds > LDS_MAX) return fail(-3, "dwpw: LDS budget exceeded");
+  switch (cfg.MT * 10 + cfg.NT) {
+    case 11: return launch_dwpw<1, 1>(cfg, a, lds, s);
+    case 12: return launch_dwpw<1, 2>(cfg, a, lds, s);
+    case 21: return launch_dwpw<2, 1>(cfg, a, lds, s);
+    case 22: return launch_dwpw<2, 2>(cfg, a, lds, s);
+    case 41: return launch_dwpw<4, 1>(cfg, a, lds, s);
+    case 42: return launch_dwpw<4, 2>(cfg, a, lds, s);
+    case 51: return launch_dwpw<5, 1>(cfg, a, lds, s);
+    case 52: return launch_dwpw<5, 2>(cfg, a, lds, s);
+  }
+  return fail(-3, "dwpw: unsupported tile shape");
 }
 
 // `a` arrives with pointers, plane sizes, geometry, Cin/Cout/stride/act/out_f32 filled in.

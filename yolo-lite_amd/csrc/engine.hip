@@ -233,16 +233,36 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
         if (!o.weight || !o.bias) return fail(-1, tag + ": dwconv needs weight and bias");
         if (o.in.H != o.out.H || o.in.W != o.out.W || o.in.dtype != YL_BF16 || o.out.dtype != YL_BF16)
           return fail(-1, tag + ": dwconv dims mismatch");
-        const int C = o.out.C;
+        const bool pw = o.post_weight != nullptr;  // depthwise 3x3 -> pointwise 1x1 in one launch
+        const int C = pw ? o.in.C : o.out.C;
+        if (pw) {
+          if (!o.post_bias || o.accumulate || o.grp || o.post_cin != C)
+            return fail(-1, tag + ": fused depthwise+pointwise needs a plain depthwise conv and post_cin == in.C");
+          if (int rc = conv_choose(batch, C, o.out.C, 1, 1, o.out.H, o.out.W, 0, &r.cfg)) return rc;
+          if (r.cfg.NT > 2) {
+            r.cfg.NT = 2;
+            r.cfg.npatches = (int)(((long long)batch * o.out.H * o.out.W + 31) / 32);
+          }
+          if (r.cfg.ncb != 1 || r.cfg.kchunk < r.cfg.ksteps)
+            return fail(-3, tag + ": fused depthwise+pointwise needs Cout <= 80 and a filter that fits the slab");
+          std::vector<uint16_t> pk;
+          conv_pack_weights(o.post_weight, o.out.C, C, 1, r.cfg, &pk);
+          uint16_t* d = nullptr;
+          if (int rc = dev_upload(e.get(), pk, &d)) return rc;
+          r.d_wpk = reinterpret_cast<__bf16*>(d);
+          std::vector<float> b2((size_t)r.cfg.MT * 16 + 16, 0.f);
+          for (int c = 0; c < o.out.C; ++c) b2[c] = o.post_bias[c];
+          if (int rc = dev_upload(e.get(), b2, &r.d_bias2)) return rc;
+        }
         std::vector<float> wt((size_t)9 * C);
         for (int c = 0; c < C; ++c)
           for (int t = 0; t < 9; ++t) wt[(size_t)t * C + c] = o.weight[(size_t)c * 9 + t];
         if (int rc = dev_upload(e.get(), wt, &r.d_w)) return rc;
         std::vector<float> bias(o.bias, o.bias + C);
         if (int rc = dev_upload(e.get(), bias, &r.d_bias)) return rc;
-        r.flops = 2.0 * px_out * C * 9;
-        r.bytes = px_out * C * 2 * (o.accumulate ? 3 : 2);
-        r.name = "dwconv3x3";
+        r.flops = 2.0 * px_out * C * 9 + (pw ? 2.0 * px_out * C * o.out.C : 0.0);
+        r.bytes = pw ? px_out * (C + o.out.C) * 2 : px_out * C * 2 * (o.accumulate ? 3 : 2);
+        r.name = pw ? "dw3x3+pw1x1_mfma" : "dwconv3x3";
         break;
       }
       case YL_OP_STEM: {
@@ -368,6 +388,32 @@ static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s, c
       return stem_launch(a, in_dtype, s);
     }
     case YL_OP_DWCONV3: {
+      if (r.d_wpk) {  // fused depthwise + pointwise
+        ConvArgs a{};
+        const Geo gi = geo_of(B, o.in.H, o.in.W);
+        a.in = pview(ws, o.in, B).base;
+        a.in_plane = (unsigned)plane_bytes(gi);
+        a.in_w1 = gi.W1;
+        a.in_img = gi.img;
+        a.in_g0 = gi.g0;
+        a.out = pview(ws, o.out, B).base;
+        a.out_plane = a.in_plane;
+        a.out_w1 = gi.W1;
+        a.out_img = gi.img;
+        a.out_g0 = gi.g0;
+        a.wpk = r.d_wpk;
+        a.bias = r.d_bias2;
+        a.dw_w = r.d_w;
+        a.dw_b = r.d_bias;
+        a.dw_act = o.act;
+        a.Ho = o.out.H;
+        a.Wo = o.out.W;
+        a.Cin = o.in.C;
+        a.Cout = o.out.C;
+        a.stride = 1;
+        a.act = o.post_act;
+        return dwpw_launch(r.cfg, a, B, s);
+      }
       DwArgs a{};
       a.in = pview(ws, o.in, B);
       a.out = pview(ws, o.out, B);

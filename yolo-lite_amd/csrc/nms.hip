@@ -145,7 +145,7 @@ __global__ __launch_bounds__(1024) void nms_sort_kernel(const float* __restrict_
     int pre[NSUB + 1];
     pre[0] = 0;
 #pragma unroll
-    for (int q = 0; q < NSUB; ++q) pre[q + 1] = pre[q] + w.pre_count[b * NSUB + q];
+    for (int q = 0; q < NSUB; ++q) pre[q + 1] = pre[q] + min(max(w.pre_count[b * NSUB + q], 0), w.sub_cap);
     n = pre[NSUB];
     while (np < n) np <<= 1;
     if (np <= SORT_LDS_KEYS) {
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(1024) void nms_sort_kernel(const float* __restrict_
   const float* pb = pred ? pred + (long long)b * (4 + nc) * A : nullptr;
   for (int i = tid; i < nf; i += 1024) {
     const unsigned long long key = k[i];
-    const int a = (int)(key & 0xffffffffu);
+    const int a = min((int)(key & 0xffffffffu), A - 1);  // never index out of range, whatever the key holds
     const float score = __uint_as_float(~(unsigned)(key >> 32));
     const int cls = w.cls_of[(long long)b * A + a];
     float cx, cy, bw, bh;
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(256) void decode_candidates_sparse_kernel(DecCandAr
   if (m > a.logit_lo) {
     const int sub = b * NSUB + ((an >> 6) & (NSUB - 1));
     const int slot = atomicAdd(&w.pre_count[sub], 1);
-    w.pre_list[(long long)sub * w.sub_cap + slot] = an;
+    if (slot < w.sub_cap) w.pre_list[(long long)sub * w.sub_cap + slot] = an;
   }
 }
 
@@ -540,9 +540,9 @@ constexpr int DX_BLOCKS = 4;  // workgroups per sub-list (4 waves each)
 __global__ __launch_bounds__(256) void decode_exact_kernel(DecCandArgs a, NmsWs w) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.z, sub = blockIdx.y;
-  const int n = w.pre_count[b * NSUB + sub];
+  const int n = min(w.pre_count[b * NSUB + sub], w.sub_cap);
   for (int j = blockIdx.x * 4 + wave; j < n; j += DX_BLOCKS * 4) {
-    const int an = w.pre_list[(long long)(b * NSUB + sub) * w.sub_cap + j];
+    const int an = min(max(w.pre_list[(long long)(b * NSUB + sub) * w.sub_cap + j], 0), a.A - 1);
     const DcAnchor d = dc_anchor(a, b, an);
     // lane = box channel lane: plane lane >> 3, element lane & 7
     const float v = (float)d.L.box.base[(long long)(lane >> 3) * d.L.box.plane + (long long)d.pix * 8 + (lane & 7)];

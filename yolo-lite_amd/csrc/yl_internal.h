@@ -75,6 +75,9 @@ struct ConvArgs {
   const __bf16* wpk2;  // fused follow-up 1x1: [MT/2 k-steps][MT][64 lanes][8], nullptr: none
   const float* bias2;  // its bias, padded to MT*16
   int post_cout, post_act;
+  const float* dw_w;   // dwpw_kernel: depthwise taps [9][C] and bias [C], SiLU flag
+  const float* dw_b;
+  int dw_act;
   const float* bias;   // padded to ncb*MT*16
   unsigned in_plane, out_plane, res_plane;  // bytes per plane
   int Ho, Wo;
@@ -104,6 +107,7 @@ int conv_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo,
 void conv_pack_weights(const float* w_oihw, int Cout, int Cin_w, int k, const ConvConfig& cfg,
                        std::vector<uint16_t>* out);
 int conv_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s);
+int dwpw_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s);
 
 // ------------------------------------------------------------------------ elementwise-ish
 // PView: a channel slice of a planar buffer as the kernels see it.

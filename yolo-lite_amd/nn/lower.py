@@ -139,6 +139,47 @@ def fuse_follow_up_convs(ops: List[dict]) -> List[dict]:
     return [o for i, o in enumerate(ops) if i not in drop]
 
 
+def fuse_depthwise_pointwise(ops: List[dict]) -> List[dict]:
+    """DWConv 3x3 -> 1x1 Conv (the Detect class branch, head.py:41-48) when the 1x1 conv is the only reader
+    of the depthwise output and has at most 80 output channels: one launch, the depthwise output lives in
+    LDS only (``yl_op.post_*`` on a YL_OP_DWCONV3 op)."""
+
+    def planes(v: TView):
+        return {(v.offset, p) for p in range(v.coff // 8, (v.coff + v.C) // 8)}
+
+    drop = set()
+    for i, a in enumerate(ops):
+        if a["kind"] != OP_DWCONV3 or a.get("accumulate") or a.get("grp") or "post_weight" in a:
+            continue
+        mine = planes(a["out"])
+        rd = []
+        for j, o in enumerate(ops):
+            for k in ("inp", "res", "inp2"):
+                v = o.get(k)
+                if v is not None and v.dtype == BF16 and planes(v) & mine:
+                    rd.append(j)
+            if o.get("accumulate") and planes(o["out"]) & mine:
+                rd.append(j)
+        if len(rd) != 1 or rd[0] <= i:
+            continue
+        b = ops[rd[0]]
+        y = a["out"]
+        if (b["kind"] != OP_CONV or b.get("k") != 1 or b.get("stride", 1) != 1 or b.get("res") is not None
+                or "post_weight" in b or "inp2" in b or b.get("cin_weight", 0)
+                or (b["out"].C + 15) // 16 not in (1, 2, 4, 5)
+                or b.get("lane", 0) != a.get("lane", 0)
+                or (b["inp"].offset, b["inp"].coff, b["inp"].C) != (y.offset, y.coff, y.C)):
+            continue
+        a["post_weight"] = b["weight"].reshape(b["weight"].shape[0], -1)
+        a["post_bias"] = b["bias"]
+        a["post_act"] = b.get("act", 0)
+        a["out"] = b["out"]
+        a["name"] = f"{a.get('name', '')}+pw"
+        a["fused_names"] = [b.get("name", "")]
+        drop.add(rd[0])
+    return [o for i, o in enumerate(ops) if i not in drop]
+
+
 def fuse_upsample_into_convs(ops: List[dict]) -> List[dict]:
     """nn.Upsample(2, nearest) -> Concat -> 1x1 conv (yolo11.yaml:31-36): when that conv is the only
     reader of the upsampled planes, it reads the low-resolution map itself at pixel (y/2, x/2)
@@ -347,6 +388,9 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
         conv(f"{dp}.cv3.{lvl}.2", e2, head_cls, 1, 1, act=False, wb=(wc, bc))
         for o in ops[n1:]:
             o["lane"] = cls_lane(lvl)
+        ncut = int(os.environ.get("YL_LANE_CUT", "0"))  # experiment: last ncut ops of the chain stay on main
+        for o in ops[len(ops) - ncut:] if ncut else []:
+            o["lane"] = 0
         level_rec[lvl] = dict(offset=head_box.offset, offset_cls=head_cls.offset, nc8=nc8, H=h, W=w,
                               stride=float(strides[lvl]))
 
@@ -425,6 +469,8 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
     ops.extend(deferred)
     if fuse_post and os.environ.get("YL_FUSE_POST", "1") != "0":
         ops[:] = fuse_follow_up_convs(ops)
+    if fuse_post and os.environ.get("YL_FUSE_DWPW", "1") != "0":
+        ops[:] = fuse_depthwise_pointwise(ops)
     if fuse_post and os.environ.get("YL_FUSE_UP", "1") != "0":
         ops[:] = fuse_upsample_into_convs(ops)
     a_total = 0
