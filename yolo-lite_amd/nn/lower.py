@@ -388,9 +388,6 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
         conv(f"{dp}.cv3.{lvl}.2", e2, head_cls, 1, 1, act=False, wb=(wc, bc))
         for o in ops[n1:]:
             o["lane"] = cls_lane(lvl)
-        ncut = int(os.environ.get("YL_LANE_CUT", "0"))  # experiment: last ncut ops of the chain stay on main
-        for o in ops[len(ops) - ncut:] if ncut else []:
-            o["lane"] = 0
         level_rec[lvl] = dict(offset=head_box.offset, offset_cls=head_cls.offset, nc8=nc8, H=h, W=w,
                               stride=float(strides[lvl]))
 
