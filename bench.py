@@ -17,6 +17,7 @@ import argparse
 import os
 
 os.environ.setdefault("DEBUG_HIP_FORCE_GRAPH_QUEUES", "2")  # see yololite_amd/_lib.py; before HIP initialises
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import json
 import os
 import sys

@@ -14,6 +14,9 @@ from pathlib import Path
 # trunk (measured: 27.0 k vs 33.3 k images/s) -- two forced graph queues make the mapping deterministic.
 # Must be in the environment before the HIP runtime initialises, hence at import time.
 os.environ.setdefault("DEBUG_HIP_FORCE_GRAPH_QUEUES", "2")
+# Four batches in flight x two graph queues each = eight streams: give each its own hardware queue
+# (the runtime's default of four makes them share; 37.4 k -> 38.6 k images/s).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 _PKG = Path(__file__).resolve().parent
 LIB_PATH = _PKG / "libyl_amd.so"
