@@ -173,9 +173,12 @@ def main():
 
     ndet = None
     if world == 1:
-        # one resident input batch per slot (a graph bakes its input pointer)
-        xs = [x] + [torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(1000 + j)).to(dev)
-                    for j in range(1, S)]
+        # one resident input batch per slot (a graph bakes its input pointer): uint8 NCHW, what the
+        # predictor's preprocess hands to the device (predictor.py:77-84); the /255 is fused into the stem.
+        # Same input format as the N > 1 path, so per-GPU work is identical at every N.
+        x8 = (x * 255).to(torch.uint8)
+        xs = [x8] + [torch.randint(0, 256, (B, 3, H, W), generator=torch.Generator().manual_seed(1000 + j),
+                                   dtype=torch.uint8).to(dev) for j in range(1, S)]
         for k in range(max(args.warmup, 2 * S)):
             out, cnt = hot_path(xs[step_no[0] % S])
         sync_all()
@@ -190,7 +193,7 @@ def main():
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
         for _ in range(20):
-            eng.detect(x, conf, iou, max_det=max_det, graph=True, slot=0)
+            eng.detect(x8, conf, iou, max_det=max_det, graph=True, slot=0)
         torch.cuda.synchronize(dev)
         latency_ms = (time.perf_counter() - t1) / 20 * 1e3
     else:
@@ -225,7 +228,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"YOLO11{args.scale} bf16, {H}x{W} batch={B} per GPU (fused Conv+BN+SiLU + HIP NMS), "
-                                   f"random-init weights, torch.rand images, conf {conf} iou {iou} max_det {max_det}; "
+                                   f"random-init weights, random uint8 NCHW images resident in HBM, conf {conf} iou {iou} max_det {max_det}; "
                                    f"{S} batches in flight on {S} HIP streams (one hipGraph launch per step)",
                        "global_batch": world * B, "parallelism": f"dp{world}" if world > 1 else "single",
                        "streams": S,
@@ -235,7 +238,7 @@ def main():
         }
         if world == 1:
             res["latency_ms_single_stream"] = round(latency_ms, 4)
-            rows = eng.profile(x, iters=20)
+            rows = eng.profile(x8, iters=20)
             roof, kernels = roofline_from_profile(rows, B)
             res["roofline"] = roof
             res["kernels"] = kernels
