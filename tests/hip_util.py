@@ -57,7 +57,8 @@ class Mini:
         return self.eng.view_tensor(view).cpu()
 
 
-def run_conv(device, x, w, b, k, s, act, res=None, pitch_extra=(0, 0), out_f32=False, cin_weight=0):
+def run_conv(device, x, w, b, k, s, act, res=None, pitch_extra=(0, 0), out_f32=False, cin_weight=0,
+             expect_kernel=None):
     """x (B,Cin,H,W) fp32 (already bf16-representable), w OIHW, b (Cout,) -> HIP conv output (fp32 NCHW)."""
     B, Cin, H, W = x.shape
     Cout = w.shape[0]
@@ -75,4 +76,6 @@ def run_conv(device, x, w, b, k, s, act, res=None, pitch_extra=(0, 0), out_f32=F
     m.op(kind=OP_CONV, name="t", k=k, stride=s, act=int(act), inp=xin, out=yv, res=rv,
          weight=np.ascontiguousarray(w.numpy()), bias=np.ascontiguousarray(b.numpy()), cin_weight=cin_weight)
     m.run()
+    if expect_kernel is not None:
+        assert m.eng.op_kernel(0) == expect_kernel, (m.eng.op_kernel(0), expect_kernel)
     return m.read(yv)

@@ -253,3 +253,42 @@ def test_attention_vs_torch(gpu_device, nh, h, w):
     err = (got - ref).abs()
     tol = 2.0 ** -8 * bound + 2.0 ** -8 * ref.abs() + 1e-3
     assert not (err > tol).any(), f"attention: max err {float(err.max()):.4g}, worst ratio {float((err / tol).max()):.2f}"
+
+
+TILE_CASES = [
+    # Cin, Cout, H, W, act, res, NT     conv3_tile_kernel (input tile in LDS), forced onto small maps
+    (64, 64, 20, 20, True, True, 4),
+    (64, 64, 20, 20, True, False, 1),
+    (64, 64, 7, 9, True, False, 2),
+    (32, 32, 40, 40, True, True, 4),
+    (64, 32, 13, 17, True, False, 2),
+    (32, 64, 24, 40, False, False, 4),
+    (64, 64, 80, 80, True, False, 4),
+]
+
+
+@pytest.mark.parametrize("cin,cout,h,w,act,res,nt", TILE_CASES)
+def test_conv3_tile_vs_torch_and_direct(gpu_device, monkeypatch, cin, cout, h, w, act, res, nt):
+    """The LDS-tile 3x3 kernel against torch, and against the direct kernel (the k order differs, so the two
+    agree to one bf16 ulp, not bit for bit)."""
+    g = torch.Generator().manual_seed(cin * 100 + cout + h + nt)
+    B = 3
+    x = _rand(g, B, cin, h, w)
+    wt = _rand(g, cout, cin, 3, 3, scale=1.0 / math.sqrt(cin * 9))
+    b = torch.randn(cout, generator=g) * 0.5
+    ref = F.conv2d(x, wt, b, 1, 1)
+    if act:
+        ref = F.silu(ref)
+    r = None
+    if res:
+        r = _rand(g, *ref.shape)
+        ref = ref + r
+    monkeypatch.setenv("YL_CONV_TILE", "1")
+    monkeypatch.setenv("YL_CONV_TILE_MIN", "1")
+    monkeypatch.setenv("YL_CONV_TILE_NT", str(nt))
+    got = run_conv(gpu_device, x, wt, b, 3, 1, act, r, expect_kernel="conv3x3_tile_mfma")
+    _assert_close_bf16(got, ref, f"tile conv {cin}->{cout} NT={nt}")
+    monkeypatch.setenv("YL_CONV_TILE", "0")
+    direct = run_conv(gpu_device, x, wt, b, 3, 1, act, r, expect_kernel="conv3x3_mfma")
+    # both are within half a bf16 ulp of the exact sum, so they differ by at most one ulp (2^-7 relative)
+    assert ((got - direct).abs() <= 2.0 ** -7 * direct.abs().clamp(min=1e-2) + 1e-3).all(), "tile vs direct kernel"

@@ -19,7 +19,7 @@ os.environ.setdefault("DEBUG_HIP_FORCE_GRAPH_QUEUES", "2")
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 _PKG = Path(__file__).resolve().parent
-LIB_PATH = _PKG / "libyl_amd.so"
+LIB_PATH = Path(os.environ["YL_AMD_LIB"]) if os.environ.get("YL_AMD_LIB") else _PKG / "libyl_amd.so"  # dev override
 
 YL_BF16, YL_F32, YL_F16, YL_U8 = 0, 1, 2, 3
 OP_CONV, OP_DWCONV3, OP_SPPF_POOL, OP_UPSAMPLE, OP_ATTENTION, OP_STEM = 1, 2, 3, 4, 5, 6

@@ -1,0 +1,248 @@
+// Device helpers shared by the MFMA conv kernels (conv_mfma.hip, conv3_tile.hip): SiLU, the output-channel
+// permutation of the packed filters, buffer-addressing constants, fragment fetch and the common epilogue.
+#pragma once
+#include "yl_internal.h"
+
+namespace yl {
+
+__device__ __forceinline__ int fastdiv(int x, int d, unsigned magic) {
+  return d == 1 ? x : (int)__umulhi((unsigned)x, magic);
+}
+
+// SiLU with the hardware exp2 / reciprocal (v_exp_f32, v_rcp_f32; ~1 ulp each, far inside bf16 output
+// rounding): an IEEE divide here costs ~10 VALU instructions per element and made the epilogue, not
+// memory, the bottleneck of the streaming layers.
+__device__ __forceinline__ float silu_f(float v) {
+  return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * v));
+}
+
+// Output-channel order inside a block of MT*16 channels.  The MFMA leaves lane (pixel n, quad g)
+// with rows g*4+r of every 16-row tile; the filter rows are permuted at pack time so that one lane's
+// rows of two adjacent tiles are 8 CONSECUTIVE channels = one pixel of one plane: 16-byte stores,
+// 256 contiguous bytes per 16 lanes.
+__host__ __device__ inline int chan_in_block(int MT, int mt, int g, int r) {
+  const int even = MT & ~1;
+  return mt < even ? ((((mt >> 1) * 4 + g) * 2 + (mt & 1)) * 4 + r) : (even * 16 + g * 4 + r);
+}
+
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+// Buffer addressing (raw_buffer_load/store with a 32-bit byte offset): an offset beyond the
+// descriptor's size makes a load return zeros and a store vanish, so ragged patches and k tails need
+// no branches.  Views are limited to 2^30 bytes (host-checked) so that the sums below can never wrap
+// back into range: dead lane 2^31 (+/- a tap offset), k tail 2^30, both 3 * 2^30.
+constexpr unsigned OOB_LANE = 0x80000000u;
+constexpr unsigned OOB_K = 0x40000000u;
+
+template <int NT>
+struct Patch {
+  unsigned base[NT];  // byte offset of the (stride-scaled) centre pixel in the lane's first input plane
+  unsigned base2[NT]; // UP only: the same for the low-resolution source (pixel (y/2, x/2))
+  int opix[NT];       // output pixel: guarded plane index (bf16) or linear NHWC index (fp32); -1 = none
+};
+
+template <int NT, bool UP = false>
+__device__ __forceinline__ void patch_setup(const ConvArgs& a, int patch, int n, unsigned lane_off, Patch<NT>& P,
+                                            unsigned lane_off2 = 0) {
+  const int first = patch * (16 * NT);  // wave-uniform
+  const int hw = a.Ho * a.Wo;
+  const int b0 = first / hw;
+  const int rem = first - b0 * hw;
+  const int oy0 = rem / a.Wo;
+  const int ox0 = rem - oy0 * a.Wo;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int t = ox0 + nt * 16 + n;
+    const int q = fastdiv(t, a.Wo, a.magic_wo);
+    const int ox = t - q * a.Wo;
+    const int oyt = oy0 + q;
+    const int qb = fastdiv(oyt, a.Ho, a.magic_ho);
+    const int oy = oyt - qb * a.Ho;
+    const int b = b0 + qb;
+    const int gp = first + nt * 16 + n;
+    const bool valid = gp < a.npix;
+    const int pi = a.in_g0 + b * a.in_img + oy * a.stride * a.in_w1 + ox * a.stride;
+    const int po = a.out_f32 ? gp : a.out_g0 + b * a.out_img + oy * a.out_w1 + ox;
+    P.base[nt] = valid ? (unsigned)pi * 16u + lane_off : OOB_LANE;
+    if (UP) {
+      const int pi2 = a.in2_g0 + b * a.in2_img + (oy >> 1) * a.in2_w1 + (ox >> 1);
+      P.base2[nt] = valid ? (unsigned)pi2 * 16u + lane_off2 : OOB_LANE;
+    }
+    P.opix[nt] = valid ? po : -1;
+  }
+}
+
+template <int KS>
+__device__ __forceinline__ int tap_offset(const ConvArgs& a, int tap) {  // bytes
+  if (KS == 1) return 0;
+  const int kh = (tap * 11) >> 5;
+  return ((kh - 1) * a.in_w1 + (tap - 3 * kh - 1)) * 16;
+}
+
+// B-fragment fetch of k-step `ks` (wave-uniform).  In the UNIFORM case (Cin % 32 == 0) a k-step lies
+// inside one tap: tap, channel block and byte offset are scalars (the lane's k-group plane is already
+// in Patch::base) and the per-lane work is ONE add per load; otherwise (tap, channel group) are derived
+// per lane.  K-steps past the end (ring refills) resolve to the out-of-range offset and return zeros.
+// UP (1x1 convs reading a Concat whose first channels are a nearest-upsampled low-resolution map,
+// yolo11.yaml:31-36): k-steps below ks_split read the low-resolution source itself at pixel (y/2, x/2),
+// so the 4x larger upsampled copy is never written or read.
+template <int KS, int NT, bool UNIFORM, bool UP = false>
+__device__ __forceinline__ void fetch_b(const ConvArgs& a, __amdgpu_buffer_rsrc_t rin, int ks, int g,
+                                        const Patch<NT>& P, bf16x8 (&xb)[NT],
+                                        __amdgpu_buffer_rsrc_t rin2 = __amdgpu_buffer_rsrc_t()) {
+  if constexpr (UP) {
+    static_assert(!UP || (KS == 1 && UNIFORM), "UP is a 1x1, Cin % 32 == 0 feature");
+    if (ks < a.ks_split) {
+      const unsigned off2 = (unsigned)(ks * 4) * a.in2_plane;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        xb[nt] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rin2, P.base2[nt] + off2, 0, 0));
+      return;
+    }
+    ks -= a.ks_split;  // k-step within the full-resolution source
+    const unsigned off1 = ks < a.ksteps - a.ks_split ? (unsigned)(ks * 4) * a.in_plane : OOB_K;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      xb[nt] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rin, P.base[nt] + off1, 0, 0));
+    return;
+  }
+  unsigned off;
+  if (UNIFORM) {
+    const int tap = fastdiv(ks, a.kkn, a.magic_kkn);
+    const int kk = ks - tap * a.kkn;
+    off = ks < a.ksteps ? (unsigned)tap_offset<KS>(a, tap) + (unsigned)(kk * 4) * a.in_plane : OOB_K;
+  } else {
+    const int k8 = ks * 4 + g;
+    const int tap = KS == 1 ? 0 : fastdiv(k8, a.cg, a.magic_cg);
+    const int c8 = k8 - tap * a.cg;
+    off = k8 < a.ntaps * a.cg ? (unsigned)tap_offset<KS>(a, tap) + (unsigned)c8 * a.in_plane : OOB_K;
+  }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+    xb[nt] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rin, P.base[nt] + off, 0, 0));
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void mma_step(const bf16x8 (&wa)[MT], const bf16x8 (&xb)[NT], f32x4 (&acc)[MT][NT]) {
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[mt], xb[nt], acc[mt][nt], 0, 0, 0);
+}
+
+// Global -> LDS copy of a packed filter slab: 8 independent 16-byte loads per thread are issued
+// before the first LDS store, so the copy costs one memory round trip per 32 KB, not one per 4 KB.
+__device__ __forceinline__ void copy_slab(const bf16x8* __restrict__ src, bf16x8* dst, int n16, int tid) {
+  for (int i0 = tid; i0 < n16; i0 += 256 * 8) {
+    bf16x8 t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * 256;
+      if (i < n16) t[u] = src[i];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u * 256;
+      if (i < n16) dst[i] = t[u];
+    }
+  }
+}
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+  const bf16x2 t = {(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(unsigned, t);
+}
+
+// fp32 NHWC store of W consecutive channels starting at `co` (Detect level maps, head.py:64-65).
+template <int W>
+__device__ __forceinline__ void store_f32(const ConvArgs& a, __amdgpu_buffer_rsrc_t rout, bool ok, int pix, int co,
+                                          const float (&v)[W]) {
+  const bool vec = ((a.out_pitch | a.out_coff) & 3) == 0;
+#pragma unroll
+  for (int q = 0; q < W; q += 4) {
+    const unsigned vo = (unsigned)pix * ((unsigned)a.out_pitch * 4u) + (unsigned)(a.out_coff + co + q) * 4u;
+    if (vec && co + q + 4 <= a.Cout) {
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v[q]), __float_as_uint(v[q + 1]),
+                                                   __float_as_uint(v[q + 2]), __float_as_uint(v[q + 3])},
+                                             rout, ok ? vo : OOB_LANE, 0, 0);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[q + r]), rout,
+                                              (ok && co + q + r < a.Cout) ? vo + 4u * r : OOB_LANE, 0, 0);
+    }
+  }
+}
+
+// Epilogue (the accumulators already contain the bias): SiLU, residual, 16-byte buffer stores.
+template <int MT, int NT>
+__device__ __forceinline__ void epilogue(const ConvArgs& a, __amdgpu_buffer_rsrc_t rout, __amdgpu_buffer_rsrc_t rres,
+                                         int cb, int g, const int (&opix)[NT], f32x4 (&acc)[MT][NT]) {
+  const int cbase = cb * MT * 16;
+  if (a.act && !(a.dbg & 8)) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[mt][nt][r] = silu_f(acc[mt][nt][r]);
+  }
+#pragma unroll
+  for (int p = 0; p < MT / 2; ++p) {
+    const int co = cbase + (p * 4 + g) * 8;
+    const bool cok = co < a.Cout;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const bool ok = cok && opix[nt] >= 0;
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[2 * p][nt][r];
+        v[4 + r] = acc[2 * p + 1][nt][r];
+      }
+      if (a.out_f32) {
+        store_f32<8>(a, rout, ok, opix[nt], co, v);
+        continue;
+      }
+      if (a.res) {
+        const unsigned ro = ok ? (unsigned)(co >> 3) * a.res_plane + (unsigned)opix[nt] * 16u : OOB_LANE;
+        const bf16x8 rv = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rres, ro, 0, 0));
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += (float)rv[r];
+      }
+      const unsigned vo = ok ? (unsigned)(co >> 3) * a.out_plane + (unsigned)opix[nt] * 16u : OOB_LANE;
+      __builtin_amdgcn_raw_buffer_store_b128(
+          u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])},
+          rout, vo, 0, 0);
+    }
+  }
+  if (MT & 1) {
+    constexpr int mt = MT - 1;
+    const int co = cbase + (MT & ~1) * 16 + g * 4;
+    const bool cok = co < a.Cout;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const bool ok = cok && opix[nt] >= 0;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = acc[mt][nt][r];
+      if (a.out_f32) {
+        store_f32<4>(a, rout, ok, opix[nt], co, v);
+        continue;
+      }
+      const unsigned po = (unsigned)opix[nt] * 16u + (unsigned)(co & 7) * 2u;
+      if (a.res) {
+        const unsigned ro = ok ? (unsigned)(co >> 3) * a.res_plane + po : OOB_LANE;
+        const bf16x4 rv = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rres, ro, 0, 0));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+      }
+      const unsigned vo = ok ? (unsigned)(co >> 3) * a.out_plane + po : OOB_LANE;
+      __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])}, rout, vo, 0, 0);
+    }
+  }
+}
+
+}  // namespace yl

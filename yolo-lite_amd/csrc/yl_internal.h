@@ -92,10 +92,14 @@ struct ConvArgs {
   unsigned in_bytes, out_bytes, res_bytes;  // buffer-descriptor sizes (bytes past the base pointers)
   int nblocks;
   int dbg;  // development ablation flags (YL_CONV_DBG), 0 in production
+  // conv3_tile_kernel (3x3, stride 1, input tile in LDS): tile geometry in guarded-pixel units
+  int t_px, t_PL, t_ppp, t_ntiles, t_plane_px, t_H, t_W, t_B;  // pixels staged / LDS plane pitch / DMA pieces per plane
+  unsigned magic_ppp, magic_img, magic_w1;
 };
 
 struct ConvConfig {
   int MT, NT, uniform, post, ncb, cg, ksteps, kchunk, ntaps, npatches, gws, ppw;
+  int tile;          // > 0: conv3_tile_kernel with this many 16-pixel column tiles per wave (else conv_kernel)
   size_t lds_bytes;
   size_t wpk_elems;  // packed weight elements
   const char* name;
@@ -107,6 +111,9 @@ int conv_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo,
 void conv_pack_weights(const float* w_oihw, int Cout, int Cin_w, int k, const ConvConfig& cfg,
                        std::vector<uint16_t>* out);
 int conv_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s);
+// conv3_tile.hip: decides whether the LDS-tile kernel takes this layer (sets cfg->tile) / launches it
+void conv3_tile_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, int post, ConvConfig* cfg);
+int conv3_tile_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s);
 int dwpw_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s);
 
 // ------------------------------------------------------------------------ elementwise-ish

@@ -236,6 +236,12 @@ class HipEngine:
     def layer_output(self, i: int) -> torch.Tensor:
         return self.view_tensor(self.prog.layer_views[i])
 
+    def op_kernel(self, i: int) -> str:
+        """Name of the kernel family the engine chose for op i (yl_engine_op_info)."""
+        fl, by, nm = C.c_double(), C.c_double(), C.c_char_p()
+        self.lib.yl_engine_op_info(self._h, i, C.byref(fl), C.byref(by), C.byref(nm))
+        return nm.value.decode()
+
     def profile(self, im: torch.Tensor, iters: int = 20) -> List[dict]:
         """Per-op HIP-event timings with algorithmic flops/bytes (see yl_engine_profile)."""
         self._check_input(im)
