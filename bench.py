@@ -77,6 +77,20 @@ def cpu_baseline(sd, scale, h, w, conf, iou, sample_b=8, iters=2):
             "sample": f"{iters} iterations of batch {sample_b} at {h}x{w} after 1 warm-up, fp32 oracle forward + NMS"}
 
 
+def measured_traffic(kernel):
+    """HBM bytes per launch of a kernel family from the newest committed PMC summary (profiles/rNN_traffic.json,
+    written by tools/summarize_profile.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
+    bench; PMC counters cannot be read from inside the un-profiled run).  None when there is none."""
+    files = sorted((ROOT / "profiles").glob("r*_traffic.json"))
+    if not files:
+        return None, None
+    t = json.loads(files[-1].read_text())
+    for fam, v in t.items():
+        if not fam.startswith("_") and kernel in fam.split("+"):
+            return v["read_bytes_per_launch"] + v["write_bytes_per_launch"], f"{files[-1].name}: {t.get('_source', '')}"
+    return None, None
+
+
 def roofline_from_profile(rows, batch):
     """Aggregate per-op HIP-event timings by kernel; dominant kernel = largest total time."""
     agg = {}
@@ -98,7 +112,12 @@ def roofline_from_profile(rows, batch):
             "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
             "frac": round(max(mfma_frac, hbm_frac), 4), "traffic": None,
             "launches_per_step": a["launches"], "avg_launch_us": round(a["ms"] * 1e3 / a["launches"], 2),
-            "mfma_frac": round(mfma_frac, 4), "hbm_frac": round(hbm_frac, 4)}
+            "mfma_frac": round(mfma_frac, 4), "hbm_frac": round(hbm_frac, 4),
+            "algorithmic_bytes_per_launch": round(a["bytes"] / a["launches"])}
+    roof["traffic"], src = measured_traffic(name)
+    if src:
+        roof["traffic_unit"] = "HBM bytes per launch (PMC)"
+        roof["traffic_source"] = src
     # best single 3x3 layer against the MFMA roof (the north-star target names the fused 3x3 conv)
     best = None
     for r in rows:

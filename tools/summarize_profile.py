@@ -33,6 +33,27 @@ def pmc(dirpath, counter):
     return {k: v[0] / v[1] for k, v in out.items() if v[1]}
 
 
+def family(k):
+    """rocprofv3 kernel name -> the kernel family names bench.py's roofline uses (yl_engine_op_info)."""
+    if k.startswith("conv_kernel<1,"):
+        return "conv1x1_mfma"
+    if k.startswith("conv_kernel<3,"):
+        return "conv3x3_mfma+conv3x3s2_mfma"   # one template serves both strides
+    if k.startswith("conv3_tile_kernel"):
+        return "conv3x3_tile_mfma"
+    if k.startswith("dwpw_kernel"):
+        return "dw3x3+pw1x1_mfma"
+    if k.startswith("stem_kernel"):
+        return "stem_conv3x3s2"
+    if k.startswith("dwconv3_kernel"):
+        return "dwconv3x3"
+    if k.startswith("sppf_pool"):
+        return "sppf_maxpool"
+    if k.startswith("attention_kernel"):
+        return "attention"
+    return None
+
+
 def main():
     src, dst, tag = Path(sys.argv[1]), Path(sys.argv[2]), sys.argv[3]
     dst.mkdir(parents=True, exist_ok=True)
@@ -68,6 +89,24 @@ def main():
         lines.append(f"| `{k}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} | "
                      f"{'' if rd is None else f'{2 * rd * 1024 / 1e6:.1f}'} | {'' if wr is None else f'{wr * 1024 / 1e6:.1f}'} |")
     (dst / f"{tag}_summary.md").write_text("\n".join(lines) + "\n")
+    # per-family HBM bytes per launch (launch-weighted over the template instances), read by bench.py
+    fam = {}
+    for r in rows:
+        k = short(r["Name"])
+        f = family(k)
+        if f is None or k not in fetch or k not in write:
+            continue
+        a = fam.setdefault(f, dict(launches=0, read=0.0, write=0.0))
+        n = int(r["Calls"])
+        a["launches"] += n
+        a["read"] += n * 2 * fetch[k] * 1024
+        a["write"] += n * write[k] * 1024
+    traffic = {f: {"read_bytes_per_launch": round(a["read"] / a["launches"]),
+                   "write_bytes_per_launch": round(a["write"] / a["launches"]),
+                   "launches_in_trace": a["launches"]} for f, a in fam.items()}
+    traffic["_source"] = (f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py, {tag}; "
+                          "read side = 2 x FETCH_SIZE (gfx950 correction, MI355X_MICROARCH.md)")
+    (dst / f"{tag}_traffic.json").write_text(json.dumps(traffic, indent=1))
     print("\n".join(lines[:40]))
 
 
