@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define YL_ABI_VERSION 4
+#define YL_ABI_VERSION 5
 
 /* element types */
 enum { YL_BF16 = 0, YL_F32 = 1, YL_F16 = 2, YL_U8 = 3 };
@@ -187,6 +187,18 @@ int yl_engine_detect_graph(yl_engine* e, const void* input, int in_dtype, void* 
 
 /* uint8 HWC BGR letterboxed images -> float NCHW RGB / 255 (engine/predictor.py:77-84). */
 int yl_preprocess_u8(const uint8_t* bgr_hwc, int batch, int h, int w, float* out_nchw, void* stream);
+
+/* LetterBox on the device (data/augment.py:636-681 LetterBox.__call__, then engine/predictor.py:77-81:
+ * BGR -> RGB, HWC -> CHW) for ONE uint8 HWC BGR source image (device pointer, row pitch in bytes) into
+ * dst_chw = the [3][H][W] uint8 slot of that image in the NCHW batch.  The image is resized to
+ * (new_h, new_w) -- bilinear in OpenCV's 8-bit fixed-point convention, the same integer arithmetic as the
+ * CPU restatement data/augment.py::resize_linear_u8 -- placed at (top, left), the rest filled with 114.
+ * xtab / ytab: device arrays of new_w / new_h int32[4] = {i0, i1, c0, c1} (source indices and 11-bit
+ * coefficients per output column / row, computed by the host exactly as the CPU restatement does); unused
+ * when the size does not change.  The geometry (new size, pads) is LetterBox.geometry's. */
+int yl_letterbox_u8(const uint8_t* src_bgr_hwc, int src_h, int src_w, int src_pitch, uint8_t* dst_chw, int H,
+                    int W, int top, int left, int new_h, int new_w, const int32_t* xtab, const int32_t* ytab,
+                    void* stream);
 
 #ifdef __cplusplus
 }

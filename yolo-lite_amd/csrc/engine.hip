@@ -731,3 +731,58 @@ extern "C" int yl_preprocess_u8(const uint8_t* bgr_hwc, int batch, int h, int w,
   YL_HIP(hipGetLastError());
   return 0;
 }
+
+// ------------------------------------------------------------------- letterbox on the device
+// Reference data/augment.py:636-681 (LetterBox.__call__: cv2.resize INTER_LINEAR + copyMakeBorder(114))
+// followed by predictor.py:77-81 (stack, BGR -> RGB, HWC -> CHW), for ONE source image into slot b of the
+// uint8 NCHW batch.  The bilinear arithmetic is OpenCV's published 8-bit fixed-point scheme, restated in
+// data/augment.py::resize_linear_u8 (the CPU oracle of this kernel; cv2 itself is absent, so pixel parity
+// with cv2 stays unpinned): horizontal pass with 11-bit coefficients, >> 4, vertical pass (b * s) >> 16,
+// + 2, >> 2.  The coefficient tables come from the host (x: [x0, x1, a0, a1] per output column, y likewise)
+// so the float -> fixed conversion is the CPU restatement's own and the integer part is bit-exact.
+__global__ void letterbox_u8_kernel(const uint8_t* __restrict__ src, int sh, int sw, int spitch,
+                                    uint8_t* __restrict__ dst, int H, int W, int top, int left, int nh, int nw,
+                                    const int4* __restrict__ xt, const int4* __restrict__ yt, int resize) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= W) return;
+  const int HW = H * W;
+  uint8_t* o = dst + y * W + x;
+  const int ux = x - left, uy = y - top;
+  if (ux < 0 || ux >= nw || uy < 0 || uy >= nh) {
+    o[0] = o[HW] = o[2 * HW] = 114;
+    return;
+  }
+  if (!resize) {  // same size: copy (augment.py:665 skips cv2.resize)
+    const uint8_t* p = src + (long long)uy * spitch + ux * 3;
+    o[0] = p[2], o[HW] = p[1], o[2 * HW] = p[0];
+    return;
+  }
+  const int4 cx = xt[ux], cy = yt[uy];
+  const uint8_t* r0 = src + (long long)cy.x * spitch;
+  const uint8_t* r1 = src + (long long)cy.y * spitch;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const int h0 = r0[cx.x * 3 + c] * cx.z + r0[cx.y * 3 + c] * cx.w;  // scaled by 2^11
+    const int h1 = r1[cx.x * 3 + c] * cx.z + r1[cx.y * 3 + c] * cx.w;
+    int v = (((cy.z * (h0 >> 4)) >> 16) + ((cy.w * (h1 >> 4)) >> 16) + 2) >> 2;
+    v = v < 0 ? 0 : (v > 255 ? 255 : v);
+    o[(2 - c) * HW] = (uint8_t)v;  // BGR -> RGB
+  }
+}
+
+extern "C" int yl_letterbox_u8(const uint8_t* src_bgr_hwc, int src_h, int src_w, int src_pitch, uint8_t* dst_chw,
+                               int H, int W, int top, int left, int new_h, int new_w, const int32_t* xtab,
+                               const int32_t* ytab, void* stream) {
+  if (!src_bgr_hwc || !dst_chw || src_h <= 0 || src_w <= 0 || H <= 0 || W <= 0 || new_h <= 0 || new_w <= 0 ||
+      src_pitch < 3 * src_w)
+    return fail(-1, "yl_letterbox_u8: bad arguments");
+  if (top < 0 || left < 0 || top + new_h > H || left + new_w > W)
+    return fail(-1, "yl_letterbox_u8: the resized image does not fit the output");
+  const int resize = !(new_h == src_h && new_w == src_w);
+  if (resize && (!xtab || !ytab)) return fail(-1, "yl_letterbox_u8: coefficient tables missing");
+  hipLaunchKernelGGL(letterbox_u8_kernel, dim3((W + 255) / 256, H), dim3(256), 0, (hipStream_t)stream, src_bgr_hwc,
+                     src_h, src_w, src_pitch, dst_chw, H, W, top, left, new_h, new_w,
+                     reinterpret_cast<const int4*>(xtab), reinterpret_cast<const int4*>(ytab), resize);
+  YL_HIP(hipGetLastError());
+  return 0;
+}

@@ -86,3 +86,59 @@ class LetterBox:
         out = np.full((img.shape[0] + top + bottom, img.shape[1] + left + right, img.shape[2]), 114, dtype=img.dtype)
         out[top: top + img.shape[0], left: left + img.shape[1]] = img
         return out
+
+
+class DeviceLetterBox:
+    """LetterBox + stack + BGR->RGB + HWC->CHW on the GPU (``yl_letterbox_u8``): the raw uint8 source images
+    cross PCIe (fewer bytes than the letterboxed float batch) and one kernel per image writes its slot of the
+    uint8 NCHW batch the network's first layer reads.  Geometry = ``LetterBox.geometry``; pixels = the same
+    fixed-point arithmetic as ``resize_linear_u8`` (bit-identical, tests/test_gpu_frontend.py)."""
+
+    def __init__(self, new_shape=(640, 640), auto=False, stride=32, device="cuda:0"):
+        import torch
+
+        self.lb = LetterBox(new_shape, auto=auto, stride=stride)
+        self.device = torch.device(device)
+        self._tabs = {}
+
+    def _tab(self, dst: int, src: int):
+        import torch
+
+        key = (dst, src)
+        if key not in self._tabs:
+            i0, i1, c0, c1 = _axis_coeffs(dst, src)
+            t = np.stack([i0, i1, c0, c1], axis=1).astype(np.int32)
+            self._tabs[key] = torch.from_numpy(np.ascontiguousarray(t)).to(self.device)
+        return self._tabs[key]
+
+    def __call__(self, images):
+        """list of HWC BGR uint8 arrays (all mapping to one output shape) -> (B, 3, H, W) uint8 tensor on the device."""
+        import torch
+
+        from .. import _lib
+
+        L = _lib.lib()
+        geos = [self.lb.geometry(im.shape[:2]) for im in images]
+        shapes = {(nu[1] + p[0] + p[1], nu[0] + p[2] + p[3]) for nu, p, _ in geos}
+        if len(shapes) != 1:
+            raise ValueError(f"images letterbox to different shapes {sorted(shapes)}; batch them by shape")
+        H, W = shapes.pop()
+        out = torch.empty((len(images), 3, H, W), dtype=torch.uint8, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        keep = []
+        for b, (im, (new_unpad, (top, _bottom, left, _right), _)) in enumerate(zip(images, geos)):
+            if im.ndim != 3 or im.shape[2] != 3 or im.dtype != np.uint8:
+                raise TypeError("DeviceLetterBox takes HWC uint8 images with 3 channels")
+            src = torch.from_numpy(np.ascontiguousarray(im)).to(self.device, non_blocking=True)
+            keep.append(src)
+            h, w = im.shape[:2]
+            nw, nh = new_unpad
+            resize = (w, h) != (nw, nh)
+            xt = self._tab(nw, w) if resize else None
+            yt = self._tab(nh, h) if resize else None
+            _lib.check(L.yl_letterbox_u8(src.data_ptr(), h, w, 3 * w, out[b].data_ptr(), H, W, top, left, nh, nw,
+                                         xt.data_ptr() if resize else None, yt.data_ptr() if resize else None, stream),
+                       "yl_letterbox_u8")
+        for t in keep:  # the uploads must outlive the kernels queued on this stream
+            t.record_stream(torch.cuda.current_stream(self.device))
+        return out

@@ -62,6 +62,9 @@ class DetectionPredictor:
         """BCHW tensor passthrough, or list of HWC BGR uint8 -> letterbox -> RGB CHW /255
         (reference predictor.py:67-85)."""
         not_tensor = not isinstance(im, torch.Tensor)
+        if not_tensor and self.device is not None and torch.device(self.device).type == "cuda" and \
+                type(self).pre_transform is DetectionPredictor.pre_transform:
+            return self._device_letterbox(im)  # letterbox + RGB + CHW on the GPU, uint8 batch for the stem
         if not_tensor:
             im = np.stack(self.pre_transform(im))
             im = im[..., ::-1].transpose((0, 3, 1, 2))
@@ -70,6 +73,16 @@ class DetectionPredictor:
         if not_tensor:
             return im  # uint8: the engine's input kernel divides by 255 (predictor.py:82-84)
         return im if im.dtype in (torch.float16, torch.float32, torch.uint8) else im.float()
+
+    def _device_letterbox(self, im: List[np.ndarray]):
+        from ..data.augment import DeviceLetterBox
+
+        same_shapes = len({x.shape for x in im}) == 1
+        key = (tuple(self.imgsz) if isinstance(self.imgsz, (list, tuple)) else self.imgsz, bool(same_shapes and self.model.pt))
+        cache = self.__dict__.setdefault("_dlb", {})
+        if key not in cache:
+            cache[key] = DeviceLetterBox(self.imgsz, auto=key[1], stride=self.model.stride, device=self.device)
+        return cache[key](im)
 
     def pre_transform(self, im: List[np.ndarray]):
         same_shapes = len({x.shape for x in im}) == 1
