@@ -55,3 +55,20 @@ def test_predict_image_list_uses_device_letterbox(gpu_device):
     out, cnt = eng.detect(x, 0.25, 0.7, max_det=300, scale=torch.tensor(sc, dtype=torch.float32, device=gpu_device), graph=False)
     for i, r in enumerate(res):
         assert torch.equal(r.boxes.data, out[i, : int(cnt[i])])
+
+
+def test_predict_saves_annotated_images_and_crops(gpu_device, tmp_path):
+    """save=True / save_crop=True / save_txt=True on an image source write the reference's files (PIL-drawn)."""
+    from yololite_amd import YOLOLite
+
+    g = np.random.default_rng(9)
+    images = [g.integers(0, 256, (200, 320, 3), dtype=np.uint8) for _ in range(2)]
+    model = YOLOLite("yolo11n.yaml")
+    res = model.predict(images, conf=0.05, imgsz=320, device=str(gpu_device), save=True, save_crop=True, save_txt=True,
+                        project=str(tmp_path), name="run", verbose=False)
+    d = tmp_path / "run"
+    assert sorted(p.name for p in d.glob("*.jpg")) == ["image0.jpg", "image1.jpg"]
+    n = sum(len(r) for r in res)
+    if n:
+        assert len(list((d / "crops").rglob("*.jpg"))) == n
+        assert sum(len(f.read_text().strip().splitlines()) for f in (d / "labels").glob("*.txt")) == n

@@ -113,14 +113,16 @@ def test_model_facade():
         m.predict(torch.rand(1, 3, 64, 64), cnof=1)
 
 
-def _fake_reference_module_tree(sd, yaml_d):
+def _fake_reference_module_tree(sd, yaml_d, pkg="yololite"):
     """Build nn.Modules under the reference's pickle GLOBAL names (yololite.nn.tasks.DetectionModel,
-    yololite.nn.modules.conv.Conv, ...) so torch.save writes the same kind of pickle the reference does."""
+    yololite.nn.modules.conv.Conv, ...; pkg="ultralytics": the upstream names) so torch.save writes the same
+    kind of pickle the reference / upstream does."""
     import torch.nn as nn
 
     mods = {}
     for name in ("yololite", "yololite.nn", "yololite.nn.tasks", "yololite.nn.modules", "yololite.nn.modules.conv",
                  "yololite.nn.modules.block", "yololite.nn.modules.head"):
+        name = name.replace("yololite", pkg)
         mods[name] = types.ModuleType(name)
 
     def mk(modname, clsname):
@@ -128,9 +130,9 @@ def _fake_reference_module_tree(sd, yaml_d):
         setattr(mods[modname], clsname, cls)
         return cls
 
-    Generic = mk("yololite.nn.modules.block", "C3k2")
-    Conv = mk("yololite.nn.modules.conv", "Conv")
-    Det = mk("yololite.nn.tasks", "DetectionModel")
+    Generic = mk(f"{pkg}.nn.modules.block", "C3k2")
+    Conv = mk(f"{pkg}.nn.modules.conv", "Conv")
+    Det = mk(f"{pkg}.nn.tasks", "DetectionModel")
     root = Det()
     # rebuild the hierarchy from the state-dict keys
     for key, val in sd.items():
@@ -181,6 +183,34 @@ def test_pt_loader_restricted_unpickler(tmp_path):
     assert y.ckpt_path == str(f) and y.overrides["imgsz"] == 640 and y.names[0] == "cls0"
 
 
+def test_pt_loader_ultralytics_namespace_and_stripped_checkpoint(tmp_path):
+    """an upstream-style checkpoint -- `ultralytics.nn.*` pickle globals, `strip_optimizer` form
+    (torch_utils.py:355-399: ema None, optimizer None, fp16 `model`), class names as a list -- loads the same way."""
+    from yololite_amd.nn import arch
+    from yololite_amd.nn.synth import synth_state_dict
+
+    sd = synth_state_dict("s", 3)
+    yaml_d = arch.yolo11_dict("s")
+    root, mods = _fake_reference_module_tree(sd, yaml_d, pkg="ultralytics")
+    root.names = [f"thing{i}" for i in range(yaml_d["nc"])]
+    sys.modules.update(mods)
+    try:
+        ckpt = {"epoch": -1, "best_fitness": None, "model": root.half(), "ema": None, "updates": None, "optimizer": None,
+                "train_args": {"imgsz": 640, "data": "coco.yaml", "model": "yolo11s.pt"}, "version": "8.3.0"}
+        f = tmp_path / "yolo11s.pt"
+        torch.save(ckpt, f)
+    finally:
+        for k in mods:
+            sys.modules.pop(k, None)
+    assert "ultralytics" not in sys.modules
+    model, _ = attempt_load_one_weight(str(f))
+    assert "ultralytics" not in sys.modules
+    assert model.names[79] == "thing79" and model.yaml["scale"] == "s"
+    got = model.state_dict()
+    assert set(got) == set(sd)
+    assert all(torch.equal(got[k], sd[k].half().float()) for k in sd if sd[k].is_floating_point())
+
+
 def test_pt_loader_blocks_code_execution(tmp_path):
     class Evil:
         def __reduce__(self):
@@ -195,3 +225,39 @@ def test_pt_loader_blocks_code_execution(tmp_path):
     with pytest.raises(Exception):
         attempt_load_one_weight(str(f))
     assert not os.path.exists("/tmp/yl_pwned"), "restricted unpickler executed a pickled callable"
+
+
+def test_result_sinks_plot_save_crop_txt_json(tmp_path):
+    """Results.plot / save / save_crop / save_txt / to_json on a hand-made result."""
+    import json
+
+    import numpy as np
+
+    from yololite_amd.engine.results import Results
+
+    img = np.full((120, 160, 3), 30, np.uint8)
+    img[40:80, 50:110] = (0, 0, 255)  # a red rectangle (BGR)
+    boxes = torch.tensor([[50.0, 40.0, 110.0, 80.0, 0.9, 1.0], [5.0, 5.0, 20.0, 30.0, 0.4, 0.0]])
+    r = Results(img, path="a/b/frame.jpg", names={0: "cat", 1: "box"}, boxes=boxes)
+    out = r.plot()
+    assert out.shape == img.shape and out.dtype == np.uint8 and (out != img).any()
+    assert tuple(out[60, 80]) == (0, 0, 255)  # interior untouched, still BGR
+    assert tuple(out[40, 80]) != (0, 0, 255)  # the outline was drawn in the class colour
+    pil = r.plot(pil=True, conf=False)
+    assert pil.size == (160, 120)
+    f = r.save(tmp_path / "annotated.png")
+    assert (tmp_path / "annotated.jpg").exists() and str(f).endswith("annotated.png")
+    r.save_crop(tmp_path / "crops", file_name="x.jpg")
+    r.save_crop(tmp_path / "crops", file_name="x.jpg")  # second call increments the name
+    assert (tmp_path / "crops" / "box" / "x.jpg").exists() and (tmp_path / "crops" / "box" / "x2.jpg").exists()
+    assert (tmp_path / "crops" / "cat" / "x.jpg").exists()
+    from PIL import Image
+    crop = Image.open(tmp_path / "crops" / "box" / "x.jpg")
+    assert crop.size == (round(60 * 1.02 + 10), round(40 * 1.02 + 10))  # gain 1.02, pad 10 (plotting.py:785)
+    r.save_txt(tmp_path / "l.txt", save_conf=True)
+    lines = (tmp_path / "l.txt").read_text().strip().splitlines()
+    assert lines[0].split()[0] == "1" and len(lines[0].split()) == 6 and abs(float(lines[0].split()[1]) - 0.5) < 1e-6
+    js = json.loads(r.to_json(normalize=True))
+    assert js[0]["name"] == "box" and abs(js[0]["box"]["x2"] - 110 / 160) < 1e-5
+    with pytest.raises(ValueError):
+        Results(None, path="p", names={0: "a"}, boxes=boxes[:1], orig_shape=(120, 160)).plot()

@@ -7,8 +7,8 @@ Differences from the reference, all deliberate and documented in DESIGN.md:
   output stage; one host sync (the per-image counts) per batch instead of three ``synchronize`` s.
 * for tensor sources the uint8 host copy of the input (``convert_torch2numpy_batch``,
   predictor.py:120-121) is only made when ``keep_orig_img=True``; ``Results.orig_shape`` is always set.
-* saving / plotting / showing are result sinks outside the accelerated path: ``save=True`` is
-  accepted (the reference's ``predict`` forces it) but nothing is drawn; ``save_txt`` works.
+* saving / plotting are result sinks outside the accelerated path, drawn with PIL instead of cv2
+  (``save``, ``save_crop``, ``save_txt`` work for image sources; ``show`` needs a display and raises).
 """
 from __future__ import annotations
 
@@ -202,7 +202,7 @@ class DetectionPredictor:
                     self.results[i].speed = {"preprocess": profilers[0].dt * 1e3 / n,
                                              "inference": profilers[1].dt * 1e3 / n,
                                              "postprocess": profilers[2].dt * 1e3 / n}
-                    if self.args.verbose or self.args.save_txt:
+                    if self.args.verbose or self.args.save_txt or self.args.save or self.args.save_crop:
                         s[i] += self.write_results(i, Path(paths[i]), im, s)
                 if self.args.verbose:
                     LOGGER.info("\n".join(s))
@@ -222,4 +222,14 @@ class DetectionPredictor:
             self.txt_path = self.save_dir / "labels" / p.stem
             result.save_dir = str(self.save_dir)
             result.save_txt(f"{self.txt_path}.txt", save_conf=self.args.save_conf)
+        # image sinks (reference predictor.py:270-283): only when the source image is at hand (image sources;
+        # tensor sources keep none unless keep_orig_img=True)
+        if result.orig_img is not None and (self.args.save or self.args.save_crop):
+            result.save_dir = str(self.save_dir)
+            if self.args.save_crop:
+                result.save_crop(save_dir=self.save_dir / "crops", file_name=p.stem)
+            if self.args.save:
+                self.save_dir.mkdir(parents=True, exist_ok=True)
+                result.save(str(self.save_dir / p.name), conf=self.args.show_conf, labels=self.args.show_labels,
+                            boxes=self.args.show_boxes, line_width=self.args.line_width)
         return string

@@ -1,7 +1,8 @@
 """Result containers with the reference's accessors (``yololite/engine/results.py:13-101, 443-580``).
 
-``plot`` / ``save_crop`` (cv2 drawing) are result sinks outside the accelerated path; ``save_txt``,
-``summary``, ``to_json`` / ``tojson`` and ``verbose`` are plain Python and are provided.
+``save_txt``, ``summary``, ``to_json`` / ``tojson`` and ``verbose`` are plain Python; ``plot`` / ``save`` /
+``save_crop`` are result sinks outside the accelerated path, drawn with PIL (utils/plotting.py) because the
+reference's default cv2 drawing is unavailable.
 """
 from __future__ import annotations
 
@@ -190,8 +191,44 @@ class Results(SimpleClass):
             with open(txt_file, "a") as f:
                 f.writelines(t + "\n" for t in texts)
 
-    def plot(self, *args, **kwargs):
-        raise NotImplementedError("Results.plot draws with cv2; result sinks are outside the accelerated path")
+    def plot(self, conf=True, line_width=None, font_size=None, font="Arial.ttf", pil=False, img=None, labels=True,
+             boxes=True, show=False, save=False, filename=None, color_mode="class"):
+        """Annotated copy of the image (reference results.py:130-244).  Drawn with PIL (cv2 is absent): returns a
+        BGR ``np.ndarray`` like the reference, or the PIL image when ``pil=True``."""
+        from ..utils.plotting import Annotator, colors
 
-    def save_crop(self, *args, **kwargs):
-        raise NotImplementedError("Results.save_crop is outside the accelerated path")
+        assert color_mode in {"instance", "class"}, f"Expected color_mode='instance' or 'class', not {color_mode}."
+        if show:
+            raise NotImplementedError("show=True needs a display (cv2.imshow); save the image instead")
+        if img is None:
+            img = self.orig_img
+            if isinstance(img, torch.Tensor):  # (1, 3, H, W) RGB in [0, 1] -> HWC BGR uint8
+                img = (img[0].detach().permute(1, 2, 0).contiguous() * 255).to(torch.uint8).cpu().numpy()[..., ::-1]
+        if img is None:
+            raise ValueError("plot() needs the source image: predict with keep_orig_img=True or pass img=")
+        ann = Annotator(np.ascontiguousarray(np.asarray(img)[..., ::-1]), line_width, font_size)  # BGR -> RGB
+        if self.boxes is not None and boxes:
+            for i, d in enumerate(reversed(self.boxes)):
+                c = int(d.cls)
+                name = self.names[c]
+                label = (f"{name} {float(d.conf):.2f}" if conf else name) if labels else None
+                ann.box_label(d.xyxy.reshape(-1), label, color=colors(c if color_mode == "class" else i))
+        if save:
+            ann.im.save(filename or f"results_{Path(self.path or 'image0').stem}.jpg")
+        return ann.im if pil else ann.result()[..., ::-1].copy()
+
+    def save(self, filename=None, *args, **kwargs):
+        """Save the annotated image (reference results.py: save)."""
+        filename = filename or f"results_{Path(self.path or 'image0').name}"
+        self.plot(save=True, filename=str(Path(filename).with_suffix(".jpg")), *args, **kwargs)
+        return filename
+
+    def save_crop(self, save_dir, file_name=Path("im.jpg")):
+        """One crop per detection under save_dir/<class name>/ (reference results.py:289-312)."""
+        from ..utils.plotting import save_one_box
+
+        if self.orig_img is None:
+            raise ValueError("save_crop() needs the source image: predict with keep_orig_img=True")
+        for d in self.boxes:
+            save_one_box(d.xyxy, np.asarray(self.orig_img).copy(),
+                         file=Path(save_dir) / self.names[int(d.cls)] / Path(file_name).with_suffix(".jpg"), BGR=True)
