@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define YL_ABI_VERSION 5
+#define YL_ABI_VERSION 6
 
 /* element types */
 enum { YL_BF16 = 0, YL_F32 = 1, YL_F16 = 2, YL_U8 = 3 };
@@ -166,6 +166,17 @@ int64_t yl_nms_workspace_bytes(int batch, int anchors, int max_cand);
 int yl_nms(const float* pred, int batch, int nc, int anchors, float conf_thres, float iou_thres,
            int max_det, int agnostic, const int32_t* classes, int n_classes, int max_cand,
            float max_wh, const float* scale, float* out, int32_t* out_count, void* work, void* stream);
+
+/* Multi-label NMS: the validator's postprocess (engine/validator.py:281-291 calls non_max_suppression with
+ * multi_label=True; utils/ops.py:208, 239-241): EVERY (anchor, class) pair with score > conf_thres is a
+ * candidate row, capped to the max_cand best by score, then the same class-aware NMS.  Same arguments as
+ * yl_nms; `work` must hold yl_nms_ml_workspace_bytes(B, nc, A, max_cand) bytes (keys for up to nc * A pairs
+ * per image).  With nc == 1 it degenerates to yl_nms, as the reference does.  Equal scores keep the
+ * reference's row order (anchor-major, then class). */
+int64_t yl_nms_ml_workspace_bytes(int batch, int nc, int anchors, int max_cand);
+int yl_nms_ml(const float* pred, int batch, int nc, int anchors, float conf_thres, float iou_thres,
+              int max_det, int agnostic, const int32_t* classes, int n_classes, int max_cand,
+              float max_wh, const float* scale, float* out, int32_t* out_count, void* work, void* stream);
 
 /* Fused Detect decode + NMS straight from the raw level maps in the workspace: identical results
  * to yl_detect_decode followed by yl_nms (same decode arithmetic, same candidate order), but

@@ -337,9 +337,12 @@ def nms_greedy(boxes: np.ndarray, scores: np.ndarray, iou_thres: float) -> np.nd
 
 def non_max_suppression(prediction: torch.Tensor, conf_thres: float = 0.25, iou_thres: float = 0.45,
                         classes: Optional[Sequence[int]] = None, agnostic: bool = False,
-                        max_det: int = 300, max_nms: int = 30000, max_wh: int = 7680) -> List[torch.Tensor]:
-    """utils/ops.py:138-273 (single-label, no masks, not rotated, no wall-clock limit —
-    the reference's time-limit break, ops.py:269-271, is a load-dependent defect we do not restate).
+                        max_det: int = 300, max_nms: int = 30000, max_wh: int = 7680,
+                        multi_label: bool = False) -> List[torch.Tensor]:
+    """utils/ops.py:138-273 (no masks, not rotated, no `labels`, no wall-clock limit — the reference's
+    time-limit break, ops.py:269-271, is a load-dependent defect we do not restate).  ``multi_label`` is the
+    validator's mode (engine/validator.py:281-291): every (anchor, class) pair above the threshold is a row
+    (ops.py:239-241), in ``torch.where`` order, and ties in the cap / NMS sorts keep that order (stable).
 
     prediction: (B, 4+nc, A) fp32, rows [cx, cy, w, h, scores...].  Not modified (the reference
     converts in place, ops.py:212-213).
@@ -357,8 +360,12 @@ def non_max_suppression(prediction: torch.Tensor, conf_thres: float = 0.25, iou_
         if not x.shape[0]:
             continue
         box, cls = x[:, :4], x[:, 4:]
-        conf, j = cls.max(1, keepdim=True)  # first max wins on ties, ops.py:243
-        x = torch.cat((box, conf, j.float()), 1)[conf.view(-1) > conf_thres]  # ops.py:244
+        if multi_label and nc > 1:  # ops.py:208, 239-241
+            i, j = torch.where(cls > conf_thres)
+            x = torch.cat((box[i], x[i, 4 + j, None], j[:, None].float()), 1)
+        else:
+            conf, j = cls.max(1, keepdim=True)  # first max wins on ties, ops.py:243
+            x = torch.cat((box, conf, j.float()), 1)[conf.view(-1) > conf_thres]  # ops.py:244
         if classes is not None:
             x = x[(x[:, 5:6] == torch.tensor(classes, dtype=torch.float32)).any(1)]  # ops.py:247-248
         n = x.shape[0]

@@ -311,3 +311,45 @@ def test_slots_in_flight_on_two_streams(gpu_device, golden):
             n = int(ref[j][1][i])
             assert torch.equal(got[j][0][i, :n], ref[j][0][i, :n])
     assert int(ref[0][1].sum()) > 0
+
+
+@pytest.mark.parametrize("conf,kw", [(0.001, {}), (0.001, dict(agnostic=True)), (0.25, dict(classes=[3, 17])),
+                                     (0.05, dict(max_det=50))])
+def test_nms_multi_label_vs_oracle(gpu_device, conf, kw):
+    """Validator mode (engine/validator.py:281-291: conf 0.001, multi_label=True): every (anchor, class) pair
+    above the threshold is a row; bit-exact against the oracle, thousands of candidates per image."""
+    g = torch.Generator().manual_seed(31)
+    B, A, nc = 3, 2100, 80
+    p = torch.zeros(B, 4 + nc, A)
+    p[:, 0:2] = torch.rand(B, 2, A, generator=g) * 600 + 20
+    p[:, 2:4] = torch.rand(B, 2, A, generator=g) * 120 + 8
+    sc = torch.rand(B, nc, A, generator=g) ** 12  # most pairs far below 0.001, a few per anchor above
+    hot = torch.rand(B, 1, A, generator=g) < 0.1
+    sc = torch.where(hot, torch.rand(B, nc, A, generator=g) ** 3, sc)
+    p[:, 4:] = sc
+    ref = oracle.non_max_suppression(p, conf, 0.7, multi_label=True, **kw)
+    got = hops.non_max_suppression(p.to(gpu_device), conf, 0.7, multi_label=True, **kw)
+    npairs = int((sc > conf).sum())
+    assert npairs > 3000 * B or conf > 0.01, npairs
+    for r, q in zip(ref, got):
+        np.testing.assert_array_equal(q.cpu().numpy(), r.numpy())
+
+
+def test_nms_multi_label_cap_and_single_class(gpu_device):
+    """More pairs than max_nms: the best max_nms by score survive the cap (ops.py:254-255); nc == 1 degenerates
+    to the single-label path (ops.py:208)."""
+    g = torch.Generator().manual_seed(32)
+    B, A, nc = 2, 1200, 16
+    p = torch.zeros(B, 4 + nc, A)
+    p[:, 0:2] = torch.rand(B, 2, A, generator=g) * 600 + 20
+    p[:, 2:4] = torch.rand(B, 2, A, generator=g) * 40 + 8
+    p[:, 4:] = torch.rand(B, nc, A, generator=g) * 0.9 + 0.05  # all 19200 pairs above 0.01
+    ref = oracle.non_max_suppression(p, 0.01, 0.5, multi_label=True, max_nms=5000)
+    got = hops.non_max_suppression(p.to(gpu_device), 0.01, 0.5, multi_label=True, max_nms=5000)
+    for r, q in zip(ref, got):
+        np.testing.assert_array_equal(q.cpu().numpy(), r.numpy())
+    p1 = p[:, :5].contiguous()
+    ref = oracle.non_max_suppression(p1, 0.3, 0.5, multi_label=True)
+    got = hops.non_max_suppression(p1.to(gpu_device), 0.3, 0.5, multi_label=True)
+    for r, q in zip(ref, got):
+        np.testing.assert_array_equal(q.cpu().numpy(), r.numpy())

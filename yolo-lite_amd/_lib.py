@@ -28,7 +28,7 @@ EXPORTS = (
     "yl_last_error", "yl_abi_version", "yl_device_count", "yl_engine_create", "yl_engine_destroy",
     "yl_engine_prepare_workspace", "yl_engine_forward", "yl_engine_forward_graph", "yl_engine_profile", "yl_engine_num_ops",
     "yl_engine_op_info", "yl_engine_detect_graph", "yl_detect_decode", "yl_nms_workspace_bytes", "yl_nms", "yl_decode_nms",
-    "yl_preprocess_u8", "yl_letterbox_u8",
+    "yl_preprocess_u8", "yl_letterbox_u8", "yl_nms_ml_workspace_bytes", "yl_nms_ml",
 )
 
 
@@ -115,6 +115,10 @@ def lib() -> C.CDLL:
     L.yl_nms_workspace_bytes.argtypes = [i32, i32, i32]
     L.yl_nms.restype = i32
     L.yl_nms.argtypes = [vp, i32, i32, i32, f32, f32, i32, i32, vp, i32, i32, f32, vp, vp, vp, vp, vp]
+    L.yl_nms_ml_workspace_bytes.restype = i64
+    L.yl_nms_ml_workspace_bytes.argtypes = [i32, i32, i32, i32]
+    L.yl_nms_ml.restype = i32
+    L.yl_nms_ml.argtypes = L.yl_nms.argtypes
     L.yl_decode_nms.restype = i32
     L.yl_decode_nms.argtypes = [vp, C.POINTER(Level), i32, i32, i32, f32, f32, i32, i32, vp, i32, i32, f32, vp, vp, vp,
                                 vp, vp]
@@ -124,7 +128,7 @@ def lib() -> C.CDLL:
     L.yl_preprocess_u8.argtypes = [vp, i32, i32, i32, vp, vp]
     L.yl_letterbox_u8.restype = i32
     L.yl_letterbox_u8.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]
-    if L.yl_abi_version() != 5:
+    if L.yl_abi_version() != 6:
         raise RuntimeError("libyl_amd.so ABI version mismatch; rebuild it")
     _lib = L
     return L

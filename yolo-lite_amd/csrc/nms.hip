@@ -35,6 +35,7 @@ struct NmsWs {
   unsigned long long* mask;  // [B][M][MW]
   float4* cbox;         // [B][A] (cx, cy, w, h) of candidate anchors (fused decode path only)
   int KP, M, MW;
+  int ml_nc;            // > 0: multi-label mode, the low key word is anchor * nc + class (ops.py:239-241)
 };
 
 static inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
@@ -44,10 +45,11 @@ static int pow2_ge(int x) {
   return p;
 }
 
-static int64_t nms_layout(int B, int A, int max_cand, char* base, NmsWs* w) {
-  const int M = max_cand < A ? max_cand : A;
+static int64_t nms_layout(int B, int A, int max_cand, char* base, NmsWs* w, long long pairs = 0) {
+  const long long cand = pairs > A ? pairs : A;  // candidate rows an image can have (multi-label: nc * A)
+  const int M = max_cand < cand ? max_cand : (int)cand;
   const int MW = (M + 63) / 64;
-  const int KP = pow2_ge(A + 128 * NSUB);  // >= NSUB * sub_cap
+  const int KP = pow2_ge((int)cand + 128 * NSUB);  // >= NSUB * sub_cap
   int64_t o = 0;
   auto take = [&](int64_t bytes) {
     int64_t r = o;
@@ -78,6 +80,7 @@ static int64_t nms_layout(int B, int A, int max_cand, char* base, NmsWs* w) {
     w->KP = KP;
     w->M = M;
     w->MW = MW;
+    w->ml_nc = 0;
   }
   return o;
 }
@@ -108,6 +111,43 @@ __global__ void nms_candidates_kernel(const float* __restrict__ pred, int nc, in
   const unsigned sb = __float_as_uint(best);  // positive floats order like their bit patterns
   w.keys[(long long)b * w.KP + slot] = ((unsigned long long)(~sb) << 32) | (unsigned)a;
   w.cls_of[(long long)b * A + a] = bi;
+}
+
+// ---- 1b. multi-label candidates (the validator's mode, ops.py:239-241): EVERY (anchor, class) pair with
+// score > conf is a row.  One thread per anchor walks the classes; the appends of a wavefront are
+// aggregated into one atomic per class step (a per-image counter would otherwise see up to nc * A
+// same-address atomics).  Key = (~score, anchor * nc + class): equal scores keep torch.where order.
+__global__ void nms_candidates_ml_kernel(const float* __restrict__ pred, int nc, int A, float conf_thres,
+                                         const int32_t* __restrict__ classes, int n_classes, NmsWs w) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & 63;
+  const float* p = pred + (long long)b * (4 + nc) * A + 4LL * A + (a < A ? a : 0);
+  for (int c = 0; c < nc; ++c) {
+    bool keep = false;
+    float v = 0.f;
+    if (a < A) {
+      v = p[(long long)c * A];
+      keep = v > conf_thres;
+    }
+    if (keep && classes) {
+      bool ok = false;
+      for (int i = 0; i < n_classes; ++i) ok |= (classes[i] == c);
+      keep = ok;
+    }
+    const unsigned long long m = __ballot(keep);
+    if (m == 0) continue;
+    int base = 0;
+    const int leader = __ffsll((long long)m) - 1;
+    if (lane == leader) base = atomicAdd(&w.count[b], __popcll(m));
+    base = __shfl(base, leader);
+    if (keep) {
+      const int slot = base + __popcll(m & ((1ull << lane) - 1ull));
+      if (slot < w.KP)
+        w.keys[(long long)b * w.KP + slot] =
+            ((unsigned long long)(~__float_as_uint(v)) << 32) | (unsigned)(a * nc + c);
+    }
+  }
 }
 
 // ---- 2. sort by (score desc, anchor asc); gather boxes in xyxy + class offset
@@ -171,7 +211,8 @@ __global__ __launch_bounds__(1024) void nms_sort_kernel(const float* __restrict_
     }
   } else {
     n = w.count[b];
-    if (n > A) n = A;
+    const int nmax = w.ml_nc ? min(w.KP, A * w.ml_nc) : A;
+    if (n > nmax) n = nmax;
     while (np < n) np <<= 1;
     k = (np <= SORT_LDS_KEYS) ? sk : gk;
     if (k == sk) {
@@ -193,9 +234,10 @@ __global__ __launch_bounds__(1024) void nms_sort_kernel(const float* __restrict_
   const float* pb = pred ? pred + (long long)b * (4 + nc) * A : nullptr;
   for (int i = tid; i < nf; i += 1024) {
     const unsigned long long key = k[i];
-    const int a = min((int)(key & 0xffffffffu), A - 1);  // never index out of range, whatever the key holds
+    const unsigned lo = (unsigned)(key & 0xffffffffu);
+    const int a = min((int)(w.ml_nc ? lo / (unsigned)w.ml_nc : lo), A - 1);  // never out of range, whatever the key holds
     const float score = __uint_as_float(~(unsigned)(key >> 32));
-    const int cls = w.cls_of[(long long)b * A + a];
+    const int cls = w.ml_nc ? (int)(lo % (unsigned)w.ml_nc) : w.cls_of[(long long)b * A + a];
     float cx, cy, bw, bh;
     if (pb) {
       cx = pb[a], cy = pb[A + a], bw = pb[2LL * A + a], bh = pb[3LL * A + a];
@@ -409,6 +451,39 @@ extern "C" int yl_nms(const float* pred, int batch, int nc, int anchors, float c
   YL_HIP(hipMemsetAsync(w.count, 0, 4 * (size_t)batch, s));
   hipLaunchKernelGGL(nms_candidates_kernel, dim3((anchors + 255) / 256, batch), dim3(256), 0, s, pred, nc, anchors,
                      conf_thres, classes, classes ? n_classes : 0, w);
+  hipLaunchKernelGGL(nms_sort_kernel, dim3(batch), dim3(1024), 0, s, pred, nc, anchors, agnostic, max_wh, w);
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(64, batch), dim3(256), 0, s, iou_thres, w);
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(batch), dim3(64), 0, s, max_det, scale, out, out_count, w);
+  YL_HIP(hipGetLastError());
+  return 0;
+}
+
+/* multi-label variant (the validator's postprocess, engine/validator.py:281-291 -> ops.py:239-241) */
+extern "C" int64_t yl_nms_ml_workspace_bytes(int batch, int nc, int anchors, int max_cand) {
+  if (batch <= 0 || nc <= 0 || anchors <= 0 || max_cand <= 0 || (long long)nc * anchors > (1LL << 30)) return -1;
+  return nms_layout(batch, anchors, max_cand, nullptr, nullptr, (long long)nc * anchors);
+}
+
+extern "C" int yl_nms_ml(const float* pred, int batch, int nc, int anchors, float conf_thres, float iou_thres,
+                         int max_det, int agnostic, const int32_t* classes, int n_classes, int max_cand, float max_wh,
+                         const float* scale, float* out, int32_t* out_count, void* work, void* stream) {
+  if (!pred || !out || !out_count || !work) return fail(-1, "yl_nms_ml: null pointer");
+  if (batch <= 0 || nc <= 0 || anchors <= 0 || max_det <= 0 || max_cand <= 0 || (long long)nc * anchors > (1LL << 30))
+    return fail(-1, "yl_nms_ml: bad sizes");
+  if (!(conf_thres >= 0.f && conf_thres <= 1.f) || !(iou_thres >= 0.f && iou_thres <= 1.f))
+    return fail(-4, "yl_nms_ml: thresholds must lie in [0, 1]");  // ops.py:186-187 AssertionError
+  NmsWs w;
+  nms_layout(batch, anchors, max_cand, (char*)work, &w, (long long)nc * anchors);
+  if (w.M > 64 * 64 * SCAN_T) return fail(-3, "yl_nms_ml: max_cand above 32768 is not supported");
+  w.ml_nc = nc > 1 ? nc : 0;  // ops.py:208: multi_label &= nc > 1
+  hipStream_t s = (hipStream_t)stream;
+  YL_HIP(hipMemsetAsync(w.count, 0, 4 * (size_t)batch, s));
+  if (w.ml_nc)
+    hipLaunchKernelGGL(nms_candidates_ml_kernel, dim3((anchors + 255) / 256, batch), dim3(256), 0, s, pred, nc, anchors,
+                       conf_thres, classes, classes ? n_classes : 0, w);
+  else
+    hipLaunchKernelGGL(nms_candidates_kernel, dim3((anchors + 255) / 256, batch), dim3(256), 0, s, pred, nc, anchors,
+                       conf_thres, classes, classes ? n_classes : 0, w);
   hipLaunchKernelGGL(nms_sort_kernel, dim3(batch), dim3(1024), 0, s, pred, nc, anchors, agnostic, max_wh, w);
   hipLaunchKernelGGL(nms_mask_kernel, dim3(64, batch), dim3(256), 0, s, iou_thres, w);
   hipLaunchKernelGGL(nms_scan_kernel, dim3(batch), dim3(64), 0, s, max_det, scale, out, out_count, w);

@@ -2,7 +2,8 @@
 
 ``YOLOLite("yolo11n.yaml")`` builds from the architecture table, anything else loads a ``.pt``
 checkpoint; ``model(source)`` == ``model.predict(source)`` returns ``list[Results]``.
-Training and validation are outside the accelerated path and raise ``NotImplementedError``.
+Training is outside the accelerated path and raises ``NotImplementedError``; ``val`` runs the
+DetectionValidator on a caller-supplied dataloader.
 """
 from __future__ import annotations
 
@@ -79,8 +80,16 @@ class YOLOLite:
             self._pred_args = (dict(args), keep)
         return self.predictor(source=source, stream=stream)
 
-    def val(self, **kwargs):
-        raise NotImplementedError("validation is not part of the MI355X predict path (SURVEY.md section 8f-2)")
+    def val(self, dataloader=None, **kwargs):
+        """Reference model.py:101-107 with one addition: ``dataloader=`` (an iterable of the reference's batch
+        dicts), because dataset construction is out of scope here (see engine/validator.py)."""
+        from .validator import DetectionValidator
+
+        args = {**self.overrides, "rect": True, **kwargs, "mode": "val"}
+        validator = DetectionValidator(dataloader=dataloader, args=args)
+        validator(model=self.model)
+        self.metrics = validator.metrics
+        return validator.metrics
 
     def train(self, **kwargs):
         raise NotImplementedError("training is not part of the MI355X predict path")

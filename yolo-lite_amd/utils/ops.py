@@ -45,11 +45,14 @@ class Profile(contextlib.ContextDecorator):
 _NMS_WORK: dict = {}
 
 
-def _nms_workspace(device, batch, anchors, max_cand) -> torch.Tensor:
-    key = (str(device), batch, anchors, max_cand)
+def _nms_workspace(device, batch, anchors, max_cand, ml_nc: int = 0) -> torch.Tensor:
+    key = (str(device), batch, anchors, max_cand, ml_nc)
     w = _NMS_WORK.get(key)
     if w is None:
-        nbytes = _lib.lib().yl_nms_workspace_bytes(batch, anchors, max_cand)
+        if ml_nc:
+            nbytes = _lib.lib().yl_nms_ml_workspace_bytes(batch, ml_nc, anchors, max_cand)
+        else:
+            nbytes = _lib.lib().yl_nms_workspace_bytes(batch, anchors, max_cand)
         if nbytes < 0:
             raise RuntimeError("yl_nms_workspace_bytes failed")
         _NMS_WORK.clear()  # keep a single scratch buffer alive
@@ -59,8 +62,9 @@ def _nms_workspace(device, batch, anchors, max_cand) -> torch.Tensor:
 
 def nms_padded(prediction: torch.Tensor, conf_thres: float, iou_thres: float, classes=None, agnostic=False,
                max_det: int = 300, max_nms: int = 30000, max_wh: float = 7680.0,
-               scale: Optional[torch.Tensor] = None):
-    """GPU NMS returning padded ``(out[B, max_det, 6], count[B])`` device tensors; no host sync."""
+               scale: Optional[torch.Tensor] = None, multi_label: bool = False):
+    """GPU NMS returning padded ``(out[B, max_det, 6], count[B])`` device tensors; no host sync.
+    ``multi_label``: every (anchor, class) pair above the threshold is a candidate (validator mode)."""
     if prediction.device.type != "cuda":
         raise RuntimeError("non_max_suppression runs on the GPU only (HIP kernel, no CPU fallback)")
     if prediction.dtype != torch.float32 or not prediction.is_contiguous():
@@ -68,19 +72,21 @@ def nms_padded(prediction: torch.Tensor, conf_thres: float, iou_thres: float, cl
     B, no, A = prediction.shape
     nc = no - 4
     dev = prediction.device
-    max_cand = min(int(max_nms), A)
-    work = _nms_workspace(dev, B, A, max_cand)
+    multi_label = bool(multi_label) and nc > 1  # ops.py:208
+    max_cand = min(int(max_nms), A * nc if multi_label else A)
+    work = _nms_workspace(dev, B, A, max_cand, nc if multi_label else 0)
     out = torch.empty((B, max_det, 6), dtype=torch.float32, device=dev)
     cnt = torch.empty((B,), dtype=torch.int32, device=dev)
     cls_t = None
     if classes is not None:
         cls_t = torch.as_tensor(list(np.atleast_1d(classes)), dtype=torch.int32, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
-    rc = _lib.lib().yl_nms(prediction.data_ptr(), B, nc, A, float(conf_thres), float(iou_thres), int(max_det),
-                           int(bool(agnostic)), cls_t.data_ptr() if cls_t is not None else None,
-                           int(cls_t.numel()) if cls_t is not None else 0, max_cand, float(max_wh),
-                           scale.data_ptr() if scale is not None else None, out.data_ptr(), cnt.data_ptr(),
-                           work.data_ptr(), stream)
+    fn = _lib.lib().yl_nms_ml if multi_label else _lib.lib().yl_nms
+    rc = fn(prediction.data_ptr(), B, nc, A, float(conf_thres), float(iou_thres), int(max_det),
+            int(bool(agnostic)), cls_t.data_ptr() if cls_t is not None else None,
+            int(cls_t.numel()) if cls_t is not None else 0, max_cand, float(max_wh),
+            scale.data_ptr() if scale is not None else None, out.data_ptr(), cnt.data_ptr(),
+            work.data_ptr(), stream)
     _lib.check(rc, "yl_nms")
     return out, cnt
 
@@ -92,17 +98,19 @@ def non_max_suppression(prediction, conf_thres=0.25, iou_thres=0.45, classes=Non
 
     Differences, all documented: the input is never modified (``in_place`` is accepted and ignored);
     there is no wall-clock bail-out (``max_time_img`` ignored; reference defect ops.py:269-271);
-    ``multi_label``, ``labels`` and ``rotated`` are not part of the predict path and raise.
+    ``multi_label`` (the validator's mode, ops.py:239-241) runs ``yl_nms_ml``; ``labels`` (autolabelling
+    a-priori boxes) and ``rotated`` are not part of the detect path and raise.
     """
     assert 0 <= conf_thres <= 1, f"Invalid Confidence threshold {conf_thres}, valid values are between 0.0 and 1.0"
     assert 0 <= iou_thres <= 1, f"Invalid IoU {iou_thres}, valid values are between 0.0 and 1.0"
-    if multi_label or rotated or (labels is not None and len(labels)):
-        raise NotImplementedError("multi_label / labels / rotated NMS are outside the YOLO11 predict path")
+    if rotated or (labels is not None and len(labels)):
+        raise NotImplementedError("labels / rotated NMS are outside the YOLO11 detect path")
     if isinstance(prediction, (list, tuple)):
         prediction = prediction[0]
     if prediction.shape[-1] == 6:
         raise NotImplementedError("end2end (B, N, 6) predictions are outside the YOLO11 predict path")
-    out, cnt = nms_padded(prediction, conf_thres, iou_thres, classes, agnostic, max_det, max_nms, float(max_wh))
+    out, cnt = nms_padded(prediction, conf_thres, iou_thres, classes, agnostic, max_det, max_nms, float(max_wh),
+                          multi_label=multi_label)
     counts = cnt.tolist()  # the one host sync of post-processing
     return [out[i, :n] for i, n in enumerate(counts)]
 
