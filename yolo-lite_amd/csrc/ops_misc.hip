@@ -394,30 +394,39 @@ __device__ __forceinline__ bf16x8 max8(bf16x8 a, bf16x8 b) {
   return o;
 }
 
+// bf16 -> int16 key that orders like the value (sign-magnitude -> two's complement: flip the magnitude bits of
+// negatives); its own inverse.  A maximum of bf16 values is then ONE v_pk_max_i16 per two values instead of two
+// conversions, a compare and a select per value: the fp32-compare form made this kernel VALU bound (~30
+// instructions per 8-channel maximum, 40 maxima per pixel).  -0 orders below +0 (a float compare calls them
+// equal; the values are the same); NaNs are not expected in activations.
+typedef short i16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ i16x8 ord_key(i16x8 x) { return x ^ ((x >> 15) & (short)0x7fff); }
+__device__ __forceinline__ i16x8 kmax(i16x8 a, i16x8 b) { return __builtin_elementwise_max(a, b); }
+
 __global__ __launch_bounds__(256) void sppf_pool_lds_kernel(PoolArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
   const int HW = a.H * a.W;
-  bf16x8* sx = reinterpret_cast<bf16x8*>(psm);  // [HW] input
-  bf16x8* sh = sx + HW;                         // [3][HW] horizontal maxima
+  i16x8* sx = reinterpret_cast<i16x8*>(psm);  // [HW] input, as ordered keys
+  i16x8* sh = sx + HW;                        // [3][HW] horizontal maxima
   const int cg = a.C >> 3;
   const int b = blockIdx.x / cg, g8 = blockIdx.x % cg;
   for (int p = threadIdx.x; p < HW; p += 256) {
     const int y = p / a.W, x = p - y * a.W;
-    sx[p] = *reinterpret_cast<const bf16x8*>(pv_ptr(a.v, g8, pv_pix(a.v, b, y, x)));
+    sx[p] = ord_key(*reinterpret_cast<const i16x8*>(pv_ptr(a.v, g8, pv_pix(a.v, b, y, x))));
   }
   __syncthreads();
   for (int p = threadIdx.x; p < HW; p += 256) {
     const int y = p / a.W, x = p - y * a.W;
-    bf16x8 m = sx[p];
-    bf16x8 m5 = m, m9 = m, m13 = m;
+    const i16x8 m = sx[p];
+    i16x8 m5 = m, m9 = m, m13 = m;
 #pragma unroll
     for (int d = 1; d <= 6; ++d) {
-      bf16x8 t = m;
-      if (x - d >= 0) t = max8(t, sx[p - d]);
-      if (x + d < a.W) t = max8(t, sx[p + d]);
-      m13 = max8(m13, t);
-      if (d <= 4) m9 = max8(m9, t);
-      if (d <= 2) m5 = max8(m5, t);
+      i16x8 t = m;
+      if (x - d >= 0) t = kmax(t, sx[p - d]);
+      if (x + d < a.W) t = kmax(t, sx[p + d]);
+      m13 = kmax(m13, t);
+      if (d <= 4) m9 = kmax(m9, t);
+      if (d <= 2) m5 = kmax(m5, t);
     }
     sh[p] = m5;
     sh[HW + p] = m9;
@@ -426,21 +435,21 @@ __global__ __launch_bounds__(256) void sppf_pool_lds_kernel(PoolArgs a) {
   __syncthreads();
   for (int p = threadIdx.x; p < HW; p += 256) {
     const int y = p / a.W, x = p - y * a.W;
-    bf16x8 o[3];
+    i16x8 o[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
       const int r = 2 + 2 * k;
-      const bf16x8* hk = sh + k * HW;
-      bf16x8 m = hk[p];
+      const i16x8* hk = sh + k * HW;
+      i16x8 m = hk[p];
       for (int d = 1; d <= r; ++d) {
-        if (y - d >= 0) m = max8(m, hk[p - d * a.W]);
-        if (y + d < a.H) m = max8(m, hk[p + d * a.W]);
+        if (y - d >= 0) m = kmax(m, hk[p - d * a.W]);
+        if (y + d < a.H) m = kmax(m, hk[p + d * a.W]);
       }
-      o[k] = m;
+      o[k] = ord_key(m);
     }
     const int po = pv_pix(a.v, b, y, x);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) *reinterpret_cast<bf16x8*>(pv_ptr(a.v, (k + 1) * cg + g8, po)) = o[k];
+    for (int k = 0; k < 3; ++k) *reinterpret_cast<i16x8*>(pv_ptr(a.v, (k + 1) * cg + g8, po)) = o[k];
   }
 }
 
