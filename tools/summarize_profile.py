@@ -24,7 +24,9 @@ def short(name):
 
 def pmc(dirpath, counter):
     out = defaultdict(lambda: [0.0, 0])
-    for f in glob.glob(str(Path(dirpath) / "**" / "*counter_collection.csv"), recursive=True):
+    files = sorted(glob.glob(str(Path(dirpath) / "**" / "*counter_collection.csv"), recursive=True),
+                   key=lambda f: Path(f).stat().st_mtime)
+    for f in files[-1:]:  # the newest run only (gpurun merges into an existing directory)
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == counter:
                 a = out[short(r["Kernel_Name"])]
@@ -57,12 +59,15 @@ def family(k):
 def main():
     src, dst, tag = Path(sys.argv[1]), Path(sys.argv[2]), sys.argv[3]
     dst.mkdir(parents=True, exist_ok=True)
-    stats = glob.glob(str(src / "trace" / "**" / "*kernel_stats.csv"), recursive=True)
+    stats = sorted(glob.glob(str(src / "trace" / "**" / "*kernel_stats.csv"), recursive=True),
+                   key=lambda f: Path(f).stat().st_mtime)[-1:]
     rows = list(csv.DictReader(open(stats[0]))) if stats else []
     if stats:
         shutil.copy(stats[0], dst / f"{tag}_kernel_stats.csv")
     fetch = pmc(src / "pmc_fetch", "FETCH_SIZE")
     write = pmc(src / "pmc_write", "WRITE_SIZE")
+    mfma_busy = pmc(src / "pmc_mfma", "SQ_VALU_MFMA_BUSY_CYCLES")
+    gui = pmc(src / "pmc_mfma", "GRBM_GUI_ACTIVE")
     bench = None
     if (src / "bench.json").exists():
         txt = (src / "bench.json").read_text().strip().splitlines()
@@ -78,16 +83,21 @@ def main():
               "side is doubled as MI355X_MICROARCH.md prescribes for gfx950.  That correction matches the algorithmic",
               "bytes of the streaming kernels (1x1 convs, stem = 1.5x by design); for the 3x3 kernels, whose tap-shifted",
               "fragments are not 128-byte aligned, it probably over-counts by up to 2x.", "",
-              "| kernel | calls | avg us | total % | HBM read MB/launch (2 x FETCH_SIZE) | HBM write MB/launch |",
-              "|---|---|---|---|---|---|"]
+              "MFMA busy: SQ_VALU_MFMA_BUSY_CYCLES (summed over the 1024 SIMDs) / (1024 x GRBM_GUI_ACTIVE / 8 XCDs), from a",
+              "separate pass with one batch in flight.", "",
+              "| kernel | calls | avg us | total % | HBM read MB/launch (2 x FETCH_SIZE) | HBM write MB/launch | MFMA busy % |",
+              "|---|---|---|---|---|---|---|"]
     for r in rows:
         if float(r["Percentage"]) < 0.05:
             continue
         k = short(r["Name"])
         rd = fetch.get(k)
         wr = write.get(k)
+        mb = ""
+        if k in mfma_busy and gui.get(k):
+            mb = f"{100.0 * mfma_busy[k] / (1024.0 * gui[k] / 8.0):.1f}"
         lines.append(f"| `{k}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} | "
-                     f"{'' if rd is None else f'{2 * rd * 1024 / 1e6:.1f}'} | {'' if wr is None else f'{wr * 1024 / 1e6:.1f}'} |")
+                     f"{'' if rd is None else f'{2 * rd * 1024 / 1e6:.1f}'} | {'' if wr is None else f'{wr * 1024 / 1e6:.1f}'} | {mb} |")
     (dst / f"{tag}_summary.md").write_text("\n".join(lines) + "\n")
     # per-family HBM bytes per launch (launch-weighted over the template instances), read by bench.py
     fam = {}
