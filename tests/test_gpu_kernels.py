@@ -292,3 +292,15 @@ def test_conv3_tile_vs_torch_and_direct(gpu_device, monkeypatch, cin, cout, h, w
     direct = run_conv(gpu_device, x, wt, b, 3, 1, act, r, expect_kernel="conv3x3_mfma")
     # both are within half a bf16 ulp of the exact sum, so they differ by at most one ulp (2^-7 relative)
     assert ((got - direct).abs() <= 2.0 ** -7 * direct.abs().clamp(min=1e-2) + 1e-3).all(), "tile vs direct kernel"
+
+
+def test_view_above_one_gib_fails_loudly(gpu_device):
+    """Maximum sizes: buffer offsets are 32 bits with out-of-range sentinels, so a tensor slice above 1 GiB must be
+    refused with an error (never wrapped around or silently truncated)."""
+    m = Mini(1, gpu_device)
+    H = W = 8200  # one plane of 8 channels: 8201 * 8201 * 16 B = 1.08 GB
+    xin, out = m.buf(H, W, 8), m.buf(H, W, 16)
+    m.op(kind=OP_CONV, name="big", k=1, stride=1, act=1, inp=xin, out=out, res=None,
+         weight=np.zeros((16, 8, 1, 1), np.float32), bias=np.zeros(16, np.float32))
+    with pytest.raises(RuntimeError, match="1 GiB"):
+        m.run()
