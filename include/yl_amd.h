@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define YL_ABI_VERSION 6
+#define YL_ABI_VERSION 7
 
 /* element types */
 enum { YL_BF16 = 0, YL_F32 = 1, YL_F16 = 2, YL_U8 = 3 };
@@ -96,6 +96,13 @@ typedef struct yl_op {
      `weight` is [Cout][in2.C + in.C]. */
   yl_view in2;
   int32_t up, reserved;
+  /* 3x3 stride-2 conv that is op 0 only: stem_weight != NULL fuses the network's first layer in front of it
+     (Conv(3 -> in.C, 3x3, s2) on the NCHW network input, weight [in.C][3][3][3], bias [in.C], SiLU if stem_act):
+     `in` then describes a tensor that is never materialised (its offset is ignored); in.C must be 16 (YOLO11n)
+     and this conv's own output channels 32 or 64.  Results are bit-identical to YL_OP_STEM followed by the plain conv. */
+  const float* stem_weight;
+  const float* stem_bias;
+  int32_t stem_act, reserved2;
 } yl_op;
 
 /* Detect-level raw maps (reference head.py:64-65 torch.cat(cv2, cv3)): two bf16 buffers in the planar

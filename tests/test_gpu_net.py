@@ -85,7 +85,8 @@ def test_fused_stem_vs_generic_conv_and_torch(gpu_device, dtype):
     xin = x if dtype == torch.uint8 else x.float() / 255
     outs = []
     for fused in (True, False):
-        eng = HipEngine(lower(specs, sd, 2, 64, 96, fused_stem=fused), gpu_device)
+        # fuse_post=False keeps every layer's output (otherwise the stem's output exists only in LDS, stem2.hip)
+        eng = HipEngine(lower(specs, sd, 2, 64, 96, fused_stem=fused, fuse_post=False), gpu_device)
         eng.forward(xin.to(gpu_device))
         torch.cuda.synchronize()
         outs.append(eng.layer_output(0).cpu())
@@ -353,3 +354,28 @@ def test_nms_multi_label_cap_and_single_class(gpu_device):
     got = hops.non_max_suppression(p1.to(gpu_device), 0.3, 0.5, multi_label=True)
     for r, q in zip(ref, got):
         np.testing.assert_array_equal(q.cpu().numpy(), r.numpy())
+
+
+@pytest.mark.parametrize("scale,h,w,dtype", [("n", 64, 64, torch.float32), ("n", 96, 128, torch.uint8),
+                                               ("n", 160, 352, torch.uint8), ("s", 64, 96, torch.float16),
+                                               ("n", 32, 32, torch.uint8), ("n", 224, 416, torch.float16)])
+def test_fused_stem_conv_is_bit_identical(gpu_device, monkeypatch, scale, h, w, dtype):
+    """Layers 0 + 1 in one launch (csrc/stem2.hip, the stem output only in LDS) against the two-launch form:
+    every bit of the network output, on sizes that exercise ragged tiles, several column tiles and all input types."""
+    sd = synth_state_dict(scale, 4, cls_bias=[-2.0, -2.0, -2.0], cls_gain=4.0)
+    g = torch.Generator().manual_seed(h * w)
+    if dtype == torch.uint8:
+        x = torch.randint(0, 256, (2, 3, h, w), generator=g, dtype=torch.uint8)
+    else:
+        x = torch.rand(2, 3, h, w, generator=g).to(dtype)
+    eng = _engine(scale, sd, 2, h, w, gpu_device)
+    # only the 16-channel stem of YOLO11n is fused so far; wider stems must quietly keep the two-launch form
+    assert eng.op_kernel(0) == ("stem+conv3x3s2_mfma" if scale == "n" else "stem_conv3x3s2"), eng.op_kernel(0)
+    y = eng.forward(x.to(gpu_device)).clone()
+    monkeypatch.setenv("YL_FUSE_STEM", "0")
+    ref_eng = _engine(scale, sd, 2, h, w, gpu_device)
+    assert ref_eng.op_kernel(0) == "stem_conv3x3s2"
+    y_ref = ref_eng.forward(x.to(gpu_device))
+    assert torch.equal(y, y_ref)
+    for a, b in zip(eng.raw_levels(), ref_eng.raw_levels()):
+        assert torch.equal(a, b)

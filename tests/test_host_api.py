@@ -261,3 +261,15 @@ def test_result_sinks_plot_save_crop_txt_json(tmp_path):
     assert js[0]["name"] == "box" and abs(js[0]["box"]["x2"] - 110 / 160) < 1e-5
     with pytest.raises(ValueError):
         Results(None, path="p", names={0: "a"}, boxes=boxes[:1], orig_shape=(120, 160)).plot()
+
+
+def test_uint8_scale_by_reciprocal_is_exact_in_bf16():
+    """csrc/stem2.hip converts uint8 pixels with byte * (1 / 255.f) instead of the reference's byte / 255
+    (predictor.py:84): the fp32 products differ in the last bit for about half of the byte values, but after the
+    rounding to bf16 that follows immediately all 256 agree -- checked exhaustively here."""
+    import numpy as np
+
+    x = np.arange(256, dtype=np.float32)
+    div = torch.from_numpy((x / np.float32(255.0)).astype(np.float32)).to(torch.bfloat16)
+    mul = torch.from_numpy((x * np.float32(1.0 / 255.0)).astype(np.float32)).to(torch.bfloat16)
+    assert torch.equal(div, mul)

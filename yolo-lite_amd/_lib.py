@@ -47,7 +47,9 @@ class Op(C.Structure):
                 ("weight", C.c_void_p), ("bias", C.c_void_p),
                 ("post_cin", C.c_int32), ("post_act", C.c_int32),
                 ("post_weight", C.c_void_p), ("post_bias", C.c_void_p),
-                ("inp2", View), ("up", C.c_int32), ("reserved", C.c_int32)]
+                ("inp2", View), ("up", C.c_int32), ("reserved", C.c_int32),
+                ("stem_weight", C.c_void_p), ("stem_bias", C.c_void_p),
+                ("stem_act", C.c_int32), ("reserved2", C.c_int32)]
 
 
 class Level(C.Structure):
@@ -128,7 +130,7 @@ def lib() -> C.CDLL:
     L.yl_preprocess_u8.argtypes = [vp, i32, i32, i32, vp, vp]
     L.yl_letterbox_u8.restype = i32
     L.yl_letterbox_u8.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]
-    if L.yl_abi_version() != 6:
+    if L.yl_abi_version() != 7:
         raise RuntimeError("libyl_amd.so ABI version mismatch; rebuild it")
     _lib = L
     return L

@@ -27,6 +27,8 @@ struct OpRec {
   float* d_bias2 = nullptr;
   float* d_w = nullptr;     // dwconv weights [9][C]
   float* d_bias = nullptr;
+  float* d_w0 = nullptr;    // fused stem in front of a conv (stem2.hip): filters [C0][27], bias [C0]
+  float* d_b0 = nullptr;
   double flops = 0, bytes = 0;
   const char* name = "";
 };
@@ -223,10 +225,35 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
         std::vector<float> bias((size_t)r.cfg.ncb * r.cfg.MT * 16 + 16, 0.f);
         for (int c = 0; c < cout1; ++c) bias[c] = o.bias[c];
         if (int rc = dev_upload(e.get(), bias, &r.d_bias)) return rc;
+        if (o.stem_weight) {  // the network's first layer fused in front (stem2.hip)
+          const int sh = (in_h + 2 - 3) / 2 + 1, sw = (in_w + 2 - 3) / 2 + 1;
+          if (i != 0 || !o.stem_bias || o.k != 3 || o.stride != 2 || up || o.res.offset >= 0 || o.cin_weight ||
+              o.out.dtype != YL_BF16 || o.lane != 0)
+            return fail(-1, tag + ": a fused stem needs a plain 3x3 stride-2 conv as op 0");
+          if (o.in.H != sh || o.in.W != sw || o.in.C != 16 || (cout1 != 32 && cout1 != 64) ||
+              r.cfg.ncb != 1 || r.cfg.ksteps > 8)
+            return fail(-1, tag + ": fused stem: unsupported widths or dims");
+          std::vector<float> wt((size_t)o.in.C * 27);
+          for (size_t q = 0; q < wt.size(); ++q) {  // round to bf16 like every other conv filter
+            uint32_t u;
+            memcpy(&u, &o.stem_weight[q], 4);
+            u += 0x7fffu + ((u >> 16) & 1u);
+            u &= 0xffff0000u;
+            memcpy(&wt[q], &u, 4);
+          }
+          if (int rc = dev_upload(e.get(), wt, &r.d_w0)) return rc;
+          std::vector<float> b0(o.stem_bias, o.stem_bias + o.in.C);
+          if (int rc = dev_upload(e.get(), b0, &r.d_b0)) return rc;
+        }
         r.flops = 2.0 * px_out * cout1 * cin_w * o.k * o.k + (post ? 2.0 * px_out * o.out.C * o.post_cin : 0.0);
         r.bytes = px_in * o.in.C * 2 + (up ? px_in / 4 * o.in2.C * 2 : 0.0) + px_out * o.out.C * view_elem_size(o.out) +
                   (o.res.offset >= 0 ? px_out * o.out.C * 2 : 0) + (double)cout1 * cin_w * o.k * o.k * 2;
         r.name = r.cfg.name;
+        if (o.stem_weight) {
+          r.flops += 2.0 * px_in * o.in.C * 27;
+          r.bytes = (double)batch * 3 * in_h * in_w * 4 + px_out * o.out.C * 2 + (double)cout1 * cin_w * 9 * 2;
+          r.name = "stem+conv3x3s2_mfma";
+        }
         break;
       }
       case YL_OP_DWCONV3: {
@@ -325,6 +352,36 @@ static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s, c
   const int B = e->batch;
   switch (o.kind) {
     case YL_OP_CONV: {
+      if (r.d_w0) {  // layers 0 + 1 in one launch
+        if (!input) return fail(-1, "run_op: the fused stem needs the network input");
+        Stem2Args q{};
+        q.in = input;
+        q.B = B;
+        q.H = e->in_h;
+        q.W = e->in_w;
+        q.H0 = o.in.H;
+        q.W0 = o.in.W;
+        q.C0 = o.in.C;
+        q.H1 = o.out.H;
+        q.W1 = o.out.W;
+        q.w0 = r.d_w0;
+        q.b0 = r.d_b0;
+        q.act0 = o.stem_act;
+        q.wpk = r.d_wpk;
+        q.bias = r.d_bias;
+        q.ksteps = r.cfg.ksteps;
+        q.Cout = r.d_wpk2 ? o.post_cin : o.out.C;
+        q.act = o.act;
+        q.wpk2 = r.d_wpk2;
+        q.bias2 = r.d_bias2;
+        q.post_cout = o.out.C;
+        q.post_act = o.post_act;
+        q.out = pview(ws, o.out, B);
+        const long long ob = (long long)((o.out.C + 7) / 8) * plane_bytes(geo_of(B, o.out.H, o.out.W));
+        if (ob > (1LL << 30)) return fail(-3, "stem2: the output slice exceeds 1 GiB; lower the batch size");
+        q.out_bytes = (unsigned)ob;
+        return stem2_launch(q, r.cfg.MT, in_dtype, s);
+      }
       ConvArgs a{};
       const Geo gi = geo_of(B, o.in.H, o.in.W), go = geo_of(B, o.out.H, o.out.W);
       a.in = pview(ws, o.in, B).base;
@@ -532,7 +589,7 @@ extern "C" int yl_engine_forward(yl_engine* e, const void* input, int in_dtype, 
   yl_engine::StreamSet& ss = e->sets[workspace];
   if (e->max_lane > 0)
     if (int rc = lane_resources(e, ss, e->ops.size() + e->max_lane + 1)) return rc;
-  const bool stem = !e->ops.empty() && e->ops[0].op.kind == YL_OP_STEM;
+  const bool stem = !e->ops.empty() && (e->ops[0].op.kind == YL_OP_STEM || e->ops[0].d_w0);
   if (!stem)
     if (int rc = run_convert(e, input, in_dtype, ws, s)) return rc;
   size_t nev = 0;
@@ -678,7 +735,7 @@ extern "C" int yl_engine_profile(yl_engine* e, const void* input, int in_dtype, 
   int rc = 0;
   for (int it = 0; it < iters && !rc; ++it) {
     (void)hipEventRecord(ev[0], s);
-    if (e->ops[0].op.kind != YL_OP_STEM) rc = run_convert(e, input, in_dtype, ws, s);
+    if (e->ops[0].op.kind != YL_OP_STEM && !e->ops[0].d_w0) rc = run_convert(e, input, in_dtype, ws, s);
     (void)hipEventRecord(ev[1], s);
     for (int i = 0; i < n && !rc; ++i) {
       rc = run_op(e, e->ops[i], ws, s, input, in_dtype);

@@ -1,0 +1,293 @@
+// Layers 0 and 1 of yolo11.yaml in ONE launch: Conv(3 -> c0, 3x3, s2) + SiLU, then Conv(c0 -> c1, 3x3, s2) +
+// SiLU [+ the 1x1 conv fused behind it], reference nn/modules/conv.py:35-53 twice, fed by the predictor's input
+// conversion (engine/predictor.py:82-84).
+//
+// Why: the stem's output (c0 = 16 channels at half resolution, 105 MB at batch 32 x 640^2) is the largest tensor
+// of the network and has exactly one reader.  stem_kernel + conv_kernel write and re-read it through HBM
+// (0.21 GB of the ~2.3 GB a batch moves); here it only ever exists as a bf16 tile in LDS.
+//
+// One workgroup (256 threads) = TR x TC = 2 x 80 output pixels of layer 1 for one image:
+//   1. the 11 x 324 input window (3 channels) is read with aligned dword buffer loads (zeros outside the image),
+//      converted (/255 for uint8, true division) and rounded to bf16 into LDS;
+//   2. the 5 x 161 stem outputs the tile needs are computed from it exactly as stem_kernel does (MFMA with K = 27
+//      taps padded to 32, im2col gathered from LDS), SiLU'd, rounded to bf16 and parked in LDS as C8 planes; stem
+//      positions outside the stem map (layer 1's zero padding) are written as zeros;
+//   3. layer 1 runs as conv_kernel would -- same packed filters, same k order (tap-major, 8-channel groups), same
+//      epilogue and follow-up 1x1 -- with its B fragments read from the LDS planes (stride-2 pixels).
+// Same operands, same MFMA sequence: bit-identical to the two-launch path (tests/test_gpu_net.py).
+// Recompute: 5 stem rows per 2 output rows and 161 columns per 80 (1.26x of a 0.9 GFLOP layer).
+#include "conv_common.h"
+
+namespace yl {
+
+constexpr int S2_TR = 2, S2_TC = 80;                 // layer-1 output tile
+constexpr int S2_SR = 2 * S2_TR + 1;                 // stem rows (5)
+constexpr int S2_SC = 2 * S2_TC + 1;                 // stem columns (161)
+constexpr int S2_SP = S2_SC + 1;                     // stem tile pitch in pixels
+constexpr int S2_IR = 2 * S2_SR + 1;                 // input rows (11)
+constexpr int S2_IC = 2 * S2_SC + 2;                 // input columns incl. one alignment column (324)
+constexpr int S2_IP = S2_IC + 4;                     // input tile pitch in elements
+
+size_t stem2_lds_bytes(int C0) {
+  return (size_t)3 * S2_IR * S2_IP * 2 + (size_t)(C0 / 8) * S2_SR * S2_SP * 16;
+}
+
+template <typename T>
+__device__ __forceinline__ float s2_cvt(T v) {
+  float f = (float)v;
+  if constexpr (sizeof(T) == 1) f = f / 255.0f;  // true division, as predictor.py:84
+  return f;
+}
+
+template <typename T, int MT, bool POST>
+__global__ __launch_bounds__(256) void stem2_kernel(Stem2Args a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char s2mem[];
+  __bf16* img = reinterpret_cast<__bf16*>(s2mem);                          // [3][S2_IR][S2_IP]
+  unsigned char* stile = s2mem + (size_t)3 * S2_IR * S2_IP * 2;            // [C0/8][S2_SR][S2_SP] x 16 B
+  constexpr int VW = 4 / (int)sizeof(T);                                   // elements per dword
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: tile rows / columns below stay in SGPRs
+  const int n = lane & 15, g = lane >> 4;
+  int bid = xcd_remap(blockIdx.x, gridDim.x);
+  const int tx = bid % a.tiles_x;
+  bid /= a.tiles_x;
+  const int ty = bid % a.tiles_y;
+  const int b = bid / a.tiles_y;
+  const int y0 = ty * S2_TR, x0 = tx * S2_TC;
+
+  // ---- 1. input window -> LDS (bf16).  Local (ir, ic) <-> image (4*y0 - 3 + ir, 4*x0 - 4 + ic).
+  {
+    const T* in = reinterpret_cast<const T*>(a.in) + (long long)b * 3 * a.H * a.W;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)in, (short)0, (int)((long long)3 * a.H * a.W * (long long)sizeof(T)), 0x00020000);
+    constexpr int DW = S2_IC / VW;  // dwords per row
+    constexpr int TOTAL = 3 * S2_IR * DW;
+    // 12 loads in flight per thread: the whole uint8 window (2673 dwords) is ONE memory round trip
+    constexpr int CH = 12;
+    for (int i0 = tid; i0 < TOTAL; i0 += 256 * CH) {
+      unsigned v[CH];
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        const int idx = i0 + u * 256;
+        const int rowi = idx / DW, d = idx - rowi * DW;
+        const int ch = rowi / S2_IR, ir = rowi - ch * S2_IR;
+        const int iy = 4 * y0 - 3 + ir, ix = 4 * x0 - 4 + d * VW;
+        const bool ok = idx < TOTAL && (unsigned)iy < (unsigned)a.H && ix >= 0 && ix + VW <= a.W;
+        const unsigned off = ok ? (unsigned)(((ch * a.H + iy) * a.W + ix) * (int)sizeof(T)) : 0x80000000u;
+        v[u] = __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        const int idx = i0 + u * 256;
+        if (idx < TOTAL) {
+          const int rowi = idx / DW, d = idx - rowi * DW;
+          __bf16* dst = img + rowi * S2_IP + d * VW;
+          if constexpr (sizeof(T) == 1) {
+            // byte / 255 (predictor.py:84), rounded to bf16 at once.  A true fp32 division costs ~12 VALU
+            // instructions per pixel and made this kernel VALU bound; byte * (1 / 255.f) differs from it in the last
+            // fp32 bit for 126 of the 256 byte values, but NEVER after the bf16 rounding
+            // (tests/test_host_api.py::test_uint8_scale_by_reciprocal_is_exact_in_bf16 checks all 256).
+            typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+            const float k = 1.0f / 255.0f;
+            const bf16x4_t o = {(__bf16)((float)(v[u] & 0xffu) * k), (__bf16)((float)((v[u] >> 8) & 0xffu) * k),
+                                (__bf16)((float)((v[u] >> 16) & 0xffu) * k), (__bf16)((float)(v[u] >> 24) * k)};
+            *reinterpret_cast<bf16x4_t*>(dst) = o;
+          } else if constexpr (sizeof(T) == 2) {
+            typedef __attribute__((ext_vector_type(2))) _Float16 h2;
+            const h2 h = __builtin_bit_cast(h2, v[u]);
+            dst[0] = (__bf16)(float)h[0];
+            dst[1] = (__bf16)(float)h[1];
+          } else {
+            dst[0] = (__bf16)__uint_as_float(v[u]);
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- 2. stem outputs of the window -> LDS planes.  Local (r, c) <-> stem pixel (2*y0 - 1 + r, 2*x0 - 1 + c);
+  //         it reads input rows 2r + kh and columns 2c + kw + 1 of the window.
+  {
+    // LDS element of tap k = (ch*3 + kh)*3 + kw relative to the pixel's (2r, 2c) corner; taps >= 27 (zero
+    // filter values) read tap 0's element, which is initialised and finite
+    int koff[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = g * 8 + j;
+      const int kk = k < 27 ? k : 0;
+      const int ch = kk / 9, kh = (kk - ch * 9) / 3, kw = kk - ch * 9 - kh * 3;
+      koff[j] = (ch * S2_IR + kh) * S2_IP + kw + 1;
+    }
+    // 16-pixel tiles aligned to the window's rows (11 per row, the last one 1 pixel wide): row and column tile are
+    // wave-uniform, so the address arithmetic per tile is a handful of scalar instructions plus one add per gather
+    constexpr int TPR = (S2_SC + 15) / 16;
+    for (int mb = 0; mb < a.C0; mb += 16) {
+      bf16x8 af;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = g * 8 + j;
+        af[j] = (__bf16)(k < 27 ? a.w0[(mb + n) * 27 + k] : 0.f);
+      }
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(a.b0 + mb + g * 4);
+      const int ch = mb + g * 4;
+      unsigned char* const sbase = stile + (size_t)(ch >> 3) * S2_SR * S2_SP * 16 + (ch & 7) * 2;
+      // two tiles per trip (t and t + 4): both gathers are requested before the first MFMA, so the LDS latency
+      // and the MFMA -> SiLU dependency of one tile hide behind the other
+      for (int t0 = wave; t0 < S2_SR * TPR; t0 += 8) {
+        bf16x8 bf[2];
+        int rr[2], cc[2], cts[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int t = min(t0 + 4 * u, S2_SR * TPR - 1);    // scalar; a missing second tile repeats the last one
+          const int r = t / TPR, ct = t - r * TPR;
+          const int c = min(ct * 16 + n, S2_SC - 1);         // the ragged last tile recomputes the last pixel
+          rr[u] = r;
+          cc[u] = c;
+          cts[u] = (t0 + 4 * u < S2_SR * TPR) ? ct : TPR;    // TPR: nothing of this tile is stored
+          const __bf16* corner = img + 2 * r * S2_IP + 2 * c;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) bf[u][j] = corner[koff[j]];
+        }
+        f32x4 acc[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[u], bv, 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int sy = 2 * y0 - 1 + rr[u], sx = 2 * x0 - 1 + cc[u];
+          const bool inside = (unsigned)sy < (unsigned)a.H0 && (unsigned)sx < (unsigned)a.W0;
+          bf16x4 o;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o[q] = (__bf16)(a.act0 ? silu_f(acc[u][q]) : acc[u][q]);
+          const bf16x4 z = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+          if (cts[u] * 16 + n < S2_SC)
+            *reinterpret_cast<bf16x4*>(sbase + (size_t)(rr[u] * S2_SP + cc[u]) * 16) = inside ? o : z;
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- 3. layer 1 from the LDS planes: 16-pixel tiles aligned to the output rows (TC / 16 per row)
+  constexpr int cg0 = 2;                   // the stem has 16 channels (host-checked): two planes,
+  constexpr int KS = (9 * cg0 + 3) / 4;    // 18 k-groups of 8 channels = 5 k-steps of the second conv
+  bf16x8 wa[KS][MT];  // the whole filter in registers
+  int boff[KS];       // byte offset of this lane's B fragment of k-step ks relative to the tile's corner
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) wa[ks][mt] = reinterpret_cast<const bf16x8*>(a.wpk)[(ks * MT + mt) * 64 + lane];
+    const int k8 = ks * 4 + g;
+    const int tap = min(k8 / cg0, 8);  // k groups past the last tap have zero filters: any finite data will do
+    const int c8 = k8 - (k8 / cg0) * cg0;
+    const int kh = tap / 3, kw = tap - kh * 3;
+    boff[ks] = ((c8 * S2_SR + kh) * S2_SP + kw + 2 * n) * 16;
+  }
+  f32x4 bias_r[MT], bias2_r[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    bias_r[mt] = *reinterpret_cast<const f32x4*>(a.bias + chan_in_block(MT, mt, g, 0));
+    if constexpr (POST) bias2_r[mt] = *reinterpret_cast<const f32x4*>(a.bias2 + chan_in_block(MT, mt, g, 0));
+  }
+  bf16x8 w2[MT / 2][MT];
+  if constexpr (POST) {
+#pragma unroll
+    for (int p = 0; p < MT / 2; ++p)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) w2[p][mt] = reinterpret_cast<const bf16x8*>(a.wpk2)[(p * MT + mt) * 64 + lane];
+  }
+  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.out.base, (short)0, a.out_bytes, 0x00020000);
+  const unsigned out_plane = (unsigned)(a.out.plane * 2);
+  const int act_last = POST ? a.post_act : a.act;
+  constexpr int TPR1 = S2_TC / 16;
+  for (int t = wave; t < S2_TR * TPR1; t += 4) {
+    const int ly = t / TPR1, ct = t - ly * TPR1;  // scalar
+    const int oy = y0 + ly, ox = x0 + ct * 16 + n;
+    const unsigned char* corner = stile + (size_t)(2 * ly * S2_SP + 2 * ct * 16) * 16;
+    f32x4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = bias_r[mt];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const bf16x8 xb = *reinterpret_cast<const bf16x8*>(corner + boff[ks]);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ks][mt], xb, acc[mt], 0, 0, 0);
+    }
+    if constexpr (POST) {
+      // the follow-up 1x1 on the packed accumulators, exactly as conv_kernel<..., POST> does
+      bf16x8 xb2[MT / 2];
+#pragma unroll
+      for (int p = 0; p < MT / 2; ++p) {
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = acc[2 * p][r];
+          v[4 + r] = acc[2 * p + 1][r];
+        }
+        if (a.act) {
+#pragma unroll
+          for (int r = 0; r < 8; ++r) v[r] = silu_f(v[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 8; ++r) xb2[p][r] = (__bf16)v[r];
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt] = bias2_r[mt];
+#pragma unroll
+      for (int p = 0; p < MT / 2; ++p)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[p][mt], xb2[p], acc[mt], 0, 0, 0);
+    }
+    // epilogue as conv_common.h's (SiLU, bf16 pack, one 16-byte pixel of plane p*4+g per lane), branch-free
+    const unsigned po = (oy < a.H1 && ox < a.W1) ? (unsigned)(a.out.g0 + b * a.out.img + oy * a.out.W1 + ox) * 16u : OOB_LANE;
+    const int cout_last = POST ? a.post_cout : a.Cout;
+#pragma unroll
+    for (int p = 0; p < MT / 2; ++p) {
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[2 * p][r];
+        v[4 + r] = acc[2 * p + 1][r];
+      }
+      if (act_last) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = silu_f(v[r]);
+      }
+      const int co = (p * 4 + g) * 8;
+      __builtin_amdgcn_raw_buffer_store_b128(
+          u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])},
+          rout, co < cout_last ? (unsigned)(p * 4 + g) * out_plane + po : OOB_LANE, 0, 0);
+    }
+  }
+}
+
+template <typename T>
+static int stem2_launch_t(const Stem2Args& a, int MT, size_t lds, hipStream_t s) {
+  const dim3 grid((unsigned)(a.B * a.tiles_y * a.tiles_x));
+  const bool post = a.wpk2 != nullptr;
+  if (MT == 2 && post) hipLaunchKernelGGL((stem2_kernel<T, 2, true>), grid, dim3(256), lds, s, a);
+  else if (MT == 2) hipLaunchKernelGGL((stem2_kernel<T, 2, false>), grid, dim3(256), lds, s, a);
+  else if (MT == 4 && post) hipLaunchKernelGGL((stem2_kernel<T, 4, true>), grid, dim3(256), lds, s, a);
+  else if (MT == 4) hipLaunchKernelGGL((stem2_kernel<T, 4, false>), grid, dim3(256), lds, s, a);
+  else return fail(-3, "stem2: the second conv needs 32 or 64 output channels");
+  YL_HIP(hipGetLastError());
+  return 0;
+}
+
+int stem2_launch(const Stem2Args& a0, int MT, int in_dtype, hipStream_t s) {
+  Stem2Args a = a0;
+  if (a.C0 != 16 || a.ksteps != 5) return fail(-3, "stem2: the stem must have 16 output channels");
+  const int esz = in_dtype == YL_F32 ? 4 : in_dtype == YL_F16 ? 2 : 1;
+  if ((a.W * esz) % 4) return fail(-3, "stem2: input rows must be a multiple of 4 bytes (set YL_FUSE_STEM=0)");
+  if ((long long)3 * a.H * a.W * esz >= (1LL << 30)) return fail(-3, "stem2: one input image exceeds 1 GiB");
+  a.tiles_x = (a.W1 + S2_TC - 1) / S2_TC;
+  a.tiles_y = (a.H1 + S2_TR - 1) / S2_TR;
+  const size_t lds = stem2_lds_bytes(a.C0);
+  if (in_dtype == YL_F32) return stem2_launch_t<float>(a, MT, lds, s);
+  if (in_dtype == YL_F16) return stem2_launch_t<_Float16>(a, MT, lds, s);
+  if (in_dtype == YL_U8) return stem2_launch_t<uint8_t>(a, MT, lds, s);
+  return fail(-3, "stem2: unsupported input dtype");
+}
+
+}  // namespace yl

@@ -164,6 +164,27 @@ int stem_launch(const StemArgs& a, int in_dtype, hipStream_t s);
 
 int convert_input_launch(const void* in, int in_dtype, const PView& out, int batch, int H, int W, hipStream_t s);
 
+// stem2.hip: layers 0 and 1 in one launch (the stem's output lives only in LDS)
+struct Stem2Args {
+  const void* in;        // NCHW [B][3][H][W]
+  int B, H, W;
+  int H0, W0, C0;        // stem output (never materialised)
+  int H1, W1;            // output of the second conv
+  const float* w0;       // stem filters [C0][27] (bf16-rounded values), bias [C0]
+  const float* b0;
+  int act0;
+  const __bf16* wpk;     // second conv: conv_pack_weights order [kstep][MT][64][8]; bias padded to MT*16
+  const float* bias;
+  int ksteps, Cout, act;
+  const __bf16* wpk2;    // fused follow-up 1x1 (nullptr: none), as ConvArgs
+  const float* bias2;
+  int post_cout, post_act;
+  PView out;
+  unsigned out_bytes;
+  int tiles_x, tiles_y;
+};
+int stem2_launch(const Stem2Args& a, int MT, int in_dtype, hipStream_t s);
+
 struct DecodeLevel {
   PView box;     // 8 planes: DFL logits (head.py:64 cv2)
   PView cls;     // nc8 / 8 planes: class logits (cv3); padding channels hold large negative values

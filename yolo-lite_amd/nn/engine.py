@@ -58,6 +58,11 @@ class HipEngine:
                 b = np.ascontiguousarray(o["bias"], dtype=np.float32)
                 self._keep += [w, b]
                 c.weight, c.bias = w.ctypes.data, b.ctypes.data
+            if "stem_weight" in o:
+                w0 = np.ascontiguousarray(o["stem_weight"], dtype=np.float32)
+                b0 = np.ascontiguousarray(o["stem_bias"], dtype=np.float32)
+                self._keep += [w0, b0]
+                c.stem_weight, c.stem_bias, c.stem_act = w0.ctypes.data, b0.ctypes.data, int(o.get("stem_act", 1))
             if "post_weight" in o:
                 w2 = np.ascontiguousarray(o["post_weight"], dtype=np.float32).reshape(o["post_weight"].shape[0], -1)
                 b2 = np.ascontiguousarray(o["post_bias"], dtype=np.float32)

@@ -218,6 +218,34 @@ def fuse_upsample_into_convs(ops: List[dict]) -> List[dict]:
     return [o for i, o in enumerate(ops) if i not in drop]
 
 
+def fuse_stem_into_conv(ops: List[dict], in_w: int) -> List[dict]:
+    """Layer 0 (the stem, op 0) -> layer 1, a 3x3 stride-2 conv that is the stem output's ONLY reader: both run in
+    one launch (``yl_op.stem_*``, csrc/stem2.hip) and the stem's output -- the largest tensor of the network, 105 MB
+    at batch 32 x 640^2 -- exists only as LDS tiles.  Bit-identical to the two-launch form."""
+    if not ops or ops[0]["kind"] != OP_STEM or in_w % 4:
+        return ops
+    st = ops[0]
+    y = st["out"]
+
+    def touches(v):
+        return v is not None and v.dtype == BF16 and v.offset == y.offset
+
+    readers = [i for i, o in enumerate(ops) if i and (touches(o.get("inp")) or touches(o.get("res")) or touches(o.get("inp2")))]
+    if readers != [1]:
+        return ops
+    b = ops[1]
+    cout1 = b["post_weight"].shape[1] if "post_weight" in b else b["out"].C
+    if (b["kind"] != OP_CONV or b.get("k") != 3 or b.get("stride") != 2 or b.get("res") is not None
+            or b.get("inp2") is not None or b.get("cin_weight", 0) or b.get("lane", 0)
+            or (b["inp"].offset, b["inp"].coff, b["inp"].C) != (y.offset, 0, y.C) or y.pitch != y.C
+            or y.C != 16 or cout1 not in (32, 64)):  # wider stems (s/m/l/x) keep the two-launch form for now
+        return ops
+    b["stem_weight"], b["stem_bias"], b["stem_act"] = st["weight"], st["bias"], st.get("act", 1)
+    b["name"] = f"{st.get('name', '')}+{b.get('name', '')}"
+    b["fused_names"] = list(b.get("fused_names", [])) + [st.get("name", "")]
+    return ops[1:]
+
+
 def fold_conv_bn(sd: Dict[str, torch.Tensor], name: str, bn: bool = True) -> Tuple[np.ndarray, np.ndarray]:
     """BN-folded fp32 (weight OIHW, bias) of the Conv unit ``name`` (torch_utils.py:182-209)."""
     if bn:
@@ -470,6 +498,8 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
         ops[:] = fuse_depthwise_pointwise(ops)
     if fuse_post and os.environ.get("YL_FUSE_UP", "1") != "0":
         ops[:] = fuse_upsample_into_convs(ops)
+    if fuse_post and os.environ.get("YL_FUSE_STEM", "1") != "0":
+        ops[:] = fuse_stem_into_conv(ops, in_w)
     a_total = 0
     for lvl in range(len(det.f)):
         prog.levels.append(level_rec[lvl])
