@@ -26,7 +26,7 @@ constexpr int S2_SC = 2 * S2_TC + 1;                 // stem columns (161)
 constexpr int S2_SP = S2_SC + 1;                     // stem tile pitch in pixels
 constexpr int S2_IR = 2 * S2_SR + 1;                 // input rows (11)
 constexpr int S2_IC = 2 * S2_SC + 2;                 // input columns incl. one alignment column (324)
-constexpr int S2_IP = S2_IC + 4;                     // input tile pitch in elements
+constexpr int S2_IP = 352;                           // input tile pitch in elements (>= S2_IC; 32 mod 64: rows alternate LDS bank halves)
 
 size_t stem2_lds_bytes(int C0) {
   return (size_t)3 * S2_IR * S2_IP * 2 + (size_t)(C0 / 8) * S2_SR * S2_SP * 16;
