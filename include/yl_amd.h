@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define YL_ABI_VERSION 7
+#define YL_ABI_VERSION 8
 
 /* element types */
 enum { YL_BF16 = 0, YL_F32 = 1, YL_F16 = 2, YL_U8 = 3 };
@@ -32,9 +32,15 @@ enum {
   YL_OP_SPPF_POOL = 3,/* three chained MaxPool2d(5,1,2): writes pool5/9/13 after the input slice  */
   YL_OP_UPSAMPLE = 4, /* nearest upsample by `stride` (1 = plain copy) into a channel slice        */
   YL_OP_ATTENTION = 5,/* softmax(q^T k * scale) applied to v, per head (C2PSA)                     */
-  YL_OP_STEM = 6      /* first layer fused with the input conversion: 3x3 stride-2 conv on the 3-channel
+  YL_OP_STEM = 6,     /* first layer fused with the input conversion: 3x3 stride-2 conv on the 3-channel
                          NCHW network input (fp32 / fp16 / uint8, /255 for uint8) -> bf16 planes; must be
                          op 0; weight [Cout][3][3][3]                                              */
+  YL_OP_C3K2S = 7     /* body of a narrow C3k2 block in one launch (nn/modules/block.py:220-235, 330-343), c = 16:
+                         `in` = the block's concat buffer [a | b | ...] (a, b = halves of C3k2.cv1's output, 16 channels
+                         each); c_out = b + SiLU(cv2(SiLU(cv1(b)))) with the Bottleneck's two 3x3 convs
+                         (weight / bias = cv1 [8][16][3][3]; post_weight / post_bias = cv2 [16][8][3][3], post_cin = 72);
+                         out = SiLU(C3k2.cv2(cat(a, b, c_out))) (stem_weight / stem_bias = that 1x1 conv, [64][48]).
+                         The intermediates live in LDS; bit-identical to the three YL_OP_CONV ops it replaces.     */
 };
 
 /* A channel-slice view of a buffer inside the workspace arena.

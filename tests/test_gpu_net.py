@@ -379,3 +379,26 @@ def test_fused_stem_conv_is_bit_identical(gpu_device, monkeypatch, scale, h, w, 
     assert torch.equal(y, y_ref)
     for a, b in zip(eng.raw_levels(), ref_eng.raw_levels()):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("h,w,dtype", [(64, 64, torch.float32), (96, 128, torch.uint8), (160, 352, torch.uint8),
+                                        (32, 32, torch.uint8), (224, 416, torch.float16)])
+def test_fused_c3k2_block_is_bit_identical(gpu_device, monkeypatch, h, w, dtype):
+    """Layer 2's Bottleneck (two 3x3 convs + residual) and cv2 (1x1) in one launch (csrc/c3k2s.hip, intermediates
+    in LDS) against the three-launch form: every bit of the network output, on maps with ragged tiles."""
+    sd = synth_state_dict("n", 6, cls_bias=[-2.0, -2.0, -2.0], cls_gain=4.0)
+    g = torch.Generator().manual_seed(h + w)
+    if dtype == torch.uint8:
+        x = torch.randint(0, 256, (2, 3, h, w), generator=g, dtype=torch.uint8)
+    else:
+        x = torch.rand(2, 3, h, w, generator=g).to(dtype)
+    eng = _engine("n", sd, 2, h, w, gpu_device)
+    assert eng.op_kernel(1) == "c3k2_fused_mfma", eng.op_kernel(1)
+    y = eng.forward(x.to(gpu_device)).clone()
+    monkeypatch.setenv("YL_FUSE_C3K2", "0")
+    ref_eng = _engine("n", sd, 2, h, w, gpu_device)
+    assert ref_eng.op_kernel(1).startswith("conv3x3")
+    y_ref = ref_eng.forward(x.to(gpu_device))
+    assert torch.equal(y, y_ref)
+    for a, b in zip(eng.raw_levels(), ref_eng.raw_levels()):
+        assert torch.equal(a, b)

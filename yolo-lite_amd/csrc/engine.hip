@@ -29,6 +29,8 @@ struct OpRec {
   float* d_bias = nullptr;
   float* d_w0 = nullptr;    // fused stem in front of a conv (stem2.hip): filters [C0][27], bias [C0]
   float* d_b0 = nullptr;
+  __bf16* d_wpk3 = nullptr;  // YL_OP_C3K2S: the block's 1x1 conv (d_wpk / d_wpk2 = the Bottleneck's two 3x3 convs)
+  float* d_bias3 = nullptr;
   double flops = 0, bytes = 0;
   const char* name = "";
 };
@@ -292,6 +294,35 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
         r.name = pw ? "dw3x3+pw1x1_mfma" : "dwconv3x3";
         break;
       }
+      case YL_OP_C3K2S: {
+        if (!o.weight || !o.bias || !o.post_weight || !o.post_bias || !o.stem_weight || !o.stem_bias)
+          return fail(-1, tag + ": c3k2 needs the three convs' weights and biases");
+        if (o.in.dtype != YL_BF16 || o.out.dtype != YL_BF16 || o.in.H != o.out.H || o.in.W != o.out.W || o.in.coff != 0 ||
+            o.in.C < 32 || o.in.pitch < 32 || o.out.C != 64 || o.post_cin != 72 || o.lane != 0)
+          return fail(-1, tag + ": c3k2: only the c = 16 block (16 -> 8 -> 16, then 48 -> 64) is supported");
+        struct Part { const float* w; const float* b; int cin, cout, k; __bf16** dw; float** db; };
+        const Part parts[3] = {{o.weight, o.bias, 16, 8, 3, &r.d_wpk, &r.d_bias},
+                               {o.post_weight, o.post_bias, 8, 16, 3, &r.d_wpk2, &r.d_bias2},
+                               {o.stem_weight, o.stem_bias, 48, 64, 1, &r.d_wpk3, &r.d_bias3}};
+        const int want_mt[3] = {1, 1, 4}, want_ks[3] = {5, 3, 2};
+        for (int q = 0; q < 3; ++q) {
+          ConvConfig c{};
+          if (int rc = conv_choose(batch, parts[q].cin, parts[q].cout, parts[q].k, 1, o.out.H, o.out.W, 0, &c)) return rc;
+          if (c.MT != want_mt[q] || c.ksteps != want_ks[q] || c.ncb != 1) return fail(-3, tag + ": c3k2: unexpected tiling");
+          std::vector<uint16_t> pk;
+          conv_pack_weights(parts[q].w, parts[q].cout, parts[q].cin, parts[q].k, c, &pk);
+          uint16_t* d = nullptr;
+          if (int rc = dev_upload(e.get(), pk, &d)) return rc;
+          *parts[q].dw = reinterpret_cast<__bf16*>(d);
+          std::vector<float> bias((size_t)c.MT * 16 + 16, 0.f);
+          for (int ch = 0; ch < parts[q].cout; ++ch) bias[ch] = parts[q].b[ch];
+          if (int rc = dev_upload(e.get(), bias, parts[q].db)) return rc;
+        }
+        r.flops = 2.0 * px_out * (8 * 16 * 9 + 16 * 8 * 9 + 64 * 48);
+        r.bytes = px_out * (32 + 64) * 2;
+        r.name = "c3k2_fused_mfma";
+        break;
+      }
       case YL_OP_STEM: {
         if (i != 0) return fail(-1, tag + ": the stem must be op 0");
         if (!o.weight || !o.bias) return fail(-1, tag + ": stem needs weight and bias");
@@ -427,6 +458,27 @@ static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s, c
       a.stride = o.stride;
       a.act = o.act;
       return conv_launch(r.cfg, a, B, s);
+    }
+    case YL_OP_C3K2S: {
+      C3k2sArgs q{};
+      q.tin = pview(ws, o.in, B);
+      q.yout = pview(ws, o.out, B);
+      q.B = B;
+      q.H = o.out.H;
+      q.W = o.out.W;
+      q.wA = r.d_wpk;
+      q.bA = r.d_bias;
+      q.wB = r.d_wpk2;
+      q.bB = r.d_bias2;
+      q.wC = r.d_wpk3;
+      q.bC = r.d_bias3;
+      const Geo gq = geo_of(B, o.out.H, o.out.W);
+      const long long ib = 4LL * plane_bytes(gq), ob = 8LL * plane_bytes(gq);
+      if (ib > (1LL << 30) || ob > (1LL << 30)) return fail(-3, "c3k2: a tensor slice exceeds 1 GiB; lower the batch size");
+      q.in_bytes = (unsigned)ib;
+      q.out_bytes = (unsigned)ob;
+      q.plane_px = gq.plane_px;
+      return c3k2s_launch(q, s);
     }
     case YL_OP_STEM: {
       if (!input) return fail(-1, "run_op: the stem needs the network input");

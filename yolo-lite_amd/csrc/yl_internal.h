@@ -185,6 +185,23 @@ struct Stem2Args {
 };
 int stem2_launch(const Stem2Args& a, int MT, int in_dtype, hipStream_t s);
 
+// c3k2s.hip: the body of a narrow C3k2 block (Bottleneck 16 -> 8 -> 16 + residual, then cv2 48 -> 64) in one launch
+struct C3k2sArgs {
+  PView tin;             // first plane of the block's concat buffer: planes [a0 a1 | b0 b1 | (c_out, not used)]
+  PView yout;            // first plane of the 64-channel output slice
+  int B, H, W;
+  const __bf16* wA;      // Bottleneck.cv1 (16 -> 8, 3x3), conv_pack_weights order, MT = 1, 5 k-steps
+  const float* bA;       // padded to 16
+  const __bf16* wB;      // Bottleneck.cv2 (8 -> 16, 3x3), MT = 1, 3 k-steps
+  const float* bB;
+  const __bf16* wC;      // C3k2.cv2 (48 -> 64, 1x1), MT = 4, 2 k-steps
+  const float* bC;
+  unsigned in_bytes, out_bytes;
+  long long plane_px;    // pixels per input plane
+  int tiles_x, tiles_y;
+};
+int c3k2s_launch(const C3k2sArgs& a, hipStream_t s);
+
 struct DecodeLevel {
   PView box;     // 8 planes: DFL logits (head.py:64 cv2)
   PView cls;     // nc8 / 8 planes: class logits (cv3); padding channels hold large negative values
