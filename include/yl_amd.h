@@ -35,12 +35,13 @@ enum {
   YL_OP_STEM = 6,     /* first layer fused with the input conversion: 3x3 stride-2 conv on the 3-channel
                          NCHW network input (fp32 / fp16 / uint8, /255 for uint8) -> bf16 planes; must be
                          op 0; weight [Cout][3][3][3]                                              */
-  YL_OP_C3K2S = 7     /* body of a narrow C3k2 block in one launch (nn/modules/block.py:220-235, 330-343), c = 16:
-                         `in` = the block's concat buffer [a | b | ...] (a, b = halves of C3k2.cv1's output, 16 channels
-                         each); c_out = b + SiLU(cv2(SiLU(cv1(b)))) with the Bottleneck's two 3x3 convs
-                         (weight / bias = cv1 [8][16][3][3]; post_weight / post_bias = cv2 [16][8][3][3], post_cin = 72);
-                         out = SiLU(C3k2.cv2(cat(a, b, c_out))) (stem_weight / stem_bias = that 1x1 conv, [64][48]).
-                         The intermediates live in LDS; bit-identical to the three YL_OP_CONV ops it replaces.     */
+  YL_OP_C3K2S = 7     /* body of a narrow C3k2 block in one launch (nn/modules/block.py:220-235, 330-343), half width
+                         c = 16 or 32: `in` = the block's concat buffer [a | b | ...] (a, b = halves of C3k2.cv1's output,
+                         c channels each); c_out = b + SiLU(cv2(SiLU(cv1(b)))) with the Bottleneck's two 3x3 convs
+                         (weight / bias = cv1 [c/2][c][3][3]; post_weight / post_bias = cv2 [c][c/2][3][3], post_cin =
+                         9c/2); out = SiLU(C3k2.cv2(cat(a, b, c_out))) (stem_weight / stem_bias = that 1x1 conv,
+                         [out.C][3c]; out.C = 64, or 128 with c = 32).  The intermediates live in LDS; bit-identical to
+                         the three YL_OP_CONV ops it replaces.                                                      */
 };
 
 /* A channel-slice view of a buffer inside the workspace arena.

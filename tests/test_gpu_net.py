@@ -384,8 +384,9 @@ def test_fused_stem_conv_is_bit_identical(gpu_device, monkeypatch, scale, h, w, 
 @pytest.mark.parametrize("h,w,dtype", [(64, 64, torch.float32), (96, 128, torch.uint8), (160, 352, torch.uint8),
                                         (32, 32, torch.uint8), (224, 416, torch.float16)])
 def test_fused_c3k2_block_is_bit_identical(gpu_device, monkeypatch, h, w, dtype):
-    """Layer 2's Bottleneck (two 3x3 convs + residual) and cv2 (1x1) in one launch (csrc/c3k2s.hip, intermediates
-    in LDS) against the three-launch form: every bit of the network output, on maps with ragged tiles."""
+    """The Bottleneck (two 3x3 convs + residual) and cv2 (1x1) of layers 2, 4 and 16 in one launch each
+    (csrc/c3k2s.hip, intermediates in LDS) against the three-launch form: every bit of the network output, on maps
+    with ragged tiles."""
     sd = synth_state_dict("n", 6, cls_bias=[-2.0, -2.0, -2.0], cls_gain=4.0)
     g = torch.Generator().manual_seed(h + w)
     if dtype == torch.uint8:
@@ -393,7 +394,8 @@ def test_fused_c3k2_block_is_bit_identical(gpu_device, monkeypatch, h, w, dtype)
     else:
         x = torch.rand(2, 3, h, w, generator=g).to(dtype)
     eng = _engine("n", sd, 2, h, w, gpu_device)
-    assert eng.op_kernel(1) == "c3k2_fused_mfma", eng.op_kernel(1)
+    fused = [i for i in range(len(eng.prog.ops)) if eng.op_kernel(i) == "c3k2_fused_mfma"]
+    assert len(fused) == 3 and fused[0] == 1, fused  # layers 2 (c = 16 -> 64), 4 (c = 32 -> 128) and 16 (c = 32 -> 64)
     y = eng.forward(x.to(gpu_device)).clone()
     monkeypatch.setenv("YL_FUSE_C3K2", "0")
     ref_eng = _engine("n", sd, 2, h, w, gpu_device)

@@ -297,29 +297,34 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
       case YL_OP_C3K2S: {
         if (!o.weight || !o.bias || !o.post_weight || !o.post_bias || !o.stem_weight || !o.stem_bias)
           return fail(-1, tag + ": c3k2 needs the three convs' weights and biases");
+        const int c = o.post_cin * 2 / 9;  // Bottleneck.cv2 is [c][c/2][3][3]: post_cin = 9 * c / 2
         if (o.in.dtype != YL_BF16 || o.out.dtype != YL_BF16 || o.in.H != o.out.H || o.in.W != o.out.W || o.in.coff != 0 ||
-            o.in.C < 32 || o.in.pitch < 32 || o.out.C != 64 || o.post_cin != 72 || o.lane != 0)
-          return fail(-1, tag + ": c3k2: only the c = 16 block (16 -> 8 -> 16, then 48 -> 64) is supported");
+            (c != 16 && c != 32) || o.post_cin * 2 != 9 * c || o.in.C < 2 * c || o.in.pitch < 2 * c ||
+            (o.out.C != 64 && !(o.out.C == 128 && c == 32)) || o.lane != 0)
+          return fail(-1, tag + ": c3k2: supported are c = 16 (-> 64 output channels) and c = 32 (-> 64 or 128)");
         struct Part { const float* w; const float* b; int cin, cout, k; __bf16** dw; float** db; };
-        const Part parts[3] = {{o.weight, o.bias, 16, 8, 3, &r.d_wpk, &r.d_bias},
-                               {o.post_weight, o.post_bias, 8, 16, 3, &r.d_wpk2, &r.d_bias2},
-                               {o.stem_weight, o.stem_bias, 48, 64, 1, &r.d_wpk3, &r.d_bias3}};
-        const int want_mt[3] = {1, 1, 4}, want_ks[3] = {5, 3, 2};
+        const Part parts[3] = {{o.weight, o.bias, c, c / 2, 3, &r.d_wpk, &r.d_bias},
+                               {o.post_weight, o.post_bias, c / 2, c, 3, &r.d_wpk2, &r.d_bias2},
+                               {o.stem_weight, o.stem_bias, 3 * c, o.out.C, 1, &r.d_wpk3, &r.d_bias3}};
+        const int cp = c / 8;
+        const int want_mt[3] = {1, cp / 2, 4}, want_ks[3] = {(9 * cp + 3) / 4, (9 * (cp / 2) + 3) / 4, (3 * cp + 3) / 4};
+        const int want_ncb[3] = {1, 1, o.out.C / 64};
         for (int q = 0; q < 3; ++q) {
-          ConvConfig c{};
-          if (int rc = conv_choose(batch, parts[q].cin, parts[q].cout, parts[q].k, 1, o.out.H, o.out.W, 0, &c)) return rc;
-          if (c.MT != want_mt[q] || c.ksteps != want_ks[q] || c.ncb != 1) return fail(-3, tag + ": c3k2: unexpected tiling");
+          ConvConfig cc{};
+          if (int rc = conv_choose(batch, parts[q].cin, parts[q].cout, parts[q].k, 1, o.out.H, o.out.W, 0, &cc)) return rc;
+          if (cc.MT != want_mt[q] || cc.ksteps != want_ks[q] || cc.ncb != want_ncb[q])
+            return fail(-3, tag + ": c3k2: unexpected tiling");
           std::vector<uint16_t> pk;
-          conv_pack_weights(parts[q].w, parts[q].cout, parts[q].cin, parts[q].k, c, &pk);
+          conv_pack_weights(parts[q].w, parts[q].cout, parts[q].cin, parts[q].k, cc, &pk);
           uint16_t* d = nullptr;
           if (int rc = dev_upload(e.get(), pk, &d)) return rc;
           *parts[q].dw = reinterpret_cast<__bf16*>(d);
-          std::vector<float> bias((size_t)c.MT * 16 + 16, 0.f);
+          std::vector<float> bias((size_t)cc.ncb * cc.MT * 16 + 16, 0.f);
           for (int ch = 0; ch < parts[q].cout; ++ch) bias[ch] = parts[q].b[ch];
           if (int rc = dev_upload(e.get(), bias, parts[q].db)) return rc;
         }
-        r.flops = 2.0 * px_out * (8 * 16 * 9 + 16 * 8 * 9 + 64 * 48);
-        r.bytes = px_out * (32 + 64) * 2;
+        r.flops = 2.0 * px_out * (9.0 * c * c / 2 * 2 + 3.0 * c * o.out.C);
+        r.bytes = px_out * (2 * c + o.out.C) * 2;
         r.name = "c3k2_fused_mfma";
         break;
       }
@@ -466,6 +471,8 @@ static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s, c
       q.B = B;
       q.H = o.out.H;
       q.W = o.out.W;
+      q.c = o.post_cin * 2 / 9;
+      q.cout = o.out.C;
       q.wA = r.d_wpk;
       q.bA = r.d_bias;
       q.wB = r.d_wpk2;
@@ -473,7 +480,7 @@ static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s, c
       q.wC = r.d_wpk3;
       q.bC = r.d_bias3;
       const Geo gq = geo_of(B, o.out.H, o.out.W);
-      const long long ib = 4LL * plane_bytes(gq), ob = 8LL * plane_bytes(gq);
+      const long long ib = (long long)(q.c / 4) * plane_bytes(gq), ob = (long long)(o.out.C / 8) * plane_bytes(gq);
       if (ib > (1LL << 30) || ob > (1LL << 30)) return fail(-3, "c3k2: a tensor slice exceeds 1 GiB; lower the batch size");
       q.in_bytes = (unsigned)ib;
       q.out_bytes = (unsigned)ob;

@@ -190,7 +190,8 @@ struct C3k2sArgs {
   PView tin;             // first plane of the block's concat buffer: planes [a0 a1 | b0 b1 | (c_out, not used)]
   PView yout;            // first plane of the 64-channel output slice
   int B, H, W;
-  const __bf16* wA;      // Bottleneck.cv1 (16 -> 8, 3x3), conv_pack_weights order, MT = 1, 5 k-steps
+  int c, cout;           // half width (16 or 32) and output channels (64 or 128)
+  const __bf16* wA;      // Bottleneck.cv1 (c -> c/2, 3x3), conv_pack_weights order, MT = 1
   const float* bA;       // padded to 16
   const __bf16* wB;      // Bottleneck.cv2 (8 -> 16, 3x3), MT = 1, 3 k-steps
   const float* bB;

@@ -247,9 +247,9 @@ def fuse_stem_into_conv(ops: List[dict], in_w: int) -> List[dict]:
 
 
 def fuse_c3k2_small(ops: List[dict]) -> List[dict]:
-    """Bottleneck.cv1 (3x3, 16 -> 8), Bottleneck.cv2 (3x3, 8 -> 16, + residual) and C3k2.cv2 (1x1, 48 -> 64) of a
-    C3k2 block with c = 16 (layer 2 of YOLO11n, 160x160 at a 640 input): one launch (``OP_C3K2S``, csrc/c3k2s.hip)
-    with the intermediates in LDS instead of three that move 0.39 GB per batch of 32.  Bit-identical."""
+    """Bottleneck.cv1 (3x3, c -> c/2), Bottleneck.cv2 (3x3, c/2 -> c, + residual) and C3k2.cv2 (1x1, 3c -> c2) of a
+    C3k2 block with c = 16 or 32 (layers 2, 4 and 16 of YOLO11n): one launch (``OP_C3K2S``, csrc/c3k2s.hip) with the
+    intermediates in LDS instead of three (0.39 GB per batch of 32 for layer 2 alone).  Bit-identical."""
 
     def same(u: TView, v: TView):
         return u is not None and v is not None and (u.offset, u.coff, u.C, u.pitch) == (v.offset, v.coff, v.C, v.pitch)
@@ -269,12 +269,14 @@ def fuse_c3k2_small(ops: List[dict]) -> List[dict]:
         ok = (b is not None and c is not None and all(o["kind"] == OP_CONV and not o.get("lane", 0) and o.get("act", 0)
                                                        and "post_weight" not in o and "stem_weight" not in o
                                                        and o.get("inp2") is None and not o.get("cin_weight", 0) for o in (a, b, c))
-              and a.get("k") == 3 and a.get("stride", 1) == 1 and a.get("res") is None and a["inp"].C == 16 and a["out"].C == 8
+              and a.get("k") == 3 and a.get("stride", 1) == 1 and a.get("res") is None and a["inp"].C in (16, 32)
+              and a["out"].C * 2 == a["inp"].C
               and b.get("k") == 3 and b.get("stride", 1) == 1 and same(b["inp"], a["out"]) and same(b.get("res"), a["inp"])
-              and b["out"].C == 16 and c.get("k") == 1 and c.get("stride", 1) == 1 and c.get("res") is None
-              and c["inp"].C == 48 and c["inp"].coff == 0 and c["out"].C == 64 and c["out"].dtype == BF16
-              and a["inp"].offset == c["inp"].offset and a["inp"].coff == 16 and a["inp"].pitch == c["inp"].pitch
-              and b["out"].offset == c["inp"].offset and b["out"].coff == 32)
+              and b["out"].C == a["inp"].C and c.get("k") == 1 and c.get("stride", 1) == 1 and c.get("res") is None
+              and c["inp"].C == 3 * a["inp"].C and c["inp"].coff == 0 and c["out"].dtype == BF16
+              and (c["out"].C == 64 or (c["out"].C == 128 and a["inp"].C == 32))
+              and a["inp"].offset == c["inp"].offset and a["inp"].coff == a["inp"].C and a["inp"].pitch == c["inp"].pitch
+              and b["out"].offset == c["inp"].offset and b["out"].coff == 2 * a["inp"].C)
         if ok:  # the intermediate and c_out must have no other reader
             others = [o for j, o in enumerate(ops) if j not in (i, i + 1, i + 2)]
             ok = not any(reads(o, a["out"]) or reads(o, b["out"]) for o in others)
