@@ -47,6 +47,10 @@ def family(k):
         return "dw3x3+pw1x1_mfma"
     if k.startswith("stem_kernel"):
         return "stem_conv3x3s2"
+    if k.startswith("stem2_kernel"):
+        return "stem+conv3x3s2_mfma"
+    if k.startswith("c3k2s_kernel"):
+        return "c3k2_fused_mfma"
     if k.startswith("dwconv3_kernel"):
         return "dwconv3x3"
     if k.startswith("sppf_pool"):
