@@ -110,6 +110,10 @@ typedef struct yl_op {
   const float* stem_weight;
   const float* stem_bias;
   int32_t stem_act, reserved2;
+  /* YL_OP_DWCONV3 with post_weight (depthwise 3x3 -> pointwise 1x1 in one launch) AND stem_weight: a further 1x1
+     conv behind the pointwise one (the nn.Conv2d(c3, nc, 1) that ends Detect's class branch, head.py:47), also in
+     that launch: reserved2 = output channels of the pointwise conv (post_weight [reserved2][in.C]), stem_weight
+     [out.C][reserved2], stem_bias [out.C], SiLU if stem_act; `out` is the last conv's output. */
 } yl_op;
 
 /* Detect-level raw maps (reference head.py:64-65 torch.cat(cv2, cv3)): two bf16 buffers in the planar

@@ -404,3 +404,23 @@ def test_fused_c3k2_block_is_bit_identical(gpu_device, monkeypatch, h, w, dtype)
     assert torch.equal(y, y_ref)
     for a, b in zip(eng.raw_levels(), ref_eng.raw_levels()):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("h,w", [(64, 64), (96, 128), (160, 352)])
+def test_fused_class_branch_tail_is_bit_identical(gpu_device, monkeypatch, h, w):
+    """Detect's class branch: DWConv -> Conv 1x1 -> nn.Conv2d 1x1 (head.py:41-48) in one launch per level against
+    the two-launch form (the 80-channel tensor between the 1x1 convs stays in LDS): every bit of the output."""
+    sd = synth_state_dict("n", 8, cls_bias=[-2.0, -2.0, -2.0], cls_gain=4.0)
+    x = torch.rand(2, 3, h, w, generator=torch.Generator().manual_seed(h * 3 + w))
+    monkeypatch.setenv("YL_FUSE_DWPW_TAIL", "1")  # opt-in (slower end to end, see nn/lower.py)
+    eng = _engine("n", sd, 2, h, w, gpu_device)
+    fused = [i for i in range(len(eng.prog.ops)) if eng.op_kernel(i) == "dw3x3+pw1x1+1x1_mfma"]
+    assert len(fused) == 3, fused
+    y = eng.forward(x.to(gpu_device)).clone()
+    monkeypatch.setenv("YL_FUSE_DWPW_TAIL", "0")
+    ref_eng = _engine("n", sd, 2, h, w, gpu_device)
+    assert not any(ref_eng.op_kernel(i) == "dw3x3+pw1x1+1x1_mfma" for i in range(len(ref_eng.prog.ops)))
+    y_ref = ref_eng.forward(x.to(gpu_device))
+    assert torch.equal(y, y_ref)
+    for a, b in zip(eng.raw_levels(), ref_eng.raw_levels()):
+        assert torch.equal(a, b)

@@ -22,9 +22,11 @@ def _conv_gflop(prog):
             f += 2.0 * o["out"].H * o["out"].W * w.shape[0] * w.shape[1] * w.shape[2] * w.shape[3]
             if "post_weight" in o:  # a 1x1 conv fused into this conv's epilogue
                 f += 2.0 * o["out"].H * o["out"].W * o["post_weight"].shape[0] * o["post_weight"].shape[1]
-            if "stem_weight" in o:  # the network's first layer fused in front of this conv
+            if "stem_weight" in o and o["kind"] == OP_CONV:  # the network's first layer fused in front of this conv
                 w0 = o["stem_weight"]
                 f += 2.0 * o["inp"].H * o["inp"].W * w0.shape[0] * w0.shape[1] * w0.shape[2] * w0.shape[3]
+            if "stem_weight" in o and o["kind"] == OP_DWCONV3:  # a further 1x1 behind depthwise + pointwise
+                f += 2.0 * o["out"].H * o["out"].W * o["stem_weight"].shape[0] * o["stem_weight"].shape[1]
     return f / 1e9
 
 

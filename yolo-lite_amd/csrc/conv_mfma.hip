@@ -199,7 +199,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
 // the intermediate tensor is never written to or read from HBM.  Same arithmetic and operation order as
 // dwconv3_kernel followed by conv_kernel (bit-identical results).  Needs all output channels in one
 // workgroup (Cout <= 80 here: MT <= 5, ncb == 1).
-template <int MT, int NT>
+// PW2: a further 1x1 conv that consumes ONLY the pointwise conv's output (head.py:47: the nn.Conv2d(c3, nc, 1) that
+// ends the class branch) runs behind it from LDS: the pointwise result is written into the depthwise tile's place in
+// B-fragment order and multiplied by the second filter slab; that tensor is never stored either.
+template <int MT, int NT, bool PW2 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void dwpw_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int P = 64 * NT;  // pixels per workgroup
@@ -208,13 +211,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
   const int pblk = xcd_remap(blockIdx.x, gridDim.x);
   const int C = a.Cin;
   bf16x8* slab = reinterpret_cast<bf16x8*>(smem);
-  bf16x8* tile = slab + a.ksteps * MT * 64;                       // [cg][P]
-  float* dww = reinterpret_cast<float*>(tile + a.cg * P);         // [9][C] filter taps, then [C] bias
+  bf16x8* tile = slab + a.ksteps * MT * 64;                       // [max(cg, cg2)][P]
+  const int tile_planes = PW2 ? max(a.cg, a.cg2) : a.cg;
+  float* dww = reinterpret_cast<float*>(tile + tile_planes * P);  // [9][C] filter taps, then [C] bias
+  bf16x8* slab2 = reinterpret_cast<bf16x8*>(dww + 10 * C);        // PW2: [ksteps2][MT][64]
   const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, (short)0, a.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.out, (short)0, a.out_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc((void*)nullptr, (short)0, 0, 0x00020000);
 
   copy_slab(reinterpret_cast<const bf16x8*>(a.wpk), slab, a.ksteps * MT * 64, tid);
+  if constexpr (PW2) copy_slab(reinterpret_cast<const bf16x8*>(a.wpk2), slab2, a.ksteps2 * MT * 64, tid);
   for (int i = tid; i < 10 * C; i += 256) dww[i] = i < 9 * C ? a.dw_w[i] : a.dw_b[i - 9 * C];
   __syncthreads();
 
@@ -261,9 +267,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
 
   // ---- 1x1 GEMM from LDS
   const int patch = pblk * 4 + wave;
-  if (patch >= a.npatches) return;
+  const bool live = patch < a.npatches;
+  if (!PW2 && !live) return;
   Patch<NT> Pp;
-  patch_setup<NT>(a, patch, n, 0u, Pp);
+  patch_setup<NT>(a, live ? patch : 0, n, 0u, Pp);
   f32x4 acc[MT][NT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -281,7 +288,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
     for (int nt = 0; nt < NT; ++nt) xb[nt] = k8 < a.cg ? tile[k8 * P + wave * 16 * NT + nt * 16 + n] : zero;
     mma_step<MT, NT>(wa, xb, acc);
   }
-  epilogue<MT, NT>(a, rout, rres, 0, g, Pp.opix, acc);
+  if constexpr (!PW2) {
+    epilogue<MT, NT>(a, rout, rres, 0, g, Pp.opix, acc);
+  } else {
+    // pointwise result (SiLU, bf16: exactly what the unfused kernel stores) -> the tile, as planes of 8 channels:
+    // rows of tile mt are channels chan_in_block(MT, mt, g, 0..3), i.e. half a 16-byte pixel of one plane
+    __syncthreads();  // every wave has read its depthwise operands
+    unsigned char* tb = reinterpret_cast<unsigned char*>(tile);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int ch = chan_in_block(MT, mt, g, 0);
+      if (ch < a.cg2 * 8) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          bf16x4 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = (__bf16)(a.act ? silu_f(acc[mt][nt][r]) : acc[mt][nt][r]);
+          *reinterpret_cast<bf16x4*>(tb + ((size_t)(ch >> 3) * P + wave * 16 * NT + nt * 16 + n) * 16 + (ch & 7) * 2) = o;
+        }
+      }
+    }
+    __syncthreads();
+    if (!live) return;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias2 + chan_in_block(MT, mt, g, 0));
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = bv;
+    }
+    for (int ks = 0; ks < a.ksteps2; ++ks) {
+      bf16x8 wa[MT], xb[NT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) wa[mt] = slab2[(ks * MT + mt) * 64 + lane];
+      const int k8 = ks * 4 + g;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) xb[nt] = k8 < a.cg2 ? tile[k8 * P + wave * 16 * NT + nt * 16 + n] : zero;
+      mma_step<MT, NT>(wa, xb, acc);
+    }
+    ConvArgs a2 = a;
+    a2.Cout = a.post_cout;
+    a2.act = a.post_act;
+    epilogue<MT, NT>(a2, rout, rres, 0, g, Pp.opix, acc);
+  }
 }
 
 // ------------------------------------------------------------------------------------ host
@@ -454,9 +502,9 @@ static int launch_m(const ConvConfig& cfg, const ConvArgs& a, hipStream_t s) {
   return fail(-3, "conv: bad MT");
 }
 
-template <int MT, int NT>
-static int launch_dwpw(const ConvConfig& cfg, const ConvArgs& a, size_t lds, hipStream_t s) {
-  auto kern = dwpw_kernel<MT, NT>;
+template <int MT, int NT, bool PW2>
+static int launch_dwpw2(const ConvConfig& cfg, const ConvArgs& a, size_t lds, hipStream_t s) {
+  auto kern = dwpw_kernel<MT, NT, PW2>;
   static size_t attr = 0;
   if (lds > attr) {
     YL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -469,7 +517,12 @@ static int launch_dwpw(const ConvConfig& cfg, const ConvArgs& a, size_t lds, hip
   return 0;
 }
 
-// depthwise 3x3 + pointwise 1x1 (see dwpw_kernel); cfg from conv_choose(Cin = C, k = 1)
+template <int MT, int NT>
+static int launch_dwpw(const ConvConfig& cfg, const ConvArgs& a, size_t lds, hipStream_t s) {
+  return a.wpk2 ? launch_dwpw2<MT, NT, true>(cfg, a, lds, s) : launch_dwpw2<MT, NT, false>(cfg, a, lds, s);
+}
+
+// depthwise 3x3 + pointwise 1x1 [+ a further 1x1] (see dwpw_kernel); cfg from conv_choose(Cin = C, k = 1)
 int dwpw_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s) {
   if (cfg.ncb != 1 || cfg.kchunk < cfg.ksteps || cfg.NT > 2)
     return fail(-3, "dwpw: needs all output channels in one workgroup and NT <= 2");
@@ -484,13 +537,16 @@ int dwpw_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s) {
   a.ppw = 1;
   a.npix = batch * a.Ho * a.Wo;
   const long long lim = 1LL << 30;
-  const long long inb = (long long)cfg.cg * a.in_plane, outb = (long long)((a.Cout + 7) / 8) * a.out_plane;
+  const int cout_stored = a.wpk2 ? a.post_cout : a.Cout;
+  const long long inb = (long long)cfg.cg * a.in_plane, outb = (long long)((cout_stored + 7) / 8) * a.out_plane;
   if (inb > lim || outb > lim) return fail(-3, "dwpw: a tensor slice exceeds 1 GiB; lower the batch size");
   a.in_bytes = (unsigned)inb;
   a.out_bytes = (unsigned)outb;
   a.nblocks = (cfg.npatches + 3) / 4;
   a.dbg = 0;
-  const size_t lds = (size_t)cfg.ksteps * cfg.MT * 1024 + (size_t)cfg.cg * 64 * cfg.NT * 16 + (size_t)10 * a.Cin * 4;
+  const int planes = a.wpk2 && a.cg2 > cfg.cg ? a.cg2 : cfg.cg;
+  const size_t lds = (size_t)cfg.ksteps * cfg.MT * 1024 + (size_t)planes * 64 * cfg.NT * 16 + (size_t)10 * a.Cin * 4 +
+                     (a.wpk2 ? (size_t)a.ksteps2 * cfg.MT * 1024 : 0);
   if (lds > LDS_MAX) return fail(-3, "dwpw: LDS budget exceeded");
   switch (cfg.MT * 10 + cfg.NT) {
     case 11: return launch_dwpw<1, 1>(cfg, a, lds, s);

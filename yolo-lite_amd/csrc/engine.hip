@@ -267,7 +267,12 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
         if (pw) {
           if (!o.post_bias || o.accumulate || o.grp || o.post_cin != C)
             return fail(-1, tag + ": fused depthwise+pointwise needs a plain depthwise conv and post_cin == in.C");
-          if (int rc = conv_choose(batch, C, o.out.C, 1, 1, o.out.H, o.out.W, 0, &r.cfg)) return rc;
+          // a further 1x1 behind the pointwise conv (stem_weight [out.C][mid], mid = reserved2 channels of the pointwise)
+          const bool tail = o.stem_weight != nullptr;
+          const int pw_cout = tail ? o.reserved2 : o.out.C;
+          if (tail && (!o.stem_bias || pw_cout <= 0 || pw_cout % 8))
+            return fail(-1, tag + ": depthwise+pointwise+1x1 needs stem_bias and reserved2 = pointwise channels (% 8 == 0)");
+          if (int rc = conv_choose(batch, C, pw_cout, 1, 1, o.out.H, o.out.W, 0, &r.cfg)) return rc;
           if (r.cfg.NT > 2) {
             r.cfg.NT = 2;
             r.cfg.npatches = (int)(((long long)batch * o.out.H * o.out.W + 31) / 32);
@@ -275,13 +280,28 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
           if (r.cfg.ncb != 1 || r.cfg.kchunk < r.cfg.ksteps)
             return fail(-3, tag + ": fused depthwise+pointwise needs Cout <= 80 and a filter that fits the slab");
           std::vector<uint16_t> pk;
-          conv_pack_weights(o.post_weight, o.out.C, C, 1, r.cfg, &pk);
+          conv_pack_weights(o.post_weight, pw_cout, C, 1, r.cfg, &pk);
           uint16_t* d = nullptr;
           if (int rc = dev_upload(e.get(), pk, &d)) return rc;
           r.d_wpk = reinterpret_cast<__bf16*>(d);
           std::vector<float> b2((size_t)r.cfg.MT * 16 + 16, 0.f);
-          for (int c = 0; c < o.out.C; ++c) b2[c] = o.post_bias[c];
+          for (int c = 0; c < pw_cout; ++c) b2[c] = o.post_bias[c];
           if (int rc = dev_upload(e.get(), b2, &r.d_bias2)) return rc;
+          if (tail) {
+            ConvConfig c3{};
+            if (int rc = conv_choose(batch, pw_cout, o.out.C, 1, 1, o.out.H, o.out.W, 0, &c3)) return rc;
+            if (c3.MT != r.cfg.MT || c3.ncb != 1 || c3.kchunk < c3.ksteps)
+              return fail(-3, tag + ": depthwise+pointwise+1x1: both 1x1 convs must have the same number of channel tiles");
+            std::vector<uint16_t> pk3;
+            conv_pack_weights(o.stem_weight, o.out.C, pw_cout, 1, c3, &pk3);
+            uint16_t* d3 = nullptr;
+            if (int rc = dev_upload(e.get(), pk3, &d3)) return rc;
+            r.d_wpk3 = reinterpret_cast<__bf16*>(d3);
+            std::vector<float> b3((size_t)c3.MT * 16 + 16, 0.f);
+            for (int c = 0; c < o.out.C; ++c) b3[c] = o.stem_bias[c];
+            if (int rc = dev_upload(e.get(), b3, &r.d_bias3)) return rc;
+            r.cfg.kchunk = c3.ksteps;  // (kchunk == ksteps was checked above) carries the tail's k-steps to run_op
+          }
         }
         std::vector<float> wt((size_t)9 * C);
         for (int c = 0; c < C; ++c)
@@ -289,9 +309,13 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
         if (int rc = dev_upload(e.get(), wt, &r.d_w)) return rc;
         std::vector<float> bias(o.bias, o.bias + C);
         if (int rc = dev_upload(e.get(), bias, &r.d_bias)) return rc;
-        r.flops = 2.0 * px_out * C * 9 + (pw ? 2.0 * px_out * C * o.out.C : 0.0);
+        {
+          const int pwc = pw && o.stem_weight ? o.reserved2 : o.out.C;
+          r.flops = 2.0 * px_out * C * 9 + (pw ? 2.0 * px_out * C * pwc : 0.0) +
+                    (pw && o.stem_weight ? 2.0 * px_out * pwc * o.out.C : 0.0);
+        }
         r.bytes = pw ? px_out * (C + o.out.C) * 2 : px_out * C * 2 * (o.accumulate ? 3 : 2);
-        r.name = pw ? "dw3x3+pw1x1_mfma" : "dwconv3x3";
+        r.name = pw ? (o.stem_weight ? "dw3x3+pw1x1+1x1_mfma" : "dw3x3+pw1x1_mfma") : "dwconv3x3";
         break;
       }
       case YL_OP_C3K2S: {
@@ -528,7 +552,18 @@ static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s, c
         a.Cout = o.out.C;
         a.stride = 1;
         a.act = o.post_act;
-        return dwpw_launch(r.cfg, a, B, s);
+        ConvConfig cfg = r.cfg;
+        if (r.d_wpk3) {  // a further 1x1 behind the pointwise conv
+          a.Cout = o.reserved2;
+          a.wpk2 = r.d_wpk3;
+          a.bias2 = r.d_bias3;
+          a.post_cout = o.out.C;
+          a.post_act = o.stem_act;
+          a.cg2 = o.reserved2 / 8;
+          a.ksteps2 = r.cfg.kchunk;
+          cfg.kchunk = cfg.ksteps;
+        }
+        return dwpw_launch(cfg, a, B, s);
       }
       DwArgs a{};
       a.in = pview(ws, o.in, B);

@@ -75,6 +75,7 @@ struct ConvArgs {
   const __bf16* wpk2;  // fused follow-up 1x1: [MT/2 k-steps][MT][64 lanes][8], nullptr: none
   const float* bias2;  // its bias, padded to MT*16
   int post_cout, post_act;
+  int ksteps2, cg2;    // dwpw_kernel with a further 1x1 (wpk2): its k-steps and input planes
   const float* dw_w;   // dwpw_kernel: depthwise taps [9][C] and bias [C], SiLU flag
   const float* dw_b;
   int dw_act;

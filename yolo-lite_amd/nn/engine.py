@@ -63,6 +63,7 @@ class HipEngine:
                 b0 = np.ascontiguousarray(o["stem_bias"], dtype=np.float32)
                 self._keep += [w0, b0]
                 c.stem_weight, c.stem_bias, c.stem_act = w0.ctypes.data, b0.ctypes.data, int(o.get("stem_act", 1))
+                c.reserved2 = int(o.get("mid_c", 0))
             if "post_weight" in o:
                 w2 = np.ascontiguousarray(o["post_weight"], dtype=np.float32).reshape(o["post_weight"].shape[0], -1)
                 b2 = np.ascontiguousarray(o["post_bias"], dtype=np.float32)

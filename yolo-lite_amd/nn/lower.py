@@ -180,6 +180,43 @@ def fuse_depthwise_pointwise(ops: List[dict]) -> List[dict]:
     return [o for i, o in enumerate(ops) if i not in drop]
 
 
+def fuse_dwpw_tail(ops: List[dict]) -> List[dict]:
+    """(DWConv 3x3 -> 1x1 Conv) -> 1x1 Conv, where the last conv is the only reader of the pair's output and has the
+    same number of 16-channel tiles (Detect's class branch, head.py:41-48: ..., DWConv(c3, c3, 3), Conv(c3, c3, 1),
+    nn.Conv2d(c3, nc, 1)): the last conv joins the fused depthwise + pointwise launch (``yl_op.stem_*`` on a
+    YL_OP_DWCONV3 op); the c3-channel tensor between them is never stored."""
+
+    def planes(v: TView):
+        return {(v.offset, p) for p in range(v.coff // 8, (v.coff + v.C) // 8)}
+
+    drop = set()
+    for i, a in enumerate(ops):
+        if a["kind"] != OP_DWCONV3 or "post_weight" not in a or "stem_weight" in a:
+            continue
+        y = a["out"]
+        mine = planes(y)
+        rd = [j for j, o in enumerate(ops) for k in ("inp", "res", "inp2")
+              if o.get(k) is not None and o[k].dtype == BF16 and planes(o[k]) & mine]
+        if len(rd) != 1 or rd[0] <= i:
+            continue
+        b = ops[rd[0]]
+        if (b["kind"] != OP_CONV or b.get("k") != 1 or b.get("stride", 1) != 1 or b.get("res") is not None
+                or "post_weight" in b or b.get("inp2") is not None or b.get("cin_weight", 0) or y.C % 8
+                or (b["out"].C + 15) // 16 != (y.C + 15) // 16 or b["out"].dtype != BF16
+                or b.get("lane", 0) != a.get("lane", 0)
+                or (b["inp"].offset, b["inp"].coff, b["inp"].C) != (y.offset, y.coff, y.C)):
+            continue
+        a["stem_weight"] = b["weight"].reshape(b["weight"].shape[0], -1)
+        a["stem_bias"] = b["bias"]
+        a["stem_act"] = b.get("act", 0)
+        a["mid_c"] = y.C
+        a["out"] = b["out"]
+        a["name"] = f"{a.get('name', '')}+{b.get('name', '').split('.')[-1]}"
+        a["fused_names"] = list(a.get("fused_names", [])) + [b.get("name", "")]
+        drop.add(rd[0])
+    return [o for i, o in enumerate(ops) if i not in drop]
+
+
 def fuse_upsample_into_convs(ops: List[dict]) -> List[dict]:
     """nn.Upsample(2, nearest) -> Concat -> 1x1 conv (yolo11.yaml:31-36): when that conv is the only
     reader of the upsampled planes, it reads the low-resolution map itself at pixel (y/2, x/2)
@@ -542,6 +579,12 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
         ops[:] = fuse_follow_up_convs(ops)
     if fuse_post and os.environ.get("YL_FUSE_DWPW", "1") != "0":
         ops[:] = fuse_depthwise_pointwise(ops)
+        # opt-in: the three class-branch tails take 85 us instead of 110 us one after the other, but the whole step
+        # got SLOWER on MI355X (34.7-37.1 k vs 40.9-41.7 k images/s, one-batch latency 1.47 vs 1.28 ms): the 80x80
+        # class branch runs on the graph's second queue beside the trunk, and the longer, LDS-heavier kernel (53 KB
+        # per workgroup instead of 38) crowds the trunk's kernels out of the CUs
+        if os.environ.get("YL_FUSE_DWPW_TAIL", "0") == "1":
+            ops[:] = fuse_dwpw_tail(ops)
     if fuse_post and os.environ.get("YL_FUSE_UP", "1") != "0":
         ops[:] = fuse_upsample_into_convs(ops)
     if fuse_post and os.environ.get("YL_FUSE_STEM", "1") != "0":
