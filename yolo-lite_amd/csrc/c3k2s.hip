@@ -8,11 +8,12 @@
 // intermediate and c_out are written and re-read, cat(a, b, c_out) is re-read) for 52 MB of input and 105 MB of
 // output; their matrix work is trivial.  Here b, the intermediate and c_out live in LDS tiles.
 //
-// One workgroup (256 threads) = TR x TC = 4 x 32 output pixels of one image (sizes for c = 16):
-//   0. b with a halo of 2 (8 x 36 pixels, 2 planes) and a (4 x 32, 2 planes) -> LDS.  Positions outside the map read
+// One workgroup (256 threads) = TR x TC = 8 x 32 output pixels of one image (sizes for c = 16; 4 x 32 tiles took
+// 126 us for the three blocks, 8 x 32 take 117 us: less halo per output):
+//   0. b with a halo of 2 (12 x 36 pixels, 2 planes) and a (8 x 32, 2 planes) -> LDS.  Positions outside the map read
 //      the layout's zero guards or a neighbouring row / image; those values only ever feed intermediate positions
 //      that phase A forces to zero, so no bounds logic is needed on the loads.
-//   A. mid = SiLU(cv1(b)) on the 6 x 34 pixels phase B needs, ZERO outside the map (it is cv2's zero padding).
+//   A. mid = SiLU(cv1(b)) on the 10 x 34 pixels phase B needs, ZERO outside the map (it is cv2's zero padding).
 //   B. c_out = b + SiLU(cv2(mid)) on the tile.
 //   C. y = SiLU(cv2'(a, b, c_out)): K = 48 channels from three LDS tiles, 64 output channels, 16-byte stores.
 // Filters arrive as conv_pack_weights fragments (the whole block is 88 KB of bf16 registers-worth: 15 fragments per
@@ -21,7 +22,7 @@
 
 namespace yl {
 
-constexpr int C3_TR = 4, C3_TC = 32;
+constexpr int C3_TR = 8, C3_TC = 32;
 constexpr int C3_BR = C3_TR + 4, C3_BC = C3_TC + 4;   // b tile with halo 2
 constexpr int C3_MR = C3_TR + 2, C3_MC = C3_TC + 2;   // intermediate with halo 1
 
