@@ -141,7 +141,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="images per GPU")
     ap.add_argument("--imgsz", type=int, default=640)
     ap.add_argument("--scale", default="n")
-    ap.add_argument("--streams", type=int, default=4,
+    ap.add_argument("--streams", type=int, default=5,
                     help="batches in flight: consecutive steps are issued round-robin on this many HIP streams "
                          "(one workspace slot each) so one batch's large kernels overlap another's small ones")
     ap.add_argument("--no-cpu-baseline", action="store_true")
