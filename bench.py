@@ -4,11 +4,11 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of the hot path over one batch of synthetic images: HIP network forward
-(input conversion + 110 kernels + Detect decode, replayed from a hipGraph) + GPU NMS, with the
-inputs already resident in HBM at N=1.  For N>1 the images are sharded 32 per GPU (weak scaling):
-rank 0 owns the global uint8 batch, scatters slices over RCCL (overlapped with the previous step's
-compute) and gathers fixed-size result records; value = all ranks' images / max-over-ranks time.
+One "step" = one pass of the hot path over one batch of synthetic images: HIP network forward (about 70
+kernels from the uint8 input to the Detect level maps) + fused Detect decode + GPU NMS, replayed as ONE
+hipGraph, with the inputs already resident in HBM.  For N>1 the images are sharded 32 per GPU (weak
+scaling): every rank runs the same hot path on shards resident in its own HBM, one RCCL gather returns the
+last step's result records to rank 0; value = all ranks' images / max-over-ranks time.
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
