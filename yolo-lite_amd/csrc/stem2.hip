@@ -32,13 +32,6 @@ size_t stem2_lds_bytes(int C0) {
   return (size_t)3 * S2_IR * S2_IP * 2 + (size_t)(C0 / 8) * S2_SR * S2_SP * 16;
 }
 
-template <typename T>
-__device__ __forceinline__ float s2_cvt(T v) {
-  float f = (float)v;
-  if constexpr (sizeof(T) == 1) f = f / 255.0f;  // true division, as predictor.py:84
-  return f;
-}
-
 template <typename T, int MT, bool POST>
 __global__ __launch_bounds__(256) void stem2_kernel(Stem2Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s2mem[];
