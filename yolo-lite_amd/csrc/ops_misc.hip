@@ -515,7 +515,9 @@ constexpr int AT_KP = AT_KD + 8;       // K row pitch (elements): 80-byte rows
 constexpr int AT_VP = AT_STAGE + 8;    // V^T row pitch (elements)
 constexpr int AT_QSPLIT = 4;           // workgroups per (image, head)
 
-__global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
+constexpr int AT_WAVES = 8;  // waves per workgroup: 4 x 8 = 32 query-tile slots per (image, head) cover the 25 tiles of a
+                             // 20x20 map in ONE round (4 waves needed two, the second 9/16 full)
+__global__ __launch_bounds__(64 * AT_WAVES) void attention_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char asm_[];
   __bf16* sK = reinterpret_cast<__bf16*>(asm_);   // [AT_STAGE][AT_KP]
   __bf16* sVt = sK + AT_STAGE * AT_KP;            // [64][AT_VP]
@@ -535,12 +537,12 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
   };
   const int nqt = (a.N + 15) / 16;                       // query tiles
   const int nstage = (a.N + AT_STAGE - 1) / AT_STAGE;
-  const int wslot = qs * 4 + wave;                       // this wave takes q tiles wslot, wslot + 8, ...
-  const int rounds = (nqt + 4 * AT_QSPLIT - 1) / (4 * AT_QSPLIT);
+  const int wslot = qs * AT_WAVES + wave;                // this wave takes q tiles wslot, wslot + AT_WAVES * AT_QSPLIT, ...
+  const int rounds = (nqt + AT_WAVES * AT_QSPLIT - 1) / (AT_WAVES * AT_QSPLIT);
   const float ninf = -__builtin_huge_valf();
 
   for (int rd = 0; rd < rounds; ++rd) {
-    const int qt = wslot + rd * 4 * AT_QSPLIT;
+    const int qt = wslot + rd * AT_WAVES * AT_QSPLIT;
     const bool active = qt < nqt;
     const int q = qt * 16 + n;
     bf16x8 qf = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -558,33 +560,33 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs a) {
         __syncthreads();  // previous users of the stage buffers are done
         // loads are issued in batches of 8 per thread before the first LDS write (one memory round
         // trip per batch instead of one per vector)
-        for (int i0 = tid; i0 < nk32 * 4; i0 += 256 * 8) {
+        for (int i0 = tid; i0 < nk32 * 4; i0 += 64 * AT_WAVES * 8) {
           bf16x8 v[8];
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
-            const int i = i0 + u * 256, key = i >> 2, c8 = i & 3;
+            const int i = i0 + u * 64 * AT_WAVES, key = i >> 2, c8 = i & 3;
             v[u] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
             if (i < nk32 * 4 && key < nk)
               v[u] = *reinterpret_cast<const bf16x8*>(pv_ptr(a.in, hplane + AT_KD / 8 + c8, tok(k0s + key)));
           }
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
-            const int i = i0 + u * 256, key = i >> 2, c8 = i & 3;
+            const int i = i0 + u * 64 * AT_WAVES, key = i >> 2, c8 = i & 3;
             if (i < nk32 * 4) *reinterpret_cast<bf16x8*>(sK + key * AT_KP + c8 * 8) = v[u];
           }
         }
-        for (int i0 = tid; i0 < nk32 * 8; i0 += 256 * 8) {
+        for (int i0 = tid; i0 < nk32 * 8; i0 += 64 * AT_WAVES * 8) {
           bf16x8 v[8];
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
-            const int i = i0 + u * 256, key = i >> 3, c8 = i & 7;
+            const int i = i0 + u * 64 * AT_WAVES, key = i >> 3, c8 = i & 7;
             v[u] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
             if (i < nk32 * 8 && key < nk)
               v[u] = *reinterpret_cast<const bf16x8*>(pv_ptr(a.in, hplane + 2 * AT_KD / 8 + c8, tok(k0s + key)));
           }
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
-            const int i = i0 + u * 256, key = i >> 3, c8 = i & 7;
+            const int i = i0 + u * 64 * AT_WAVES, key = i >> 3, c8 = i & 7;
             if (i < nk32 * 8) {
 #pragma unroll
               for (int j = 0; j < 8; ++j) sVt[(c8 * 8 + j) * AT_VP + key] = v[u][j];
@@ -660,7 +662,7 @@ int attention_launch(const AttnArgs& a, hipStream_t s) {
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr = true;
   }
-  hipLaunchKernelGGL(attention_kernel, dim3(a.batch * a.heads * AT_QSPLIT), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(attention_kernel, dim3(a.batch * a.heads * AT_QSPLIT), dim3(64 * AT_WAVES), lds, s, a);
   YL_HIP(hipGetLastError());
   return 0;
 }
