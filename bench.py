@@ -54,7 +54,7 @@ def build_model(scale, device, batch, h, w, x_calib, target_frac=0.015):
     return specs, sd, HipEngine.from_model(specs, sd, batch, h, w, device)
 
 
-def cpu_baseline(sd, scale, h, w, conf, iou, sample_b=8, iters=40):
+def cpu_baseline(sd, scale, h, w, conf, iou, sample_b=8, iters=100):
     """The oracle (fp32 eager PyTorch restatement of the reference path, unfused Conv->BN->SiLU +
     python-loop NMS) timed on this host's cores: threads = min(8, cores-1) as the reference sets
     (utils/__init__.py:32, torch_utils.py:168-169).  kind = "port"."""
