@@ -54,7 +54,46 @@ def build_model(scale, device, batch, h, w, x_calib, target_frac=0.015):
     return specs, sd, HipEngine.from_model(specs, sd, batch, h, w, device)
 
 
-def cpu_baseline(sd, scale, h, w, conf, iou, sample_b=8, iters=100):
+def _iou(a, b):
+    iw = min(float(a[2]), float(b[2])) - max(float(a[0]), float(b[0]))
+    ih = min(float(a[3]), float(b[3])) - max(float(a[1]), float(b[1]))
+    inter = max(iw, 0.0) * max(ih, 0.0)
+    ua = (float(a[2]) - float(a[0])) * (float(a[3]) - float(a[1])) + (float(b[2]) - float(b[0])) * (float(b[3]) - float(b[1])) - inter
+    return inter / ua if ua > 0 else 0.0
+
+
+def parity_gate(ref_dets, got_dets, conf, iou, band=0.08, iou_match=0.9, iou_band=0.1):
+    """SURVEY.md section 8(d) gate between the oracle's and the engine's detections of the same images: greedy
+    one-to-one match by IoU >= 0.9 and |dconf| <= band (the stated bf16 tolerance); matched pairs
+    must agree on the class exactly; a box present on one side only is explained when its score lies within the
+    band of the confidence threshold or a same-class box overlaps it within iou_band of the NMS threshold."""
+    st = dict(ref=0, det=0, matched=0, class_mismatch=0, unexplained=0, max_dconf=0.0)
+    for ref, det in zip(ref_dets, got_dets):
+        ref, det = ref.tolist(), det.tolist()
+        st["ref"] += len(ref)
+        st["det"] += len(det)
+        used = set()
+
+        def explained(box, others):
+            return box[4] <= conf + band or any(o[5] == box[5] and iou - iou_band <= _iou(o, box) < iou_match for o in others)
+
+        for r in ref:
+            hit = next((j for j, d in enumerate(det)
+                        if j not in used and _iou(d, r) >= iou_match and abs(d[4] - r[4]) <= band), None)
+            if hit is None:
+                st["unexplained"] += int(not explained(r, det))
+            else:
+                used.add(hit)
+                st["matched"] += 1
+                st["class_mismatch"] += int(det[hit][5] != r[5])
+                st["max_dconf"] = max(st["max_dconf"], abs(det[hit][4] - r[4]))
+        st["unexplained"] += sum(1 for j, d in enumerate(det) if j not in used and not explained(d, ref))
+    st["max_dconf"] = round(st["max_dconf"], 4)
+    st["ok"] = st["class_mismatch"] == 0 and st["unexplained"] == 0 and st["matched"] > 0
+    return st
+
+
+def cpu_baseline(sd, scale, h, w, conf, iou, sample_b=8, iters=100, eng=None, dev=None, max_det=300):
     """The oracle (fp32 eager PyTorch restatement of the reference path, unfused Conv->BN->SiLU +
     python-loop NMS) timed on this host's cores: threads = min(8, cores-1) as the reference sets
     (utils/__init__.py:32, torch_utils.py:168-169).  kind = "port"."""
@@ -72,9 +111,18 @@ def cpu_baseline(sd, scale, h, w, conf, iou, sample_b=8, iters=100):
             y, _ = oracle.forward(sd, x, scale)
             oracle.non_max_suppression(y, conf, iou)
         dt = time.time() - t0
-    return {"value": round(sample_b * iters / dt, 2), "unit": "images/sec", "cores": threads, "kind": "port",
-            "host_cores": cores,
-            "sample": f"{iters} iterations of batch {sample_b} at {h}x{w} after 1 warm-up, fp32 oracle forward + NMS"}
+        ref = oracle.non_max_suppression(y, conf, iou, max_det=max_det)
+    out = {"value": round(sample_b * iters / dt, 2), "unit": "images/sec", "cores": threads, "kind": "port",
+           "host_cores": cores,
+           "sample": f"{iters} iterations of batch {sample_b} at {h}x{w} after 1 warm-up, fp32 oracle forward + NMS"}
+    if eng is not None:  # the checker's last outputs double as the parity gate of the measured HIP path
+        xb = torch.zeros(eng.batch, 3, h, w)
+        xb[:sample_b] = x
+        o, c = eng.detect(xb.to(dev), conf, iou, max_det=max_det, graph=False)
+        torch.cuda.synchronize(dev)
+        got = [o[i, : int(c[i])].cpu() for i in range(sample_b)]
+        out["parity_vs_oracle"] = parity_gate(ref, got, conf, iou)
+    return out
 
 
 def measured_traffic(kernel):
@@ -265,7 +313,7 @@ def main():
                 Path(args.profile_out).parent.mkdir(parents=True, exist_ok=True)
                 Path(args.profile_out).write_text(json.dumps(rows, indent=1))
             if not args.no_cpu_baseline:
-                res["cpu_baseline"] = cpu_baseline(sd, args.scale, H, W, conf, iou)
+                res["cpu_baseline"] = cpu_baseline(sd, args.scale, H, W, conf, iou, eng=eng, dev=dev, max_det=max_det)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
