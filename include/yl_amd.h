@@ -105,8 +105,8 @@ typedef struct yl_op {
   int32_t up, reserved;
   /* 3x3 stride-2 conv that is op 0 only: stem_weight != NULL fuses the network's first layer in front of it
      (Conv(3 -> in.C, 3x3, s2) on the NCHW network input, weight [in.C][3][3][3], bias [in.C], SiLU if stem_act):
-     `in` then describes a tensor that is never materialised (its offset is ignored); in.C must be 16 (YOLO11n)
-     and this conv's own output channels 32 or 64.  Results are bit-identical to YL_OP_STEM followed by the plain conv. */
+     `in` then describes a tensor that is never materialised (its offset is ignored); in.C must be 16 or 32
+     (YOLO11n / s) and this conv's own output channels 32 or 64.  Results are bit-identical to YL_OP_STEM followed by the plain conv. */
   const float* stem_weight;
   const float* stem_bias;
   int32_t stem_act, reserved2;

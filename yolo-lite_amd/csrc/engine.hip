@@ -232,8 +232,8 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
           if (i != 0 || !o.stem_bias || o.k != 3 || o.stride != 2 || up || o.res.offset >= 0 || o.cin_weight ||
               o.out.dtype != YL_BF16 || o.lane != 0)
             return fail(-1, tag + ": a fused stem needs a plain 3x3 stride-2 conv as op 0");
-          if (o.in.H != sh || o.in.W != sw || o.in.C != 16 || (cout1 != 32 && cout1 != 64) ||
-              r.cfg.ncb != 1 || r.cfg.ksteps > 8)
+          if (o.in.H != sh || o.in.W != sw || (o.in.C != 16 && o.in.C != 32) || (cout1 != 32 && cout1 != 64) ||
+              r.cfg.ncb != 1 || r.cfg.ksteps > 9)
             return fail(-1, tag + ": fused stem: unsupported widths or dims");
           std::vector<float> wt((size_t)o.in.C * 27);
           for (size_t q = 0; q < wt.size(); ++q) {  // round to bf16 like every other conv filter

@@ -32,7 +32,7 @@ size_t stem2_lds_bytes(int C0) {
   return (size_t)3 * S2_IR * S2_IP * 2 + (size_t)(C0 / 8) * S2_SR * S2_SP * 16;
 }
 
-template <typename T, int MT, bool POST>
+template <typename T, int MT, bool POST, int CG0>
 __global__ __launch_bounds__(256) void stem2_kernel(Stem2Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s2mem[];
   __bf16* img = reinterpret_cast<__bf16*>(s2mem);                          // [3][S2_IR][S2_IP]
@@ -162,8 +162,8 @@ __global__ __launch_bounds__(256) void stem2_kernel(Stem2Args a) {
   __syncthreads();
 
   // ---- 3. layer 1 from the LDS planes: 16-pixel tiles aligned to the output rows (TC / 16 per row)
-  constexpr int cg0 = 2;                   // the stem has 16 channels (host-checked): two planes,
-  constexpr int KS = (9 * cg0 + 3) / 4;    // 18 k-groups of 8 channels = 5 k-steps of the second conv
+  constexpr int cg0 = CG0;                 // planes of the stem's output (2: 16 channels, YOLO11n; 4: 32, YOLO11s)
+  constexpr int KS = (9 * cg0 + 3) / 4;    // k-steps of the second conv (5 or 9)
   bf16x8 wa[KS][MT];  // the whole filter in registers
   int boff[KS];       // byte offset of this lane's B fragment of k-step ks relative to the tile's corner
 #pragma unroll
@@ -255,22 +255,38 @@ __global__ __launch_bounds__(256) void stem2_kernel(Stem2Args a) {
   }
 }
 
-template <typename T>
-static int stem2_launch_t(const Stem2Args& a, int MT, size_t lds, hipStream_t s) {
+template <typename T, int CG0>
+static int stem2_launch_c(const Stem2Args& a, int MT, size_t lds, hipStream_t s) {
   const dim3 grid((unsigned)(a.B * a.tiles_y * a.tiles_x));
   const bool post = a.wpk2 != nullptr;
-  if (MT == 2 && post) hipLaunchKernelGGL((stem2_kernel<T, 2, true>), grid, dim3(256), lds, s, a);
-  else if (MT == 2) hipLaunchKernelGGL((stem2_kernel<T, 2, false>), grid, dim3(256), lds, s, a);
-  else if (MT == 4 && post) hipLaunchKernelGGL((stem2_kernel<T, 4, true>), grid, dim3(256), lds, s, a);
-  else if (MT == 4) hipLaunchKernelGGL((stem2_kernel<T, 4, false>), grid, dim3(256), lds, s, a);
-  else return fail(-3, "stem2: the second conv needs 32 or 64 output channels");
-  YL_HIP(hipGetLastError());
-  return 0;
+  auto go = [&](auto kern) {
+    static bool attr = false;  // per instantiation (one lambda instance per call site below)
+    if (lds > 64 * 1024 && !attr) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+          hipSuccess)
+        return fail(-2, "stem2: hipFuncSetAttribute failed");
+      attr = true;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+    YL_HIP(hipGetLastError());
+    return 0;
+  };
+  if (MT == 2 && post) return go(stem2_kernel<T, 2, true, CG0>);
+  if (MT == 2) return go(stem2_kernel<T, 2, false, CG0>);
+  if (MT == 4 && post) return go(stem2_kernel<T, 4, true, CG0>);
+  if (MT == 4) return go(stem2_kernel<T, 4, false, CG0>);
+  return fail(-3, "stem2: the second conv needs 32 or 64 output channels");
+}
+
+template <typename T>
+static int stem2_launch_t(const Stem2Args& a, int MT, size_t lds, hipStream_t s) {
+  return a.C0 == 16 ? stem2_launch_c<T, 2>(a, MT, lds, s) : stem2_launch_c<T, 4>(a, MT, lds, s);
 }
 
 int stem2_launch(const Stem2Args& a0, int MT, int in_dtype, hipStream_t s) {
   Stem2Args a = a0;
-  if (a.C0 != 16 || a.ksteps != 5) return fail(-3, "stem2: the stem must have 16 output channels");
+  if ((a.C0 != 16 && a.C0 != 32) || a.ksteps != (9 * (a.C0 / 8) + 3) / 4)
+    return fail(-3, "stem2: the stem must have 16 or 32 output channels");
   const int esz = in_dtype == YL_F32 ? 4 : in_dtype == YL_F16 ? 2 : 1;
   if ((a.W * esz) % 4) return fail(-3, "stem2: input rows must be a multiple of 4 bytes (set YL_FUSE_STEM=0)");
   if ((long long)3 * a.H * a.W * esz >= (1LL << 30)) return fail(-3, "stem2: one input image exceeds 1 GiB");
