@@ -77,39 +77,29 @@ def ap_per_class(tp, conf, pred_cls, target_cls, eps=1e-16):
 
 
 class Metric(SimpleClass):
-    """Holds per-class results and the usual means (metrics.py:567-736)."""
+    """Per-class detection results and their means (API of reference metrics.py:567-736): ``p r f1`` (nc,),
+    ``all_ap`` (nc, 10) over IoU 0.50:0.95, ``ap_class_index``; everything else is derived from those."""
+
+    _FITNESS_W = (0.0, 0.0, 0.1, 0.9)  # weights of [P, R, mAP50, mAP50-95]
 
     def __init__(self) -> None:
-        self.p, self.r, self.f1, self.all_ap, self.ap_class_index = [], [], [], [], []
+        self.p = self.r = self.f1 = self.all_ap = self.ap_class_index = ()
         self.nc = 0
 
-    @property
-    def ap50(self):
-        return self.all_ap[:, 0] if len(self.all_ap) else []
+    def _have(self) -> bool:
+        return len(self.all_ap) > 0
 
-    @property
-    def ap(self):
-        return self.all_ap.mean(1) if len(self.all_ap) else []
+    def _ap_at(self, j):
+        """AP column j (IoU 0.5 + 0.05 j) per class."""
+        return self.all_ap[:, j] if self._have() else []
 
-    @property
-    def mp(self):
-        return self.p.mean() if len(self.p) else 0.0
-
-    @property
-    def mr(self):
-        return self.r.mean() if len(self.r) else 0.0
-
-    @property
-    def map50(self):
-        return self.all_ap[:, 0].mean() if len(self.all_ap) else 0.0
-
-    @property
-    def map75(self):
-        return self.all_ap[:, 5].mean() if len(self.all_ap) else 0.0
-
-    @property
-    def map(self):
-        return self.all_ap.mean() if len(self.all_ap) else 0.0
+    ap50 = property(lambda self: self._ap_at(0))
+    ap = property(lambda self: self.all_ap.mean(1) if self._have() else [])
+    mp = property(lambda self: float(np.mean(self.p)) if len(self.p) else 0.0)
+    mr = property(lambda self: float(np.mean(self.r)) if len(self.r) else 0.0)
+    map50 = property(lambda self: float(self._ap_at(0).mean()) if self._have() else 0.0)
+    map75 = property(lambda self: float(self._ap_at(5).mean()) if self._have() else 0.0)
+    map = property(lambda self: float(self.all_ap.mean()) if self._have() else 0.0)
 
     def mean_results(self):
         return [self.mp, self.mr, self.map50, self.map]
@@ -119,36 +109,39 @@ class Metric(SimpleClass):
 
     @property
     def maps(self):
-        maps = np.zeros(self.nc) + self.map
-        for i, c in enumerate(self.ap_class_index):
-            maps[c] = self.ap[i]
-        return maps
+        """mAP50-95 per class index; classes without data get the overall mean."""
+        out = np.full(self.nc, self.map, dtype=np.float64)
+        ap = self.ap
+        for row, cls in enumerate(self.ap_class_index):
+            out[cls] = ap[row]
+        return out
 
     def fitness(self):
-        return float((np.array(self.mean_results()) * [0.0, 0.0, 0.1, 0.9]).sum())
+        return float(np.dot(self.mean_results(), self._FITNESS_W))
 
     def update(self, results):
-        (self.p, self.r, self.f1, self.all_ap, self.ap_class_index,
-         self.p_curve, self.r_curve, self.f1_curve, self.px, self.prec_values) = results
+        """results = ap_per_class(...)[2:]"""
+        names = ("p", "r", "f1", "all_ap", "ap_class_index", "p_curve", "r_curve", "f1_curve", "px", "prec_values")
+        for k, v in zip(names, results):
+            setattr(self, k, v)
 
 
 class DetMetrics(SimpleClass):
-    """Detection metrics front (metrics.py:739-837)."""
+    """Front of the validator's metrics (API of reference metrics.py:739-837): ``process`` the accumulated
+    statistics, then read ``results_dict`` / ``mean_results`` / ``maps`` / ``fitness``."""
+
+    keys = ["metrics/precision(B)", "metrics/recall(B)", "metrics/mAP50(B)", "metrics/mAP50-95(B)"]
 
     def __init__(self, save_dir=Path("."), plot=False, on_plot=None, names=None) -> None:
         self.save_dir, self.plot, self.on_plot = save_dir, plot, on_plot
         self.names = names or {}
         self.box = Metric()
-        self.speed = {"preprocess": 0.0, "inference": 0.0, "loss": 0.0, "postprocess": 0.0}
+        self.speed = dict.fromkeys(("preprocess", "inference", "loss", "postprocess"), 0.0)
         self.task = "detect"
 
     def process(self, tp, conf, pred_cls, target_cls):
         self.box.nc = len(self.names)
         self.box.update(ap_per_class(tp, conf, pred_cls, target_cls)[2:])
-
-    @property
-    def keys(self):
-        return ["metrics/precision(B)", "metrics/recall(B)", "metrics/mAP50(B)", "metrics/mAP50-95(B)"]
 
     def mean_results(self):
         return self.box.mean_results()
@@ -156,18 +149,10 @@ class DetMetrics(SimpleClass):
     def class_result(self, i):
         return self.box.class_result(i)
 
-    @property
-    def maps(self):
-        return self.box.maps
-
-    @property
-    def fitness(self):
-        return self.box.fitness()
-
-    @property
-    def ap_class_index(self):
-        return self.box.ap_class_index
+    maps = property(lambda self: self.box.maps)
+    fitness = property(lambda self: self.box.fitness())
+    ap_class_index = property(lambda self: self.box.ap_class_index)
 
     @property
     def results_dict(self):
-        return dict(zip(self.keys + ["fitness"], self.mean_results() + [self.fitness]))
+        return dict(zip([*self.keys, "fitness"], [*self.mean_results(), self.fitness]))
