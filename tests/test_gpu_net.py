@@ -425,3 +425,23 @@ def test_fused_class_branch_tail_is_bit_identical(gpu_device, monkeypatch, h, w)
     assert torch.equal(y, y_ref)
     for a, b in zip(eng.raw_levels(), ref_eng.raw_levels()):
         assert torch.equal(a, b)
+
+
+def test_cross_layer_fusions_bit_identical_at_640(gpu_device, monkeypatch):
+    """BASELINE resolution: the fused stem + layer 1 and the three fused C3k2 blocks against the launch-per-conv
+    form at 640x640 (full-width tiles, 160 / 80-pixel rows), every bit of the level maps and of the detections."""
+    sd = synth_state_dict("n", 9, cls_bias=[-3.0, -3.0, -3.0], cls_gain=6.0)
+    x = torch.randint(0, 256, (2, 3, 640, 640), generator=torch.Generator().manual_seed(640), dtype=torch.uint8).to(gpu_device)
+    eng = _engine("n", sd, 2, 640, 640, gpu_device)
+    out, cnt = eng.detect(x, 0.25, 0.7, graph=False)
+    lv = [t.clone() for t in eng.raw_levels()]
+    monkeypatch.setenv("YL_FUSE_STEM", "0")
+    monkeypatch.setenv("YL_FUSE_C3K2", "0")
+    ref = _engine("n", sd, 2, 640, 640, gpu_device)
+    assert len(ref.prog.ops) == len(eng.prog.ops) + 1 + 3 * 2
+    out_r, cnt_r = ref.detect(x, 0.25, 0.7, graph=False)
+    for a, b in zip(lv, ref.raw_levels()):
+        assert torch.equal(a, b)
+    assert torch.equal(cnt, cnt_r) and int(cnt.sum()) > 0
+    for i in range(2):
+        assert torch.equal(out[i, : int(cnt[i])], out_r[i, : int(cnt_r[i])])
