@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define YL_ABI_VERSION 8
+#define YL_ABI_VERSION 9
 
 /* element types */
 enum { YL_BF16 = 0, YL_F32 = 1, YL_F16 = 2, YL_U8 = 3 };
@@ -35,6 +35,11 @@ enum {
   YL_OP_STEM = 6,     /* first layer fused with the input conversion: 3x3 stride-2 conv on the 3-channel
                          NCHW network input (fp32 / fp16 / uint8, /255 for uint8) -> bf16 planes; must be
                          op 0; weight [Cout][3][3][3]                                              */
+  YL_OP_BNECK2 = 8,   /* a whole Bottleneck(c, c, k = (3, 3), e = 1) in one launch (nn/modules/block.py:330-343; the
+                         Bottlenecks of a C3k block): out = in + SiLU(cv2(SiLU(cv1(in)))), c = in.C = out.C = 32 or 64;
+                         weight / bias = cv1 [c][c][3][3], post_weight / post_bias = cv2 (post_cin = 9c).  `in` and `out`
+                         must be different buffers (a workgroup reads a halo of `in`).  The tensor between the convs lives
+                         in LDS; bit-identical to the two YL_OP_CONV ops it replaces.                                */
   YL_OP_C3K2S = 7     /* body of a narrow C3k2 block in one launch (nn/modules/block.py:220-235, 330-343), half width
                          c = 16 or 32: `in` = the block's concat buffer [a | b | ...] (a, b = halves of C3k2.cv1's output,
                          c channels each); c_out = b + SiLU(cv2(SiLU(cv1(b)))) with the Bottleneck's two 3x3 convs

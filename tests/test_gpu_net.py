@@ -445,3 +445,24 @@ def test_cross_layer_fusions_bit_identical_at_640(gpu_device, monkeypatch):
     assert torch.equal(cnt, cnt_r) and int(cnt.sum()) > 0
     for i in range(2):
         assert torch.equal(out[i, : int(cnt[i])], out_r[i, : int(cnt_r[i])])
+
+
+@pytest.mark.parametrize("scale,h,w", [("n", 64, 64), ("n", 96, 128), ("n", 160, 352), ("n", 640, 640), ("s", 64, 96)])
+def test_fused_bottlenecks_are_bit_identical(gpu_device, monkeypatch, scale, h, w):
+    """The Bottlenecks of the C3k blocks (two 3x3 convs + x, c = 32 / 64) in one launch each (csrc/bneck2.hip, the
+    tensor between the convs in LDS, ping-pong buffers instead of the in-place update) against the two-launch form:
+    every bit of the level maps."""
+    sd = synth_state_dict(scale, 10, cls_bias=[-2.0, -2.0, -2.0], cls_gain=4.0)
+    x = torch.randint(0, 256, (2, 3, h, w), generator=torch.Generator().manual_seed(h + 7 * w), dtype=torch.uint8).to(gpu_device)
+    monkeypatch.setenv("YL_FUSE_BNECK", "2")  # both widths (the default fuses c = 32 only)
+    eng = _engine(scale, sd, 2, h, w, gpu_device)
+    fused = [i for i in range(len(eng.prog.ops)) if eng.op_kernel(i) == "bottleneck_fused_mfma"]
+    assert len(fused) >= 2, fused
+    y = eng.forward(x).clone()
+    lv = [t.clone() for t in eng.raw_levels()]
+    monkeypatch.setenv("YL_FUSE_BNECK", "0")
+    ref = _engine(scale, sd, 2, h, w, gpu_device)
+    assert not any(ref.op_kernel(i) == "bottleneck_fused_mfma" for i in range(len(ref.prog.ops)))
+    assert torch.equal(y, ref.forward(x))
+    for a, b in zip(lv, ref.raw_levels()):
+        assert torch.equal(a, b)

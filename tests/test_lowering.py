@@ -2,7 +2,7 @@
 import pytest
 
 from yololite_amd.nn import arch
-from yololite_amd.nn.lower import OP_C3K2S, OP_ATTENTION, OP_CONV, OP_DWCONV3, OP_SPPF_POOL, OP_STEM, OP_UPSAMPLE, lower, plane_pixels, view_bytes
+from yololite_amd.nn.lower import OP_BNECK2, OP_C3K2S, OP_ATTENTION, OP_CONV, OP_DWCONV3, OP_SPPF_POOL, OP_STEM, OP_UPSAMPLE, lower, plane_pixels, view_bytes
 from yololite_amd.nn.synth import synth_state_dict
 
 
@@ -14,6 +14,9 @@ def _prog(scale, b=2, h=640, w=640):
 def _conv_gflop(prog):
     f = 0.0
     for o in prog.ops:
+        if o["kind"] == OP_BNECK2:  # both 3x3 convs of a Bottleneck in one op
+            for w in (o["weight"], o["post_weight"]):
+                f += 2.0 * o["out"].H * o["out"].W * w.shape[0] * w.shape[1] * w.shape[2] * w.shape[3]
         if o["kind"] == OP_C3K2S:  # Bottleneck.cv1, Bottleneck.cv2 and C3k2.cv2 in one op
             for w in (o["weight"], o["post_weight"], o["stem_weight"]):
                 f += 2.0 * o["out"].H * o["out"].W * w.shape[0] * w.shape[1] * w.shape[2] * w.shape[3]
@@ -39,7 +42,7 @@ def test_algorithmic_flops_match_survey(scale, gflop, nconv):
     assert abs(got - gflop) < 2e-3 * gflop
     # C3k cv1+cv2 pairs are merged into one launch: count reference Conv2d calls
     calls = sum((2 if o.get("name", "").endswith("cv1+cv2") else 1) + len(o.get("fused_names", []))
-                for o in p.ops if o["kind"] in (OP_CONV, OP_DWCONV3, OP_STEM, OP_C3K2S))
+                for o in p.ops if o["kind"] in (OP_CONV, OP_DWCONV3, OP_STEM, OP_C3K2S, OP_BNECK2))
     assert calls + 1 == nconv  # + the DFL conv
 
 

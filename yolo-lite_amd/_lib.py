@@ -130,7 +130,7 @@ def lib() -> C.CDLL:
     L.yl_preprocess_u8.argtypes = [vp, i32, i32, i32, vp, vp]
     L.yl_letterbox_u8.restype = i32
     L.yl_letterbox_u8.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]
-    if L.yl_abi_version() != 8:
+    if L.yl_abi_version() != 9:
         raise RuntimeError("libyl_amd.so ABI version mismatch; rebuild it")
     _lib = L
     return L

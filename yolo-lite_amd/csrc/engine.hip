@@ -318,6 +318,34 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
         r.name = pw ? (o.stem_weight ? "dw3x3+pw1x1+1x1_mfma" : "dw3x3+pw1x1_mfma") : "dwconv3x3";
         break;
       }
+      case YL_OP_BNECK2: {
+        if (!o.weight || !o.bias || !o.post_weight || !o.post_bias) return fail(-1, tag + ": bottleneck needs both convs' weights and biases");
+        const int c = o.in.C;
+        if (o.in.dtype != YL_BF16 || o.out.dtype != YL_BF16 || o.in.H != o.out.H || o.in.W != o.out.W || o.out.C != c ||
+            (c != 32 && c != 64) || o.post_cin != 9 * c || o.lane != 0 || o.in.offset == o.out.offset)
+          return fail(-1, tag + ": bottleneck: c = 32 or 64, same dims in and out, different buffers");
+        const float* ws[2] = {o.weight, o.post_weight};
+        const float* bs[2] = {o.bias, o.post_bias};
+        __bf16** dw[2] = {&r.d_wpk, &r.d_wpk2};
+        float** db[2] = {&r.d_bias, &r.d_bias2};
+        for (int q = 0; q < 2; ++q) {
+          ConvConfig cc{};
+          if (int rc = conv_choose(batch, c, c, 3, 1, o.out.H, o.out.W, 0, &cc)) return rc;
+          if (cc.MT != c / 16 || cc.ksteps != 9 * c / 32 || cc.ncb != 1) return fail(-3, tag + ": bottleneck: unexpected tiling");
+          std::vector<uint16_t> pk;
+          conv_pack_weights(ws[q], c, c, 3, cc, &pk);
+          uint16_t* d = nullptr;
+          if (int rc = dev_upload(e.get(), pk, &d)) return rc;
+          *dw[q] = reinterpret_cast<__bf16*>(d);
+          std::vector<float> bias((size_t)cc.MT * 16 + 16, 0.f);
+          for (int ch = 0; ch < c; ++ch) bias[ch] = bs[q][ch];
+          if (int rc = dev_upload(e.get(), bias, db[q])) return rc;
+        }
+        r.flops = 2.0 * px_out * 2.0 * 9.0 * c * c;
+        r.bytes = px_out * 2.0 * c * 2;
+        r.name = "bottleneck_fused_mfma";
+        break;
+      }
       case YL_OP_C3K2S: {
         if (!o.weight || !o.bias || !o.post_weight || !o.post_bias || !o.stem_weight || !o.stem_bias)
           return fail(-1, tag + ": c3k2 needs the three convs' weights and biases");
@@ -487,6 +515,25 @@ static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s, c
       a.stride = o.stride;
       a.act = o.act;
       return conv_launch(r.cfg, a, B, s);
+    }
+    case YL_OP_BNECK2: {
+      Bneck2Args q{};
+      q.xin = pview(ws, o.in, B);
+      q.yout = pview(ws, o.out, B);
+      q.B = B;
+      q.H = o.out.H;
+      q.W = o.out.W;
+      q.c = o.in.C;
+      q.w1 = r.d_wpk;
+      q.b1 = r.d_bias;
+      q.w2 = r.d_wpk2;
+      q.b2 = r.d_bias2;
+      const Geo gq = geo_of(B, o.out.H, o.out.W);
+      const long long nb = (long long)(q.c / 8) * plane_bytes(gq);
+      if (nb > (1LL << 30)) return fail(-3, "bottleneck: a tensor slice exceeds 1 GiB; lower the batch size");
+      q.in_bytes = q.out_bytes = (unsigned)nb;
+      q.plane_px = gq.plane_px;
+      return bneck2_launch(q, s);
     }
     case YL_OP_C3K2S: {
       C3k2sArgs q{};

@@ -204,6 +204,20 @@ struct C3k2sArgs {
 };
 int c3k2s_launch(const C3k2sArgs& a, hipStream_t s);
 
+// bneck2.hip: a whole Bottleneck (3x3 c -> c, 3x3 c -> c, + x) in one launch, c = 32 or 64; x and y in different buffers
+struct Bneck2Args {
+  PView xin, yout;
+  int B, H, W, c;
+  const __bf16* w1;      // conv_pack_weights order, MT = c / 16, 9 * c / 32 k-steps
+  const float* b1;       // padded to MT * 16
+  const __bf16* w2;
+  const float* b2;
+  unsigned in_bytes, out_bytes;
+  long long plane_px;
+  int tiles_x, tiles_y;
+};
+int bneck2_launch(const Bneck2Args& a, hipStream_t s);
+
 struct DecodeLevel {
   PView box;     // 8 planes: DFL logits (head.py:64 cv2)
   PView cls;     // nc8 / 8 planes: class logits (cv3); padding channels hold large negative values

@@ -22,7 +22,7 @@ from .arch import LayerSpec, detect_mid_channels
 
 BN_EPS = 1e-3
 BF16, F32 = 0, 1
-OP_CONV, OP_DWCONV3, OP_SPPF_POOL, OP_UPSAMPLE, OP_ATTENTION, OP_STEM, OP_C3K2S = 1, 2, 3, 4, 5, 6, 7
+OP_CONV, OP_DWCONV3, OP_SPPF_POOL, OP_UPSAMPLE, OP_ATTENTION, OP_STEM, OP_C3K2S, OP_BNECK2 = 1, 2, 3, 4, 5, 6, 7, 8
 
 
 @dataclass
@@ -428,8 +428,22 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
         # C3.cv1 and C3.cv2 read the same input (block.py:259): one conv with stacked filters
         conv(p + ".cv1+cv2", x, u, 1, 1, wb=(np.concatenate([w1, w2], 0), np.concatenate([b1, b2], 0)))
         a = u.slice(0, c_)
-        for j in range(2):
-            bottleneck(f"{p}.m.{j}", a, a, c_)
+        fb = os.environ.get("YL_FUSE_BNECK", "1")
+        if fuse_post and fb != "0" and c_ in ((32, 64) if fb == "2" else (32,)):
+            # each Bottleneck (3x3, 3x3, + x) in ONE launch (csrc/bneck2.hip).  A workgroup reads a halo of its
+            # input, so the in-place update of the unfused form would race: the two Bottlenecks ping-pong between
+            # the block's buffer and a scratch buffer instead.  Default: c = 32 only (40x40 in YOLO11n: 15 us against
+            # 19 us for the two launches); c = 64 (20x20: 160 workgroups of 4 x 32 outputs, 25 us against 24 us) is
+            # opt-in with YL_FUSE_BNECK=2.
+            t2 = ar.alloc(x.H, x.W, c_)
+            for j, (src_v, dst_v) in enumerate(((a, t2), (t2, a))):
+                w1_, b1_ = fold_conv_bn(sd, f"{p}.m.{j}.cv1")
+                w2_, b2_ = fold_conv_bn(sd, f"{p}.m.{j}.cv2")
+                ops.append(dict(kind=OP_BNECK2, name=f"{p}.m.{j}", act=1, inp=src_v, out=dst_v, res=None, weight=w1_, bias=b1_,
+                                post_weight=w2_, post_bias=b2_, fused_names=[f"{p}.m.{j}.cv2"]))
+        else:
+            for j in range(2):
+                bottleneck(f"{p}.m.{j}", a, a, c_)
         conv(p + ".cv3", u, y, 1, 1)
 
     # ---- Detect (head.py:29-69): box branch cv2, class branch cv3, raw level maps as bf16 planes.
