@@ -91,6 +91,18 @@ class YOLOLite:
         self.metrics = validator.metrics
         return validator.metrics
 
+    def export(self, format: str = "safetensors", file=None, folded: bool = True) -> str:
+        """Write the model as a flat table of tensors (``nn/export.py``): BN-folded filters and biases plus the
+        architecture, names and strides in the header; ``YOLOLite("x.safetensors")`` reads it back without
+        unpickling anything.  Other formats (onnx, engine ...) are not part of this path."""
+        if format != "safetensors":
+            raise NotImplementedError(f"export format '{format}' is outside the MI355X predict path (only 'safetensors')")
+        from ..nn.export import save_safetensors
+
+        if file is None:
+            file = Path(str(self.ckpt_path or self.model_name or "model")).with_suffix(".safetensors")
+        return save_safetensors(self.model, file, folded=folded)
+
     def train(self, **kwargs):
         raise NotImplementedError("training is not part of the MI355X predict path")
 

@@ -40,8 +40,8 @@ class AutoBackend:
             model = w
         else:
             # reference bug not inherited: `w.split('.')[1] == 'pt'` (autobackend.py:63) breaks on './x.pt'
-            if Path(str(w)).suffix != ".pt":
-                raise TypeError(f"model='{w}' is not a supported model format (only *.pt / in-memory models)")
+            if Path(str(w)).suffix not in (".pt", ".safetensors"):
+                raise TypeError(f"model='{w}' is not a supported model format (only *.pt / *.safetensors / in-memory models)")
             model = attempt_load_weights(str(w), device=device, inplace=True, fuse=fuse)
         if fuse:
             model = model.fuse(verbose=verbose)

@@ -333,8 +333,12 @@ def fuse_c3k2_small(ops: List[dict]) -> List[dict]:
 
 
 def fold_conv_bn(sd: Dict[str, torch.Tensor], name: str, bn: bool = True) -> Tuple[np.ndarray, np.ndarray]:
-    """BN-folded fp32 (weight OIHW, bias) of the Conv unit ``name`` (torch_utils.py:182-209)."""
-    if bn:
+    """BN-folded fp32 (weight OIHW, bias) of the Conv unit ``name`` (torch_utils.py:182-209).  A unit that already
+    carries ``conv.bias`` and no BN tensors (``nn/export.py``'s folded form) is returned as stored."""
+    if bn and name + ".bn.weight" not in sd and name + ".conv.bias" in sd:
+        w = sd[name + ".conv.weight"].detach().float()
+        bias = sd[name + ".conv.bias"].detach().float()
+    elif bn:
         w = sd[name + ".conv.weight"].detach().float()
         g, b = sd[name + ".bn.weight"].float(), sd[name + ".bn.bias"].float()
         mu, var = sd[name + ".bn.running_mean"].float(), sd[name + ".bn.running_var"].float()

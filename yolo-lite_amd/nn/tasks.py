@@ -204,7 +204,18 @@ def torch_safe_load(weight: Union[str, Path]):
 
 
 def attempt_load_one_weight(weight, device=None, inplace=True, fuse=False):
-    """Reference ``tasks.py:499-522``: pick ``ema`` else ``model``, fp32, attach args / pt_path / task."""
+    """Reference ``tasks.py:499-522``: pick ``ema`` else ``model``, fp32, attach args / pt_path / task.
+    ``*.safetensors`` files written by ``nn/export.py`` load without any unpickling."""
+    if Path(str(weight)).suffix == ".safetensors":
+        import json
+
+        from .export import load_safetensors
+
+        model, meta = load_safetensors(weight)
+        args = {**DEFAULT_CFG_DICT, **json.loads(meta.get("args", "{}"))}
+        model.args = {k: v for k, v in args.items() if k in DEFAULT_CFG_KEYS}
+        model.task = "detect"
+        return model, {"model": None, "train_args": model.args, "safetensors": meta}
     ckpt, weight = torch_safe_load(weight)
     args = {**DEFAULT_CFG_DICT, **{k: v for k, v in (ckpt.get("train_args") or {}).items() if not isinstance(v, _Shell)}}
     shell = ckpt.get("ema") or ckpt["model"]
