@@ -20,10 +20,10 @@
 extern "C" {
 #endif
 
-#define YL_ABI_VERSION 9
+#define YL_ABI_VERSION 10
 
 /* element types */
-enum { YL_BF16 = 0, YL_F32 = 1, YL_F16 = 2, YL_U8 = 3 };
+enum { YL_BF16 = 0, YL_F32 = 1, YL_F16 = 2, YL_U8 = 3, YL_FP8 = 4 /* OCP e4m3 */ };
 
 /* op kinds of an engine program */
 enum {
@@ -35,6 +35,8 @@ enum {
   YL_OP_STEM = 6,     /* first layer fused with the input conversion: 3x3 stride-2 conv on the 3-channel
                          NCHW network input (fp32 / fp16 / uint8, /255 for uint8) -> bf16 planes; must be
                          op 0; weight [Cout][3][3][3]                                              */
+  YL_OP_QUANT = 9,    /* in (bf16 planes) -> out (fp8 planes, same dims): out = e4m3(in / out_scale), saturating, round to
+                         nearest even; feeds the fp8 convs (BASELINE.json config 5: e4m3 weights + activations)        */
   YL_OP_BNECK2 = 8,   /* a whole Bottleneck(c, c, k = (3, 3), e = 1) in one launch (nn/modules/block.py:330-343; the
                          Bottlenecks of a C3k block): out = in + SiLU(cv2(SiLU(cv1(in)))), c = in.C = out.C = 32 or 64;
                          weight / bias = cv1 [c][c][3][3], post_weight / post_bias = cv2 (post_cin = 9c).  `in` and `out`
@@ -66,8 +68,10 @@ typedef struct yl_view {
   int32_t H, W, C;/* logical dims per image                                                  */
   int32_t pitch;  /* channels of the underlying buffer                                       */
   int32_t coff;   /* first channel of this view inside the buffer                            */
-  int32_t dtype;  /* YL_BF16 or YL_F32                                                       */
+  int32_t dtype;  /* YL_BF16, YL_F32 or YL_FP8                                               */
 } yl_view;
+/* YL_FP8 views: the bf16 layout with 16 channels per plane -- buffer[C/16][plane_px][16] e4m3 bytes, same guarded
+ * pixel geometry, 16 bytes per pixel; C, pitch and coff multiples of 16.  A real value is e4m3 x scale of its tensor. */
 
 /* One op.  Weights are HOST pointers to BN-folded fp32 data; yl_engine_create packs them
  * (bf16, MFMA fragment order) into device memory it owns.
@@ -115,6 +119,12 @@ typedef struct yl_op {
   const float* stem_weight;
   const float* stem_bias;
   int32_t stem_act, reserved2;
+  /* YL_OP_CONV with in.dtype == YL_FP8 (csrc/conv_f8.hip; plain conv: no post / in2 / stem fusion, in.C % 16 == 0,
+     out.C % 32 == 0 or % 48 == 0): the filters are quantised to e4m3 per output channel at create time, `in` holds
+     e4m3(x / in_scale); out may be bf16 planes or, with out.dtype == YL_FP8, e4m3(y / out_scale); res (bf16, or fp8
+     with res_scale) is added after the activation as in the bf16 conv.  YL_OP_QUANT uses out_scale. */
+  float in_scale, out_scale, res_scale;
+  int32_t reserved3;
   /* YL_OP_DWCONV3 with post_weight (depthwise 3x3 -> pointwise 1x1 in one launch) AND stem_weight: a further 1x1
      conv behind the pointwise one (the nn.Conv2d(c3, nc, 1) that ends Detect's class branch, head.py:47), also in
      that launch: reserved2 = output channels of the pointwise conv (post_weight [reserved2][in.C]), stem_weight

@@ -79,3 +79,45 @@ def run_conv(device, x, w, b, k, s, act, res=None, pitch_extra=(0, 0), out_f32=F
     if expect_kernel is not None:
         assert m.eng.op_kernel(0) == expect_kernel, (m.eng.op_kernel(0), expect_kernel)
     return m.read(yv)
+
+
+# ------------------------------------------------------------------------------------------------ fp8 (e4m3) convs
+F8_MAX = 448.0
+
+
+def e4m3_round(t: torch.Tensor) -> torch.Tensor:
+    """Saturating round-to-nearest-even onto the OCP e4m3 grid (what the kernels' v_cvt_pk_fp8_f32 + clamp do)."""
+    return t.float().clamp(-F8_MAX, F8_MAX).to(torch.float8_e4m3fn).float()
+
+
+def quantize_filters_e4m3(w: torch.Tensor):
+    """Per-output-channel e4m3 quantisation as conv_f8_pack_weights does it: scale = absmax / 448."""
+    m = w.abs().flatten(1).amax(1)
+    s = torch.where(m > 0, m / F8_MAX, torch.ones_like(m))
+    return e4m3_round(w / s.view(-1, 1, 1, 1)), s
+
+
+def run_conv_f8(device, xq, in_scale, w, b, k, s, act, res=None, res_scale=0.0, out_scale=0.0, expect_kernel=None):
+    """xq (B,Cin,H,W): e4m3-representable values (the real input is xq * in_scale); w fp32 OIHW; res: bf16-representable
+    tensor, or e4m3-representable values when res_scale > 0; out_scale > 0: fp8 output (returned as raw e4m3 values)."""
+    from yololite_amd.nn.lower import FP8
+
+    B, Cin, H, W = xq.shape
+    Cout = w.shape[0]
+    p = k // 2
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    m = Mini(B, device)
+    xin = m.buf(H, W, Cin, FP8)
+    yv = m.buf(Ho, Wo, Cout, FP8 if out_scale > 0 else BF16)
+    m.fill(xin, xq)
+    rv = None
+    if res is not None:
+        rv = m.buf(Ho, Wo, Cout, FP8 if res_scale > 0 else BF16)
+        m.fill(rv, res)
+    m.op(kind=OP_CONV, name="t8", k=k, stride=s, act=int(act), inp=xin, out=yv, res=rv, in_scale=in_scale,
+         out_scale=out_scale, res_scale=res_scale,
+         weight=np.ascontiguousarray(w.numpy()), bias=np.ascontiguousarray(b.numpy()))
+    m.run()
+    if expect_kernel is not None:
+        assert m.eng.op_kernel(0) == expect_kernel, (m.eng.op_kernel(0), expect_kernel)
+    return m.read(yv)

@@ -1,0 +1,90 @@
+"""fp8 (OCP e4m3) conv path (csrc/conv_f8.hip; BASELINE.json config 5: e4m3 weights + activations, fp32 accumulate)
+against plain torch fp32 on the SAME quantised operands: the products of e4m3 values are exact in fp32, so the only
+differences are the summation order (relative 1e-5 of the accumulated magnitude) and the rounding of the stored output
+(bf16: 2^-8 relative; fp8: the neighbouring e4m3 value at most, the large majority identical)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from hip_util import F8_MAX, Mini, bf16_round, e4m3_round, quantize_filters_e4m3, run_conv_f8
+from yololite_amd.nn.lower import BF16, FP8, OP_QUANT
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(xq, in_scale, w, b, k, s, act, res=None, res_scale=0.0):
+    wq, sw = quantize_filters_e4m3(w)
+    y = F.conv2d(xq.double(), wq.double(), None, s, k // 2).float()
+    y = y * (in_scale * sw).view(1, -1, 1, 1) + b.view(1, -1, 1, 1)
+    if act:
+        y = F.silu(y)
+    if res is not None:
+        y = y + (res * res_scale if res_scale > 0 else res)
+    return y
+
+
+CASES = [
+    # B, Cin, Cout, H, W, k, s, kernel
+    (2, 128, 64, 20, 20, 3, 1, "conv3x3_f8_mfma"),    # a k-step inside one tap (Cin % 128 == 0), 4 channel tiles
+    (2, 48, 48, 13, 17, 3, 1, "conv3x3_f8_mfma"),     # x-scale Bottleneck width: 3 tiles, steps straddle taps, ragged map
+    (1, 96, 192, 24, 40, 1, 1, "conv1x1_f8_mfma"),    # 1x1, three channel blocks, K tail (96 = 6 groups of 16)
+    (2, 64, 96, 32, 32, 3, 2, "conv3x3s2_f8_mfma"),   # stride 2
+    (1, 384, 64, 16, 16, 3, 1, "conv3x3_f8_mfma"),    # 27 k-steps: the filter slab is restaged in chunks
+    (3, 16, 32, 9, 9, 3, 1, "conv3x3_f8_mfma"),       # one k-group per tap, 2 tiles
+]
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,k,s,kern", CASES)
+@pytest.mark.parametrize("mode", ["bf16", "bf16+res", "fp8", "fp8+res8"])
+def test_conv_f8_vs_torch(gpu_device, B, Cin, Cout, H, W, k, s, kern, mode):
+    g = torch.Generator().manual_seed(Cin * 7 + Cout + H + k + s)
+    in_scale = 0.037
+    xq = e4m3_round(torch.randn(B, Cin, H, W, generator=g) * 30)   # e4m3 values, a few saturate
+    w = torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.3
+    Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
+    res, res_scale, out_scale = None, 0.0, 0.0
+    if mode == "bf16+res":
+        res = bf16_round(torch.randn(B, Cout, Ho, Wo, generator=g))
+    if mode == "fp8+res8":
+        res, res_scale = e4m3_round(torch.randn(B, Cout, Ho, Wo, generator=g) * 40), 0.02
+    if mode.startswith("fp8"):
+        out_scale = 0.05
+    y = run_conv_f8(gpu_device, xq, in_scale, w, b, k, s, True, res, res_scale, out_scale, expect_kernel=kern)
+    ref = _ref(xq, in_scale, w, b, k, s, True, res, res_scale)
+    if out_scale > 0:
+        want = e4m3_round(ref / out_scale)
+        same = (y == want).float().mean().item()
+        assert same > 0.99, same                                  # ties at rounding boundaries may fall either way
+        mag = torch.maximum(y.abs(), want.abs()).clamp_min(2.0 ** -6)
+        step = torch.exp2(torch.floor(torch.log2(mag)) - 3)          # e4m3 spacing at that magnitude
+        assert bool(((y - want).abs() <= step).all())               # never further than the neighbouring value
+    else:
+        err = (y - ref).abs()
+        assert bool((err <= 2 ** -7 * ref.abs() + 1e-3).all()), err.max()
+        assert (y == bf16_round(ref)).float().mean().item() > 0.97
+
+
+def test_conv_f8_no_act_and_identity_filter(gpu_device):
+    """A = I with an asymmetric B: a 1x1 conv whose filter is the identity copies its input channel for channel
+    (catches a swapped row / column or a permuted k order that random data could hide behind tolerances)."""
+    C = 64
+    xq = e4m3_round(torch.arange(2 * C * 6 * 10, dtype=torch.float32).reshape(2, C, 6, 10) % 97 - 40)
+    w = torch.eye(C).view(C, C, 1, 1) * 3.0
+    y = run_conv_f8(gpu_device, xq, 1.0, w, torch.zeros(C), 1, 1, False)
+    assert torch.equal(y, bf16_round(xq * 3.0))
+
+
+def test_quantize_op(gpu_device):
+    B, C, H, W = 2, 48, 11, 14
+    x = bf16_round(torch.randn(B, C, H, W, generator=torch.Generator().manual_seed(1)) * 20)
+    x[0, 0, 0, :4] = torch.tensor([1e4, -1e4, 2 ** -12, 0.0])    # saturation, flush to zero
+    m = Mini(B, gpu_device)
+    a = m.buf(H, W, C, BF16)
+    q = m.buf(H, W, C, FP8)
+    m.fill(a, x)
+    m.op(kind=OP_QUANT, name="q", inp=a, out=q, out_scale=0.11)
+    m.run()
+    assert m.eng.op_kernel(0) == "quantize_f8"
+    assert torch.equal(m.read(q), e4m3_round(x * (torch.tensor(1.0) / torch.tensor(0.11))))

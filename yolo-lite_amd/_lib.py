@@ -21,7 +21,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 _PKG = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ["YL_AMD_LIB"]) if os.environ.get("YL_AMD_LIB") else _PKG / "libyl_amd.so"  # dev override
 
-YL_BF16, YL_F32, YL_F16, YL_U8 = 0, 1, 2, 3
+YL_BF16, YL_F32, YL_F16, YL_U8, YL_FP8 = 0, 1, 2, 3, 4
 OP_CONV, OP_DWCONV3, OP_SPPF_POOL, OP_UPSAMPLE, OP_ATTENTION, OP_STEM = 1, 2, 3, 4, 5, 6
 
 EXPORTS = (
@@ -49,7 +49,8 @@ class Op(C.Structure):
                 ("post_weight", C.c_void_p), ("post_bias", C.c_void_p),
                 ("inp2", View), ("up", C.c_int32), ("reserved", C.c_int32),
                 ("stem_weight", C.c_void_p), ("stem_bias", C.c_void_p),
-                ("stem_act", C.c_int32), ("reserved2", C.c_int32)]
+                ("stem_act", C.c_int32), ("reserved2", C.c_int32),
+                ("in_scale", C.c_float), ("out_scale", C.c_float), ("res_scale", C.c_float), ("reserved3", C.c_int32)]
 
 
 class Level(C.Structure):
@@ -130,7 +131,7 @@ def lib() -> C.CDLL:
     L.yl_preprocess_u8.argtypes = [vp, i32, i32, i32, vp, vp]
     L.yl_letterbox_u8.restype = i32
     L.yl_letterbox_u8.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]
-    if L.yl_abi_version() != 9:
+    if L.yl_abi_version() != 10:
         raise RuntimeError("libyl_amd.so ABI version mismatch; rebuild it")
     _lib = L
     return L

@@ -1,0 +1,384 @@
+// fp8 (OCP e4m3) Conv2d + bias + SiLU [+ residual] as an MFMA implicit GEMM on the block-scaled matrix pipe of gfx950:
+// v_mfma_f32_16x16x128_f8f6f4 (K = 128 per instruction, twice the bf16 rate per clock; scales unused = 1.0).
+//
+// Same reference semantics as conv_mfma.hip (nn/modules/conv.py:35-53 with BN folded per utils/torch_utils.py:182-209,
+// Bottleneck add block.py:341-343), computed on quantised operands (BASELINE.json config 5: "e4m3 weights +
+// activations, fp32 accumulate"):
+//     x_q = e4m3(x / s_in)          per-tensor activation scale, calibrated by the host (nn/lower.py::apply_fp8)
+//     w_q = e4m3(w[c] / s_w[c])     per-output-channel filter scale, chosen at pack time (absmax / 448)
+//     y   = act(alpha[c] * sum(w_q * x_q) + bias[c]) [+ res],   alpha[c] = s_in * s_w[c],  fp32 accumulation
+// and y leaves either as bf16 planes (the layout of every other kernel) or as e4m3(y / s_out) fp8 planes.
+//
+// fp8 activation layout ("C16-planar, guarded"): buffer[C/16][plane_px][16] -- the bf16 layout's geometry (yl_internal.h:
+// one zero guard pixel after every row, one guard row after every image, 16 bytes per pixel) with 16 channels per
+// plane instead of 8, so taps are the same constant byte offsets and a wave's fragment is again runs of 256 contiguous
+// bytes.
+//
+// GEMM mapping: A (16 x 128) = packed filters from an LDS slab, row = output channel (natural order); B (128 x 16) =
+// activations straight from the planes, column = pixel.  K = (tap, cin) in groups of 16 channels; one k-step is 8 groups;
+// lane group g = lane >> 4 supplies groups 2g and 2g + 1 of a step for A and B alike (32 bytes each: two 16-byte loads),
+// so whatever order the instruction gives the 32 bytes of a lane inside K, filters and activations agree on it.
+// D: lane (pixel n, group g) holds channels 16 mt + 4 g + r of tile mt: 4-byte (fp8) or 8-byte (bf16) stores, which a
+// wave still issues as 256 contiguous bytes per tile.
+#include "conv_common.h"
+
+#include <cmath>
+
+namespace yl {
+
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+constexpr float F8_MAX = 448.0f;  // largest finite e4m3
+
+__device__ __forceinline__ unsigned pack_f8x4(float a, float b, float c, float d) {
+  a = __builtin_fminf(__builtin_fmaxf(a, -F8_MAX), F8_MAX);
+  b = __builtin_fminf(__builtin_fmaxf(b, -F8_MAX), F8_MAX);
+  c = __builtin_fminf(__builtin_fmaxf(c, -F8_MAX), F8_MAX);
+  d = __builtin_fminf(__builtin_fmaxf(d, -F8_MAX), F8_MAX);
+  int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+  return (unsigned)r;
+}
+
+// ---------------------------------------------------------------------------------------- bf16 planes -> fp8 planes
+// One thread = one pixel of one 16-channel plane (two bf16 planes in, 16 bytes out).  Runs over whole planes, guards
+// included: a guard is zero on both sides.
+__global__ __launch_bounds__(256) void quant_f8_kernel(const bf16x8* __restrict__ in, v4i* __restrict__ out, unsigned plane_px,
+                                                      int planes16, float inv_scale) {
+  const unsigned px = blockIdx.x * 256u + threadIdx.x;
+  const int p = blockIdx.y;
+  if (px >= plane_px || p >= planes16) return;
+  const bf16x8 lo = in[(size_t)(2 * p) * plane_px + px];
+  const bf16x8 hi = in[(size_t)(2 * p + 1) * plane_px + px];
+  float v[16];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    v[j] = (float)lo[j] * inv_scale;
+    v[8 + j] = (float)hi[j] * inv_scale;
+  }
+  v4i o;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) o[q] = (int)pack_f8x4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+  out[(size_t)p * plane_px + px] = o;
+}
+
+int quant_f8_launch(const PView& in, void* out, unsigned plane_px, int C, float scale, hipStream_t s) {
+  if (C % 16 || !(scale > 0.f)) return fail(-3, "quantize: channel count must be a multiple of 16 and the scale positive");
+  hipLaunchKernelGGL(quant_f8_kernel, dim3((plane_px + 255) / 256, C / 16), dim3(256), 0, s,
+                     reinterpret_cast<const bf16x8*>(in.base), reinterpret_cast<v4i*>(out), plane_px, C / 16, 1.0f / scale);
+  YL_HIP(hipGetLastError());
+  return 0;
+}
+
+// --------------------------------------------------------------------------------------------------- conv kernel
+// B fragments of k-step ks: two 16-byte loads per pixel tile (k-groups 2g and 2g + 1).  UNIFORM (Cin % 128 == 0): a
+// step lies inside one tap, offsets are wave-uniform and Patch::base already contains the lane group's plane.
+template <int KS, int NT, bool UNIFORM>
+__device__ __forceinline__ void fetch_b8(const ConvArgs& a, __amdgpu_buffer_rsrc_t rin, int ks, int g, const Patch<NT>& P,
+                                         v8i (&xb)[NT]) {
+  unsigned off0, off1;
+  if (UNIFORM) {
+    const int tap = fastdiv(ks, a.kkn, a.magic_kkn);
+    const int kk = ks - tap * a.kkn;
+    off0 = ks < a.ksteps ? (unsigned)tap_offset<KS>(a, tap) + (unsigned)(kk * 8) * a.in_plane : OOB_K;
+    off1 = off0 + a.in_plane;
+  } else {
+    const int q0 = ks * 8 + 2 * g, q1 = q0 + 1;
+    const int t0 = KS == 1 ? 0 : fastdiv(q0, a.cg, a.magic_cg), t1 = KS == 1 ? 0 : fastdiv(q1, a.cg, a.magic_cg);
+    const int nq = a.ntaps * a.cg;
+    off0 = q0 < nq ? (unsigned)tap_offset<KS>(a, t0) + (unsigned)(q0 - t0 * a.cg) * a.in_plane : OOB_K;
+    off1 = q1 < nq ? (unsigned)tap_offset<KS>(a, t1) + (unsigned)(q1 - t1 * a.cg) * a.in_plane : OOB_K;
+  }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const u32x4 lo = __builtin_amdgcn_raw_buffer_load_b128(rin, P.base[nt] + off0, 0, 0);
+    const u32x4 hi = __builtin_amdgcn_raw_buffer_load_b128(rin, P.base[nt] + off1, 0, 0);
+    xb[nt] = v8i{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+  }
+}
+
+// slab: [k-step][MT][half][64 lanes] x 16 bytes (a lane's two halves 1 KiB apart: conflict-free ds_read_b128)
+template <int MT, int NT>
+__device__ __forceinline__ void mma_step8(const v4i* wl, int row, const v8i (&xb)[NT], f32x4 (&acc)[MT][NT]) {
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const v4i lo = wl[((row * MT + mt) * 2) * 64], hi = wl[((row * MT + mt) * 2 + 1) * 64];
+    const v8i wa = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wa, xb[nt], acc[mt][nt], 0, 0, 0, 0, 0, 0);
+  }
+}
+
+template <int KS, int MT, int NT, bool UNIFORM, int D>
+__device__ __forceinline__ void run_ksteps8(const ConvArgs& a, __amdgpu_buffer_rsrc_t rin, int g, const Patch<NT>& P,
+                                            const v4i* wl, int kbeg, int nk, v8i (&xr)[D][NT], f32x4 (&acc)[MT][NT]) {
+  int i0 = 0;
+  for (; i0 + D <= nk; i0 += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      mma_step8<MT, NT>(wl, i0 + d, xr[d], acc);
+      fetch_b8<KS, NT, UNIFORM>(a, rin, kbeg + i0 + d + D, g, P, xr[d]);
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < D - 1; ++d)
+    if (i0 + d < nk) mma_step8<MT, NT>(wl, i0 + d, xr[d], acc);
+}
+
+template <int KS, int MT, int NT, bool UNIFORM>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_f8_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem8[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int g = lane >> 4, n = lane & 15;
+  const int bid = xcd_remap(blockIdx.x, a.nblocks);
+  const int cb = bid % a.ncb;
+  const int pblk = bid / a.ncb;
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, (short)0, a.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.out, (short)0, a.out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rres =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.res, (short)0, a.res ? a.res_bytes : 0, 0x00020000);
+  constexpr int D = 2;
+  v8i xr[D][NT];
+  Patch<NT> P;
+  const unsigned lane_off = UNIFORM ? (unsigned)(2 * g) * a.in_plane : 0u;
+  int patch = __builtin_amdgcn_readfirstlane(pblk * a.ppw * 4 + wave);
+  bool live = patch < a.npatches;
+  if (live) {
+    patch_setup<NT>(a, patch, n, lane_off, P);
+#pragma unroll
+    for (int d = 0; d < D; ++d) fetch_b8<KS, NT, UNIFORM>(a, rin, d, g, P, xr[d]);
+  }
+  // per-lane dequantisation factor and bias of its 4 channels of every tile
+  f32x4 alpha_r[MT], bias_r[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    alpha_r[mt] = *reinterpret_cast<const f32x4*>(a.alpha + cb * MT * 16 + mt * 16 + g * 4);
+    bias_r[mt] = *reinterpret_cast<const f32x4*>(a.bias + cb * MT * 16 + mt * 16 + g * 4);
+  }
+  const bf16x8* wsrc = reinterpret_cast<const bf16x8*>(a.wpk) + (size_t)cb * a.ksteps * MT * 128;  // 16-byte units
+  const v4i* wl = reinterpret_cast<const v4i*>(smem8) + lane;
+  const bool multi = a.kchunk < a.ksteps;
+  bool first = true;
+  for (int pp = 0; pp < a.ppw; ++pp) {
+    if (!first && !live) break;
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int kc = 0; kc < a.ksteps; kc += a.kchunk) {
+      const int nk = min(a.kchunk, a.ksteps - kc);
+      if (multi || first) {
+        if (!first) __syncthreads();
+        copy_slab(wsrc + (size_t)kc * MT * 128, reinterpret_cast<bf16x8*>(smem8), nk * MT * 128, tid);
+        __syncthreads();
+        first = false;
+      }
+      if (live) run_ksteps8<KS, MT, NT, UNIFORM, D>(a, rin, g, P, wl, kc, nk, xr, acc);
+    }
+    if (!live) break;
+    int opix[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) opix[nt] = P.opix[nt];
+    patch += 4;
+    live = (pp + 1 < a.ppw) && patch < a.npatches;
+    if (live) {
+      patch_setup<NT>(a, patch, n, lane_off, P);
+#pragma unroll
+      for (int d = 0; d < D; ++d) fetch_b8<KS, NT, UNIFORM>(a, rin, d, g, P, xr[d]);
+    }
+    // ---- epilogue: dequantise, bias, SiLU, residual, store
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int co = cb * MT * 16 + mt * 16 + g * 4;
+      const bool cok = co < a.Cout;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const bool ok = cok && opix[nt] >= 0;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = __builtin_fmaf(acc[mt][nt][r], alpha_r[mt][r], bias_r[mt][r]);
+          if (a.act) v[r] = silu_f(v[r]);
+        }
+        if (a.res) {
+          if (a.res_f8) {
+            const unsigned ro = ok ? (unsigned)(co >> 4) * a.res_plane + (unsigned)opix[nt] * 16u + (unsigned)(co & 15) : OOB_LANE;
+            const int rv = (int)__builtin_amdgcn_raw_buffer_load_b32(rres, ro, 0, 0);
+            v[0] += a.res_scale * __builtin_amdgcn_cvt_f32_fp8(rv, 0);
+            v[1] += a.res_scale * __builtin_amdgcn_cvt_f32_fp8(rv, 1);
+            v[2] += a.res_scale * __builtin_amdgcn_cvt_f32_fp8(rv, 2);
+            v[3] += a.res_scale * __builtin_amdgcn_cvt_f32_fp8(rv, 3);
+          } else {
+            const unsigned ro = ok ? (unsigned)(co >> 3) * a.res_plane + (unsigned)opix[nt] * 16u + (unsigned)(co & 7) * 2u : OOB_LANE;
+            const bf16x4 rv = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rres, ro, 0, 0));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+          }
+        }
+        if (a.out_f8) {
+          const unsigned vo = ok ? (unsigned)(co >> 4) * a.out_plane + (unsigned)opix[nt] * 16u + (unsigned)(co & 15) : OOB_LANE;
+          const float is = a.out_inv_scale;
+          __builtin_amdgcn_raw_buffer_store_b32(pack_f8x4(v[0] * is, v[1] * is, v[2] * is, v[3] * is), rout, vo, 0, 0);
+        } else {
+          const unsigned vo = ok ? (unsigned)(co >> 3) * a.out_plane + (unsigned)opix[nt] * 16u + (unsigned)(co & 7) * 2u : OOB_LANE;
+          __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])}, rout, vo, 0, 0);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------ host
+static unsigned magic8(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull / (unsigned)d) + 1ull); }
+
+// float -> OCP e4m3fn, round to nearest even, saturating (what v_cvt_pk_fp8_f32 does for in-range values)
+uint8_t f32_to_e4m3(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  const uint8_t sign = (uint8_t)((u >> 24) & 0x80);
+  if (std::isnan(f)) return (uint8_t)(sign | 0x7f);
+  float a = std::fabs(f);
+  if (a >= F8_MAX) return (uint8_t)(sign | 0x7e);
+  int ex = a > 0.f ? std::ilogb(a) : -6;
+  if (ex < -6) ex = -6;                           // subnormals share the exponent of the smallest normal
+  const float step = std::ldexp(1.0f, ex - 3);    // spacing of representable values in this binade
+  const float q = std::nearbyint(a / step);       // RNE in the default rounding mode
+  const float v = q * step;
+  if (v == 0.f) return sign;
+  if (v >= F8_MAX) return (uint8_t)(sign | 0x7e);
+  if (v < std::ldexp(1.0f, -6)) return (uint8_t)(sign | (uint8_t)std::lrint(v / std::ldexp(1.0f, -9)));
+  const int e2 = std::ilogb(v);
+  const int mant = (int)std::lrint(v / std::ldexp(1.0f, e2 - 3)) - 8;
+  return (uint8_t)(sign | ((e2 + 7) << 3) | mant);
+}
+
+int conv_f8_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, ConvConfig* c) {
+  if ((k != 1 && k != 3) || (stride != 1 && stride != 2) || Cin % 16 || Cout % 16 || Cin <= 0 || Cout <= 0)
+    return fail(-3, "fp8 conv: k in {1,3}, stride in {1,2}, Cin % 16 == 0, Cout % 16 == 0");
+  const int cout16 = Cout / 16;
+  const int MT = cout16 % 4 == 0 ? 4 : (cout16 % 3 == 0 ? 3 : (cout16 % 2 == 0 ? 2 : 0));
+  if (!MT) return fail(-3, "fp8 conv: Cout must be a multiple of 32 or 48");
+  const int ntaps = k * k, cg = Cin / 16;
+  const int ksteps = (ntaps * cg + 7) / 8;
+  const size_t slab_max = 72 * 1024, step_bytes = (size_t)MT * 2048;
+  int kchunk = ksteps;
+  if ((size_t)ksteps * step_bytes > slab_max) kchunk = (int)(slab_max / step_bytes) & ~1;  // multiple of the ring depth
+  const long long npix = (long long)batch * Ho * Wo;
+  const int ncb = cout16 / MT;
+  const int NT = (npix + 63) / 64 * ncb / 4 >= 256 ? 4 : 2;
+  c->MT = MT;
+  c->NT = NT;
+  c->ncb = ncb;
+  c->cg = cg;
+  c->ntaps = ntaps;
+  c->uniform = cg % 8 == 0;
+  c->ksteps = ksteps;
+  c->kchunk = kchunk;
+  c->lds_bytes = (size_t)kchunk * step_bytes;
+  c->post = 0;
+  c->tile = 0;
+  c->wpk_elems = (size_t)ncb * ksteps * MT * 2048;  // bytes
+  c->npatches = (int)((npix + 16 * NT - 1) / (16 * NT));
+  long long blocks1 = ((long long)c->npatches + 3) / 4 * ncb;
+  int ppw = (int)(blocks1 / (8 * 256));
+  if (ppw < 1) ppw = 1;
+  if (ppw > 32) ppw = 32;
+  if (kchunk < ksteps) ppw = 1;
+  c->ppw = ppw;
+  c->gws = (int)(((long long)c->npatches + 4 * ppw - 1) / (4 * ppw));
+  c->name = k == 3 ? (stride == 2 ? "conv3x3s2_f8_mfma" : "conv3x3_f8_mfma") : "conv1x1_f8_mfma";
+  return 0;
+}
+
+// Folded fp32 OIHW filters -> e4m3 in fragment order [cb][k-step][MT][half][64 lanes][16], and the per-channel scales.
+void conv_f8_pack_weights(const float* w, int Cout, int Cin, int k, const ConvConfig& c, std::vector<uint8_t>* out,
+                          std::vector<float>* wscale) {
+  const int kk = k * k;
+  wscale->assign((size_t)c.ncb * c.MT * 16 + 16, 1.0f);
+  for (int co = 0; co < Cout; ++co) {
+    float m = 0.f;
+    for (size_t i = 0; i < (size_t)Cin * kk; ++i) m = std::fmax(m, std::fabs(w[(size_t)co * Cin * kk + i]));
+    (*wscale)[co] = m > 0.f ? m / F8_MAX : 1.0f;
+  }
+  out->assign(c.wpk_elems, 0);
+  size_t o = 0;
+  for (int cb = 0; cb < c.ncb; ++cb)
+    for (int ks = 0; ks < c.ksteps; ++ks)
+      for (int mt = 0; mt < c.MT; ++mt)
+        for (int h = 0; h < 2; ++h)
+          for (int lane = 0; lane < 64; ++lane) {
+            const int co = cb * c.MT * 16 + mt * 16 + (lane & 15);
+            const int q = ks * 8 + 2 * (lane >> 4) + h;
+            const int tap = q / c.cg, c16 = q % c.cg;
+            for (int j = 0; j < 16; ++j, ++o) {
+              if (co < Cout && tap < c.ntaps) {
+                const int ci = c16 * 16 + j, kh = tap / k, kw = tap % k;
+                (*out)[o] = f32_to_e4m3(w[(((size_t)co * Cin + ci) * k + kh) * k + kw] / (*wscale)[co]);
+              }
+            }
+          }
+}
+
+template <int KS, int MT, int NT, bool U>
+static int launch8(const ConvConfig& cfg, const ConvArgs& a, hipStream_t s) {
+  auto kern = conv_f8_kernel<KS, MT, NT, U>;
+  static bool attr = false;
+  if (!attr) {
+    YL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.nblocks), dim3(256), cfg.lds_bytes, s, a);
+  YL_HIP(hipGetLastError());
+  return 0;
+}
+
+template <int KS, int MT>
+static int launch8_n(const ConvConfig& cfg, const ConvArgs& a, hipStream_t s) {
+  if (cfg.NT == 4) return cfg.uniform ? launch8<KS, MT, 4, true>(cfg, a, s) : launch8<KS, MT, 4, false>(cfg, a, s);
+  return cfg.uniform ? launch8<KS, MT, 2, true>(cfg, a, s) : launch8<KS, MT, 2, false>(cfg, a, s);
+}
+
+template <int KS>
+static int launch8_m(const ConvConfig& cfg, const ConvArgs& a, hipStream_t s) {
+  switch (cfg.MT) {
+    case 2: return launch8_n<KS, 2>(cfg, a, s);
+    case 3: return launch8_n<KS, 3>(cfg, a, s);
+    case 4: return launch8_n<KS, 4>(cfg, a, s);
+  }
+  return fail(-3, "fp8 conv: bad MT");
+}
+
+// `a` arrives with pointers, plane sizes, geometry, Cin / Cout / stride / act, alpha / bias, out_f8 / res_f8 and scales.
+int conv_f8_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s) {
+  a.ncb = cfg.ncb;
+  a.cg = cfg.cg;
+  a.ksteps = cfg.ksteps;
+  a.kchunk = cfg.kchunk;
+  a.ntaps = cfg.ntaps;
+  a.kkn = cfg.cg >> 3;
+  a.magic_kkn = magic8(cfg.cg >> 3);
+  a.magic_cg = magic8(cfg.cg);
+  a.magic_wo = magic8(a.Wo);
+  a.magic_ho = magic8(a.Ho);
+  a.npatches = cfg.npatches;
+  a.ppw = cfg.ppw;
+  a.npix = batch * a.Ho * a.Wo;
+  a.out_f32 = 0;
+  const long long lim = 1LL << 30;
+  const long long inb = (long long)cfg.cg * a.in_plane;
+  const long long outb = (long long)(a.out_f8 ? a.Cout / 16 : a.Cout / 8) * a.out_plane;
+  const long long resb = a.res ? (long long)(a.res_f8 ? a.Cout / 16 : a.Cout / 8) * a.res_plane : 0;
+  if (inb > lim || outb > lim || resb > lim)
+    return fail(-3, "fp8 conv: a tensor slice exceeds 1 GiB (32-bit buffer offsets); lower the batch size");
+  a.in_bytes = (unsigned)inb;
+  a.out_bytes = (unsigned)outb;
+  a.res_bytes = (unsigned)resb;
+  a.nblocks = cfg.gws * cfg.ncb;
+  a.dbg = 0;
+  return cfg.ntaps == 9 ? launch8_m<3>(cfg, a, s) : launch8_m<1>(cfg, a, s);
+}
+
+}  // namespace yl

@@ -31,6 +31,8 @@ struct OpRec {
   float* d_b0 = nullptr;
   __bf16* d_wpk3 = nullptr;  // YL_OP_C3K2S: the block's 1x1 conv (d_wpk / d_wpk2 = the Bottleneck's two 3x3 convs)
   float* d_bias3 = nullptr;
+  float* d_alpha = nullptr;  // fp8 conv: in_scale * filter scale per output channel
+  bool f8 = false;
   double flops = 0, bytes = 0;
   const char* name = "";
 };
@@ -75,7 +77,7 @@ struct yl_engine {
   std::vector<void*> zeroed;  // workspaces whose guard pixels this engine has already cleared
 };
 
-static int64_t view_elem_size(const yl_view& v) { return v.dtype == YL_F32 ? 4 : 2; }
+static int64_t view_elem_size(const yl_view& v) { return v.dtype == YL_F32 ? 4 : (v.dtype == YL_FP8 ? 1 : 2); }
 
 // bf16 views are plane ranges of a C8-planar guarded buffer (yl_internal.h); fp32 views are NHWC.
 static int check_view(const yl_view& v, int batch, int64_t ws_bytes, const char* what) {
@@ -85,6 +87,10 @@ static int check_view(const yl_view& v, int batch, int64_t ws_bytes, const char*
   int64_t end;
   if (v.dtype == YL_F32) {
     end = v.offset + (int64_t)batch * v.H * v.W * v.pitch * 4;
+  } else if (v.dtype == YL_FP8) {
+    if ((v.C | v.pitch | v.coff) & 15)
+      return fail(-3, std::string(what) + ": fp8 channel counts / offsets must be multiples of 16 (planar layout)");
+    end = v.offset + (int64_t)(v.pitch / 16) * plane_bytes(geo_of(batch, v.H, v.W));
   } else {
     if ((v.C | v.pitch | v.coff) & 7)
       return fail(-3, std::string(what) + ": bf16 channel counts / offsets must be multiples of 8 (planar layout)");
@@ -98,7 +104,7 @@ static int check_view(const yl_view& v, int batch, int64_t ws_bytes, const char*
 static PView pview(char* ws, const yl_view& v, int batch) {
   const Geo g = geo_of(batch, v.H, v.W);
   PView p;
-  p.base = reinterpret_cast<__bf16*>(ws + v.offset + (int64_t)(v.coff / 8) * plane_bytes(g));
+  p.base = reinterpret_cast<__bf16*>(ws + v.offset + (int64_t)(v.coff / (v.dtype == YL_FP8 ? 16 : 8)) * plane_bytes(g));
   p.plane = (long long)g.plane_px * 8;
   p.W1 = g.W1;
   p.img = g.img;
@@ -179,10 +185,42 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
     switch (o.kind) {
       case YL_OP_CONV: {
         if (!o.weight || !o.bias) return fail(-1, tag + ": conv needs weight and bias");
-        if (o.in.dtype != YL_BF16) return fail(-1, tag + ": conv input must be bf16");
+        if (o.in.dtype != YL_BF16 && o.in.dtype != YL_FP8) return fail(-1, tag + ": conv input must be bf16 or fp8");
         const int pad = o.k / 2;
         const int Ho = (o.in.H + 2 * pad - o.k) / o.stride + 1, Wo = (o.in.W + 2 * pad - o.k) / o.stride + 1;
         if (Ho != o.out.H || Wo != o.out.W) return fail(-1, tag + ": conv output dims mismatch");
+        if (o.in.dtype == YL_FP8) {  // e4m3 x e4m3 on the block-scaled matrix pipe (conv_f8.hip)
+          if (o.post_weight || o.in2.offset >= 0 || o.stem_weight || o.cin_weight || o.out.dtype == YL_F32)
+            return fail(-1, tag + ": an fp8 conv is a plain conv (no fused follow-up / upsampled input / stem, bf16 or fp8 output)");
+          if (!(o.in_scale > 0.f) || (o.out.dtype == YL_FP8 && !(o.out_scale > 0.f)))
+            return fail(-1, tag + ": fp8 conv needs positive in_scale (and out_scale for fp8 output)");
+          if (o.res.offset >= 0) {
+            if (int rc = check_view(o.res, batch, workspace_bytes, (tag + " res").c_str())) return rc;
+            if (o.res.H != Ho || o.res.W != Wo || o.res.C != o.out.C || (o.res.dtype != YL_BF16 && o.res.dtype != YL_FP8) ||
+                (o.res.dtype == YL_FP8 && !(o.res_scale > 0.f)))
+              return fail(-1, tag + ": residual view mismatch");
+          }
+          if (int rc = conv_f8_choose(batch, o.in.C, o.out.C, o.k, o.stride, Ho, Wo, &r.cfg)) return rc;
+          std::vector<uint8_t> pk;
+          std::vector<float> ws_;
+          conv_f8_pack_weights(o.weight, o.out.C, o.in.C, o.k, r.cfg, &pk, &ws_);
+          uint8_t* d8 = nullptr;
+          if (int rc = dev_upload(e.get(), pk, &d8)) return rc;
+          r.d_wpk = reinterpret_cast<__bf16*>(d8);
+          std::vector<float> alpha(ws_.size(), 0.f), bias(ws_.size(), 0.f);
+          for (int c = 0; c < o.out.C; ++c) {
+            alpha[c] = o.in_scale * ws_[c];
+            bias[c] = o.bias[c];
+          }
+          if (int rc = dev_upload(e.get(), alpha, &r.d_alpha)) return rc;
+          if (int rc = dev_upload(e.get(), bias, &r.d_bias)) return rc;
+          r.f8 = true;
+          r.flops = 2.0 * px_out * o.out.C * o.in.C * o.k * o.k;
+          r.bytes = px_in * o.in.C + px_out * o.out.C * view_elem_size(o.out) +
+                    (o.res.offset >= 0 ? px_out * o.out.C * view_elem_size(o.res) : 0) + (double)o.out.C * o.in.C * o.k * o.k;
+          r.name = r.cfg.name;
+          break;
+        }
         if (o.res.offset >= 0) {
           if (int rc = check_view(o.res, batch, workspace_bytes, (tag + " res").c_str())) return rc;
           if (o.res.H != Ho || o.res.W != Wo || o.res.C != o.out.C || o.res.dtype != YL_BF16)
@@ -316,6 +354,15 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
         }
         r.bytes = pw ? px_out * (C + o.out.C) * 2 : px_out * C * 2 * (o.accumulate ? 3 : 2);
         r.name = pw ? (o.stem_weight ? "dw3x3+pw1x1+1x1_mfma" : "dw3x3+pw1x1_mfma") : "dwconv3x3";
+        break;
+      }
+      case YL_OP_QUANT: {
+        if (o.in.dtype != YL_BF16 || o.out.dtype != YL_FP8 || o.in.H != o.out.H || o.in.W != o.out.W || o.in.C != o.out.C ||
+            !(o.out_scale > 0.f))
+          return fail(-1, tag + ": quantize: bf16 in, fp8 out, same dims, positive out_scale");
+        r.flops = 0;
+        r.bytes = px_in * o.in.C * 3;
+        r.name = "quantize_f8";
         break;
       }
       case YL_OP_BNECK2: {
@@ -472,6 +519,36 @@ static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s, c
       }
       ConvArgs a{};
       const Geo gi = geo_of(B, o.in.H, o.in.W), go = geo_of(B, o.out.H, o.out.W);
+      if (r.f8) {
+        a.in = pview(ws, o.in, B).base;
+        a.in_plane = (unsigned)plane_bytes(gi);
+        a.in_w1 = gi.W1;
+        a.in_img = gi.img;
+        a.in_g0 = gi.g0;
+        a.out = pview(ws, o.out, B).base;
+        a.out_plane = (unsigned)plane_bytes(go);
+        a.out_w1 = go.W1;
+        a.out_img = go.img;
+        a.out_g0 = go.g0;
+        a.out_f8 = o.out.dtype == YL_FP8;
+        a.out_inv_scale = a.out_f8 ? 1.0f / o.out_scale : 1.0f;
+        if (o.res.offset >= 0) {
+          a.res = pview(ws, o.res, B).base;
+          a.res_plane = (unsigned)plane_bytes(go);
+          a.res_f8 = o.res.dtype == YL_FP8;
+          a.res_scale = o.res_scale;
+        }
+        a.wpk = r.d_wpk;
+        a.alpha = r.d_alpha;
+        a.bias = r.d_bias;
+        a.Ho = o.out.H;
+        a.Wo = o.out.W;
+        a.Cin = o.in.C;
+        a.Cout = o.out.C;
+        a.stride = o.stride;
+        a.act = o.act;
+        return conv_f8_launch(r.cfg, a, B, s);
+      }
       a.in = pview(ws, o.in, B).base;
       a.in_plane = (unsigned)plane_bytes(gi);
       a.in_w1 = gi.W1;
@@ -515,6 +592,10 @@ static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s, c
       a.stride = o.stride;
       a.act = o.act;
       return conv_launch(r.cfg, a, B, s);
+    }
+    case YL_OP_QUANT: {
+      const Geo gq = geo_of(B, o.in.H, o.in.W);
+      return quant_f8_launch(pview(ws, o.in, B), pview(ws, o.out, B).base, gq.plane_px, o.in.C, o.out_scale, s);
     }
     case YL_OP_BNECK2: {
       Bneck2Args q{};

@@ -96,6 +96,11 @@ struct ConvArgs {
   // conv3_tile_kernel (3x3, stride 1, input tile in LDS): tile geometry in guarded-pixel units
   int t_px, t_PL, t_ppp, t_ntiles, t_plane_px, t_H, t_W, t_B;  // pixels staged / LDS plane pitch / DMA pieces per plane
   unsigned magic_ppp, magic_img, magic_w1;
+  // conv_f8_kernel (conv_f8.hip): in / wpk are e4m3 (planes of 16 channels; cg, kkn count groups of 16 / steps of 128)
+  const float* alpha;          // s_in * s_w[c] per output channel, padded like bias
+  float out_inv_scale;         // fp8 output: 1 / s_out
+  float res_scale;             // fp8 residual: its scale
+  int out_f8, res_f8;          // output / residual are fp8 planes (else bf16 planes)
 };
 
 struct ConvConfig {
@@ -116,6 +121,12 @@ int conv_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s);
 void conv3_tile_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, int post, ConvConfig* cfg);
 int conv3_tile_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s);
 int dwpw_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s);
+// conv_f8.hip: e4m3 x e4m3 -> fp32 on v_mfma_f32_16x16x128_f8f6f4
+int conv_f8_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, ConvConfig* cfg);
+void conv_f8_pack_weights(const float* w_oihw, int Cout, int Cin, int k, const ConvConfig& cfg, std::vector<uint8_t>* out,
+                          std::vector<float>* wscale);
+int conv_f8_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s);
+uint8_t f32_to_e4m3(float f);
 
 // ------------------------------------------------------------------------ elementwise-ish
 // PView: a channel slice of a planar buffer as the kernels see it.
@@ -124,6 +135,9 @@ struct PView {
   long long plane;  // elements per plane
   int W1, img, g0;
 };
+
+// bf16 planes (8 channels) -> e4m3 planes (16 channels), x / scale, whole planes incl. guards
+int quant_f8_launch(const PView& in, void* out, unsigned plane_px, int C, float scale, hipStream_t s);
 
 struct DwArgs {
   PView in, out;

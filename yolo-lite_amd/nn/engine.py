@@ -12,7 +12,7 @@ import torch
 
 from .. import _lib
 from .arch import LayerSpec
-from .lower import BF16, F32, Program, TView, lower, plane_pixels
+from .lower import BF16, F32, FP8, Program, TView, lower, plane_pixels
 
 _TORCH2YL = {torch.float32: _lib.YL_F32, torch.float16: _lib.YL_F16, torch.uint8: _lib.YL_U8}
 
@@ -53,6 +53,7 @@ class HipEngine:
             c.lane = o.get("lane", 0)
             c.inp, c.out, c.res = _cview(o["inp"]), _cview(o["out"]), _cview(o.get("res"))
             c.inp2, c.up = _cview(o.get("inp2")), int(o.get("up", 0))
+            c.in_scale, c.out_scale, c.res_scale = (float(o.get(k, 0.0)) for k in ("in_scale", "out_scale", "res_scale"))
             if "weight" in o:
                 w = np.ascontiguousarray(o["weight"], dtype=np.float32)
                 b = np.ascontiguousarray(o["bias"], dtype=np.float32)
@@ -213,8 +214,12 @@ class HipEngine:
 
     def _planes(self, v: TView) -> torch.Tensor:
         """The guarded planes of a bf16 view as a (C/8, B, H+1, W+1, 8) tensor aliasing the workspace
-        (index [..., :H, :W, :] is the data, the rest are guard pixels)."""
+        (index [..., :H, :W, :] is the data, the rest are guard pixels); fp8 views: (C/16, B, H+1, W+1, 16) e4m3."""
         pp = plane_pixels(self.batch, v.H, v.W)
+        if v.dtype == FP8:
+            t = self.workspace[v.offset: v.offset + (v.pitch // 16) * pp * 16].view(torch.float8_e4m3fn).view(v.pitch // 16, pp, 16)
+            t = t[v.coff // 16: (v.coff + v.C) // 16, v.W + 2: v.W + 2 + self.batch * (v.H + 1) * (v.W + 1)]
+            return t.view(v.C // 16, self.batch, v.H + 1, v.W + 1, 16)
         n = (v.pitch // 8) * pp * 8
         t = self.workspace[v.offset: v.offset + 2 * n].view(torch.bfloat16).view(v.pitch // 8, pp, 8)
         t = t[v.coff // 8: (v.coff + v.C) // 8, v.W + 2: v.W + 2 + self.batch * (v.H + 1) * (v.W + 1)]
@@ -226,17 +231,23 @@ class HipEngine:
             n = self.batch * v.H * v.W * v.pitch
             t = self.workspace[v.offset: v.offset + 4 * n].view(torch.float32).view(self.batch, v.H, v.W, v.pitch)
             return t[..., v.coff: v.coff + v.C].permute(0, 3, 1, 2).contiguous()
-        t = self._planes(v)[:, :, : v.H, : v.W]  # (C/8, B, H, W, 8)
-        return t.permute(1, 0, 4, 2, 3).reshape(self.batch, v.C, v.H, v.W).float().contiguous()
+        t = self._planes(v)[:, :, : v.H, : v.W]  # (C/8, B, H, W, 8); fp8: (C/16, B, H, W, 16), raw e4m3 values (no scale)
+        return t.float().permute(1, 0, 4, 2, 3).reshape(self.batch, v.C, v.H, v.W).contiguous()
 
     def write_view(self, v: TView, x: torch.Tensor) -> None:
-        """Store an NCHW tensor into a bf16 arena view (tests / micro-benchmarks)."""
+        """Store an NCHW tensor into a bf16 arena view (tests / micro-benchmarks); fp8 views take e4m3-representable values."""
+        if v.dtype == FP8:
+            t = x.to(self.device, torch.float32).view(self.batch, v.C // 16, 16, v.H, v.W).permute(1, 0, 3, 4, 2)
+            self._planes(v).view(torch.uint8)[:, :, : v.H, : v.W] = t.contiguous().to(torch.float8_e4m3fn).view(torch.uint8)
+            return
         t = x.to(self.device, torch.bfloat16).view(self.batch, v.C // 8, 8, v.H, v.W).permute(1, 0, 3, 4, 2)
         self._planes(v)[:, :, : v.H, : v.W] = t
 
     def guards_are_zero(self, v: TView) -> bool:
         """True if no kernel has written a guard pixel of this view (layout invariant, tests)."""
         t = self._planes(v)
+        if v.dtype == FP8:
+            t = t.view(torch.uint8)
         return bool((t[:, :, v.H, :] == 0).all()) and bool((t[:, :, :, v.W] == 0).all())
 
     def layer_output(self, i: int) -> torch.Tensor:

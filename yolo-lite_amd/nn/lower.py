@@ -21,8 +21,8 @@ import torch
 from .arch import LayerSpec, detect_mid_channels
 
 BN_EPS = 1e-3
-BF16, F32 = 0, 1
-OP_CONV, OP_DWCONV3, OP_SPPF_POOL, OP_UPSAMPLE, OP_ATTENTION, OP_STEM, OP_C3K2S, OP_BNECK2 = 1, 2, 3, 4, 5, 6, 7, 8
+BF16, F32, FP8 = 0, 1, 4  # yl_amd.h element types (FP8 = OCP e4m3, planes of 16 channels)
+OP_CONV, OP_DWCONV3, OP_SPPF_POOL, OP_UPSAMPLE, OP_ATTENTION, OP_STEM, OP_C3K2S, OP_BNECK2, OP_QUANT = 1, 2, 3, 4, 5, 6, 7, 8, 9
 
 
 @dataclass
@@ -71,7 +71,7 @@ def view_bytes(batch: int, v: "TView") -> int:
     """Bytes of the whole buffer underneath a view."""
     if v.dtype == F32:
         return batch * v.H * v.W * v.pitch * 4
-    return (v.pitch // 8) * plane_pixels(batch, v.H, v.W) * 16
+    return (v.pitch // (16 if v.dtype == FP8 else 8)) * plane_pixels(batch, v.H, v.W) * 16
 
 
 class _Arena:
@@ -83,6 +83,8 @@ class _Arena:
         self.top = 0
 
     def alloc(self, H: int, W: int, C: int, dtype: int = BF16) -> TView:
+        if dtype == FP8 and C % 16:
+            raise NotImplementedError(f"fp8 activations need channel counts that are multiples of 16, got {C}")
         if dtype != F32 and C % 8:
             raise NotImplementedError(f"bf16 activations need channel counts that are multiples of 8, got {C}")
         v = TView(self.top, H, W, C, C, 0, dtype)
