@@ -36,8 +36,10 @@ CONV_GFLOP_PER_IMG = 6.4811  # 2*MAC over all nn.Conv2d 
 ACT_MB_PER_IMG = 81.7        # activation elements in+out, bf16
 
 
-def build_model(scale, device, batch, h, w, x_calib, target_frac=0.015):
-    """Random-init YOLO11 with the class bias calibrated on-device so ~1.5 % of anchors pass conf 0.25."""
+def build_model(scale, device, batch, h, w, x_calib, target_frac=0.015, fp8=False):
+    """Random-init YOLO11 with the class bias calibrated on-device so ~1.5 % of anchors pass conf 0.25.
+    fp8: the dense 3x3 convs run in e4m3 (weights + activations, fp32 accumulate), activation scales calibrated on
+    ``x_calib`` (BASELINE.json config 5)."""
     from yololite_amd.nn import arch
     from yololite_amd.nn.engine import HipEngine
     from yololite_amd.nn.synth import calibrate_cls_bias, synth_state_dict
@@ -51,7 +53,8 @@ def build_model(scale, device, batch, h, w, x_calib, target_frac=0.015):
     bias = calibrate_cls_bias(mx, target_frac)
     del eng
     sd = synth_state_dict(scale, 0, cls_bias=bias)
-    return specs, sd, HipEngine.from_model(specs, sd, batch, h, w, device)
+    torch.cuda.empty_cache()
+    return specs, sd, HipEngine.from_model(specs, sd, batch, h, w, device, fp8_calib=x_calib if fp8 else None)
 
 
 def _iou(a, b):
@@ -195,6 +198,9 @@ def main():
     ap.add_argument("--cand-frac", type=float, default=0.015,
                     help="fraction of anchors above conf 0.25 the synthetic class bias is calibrated to "
                          "(0.015 = the bench's operating point; 0.05 = the NMS stress point of SURVEY 8d)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"],
+                    help="fp8: dense 3x3 convs in OCP e4m3 (weights + activations, fp32 accumulate) on "
+                         "v_mfma_f32_16x16x128_f8f6f4, everything else bf16 (BASELINE.json config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-out", default="", help="write the per-op timing table to this JSON file")
     args = ap.parse_args()
@@ -221,7 +227,7 @@ def main():
     B, H, W = args.batch, args.imgsz, args.imgsz
     conf, iou, max_det = 0.25, 0.7, 300
     x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(rank)).to(dev)
-    specs, sd, eng = build_model(args.scale, dev, B, H, W, x, target_frac=args.cand_frac)
+    specs, sd, eng = build_model(args.scale, dev, B, H, W, x, target_frac=args.cand_frac, fp8=args.dtype == "fp8")
 
     S = max(1, args.streams)
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
@@ -296,8 +302,8 @@ def main():
             "metric": f"images/sec end-to-end (incl. NMS), YOLO11{args.scale} {H}x{W} batch={B}",
             "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"YOLO11{args.scale} bf16, {H}x{W} batch={B} per GPU (fused Conv+BN+SiLU + HIP NMS), "
+            "vs_baseline": None, "dtype": "bf16" if args.dtype == "bf16" else "fp8 e4m3 (dense 3x3 convs) + bf16", "data": "synthetic",
+            "config": {"workload": f"YOLO11{args.scale} {args.dtype}, {H}x{W} batch={B} per GPU (fused Conv+BN+SiLU + HIP NMS), "
                                    f"random-init weights, random uint8 NCHW images resident in HBM, conf {conf} iou {iou} max_det {max_det}; "
                                    f"{S} batches in flight on {S} HIP streams (one hipGraph launch per step)",
                        "global_batch": world * B, "parallelism": f"dp{world}" if world > 1 else "single",
@@ -315,6 +321,26 @@ def main():
             if args.profile_out:
                 Path(args.profile_out).parent.mkdir(parents=True, exist_ok=True)
                 Path(args.profile_out).write_text(json.dumps(rows, indent=1))
+            if args.dtype == "fp8":
+                # the e4m3 program against the bf16 program of the same weights on the same images (SURVEY 8(d) gate)
+                from yololite_amd.nn.engine import HipEngine
+
+                o8, c8 = eng.detect(x8, conf, iou, max_det=max_det, graph=False)
+                l8 = [t.clone() for t in eng.raw_levels()] if B * H * W <= 32 * 640 * 640 else None
+                e16 = HipEngine.from_model(specs, sd, B, H, W, dev)
+                o16, c16 = e16.detect(x8, conf, iou, max_det=max_det, graph=False)
+                torch.cuda.synchronize(dev)
+                nb = min(B, 8)
+                res["fp8_vs_bf16"] = parity_gate([o16[i, : int(c16[i])].cpu() for i in range(nb)],
+                                                 [o8[i, : int(c8[i])].cpu() for i in range(nb)], conf, iou, band=0.15)
+                if l8 is not None:
+                    l16 = e16.raw_levels()
+                    res["fp8_vs_bf16"]["level_rel_l2"] = [round(float((a - b).norm() / b.norm()), 4) for a, b in zip(l8, l16)]
+                n8 = sum(1 for r in rows if "_f8_" in r["kernel"])
+                res["fp8_vs_bf16"]["fp8_conv_launches"] = n8
+                res["fp8_vs_bf16"]["fp8_flop_share"] = round(sum(r["flops"] for r in rows if "_f8_" in r["kernel"]) /
+                                                             max(1.0, sum(r["flops"] for r in rows)), 4)
+                del e16
             if not args.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(sd, args.scale, H, W, conf, iou, eng=eng, dev=dev, max_det=max_det)
         print(json.dumps(res), flush=True)

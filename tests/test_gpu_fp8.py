@@ -88,3 +88,32 @@ def test_quantize_op(gpu_device):
     m.run()
     assert m.eng.op_kernel(0) == "quantize_f8"
     assert torch.equal(m.read(q), e4m3_round(x * (torch.tensor(1.0) / torch.tensor(0.11))))
+
+
+@pytest.mark.parametrize("scale,h,w", [("n", 96, 128), ("s", 64, 64), ("x", 64, 96)])
+def test_fp8_network_close_to_bf16(gpu_device, scale, h, w):
+    """Whole network with the dense 3x3 convs in e4m3 (activation scales calibrated on the input itself) against the
+    bf16 program of the same weights: level maps within the stated relative L2 error, graph replay bit-identical to
+    eager, guards untouched."""
+    from yololite_amd.nn import arch
+    from yololite_amd.nn.engine import HipEngine
+    from yololite_amd.nn.synth import synth_state_dict
+
+    specs, _ = arch.parse_model(arch.yolo11_dict(scale))
+    sd = synth_state_dict(scale, 3, cls_bias=[-2.0, -2.0, -2.0], cls_gain=4.0)
+    x = torch.randint(0, 256, (2, 3, h, w), generator=torch.Generator().manual_seed(5), dtype=torch.uint8).to(gpu_device)
+    e16 = HipEngine.from_model(specs, sd, 2, h, w, gpu_device)
+    e16.forward(x)
+    l16 = [t.clone() for t in e16.raw_levels()]
+    e8 = HipEngine.from_model(specs, sd, 2, h, w, gpu_device, fp8_calib=x)
+    kernels = [e8.op_kernel(i) for i in range(len(e8.prog.ops))]
+    assert sum("_f8_" in k for k in kernels) >= 15 and "quantize_f8" in kernels
+    y8 = e8.forward(x).clone()
+    l8 = [t.clone() for t in e8.raw_levels()]
+    errs = [float((a - b).norm() / b.norm()) for a, b in zip(l8, l16)]
+    print("fp8 vs bf16 level rel-L2:", scale, errs)
+    assert max(errs) < 0.12, errs
+    assert torch.equal(e8.forward(x, graph=True), y8)
+    for o in e8.prog.ops:
+        if o["out"].dtype == FP8:
+            assert e8.guards_are_zero(o["out"])

@@ -107,3 +107,37 @@ def test_concat_members_are_slices_of_one_buffer():
     assert v6.offset == v12.offset == v11.offset
     assert (v11.coff, v11.C, v6.coff, v6.C, v12.C) == (0, 256, 256, 128, 384)
     assert not any(o.get("name", "").endswith(".copy") for o in p.ops)
+
+
+@pytest.mark.parametrize("scale", ["n", "x"])
+def test_fp8_pass_structure(scale):
+    """lower.apply_fp8: every fp8 conv reads an e4m3 view written earlier (by a quantize op or by an fp8 conv) with the
+    scale the reader assumes; nothing but fp8 convs reads an e4m3 view; algorithmic FLOPs are unchanged."""
+    from yololite_amd.nn.lower import FP8, OP_QUANT, fp8_candidate
+
+    specs, _ = arch.parse_model(arch.yolo11_dict(scale))
+    sd = synth_state_dict(scale, 0)
+    p = lower(specs, sd, 2, 64, 96)
+    cands = [o for o in p.ops if fp8_candidate(o)]
+    scales = {o["name"]: 0.01 * (1 + i) for i, o in enumerate(cands)}
+    p8 = lower(specs, sd, 2, 64, 96, fp8_scales=scales)
+    assert abs(_conv_gflop(p8) - _conv_gflop(p)) < 1e-9
+    written = {}
+    n8 = 0
+    for o in p8.ops:
+        if o["kind"] == OP_CONV and o["inp"].dtype == FP8:
+            n8 += 1
+            k = (o["inp"].offset, o["inp"].coff, o["inp"].C)
+            assert k in written and written[k] == o["in_scale"], o["name"]
+            assert o["name"] in scales
+        else:
+            for key in ("inp", "res", "inp2"):
+                assert o.get(key) is None or o[key].dtype != FP8, o.get("name")
+        if o["out"].dtype == FP8:
+            assert o["kind"] in (OP_QUANT, OP_CONV) and o["out_scale"] > 0
+            written[(o["out"].offset, o["out"].coff, o["out"].C)] = o["out_scale"]
+    assert n8 == len(cands) and n8 >= (19 if scale == "n" else 70)
+    # the first 3x3 of a Bottleneck hands e4m3 straight to the second one: no bf16 copy of that tensor, no quantize op
+    direct = [o for o in p8.ops if o["kind"] == OP_CONV and o["out"].dtype == FP8]
+    assert len(direct) >= (6 if scale == "n" else 30)
+    assert p8.ws_bytes > p.ws_bytes

@@ -102,10 +102,39 @@ class HipEngine:
     @classmethod
     def from_model(cls, specs: Sequence[LayerSpec], state_dict: Dict[str, torch.Tensor], batch: int, in_h: int,
                    in_w: int, device: torch.device, strides: Sequence[float] = (8.0, 16.0, 32.0),
-                   keep_layers: bool = False) -> "HipEngine":
+                   keep_layers: bool = False, fp8_calib: Optional[torch.Tensor] = None,
+                   fp8_headroom: float = 2.0) -> "HipEngine":
         """``keep_layers=True`` (debug: ``layer_output`` of every layer) disables the fusions that make
-        intermediate tensors disappear; pass False for the production program."""
-        return cls(lower(specs, state_dict, batch, in_h, in_w, strides, fuse_post=not keep_layers), device)
+        intermediate tensors disappear; pass False for the production program.
+
+        ``fp8_calib`` (a representative input batch) selects the e4m3 mode of BASELINE.json config 5: the bf16 program
+        runs once on it, every dense 3x3 conv's input range is measured (``calibrate_fp8``), and the program is
+        lowered again with those convs on the fp8 matrix pipe (``lower.apply_fp8``)."""
+        prog = lower(specs, state_dict, batch, in_h, in_w, strides, fuse_post=not keep_layers)
+        if fp8_calib is None:
+            return cls(prog, device)
+        e16 = cls(prog, device)
+        scales = e16.calibrate_fp8(fp8_calib, fp8_headroom)
+        del e16
+        torch.cuda.empty_cache()
+        return cls(lower(specs, state_dict, batch, in_h, in_w, strides, fuse_post=not keep_layers, fp8_scales=scales), device)
+
+    def calibrate_fp8(self, im: torch.Tensor, headroom: float = 2.0) -> Dict[str, float]:
+        """{conv name: input scale} for every conv the fp8 pass may take: absmax of the conv's input after a forward of
+        this (bf16) program on ``im``, times ``headroom``, mapped onto e4m3's largest finite value 448.  Buffers are
+        never recycled, so every tensor is still in the workspace afterwards; a buffer that is updated in place (the
+        Bottleneck residual stream) is measured in its final, largest state."""
+        from .lower import fp8_candidate
+
+        self.forward(im, decode=False)
+        torch.cuda.synchronize(self.device)
+        scales: Dict[str, float] = {}
+        for o in self.prog.ops:
+            if fp8_candidate(o):
+                v = o["inp"]
+                m = float(self._planes(v)[:, :, : v.H, : v.W].abs().amax().float().item())
+                scales[o["name"]] = max(m, 1e-6) * headroom / 448.0
+        return scales
 
     def __del__(self):
         h = getattr(self, "_h", None)

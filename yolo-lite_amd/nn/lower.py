@@ -334,6 +334,80 @@ def fuse_c3k2_small(ops: List[dict]) -> List[dict]:
     return out
 
 
+def fp8_candidate(o: dict, min_cin: int = 32) -> bool:
+    """A conv the fp8 pass may take: a plain dense 3x3 (stride 1 or 2) on bf16 planes whose channel counts fit the
+    e4m3 kernel's tiles (csrc/conv_f8.hip).  1x1 convs stay bf16: they sit at or below the ridge, and reading 1 byte
+    instead of 2 does not pay for the extra pass that makes the 1-byte copy."""
+    x, y = o.get("inp"), o.get("out")
+    return (o["kind"] == OP_CONV and o.get("k") == 3 and "post_weight" not in o and o.get("inp2") is None
+            and "stem_weight" not in o and not o.get("cin_weight", 0) and x.dtype == BF16 and y.dtype == BF16
+            and x.C % 16 == 0 and x.C >= min_cin and (y.C % 32 == 0 or y.C % 48 == 0))
+
+
+def apply_fp8(ops: List[dict], ar: "_Arena", scales: Dict[str, float]) -> List[dict]:
+    """BASELINE.json config 5 ("e4m3 weights + activations, fp32 accumulate"): every candidate conv named in ``scales``
+    (its calibrated input scale = absmax x headroom / 448, see ``HipEngine.calibrate_fp8``) runs on the fp8 matrix
+    pipe.  Its input is the e4m3 copy of the bf16 tensor -- made once per tensor version by a YL_OP_QUANT op and shared
+    by every fp8 reader -- or comes straight from the producing fp8 conv when all readers of that tensor are fp8 convs
+    (the first 3x3 of a Bottleneck -> the second): then the bf16 tensor is never written.  Outputs that anything else
+    reads, and residuals, stay bf16, so the rest of the program is untouched."""
+
+    def planes(v: Optional[TView]):
+        if v is None or v.dtype != BF16:
+            return set()
+        return {(v.offset, p) for p in range(v.coff // 8, (v.coff + v.C) // 8)}
+
+    def key(v: TView):
+        return (v.offset, v.coff, v.C, v.H, v.W)
+
+    def reads(o: dict):
+        r = set()
+        for k in ("inp", "res", "inp2"):
+            r |= planes(o.get(k))
+        if o.get("accumulate") or o["kind"] in (OP_SPPF_POOL,):
+            r |= planes(o["out"])
+        return r
+
+    def cand(o: dict) -> bool:
+        return fp8_candidate(o) and o.get("name") in scales
+
+    out: List[dict] = []
+    live: Dict[tuple, Tuple[TView, float]] = {}
+    for i, o in enumerate(ops):
+        wrote = planes(o.get("out"))
+        if cand(o):
+            x = o["inp"]
+            if key(x) not in live:
+                q = ar.alloc(x.H, x.W, x.C, FP8)
+                out.append(dict(kind=OP_QUANT, name=o["name"] + ".q8", inp=x, out=q, res=None,
+                                out_scale=float(scales[o["name"]]), lane=o.get("lane", 0)))
+                live[key(x)] = (q, float(scales[o["name"]]))
+            q, s_in = live[key(x)]
+            o = dict(o, inp=q, in_scale=s_in)
+            # all readers of this conv's output (until something overwrites it) are fp8 convs -> write e4m3 directly
+            y = o["out"]
+            rd, direct = [], True
+            for r in ops[i + 1:]:
+                if reads(r) & wrote:
+                    rd.append(r)
+                    if not (cand(r) and key(r["inp"]) == key(y) and not (planes(r.get("res")) & wrote)
+                            and r.get("lane", 0) == o.get("lane", 0)):
+                        direct = False
+                if planes(r.get("out")) & wrote:
+                    break
+            if direct and rd:
+                y8 = ar.alloc(y.H, y.W, y.C, FP8)
+                s_out = float(scales[rd[0]["name"]])
+                o["out"], o["out_scale"] = y8, s_out
+                out.append(o)
+                live[key(y)] = (y8, s_out)
+                continue
+        out.append(o)
+        for k in [k for k in live if {(k[0], p) for p in range(k[1] // 8, (k[1] + k[2]) // 8)} & wrote]:
+            del live[k]
+    return out
+
+
 def fold_conv_bn(sd: Dict[str, torch.Tensor], name: str, bn: bool = True) -> Tuple[np.ndarray, np.ndarray]:
     """BN-folded fp32 (weight OIHW, bias) of the Conv unit ``name`` (torch_utils.py:182-209).  A unit that already
     carries ``conv.bias`` and no BN tensors (``nn/export.py``'s folded form) is returned as stored."""
@@ -360,7 +434,7 @@ def _out_hw(h: int, w: int, k: int, s: int) -> Tuple[int, int]:
 
 def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, in_h: int, in_w: int,
           strides: Sequence[float] = (8.0, 16.0, 32.0), side_lanes: bool = True, fuse_post: bool = True,
-          fused_stem: bool = True) -> Program:
+          fused_stem: bool = True, fp8_scales: Optional[Dict[str, float]] = None) -> Program:
     det = specs[-1]
     assert det.kind == "Detect"
     prog = Program(batch, in_h, in_w, det.nc, strides=tuple(float(s) for s in strides))
@@ -614,6 +688,8 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
         ops[:] = fuse_stem_into_conv(ops, in_w)
     if fuse_post and os.environ.get("YL_FUSE_C3K2", "1") != "0":
         ops[:] = fuse_c3k2_small(ops)
+    if fp8_scales:
+        ops[:] = apply_fp8(ops, ar, fp8_scales)
     a_total = 0
     for lvl in range(len(det.f)):
         prog.levels.append(level_rec[lvl])
