@@ -117,3 +117,34 @@ def test_fp8_network_close_to_bf16(gpu_device, scale, h, w):
     for o in e8.prog.ops:
         if o["out"].dtype == FP8:
             assert e8.guards_are_zero(o["out"])
+
+
+FP8_SCORE_ATOL = 0.12  # stated tolerance of the e4m3 mode: 1.5 x the bf16 band (measured max |dscore| below)
+
+
+def test_fp8_end_to_end_640_vs_reference_golden(gpu_device, golden):
+    """Post-NMS detections of the e4m3 program at 640x640 against the REFERENCE's fp32 detections (golden_v1.npz):
+    same gate as the bf16 path (one-to-one IoU >= 0.9, matched classes bit-exact, nothing unexplained) with the score
+    band widened to the stated fp8 tolerance."""
+    from test_gpu_net import match_detections
+    from yololite_amd.nn import arch
+    from yololite_amd.nn.engine import HipEngine
+    from yololite_amd.nn.synth import synth_state_dict
+    from yololite_amd.utils import ops as hops
+
+    sd = synth_state_dict("n", 0, cls_bias=list(golden["net_n_640_bias"]), cls_gain=8.0)
+    x = torch.rand(1, 3, 640, 640, generator=torch.Generator().manual_seed(300)).to(gpu_device)
+    specs, _ = arch.parse_model(arch.yolo11_dict("n"))
+    eng = HipEngine.from_model(specs, sd, 1, 640, 640, gpu_device, fp8_calib=x)
+    assert sum("_f8_" in eng.op_kernel(i) for i in range(len(eng.prog.ops))) >= 15
+    y = eng.forward(x)
+    dscore = float((y[:, 4:, ::37].cpu() - torch.from_numpy(golden["net_n_640_ysub"][:, 4:])).abs().max())
+    print("fp8 e2e 640: max |dscore| on the golden subsample", dscore)
+    assert dscore <= FP8_SCORE_ATOL
+    det = hops.non_max_suppression(y, 0.25, 0.7)[0].cpu()
+    ref = torch.from_numpy(golden["net_n_640_det0"])
+    stats = match_detections(det, ref, conf_thres=0.25, iou_thres=0.7, band=FP8_SCORE_ATOL)
+    print("fp8 e2e 640 match:", stats)
+    assert stats["class_mismatch"] == 0, "class indices of matched boxes must be bit-exact"
+    assert stats["ref_unexplained"] == 0 and stats["det_unexplained"] == 0, stats
+    assert stats["matched"] >= 0.5 * stats["ref_mandatory"]
