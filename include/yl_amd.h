@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define YL_ABI_VERSION 10
+#define YL_ABI_VERSION 11
 
 /* element types */
 enum { YL_BF16 = 0, YL_F32 = 1, YL_F16 = 2, YL_U8 = 3, YL_FP8 = 4 /* OCP e4m3 */ };
@@ -124,7 +124,14 @@ typedef struct yl_op {
      e4m3(x / in_scale); out may be bf16 planes or, with out.dtype == YL_FP8, e4m3(y / out_scale); res (bf16, or fp8
      with res_scale) is added after the activation as in the bf16 conv.  YL_OP_QUANT uses out_scale. */
   float in_scale, out_scale, res_scale;
-  int32_t reserved3;
+  int32_t out8_c0;
+  /* YL_OP_CONV (plain, bf16 or fp8 input, bf16 output) and YL_OP_STEM: out8.offset >= 0 makes the epilogue ALSO store
+     e4m3(y / out8_scale) of output channels [out8_c0, out8_c0 + out8.C) into the fp8 view out8 (same H, W) -- the copy an
+     fp8 conv reads -- so no YL_OP_QUANT pass over the tensor is needed.  out8_c0 % 8 == 0, out8.C % 16 == 0.
+     YL_OP_STEM with out8_only != 0 stores nothing but that copy (every reader of the stem's output is an fp8 conv). */
+  yl_view out8;
+  float out8_scale;
+  int32_t out8_only;
   /* YL_OP_DWCONV3 with post_weight (depthwise 3x3 -> pointwise 1x1 in one launch) AND stem_weight: a further 1x1
      conv behind the pointwise one (the nn.Conv2d(c3, nc, 1) that ends Detect's class branch, head.py:47), also in
      that launch: reserved2 = output channels of the pointwise conv (post_weight [reserved2][in.C]), stem_weight

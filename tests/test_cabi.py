@@ -21,7 +21,7 @@ def test_header_symbols_exported():
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/yl_amd.h but not exported"
     assert set(names) == set(_lib.EXPORTS), "python binding list and header drifted apart"
-    assert L.yl_abi_version() == 10
+    assert L.yl_abi_version() == 11
 
 
 def test_struct_layouts_match_header():
@@ -30,7 +30,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.View) == 32       # int64 + 6 x int32
     assert ctypes.sizeof(_lib.Level) == 32
     # yl_op: 13 x int32/float (52) + pad to 8 (56) + 3 views (96) + 2 pointers (16)
-    assert ctypes.sizeof(_lib.Op) == 56 + 96 + 16 + 8 + 16 + 32 + 8 + 16 + 8 + 16  # + post_*, in2, up, reserved, stem_*, fp8 scales
+    assert ctypes.sizeof(_lib.Op) == 56 + 96 + 16 + 8 + 16 + 32 + 8 + 16 + 8 + 16 + 40  # + post_*, in2, up, reserved, stem_*, fp8 scales, out8
 
 
 def test_no_gpu_calls_fail_loudly():

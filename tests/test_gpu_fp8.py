@@ -90,8 +90,8 @@ def test_quantize_op(gpu_device):
     assert torch.equal(m.read(q), e4m3_round(x * (torch.tensor(1.0) / torch.tensor(0.11))))
 
 
-@pytest.mark.parametrize("scale,h,w", [("n", 96, 128), ("s", 64, 64), ("x", 64, 96)])
-def test_fp8_network_close_to_bf16(gpu_device, scale, h, w):
+@pytest.mark.parametrize("scale,h,w,dual", [("n", 96, 128, "1"), ("n", 96, 128, "0"), ("s", 64, 64, "1"), ("x", 64, 96, "1")])
+def test_fp8_network_close_to_bf16(gpu_device, monkeypatch, scale, h, w, dual):
     """Whole network with the dense 3x3 convs in e4m3 (activation scales calibrated on the input itself) against the
     bf16 program of the same weights: level maps within the stated relative L2 error, graph replay bit-identical to
     eager, guards untouched."""
@@ -105,9 +105,12 @@ def test_fp8_network_close_to_bf16(gpu_device, scale, h, w):
     e16 = HipEngine.from_model(specs, sd, 2, h, w, gpu_device)
     e16.forward(x)
     l16 = [t.clone() for t in e16.raw_levels()]
+    monkeypatch.setenv("YL_FP8_DUAL", dual)  # 0: separate quantize passes instead of e4m3 copies from the producers' epilogues
     e8 = HipEngine.from_model(specs, sd, 2, h, w, gpu_device, fp8_calib=x)
     kernels = [e8.op_kernel(i) for i in range(len(e8.prog.ops))]
-    assert sum("_f8_" in k for k in kernels) >= 15 and "quantize_f8" in kernels
+    assert sum("_f8_" in k for k in kernels) >= 15
+    assert ("quantize_f8" in kernels) == (dual == "0" or scale != "x")
+    assert any("out8" in o for o in e8.prog.ops) == (dual == "1")
     y8 = e8.forward(x).clone()
     l8 = [t.clone() for t in e8.raw_levels()]
     errs = [float((a - b).norm() / b.norm()) for a, b in zip(l8, l16)]
@@ -148,3 +151,49 @@ def test_fp8_end_to_end_640_vs_reference_golden(gpu_device, golden):
     assert stats["class_mismatch"] == 0, "class indices of matched boxes must be bit-exact"
     assert stats["ref_unexplained"] == 0 and stats["det_unexplained"] == 0, stats
     assert stats["matched"] >= 0.5 * stats["ref_mandatory"]
+
+
+@pytest.mark.parametrize("producer", ["bf16", "fp8"])
+def test_out8_copy_from_the_producers_epilogue(gpu_device, producer):
+    """yl_op.out8: a conv's epilogue also stores e4m3(y / out8_scale) of a channel range of its bf16 output -- the copy an
+    fp8 conv downstream reads, instead of a quantize pass over the tensor.  Compared with quantising the stored bf16
+    tensor (identical except where the bf16 rounding moved a value across an e4m3 rounding boundary)."""
+    from hip_util import OP_CONV
+
+    B, Cin, Cout, H, W, c0, n8, sc8 = 2, 64, 96, 12, 20, 32, 48, 0.03
+    g = torch.Generator().manual_seed(9)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.3
+    res = bf16_round(torch.randn(B, Cout, H, W, generator=g))
+    m = Mini(B, gpu_device)
+    if producer == "bf16":
+        x = bf16_round(torch.randn(B, Cin, H, W, generator=g))
+        xin = m.buf(H, W, Cin, BF16)
+    else:
+        x = e4m3_round(torch.randn(B, Cin, H, W, generator=g) * 30)
+        xin = m.buf(H, W, Cin, FP8)
+    m.fill(xin, x)
+    y = m.buf(H, W, Cout, BF16)
+    y8 = m.buf(H, W, n8, FP8)
+    r = m.buf(H, W, Cout, BF16)
+    m.fill(r, res)
+    m.op(kind=OP_CONV, name="p", k=3, stride=1, act=1, inp=xin, out=y, res=r, in_scale=0.05, out8=y8, out8_c0=c0, out8_scale=sc8,
+         weight=np.ascontiguousarray(w.numpy()), bias=np.ascontiguousarray(b.numpy()))
+    m.run()
+    assert m.eng.op_kernel(0) == ("conv3x3_mfma" if producer == "bf16" else "conv3x3_f8_mfma")
+    yb, q = m.read(y), m.read(y8)
+    want = e4m3_round(yb[:, c0: c0 + n8] * (torch.tensor(1.0) / torch.tensor(sc8)))
+    assert (q == want).float().mean().item() > 0.97
+    mag = torch.maximum(q.abs(), want.abs()).clamp_min(2.0 ** -6)
+    assert bool(((q - want).abs() <= torch.exp2(torch.floor(torch.log2(mag)) - 3)).all())
+    # and the bf16 output is what it is without the copy
+    m2 = Mini(B, gpu_device)
+    xin2 = m2.buf(H, W, Cin, xin.dtype)
+    m2.fill(xin2, x)
+    y2 = m2.buf(H, W, Cout, BF16)
+    r2 = m2.buf(H, W, Cout, BF16)
+    m2.fill(r2, res)
+    m2.op(kind=OP_CONV, name="p", k=3, stride=1, act=1, inp=xin2, out=y2, res=r2, in_scale=0.05,
+          weight=np.ascontiguousarray(w.numpy()), bias=np.ascontiguousarray(b.numpy()))
+    m2.run()
+    assert torch.equal(m2.read(y2), yb)

@@ -136,6 +136,13 @@ def test_fp8_pass_structure(scale):
         if o["out"].dtype == FP8:
             assert o["kind"] in (OP_QUANT, OP_CONV) and o["out_scale"] > 0
             written[(o["out"].offset, o["out"].coff, o["out"].C)] = o["out_scale"]
+        if "out8" in o:  # the producer's epilogue stores the e4m3 copy of a channel range of its bf16 output
+            v = o["out8"]
+            assert v.dtype == FP8 and o["out"].dtype != FP8 and o["out8_c0"] % 8 == 0 and o["out8_c0"] + v.C <= o["out"].C
+            assert (v.H, v.W) == (o["out"].H, o["out"].W) and o["out8_scale"] > 0
+            written[(v.offset, v.coff, v.C)] = o["out8_scale"]
+    if scale == "x":  # every e4m3 copy comes out of a producer's epilogue: no quantize pass left, the stem stores fp8 only
+        assert not any(o["kind"] == OP_QUANT for o in p8.ops) and p8.ops[0].get("out8_only") == 1
     assert n8 == len(cands) and n8 >= (19 if scale == "n" else 70)
     # the first 3x3 of a Bottleneck hands e4m3 straight to the second one: no bf16 copy of that tensor, no quantize op
     direct = [o for o in p8.ops if o["kind"] == OP_CONV and o["out"].dtype == FP8]

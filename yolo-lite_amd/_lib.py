@@ -50,7 +50,8 @@ class Op(C.Structure):
                 ("inp2", View), ("up", C.c_int32), ("reserved", C.c_int32),
                 ("stem_weight", C.c_void_p), ("stem_bias", C.c_void_p),
                 ("stem_act", C.c_int32), ("reserved2", C.c_int32),
-                ("in_scale", C.c_float), ("out_scale", C.c_float), ("res_scale", C.c_float), ("reserved3", C.c_int32)]
+                ("in_scale", C.c_float), ("out_scale", C.c_float), ("res_scale", C.c_float), ("out8_c0", C.c_int32),
+                ("out8", View), ("out8_scale", C.c_float), ("out8_only", C.c_int32)]
 
 
 class Level(C.Structure):
@@ -131,7 +132,7 @@ def lib() -> C.CDLL:
     L.yl_preprocess_u8.argtypes = [vp, i32, i32, i32, vp, vp]
     L.yl_letterbox_u8.restype = i32
     L.yl_letterbox_u8.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]
-    if L.yl_abi_version() != 10:
+    if L.yl_abi_version() != 11:
         raise RuntimeError("libyl_amd.so ABI version mismatch; rebuild it")
     _lib = L
     return L

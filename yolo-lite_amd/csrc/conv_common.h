@@ -155,6 +155,18 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
   return __builtin_bit_cast(unsigned, t);
 }
 
+// four floats -> four OCP e4m3 bytes, saturating (v_cvt_pk_fp8_f32 rounds to nearest even)
+__device__ __forceinline__ unsigned pack_f8x4(float a, float b, float c, float d) {
+  constexpr float M = 448.0f;  // largest finite e4m3
+  a = __builtin_fminf(__builtin_fmaxf(a, -M), M);
+  b = __builtin_fminf(__builtin_fmaxf(b, -M), M);
+  c = __builtin_fminf(__builtin_fmaxf(c, -M), M);
+  d = __builtin_fminf(__builtin_fmaxf(d, -M), M);
+  int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
+  return (unsigned)r;
+}
+
 // fp32 NHWC store of W consecutive channels starting at `co` (Detect level maps, head.py:64-65).
 template <int W>
 __device__ __forceinline__ void store_f32(const ConvArgs& a, __amdgpu_buffer_rsrc_t rout, bool ok, int pix, int co,
@@ -216,6 +228,16 @@ __device__ __forceinline__ void epilogue(const ConvArgs& a, __amdgpu_buffer_rsrc
       __builtin_amdgcn_raw_buffer_store_b128(
           u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])},
           rout, vo, 0, 0);
+      if (a.out8) {  // e4m3 copy for an fp8 conv downstream (conv_f8.hip): this lane's 8 channels = half a 16-byte pixel
+        const __amdgpu_buffer_rsrc_t r8 = __builtin_amdgcn_make_buffer_rsrc(a.out8, (short)0, a.out8_bytes, 0x00020000);
+        const int c = co - a.out8_c0;
+        const bool ok8 = ok && c >= 0 && c < a.out8_n;
+        const float is = a.out8_inv_scale;
+        const unsigned v8 = ok8 ? (unsigned)(c >> 4) * a.out8_plane + (unsigned)opix[nt] * 16u + (unsigned)(c & 15) : OOB_LANE;
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack_f8x4(v[0] * is, v[1] * is, v[2] * is, v[3] * is),
+                                                    pack_f8x4(v[4] * is, v[5] * is, v[6] * is, v[7] * is)},
+                                              r8, v8, 0, 0);
+      }
     }
   }
   if (MT & 1) {

@@ -31,16 +31,6 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 
 constexpr float F8_MAX = 448.0f;  // largest finite e4m3
 
-__device__ __forceinline__ unsigned pack_f8x4(float a, float b, float c, float d) {
-  a = __builtin_fminf(__builtin_fmaxf(a, -F8_MAX), F8_MAX);
-  b = __builtin_fminf(__builtin_fmaxf(b, -F8_MAX), F8_MAX);
-  c = __builtin_fminf(__builtin_fmaxf(c, -F8_MAX), F8_MAX);
-  d = __builtin_fminf(__builtin_fmaxf(d, -F8_MAX), F8_MAX);
-  int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
-  r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
-  return (unsigned)r;
-}
-
 // ---------------------------------------------------------------------------------------- bf16 planes -> fp8 planes
 // One thread = one pixel of one 16-channel plane (two bf16 planes in, 16 bytes out).  Runs over whole planes, guards
 // included: a guard is zero on both sides.
@@ -225,6 +215,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
         } else {
           const unsigned vo = ok ? (unsigned)(co >> 3) * a.out_plane + (unsigned)opix[nt] * 16u + (unsigned)(co & 7) * 2u : OOB_LANE;
           __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])}, rout, vo, 0, 0);
+          if (a.out8) {  // e4m3 copy of the bf16 result for the next fp8 conv
+            const __amdgpu_buffer_rsrc_t r8 = __builtin_amdgcn_make_buffer_rsrc(a.out8, (short)0, a.out8_bytes, 0x00020000);
+            const int c = co - a.out8_c0;
+            const bool ok8 = ok && c >= 0 && c < a.out8_n;
+            const float is = a.out8_inv_scale;
+            const unsigned v8 = ok8 ? (unsigned)(c >> 4) * a.out8_plane + (unsigned)opix[nt] * 16u + (unsigned)(c & 15) : OOB_LANE;
+            __builtin_amdgcn_raw_buffer_store_b32(pack_f8x4(v[0] * is, v[1] * is, v[2] * is, v[3] * is), r8, v8, 0, 0);
+          }
         }
       }
     }

@@ -112,6 +112,26 @@ static PView pview(char* ws, const yl_view& v, int batch) {
   return p;
 }
 
+// yl_op.out8: e4m3 copy of output channels [out8_c0, out8_c0 + out8.C) written by the producer's epilogue
+static int check_out8(const yl_op& o, int batch, int64_t ws_bytes, const std::string& tag) {
+  if (o.out8.offset < 0) return 0;
+  if (int rc = check_view(o.out8, batch, ws_bytes, (tag + " out8").c_str())) return rc;
+  if (o.out8.dtype != YL_FP8 || o.out8.H != o.out.H || o.out8.W != o.out.W || o.out8_c0 < 0 || (o.out8_c0 & 7) ||
+      o.out8_c0 + o.out8.C > o.out.C || !(o.out8_scale > 0.f) || o.out.dtype != YL_BF16)
+    return fail(-1, tag + ": out8 must be an fp8 view of the output's dims covering a channel range of a bf16 output");
+  return 0;
+}
+
+static void fill_out8(ConvArgs& a, const yl_op& o, char* ws, int B) {
+  if (o.out8.offset < 0) return;
+  a.out8 = ws + o.out8.offset + (int64_t)(o.out8.coff / 16) * plane_bytes(geo_of(B, o.out8.H, o.out8.W));
+  a.out8_plane = (unsigned)plane_bytes(geo_of(B, o.out8.H, o.out8.W));
+  a.out8_bytes = (unsigned)((int64_t)(o.out8.C / 16) * a.out8_plane);
+  a.out8_inv_scale = 1.0f / o.out8_scale;
+  a.out8_c0 = o.out8_c0;
+  a.out8_n = o.out8.C;
+}
+
 template <typename T>
 static int dev_upload(yl_engine* e, const std::vector<T>& h, T** d) {
   void* p = nullptr;
@@ -200,6 +220,7 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
                 (o.res.dtype == YL_FP8 && !(o.res_scale > 0.f)))
               return fail(-1, tag + ": residual view mismatch");
           }
+          if (int rc = check_out8(o, batch, workspace_bytes, tag)) return rc;
           if (int rc = conv_f8_choose(batch, o.in.C, o.out.C, o.k, o.stride, Ho, Wo, &r.cfg)) return rc;
           std::vector<uint8_t> pk;
           std::vector<float> ws_;
@@ -241,6 +262,12 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
         if (post && (!o.post_bias || o.res.offset >= 0 || o.out.C > o.post_cin))
           return fail(-1, tag + ": fused follow-up conv needs a bias, no residual and out.C <= post_cin");
         if (int rc = conv_choose(batch, cin_total, cout1, o.k, o.stride, Ho, Wo, post, &r.cfg)) return rc;
+        if (o.out8.offset >= 0) {
+          if (int rc = check_out8(o, batch, workspace_bytes, tag)) return rc;
+          if (post || o.stem_weight || (r.cfg.MT & 1))
+            return fail(-1, tag + ": out8 needs a plain conv with an even number of channel tiles per wave");
+          r.cfg.tile = 0;  // the e4m3 copy is written by conv_kernel's epilogue
+        }
         std::vector<uint16_t> pk;
         conv_pack_weights(o.weight, cout1, cin_w, o.k, r.cfg, &pk);
         if (post) {
@@ -433,6 +460,9 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
         if (o.out.H != (in_h + 2 - 3) / 2 + 1 || o.out.W != (in_w + 2 - 3) / 2 + 1 || o.out.dtype != YL_BF16)
           return fail(-1, tag + ": stem output dims mismatch");
         if (o.out.C % 16) return fail(-1, tag + ": stem needs Cout % 16 == 0");
+        if (int rc = check_out8(o, batch, workspace_bytes, tag)) return rc;
+        if (o.out8.offset >= 0 && (o.out8_c0 != 0 || o.out8.C != o.out.C)) return fail(-1, tag + ": the stem's out8 covers all channels");
+        if (o.out8_only && o.out8.offset < 0) return fail(-1, tag + ": out8_only without out8");
         std::vector<float> wt((size_t)o.out.C * 27);
         for (size_t q = 0; q < wt.size(); ++q) {  // round to bf16 like every other conv filter
           uint32_t u;
@@ -547,6 +577,7 @@ static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s, c
         a.Cout = o.out.C;
         a.stride = o.stride;
         a.act = o.act;
+        fill_out8(a, o, ws, B);
         return conv_f8_launch(r.cfg, a, B, s);
       }
       a.in = pview(ws, o.in, B).base;
@@ -591,6 +622,7 @@ static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s, c
       a.Cout = r.d_wpk2 ? o.post_cin : o.out.C;
       a.stride = o.stride;
       a.act = o.act;
+      fill_out8(a, o, ws, B);
       return conv_launch(r.cfg, a, B, s);
     }
     case YL_OP_QUANT: {
@@ -653,6 +685,13 @@ static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s, c
       a.Wo = o.out.W;
       a.Cout = o.out.C;
       a.act = o.act;
+      if (o.out8.offset >= 0) {
+        const Geo g8 = geo_of(B, o.out8.H, o.out8.W);
+        a.out8 = reinterpret_cast<unsigned char*>(ws + o.out8.offset + (int64_t)(o.out8.coff / 16) * plane_bytes(g8));
+        a.out8_plane = plane_bytes(g8);
+        a.out8_inv_scale = 1.0f / o.out8_scale;
+        a.out8_only = o.out8_only;
+      }
       return stem_launch(a, in_dtype, s);
     }
     case YL_OP_DWCONV3: {

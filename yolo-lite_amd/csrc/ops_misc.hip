@@ -2,7 +2,7 @@
 // input conversion, fused stem, depthwise 3x3, SPPF max-pool chain, nearest upsample / slice copy,
 // C2PSA attention, and the Detect decode.  Every thread moves 16-byte pixels (8 x bf16 of one plane)
 // and neighbouring lanes touch neighbouring pixels of the same plane.
-#include "yl_internal.h"
+#include "conv_common.h"
 
 namespace yl {
 
@@ -199,7 +199,12 @@ __global__ __launch_bounds__(64 * STEM_MAXW) void stem_kernel(StemArgs a, const 
         bf16x4 o;
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = (__bf16)(a.act ? silu_g(acc[r]) : acc[r]);
-        *reinterpret_cast<bf16x4*>(op0 + 128 * g) = o;
+        if (!a.out8_only) *reinterpret_cast<bf16x4*>(op0 + 128 * g) = o;
+        if (a.out8) {  // e4m3 copy (of the bf16-rounded values, as a quantize pass over the stored tensor would see them)
+          const float is = a.out8_inv_scale;
+          *reinterpret_cast<unsigned*>(a.out8 + (long long)(ch >> 4) * a.out8_plane + (long long)(pix0 + 16 * g) * 16 + (ch & 15)) =
+              pack_f8x4((float)o[0] * is, (float)o[1] * is, (float)o[2] * is, (float)o[3] * is);
+        }
       }
     }
   }

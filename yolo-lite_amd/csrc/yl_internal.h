@@ -101,6 +101,11 @@ struct ConvArgs {
   float out_inv_scale;         // fp8 output: 1 / s_out
   float res_scale;             // fp8 residual: its scale
   int out_f8, res_f8;          // output / residual are fp8 planes (else bf16 planes)
+  // second, e4m3 copy of output channels [out8_c0, out8_c0 + out8_n) (conv_kernel without follow-up conv, conv_f8_kernel)
+  void* out8;
+  unsigned out8_plane, out8_bytes;
+  float out8_inv_scale;
+  int out8_c0, out8_n;
 };
 
 struct ConvConfig {
@@ -174,6 +179,10 @@ struct StemArgs {
   const float* w;     // [Cout][27] (bf16-rounded values)
   const float* bias;
   int B, H, W, Ho, Wo, Cout, act, nseg;
+  unsigned char* out8;   // e4m3 copy of the output (planes of 16 channels, same pixel geometry), nullptr: none
+  long long out8_plane;  // bytes per plane
+  float out8_inv_scale;
+  int out8_only;         // store only the copy
 };
 int stem_launch(const StemArgs& a, int in_dtype, hipStream_t s);
 

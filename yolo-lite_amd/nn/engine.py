@@ -54,6 +54,8 @@ class HipEngine:
             c.inp, c.out, c.res = _cview(o["inp"]), _cview(o["out"]), _cview(o.get("res"))
             c.inp2, c.up = _cview(o.get("inp2")), int(o.get("up", 0))
             c.in_scale, c.out_scale, c.res_scale = (float(o.get(k, 0.0)) for k in ("in_scale", "out_scale", "res_scale"))
+            c.out8, c.out8_c0 = _cview(o.get("out8")), int(o.get("out8_c0", 0))
+            c.out8_scale, c.out8_only = float(o.get("out8_scale", 0.0)), int(o.get("out8_only", 0))
             if "weight" in o:
                 w = np.ascontiguousarray(o["weight"], dtype=np.float32)
                 b = np.ascontiguousarray(o["bias"], dtype=np.float32)

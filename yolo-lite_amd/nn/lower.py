@@ -373,15 +373,44 @@ def apply_fp8(ops: List[dict], ar: "_Arena", scales: Dict[str, float]) -> List[d
 
     out: List[dict] = []
     live: Dict[tuple, Tuple[TView, float]] = {}
+    dual = os.environ.get("YL_FP8_DUAL", "1") != "0"
+
+    def producer(x: TView, lane: int) -> Optional[dict]:
+        """The already emitted op that wrote the current contents of x, if its epilogue can also store the e4m3 copy
+        (yl_op.out8): the stem, a plain bf16 conv with an even number of channel tiles per wave, or an fp8 conv."""
+        px = planes(x)
+        for p in reversed(out):
+            po = planes(p.get("out"))
+            if not (po & px):
+                continue
+            if not px <= po or "out8" in p or p.get("lane", 0) != lane or (x.H, x.W) != (p["out"].H, p["out"].W):
+                return None
+            if p["kind"] == OP_STEM:
+                return p if key(x) == key(p["out"]) else None
+            if p["kind"] != OP_CONV or "post_weight" in p or "stem_weight" in p:
+                return None
+            c16 = (p["out"].C + 15) // 16
+            if p["inp"].dtype != FP8 and not (c16 % 4 == 0 or (c16 % 5 and c16 % 2 == 0)):
+                return None
+            return p
+        return None
+
     for i, o in enumerate(ops):
         wrote = planes(o.get("out"))
         if cand(o):
             x = o["inp"]
             if key(x) not in live:
                 q = ar.alloc(x.H, x.W, x.C, FP8)
-                out.append(dict(kind=OP_QUANT, name=o["name"] + ".q8", inp=x, out=q, res=None,
-                                out_scale=float(scales[o["name"]]), lane=o.get("lane", 0)))
-                live[key(x)] = (q, float(scales[o["name"]]))
+                sc = float(scales[o["name"]])
+                p = producer(x, o.get("lane", 0)) if dual else None
+                if p is not None:  # the producer's epilogue writes the e4m3 copy next to (or instead of) its bf16 output
+                    p.update(out8=q, out8_c0=x.coff - p["out"].coff, out8_scale=sc)
+                    if p["kind"] == OP_STEM and all(cand(r) and key(r["inp"]) == key(x) for r in ops if reads(r) & planes(p["out"])):
+                        p["out8_only"] = 1
+                else:
+                    out.append(dict(kind=OP_QUANT, name=o["name"] + ".q8", inp=x, out=q, res=None, out_scale=sc,
+                                    lane=o.get("lane", 0)))
+                live[key(x)] = (q, sc)
             q, s_in = live[key(x)]
             o = dict(o, inp=q, in_scale=s_in)
             # all readers of this conv's output (until something overwrites it) are fp8 convs -> write e4m3 directly
