@@ -302,7 +302,9 @@ def main():
             "metric": f"images/sec end-to-end (incl. NMS), YOLO11{args.scale} {H}x{W} batch={B}",
             "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16" if args.dtype == "bf16" else "fp8 e4m3 (dense 3x3 convs) + bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "bf16" if args.dtype == "bf16" else ("fp8 e4m3 (dense 3x3 and 1x1 convs, tensors mirrored in e4m3) + bf16"
+                                                          if os.environ.get("YL_FP8_MIRROR", "0") == "1" else "fp8 e4m3 (dense 3x3 convs) + bf16"),
+            "data": "synthetic",
             "config": {"workload": f"YOLO11{args.scale} {args.dtype}, {H}x{W} batch={B} per GPU (fused Conv+BN+SiLU + HIP NMS), "
                                    f"random-init weights, random uint8 NCHW images resident in HBM, conf {conf} iou {iou} max_det {max_det}; "
                                    f"{S} batches in flight on {S} HIP streams (one hipGraph launch per step)",

@@ -109,42 +109,53 @@ def test_concat_members_are_slices_of_one_buffer():
     assert not any(o.get("name", "").endswith(".copy") for o in p.ops)
 
 
-@pytest.mark.parametrize("scale", ["n", "x"])
-def test_fp8_pass_structure(scale):
-    """lower.apply_fp8: every fp8 conv reads an e4m3 view written earlier (by a quantize op or by an fp8 conv) with the
-    scale the reader assumes; nothing but fp8 convs reads an e4m3 view; algorithmic FLOPs are unchanged."""
+@pytest.mark.parametrize("scale,with_1x1", [("n", False), ("x", False), ("n", True), ("s", True), ("x", True)])
+def test_fp8_pass_structure(scale, with_1x1, monkeypatch):
+    """lower.apply_fp8_mirrors / apply_fp8: every fp8 conv reads e4m3 planes that were written earlier (by a quantize op,
+    by an fp8 conv, or by a producer's epilogue copy) with the scale the reader assumes; nothing but fp8 convs reads an
+    e4m3 view; algorithmic FLOPs are unchanged."""
     from yololite_amd.nn.lower import FP8, OP_QUANT, fp8_candidate
 
+    monkeypatch.setenv("YL_FP8_MIRROR", "1" if with_1x1 else "0")
     specs, _ = arch.parse_model(arch.yolo11_dict(scale))
     sd = synth_state_dict(scale, 0)
     p = lower(specs, sd, 2, 64, 96)
-    cands = [o for o in p.ops if fp8_candidate(o)]
+    cands = [o for o in p.ops if fp8_candidate(o, allow_1x1=with_1x1)]
     scales = {o["name"]: 0.01 * (1 + i) for i, o in enumerate(cands)}
     p8 = lower(specs, sd, 2, 64, 96, fp8_scales=scales)
     assert abs(_conv_gflop(p8) - _conv_gflop(p)) < 1e-9
     written = {}
+
+    def wrote(v, sc):
+        assert v.coff % 16 == 0 and v.C % 16 == 0 and sc > 0
+        for pl in range(v.coff // 16, (v.coff + v.C) // 16):
+            written[(v.offset, pl)] = sc
+
     n8 = 0
     for o in p8.ops:
         if o["kind"] == OP_CONV and o["inp"].dtype == FP8:
             n8 += 1
-            k = (o["inp"].offset, o["inp"].coff, o["inp"].C)
-            assert k in written and written[k] == o["in_scale"], o["name"]
+            v = o["inp"]
+            for pl in range(v.coff // 16, (v.coff + v.C) // 16):
+                assert written.get((v.offset, pl)) == o["in_scale"], (o["name"], pl)
             assert o["name"] in scales
         else:
             for key in ("inp", "res", "inp2"):
                 assert o.get(key) is None or o[key].dtype != FP8, o.get("name")
         if o["out"].dtype == FP8:
-            assert o["kind"] in (OP_QUANT, OP_CONV) and o["out_scale"] > 0
-            written[(o["out"].offset, o["out"].coff, o["out"].C)] = o["out_scale"]
+            assert o["kind"] in (OP_QUANT, OP_CONV)
+            wrote(o["out"], o["out_scale"])
         if "out8" in o:  # the producer's epilogue stores the e4m3 copy of a channel range of its bf16 output
             v = o["out8"]
             assert v.dtype == FP8 and o["out"].dtype != FP8 and o["out8_c0"] % 8 == 0 and o["out8_c0"] + v.C <= o["out"].C
-            assert (v.H, v.W) == (o["out"].H, o["out"].W) and o["out8_scale"] > 0
-            written[(v.offset, v.coff, v.C)] = o["out8_scale"]
-    if scale == "x":  # every e4m3 copy comes out of a producer's epilogue: no quantize pass left, the stem stores fp8 only
+            assert (v.H, v.W) == (o["out"].H, o["out"].W)
+            wrote(v, o["out8_scale"])
+    if scale == "x":  # every e4m3 tensor comes out of a producer's epilogue: no quantize pass left, the stem stores fp8 only
         assert not any(o["kind"] == OP_QUANT for o in p8.ops) and p8.ops[0].get("out8_only") == 1
-    assert n8 == len(cands) and n8 >= (19 if scale == "n" else 70)
-    # the first 3x3 of a Bottleneck hands e4m3 straight to the second one: no bf16 copy of that tensor, no quantize op
-    direct = [o for o in p8.ops if o["kind"] == OP_CONV and o["out"].dtype == FP8]
-    assert len(direct) >= (6 if scale == "n" else 30)
+    if with_1x1:
+        assert n8 >= {"n": 35, "s": 50, "x": 130}[scale]
+        assert sum(o["kind"] == OP_CONV and o["out"].dtype == FP8 for o in p8.ops) >= {"n": 15, "s": 25, "x": 80}[scale]
+    else:
+        assert n8 == len(cands) and n8 >= (19 if scale == "n" else 70)
+        assert sum(o["kind"] == OP_CONV and o["out"].dtype == FP8 for o in p8.ops) >= (6 if scale == "n" else 30)
     assert p8.ws_bytes > p.ws_bytes

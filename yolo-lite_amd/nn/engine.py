@@ -132,7 +132,7 @@ class HipEngine:
         torch.cuda.synchronize(self.device)
         scales: Dict[str, float] = {}
         for o in self.prog.ops:
-            if fp8_candidate(o):
+            if fp8_candidate(o, allow_1x1=True):
                 v = o["inp"]
                 m = float(self._planes(v)[:, :, : v.H, : v.W].abs().amax().float().item())
                 scales[o["name"]] = max(m, 1e-6) * headroom / 448.0
