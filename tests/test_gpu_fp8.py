@@ -202,3 +202,20 @@ def test_out8_copy_from_the_producers_epilogue(gpu_device, producer):
           weight=np.ascontiguousarray(w.numpy()), bias=np.ascontiguousarray(b.numpy()))
     m2.run()
     assert torch.equal(m2.read(y2), yb)
+
+
+def test_predict_api_in_fp8_mode(gpu_device, monkeypatch):
+    """YL_DTYPE=fp8: YOLOLite.predict builds the e4m3 engine, calibrated on the first batch, behind the unchanged API."""
+    from yololite_amd import YOLOLite
+
+    x = torch.rand(2, 3, 64, 96, generator=torch.Generator().manual_seed(2))
+    y16 = YOLOLite("yolo11n.yaml")
+    r16 = y16.predict(x, device=0, conf=0.001, verbose=False, save=False)
+    monkeypatch.setenv("YL_DTYPE", "fp8")
+    y8 = YOLOLite("yolo11n.yaml")
+    r8 = y8.predict(x, device=0, conf=0.001, verbose=False, save=False)
+    eng = next(iter(y8.predictor.model._engines.values()))
+    assert any("_f8_" in eng.op_kernel(i) for i in range(len(eng.prog.ops)))
+    assert len(r8) == len(r16) == 2
+    for a, b in zip(r8, r16):
+        assert abs(len(a.boxes) - len(b.boxes)) <= max(10, len(b.boxes) // 3)

@@ -140,7 +140,7 @@ class DetectionPredictor:
     def _detect_fused(self, im, orig_imgs):
         """inference + postprocess in one pass: the (B, 4+nc, A) tensor is never materialised."""
         b, _, h, w = im.shape
-        eng = self.model.engine_for(b, h, w)
+        eng = self.model.engine_for(b, h, w, calib=im.contiguous())
         shapes, imgs, scale = self._shapes_and_scale(im, orig_imgs, b, im.device)
         out, cnt = eng.detect(im.contiguous(), self.args.conf, self.args.iou, max_det=self.args.max_det,
                               classes=self.args.classes, agnostic=self.args.agnostic_nms, scale=scale, graph=False)

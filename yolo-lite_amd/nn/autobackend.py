@@ -5,6 +5,8 @@ buffer offsets, tilings and the captured graph are shape-specialised; the most r
 """
 from __future__ import annotations
 
+import os
+
 from collections import OrderedDict
 from pathlib import Path
 from typing import Optional
@@ -61,15 +63,21 @@ class AutoBackend:
     def eval(self):
         return self
 
-    def engine_for(self, b: int, h: int, w: int) -> HipEngine:
+    def engine_for(self, b: int, h: int, w: int, calib: "torch.Tensor | None" = None) -> HipEngine:
+        """The engine for this input shape (built on first use).  ``YL_DTYPE=fp8`` selects the e4m3 mode (dense 3x3 convs
+        on the fp8 matrix pipe); its activation scales are calibrated on ``calib``, the first batch
+        of that shape the predictor sees."""
         key = (b, h, w, self.model._version)
         eng = self._engines.get(key)
         if eng is None:
             if self.device.type != "cuda":
                 raise RuntimeError("the YOLO11 network runs on the GPU only (HIP kernels; no CPU fallback): "
                                    "pass device=0 / 'cuda:0'")
+            fp8 = os.environ.get("YL_DTYPE", "bf16").lower() == "fp8"
+            if fp8 and calib is None:
+                raise RuntimeError("YL_DTYPE=fp8 needs a calibration batch: call forward() / predict() with real inputs")
             eng = HipEngine.from_model(self.model.specs, self.model.state_dict(), b, h, w, self.device,
-                                       strides=self.model.stride.tolist())
+                                       strides=self.model.stride.tolist(), fp8_calib=calib if fp8 else None)
             self._engines[key] = eng
             while len(self._engines) > self.MAX_ENGINES:
                 self._engines.popitem(last=False)
@@ -88,7 +96,7 @@ class AutoBackend:
             im = im.float()
         im = im.contiguous()
         b, _, h, w = im.shape
-        eng = self.engine_for(b, h, w)
+        eng = self.engine_for(b, h, w, calib=im)
         y = eng.forward(im, graph=graph)
         return [y, eng.raw_levels()]
 
@@ -101,6 +109,8 @@ class AutoBackend:
 
     def warmup(self, imgsz=(1, 3, 640, 640)):
         """One dummy forward on GPU devices (reference autobackend.py:157-165, minus its `self.jit` bug)."""
+        if os.environ.get("YL_DTYPE", "bf16").lower() == "fp8":
+            return  # the e4m3 engine is calibrated on the first real batch, not on a dummy one
         if self.device.type != "cpu":
             im = torch.zeros(*imgsz, dtype=torch.float32, device=self.device)
             self.forward(im, graph=False)
