@@ -189,7 +189,7 @@ __device__ __forceinline__ void store_f32(const ConvArgs& a, __amdgpu_buffer_rsr
 }
 
 // Epilogue (the accumulators already contain the bias): SiLU, residual, 16-byte buffer stores.
-template <int MT, int NT>
+template <int MT, int NT, bool O8 = false>
 __device__ __forceinline__ void epilogue(const ConvArgs& a, __amdgpu_buffer_rsrc_t rout, __amdgpu_buffer_rsrc_t rres,
                                          int cb, int g, const int (&opix)[NT], f32x4 (&acc)[MT][NT]) {
   const int cbase = cb * MT * 16;
@@ -228,7 +228,7 @@ __device__ __forceinline__ void epilogue(const ConvArgs& a, __amdgpu_buffer_rsrc
       __builtin_amdgcn_raw_buffer_store_b128(
           u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])},
           rout, vo, 0, 0);
-      if (a.out8) {  // e4m3 copy for an fp8 conv downstream (conv_f8.hip): this lane's 8 channels = half a 16-byte pixel
+      if constexpr (O8) {  // e4m3 copy for an fp8 conv downstream (conv_f8.hip): this lane's 8 channels = half a 16-byte pixel
         const __amdgpu_buffer_rsrc_t r8 = __builtin_amdgcn_make_buffer_rsrc(a.out8, (short)0, a.out8_bytes, 0x00020000);
         const int c = co - a.out8_c0;
         const bool ok8 = ok && c >= 0 && c < a.out8_n;

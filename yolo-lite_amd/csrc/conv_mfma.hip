@@ -68,7 +68,9 @@ __device__ __forceinline__ void run_ksteps(const ConvArgs& a, __amdgpu_buffer_rs
 // consumes ONLY this conv's output is applied in the epilogue.  After bias + SiLU + bf16 rounding the
 // accumulators of tile pair p ARE the B fragment of k-step p of that 1x1 conv (same channel permutation
 // that makes the stores 16 bytes wide), so the intermediate tensor is never written or read.
-template <int KS, int MT, int NT, bool UNIFORM, bool POST, bool UP = false>
+// O8: the epilogue also stores the e4m3 copy of the output (yl_op.out8, fp8 mode only; a separate instantiation so that the bf16
+// programs run exactly the code they ran before the copy existed).
+template <int KS, int MT, int NT, bool UNIFORM, bool POST, bool UP = false, bool O8 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -187,7 +189,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
       a2.act = a.post_act;
       epilogue<MT, NT>(a2, rout, rres, cb, g, opix, acc);
     } else {
-      epilogue<MT, NT>(a, rout, rres, cb, g, opix, acc);
+      epilogue<MT, NT, O8>(a, rout, rres, cb, g, opix, acc);
     }
   }
 }
@@ -436,9 +438,13 @@ void conv_pack_weights(const float* w, int Cout, int Cin_w, int k, const ConvCon
         }
 }
 
-template <int KS, int MT, int NT, bool U, bool POST>
+template <int KS, int MT, int NT, bool U, bool POST, bool O8 = false>
 static int launch_p(const ConvConfig& cfg, const ConvArgs& a, hipStream_t s) {
-  auto kern = conv_kernel<KS, MT, NT, U, POST>;
+  if constexpr (!O8 && !POST && (MT == 2 || MT == 4)) {
+    if (a.out8) return launch_p<KS, MT, NT, U, POST, true>(cfg, a, s);
+  }
+  if (a.out8 && !O8) return fail(-3, "conv: an e4m3 copy of the output needs 2 or 4 channel tiles per wave and no fused follow-up conv");
+  auto kern = conv_kernel<KS, MT, NT, U, POST, false, O8>;
   static size_t attr = 0;  // per instantiation: largest dynamic LDS size enabled so far
   if (cfg.lds_bytes > attr) {
     YL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -450,9 +456,13 @@ static int launch_p(const ConvConfig& cfg, const ConvArgs& a, hipStream_t s) {
   return 0;
 }
 
-template <int MT, int NT>
+template <int MT, int NT, bool O8 = false>
 static int launch_up(const ConvConfig& cfg, const ConvArgs& a, hipStream_t s) {
-  auto kern = conv_kernel<1, MT, NT, true, false, true>;
+  if constexpr (!O8 && (MT == 2 || MT == 4)) {
+    if (a.out8) return launch_up<MT, NT, true>(cfg, a, s);
+  }
+  if (a.out8 && !O8) return fail(-3, "conv: an e4m3 copy of the output needs 2 or 4 channel tiles per wave");
+  auto kern = conv_kernel<1, MT, NT, true, false, true, O8>;
   static size_t attr = 0;
   if (cfg.lds_bytes > attr) {
     YL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
