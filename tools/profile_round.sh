@@ -10,7 +10,7 @@ OUT=$R/gpurun_out/$TAG
 rm -rf $OUT
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-python3 $R/bench.py --steps 50 --warmup 10 --profile-out $OUT/per_op.json > $OUT/bench.json 2> $OUT/bench.err
+python3 $R/bench.py --profile-out $OUT/per_op.json > $OUT/bench.json 2> $OUT/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $OUT/pmc_write.log 2>&1
