@@ -31,9 +31,12 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import torch  # noqa: E402
 
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_FP8_TFLOPS = 5000.0     # dense e4m3 MFMA peak (MI355X_MICROARCH.md); the sparse figure is never used
 PEAK_HBM_GBS = 8000.0       # HBM3E spec (same table)
-CONV_GFLOP_PER_IMG = 6.4811  # 2*MAC over all nn.Conv2d calls, n @ 640
-ACT_MB_PER_IMG = 81.7        # activation elements in+out, bf16
+# SURVEY.md section 8(d), per image at 640x640 (both scale with the image area): conv GFLOP = 2 * MAC over all nn.Conv2d
+# calls; activation elements in + out of every layer (M), stored as bf16
+CONV_GFLOP_AT_640 = {"n": 6.4811, "s": 21.4669, "x": 194.9038}
+ACT_MELEM_AT_640 = {"n": 40.83, "s": 74.89, "x": 312.05}
 
 
 def build_model(scale, device, batch, h, w, x_calib, target_frac=0.015, fp8=False):
@@ -155,11 +158,12 @@ def roofline_from_profile(rows, batch):
     name, a = dom
     tf = a["flops"] / (a["ms"] * 1e-3) / 1e12 if a["ms"] > 0 else 0.0
     gbs = a["bytes"] / (a["ms"] * 1e-3) / 1e9 if a["ms"] > 0 else 0.0
-    mfma_frac, hbm_frac = tf / PEAK_BF16_TFLOPS, gbs / PEAK_HBM_GBS
+    peak_tf = PEAK_FP8_TFLOPS if "_f8_" in name else PEAK_BF16_TFLOPS  # e4m3 kernels are priced against the fp8 peak
+    mfma_frac, hbm_frac = tf / peak_tf, gbs / PEAK_HBM_GBS
     bound = "mfma" if mfma_frac >= hbm_frac else "hbm"
     roof = {"kernel": name, "bound": bound,
             "achieved": round(tf if bound == "mfma" else gbs, 2),
-            "peak": PEAK_BF16_TFLOPS if bound == "mfma" else PEAK_HBM_GBS,
+            "peak": peak_tf if bound == "mfma" else PEAK_HBM_GBS,
             "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
             "frac": round(max(mfma_frac, hbm_frac), 4), "traffic": None,
             "launches_per_step": a["launches"], "avg_launch_us": round(a["ms"] * 1e3 / a["launches"], 2),
@@ -173,7 +177,7 @@ def roofline_from_profile(rows, batch):
     best = None
     for r in rows:
         if r["kernel"].startswith("conv3x3") and r["ms"] > 0:
-            f = r["flops"] / (r["ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS
+            f = r["flops"] / (r["ms"] * 1e-3) / 1e12 / (PEAK_FP8_TFLOPS if "_f8_" in r["kernel"] else PEAK_BF16_TFLOPS)
             if best is None or f > best[1]:
                 best = (r["name"], f, r["ms"])
     if best:
@@ -313,8 +317,11 @@ def main():
                        "global_batch": world * B, "parallelism": f"dp{world}" if world > 1 else "single",
                        "streams": S, "candidate_fraction_target": args.cand_frac,
                        "mean_detections_per_image": None if ndet is None else round(ndet, 1)},
-            "e2e_mfma_frac": round(value * CONV_GFLOP_PER_IMG / 1e3 / PEAK_BF16_TFLOPS / world, 5),
-            "e2e_hbm_frac": round(value * ACT_MB_PER_IMG / 1e3 / PEAK_HBM_GBS / world, 5),
+            # end-to-end fractions of the bf16 MFMA peak and of the HBM peak (algorithmic work per image)
+            "e2e_mfma_frac": (round(value * CONV_GFLOP_AT_640[args.scale] * (H * W) / (640 * 640) / 1e3 / PEAK_BF16_TFLOPS / world, 5)
+                              if args.scale in CONV_GFLOP_AT_640 else None),
+            "e2e_hbm_frac": (round(value * ACT_MELEM_AT_640[args.scale] * 2 * (H * W) / (640 * 640) / 1e3 / PEAK_HBM_GBS / world, 5)
+                             if args.scale in ACT_MELEM_AT_640 else None),
         }
         if world == 1:
             res["latency_ms_single_stream"] = round(latency_ms, 4)
