@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Development micro-benchmark: one conv layer at batch 32, cold-ish (rotating buffers), with ablations.
-Usage: YL_CONV_DBG=<flags> python tools/conv_micro.py cin cout k s H W"""
+Usage: YL_CONV_DBG=<flags> python tools/conv_micro.py cin cout k s H W [fp8]   (fp8: e4m3 input, conv_f8_kernel)"""
 import os
 import sys
 from pathlib import Path
@@ -10,9 +10,10 @@ import numpy as np
 import torch
 
 from yololite_amd.nn.engine import HipEngine
-from yololite_amd.nn.lower import OP_CONV, Program, _Arena
+from yololite_amd.nn.lower import BF16, FP8, OP_CONV, Program, _Arena
 
 cin, cout, k, s, H, W = map(int, sys.argv[1:7])
+f8 = len(sys.argv) > 7 and sys.argv[7] == "fp8"
 B = 32
 dev = torch.device("cuda:0")
 ar = _Arena(B)
@@ -24,12 +25,12 @@ NREP = 6  # rotate through distinct buffers so inputs come from HBM / MALL, not 
 w = (np.random.randn(cout, cin, k, k) / np.sqrt(cin * k * k)).astype(np.float32)
 b = np.zeros(cout, np.float32)
 for r in range(NREP):
-    x, y = ar.alloc(H, W, cin), ar.alloc(Ho, Wo, cout)
-    prog.ops.append(dict(kind=OP_CONV, name=f"c{r}", k=k, stride=s, act=1, inp=x, out=y, res=None, weight=w, bias=b))
+    x, y = ar.alloc(H, W, cin, FP8 if f8 else BF16), ar.alloc(Ho, Wo, cout)
+    prog.ops.append(dict(kind=OP_CONV, name=f"c{r}", k=k, stride=s, act=1, inp=x, out=y, res=None, weight=w, bias=b, in_scale=0.05))
 prog.ws_bytes = ar.top + 256
 eng = HipEngine(prog, dev)
 for o in prog.ops:
-    eng.write_view(o['inp'], torch.randn(B, cin, H, W))
+    eng.write_view(o['inp'], (torch.randn(B, cin, H, W) * (20 if f8 else 1)).clamp(-448, 448))
 im = torch.zeros(B, 3, 32, 32, device=dev)
 for _ in range(3):
     eng.forward(im, decode=False, graph=True)
@@ -42,7 +43,7 @@ for _ in range(N):
 e1.record()
 torch.cuda.synchronize()
 us = e0.elapsed_time(e1) / (N * NREP) * 1e3
-byt = B * (H * W * cin + Ho * Wo * cout) * 2
+byt = B * (H * W * cin * (1 if f8 else 2) + Ho * Wo * cout * 2)
 torch.cuda.synchronize()
 fl = 2.0 * B * Ho * Wo * cout * cin * k * k
-print(f"dbg={os.environ.get('YL_CONV_DBG', '0'):>2s} {cin}->{cout} k{k} s{s} @{H}x{W}: {us:7.1f} us  {byt / us / 1e6:6.2f} TB/s  {fl / us / 1e6:7.1f} TF/s")
+print(f"{'fp8 ' if f8 else ''}dbg={os.environ.get('YL_CONV_DBG', '0'):>2s} {cin}->{cout} k{k} s{s} @{H}x{W}: {us:7.1f} us  {byt / us / 1e6:6.2f} TB/s  {fl / us / 1e6:7.1f} TF/s")
