@@ -468,16 +468,25 @@ def test_fused_bottlenecks_are_bit_identical(gpu_device, monkeypatch, scale, h, 
         assert torch.equal(a, b)
 
 
-def test_full_size_properties_batch32_640(gpu_device):
-    """BASELINE.json's bench configuration (YOLO11n, 640x640, batch 32) through size-independent properties of the path:
-    permuting the images of a batch permutes the records bit for bit (images are independent through network and NMS,
-    ops.py:219); records are score-descending, inside the image, at most max_det, classes integral and in range; NMS
-    is idempotent (no kept box suppresses another kept box of its class); the graph replay equals the eager pass."""
-    B, H, W, conf, iou = 32, 640, 640, 0.25, 0.7
-    sd = synth_state_dict("n", 0, cls_bias=[-4.3, -4.3, -4.3], cls_gain=8.0)
+@pytest.mark.parametrize("scale,B", [("n", 32), ("s", 64)])
+def test_full_size_properties(gpu_device, scale, B):
+    """BASELINE.json's configurations 2 and 3 (YOLO11n batch 32, YOLO11s batch 64, 640x640) through size-independent
+    properties of the path: permuting the images of a batch permutes the records bit for bit (images are independent
+    through network and NMS, ops.py:219); records are score-descending, inside the image, at most max_det, classes integral
+    and in range; NMS is idempotent (no kept box suppresses another kept box of its class); the graph replay equals the
+    eager pass."""
+    from yololite_amd.nn.synth import calibrate_cls_bias
+
+    H, W, conf, iou = 640, 640, 0.25, 0.7
     g = torch.Generator().manual_seed(77)
     x = torch.randint(0, 256, (B, 3, H, W), generator=g, dtype=torch.uint8).to(gpu_device)
-    eng = _engine("n", sd, B, H, W, gpu_device)
+    e0 = _engine(scale, synth_state_dict(scale, 0, cls_bias=[0.0, 0.0, 0.0]), B, H, W, gpu_device)
+    e0.forward(x, decode=False)
+    bias = calibrate_cls_bias([r[:, 64:].amax(1).float().cpu() for r in e0.raw_levels()], 0.015)  # ~1.5 % of anchors pass conf
+    del e0
+    torch.cuda.empty_cache()
+    sd = synth_state_dict(scale, 0, cls_bias=bias)
+    eng = _engine(scale, sd, B, H, W, gpu_device)
     out, cnt = (t.clone() for t in eng.detect(x, conf, iou, graph=False))
     assert int(cnt.sum()) > 5 * B, "the synthetic head must produce detections for the properties to mean anything"
     perm = torch.randperm(B, generator=g).to(gpu_device)
