@@ -41,6 +41,14 @@ def family(k):
         return "conv1x1_mfma"
     if k.startswith("conv_kernel<3,"):
         return "conv3x3_mfma+conv3x3s2_mfma"   # one template serves both strides
+    if k.startswith("conv_f8_kernel<1,"):
+        return "conv1x1_f8_mfma"
+    if k.startswith("conv_f8_kernel<3,"):
+        return "conv3x3_f8_mfma+conv3x3s2_f8_mfma"
+    if k.startswith("bneck2_kernel"):
+        return "bottleneck_fused_mfma"
+    if k.startswith("quant_f8_kernel"):
+        return "quantize_f8"
     if k.startswith("conv3_tile_kernel"):
         return "conv3x3_tile_mfma"
     if k.startswith("dwpw_kernel"):
