@@ -353,7 +353,12 @@ def main():
                                                              max(1.0, sum(r["flops"] for r in rows)), 4)
                 del e16
             if not args.no_cpu_baseline:
-                res["cpu_baseline"] = cpu_baseline(sd, args.scale, H, W, conf, iou, eng=eng, dev=dev, max_det=max_det)
+                # bounded sample: about as much host work as 800 images of YOLO11n at 640x640 (~12 s on 8 threads)
+                gf = CONV_GFLOP_AT_640.get(args.scale, 200.0) * (H * W) / (640 * 640)
+                n_img = max(1, int(800 * CONV_GFLOP_AT_640["n"] / gf))
+                sb = min(8, B, n_img)
+                res["cpu_baseline"] = cpu_baseline(sd, args.scale, H, W, conf, iou, sample_b=sb, iters=max(1, n_img // sb),
+                                                   eng=eng, dev=dev, max_det=max_det)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
