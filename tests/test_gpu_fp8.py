@@ -110,6 +110,7 @@ def test_fp8_network_close_to_bf16(gpu_device, monkeypatch, scale, h, w, mode):
     # instead; "mirror": opt-in, 1x1 convs too, tensors stored as e4m3 (faster, outside the stated detection tolerance)
     monkeypatch.setenv("YL_FP8_DUAL", "0" if mode == "passes" else "1")
     monkeypatch.setenv("YL_FP8_MIRROR", "1" if mode == "mirror" else "0")
+    monkeypatch.setenv("YL_FP8_1X1_GF", "0")  # mirror mode here: every eligible 1x1 conv
     e8 = HipEngine.from_model(specs, sd, 2, h, w, gpu_device, fp8_calib=x)
     kernels = [e8.op_kernel(i) for i in range(len(e8.prog.ops))]
     assert sum("_f8_" in k for k in kernels) >= (35 if mode == "mirror" else 15)

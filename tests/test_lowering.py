@@ -117,6 +117,7 @@ def test_fp8_pass_structure(scale, with_1x1, monkeypatch):
     from yololite_amd.nn.lower import FP8, OP_QUANT, fp8_candidate
 
     monkeypatch.setenv("YL_FP8_MIRROR", "1" if with_1x1 else "0")
+    monkeypatch.setenv("YL_FP8_1X1_GF", "0")
     specs, _ = arch.parse_model(arch.yolo11_dict(scale))
     sd = synth_state_dict(scale, 0)
     p = lower(specs, sd, 2, 64, 96)

@@ -368,8 +368,18 @@ def apply_fp8_mirrors(ops: List[dict], ar: "_Arena", scales: Dict[str, float]) -
             r |= planes(o["out"])
         return r
 
+    # YL_FP8_1X1_GF: 1x1 convs join only above this many GFLOP per launch (default 0: all of them).  Measured on YOLO11x at
+    # 1280x1280 batch 8 with 100 (the six C3k2.cv2 convs): 964 images/s against 923, but those convs write the layer outputs and
+    # the post-NMS gate already fails (1355 / 2347 boxes matched, max |dconf| 0.145) -- there is no cheap subset.
+    min_gf = float(os.environ.get("YL_FP8_1X1_GF", "0"))
+
     def cand(o: dict) -> bool:
-        return fp8_candidate(o, allow_1x1=True) and o.get("name") in scales and o["inp"].coff % 16 == 0
+        if not (fp8_candidate(o, allow_1x1=True) and o.get("name") in scales and o["inp"].coff % 16 == 0):
+            return False
+        if o.get("k") == 1:
+            y = o["out"]
+            return 2.0 * ar.batch * y.H * y.W * y.C * o["inp"].C >= min_gf * 1e9
+        return True
 
     def can_mirror(o: dict) -> bool:
         y = o["out"]
