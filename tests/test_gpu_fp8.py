@@ -32,6 +32,8 @@ CASES = [
     (2, 64, 96, 32, 32, 3, 2, "conv3x3s2_f8_mfma"),   # stride 2
     (1, 384, 64, 16, 16, 3, 1, "conv3x3_f8_mfma"),    # 27 k-steps: the filter slab is restaged in chunks
     (3, 16, 32, 9, 9, 3, 1, "conv3x3_f8_mfma"),       # one k-group per tap, 2 tiles
+    (1, 128, 192, 12, 20, 3, 1, "conv3x3_f8_mfma"),   # wide layer: six tiles per wave (two channel blocks of 96)
+    (2, 256, 384, 16, 16, 3, 2, "conv3x3s2_f8_mfma"), # the same at stride 2, slab in chunks
 ]
 
 

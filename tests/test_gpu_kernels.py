@@ -46,6 +46,11 @@ CONV_CASES = [
     (80, 80, 1, 1, 20, 20, False, False),   # Detect class head (bias, no act)
     (96, 128, 1, 1, 12, 20, True, False),
     (48, 48, 3, 1, 12, 20, True, True),     # x-scale C3k bottleneck
+    (96, 96, 3, 1, 12, 20, True, True),     # x-scale widths of 96: six channel tiles per wave, slab restaged in chunks
+    (192, 96, 1, 1, 16, 24, True, False),   # C3k cv1+cv2 of YOLO11x (six tiles, 1x1)
+    (64, 96, 3, 2, 24, 24, True, False),
+    (128, 192, 1, 1, 16, 24, True, True),   # wide layers prefer six tiles to four (two channel blocks of 96)
+    (256, 384, 3, 2, 16, 16, True, False),
     (64, 64, 3, 1, 7, 9, True, False),      # ragged map
     (32, 16, 3, 1, 33, 17, True, False),
 ]

@@ -140,13 +140,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
 #pragma unroll
     for (int d = 0; d < D; ++d) fetch_b8<KS, NT, UNIFORM>(a, rin, d, g, P, xr[d]);
   }
-  // per-lane dequantisation factor and bias of its 4 channels of every tile
-  f32x4 alpha_r[MT], bias_r[MT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    alpha_r[mt] = *reinterpret_cast<const f32x4*>(a.alpha + cb * MT * 16 + mt * 16 + g * 4);
-    bias_r[mt] = *reinterpret_cast<const f32x4*>(a.bias + cb * MT * 16 + mt * 16 + g * 4);
-  }
   const bf16x8* wsrc = reinterpret_cast<const bf16x8*>(a.wpk) + (size_t)cb * a.ksteps * MT * 128;  // 16-byte units
   const v4i* wl = reinterpret_cast<const v4i*>(smem8) + lane;
   const bool multi = a.kchunk < a.ksteps;
@@ -184,13 +177,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     for (int mt = 0; mt < MT; ++mt) {
       const int co = cb * MT * 16 + mt * 16 + g * 4;
       const bool cok = co < a.Cout;
+      // per-lane dequantisation factor and bias of its 4 channels of this tile (L1-resident; not held across the k-loop)
+      const f32x4 alpha_r = *reinterpret_cast<const f32x4*>(a.alpha + co);
+      const f32x4 bias_r = *reinterpret_cast<const f32x4*>(a.bias + co);
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
         const bool ok = cok && opix[nt] >= 0;
         float v[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          v[r] = __builtin_fmaf(acc[mt][nt][r], alpha_r[mt][r], bias_r[mt][r]);
+          v[r] = __builtin_fmaf(acc[mt][nt][r], alpha_r[r], bias_r[r]);
           if (a.act) v[r] = silu_f(v[r]);
         }
         if (a.res) {
@@ -257,8 +253,13 @@ int conv_f8_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int 
   if ((k != 1 && k != 3) || (stride != 1 && stride != 2) || Cin % 16 || Cout % 16 || Cin <= 0 || Cout <= 0)
     return fail(-3, "fp8 conv: k in {1,3}, stride in {1,2}, Cin % 16 == 0, Cout % 16 == 0");
   const int cout16 = Cout / 16;
-  const int MT = cout16 % 4 == 0 ? 4 : (cout16 % 3 == 0 ? 3 : (cout16 % 2 == 0 ? 2 : 0));
+  int MT = cout16 % 4 == 0 ? 4 : (cout16 % 3 == 0 ? 3 : (cout16 % 2 == 0 ? 2 : 0));
   if (!MT) return fail(-3, "fp8 conv: Cout must be a multiple of 32 or 48");
+  // six tiles per wave (96 output channels) instead of four on wide layers: a third fewer re-reads of the activations
+  // (YOLO11x 1280x1280: the stride-2 3x3 convs 1.56 -> 1.43 ms).  Not instead of three tiles (the 96-channel Bottleneck convs
+  // get slower: 250+ VGPRs with a few spills do not pay on short k-loops).  YL_F8_MT6=0 turns it off.
+  static const int mt6 = getenv("YL_F8_MT6") ? atoi(getenv("YL_F8_MT6")) : 1;
+  if (mt6 && MT == 4 && cout16 % 6 == 0 && Cin >= 128) MT = 6;
   const int ntaps = k * k, cg = Cin / 16;
   const int ksteps = (ntaps * cg + 7) / 8;
   const size_t slab_max = 72 * 1024, step_bytes = (size_t)MT * 2048;
@@ -266,7 +267,7 @@ int conv_f8_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int 
   if ((size_t)ksteps * step_bytes > slab_max) kchunk = (int)(slab_max / step_bytes) & ~1;  // multiple of the ring depth
   const long long npix = (long long)batch * Ho * Wo;
   const int ncb = cout16 / MT;
-  const int NT = (npix + 63) / 64 * ncb / 4 >= 256 ? 4 : 2;
+  const int NT = (npix + 63) / 64 * ncb / 4 >= 256 || MT == 6 ? 4 : 2;
   c->MT = MT;
   c->NT = NT;
   c->ncb = ncb;
@@ -345,6 +346,7 @@ static int launch8_m(const ConvConfig& cfg, const ConvArgs& a, hipStream_t s) {
     case 2: return launch8_n<KS, 2>(cfg, a, s);
     case 3: return launch8_n<KS, 3>(cfg, a, s);
     case 4: return launch8_n<KS, 4>(cfg, a, s);
+    case 6: return cfg.uniform ? launch8<KS, 6, 4, true>(cfg, a, s) : launch8<KS, 6, 4, false>(cfg, a, s);
   }
   return fail(-3, "fp8 conv: bad MT");
 }

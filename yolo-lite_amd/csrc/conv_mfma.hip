@@ -359,6 +359,10 @@ int conv_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo,
   if (cout16 % 2 == 0) mts[nmt++] = 2;
   mts[nmt++] = 1;
   int MT = mts[0];
+  // six tiles per wave (96 output channels): channel counts that are multiples of 96 but not of 64 (YOLO11x / m) would otherwise
+  // fall to two tiles; YL_CONV_MT6=2 also prefers it to four tiles on wide layers (fewer re-reads of the activations)
+  static const int mt6 = getenv("YL_CONV_MT6") ? atoi(getenv("YL_CONV_MT6")) : 2;
+  if (!post && cout16 % 6 == 0 && Cin % 32 == 0 && ((mt6 >= 1 && cout16 % 4 != 0) || (mt6 >= 2 && Cin >= 128))) MT = 6;
   if (!allow_chunk)
     for (int mi = 0; mi < nmt; ++mi) {
       MT = mts[mi];
@@ -378,6 +382,7 @@ int conv_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo,
   if (npatches(4) * ncb / 4 >= nt4_blocks) NT = 4;
   else if (npatches(2) * ncb / 4 >= nt2_blocks) NT = 2;
   if (MT == 5 && NT == 4) NT = 2;
+  if (MT == 6 && NT == 1) NT = 2;
   c->MT = MT;
   c->NT = NT;
   c->ncb = ncb;
@@ -440,10 +445,10 @@ void conv_pack_weights(const float* w, int Cout, int Cin_w, int k, const ConvCon
 
 template <int KS, int MT, int NT, bool U, bool POST, bool O8 = false>
 static int launch_p(const ConvConfig& cfg, const ConvArgs& a, hipStream_t s) {
-  if constexpr (!O8 && !POST && (MT == 2 || MT == 4)) {
+  if constexpr (!O8 && !POST && (MT == 2 || MT == 4 || MT == 6)) {
     if (a.out8) return launch_p<KS, MT, NT, U, POST, true>(cfg, a, s);
   }
-  if (a.out8 && !O8) return fail(-3, "conv: an e4m3 copy of the output needs 2 or 4 channel tiles per wave and no fused follow-up conv");
+  if (a.out8 && !O8) return fail(-3, "conv: an e4m3 copy of the output needs 2, 4 or 6 channel tiles per wave and no fused follow-up conv");
   auto kern = conv_kernel<KS, MT, NT, U, POST, false, O8>;
   static size_t attr = 0;  // per instantiation: largest dynamic LDS size enabled so far
   if (cfg.lds_bytes > attr) {
@@ -458,10 +463,10 @@ static int launch_p(const ConvConfig& cfg, const ConvArgs& a, hipStream_t s) {
 
 template <int MT, int NT, bool O8 = false>
 static int launch_up(const ConvConfig& cfg, const ConvArgs& a, hipStream_t s) {
-  if constexpr (!O8 && (MT == 2 || MT == 4)) {
+  if constexpr (!O8 && (MT == 2 || MT == 4 || MT == 6)) {
     if (a.out8) return launch_up<MT, NT, true>(cfg, a, s);
   }
-  if (a.out8 && !O8) return fail(-3, "conv: an e4m3 copy of the output needs 2 or 4 channel tiles per wave");
+  if (a.out8 && !O8) return fail(-3, "conv: an e4m3 copy of the output needs 2, 4 or 6 channel tiles per wave");
   auto kern = conv_kernel<1, MT, NT, true, false, true, O8>;
   static size_t attr = 0;
   if (cfg.lds_bytes > attr) {
@@ -508,6 +513,10 @@ static int launch_m(const ConvConfig& cfg, const ConvArgs& a, hipStream_t s) {
     case 2: return launch_n<KS, 2>(cfg, a, s);
     case 4: return launch_n<KS, 4>(cfg, a, s);
     case 5: return cfg.NT == 1 ? launch_u<KS, 5, 1>(cfg, a, s) : launch_u<KS, 5, 2>(cfg, a, s);
+    case 6:
+      if (cfg.uniform && !cfg.post)
+        return cfg.NT == 4 ? launch_t<KS, 6, 4, true>(cfg, a, s) : launch_t<KS, 6, 2, true>(cfg, a, s);
+      break;
   }
   return fail(-3, "conv: bad MT");
 }
