@@ -340,6 +340,17 @@ static unsigned magic_of(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ul
 static const size_t LDS_MAX = 160 * 1024;  // per CU and per workgroup on gfx950
 static const int NUM_CU = 256;
 
+// conv_choose_even: tilings with an even number of channel tiles per wave only (the e4m3 epilogue copy, yl_op.out8, is written
+// by tile pairs)
+static thread_local bool g_even_only = false;
+int conv_choose_even(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, ConvConfig* c) {
+  g_even_only = true;
+  const int rc = conv_choose(batch, Cin, Cout, k, stride, Ho, Wo, 0, c);
+  g_even_only = false;
+  if (rc == 0 && (c->MT & 1)) return fail(-3, "conv: no tiling with an even number of channel tiles for this channel count");
+  return rc;
+}
+
 int conv_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, int post, ConvConfig* c) {
   if ((k != 1 && k != 3) || (stride != 1 && stride != 2) || Cin % 8 || Cin <= 0 || Cout <= 0)
     return fail(-3, "conv: unsupported geometry (k in {1,3}, stride in {1,2}, Cin % 8 == 0)");
@@ -353,9 +364,10 @@ int conv_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo,
   // output-channel tiles per wave: as many as divide the layer (B-fragment traffic goes with 1/MT).
   // YL_CONV_CHUNK=0 restores the older policy of shrinking MT until the whole filter fits the slab.
   static const int allow_chunk = getenv("YL_CONV_CHUNK") ? atoi(getenv("YL_CONV_CHUNK")) : 1;
-  int mts[4], nmt = 0;
+  int mts[5], nmt = 0;
   if (cout16 % 4 == 0) mts[nmt++] = 4;
-  if (cout16 % 5 == 0) mts[nmt++] = 5;
+  if (cout16 % 5 == 0 && !g_even_only) mts[nmt++] = 5;
+  if (cout16 % 3 == 0 && !g_even_only) mts[nmt++] = 3;  // 48-channel layers (YOLO11x Bottlenecks) would otherwise run one tile per wave
   if (cout16 % 2 == 0) mts[nmt++] = 2;
   mts[nmt++] = 1;
   int MT = mts[0];
@@ -511,6 +523,7 @@ static int launch_m(const ConvConfig& cfg, const ConvArgs& a, hipStream_t s) {
   switch (cfg.MT) {
     case 1: return launch_n<KS, 1>(cfg, a, s);
     case 2: return launch_n<KS, 2>(cfg, a, s);
+    case 3: return launch_n<KS, 3>(cfg, a, s);
     case 4: return launch_n<KS, 4>(cfg, a, s);
     case 5: return cfg.NT == 1 ? launch_u<KS, 5, 1>(cfg, a, s) : launch_u<KS, 5, 2>(cfg, a, s);
     case 6:

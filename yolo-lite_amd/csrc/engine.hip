@@ -264,8 +264,9 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
         if (int rc = conv_choose(batch, cin_total, cout1, o.k, o.stride, Ho, Wo, post, &r.cfg)) return rc;
         if (o.out8.offset >= 0) {
           if (int rc = check_out8(o, batch, workspace_bytes, tag)) return rc;
-          if (post || o.stem_weight || (r.cfg.MT & 1))
-            return fail(-1, tag + ": out8 needs a plain conv with an even number of channel tiles per wave");
+          if (post || o.stem_weight) return fail(-1, tag + ": out8 needs a plain conv");
+          if (r.cfg.MT & 1)  // the copy is written by tile pairs: take the best even tiling instead
+            if (int rc = conv_choose_even(batch, cin_total, cout1, o.k, o.stride, Ho, Wo, &r.cfg)) return rc;
           r.cfg.tile = 0;  // the e4m3 copy is written by conv_kernel's epilogue
         }
         std::vector<uint16_t> pk;

@@ -118,6 +118,7 @@ struct ConvConfig {
 
 // Chooses the tiling for one conv; returns <0 when unsupported.
 int conv_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, int post, ConvConfig* cfg);
+int conv_choose_even(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, ConvConfig* cfg);
 // Packs folded fp32 OIHW weights into the fragment order cfg describes (host).
 void conv_pack_weights(const float* w_oihw, int Cout, int Cin_w, int k, const ConvConfig& cfg,
                        std::vector<uint16_t>* out);

@@ -390,7 +390,7 @@ def apply_fp8_mirrors(ops: List[dict], ar: "_Arena", scales: Dict[str, float]) -
         if o["kind"] != OP_CONV or "post_weight" in o or "stem_weight" in o:
             return False
         c16 = (y.C + 15) // 16
-        return cand(o) or c16 % 4 == 0 or bool(c16 % 5 and c16 % 2 == 0)
+        return cand(o) or c16 % 2 == 0
 
     # buffers (by arena offset) read by candidates, the planes they read, their scale
     want: Dict[int, set] = {}
@@ -489,7 +489,7 @@ def apply_fp8(ops: List[dict], ar: "_Arena", scales: Dict[str, float]) -> List[d
             if p["kind"] != OP_CONV or "post_weight" in p or "stem_weight" in p:
                 return None
             c16 = (p["out"].C + 15) // 16
-            if p["inp"].dtype != FP8 and not (c16 % 4 == 0 or (c16 % 5 and c16 % 2 == 0)):
+            if p["inp"].dtype != FP8 and c16 % 2:  # the bf16 kernel writes the copy by pairs of 16-channel tiles
                 return None
             return p
         return None
