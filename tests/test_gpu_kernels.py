@@ -56,6 +56,16 @@ CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize("cin,cout,k,s,h,w,res", [(256, 256, 1, 1, 20, 20, True), (128, 256, 3, 2, 24, 40, False), (128, 512, 3, 1, 9, 13, True)])
+def test_conv_eight_tiles_per_wave(gpu_device, monkeypatch, cin, cout, k, s, h, w, res):
+    """128 channels x 32 pixels per wave (MT = 8, NT = 2: half the activation re-reads of 64 x 64), the tiling wide layers with
+    at least 256 output channels take when the grid stays large (YOLO11s at batch 64); forced here on small maps."""
+    monkeypatch.setenv("YL_CONV_MT8_BLOCKS", "1")
+    test_conv_vs_torch(gpu_device, cin, cout, k, s, h, w, True, res)
+    monkeypatch.setenv("YL_CONV_MT8", "0")   # and the four-tile form of the same layer agrees with torch as well
+    test_conv_vs_torch(gpu_device, cin, cout, k, s, h, w, True, res)
+
+
 @pytest.mark.parametrize("cin,cout,k,s,h,w,act,res", CONV_CASES)
 def test_conv_vs_torch(gpu_device, cin, cout, k, s, h, w, act, res):
     g = torch.Generator().manual_seed(cin * 1000 + cout * 10 + k + s)

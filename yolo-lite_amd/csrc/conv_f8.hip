@@ -258,7 +258,7 @@ int conv_f8_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int 
   // six tiles per wave (96 output channels) instead of four on wide layers: a third fewer re-reads of the activations
   // (YOLO11x 1280x1280: the stride-2 3x3 convs 1.56 -> 1.43 ms).  Not instead of three tiles (the 96-channel Bottleneck convs
   // get slower: 250+ VGPRs with a few spills do not pay on short k-loops).  YL_F8_MT6=0 turns it off.
-  static const int mt6 = getenv("YL_F8_MT6") ? atoi(getenv("YL_F8_MT6")) : 1;
+  const int mt6 = getenv("YL_F8_MT6") ? atoi(getenv("YL_F8_MT6")) : 1;
   if (mt6 && MT == 4 && cout16 % 6 == 0 && Cin >= 128) MT = 6;
   const int ntaps = k * k, cg = Cin / 16;
   const int ksteps = (ntaps * cg + 7) / 8;

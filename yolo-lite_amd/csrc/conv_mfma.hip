@@ -373,8 +373,16 @@ int conv_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo,
   int MT = mts[0];
   // six tiles per wave (96 output channels): channel counts that are multiples of 96 but not of 64 (YOLO11x / m) would otherwise
   // fall to two tiles; YL_CONV_MT6=2 also prefers it to four tiles on wide layers (fewer re-reads of the activations)
-  static const int mt6 = getenv("YL_CONV_MT6") ? atoi(getenv("YL_CONV_MT6")) : 2;
+  const int mt6 = getenv("YL_CONV_MT6") ? atoi(getenv("YL_CONV_MT6")) : 2;
   if (!post && cout16 % 6 == 0 && Cin % 32 == 0 && ((mt6 >= 1 && cout16 % 4 != 0) || (mt6 >= 2 && Cin >= 128))) MT = 6;
+  // eight tiles x two pixel tiles per wave (128 channels x 32 pixels): half the activation re-reads of 4 x 4 at twice the filter
+  // reads from LDS -- a trade that pays while the texture path, not LDS, is the busier one (YL_CONV_MT8 = smallest Cin that takes it)
+  const int mt8 = getenv("YL_CONV_MT8") ? atoi(getenv("YL_CONV_MT8")) : 128;
+  const int mt8_cout = getenv("YL_CONV_MT8_COUT") ? atoi(getenv("YL_CONV_MT8_COUT")) : 256;  // smallest Cout that takes it
+  const int mt8_blocks = getenv("YL_CONV_MT8_BLOCKS") ? atoi(getenv("YL_CONV_MT8_BLOCKS")) : 512;
+  if (mt8 > 0 && !post && cout16 % 8 == 0 && Cin % 32 == 0 && Cin >= mt8 && Cout >= mt8_cout && MT == 4 &&
+      ((long long)batch * Ho * Wo + 31) / 32 / 4 * (cout16 / 8) >= mt8_blocks)  // still at least two workgroups per CU
+    MT = 8;
   if (!allow_chunk)
     for (int mi = 0; mi < nmt; ++mi) {
       MT = mts[mi];
@@ -395,6 +403,7 @@ int conv_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo,
   else if (npatches(2) * ncb / 4 >= nt2_blocks) NT = 2;
   if (MT == 5 && NT == 4) NT = 2;
   if (MT == 6 && NT == 1) NT = 2;
+  if (MT == 8) NT = 2;
   c->MT = MT;
   c->NT = NT;
   c->ncb = ncb;
@@ -457,7 +466,7 @@ void conv_pack_weights(const float* w, int Cout, int Cin_w, int k, const ConvCon
 
 template <int KS, int MT, int NT, bool U, bool POST, bool O8 = false>
 static int launch_p(const ConvConfig& cfg, const ConvArgs& a, hipStream_t s) {
-  if constexpr (!O8 && !POST && (MT == 2 || MT == 4 || MT == 6)) {
+  if constexpr (!O8 && !POST && (MT == 2 || MT == 4 || MT == 6 || MT == 8)) {
     if (a.out8) return launch_p<KS, MT, NT, U, POST, true>(cfg, a, s);
   }
   if (a.out8 && !O8) return fail(-3, "conv: an e4m3 copy of the output needs 2, 4 or 6 channel tiles per wave and no fused follow-up conv");
@@ -475,7 +484,7 @@ static int launch_p(const ConvConfig& cfg, const ConvArgs& a, hipStream_t s) {
 
 template <int MT, int NT, bool O8 = false>
 static int launch_up(const ConvConfig& cfg, const ConvArgs& a, hipStream_t s) {
-  if constexpr (!O8 && (MT == 2 || MT == 4 || MT == 6)) {
+  if constexpr (!O8 && (MT == 2 || MT == 4 || MT == 6 || MT == 8)) {
     if (a.out8) return launch_up<MT, NT, true>(cfg, a, s);
   }
   if (a.out8 && !O8) return fail(-3, "conv: an e4m3 copy of the output needs 2, 4 or 6 channel tiles per wave");
@@ -526,6 +535,9 @@ static int launch_m(const ConvConfig& cfg, const ConvArgs& a, hipStream_t s) {
     case 3: return launch_n<KS, 3>(cfg, a, s);
     case 4: return launch_n<KS, 4>(cfg, a, s);
     case 5: return cfg.NT == 1 ? launch_u<KS, 5, 1>(cfg, a, s) : launch_u<KS, 5, 2>(cfg, a, s);
+    case 8:
+      if (cfg.uniform && !cfg.post && cfg.NT == 2) return launch_t<KS, 8, 2, true>(cfg, a, s);
+      break;
     case 6:
       if (cfg.uniform && !cfg.post)
         return cfg.NT == 4 ? launch_t<KS, 6, 4, true>(cfg, a, s) : launch_t<KS, 6, 2, true>(cfg, a, s);
