@@ -397,8 +397,8 @@ int conv_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo,
   const long long npix = (long long)batch * Ho * Wo;
   auto npatches = [&](int nt) { return (npix + 16 * nt - 1) / (16 * nt); };
   int NT = 1;
-  static const int nt4_blocks = getenv("YL_CONV_NT4") ? atoi(getenv("YL_CONV_NT4")) : NUM_CU;
-  static const int nt2_blocks = getenv("YL_CONV_NT2") ? atoi(getenv("YL_CONV_NT2")) : NUM_CU / 2;
+  static const int nt4_blocks = getenv("YL_CONV_NT4") ? atoi(getenv("YL_CONV_NT4")) : NUM_CU / 2;
+  static const int nt2_blocks = getenv("YL_CONV_NT2") ? atoi(getenv("YL_CONV_NT2")) : NUM_CU / 4;
   if (npatches(4) * ncb / 4 >= nt4_blocks) NT = 4;
   else if (npatches(2) * ncb / 4 >= nt2_blocks) NT = 2;
   if (MT == 5 && NT == 4) NT = 2;
