@@ -424,7 +424,7 @@ int conv_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo,
   c->npatches = (int)npatches(NT);
   // patches per wave: amortise the slab load while keeping >= ~8 blocks per CU in the grid
   long long blocks1 = ((long long)c->npatches + 3) / 4 * ncb;
-  static const int ppw_div = getenv("YL_CONV_BPC") ? atoi(getenv("YL_CONV_BPC")) : 8;  // target blocks per CU
+  static const int ppw_div = getenv("YL_CONV_BPC") ? atoi(getenv("YL_CONV_BPC")) : 32;  // target blocks per CU (8 until several batches ran in flight: +0.7 %)
   int ppw = (int)(blocks1 / (ppw_div * NUM_CU));
   if (ppw < 1) ppw = 1;
   if (ppw > 32) ppw = 32;
