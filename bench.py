@@ -4,20 +4,23 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One "step" = one pass of the hot path over one batch of synthetic images: HIP network forward (about 70
-kernels from the uint8 input to the Detect level maps) + fused Detect decode + GPU NMS, replayed as ONE
-hipGraph, with the inputs already resident in HBM.  For N>1 the images are sharded 32 per GPU (weak
-scaling): every rank runs the same hot path on shards resident in its own HBM, one RCCL gather returns the
-last step's result records to rank 0; value = all ranks' images / max-over-ranks time.
+One "step" = one pass of the hot path over one batch of synthetic images: HIP network forward (from the uint8 input to
+the Detect level maps) + fused Detect decode + GPU NMS, replayed as ONE hipGraph.
+
+N = 1: the inputs are resident in HBM; ``value`` = steps pipelined over ``--streams`` HIP streams (one workspace slot
+each); ``value_sync_per_iteration`` = the same step with the stream synchronised after every iteration (SURVEY 8(d)'s
+literal definition); ``api_images_per_sec`` = the same batches through ``YOLOLite.predict``.
+
+N > 1 (BASELINE.json config 4): rank 0 holds the uint8 GLOBAL batch (N x 32 images) in its HBM; every
+step it scatters the 32-image slices over RCCL (issued ``--streams`` steps ahead, hidden behind the batches in
+flight), every rank runs the one-graph hot path on its slice, and rank 0 gathers the packed ``(count, 300 x 6)`` records
+of every step: ``value`` = all ranks' images / max-over-ranks time of that loop.  ``value_resident`` = the replica figure
+without any per-step collective (every rank's shards resident in its own HBM, one gather at the end), timed separately.
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
-import os
-
-os.environ.setdefault("DEBUG_HIP_FORCE_GRAPH_QUEUES", "2")  # see yololite_amd/_lib.py; before HIP initialises
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import json
 import os
 import sys
@@ -27,6 +30,13 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+from yololite_amd import _lib as yl_lib  # noqa: E402
+
+# bench.py is its own launcher: the HIP runtime knobs the hot path depends on are set here, explicitly, before the
+# first GPU call of the process (yololite_amd/_lib.py documents them); the JSON line records whether that was in time
+# and whether two graph branches really overlap on this runtime ("runtime").
+KNOBS = yl_lib.apply_runtime_knobs()
 
 import torch  # noqa: E402
 
@@ -60,69 +70,15 @@ def build_model(scale, device, batch, h, w, x_calib, target_frac=0.015, fp8=Fals
     return specs, sd, HipEngine.from_model(specs, sd, batch, h, w, device, fp8_calib=x_calib if fp8 else None)
 
 
-def _iou(a, b):
-    iw = min(float(a[2]), float(b[2])) - max(float(a[0]), float(b[0]))
-    ih = min(float(a[3]), float(b[3])) - max(float(a[1]), float(b[1]))
-    inter = max(iw, 0.0) * max(ih, 0.0)
-    ua = (float(a[2]) - float(a[0])) * (float(a[3]) - float(a[1])) + (float(b[2]) - float(b[0])) * (float(b[3]) - float(b[1])) - inter
-    return inter / ua if ua > 0 else 0.0
-
-
-def _argmax_near_tie(y_img, r, d, band):
-    """A matched pair with different classes: is it an argmax flip between two classes whose fp32 scores at that anchor lie
-    within the score tolerance of each other?  y_img: the oracle's pre-NMS tensor of the image, (4 + nc, A)."""
-    cx, cy, w, h = y_img[0], y_img[1], y_img[2], y_img[3]
-    box = torch.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], 1)
-    hit = ((box - torch.tensor(r[:4])).abs().amax(1) < 1e-2).nonzero().flatten().tolist()
-    for a in hit:
-        sc = y_img[4:, a]
-        if int(sc.argmax()) == int(r[5]) and float(sc[int(d[5])]) >= float(sc.max()) - band:
-            return True
-    return False
-
-
-def parity_gate(ref_dets, got_dets, conf, iou, band=0.08, iou_match=0.9, iou_band=0.1, ref_y=None):
-    """SURVEY.md section 8(d) gate between the oracle's and the engine's detections of the same images: greedy
-    one-to-one match by IoU >= 0.9 and |dconf| <= band (the stated bf16 tolerance); matched pairs
-    must agree on the class exactly; a box present on one side only is explained when its score lies within the
-    band of the confidence threshold or a same-class box overlaps it within iou_band of the NMS threshold."""
-    st = dict(ref=0, det=0, matched=0, class_mismatch=0, class_near_tie=0, unexplained=0, max_dconf=0.0)
-    for img, (ref, det) in enumerate(zip(ref_dets, got_dets)):
-        ref, det = ref.tolist(), det.tolist()
-        st["ref"] += len(ref)
-        st["det"] += len(det)
-        used = set()
-
-        def explained(box, others):
-            return box[4] <= conf + band or any(o[5] == box[5] and iou - iou_band <= _iou(o, box) < iou_match for o in others)
-
-        for r in ref:
-            hit = next((j for j, d in enumerate(det)
-                        if j not in used and _iou(d, r) >= iou_match and abs(d[4] - r[4]) <= band), None)
-            if hit is None:
-                st["unexplained"] += int(not explained(r, det))
-            else:
-                used.add(hit)
-                st["matched"] += 1
-                if det[hit][5] != r[5]:
-                    # the only admissible class difference: an argmax flip between two classes the reference itself scores
-                    # within the tolerance of each other at that anchor (counted separately, never silently dropped)
-                    if ref_y is not None and _argmax_near_tie(ref_y[img], r, det[hit], band):
-                        st["class_near_tie"] += 1
-                    else:
-                        st["class_mismatch"] += 1
-                st["max_dconf"] = max(st["max_dconf"], abs(det[hit][4] - r[4]))
-        st["unexplained"] += sum(1 for j, d in enumerate(det) if j not in used and not explained(d, ref))
-    st["max_dconf"] = round(st["max_dconf"], 4)
-    st["ok"] = st["class_mismatch"] == 0 and st["unexplained"] == 0 and st["matched"] > 0
-    return st
-
-
-def cpu_baseline(sd, scale, h, w, conf, iou, sample_b=8, iters=100, eng=None, dev=None, max_det=300, band=0.08):
+def cpu_baseline(sd, scale, h, w, conf, iou, sample_b=8, iters=100, eng=None, dev=None, max_det=300, band=0.08,
+                 band_bf16=0.03):
     """The oracle (fp32 eager PyTorch restatement of the reference path, unfused Conv->BN->SiLU +
     python-loop NMS) timed on this host's cores: threads = min(8, cores-1) as the reference sets
-    (utils/__init__.py:32, torch_utils.py:168-169).  kind = "port"."""
+    (utils/__init__.py:32, torch_utils.py:168-169).  kind = "port".  Its last outputs double as the parity gate of the
+    measured HIP path (oracle/parity_gate.py): against the fp32 restatement with the stated bf16 FORMAT tolerance, and
+    against the bf16-storage mode of the same restatement with the (tighter) tolerance left to the kernels themselves."""
     from oracle import yolo11_oracle as oracle
+    from oracle.parity_gate import parity_gate
 
     cores = os.cpu_count() or 1
     threads = min(8, max(1, cores - 1))
@@ -147,25 +103,33 @@ def cpu_baseline(sd, scale, h, w, conf, iou, sample_b=8, iters=100, eng=None, de
         torch.cuda.synchronize(dev)
         got = [o[i, : int(c[i])].cpu() for i in range(sample_b)]
         out["parity_vs_oracle"] = parity_gate(ref, got, conf, iou, band=band, ref_y=y)
-        out["parity_vs_oracle"]["score_band"] = band
+        with torch.inference_mode():
+            y16, _ = oracle.forward(sd, x, scale, storage="bf16")
+            ref16 = oracle.non_max_suppression(y16, conf, iou, max_det=max_det)
+        out["parity_vs_bf16_storage_oracle"] = parity_gate(ref16, got, conf, iou, band=band_bf16, ref_y=y16)
     return out
 
 
-def measured_traffic(kernel):
-    """HBM bytes per launch of a kernel family from the newest committed PMC summary (profiles/rNN_traffic.json,
-    written by tools/summarize_profile.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
-    bench; PMC counters cannot be read from inside the un-profiled run).  None when there is none."""
-    files = sorted((ROOT / "profiles").glob("r*_traffic.json"))
-    if not files:
-        return None, None
-    t = json.loads(files[-1].read_text())
-    for fam, v in t.items():
-        if not fam.startswith("_") and kernel in fam.split("+"):
-            return v["read_bytes_per_launch"] + v["write_bytes_per_launch"], f"{files[-1].name}: {t.get('_source', '')}"
-    return None, None
+def measured_traffic(kernel, cfg):
+    """HBM bytes per launch of a kernel family from a committed PMC summary (profiles/*_traffic.json, written by
+    tools/summarize_profile.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench; PMC counters
+    cannot be read from inside the un-profiled run).  Only a file whose ``_config`` (scale, imgsz, batch, dtype) equals
+    the configuration being benched is used -- the newest such file; (None, None) when there is none."""
+    best = None
+    for f in sorted((ROOT / "profiles").glob("*_traffic.json")):
+        try:
+            t = json.loads(f.read_text())
+        except ValueError:
+            continue
+        if t.get("_config") != cfg:
+            continue
+        for fam, v in t.items():
+            if not fam.startswith("_") and kernel in fam.split("+"):
+                best = (v["read_bytes_per_launch"] + v["write_bytes_per_launch"], f"{f.name}: {t.get('_source', '')}")
+    return best if best else (None, None)
 
 
-def roofline_from_profile(rows, batch):
+def roofline_from_profile(rows, batch, cfg):
     """Aggregate per-op HIP-event timings by kernel; dominant kernel = largest total time."""
     agg = {}
     for r in rows:
@@ -189,7 +153,7 @@ def roofline_from_profile(rows, batch):
             "launches_per_step": a["launches"], "avg_launch_us": round(a["ms"] * 1e3 / a["launches"], 2),
             "mfma_frac": round(mfma_frac, 4), "hbm_frac": round(hbm_frac, 4),
             "algorithmic_bytes_per_launch": round(a["bytes"] / a["launches"])}
-    roof["traffic"], src = measured_traffic(name)
+    roof["traffic"], src = measured_traffic(name, cfg)
     if src:
         roof["traffic_unit"] = "HBM bytes per launch (PMC)"
         roof["traffic_source"] = src
@@ -248,12 +212,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    from yololite_amd.utils import ops as hops
-
     B, H, W = args.batch, args.imgsz, args.imgsz
     conf, iou, max_det = 0.25, 0.7, 300
     x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(rank)).to(dev)
     specs, sd, eng = build_model(args.scale, dev, B, H, W, x, target_frac=args.cand_frac, fp8=args.dtype == "fp8")
+    cfg_key = {"scale": args.scale, "imgsz": args.imgsz, "batch": B, "dtype": args.dtype}
 
     S = max(1, args.streams)
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
@@ -274,6 +237,7 @@ def main():
             torch.cuda.synchronize(dev)
 
     ndet = None
+    extra = {}
     if world == 1:
         # one resident input batch per slot (a graph bakes its input pointer): uint8 NCHW, what the
         # predictor's preprocess hands to the device (predictor.py:77-84); the /255 is fused into the stem.
@@ -291,31 +255,66 @@ def main():
         sync_all()
         dt = time.perf_counter() - t0
         ndet = cnt.float().mean().item()
-        # single-batch latency (one stream, nothing else in flight)
-        torch.cuda.synchronize(dev)
-        t1 = time.perf_counter()
-        for _ in range(20):
-            eng.detect(x8, conf, iou, max_det=max_det, graph=True, slot=0)
-        torch.cuda.synchronize(dev)
-        latency_ms = (time.perf_counter() - t1) / 20 * 1e3
+        # SURVEY 8(d)'s literal definition: one batch at a time, stream-synchronised once per iteration
+        n_sync = max(20, min(200, args.steps))
+        st0 = streams[0]
+        with torch.cuda.stream(st0):
+            for _ in range(5):
+                eng.detect(x8, conf, iou, max_det=max_det, graph=True, slot=0)
+            st0.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(n_sync):
+                eng.detect(x8, conf, iou, max_det=max_det, graph=True, slot=0)
+                st0.synchronize()
+            lat = (time.perf_counter() - t1) / n_sync
+        extra["latency_ms_single_stream"] = round(lat * 1e3, 4)
+        extra["value_sync_per_iteration"] = round(B / lat, 1)
+        extra["sync_per_iteration_note"] = (f"{n_sync} iterations, one batch in flight, hipStreamSynchronize after every "
+                                            "iteration (SURVEY 8(d)); `value` pipelines the same step over the streams")
     else:
-        # Weak scaling: every rank owns its 32-image shards, resident in its HBM before the timed region
-        # (uint8 NCHW, what the predictor's preprocess receives), so the steps need no data-path
-        # collective; one RCCL gather returns the last step's records to rank 0 inside the timed region.
-        # (dist.ShardedRunner, the root-scatters-every-step variant, is covered by tests/test_dist_gloo.py.)
-        from yololite_amd.dist import run_resident
+        # BASELINE.json config 4: rank 0 owns the uint8 global batches (resident in its HBM before the timed region);
+        # per step: RCCL scatter of the 32-image slices (S steps ahead) -> one graph launch per rank -> RCCL gather of
+        # the packed (count, 300 x 6) records.  No all-reduce anywhere.
+        from yololite_amd.dist import ShardedRunner, record_floats, run_resident, unpack_record
 
-        g = torch.Generator().manual_seed(100 + rank)
-        shards = [torch.randint(0, 256, (B, 3, H, W), generator=g, dtype=torch.uint8).to(dev) for _ in range(S)]
-        run_resident(hot_path, shards, max(args.warmup, 2 * S), finish=lambda: torch.cuda.synchronize(dev))
+        nb = min(S, 3)
+        gb = None
+        if rank == 0:
+            g = torch.Generator().manual_seed(100)
+            gb = [torch.randint(0, 256, (world * B, 3, H, W), generator=g, dtype=torch.uint8).to(dev) for _ in range(nb)]
+        batches = gb if rank == 0 else [None] * nb
+
+        def compute(im, slot):
+            return eng.detect_record(im, conf, iou, max_det=max_det, slot=slot)
+
+        runner = ShardedRunner(compute, B, (3, H, W), torch.uint8, dev, record_floats(B, max_det), slots=S,
+                               streams=streams)
+        runner.run(batches, max(args.warmup, 2 * S))
         sync_all()
-        step_no[0] = 0
         t0 = time.perf_counter()
-        last = run_resident(hot_path, shards, args.steps, finish=lambda: torch.cuda.synchronize(dev))
+        last = runner.run(batches, args.steps)
         sync_all()
         dt = time.perf_counter() - t0
         if rank == 0:
-            ndet = torch.stack(last[1]).float().mean().item()
+            _, cnts = unpack_record(last, B, max_det)
+            ndet = torch.cat(cnts).float().mean().item()
+        # replica figure: shards resident in every rank's own HBM, no per-step collective, one gather at the end
+        g = torch.Generator().manual_seed(100 + rank)
+        shards = [torch.randint(0, 256, (B, 3, H, W), generator=g, dtype=torch.uint8).to(dev) for _ in range(S)]
+        step_no[0] = 0
+        run_resident(hot_path, shards, max(args.warmup, 2 * S), finish=lambda: torch.cuda.synchronize(dev))
+        sync_all()
+        step_no[0] = 0
+        t2 = time.perf_counter()
+        run_resident(hot_path, shards, args.steps, finish=lambda: torch.cuda.synchronize(dev))
+        sync_all()
+        dt_res = time.perf_counter() - t2
+        tr = torch.tensor([dt_res], dtype=torch.float64, device=dev)
+        dist.all_reduce(tr, op=dist.ReduceOp.MAX)
+        extra["value_resident"] = round(world * B * args.steps / float(tr.item()), 1)
+        extra["value_resident_note"] = "same steps on shards resident in each rank's HBM, no per-step collective (replicas)"
+        extra["scatter_bytes_per_step"] = (world - 1) * B * 3 * H * W
+        extra["gather_bytes_per_step"] = (world - 1) * record_floats(B, max_det) * 4
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -324,6 +323,12 @@ def main():
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         value = world * B * args.steps / dt
+        workload = (f"YOLO11{args.scale} {args.dtype}, {H}x{W} batch={B} per GPU (fused Conv+BN+SiLU + HIP NMS), "
+                    f"random-init weights, random uint8 NCHW images, conf {conf} iou {iou} max_det {max_det}; "
+                    f"{S} batches in flight on {S} HIP streams (one hipGraph launch per step); ")
+        workload += ("inputs resident in HBM" if world == 1 else
+                     f"global batch {world * B} resident on rank 0, per step: RCCL scatter of the uint8 slices -> compute -> "
+                     "RCCL gather of the packed (count, 300x6) records")
         res = {
             "metric": f"images/sec end-to-end (incl. NMS), YOLO11{args.scale} {H}x{W} batch={B}",
             "value": round(value, 1), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
@@ -331,9 +336,7 @@ def main():
             "vs_baseline": None, "dtype": "bf16" if args.dtype == "bf16" else ("fp8 e4m3 (dense 3x3 and 1x1 convs, tensors mirrored in e4m3) + bf16"
                                                           if os.environ.get("YL_FP8_MIRROR", "0") == "1" else "fp8 e4m3 (dense 3x3 convs) + bf16"),
             "data": "synthetic",
-            "config": {"workload": f"YOLO11{args.scale} {args.dtype}, {H}x{W} batch={B} per GPU (fused Conv+BN+SiLU + HIP NMS), "
-                                   f"random-init weights, random uint8 NCHW images resident in HBM, conf {conf} iou {iou} max_det {max_det}; "
-                                   f"{S} batches in flight on {S} HIP streams (one hipGraph launch per step)",
+            "config": {"workload": workload,
                        "global_batch": world * B, "parallelism": f"dp{world}" if world > 1 else "single",
                        "streams": S, "candidate_fraction_target": args.cand_frac,
                        "mean_detections_per_image": None if ndet is None else round(ndet, 1)},
@@ -343,17 +346,53 @@ def main():
             "e2e_hbm_frac": (round(value * ACT_MELEM_AT_640[args.scale] * 2 * (H * W) / (640 * 640) / 1e3 / PEAK_HBM_GBS / world, 5)
                              if args.scale in ACT_MELEM_AT_640 else None),
         }
+        res.update(extra)
+        res["bench_config"] = cfg_key  # what profiles/*_traffic.json files are matched against
+        try:
+            probe = yl_lib.graph_branch_probe(dev)
+        except Exception as e:  # the probe must never cost the bench line
+            probe = {"error": repr(e)}
+        res["runtime"] = {"knobs": KNOBS, "graph_branch_probe": probe}
         if world == 1:
-            res["latency_ms_single_stream"] = round(latency_ms, 4)
-            rows = eng.profile(x8, iters=20)
-            roof, kernels = roofline_from_profile(rows, B)
+            rows = eng.profile_detect(x8, conf, iou, max_det=max_det, iters=20)
+            roof, kernels = roofline_from_profile(rows, B, cfg_key)
             res["roofline"] = roof
             res["kernels"] = kernels
+            res["launches_per_step"] = len(rows) + 1  # + the memset node in front of the candidate pre-filter
+            fused_bytes = sum(r["bytes"] for r in rows)
+            res["program_bytes_per_step"] = round(fused_bytes)
+            res["e2e_hbm_frac_fused_program"] = round(fused_bytes / (ms_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 5)
             if args.profile_out:
                 Path(args.profile_out).parent.mkdir(parents=True, exist_ok=True)
                 Path(args.profile_out).write_text(json.dumps(rows, indent=1))
+            # the reference API on the same resident batches: YOLOLite.predict -> DetectionPredictor -> one graph launch
+            try:
+                from yololite_amd import YOLOLite
+
+                if args.dtype == "bf16" and args.scale in "nsmlx":
+                    api = YOLOLite(f"yolo11{args.scale}.yaml")
+                    api.model.load_state_dict(sd)
+                    kw = dict(conf=conf, iou=iou, max_det=max_det, device=str(dev), save=False, verbose=False, batch=B)
+                    for _ in range(3):
+                        r_api = api.predict(x8, **kw)
+                    torch.cuda.synchronize(dev)
+                    n_api = 20
+                    t3 = time.perf_counter()
+                    for _ in range(n_api):
+                        r_api = api.predict(x8, **kw)
+                    torch.cuda.synchronize(dev)
+                    res["api_images_per_sec"] = round(B * n_api / (time.perf_counter() - t3), 1)
+                    res["api_note"] = ("YOLOLite.predict(uint8 tensor resident in HBM) incl. list[Results] construction and its one "
+                                       "host sync per batch; one batch at a time")
+                    o_ref, c_ref = eng.detect(x8, conf, iou, max_det=max_det, graph=False)
+                    res["api_equals_engine"] = all(torch.equal(r.boxes.data, o_ref[i, : int(c_ref[i])]) for i, r in enumerate(r_api))
+                    del api
+            except Exception as e:
+                res["api_images_per_sec"] = None
+                res["api_note"] = "failed: " + repr(e)
             if args.dtype == "fp8":
                 # the e4m3 program against the bf16 program of the same weights on the same images (SURVEY 8(d) gate)
+                from oracle.parity_gate import parity_gate
                 from yololite_amd.nn.engine import HipEngine
 
                 o8, c8 = eng.detect(x8, conf, iou, max_det=max_det, graph=False)
@@ -361,9 +400,10 @@ def main():
                 e16 = HipEngine.from_model(specs, sd, B, H, W, dev)
                 o16, c16 = e16.detect(x8, conf, iou, max_det=max_det, graph=False)
                 torch.cuda.synchronize(dev)
-                nb = min(B, 8)
-                res["fp8_vs_bf16"] = parity_gate([o16[i, : int(c16[i])].cpu() for i in range(nb)],
-                                                 [o8[i, : int(c8[i])].cpu() for i in range(nb)], conf, iou, band=0.15)
+                nb8 = min(B, 8)
+                res["fp8_vs_bf16"] = parity_gate([o16[i, : int(c16[i])].cpu() for i in range(nb8)],
+                                                 [o8[i, : int(c8[i])].cpu() for i in range(nb8)], conf, iou, band=0.15,
+                                                 min_matched_frac=0.75)
                 if l8 is not None:
                     l16 = e16.raw_levels()
                     res["fp8_vs_bf16"]["level_rel_l2"] = [round(float((a - b).norm() / b.norm()), 4) for a, b in zip(l8, l16)]
@@ -379,7 +419,8 @@ def main():
                 sb = min(8, B, n_img)
                 res["cpu_baseline"] = cpu_baseline(sd, args.scale, H, W, conf, iou, sample_b=sb, iters=max(1, n_img // sb),
                                                    eng=eng, dev=dev, max_det=max_det,
-                                                   band=0.12 if args.dtype == "fp8" else 0.08)  # stated tolerances
+                                                   band=0.12 if args.dtype == "fp8" else 0.08,  # stated tolerances
+                                                   band_bf16=0.12 if args.dtype == "fp8" else 0.03)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

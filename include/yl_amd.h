@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define YL_ABI_VERSION 11
+#define YL_ABI_VERSION 12
 
 /* element types */
 enum { YL_BF16 = 0, YL_F32 = 1, YL_F16 = 2, YL_U8 = 3, YL_FP8 = 4 /* OCP e4m3 */ };
@@ -184,6 +184,19 @@ int yl_engine_forward_graph(yl_engine* e, const void* input, int in_dtype, void*
  * ms[n_ops + 2]: [0] input conversion, [1..n_ops] ops, [n_ops+1] decode. Synchronises. */
 int yl_engine_profile(yl_engine* e, const void* input, int in_dtype, void* workspace, float* y,
                       void* stream, int iters, float* ms);
+/* The hot path as the benchmark runs it (network ops in program order on one stream, then the fused decode + NMS of
+ * yl_decode_nms), timed launch by launch with HIP events, averaged over `iters` passes after one warm-up.
+ *   ms_ops[n_ops]: the network ops;  ms_post[5]: {zero counters + class pre-filter (decode_candidates_*), exact
+ *   decode of the survivors, per-image sort, suppression mask, scan + scale_boxes + output}
+ * i.e. the kernels that replace nn/modules/head.py:95-126 and utils/ops.py:138-273.  Synchronises. */
+int yl_engine_profile_detect(yl_engine* e, const void* input, int in_dtype, void* workspace, float conf_thres,
+                             float iou_thres, int max_det, int max_cand, float* out, int32_t* out_count, void* work,
+                             void* stream, int iters, float* ms_ops, float* ms_post);
+/* Runtime self-check: replays a captured graph of two parallel branches, each one wave spinning for spin_us
+ * microseconds.  *ms_graph = best of three replays; *concurrent = 1 when the branches overlapped (time < 1.5 x
+ * spin_us), 0 when the HIP runtime serialised them (then the hot path's class-branch lane gives no overlap either;
+ * see _lib.apply_runtime_knobs for the environment the runtime needs). */
+int yl_graph_branch_probe(void* stream, int spin_us, float* ms_graph, int* concurrent);
 int yl_engine_num_ops(const yl_engine* e);
 /* Algorithmic work of op i: flops (2*MAC), bytes read+written once; name is a static string. */
 int yl_engine_op_info(const yl_engine* e, int i, double* flops, double* bytes, const char** kernel_name);

@@ -1,0 +1,108 @@
+"""Post-NMS parity gate between two detectors' outputs on the same images  --  TEST INFRASTRUCTURE ONLY
+(imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; never by yolo-lite_amd/).
+
+SURVEY.md section 8(d): boxes are paired one to one by IoU >= ``iou_match`` ALONE (neither the score nor the class
+takes part in the pairing, so a score drift larger than the tolerance shows up as ``max_dconf`` instead of hiding as
+an unmatched box); then
+
+* every pair must agree on the class exactly (``class_mismatch``); the one admissible difference, counted apart as
+  ``class_near_tie`` and only when the reference's pre-NMS tensor is supplied, is an argmax flip between two classes
+  that the reference itself scores within ``band`` of each other at that anchor;
+* ``max_dconf`` (largest |score difference| over the pairs) must not exceed ``band``;
+* a box present on one side only must be explained by ONE of two stated mechanisms, counted separately:
+  ``near_threshold`` -- its score lies within ``band`` of the confidence threshold, so the other side's score fell
+  below it -- or ``nms_flip`` -- a same-class box of the other side overlaps it with IoU within ``iou_band`` of the
+  NMS threshold (or one of its own side's boxes does: the keep / suppress decision flipped);
+* at least ``min_matched_frac`` of the reference's boxes must be paired.
+
+``band`` is the stated score tolerance of the comparison being made (see tests/test_gpu_net.py for the two in use:
+the HIP path against the bf16-storage oracle, and the bf16 format against the fp32 reference).
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+
+
+def box_iou1(a: Sequence[float], b: Sequence[float]) -> float:
+    iw = min(float(a[2]), float(b[2])) - max(float(a[0]), float(b[0]))
+    ih = min(float(a[3]), float(b[3])) - max(float(a[1]), float(b[1]))
+    inter = max(iw, 0.0) * max(ih, 0.0)
+    ua = (float(a[2]) - float(a[0])) * (float(a[3]) - float(a[1])) + (float(b[2]) - float(b[0])) * (float(b[3]) - float(b[1])) - inter
+    return inter / ua if ua > 0 else 0.0
+
+
+def _argmax_near_tie(y_img: torch.Tensor, r, d, band: float) -> bool:
+    """y_img: the reference's pre-NMS tensor of the image, (4 + nc, A).  True when reference box r comes from an anchor
+    whose score for d's class lies within ``band`` of its best score."""
+    cx, cy, w, h = y_img[0], y_img[1], y_img[2], y_img[3]
+    box = torch.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], 1)
+    hit = ((box - torch.tensor(r[:4])).abs().amax(1) < 1e-2).nonzero().flatten().tolist()
+    for a in hit:
+        sc = y_img[4:, a]
+        if int(sc.argmax()) == int(r[5]) and float(sc[int(d[5])]) >= float(sc.max()) - band:
+            return True
+    return False
+
+
+def parity_gate(ref_dets: List[torch.Tensor], got_dets: List[torch.Tensor], conf: float, iou: float, band: float,
+                iou_match: float = 0.9, iou_band: float = 0.1, min_matched_frac: float = 0.9,
+                ref_y: Optional[torch.Tensor] = None, verbose: bool = False) -> dict:
+    """ref_dets / got_dets: per image (n, 6) [x1, y1, x2, y2, conf, cls] score-descending.  Returns the statistics
+    dict with ``ok``."""
+    st = dict(ref=0, det=0, matched=0, class_mismatch=0, class_near_tie=0, unexplained=0, near_threshold=0, nms_flip=0,
+              max_dconf=0.0)
+    dconfs: List[float] = []
+    for img, (ref, det) in enumerate(zip(ref_dets, got_dets)):
+        ref, det = ref.tolist(), det.tolist()
+        st["ref"] += len(ref)
+        st["det"] += len(det)
+        used = set()
+
+        def one_sided(box, same_side, other_side):
+            if box[4] <= conf + band:
+                st["near_threshold"] += 1
+                return
+            flip = any(o is not box and o[5] == box[5] and iou - iou_band <= box_iou1(o, box) < iou_match
+                       for o in list(other_side) + list(same_side))
+            if flip:
+                st["nms_flip"] += 1
+            else:
+                st["unexplained"] += 1
+                if verbose:
+                    near = max(((box_iou1(o, box), o[4], o[5]) for o in other_side), default=None)
+                    print("unexplained", [round(v, 3) for v in box], "nearest on the other side (iou, conf, cls)", near)
+
+        for r in ref:
+            best, hit = iou_match, None
+            for j, d in enumerate(det):
+                if j in used:
+                    continue
+                v = box_iou1(d, r)
+                if v >= best:
+                    best, hit = v, j
+            if hit is None:
+                one_sided(r, ref, det)
+                continue
+            used.add(hit)
+            st["matched"] += 1
+            dconfs.append(abs(det[hit][4] - r[4]))
+            if det[hit][5] != r[5]:
+                if ref_y is not None and _argmax_near_tie(ref_y[img], r, det[hit], band):
+                    st["class_near_tie"] += 1
+                else:
+                    st["class_mismatch"] += 1
+        for j, d in enumerate(det):
+            if j not in used:
+                one_sided(d, det, ref)
+    if dconfs:
+        t = torch.tensor(dconfs)
+        st["max_dconf"] = round(float(t.max()), 4)
+        st["p50_dconf"] = round(float(t.median()), 5)
+        st["p99_dconf"] = round(float(t.kthvalue(max(1, int(0.99 * len(dconfs)))).values), 4)
+    st["matched_frac"] = round(st["matched"] / max(1, st["ref"]), 4)
+    st["score_band"] = band
+    st["ok"] = bool(st["class_mismatch"] == 0 and st["unexplained"] == 0 and st["matched"] > 0
+                    and st["max_dconf"] <= band and st["matched_frac"] >= min_matched_frac)
+    return st

@@ -10,6 +10,10 @@ if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
+from yololite_amd import _lib as _yl_lib  # noqa: E402
+
+_yl_lib.apply_runtime_knobs()  # before any test touches the GPU (see _lib.RUNTIME_KNOBS)
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

@@ -137,7 +137,7 @@ def test_fp8_end_to_end_640_vs_reference_golden(gpu_device, golden):
     """Post-NMS detections of the e4m3 program at 640x640 against the REFERENCE's fp32 detections (golden_v1.npz):
     same gate as the bf16 path (one-to-one IoU >= 0.9, matched classes bit-exact, nothing unexplained) with the score
     band widened to the stated fp8 tolerance."""
-    from test_gpu_net import match_detections
+    from oracle.parity_gate import parity_gate
     from yololite_amd.nn import arch
     from yololite_amd.nn.engine import HipEngine
     from yololite_amd.nn.synth import synth_state_dict
@@ -154,11 +154,10 @@ def test_fp8_end_to_end_640_vs_reference_golden(gpu_device, golden):
     assert dscore <= FP8_SCORE_ATOL
     det = hops.non_max_suppression(y, 0.25, 0.7)[0].cpu()
     ref = torch.from_numpy(golden["net_n_640_det0"])
-    stats = match_detections(det, ref, conf_thres=0.25, iou_thres=0.7, band=FP8_SCORE_ATOL)
+    stats = parity_gate([ref], [det], 0.25, 0.7, band=FP8_SCORE_ATOL, min_matched_frac=0.75, verbose=True)
     print("fp8 e2e 640 match:", stats)
     assert stats["class_mismatch"] == 0, "class indices of matched boxes must be bit-exact"
-    assert stats["ref_unexplained"] == 0 and stats["det_unexplained"] == 0, stats
-    assert stats["matched"] >= 0.5 * stats["ref_mandatory"]
+    assert stats["ok"], stats
 
 
 @pytest.mark.parametrize("producer", ["bf16", "fp8"])

@@ -28,6 +28,22 @@ def test_device_letterbox_bit_exact(gpu_device, h, w, new_shape, auto):
     np.testing.assert_array_equal(got, ref)
 
 
+@pytest.mark.parametrize("h,w,new_shape,auto", [(1080, 1920, (640, 640), True), (480, 640, (640, 640), True),
+                                                 (500, 381, (640, 640), True), (37, 91, (96, 128), False)])
+def test_device_letterbox_within_one_lsb_of_float_definition(gpu_device, h, w, new_shape, auto):
+    """The HIP kernel against the INDEPENDENT float64 definition of INTER_LINEAR (oracle/letterbox_oracle.py), not against
+    the product's own integer restatement: at most 1 LSB (OpenCV's 11-bit fixed-point rounding), same geometry and
+    channel order."""
+    from oracle import letterbox_oracle as lbo
+
+    g = np.random.default_rng(h * 11 + w)
+    images = [g.integers(0, 256, (h, w, 3), dtype=np.uint8) for _ in range(2)]
+    got = DeviceLetterBox(new_shape, auto=auto, device=gpu_device)(images).cpu().numpy().astype(np.float64)
+    ref = np.stack([lbo.letterbox_f64(im, new_shape, auto=auto) for im in images])[..., ::-1].transpose(0, 3, 1, 2)
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() <= 1.0
+
+
 def test_device_letterbox_rejects_mixed_shapes(gpu_device):
     g = np.random.default_rng(0)
     images = [g.integers(0, 256, (100, 200, 3), dtype=np.uint8), g.integers(0, 256, (200, 100, 3), dtype=np.uint8)]

@@ -4,6 +4,7 @@ import pytest
 import torch
 
 from oracle import yolo11_oracle as oracle
+from oracle.parity_gate import parity_gate
 from yololite_amd.nn import arch
 from yololite_amd.nn.engine import HipEngine
 from yololite_amd.nn.synth import synth_state_dict
@@ -11,16 +12,22 @@ from yololite_amd.utils import ops as hops
 
 pytestmark = pytest.mark.gpu
 
-# Tolerances of the bf16 network against the fp32 oracle (measured on MI355X, see DESIGN.md
-# "Numerics"): activations are stored in bf16 (8 significant bits) between ~25 sequential convs, so
-# per-layer relative L2 error grows to about 1 %; box side distances carry that error times the stride.
-#   measured (round 1): worst per-layer relative L2 error 0.0059 (n, 64x64, all 23 layers);
-#   max |dscore| 0.0244 over 1.4 M scores with class-logit std ~5 (synthetic cls_gain 8: sigmoid
-#   slope 0.25 x logit error ~0.1); max box error 0.21 strides with box-logit std ~2.5.
-# The bounds leave ~1.5x margin over those measurements.
+# Two comparisons, two tolerances (profiles/r02_parity_probe.json holds the measurements behind them):
+#
+# (a) HIP path vs the REFERENCE (fp32 goldens / fp32 oracle): the distance is the bf16 storage FORMAT, not the kernels:
+#     the oracle's own bf16-storage mode -- fp32 arithmetic on the CPU, tensors rounded where the HIP path stores bf16 --
+#     sits at the same distance from the fp32 reference (tests/test_oracle_golden.py::test_bf16_storage_format_error:
+#     max |dscore| 0.074, boxes 0.22 strides at 640x640; class-logit std ~5 from the synthetic cls_gain 8).
+#       measured HIP vs fp32: per-layer rel L2 <= 0.0059, max |dscore| 0.075, boxes 0.21 strides.
 LAYER_REL_L2 = 0.015
 SCORE_ATOL = 0.08
 BOX_ATOL_STRIDES = 0.35  # box coordinate error allowed, in units of the level stride
+# (b) HIP path vs the bf16-storage oracle: what is left to the kernels themselves (MFMA accumulation order, hardware
+#     exp / rcp in SiLU and softmax); a tensor element differs only where such a 1e-6 difference crosses a bf16
+#     rounding boundary.  Bounds = measured maxima x ~2 (tools/parity_probe.py).
+BF16_LEVEL_REL_L2 = 0.004
+BF16_SCORE_ATOL = 0.03
+BF16_BOX_ATOL_STRIDES = 0.12
 
 
 def _engine(scale, sd, b, h, w, dev, keep_layers=False):
@@ -201,7 +208,9 @@ def test_nms_scale_boxes_fused(gpu_device):
 
 
 def test_end_to_end_640_vs_golden(gpu_device, golden):
-    """Post-NMS detections at 640x640 (bf16 network) matched against the reference's fp32 detections."""
+    """Post-NMS detections at 640x640 (bf16 network) paired with the REFERENCE's fp32 detections (golden_v1.npz) by
+    IoU alone: classes bit-exact, max |dconf| inside the stated format band, >= 90 % of the reference's boxes paired,
+    every one-sided box explained by the threshold band or an NMS flip (oracle/parity_gate.py)."""
     sd = synth_state_dict("n", 0, cls_bias=list(golden["net_n_640_bias"]), cls_gain=8.0)
     x = torch.rand(1, 3, 640, 640, generator=torch.Generator().manual_seed(300))
     eng = _engine("n", sd, 1, 640, 640, gpu_device)
@@ -209,59 +218,45 @@ def test_end_to_end_640_vs_golden(gpu_device, golden):
     np.testing.assert_allclose(y[:, 4:, ::37].cpu().numpy(), golden["net_n_640_ysub"][:, 4:], atol=SCORE_ATOL)
     det = hops.non_max_suppression(y, 0.25, 0.7)[0].cpu()
     ref = torch.from_numpy(golden["net_n_640_det0"])
-    stats = match_detections(det, ref, conf_thres=0.25, iou_thres=0.7)
-    print("e2e 640 match:", stats)
+    stats = parity_gate([ref], [det], 0.25, 0.7, band=SCORE_ATOL, verbose=True)
+    print("e2e 640 vs reference golden:", stats)
     assert stats["class_mismatch"] == 0, "class indices of matched boxes must be bit-exact"
-    assert stats["ref_unexplained"] == 0 and stats["det_unexplained"] == 0, stats
-    assert stats["matched"] >= 0.5 * stats["ref_mandatory"]
+    assert stats["ok"], stats
 
 
-def _iou(a, b):
-    x1, y1 = max(float(a[0]), float(b[0])), max(float(a[1]), float(b[1]))
-    x2, y2 = min(float(a[2]), float(b[2])), min(float(a[3]), float(b[3]))
-    inter = max(x2 - x1, 0.0) * max(y2 - y1, 0.0)
-    ua = float((a[2] - a[0]) * (a[3] - a[1]) + (b[2] - b[0]) * (b[3] - b[1])) - inter
-    return inter / ua if ua > 0 else 0.0
+@pytest.mark.parametrize("scale,h,w,seed,key", [("n", 64, 64, 0, "net_n_64x64"), ("n", 96, 128, 1, "net_n_96x128"),
+                                                ("s", 64, 64, 2, "net_s_64x64"), ("x", 64, 64, 4, "net_x_64x64")])
+def test_net_vs_bf16_storage_oracle(gpu_device, golden, scale, h, w, seed, key):
+    """Comparison (b): the HIP network against the oracle's bf16-storage mode on the golden inputs."""
+    sd = synth_state_dict(scale, seed, cls_bias=list(golden[key + "_bias"]), cls_gain=8.0)
+    x = torch.from_numpy(golden[key + "_x"])
+    eng = _engine(scale, sd, x.shape[0], h, w, gpu_device)
+    y = eng.forward(x.to(gpu_device)).cpu()
+    with torch.inference_mode():
+        yr, raw = oracle.forward(sd, x, scale, storage="bf16")
+    st = _stride_per_anchor(h, w)
+    box_err = float(((y[:, :4] - yr[:, :4]).abs() / st).max())
+    score_err = float((y[:, 4:] - yr[:, 4:]).abs().max())
+    rels = [float((a.cpu() - b).norm() / b.norm()) for a, b in zip(eng.raw_levels(), raw)]
+    print(f"{key} vs bf16-storage oracle: score {score_err:.4f} box {box_err:.4f} strides, level rel L2 {rels}")
+    assert box_err < BF16_BOX_ATOL_STRIDES and score_err < BF16_SCORE_ATOL
+    assert max(rels) < BF16_LEVEL_REL_L2, rels
 
 
-def match_detections(det, ref, conf_thres, iou_thres, band=SCORE_ATOL, iou_match=0.9, iou_band=0.1):
-    """SURVEY.md section 8(d) parity gate.  Greedy one-to-one match by IoU >= 0.9 and |dconf| <= band;
-    matched pairs must agree on the class exactly.  A detection present on one side only is
-    "explained" when its score lies inside the don't-care band around the confidence threshold,
-    or when a same-class box of the other side overlaps it with IoU within `iou_band` of the NMS
-    threshold (its keep/suppress decision flips under bf16 rounding)."""
-    used = set()
-    st = dict(ref=len(ref), det=len(det), matched=0, class_mismatch=0, ref_mandatory=0, ref_unexplained=0,
-              det_unexplained=0)
-
-    def explained(box, others):
-        if float(box[4]) <= conf_thres + band:
-            return True
-        return any(o[5] == box[5] and iou_thres - iou_band <= _iou(o[:4], box[:4]) < iou_match for o in others)
-
-    for r in ref:
-        if float(r[4]) > conf_thres + band:
-            st["ref_mandatory"] += 1
-        hit = None
-        for j, d in enumerate(det):
-            if j not in used and _iou(d[:4], r[:4]) >= iou_match and abs(float(d[4] - r[4])) <= band:
-                hit = j
-                break
-        if hit is None:
-            if not explained(r, det):
-                st["ref_unexplained"] += 1
-                near = max(((_iou(d[:4], r[:4]), float(d[4]), float(d[5])) for d in det), default=None)
-                print("unexplained ref", [round(float(v), 3) for v in r], "nearest det (iou, conf, cls)", near)
-        else:
-            used.add(hit)
-            st["matched"] += 1
-            st["class_mismatch"] += int(det[hit][5] != r[5])
-    for j, d in enumerate(det):
-        if j not in used and not explained(d, ref):
-            st["det_unexplained"] += 1
-            near = max(((_iou(r[:4], d[:4]), float(r[4]), float(r[5])) for r in ref), default=None)
-            print("unexplained det", [round(float(v), 3) for v in d], "nearest ref (iou, conf, cls)", near)
-    return st
+def test_end_to_end_640_vs_bf16_storage_oracle(gpu_device, golden):
+    """Comparison (b) after NMS, 4 images at 640x640: the gate with the kernels' own (tight) band."""
+    sd = synth_state_dict("n", 0, cls_bias=list(golden["net_n_640_bias"]), cls_gain=8.0)
+    x = torch.rand(4, 3, 640, 640, generator=torch.Generator().manual_seed(300))
+    eng = _engine("n", sd, 4, 640, 640, gpu_device)
+    out, cnt = eng.detect(x.to(gpu_device), 0.25, 0.7, graph=False)
+    got = [out[i, : int(cnt[i])].cpu() for i in range(4)]
+    torch.set_num_threads(8)
+    with torch.inference_mode():
+        y16, _ = oracle.forward(sd, x, "n", storage="bf16")
+    ref = oracle.non_max_suppression(y16, 0.25, 0.7)
+    stats = parity_gate(ref, got, 0.25, 0.7, band=BF16_SCORE_ATOL, ref_y=y16, verbose=True)
+    print("e2e 640 vs bf16-storage oracle:", stats)
+    assert stats["ok"] and stats["class_near_tie"] <= 1, stats
 
 
 @pytest.mark.parametrize("kw", [dict(conf=0.25, iou=0.7), dict(conf=0.25, iou=0.7, classes=[1, 27, 40]),

@@ -65,6 +65,16 @@ def family(k):
         return "sppf_maxpool"
     if k.startswith("attention_kernel"):
         return "attention"
+    if k.startswith("decode_candidates_sparse"):
+        return "decode_candidates_sparse"
+    if k.startswith("decode_exact"):
+        return "decode_exact"
+    if k.startswith("nms_sort"):
+        return "nms_sort"
+    if k.startswith("nms_mask"):
+        return "nms_mask"
+    if k.startswith("nms_scan"):
+        return "nms_scan"
     return None
 
 
@@ -128,6 +138,8 @@ def main():
                    "launches_in_trace": a["launches"]} for f, a in fam.items()}
     traffic["_source"] = (f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py, {tag}; "
                           "read side = 2 x FETCH_SIZE (gfx950 correction, MI355X_MICROARCH.md)")
+    # the configuration these counters belong to: bench.py only quotes a traffic file whose _config equals its own
+    traffic["_config"] = (bench or {}).get("bench_config")
     (dst / f"{tag}_traffic.json").write_text(json.dumps(traffic, indent=1))
     print("\n".join(lines[:40]))
 

@@ -9,14 +9,55 @@ import ctypes as C
 import os
 from pathlib import Path
 
-# The hot path replays as a hipGraph with exactly two parallel branches (network trunk + the 80x80 class
-# branch).  With the runtime's default graph-queue heuristic the branch often ends up serialised behind the
-# trunk (measured: 27.0 k vs 33.3 k images/s) -- two forced graph queues make the mapping deterministic.
-# Must be in the environment before the HIP runtime initialises, hence at import time.
-os.environ.setdefault("DEBUG_HIP_FORCE_GRAPH_QUEUES", "2")
-# Four batches in flight x two graph queues each = eight streams: give each its own hardware queue
-# (the runtime's default of four makes them share; 37.4 k -> 38.6 k images/s).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# Runtime knobs of the HIP runtime that the hot path's speed depends on.  They are NOT set at import: call
+# ``apply_runtime_knobs()`` (bench.py, tests/conftest.py, __graft_entry__ and AutoBackend do) before the first GPU
+# call of the process; ``runtime_knob_status()`` says whether that happened in time, and ``graph_branch_probe()``
+# measures on the device whether two graph branches really overlap.
+#   DEBUG_HIP_FORCE_GRAPH_QUEUES=2  the hot path replays as a hipGraph with exactly two parallel branches (network
+#       trunk + the 80x80 class branch).  With the runtime's default graph-queue heuristic the branch often ends up
+#       serialised behind the trunk (measured: 27.0 k vs 33.3 k images/s); two forced graph queues make the mapping
+#       deterministic.
+#   GPU_MAX_HW_QUEUES=8  several batches in flight x two graph queues each: give each stream its own hardware queue
+#       (the runtime's default of four makes them share; 37.4 k -> 38.6 k images/s).
+RUNTIME_KNOBS = {"DEBUG_HIP_FORCE_GRAPH_QUEUES": "2", "GPU_MAX_HW_QUEUES": "8"}
+_knob_status = {"applied": False, "before_hip_init": None, "values": {}}
+
+
+def apply_runtime_knobs() -> dict:
+    """Put RUNTIME_KNOBS into the environment (values already present win) and record whether the HIP runtime of this
+    process can still see them: it reads its flags once, when it initialises.  Returns ``runtime_knob_status()``."""
+    import sys
+
+    early = True
+    t = sys.modules.get("torch")
+    if t is not None and t.cuda.is_initialized():
+        early = False
+    if _lib is not None and not _knob_status["applied"]:
+        early = False  # libyl_amd.so was already driven without them
+    for k, v in RUNTIME_KNOBS.items():
+        os.environ.setdefault(k, v)
+    if not _knob_status["applied"]:
+        _knob_status.update(applied=True, before_hip_init=early)
+    _knob_status["values"] = {k: os.environ.get(k) for k in RUNTIME_KNOBS}
+    return runtime_knob_status()
+
+
+def runtime_knob_status() -> dict:
+    return {"applied": _knob_status["applied"], "before_hip_init": _knob_status["before_hip_init"],
+            **{k: os.environ.get(k) for k in RUNTIME_KNOBS}}
+
+
+def graph_branch_probe(device=None, spin_us: int = 300) -> dict:
+    """Device-side check that two parallel branches of a captured graph overlap (yl_graph_branch_probe)."""
+    import torch
+
+    dev = torch.device(device if device is not None else "cuda:0")
+    ms, conc = C.c_float(), C.c_int()
+    with torch.cuda.device(dev):
+        check(lib().yl_graph_branch_probe(torch.cuda.current_stream(dev).cuda_stream, int(spin_us), C.byref(ms), C.byref(conc)),
+              "yl_graph_branch_probe")
+    return {"spin_us": spin_us, "graph_ms": round(ms.value, 4), "concurrent": bool(conc.value)}
+
 
 _PKG = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ["YL_AMD_LIB"]) if os.environ.get("YL_AMD_LIB") else _PKG / "libyl_amd.so"  # dev override
@@ -28,7 +69,8 @@ EXPORTS = (
     "yl_last_error", "yl_abi_version", "yl_device_count", "yl_engine_create", "yl_engine_destroy",
     "yl_engine_prepare_workspace", "yl_engine_forward", "yl_engine_forward_graph", "yl_engine_profile", "yl_engine_num_ops",
     "yl_engine_op_info", "yl_engine_detect_graph", "yl_detect_decode", "yl_nms_workspace_bytes", "yl_nms", "yl_decode_nms",
-    "yl_preprocess_u8", "yl_letterbox_u8", "yl_nms_ml_workspace_bytes", "yl_nms_ml",
+    "yl_preprocess_u8", "yl_letterbox_u8", "yl_nms_ml_workspace_bytes", "yl_nms_ml", "yl_engine_profile_detect",
+    "yl_graph_branch_probe",
 )
 
 
@@ -132,7 +174,12 @@ def lib() -> C.CDLL:
     L.yl_preprocess_u8.argtypes = [vp, i32, i32, i32, vp, vp]
     L.yl_letterbox_u8.restype = i32
     L.yl_letterbox_u8.argtypes = [vp, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]
-    if L.yl_abi_version() != 11:
+    L.yl_engine_profile_detect.restype = i32
+    L.yl_engine_profile_detect.argtypes = [vp, vp, i32, vp, f32, f32, i32, i32, vp, vp, vp, vp, i32, C.POINTER(f32),
+                                           C.POINTER(f32)]
+    L.yl_graph_branch_probe.restype = i32
+    L.yl_graph_branch_probe.argtypes = [vp, i32, C.POINTER(f32), C.POINTER(C.c_int)]
+    if L.yl_abi_version() != 12:
         raise RuntimeError("libyl_amd.so ABI version mismatch; rebuild it")
     _lib = L
     return L

@@ -57,12 +57,46 @@ struct yl_engine {
       return std::tie(in, dt, ws, y) < std::tie(o.in, o.dt, o.ws, o.y);
     }
   };
-  std::map<GraphKey, hipGraphExec_t> graphs;
+  // Instantiated graphs, least recently used first out.  An executable may still be running on some slot's stream
+  // when the cache is full, so eviction waits for the device and then destroys exactly ONE entry (the stalest);
+  // 32 entries = 5-8 slots x a few threshold settings before anything is ever evicted.
+  template <typename K>
+  struct GraphCache {
+    struct Ent {
+      hipGraphExec_t exec;
+      uint64_t used;
+    };
+    std::map<K, Ent> m;
+    uint64_t tick = 0;
+    size_t cap = 32;
+    hipGraphExec_t find(const K& k) {
+      auto it = m.find(k);
+      if (it == m.end()) return nullptr;
+      it->second.used = ++tick;
+      return it->second.exec;
+    }
+    void insert(const K& k, hipGraphExec_t ge) {
+      if (m.size() >= cap) {
+        (void)hipDeviceSynchronize();
+        auto lru = m.begin();
+        for (auto it = m.begin(); it != m.end(); ++it)
+          if (it->second.used < lru->second.used) lru = it;
+        (void)hipGraphExecDestroy(lru->second.exec);
+        m.erase(lru);
+      }
+      m[k] = Ent{ge, ++tick};
+    }
+    void clear() {
+      for (auto& kv : m) (void)hipGraphExecDestroy(kv.second.exec);
+      m.clear();
+    }
+  };
+  GraphCache<GraphKey> graphs;
   // whole hot path (network + fused decode + NMS) as one graph, keyed by every baked-in argument
   typedef std::tuple<const void*, int, void*, float, float, int, int, const void*, int, int, float, const void*, void*,
                      void*, void*>
       DetectKey;
-  std::map<DetectKey, hipGraphExec_t> dgraphs;
+  GraphCache<DetectKey> dgraphs;
   // Per workspace (= per batch in flight): a private capture stream, one non-blocking stream per side
   // lane (yl_op.lane > 0) and a pool of fork/join events.  Batches that are in flight on different
   // caller streams use different workspaces; giving each its own lane streams keeps their graphs from
@@ -152,8 +186,8 @@ extern "C" int yl_device_count(void) {
 
 extern "C" void yl_engine_destroy(yl_engine* e) {
   if (!e) return;
-  for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
-  for (auto& kv : e->dgraphs) (void)hipGraphExecDestroy(kv.second);
+  e->graphs.clear();
+  e->dgraphs.clear();
   for (auto& kv : e->sets) {
     if (kv.second.cap) (void)hipStreamDestroy(kv.second.cap);
     for (hipStream_t st : kv.second.lanes)
@@ -886,12 +920,8 @@ extern "C" int yl_engine_forward_graph(yl_engine* e, const void* input, int in_d
   if (!e || !input || !workspace) return fail(-1, "yl_engine_forward_graph: null pointer");
   hipStream_t s = (hipStream_t)stream;
   yl_engine::GraphKey key{input, in_dtype, workspace, y};
-  auto it = e->graphs.find(key);
-  if (it == e->graphs.end()) {
-    if (e->graphs.size() >= 8) {  // pointers keep changing: drop the stale executables
-      for (auto& kv : e->graphs) (void)hipGraphExecDestroy(kv.second);
-      e->graphs.clear();
-    }
+  hipGraphExec_t exec = e->graphs.find(key);
+  if (!exec) {
     // run once eagerly so lazy one-time setup (function attributes) happens outside the capture
     if (int rc = yl_engine_forward(e, input, in_dtype, workspace, y, stream)) return rc;
     YL_HIP(hipStreamSynchronize(s));
@@ -912,9 +942,10 @@ extern "C" int yl_engine_forward_graph(yl_engine* e, const void* input, int in_d
     hipError_t ie = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
     (void)hipGraphDestroy(g);
     if (ie != hipSuccess) return fail(-2, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie));
-    it = e->graphs.emplace(key, ge).first;
+    e->graphs.insert(key, ge);
+    exec = ge;
   }
-  YL_HIP(hipGraphLaunch(it->second, s));
+  YL_HIP(hipGraphLaunch(exec, s));
   return 0;
 }
 
@@ -937,12 +968,8 @@ extern "C" int yl_engine_detect_graph(yl_engine* e, const void* input, int in_dt
   hipStream_t s = (hipStream_t)stream;
   yl_engine::DetectKey key(input, in_dtype, workspace, conf_thres, iou_thres, max_det, agnostic, classes, n_classes,
                            max_cand, max_wh, scale, out, out_count, work);
-  auto it = e->dgraphs.find(key);
-  if (it == e->dgraphs.end()) {
-    if (e->dgraphs.size() >= 8) {
-      for (auto& kv : e->dgraphs) (void)hipGraphExecDestroy(kv.second);
-      e->dgraphs.clear();
-    }
+  hipGraphExec_t exec = e->dgraphs.find(key);
+  if (!exec) {
     // eager first: argument checks, workspace preparation and lazy function attributes happen here
     if (int rc = detect_eager(e, input, in_dtype, workspace, conf_thres, iou_thres, max_det, agnostic, classes,
                               n_classes, max_cand, max_wh, scale, out, out_count, work, stream))
@@ -964,9 +991,10 @@ extern "C" int yl_engine_detect_graph(yl_engine* e, const void* input, int in_dt
     hipError_t ie = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
     (void)hipGraphDestroy(g);
     if (ie != hipSuccess) return fail(-2, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie));
-    it = e->dgraphs.emplace(key, ge).first;
+    e->dgraphs.insert(key, ge);
+    exec = ge;
   }
-  YL_HIP(hipGraphLaunch(it->second, s));
+  YL_HIP(hipGraphLaunch(exec, s));
   return 0;
 }
 
@@ -1015,6 +1043,126 @@ extern "C" int yl_engine_profile(yl_engine* e, const void* input, int in_dtype, 
   for (int i = 0; i < n + 2; ++i) ms[i] = (float)(acc[i] / iters);
   for (auto& x : ev) (void)hipEventDestroy(x);
   return rc;
+}
+
+// The hot path as bench.py runs it, timed launch by launch: every network op in program order on ONE stream (side
+// lanes folded into it), then the five stages of yl_decode_nms.  ms_ops[n_ops], ms_post[5].
+extern "C" int yl_engine_profile_detect(yl_engine* e, const void* input, int in_dtype, void* workspace, float conf_thres,
+                                        float iou_thres, int max_det, int max_cand, float* out, int32_t* out_count,
+                                        void* work, void* stream, int iters, float* ms_ops, float* ms_post) {
+  if (!e || !input || !workspace || !out || !out_count || !work || !ms_ops || !ms_post || iters <= 0)
+    return fail(-1, "yl_engine_profile_detect: bad arguments");
+  if (e->levels.empty()) return fail(-1, "yl_engine_profile_detect: engine has no Detect levels");
+  hipStream_t s = (hipStream_t)stream;
+  char* ws = (char*)workspace;
+  if (int rc = detect_eager(e, input, in_dtype, workspace, conf_thres, iou_thres, max_det, 0, nullptr, 0, max_cand, 7680.f,
+                            nullptr, out, out_count, work, stream))
+    return rc;
+  YL_HIP(hipStreamSynchronize(s));
+  const int n = (int)e->ops.size();
+  std::vector<hipEvent_t> ev((size_t)n + 1), pv(6);
+  for (auto& x : ev) YL_HIP(hipEventCreate(&x));
+  for (auto& x : pv) YL_HIP(hipEventCreate(&x));
+  std::vector<double> acc((size_t)n, 0.0), pacc(5, 0.0);
+  int rc = 0;
+  const bool stem = e->ops[0].op.kind == YL_OP_STEM || e->ops[0].d_w0;
+  for (int it = 0; it < iters && !rc; ++it) {
+    if (!stem) rc = run_convert(e, input, in_dtype, ws, s);
+    (void)hipEventRecord(ev[0], s);
+    for (int i = 0; i < n && !rc; ++i) {
+      rc = run_op(e, e->ops[i], ws, s, input, in_dtype);
+      (void)hipEventRecord(ev[i + 1], s);
+    }
+    if (!rc)
+      rc = decode_nms_stages(workspace, e->levels.data(), (int)e->levels.size(), e->batch, e->nc, conf_thres, iou_thres,
+                             max_det, 0, nullptr, 0, max_cand, 7680.f, nullptr, out, out_count, work, stream, pv.data());
+    if (!rc && hipEventSynchronize(pv[5]) != hipSuccess) rc = fail(-2, "hipEventSynchronize failed");
+    for (int i = 0; i < n && !rc; ++i) {
+      float t = 0.f;
+      (void)hipEventElapsedTime(&t, ev[i], ev[i + 1]);
+      acc[i] += t;
+    }
+    for (int i = 0; i < 5 && !rc; ++i) {
+      float t = 0.f;
+      (void)hipEventElapsedTime(&t, pv[i], pv[i + 1]);
+      pacc[i] += t;
+    }
+  }
+  for (int i = 0; i < n; ++i) ms_ops[i] = (float)(acc[i] / iters);
+  for (int i = 0; i < 5; ++i) ms_post[i] = (float)(pacc[i] / iters);
+  for (auto& x : ev) (void)hipEventDestroy(x);
+  for (auto& x : pv) (void)hipEventDestroy(x);
+  return rc;
+}
+
+// Do two parallel branches of a captured graph really run concurrently on this runtime?  (The hot path's graph has
+// exactly two; whether the runtime maps them to two hardware queues depends on DEBUG_HIP_FORCE_GRAPH_QUEUES being in
+// the environment before HIP initialised -- _lib.apply_runtime_knobs.)  Two one-wave kernels that each spin for
+// `spin_us` of the constant 100 MHz clock are captured as a fork / join; the replay takes ~spin_us when they overlap
+// and ~2 x spin_us when the runtime serialises them.
+__global__ void spin_kernel(unsigned long long ticks) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+extern "C" int yl_graph_branch_probe(void* stream, int spin_us, float* ms_graph, int* concurrent) {
+  if (!ms_graph || !concurrent || spin_us <= 0 || spin_us > 100000) return fail(-1, "yl_graph_branch_probe: bad arguments");
+  hipStream_t s = (hipStream_t)stream;
+  hipStream_t cap = nullptr, side = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr, t0 = nullptr, t1 = nullptr;
+  hipGraph_t g = nullptr;
+  hipGraphExec_t ge = nullptr;
+  int rc = 0;
+  const unsigned long long ticks = (unsigned long long)spin_us * 100ull;
+  auto cleanup = [&]() {
+    if (ge) (void)hipGraphExecDestroy(ge);
+    if (g) (void)hipGraphDestroy(g);
+    for (hipEvent_t ev : {fork, join, t0, t1})
+      if (ev) (void)hipEventDestroy(ev);
+    if (cap) (void)hipStreamDestroy(cap);
+    if (side) (void)hipStreamDestroy(side);
+  };
+#define YL_PROBE(expr)                                                                 \
+  do {                                                                                 \
+    hipError_t _e = (expr);                                                            \
+    if (_e != hipSuccess) {                                                            \
+      rc = fail(-2, std::string(#expr) + ": " + hipGetErrorString(_e));                \
+      cleanup();                                                                       \
+      return rc;                                                                       \
+    }                                                                                  \
+  } while (0)
+  YL_PROBE(hipStreamCreateWithFlags(&cap, hipStreamNonBlocking));
+  YL_PROBE(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+  YL_PROBE(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
+  YL_PROBE(hipEventCreateWithFlags(&join, hipEventDisableTiming));
+  YL_PROBE(hipEventCreate(&t0));
+  YL_PROBE(hipEventCreate(&t1));
+  YL_PROBE(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
+  YL_PROBE(hipEventRecord(fork, cap));
+  YL_PROBE(hipStreamWaitEvent(side, fork, 0));
+  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, cap, ticks);
+  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, side, ticks);
+  YL_PROBE(hipEventRecord(join, side));
+  YL_PROBE(hipStreamWaitEvent(cap, join, 0));
+  YL_PROBE(hipStreamEndCapture(cap, &g));
+  YL_PROBE(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+  YL_PROBE(hipGraphLaunch(ge, s));  // warm-up
+  YL_PROBE(hipStreamSynchronize(s));
+  float best = 1e30f;
+  for (int it = 0; it < 3; ++it) {
+    YL_PROBE(hipEventRecord(t0, s));
+    YL_PROBE(hipGraphLaunch(ge, s));
+    YL_PROBE(hipEventRecord(t1, s));
+    YL_PROBE(hipEventSynchronize(t1));
+    float t = 0.f;
+    YL_PROBE(hipEventElapsedTime(&t, t0, t1));
+    if (t < best) best = t;
+  }
+#undef YL_PROBE
+  *ms_graph = best;
+  *concurrent = best < 1.5f * (float)spin_us * 1e-3f ? 1 : 0;
+  cleanup();
+  return 0;
 }
 
 extern "C" int yl_detect_decode(const void* workspace, const yl_level* levels, int n_levels, int batch, int nc,

@@ -659,10 +659,12 @@ __global__ __launch_bounds__(256) void decode_exact_kernel(DecCandArgs a, NmsWs 
 }
 }  // namespace yl
 
-extern "C" int yl_decode_nms(const void* workspace, const yl_level* levels, int n_levels, int batch, int nc,
-                             float conf_thres, float iou_thres, int max_det, int agnostic, const int32_t* classes,
-                             int n_classes, int max_cand, float max_wh, const float* scale, float* out,
-                             int32_t* out_count, void* work, void* stream) {
+// ev != nullptr (yl_engine_profile_detect): ev[0..5] are recorded on the stream around the five stages
+// {zero counters + class pre-filter, exact decode, sort, suppression mask, scan + output}.
+int yl::decode_nms_stages(const void* workspace, const yl_level* levels, int n_levels, int batch, int nc,
+                          float conf_thres, float iou_thres, int max_det, int agnostic, const int32_t* classes,
+                          int n_classes, int max_cand, float max_wh, const float* scale, float* out,
+                          int32_t* out_count, void* work, void* stream, hipEvent_t* ev) {
   if (!workspace || !levels || !out || !out_count || !work) return fail(-1, "yl_decode_nms: null pointer");
   if (batch <= 0 || nc <= 0 || n_levels <= 0 || n_levels > 8 || max_det <= 0 || max_cand <= 0)
     return fail(-1, "yl_decode_nms: bad sizes");
@@ -695,18 +697,33 @@ extern "C" int yl_decode_nms(const void* workspace, const yl_level* levels, int 
   a.logit_lo = conf_thres >= 1.f ? __builtin_huge_valf()
                                  : (float)(std::log((double)conf_thres / (1.0 - (double)conf_thres)) - 0.05);
   hipStream_t s = (hipStream_t)stream;
+  if (ev) (void)hipEventRecord(ev[0], s);
   YL_HIP(hipMemsetAsync(w.count, 0, 4 * (size_t)batch * (1 + NSUB), s));  // count + pre_count
   const dim3 grid((unsigned)((A + 255) / 256), batch);
   if (sparse) {
     w.fused = 1;
     hipLaunchKernelGGL(decode_candidates_sparse_kernel, grid, dim3(256), 0, s, a, w, levels[0].nc8);
+    if (ev) (void)hipEventRecord(ev[1], s);
     hipLaunchKernelGGL(decode_exact_kernel, dim3(DX_BLOCKS, NSUB, batch), dim3(256), 0, s, a, w);
   } else {
     hipLaunchKernelGGL(decode_candidates_dense_kernel, grid, dim3(256), 0, s, a, w);
+    if (ev) (void)hipEventRecord(ev[1], s);
   }
+  if (ev) (void)hipEventRecord(ev[2], s);
   hipLaunchKernelGGL(nms_sort_kernel, dim3(batch), dim3(1024), 0, s, (const float*)nullptr, nc, A, agnostic, max_wh, w);
+  if (ev) (void)hipEventRecord(ev[3], s);
   hipLaunchKernelGGL(nms_mask_kernel, dim3(64, batch), dim3(256), 0, s, iou_thres, w);
+  if (ev) (void)hipEventRecord(ev[4], s);
   hipLaunchKernelGGL(nms_scan_kernel, dim3(batch), dim3(64), 0, s, max_det, scale, out, out_count, w);
+  if (ev) (void)hipEventRecord(ev[5], s);
   YL_HIP(hipGetLastError());
   return 0;
+}
+
+extern "C" int yl_decode_nms(const void* workspace, const yl_level* levels, int n_levels, int batch, int nc,
+                             float conf_thres, float iou_thres, int max_det, int agnostic, const int32_t* classes,
+                             int n_classes, int max_cand, float max_wh, const float* scale, float* out,
+                             int32_t* out_count, void* work, void* stream) {
+  return yl::decode_nms_stages(workspace, levels, n_levels, batch, nc, conf_thres, iou_thres, max_det, agnostic, classes,
+                               n_classes, max_cand, max_wh, scale, out, out_count, work, stream, nullptr);
 }

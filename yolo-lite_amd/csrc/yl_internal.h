@@ -275,6 +275,11 @@ __device__ __forceinline__ void level_load8(const PView& v, int c8, int pix, flo
   for (int j = 0; j < 8; ++j) o[j] = (float)t[j];
 }
 int decode_launch(const DecodeLevel* lv, int n_levels, int batch, int nc, int A, float* y, hipStream_t s);
+// nms.hip: yl_decode_nms with optional stage events (profiling)
+int decode_nms_stages(const void* workspace, const yl_level* levels, int n_levels, int batch, int nc, float conf_thres,
+                      float iou_thres, int max_det, int agnostic, const int32_t* classes, int n_classes, int max_cand,
+                      float max_wh, const float* scale, float* out, int32_t* out_count, void* work, void* stream,
+                      hipEvent_t* ev);
 
 // nrows contiguous rows of `n` floats -> LDS rows of `pitch` words starting at column c0 (256 threads).
 // Loads are issued in batches of 8 per thread before the first LDS write: one memory round trip per

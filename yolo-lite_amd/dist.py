@@ -1,18 +1,23 @@
 """Data-parallel batched inference: one process per GPU, images sharded across ranks.
 
-The reference has no distributed code at all; the path shards trivially --
-images are independent through the network and NMS is per image (reference utils/ops.py:219) -- so
-weights are replicated and the only exchanges are (1) root -> peers input slices and (2) peers ->
-root fixed-size result records.  Both go through ``torch.distributed`` (backend "nccl" = RCCL over
-xGMI on the GPU box, "gloo" in the CPU tests).  There is no all-reduce.
+The reference has no distributed code at all (``utils/torch_utils.py:142-159`` ends up on
+``cuda:0``); the path shards trivially -- images are independent through the network and NMS is per image
+(reference ``utils/ops.py:219``) -- so weights are replicated and the only exchanges are (1) root -> peers input
+slices and (2) peers -> root fixed-size result records.  Both go through ``torch.distributed`` (backend "nccl" =
+RCCL over xGMI on the GPU box, "gloo" in the CPU tests).  There is no all-reduce.
 
-xGMI is point-to-point: the root's scatter uses its 7 links concurrently, so its cost is about
-one slice / 153 GB/s (uint8 32x3x640x640 = 39 MB -> ~0.26 ms) and is overlapped with the previous
-batch's compute by issuing it one step ahead (``ShardedRunner.run``).
+xGMI is point-to-point: the root's scatter uses its 7 links concurrently, so its cost is about one slice /
+153 GB/s (uint8 32x3x640x640 = 39 MB -> ~0.26 ms) and is hidden behind the compute of the batches already in
+flight by issuing it ``slots`` steps ahead (``ShardedRunner.run``).
+
+Result records: one step of one rank returns ONE packed tensor of ``record_floats(b, max_det)`` fp32 words --
+``b * max_det * 6`` box words ``[x1, y1, x2, y2, conf, cls]`` followed by the ``b`` per-image counts stored as
+int32 bit patterns -- so a step costs one gather, not two (``pack_views`` / ``unpack_record``).
 """
 from __future__ import annotations
 
-from typing import Callable, List, Optional, Tuple
+import contextlib
+from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -29,32 +34,60 @@ def shard_bounds(total: int, world: int, rank: int) -> Tuple[int, int]:
     return rank * per, (rank + 1) * per
 
 
-def scatter_images(global_batch: Optional[torch.Tensor], local: torch.Tensor, src: int = 0, async_op: bool = False):
+def record_floats(b: int, max_det: int) -> int:
+    """fp32 words of one rank's packed result record of one step."""
+    return b * max_det * RECORD + b
+
+
+def pack_views(rec: torch.Tensor, b: int, max_det: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(out[b, max_det, 6] fp32, cnt[b] int32) views aliasing a packed record (no copy)."""
+    n = b * max_det * RECORD
+    return rec[:n].view(b, max_det, RECORD), rec[n: n + b].view(torch.int32)
+
+
+def unpack_record(recs: Sequence[torch.Tensor], b: int, max_det: int) -> Tuple[List[torch.Tensor], List[torch.Tensor]]:
+    """Per-rank packed records -> (outs, cnts) lists ordered by rank."""
+    pairs = [pack_views(r, b, max_det) for r in recs]
+    return [p[0] for p in pairs], [p[1] for p in pairs]
+
+
+def scatter_images(global_batch: Optional[torch.Tensor], local: torch.Tensor, src: int = 0, async_op: bool = False,
+                   group=None):
     """Root splits ``global_batch`` (world*b, 3, H, W) along dim 0; every rank receives into ``local``."""
-    world, rank = dist.get_world_size(), dist.get_rank()
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
     chunks = None
     if rank == src:
         if global_batch is None or global_batch.shape[0] != world * local.shape[0]:
             raise ValueError("root must pass the full batch")
         chunks = list(global_batch.chunk(world, 0))
-    return dist.scatter(local, chunks, src=src, async_op=async_op)
+    return dist.scatter(local, chunks, src=src, async_op=async_op, group=group)
 
 
-def gather_results(out: torch.Tensor, cnt: torch.Tensor, dst: int = 0, async_op: bool = False):
-    """Peers send (b, max_det, 6) boxes and (b,) counts; root returns lists ordered by rank."""
+def gather_record(rec: torch.Tensor, into: Optional[List[torch.Tensor]], dst: int = 0, async_op: bool = False, group=None):
+    """Peers send their packed record; the root receives into ``into`` (one tensor per rank, rank order)."""
+    return dist.gather(rec, into if dist.get_rank(group) == dst else None, dst=dst, async_op=async_op, group=group)
+
+
+def gather_results(out: torch.Tensor, cnt: torch.Tensor, dst: int = 0):
+    """Blocking convenience form: (b, max_det, 6) boxes and (b,) counts of every rank, as lists on the root."""
+    b, max_det = out.shape[0], out.shape[1]
+    rec = torch.empty(record_floats(b, max_det), dtype=torch.float32, device=out.device)
+    o, c = pack_views(rec, b, max_det)
+    o.copy_(out)
+    c.copy_(cnt)
     world, rank = dist.get_world_size(), dist.get_rank()
-    outs = [torch.empty_like(out) for _ in range(world)] if rank == dst else None
-    cnts = [torch.empty_like(cnt) for _ in range(world)] if rank == dst else None
-    w1 = dist.gather(out, outs, dst=dst, async_op=async_op)
-    w2 = dist.gather(cnt, cnts, dst=dst, async_op=async_op)
-    return outs, cnts, (w1, w2)
+    into = [torch.empty_like(rec) for _ in range(world)] if rank == dst else None
+    gather_record(rec, into, dst)
+    if rank != dst:
+        return None, None
+    return unpack_record(into, b, max_det)
 
 
 def run_resident(compute: Callable[[torch.Tensor], Tuple[torch.Tensor, torch.Tensor]], local_batches: List[torch.Tensor],
                  steps: int, dst: int = 0, finish: Optional[Callable[[], None]] = None):
     """Every rank works on image shards that already live in its own HBM: ``steps`` passes of the hot
-    path with no data-path collective at all (the path partitions by image), then ONE
-    gather of the last step's result records to ``dst``.  Returns the gathered (outs, cnts) on ``dst``.
+    path with no data-path collective at all, then ONE gather of the last step's result records to ``dst``
+    (the replica-throughput figure ``value_resident`` of bench.py).  Returns the gathered (outs, cnts) on ``dst``.
     ``compute`` may pipeline steps over several streams; ``finish`` (e.g. a device synchronise) is then
     called once after the last step, before the gather reads its outputs."""
     out = cnt = None
@@ -62,53 +95,77 @@ def run_resident(compute: Callable[[torch.Tensor], Tuple[torch.Tensor, torch.Ten
         out, cnt = compute(local_batches[k % len(local_batches)])
     if finish is not None:
         finish()
-    outs, cnts, _ = gather_results(out.clone(), cnt.clone(), dst, async_op=False)
-    return outs, cnts
+    return gather_results(out, cnt, dst)
 
 
 class ShardedRunner:
-    """Pipelined scatter -> compute -> gather loop.
+    """BASELINE.json config 4 / SURVEY 8(e): per step, root scatters the uint8 global batch, every rank runs the
+    hot path on its slice, root gathers the packed ``(count, max_det x 6)`` records.
 
-    ``compute(local_images) -> (out[b, max_det, 6], cnt[b])`` is the per-GPU hot path (HIP engine +
-    NMS).  The scatter of step k+1 is issued before the compute of step k, so it travels while the
-    GPU works; the gather of step k is issued after its compute and is tiny.
+    ``compute(images, slot) -> rec`` is the per-GPU hot path for workspace slot ``slot``; ``images`` is this
+    runner's input buffer of that slot (the SAME tensor every time the slot comes round, so a hipGraph that
+    baked its address stays valid) and ``rec`` is the engine-owned packed record of that slot
+    (``HipEngine.detect_record``).  ``slots`` batches are in flight:
+
+      * scatter k + slots is issued right after compute k on the slot's stream, so it is ordered behind the
+        compute that still reads the buffer (no WAR hazard) and travels while the other slots compute;
+      * compute k waits for scatter k on the slot's stream (``Work.wait`` = a stream-side event wait on NCCL,
+        a host wait on gloo) and for the gather that still reads the slot's record from the previous round;
+      * gather k is issued on the slot's stream right behind compute k.
+
+    ``streams``: one ``torch.cuda.Stream`` per slot on the GPU; None on the CPU (gloo tests).
     """
 
-    def __init__(self, compute: Callable[[torch.Tensor], Tuple[torch.Tensor, torch.Tensor]], per_rank: int,
-                 shape: Tuple[int, int, int], dtype: torch.dtype, device: torch.device, src: int = 0):
+    def __init__(self, compute: Callable[[torch.Tensor, int], torch.Tensor], per_rank: int,
+                 shape: Tuple[int, int, int], dtype: torch.dtype, device: torch.device, record_words: int,
+                 slots: int = 2, src: int = 0, streams: Optional[Sequence] = None, group=None):
+        if streams is not None and len(streams) != slots:
+            raise ValueError("one stream per slot")
         self.compute = compute
         self.src = src
-        self.bufs = [torch.empty((per_rank, *shape), dtype=dtype, device=device) for _ in range(2)]
-        self.rank = dist.get_rank()
-        self.world = dist.get_world_size()
+        self.slots = slots
+        self.group = group
+        self.streams = list(streams) if streams is not None else None
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.bufs = [torch.empty((per_rank, *shape), dtype=dtype, device=device) for _ in range(slots)]
+        self.gathered: List[Optional[List[torch.Tensor]]] = [
+            [torch.empty(record_words, dtype=torch.float32, device=device) for _ in range(self.world)]
+            if self.rank == src else None for _ in range(slots)]
 
-    def run(self, batches: List[Optional[torch.Tensor]], steps: int):
-        """``batches[k % len]`` is the root's global batch for step k (None on other ranks).
-        Returns the root's gathered (outs, cnts) of the last step (None elsewhere)."""
-        nb = len(batches)
-        pending = scatter_images(batches[0], self.bufs[0], self.src, async_op=True)
+    def _on(self, j: int):
+        return torch.cuda.stream(self.streams[j]) if self.streams is not None else contextlib.nullcontext()
+
+    def run(self, batches: List[Optional[torch.Tensor]], steps: int) -> Optional[List[torch.Tensor]]:
+        """``batches[k % len]`` is the root's global batch for step k (None on other ranks).  Returns the root's
+        gathered records (one packed tensor per rank) of the LAST step, None elsewhere.  On the GPU the returned
+        tensors are complete once the slot's stream has been synchronised (the caller's timed region ends with a
+        device synchronise)."""
+        nb, S = len(batches), self.slots
+        sc = [None] * S
+        ga = [None] * S
+
+        def scatter(k: int):
+            j = k % S
+            sc[j] = scatter_images(batches[k % nb], self.bufs[j], self.src, async_op=True, group=self.group)
+
+        for k in range(min(S, steps)):
+            with self._on(k % S):
+                scatter(k)
         last = None
-        tail = []
         for k in range(steps):
-            cur = self.bufs[k % 2]
-            if pending is not None:
-                pending.wait()
-            pending = None
-            if k + 1 < steps:
-                pending = scatter_images(batches[(k + 1) % nb], self.bufs[(k + 1) % 2], self.src, async_op=True)
-            out, cnt = self.compute(cur)
-            # the hot path may hand out engine-owned buffers that its next call overwrites: the
-            # asynchronous gather gets private copies
-            out, cnt = out.clone(), cnt.clone()
-            outs, cnts, works = gather_results(out, cnt, self.src, async_op=True)
-            tail.append(works)
-            if len(tail) > 2:  # bound the number of in-flight gathers
-                for w in tail.pop(0):
-                    if w is not None:
-                        w.wait()
-            last = (outs, cnts)
-        for works in tail:
-            for w in works:
-                if w is not None:
-                    w.wait()
-        return last
+            j = k % S
+            with self._on(j):
+                sc[j].wait()
+                if ga[j] is not None:  # the previous round's gather still reads this slot's record
+                    ga[j].wait()
+                rec = self.compute(self.bufs[j], j)
+                ga[j] = gather_record(rec, self.gathered[j], self.src, async_op=True, group=self.group)
+                if k + S < steps:
+                    scatter(k + S)
+            last = j
+        for j in range(S):
+            if ga[j] is not None:
+                with self._on(j):
+                    ga[j].wait()
+        return self.gathered[last] if (last is not None and self.rank == self.src) else None

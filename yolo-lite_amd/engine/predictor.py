@@ -12,6 +12,7 @@ Differences from the reference, all deliberate and documented in DESIGN.md:
 """
 from __future__ import annotations
 
+import os
 import threading
 from pathlib import Path
 from typing import List
@@ -142,12 +143,19 @@ class DetectionPredictor:
         b, _, h, w = im.shape
         eng = self.model.engine_for(b, h, w, calib=im.contiguous())
         shapes, imgs, scale = self._shapes_and_scale(im, orig_imgs, b, im.device)
+        # ONE hipGraph launch per batch (reference model.py:89-99 -> predictor.py:149-229 is ~320 module calls): the
+        # input and the scale table are staged into engine-owned buffers whose addresses the graph baked in
+        # (YL_PREDICT_GRAPH=0: the same kernels launched one by one)
+        graph = os.environ.get("YL_PREDICT_GRAPH", "1") != "0"
         out, cnt = eng.detect(im.contiguous(), self.args.conf, self.args.iou, max_det=self.args.max_det,
-                              classes=self.args.classes, agnostic=self.args.agnostic_nms, scale=scale, graph=False)
+                              classes=self.args.classes, agnostic=self.args.agnostic_nms, scale=scale, graph=graph,
+                              stage=graph)
         counts = cnt.tolist()
         self.last_preds = None
-        return [Results(imgs[i], path=self.batch[0][i], names=self.model.names, boxes=out[i, : counts[i]],
-                        orig_shape=shapes[i]) for i in range(b)]
+        # engine-owned output buffers are overwritten by the next call: Results get their own (small) copies
+        return [Results(imgs[i], path=self.batch[0][i], names=self.model.names,
+                        boxes=out[i, : counts[i]].clone() if graph else out[i, : counts[i]], orig_shape=shapes[i])
+                for i in range(b)]
 
     # ------------------------------------------------------------------ driver
     def __call__(self, source=None, model=None, stream=False, *args, **kwargs):

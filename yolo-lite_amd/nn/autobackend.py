@@ -37,6 +37,15 @@ class AutoBackend:
 
     def __init__(self, weights="yolo11n.pt", device=torch.device("cpu"), dnn=False, data=None, fp16=False, batch=1,
                  fuse=True, verbose=True):
+        from .. import _lib
+
+        if os.environ.get("YL_AMD_NO_KNOBS", "0") != "1":
+            st = _lib.apply_runtime_knobs()  # explicit, logged; effective only before the HIP runtime initialises
+            if verbose and not st["before_hip_init"]:
+                from ..utils import LOGGER
+
+                LOGGER.warning("HIP was initialised before yololite_amd's runtime knobs were set (%s): the graph's class "
+                               "branch may run serialised; call yololite_amd._lib.apply_runtime_knobs() first", st)
         w = weights[0] if isinstance(weights, (list, tuple)) else weights
         if isinstance(w, DetectionModel):
             model = w

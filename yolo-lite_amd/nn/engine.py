@@ -177,15 +177,26 @@ class HipEngine:
 
     def detect(self, im: torch.Tensor, conf: float = 0.25, iou: float = 0.7, max_det: int = 300,
                classes=None, agnostic: bool = False, max_nms: int = 30000, max_wh: float = 7680.0,
-               scale: Optional[torch.Tensor] = None, graph: bool = True, slot: int = 0):
+               scale: Optional[torch.Tensor] = None, graph: bool = True, slot: int = 0, stage: bool = False):
         """Network + fused Detect decode + NMS; returns padded (out[B, max_det, 6], count[B]).
 
         Bit-identical to ``forward`` followed by ``utils.ops.nms_padded`` but the (B, 4+nc, A) tensor
         of the reference (head.py:126) is never materialised.  No host synchronisation.  With
         ``graph=True`` the whole path is ONE hipGraph launch and the returned tensors are engine-owned
         buffers that stay valid until the next ``detect`` call with the same ``max_det`` and ``slot``.
-        Calls with different ``slot`` values may be in flight on different streams at the same time."""
+        Calls with different ``slot`` values may be in flight on different streams at the same time.
+        ``stage=True`` (with ``graph=True``): ``im`` is first copied into an engine-owned input buffer of the slot
+        (one device-to-device copy), so callers that hand over a fresh tensor every call -- the predictor API -- still
+        replay ONE captured graph instead of re-capturing per input address."""
         self._check_input(im)
+        if graph and stage:
+            sk = ("in", im.dtype)
+            st0 = self._slot(slot)["static"]
+            if sk not in st0:
+                st0[sk] = torch.empty_like(im)
+            if st0[sk].data_ptr() != im.data_ptr():
+                st0[sk].copy_(im, non_blocking=True)
+            im = st0[sk]
         max_cand = min(int(max_nms), self.anchors)
         sl = self._slot(slot)
         st = sl["static"]
@@ -197,8 +208,13 @@ class HipEngine:
         stream = torch.cuda.current_stream(self.device).cuda_stream
         if graph:
             if max_det not in st:
-                st[max_det] = (torch.empty((self.batch, max_det, 6), dtype=torch.float32, device=self.device),
-                               torch.empty((self.batch,), dtype=torch.int32, device=self.device))
+                # one packed record per slot (boxes, then the counts as int32 bit patterns): the multi-GPU
+                # gather sends it as ONE message (dist.pack_views / dist.gather_record)
+                from ..dist import pack_views, record_floats
+
+                rec = torch.empty(record_floats(self.batch, max_det), dtype=torch.float32, device=self.device)
+                st[("rec", max_det)] = rec
+                st[max_det] = pack_views(rec, self.batch, max_det)
             out, cnt = st[max_det]
         else:
             out = torch.empty((self.batch, max_det, 6), dtype=torch.float32, device=self.device)
@@ -228,6 +244,14 @@ class HipEngine:
                                         *args)
             _lib.check(rc, "yl_decode_nms")
         return out, cnt
+
+    def detect_record(self, im: torch.Tensor, conf: float = 0.25, iou: float = 0.7, max_det: int = 300, slot: int = 0,
+                      **kw) -> torch.Tensor:
+        """``detect(graph=True)`` returning the slot's packed result record (``dist.record_floats`` fp32 words:
+        ``batch * max_det * 6`` box words, then the per-image counts as int32 bit patterns) -- what one rank
+        contributes to the per-step gather of the sharded path."""
+        self.detect(im, conf, iou, max_det=max_det, graph=True, slot=slot, **kw)
+        return self._slot(slot)["static"][("rec", max_det)]
 
     def level_views(self, i: int):
         """(box, cls) arena views of Detect level i (bf16 planar buffers of 64 and nc8 channels)."""
@@ -289,6 +313,44 @@ class HipEngine:
         fl, by, nm = C.c_double(), C.c_double(), C.c_char_p()
         self.lib.yl_engine_op_info(self._h, i, C.byref(fl), C.byref(by), C.byref(nm))
         return nm.value.decode()
+
+    def profile_detect(self, im: torch.Tensor, conf: float = 0.25, iou: float = 0.7, max_det: int = 300,
+                       iters: int = 20) -> List[dict]:
+        """Per-launch HIP-event timings of the hot path as ``detect`` runs it (yl_engine_profile_detect): every network
+        op, then the kernels that really follow it -- class pre-filter, exact decode, sort, mask, scan -- with
+        algorithmic flops / bytes per launch."""
+        self._check_input(im)
+        n = self.lib.yl_engine_num_ops(self._h)
+        ms, mp = (C.c_float * n)(), (C.c_float * 5)()
+        max_cand = self.anchors
+        sl = self._slot(0)
+        wk = ("work", max_cand)
+        if wk not in sl["static"]:
+            sl["static"][wk] = torch.empty(int(self.lib.yl_nms_workspace_bytes(self.batch, self.anchors, max_cand)),
+                                           dtype=torch.uint8, device=self.device)
+        out = torch.empty((self.batch, max_det, 6), dtype=torch.float32, device=self.device)
+        cnt = torch.empty((self.batch,), dtype=torch.int32, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self.lib.yl_engine_profile_detect(self._h, im.data_ptr(), _TORCH2YL[im.dtype], sl["ws"].data_ptr(),
+                                                     float(conf), float(iou), int(max_det), max_cand, out.data_ptr(),
+                                                     cnt.data_ptr(), sl["static"][wk].data_ptr(), stream, iters, ms, mp),
+                   "yl_engine_profile_detect")
+        rows = []
+        fl, by, nm = C.c_double(), C.c_double(), C.c_char_p()
+        for i in range(n):
+            self.lib.yl_engine_op_info(self._h, i, C.byref(fl), C.byref(by), C.byref(nm))
+            rows.append(dict(name=self.prog.ops[i].get("name", ""), kernel=nm.value.decode(), ms=ms[i], flops=fl.value,
+                             bytes=by.value))
+        ncand = float(cnt.sum().item())  # detections, a lower bound of the candidates the later stages touch
+        nc8 = self.prog.levels[0]["nc8"] if self.prog.levels else self.nc
+        post = [("detect.prefilter", "decode_candidates_sparse", float(self.batch * self.anchors * nc8 * 2)),
+                ("detect.decode_exact", "decode_exact", ncand * (64 + nc8) * 2 + ncand * 32),
+                ("nms.sort", "nms_sort", ncand * 16 * 2),
+                ("nms.mask", "nms_mask", ncand * 16 + ncand * 8),
+                ("nms.scan", "nms_scan", ncand * 16 + float(self.batch * max_det * 24))]
+        for (name, kern, b), t in zip(post, mp):
+            rows.append(dict(name=name, kernel=kern, ms=t, flops=0.0, bytes=b))
+        return rows
 
     def profile(self, im: torch.Tensor, iters: int = 20) -> List[dict]:
         """Per-op HIP-event timings with algorithmic flops/bytes (see yl_engine_profile)."""

@@ -42,12 +42,17 @@ class Profile(contextlib.ContextDecorator):
         return time.time()
 
 
-_NMS_WORK: dict = {}
+_NMS_WORK: "dict[tuple, torch.Tensor]" = {}
+_NMS_WORK_MAX = 8
 
 
 def _nms_workspace(device, batch, anchors, max_cand, ml_nc: int = 0) -> torch.Tensor:
-    key = (str(device), batch, anchors, max_cand, ml_nc)
-    w = _NMS_WORK.get(key)
+    """Scratch of one NMS call, cached per (device, STREAM, shape): two callers on two streams never share candidate /
+    sort / mask arrays, and a buffer is allocated, used and eventually freed on one stream only, which is what the
+    caching allocator's reuse rule assumes.  At most _NMS_WORK_MAX buffers are kept (oldest dropped first)."""
+    stream = torch.cuda.current_stream(device).cuda_stream
+    key = (str(device), int(stream), batch, anchors, max_cand, ml_nc)
+    w = _NMS_WORK.pop(key, None)
     if w is None:
         if ml_nc:
             nbytes = _lib.lib().yl_nms_ml_workspace_bytes(batch, ml_nc, anchors, max_cand)
@@ -55,8 +60,10 @@ def _nms_workspace(device, batch, anchors, max_cand, ml_nc: int = 0) -> torch.Te
             nbytes = _lib.lib().yl_nms_workspace_bytes(batch, anchors, max_cand)
         if nbytes < 0:
             raise RuntimeError("yl_nms_workspace_bytes failed")
-        _NMS_WORK.clear()  # keep a single scratch buffer alive
-        w = _NMS_WORK[key] = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+        while len(_NMS_WORK) >= _NMS_WORK_MAX:
+            _NMS_WORK.pop(next(iter(_NMS_WORK)))
+        w = torch.empty(int(nbytes), dtype=torch.uint8, device=device)
+    _NMS_WORK[key] = w  # most recently used last
     return w
 
 
