@@ -10,7 +10,7 @@ from PIL import Image
 
 from oracle import letterbox_oracle as lbo
 from oracle import yolo11_oracle as oracle
-from oracle.parity_gate import parity_gate
+from oracle.parity_gate import format_yardstick_ok, parity_gate
 
 pytestmark = pytest.mark.gpu
 
@@ -66,13 +66,36 @@ def test_predict_jpeg_file_1080x1920(gpu_device, golden, tmp_path):
         d[:, :4] = oracle.scale_boxes((384, 640), d[:, :4], (1080, 1920))  # predictor.py:125
         return d, y
 
-    # (a) against the bf16-storage oracle: the kernels' own deviation (+ <= 1 LSB of letterbox fixed point)
-    d16, _ = oracle_dets("bf16")
-    st = parity_gate([d16], [got], 0.25, 0.7, band=0.03, verbose=True)
-    print("config 1 vs bf16-storage oracle:", st)
-    assert st["ok"], st
-    # (b) against the fp32 reference restatement: the stated bf16 format tolerance
+    # the product's letterboxed input (GPU kernel, OpenCV's fixed point) against the float definition: <= 1 LSB
+    xin = model.predictor.preprocess([bgr]).cpu().numpy().astype(np.int32)
+    assert xin.shape == (1, 3, 384, 640) and np.abs(xin - x8.astype(np.int32)).max() <= 1
+
+    # pre-NMS tensor (the reference's three-stage path keeps it): fixed format tolerances
+    model.predictor.fuse_postprocess = False
+    res3 = model.predict(str(path), imgsz=640, conf=0.25, iou=0.7, device=str(gpu_device), save=False, verbose=False)
+    assert torch.equal(res3[0].boxes.data.cpu(), got), "fused and staged predict paths disagree"
+    yh = model.predictor.last_preds.cpu()
     d32, y32 = oracle_dets("fp32")
-    st32 = parity_gate([d32], [got], 0.25, 0.7, band=0.08, ref_y=y32, verbose=True)
-    print("config 1 vs fp32 oracle:", st32)
-    assert st32["ok"], st32
+    st = torch.tensor([float(s) for s in (8, 16, 32) for _ in range((384 // s) * (640 // s))])
+    assert yh.shape == y32.shape == (1, 84, 5040)  # A = 5040 at 384 x 640
+    assert float((yh[:, 4:] - y32[:, 4:]).abs().max()) < 0.08
+    assert float(((yh[:, :4] - y32[:, :4]).abs() / st).max()) < 0.35
+
+    # post-processing in isolation: the oracle's NMS + scale_boxes applied to the HIP network's own pre-NMS tensor must
+    # reproduce the product's Results bit for bit (the network is judged above with tolerances, NMS exactly)
+    exact = oracle.non_max_suppression(yh, 0.25, 0.7)[0]
+    exact[:, :4] = oracle.scale_boxes((384, 640), exact[:, :4], (1080, 1920))
+    assert torch.equal(exact, got), "NMS / scale_boxes of the predict path differ from the oracle on identical inputs"
+
+    # post-NMS end to end against the fp32 restatement, next to what the bf16 format costs on this very image.  One image
+    # gives ~30 boxes, many of them clusters of near-identical candidates from neighbouring anchors (a smooth scene), so a
+    # pair may join boxes of DIFFERENT anchors and its |dconf| is not bounded by the per-anchor tolerance checked above:
+    # classes exact, nothing unexplained and the paired fraction are required, max |dconf| is reported and bounded loosely.
+    d16, _ = oracle_dets("bf16")
+    st_hip = parity_gate([d32], [got], 0.25, 0.7, band=0.08, ref_y=y32, min_matched_frac=0.0, verbose=True)
+    st_fmt = parity_gate([d32], [d16], 0.25, 0.7, band=0.08, ref_y=y32, min_matched_frac=0.0)
+    verdict = format_yardstick_ok(st_hip, st_fmt, 0.08)
+    print("config 1: HIP", st_hip, "\n          format", st_fmt, "\n         ", verdict)
+    ck = verdict["checks"]
+    assert ck["class_exact"] and ck["nothing_unexplained"] and ck["matched_frac_vs_format"] and ck["paired_something"], verdict
+    assert st_hip["max_dconf"] <= 0.12

@@ -309,6 +309,45 @@ def test_conv3_tile_vs_torch_and_direct(gpu_device, monkeypatch, cin, cout, h, w
     assert ((got - direct).abs() <= 2.0 ** -7 * direct.abs().clamp(min=1e-2) + 1e-3).all(), "tile vs direct kernel"
 
 
+REG_CASES = [
+    # Cin, Cout, H, W, act, res, NT     conv3_reg_kernel (filter in registers, input tile in LDS), forced onto small maps
+    (64, 64, 20, 20, True, True, 4),
+    (64, 64, 20, 20, True, False, 2),
+    (64, 64, 7, 9, True, False, 2),
+    (32, 32, 40, 40, True, True, 4),
+    (64, 32, 13, 17, True, False, 2),
+    (32, 64, 24, 40, False, False, 4),
+    (64, 64, 80, 80, True, False, 4),
+    (64, 64, 33, 150, True, True, 4),   # wide rows: more DMA pieces per wave than k-steps
+]
+
+
+@pytest.mark.parametrize("cin,cout,h,w,act,res,nt", REG_CASES)
+def test_conv3_reg_vs_torch_and_direct(gpu_device, monkeypatch, cin, cout, h, w, act, res, nt):
+    """The filter-in-registers 3x3 kernel against torch, and against the direct kernel: same k order, same MFMA
+    accumulation chain starting from the bias -> bit-identical."""
+    g = torch.Generator().manual_seed(cin * 100 + cout + h + nt + 7)
+    B = 3
+    x = _rand(g, B, cin, h, w)
+    wt = _rand(g, cout, cin, 3, 3, scale=1.0 / math.sqrt(cin * 9))
+    b = torch.randn(cout, generator=g) * 0.5
+    ref = F.conv2d(x, wt, b, 1, 1)
+    if act:
+        ref = F.silu(ref)
+    r = None
+    if res:
+        r = _rand(g, *ref.shape)
+        ref = ref + r
+    monkeypatch.setenv("YL_CONV_REG", "1")
+    monkeypatch.setenv("YL_CONV_REG_MIN", "1")
+    monkeypatch.setenv("YL_CONV_REG_NT", str(nt))
+    got = run_conv(gpu_device, x, wt, b, 3, 1, act, r, expect_kernel="conv3x3_reg_mfma")
+    _assert_close_bf16(got, ref, f"reg conv {cin}->{cout} NT={nt}")
+    monkeypatch.setenv("YL_CONV_REG", "0")
+    direct = run_conv(gpu_device, x, wt, b, 3, 1, act, r, expect_kernel="conv3x3_mfma")
+    assert torch.equal(got, direct), f"reg vs direct kernel: max diff {float((got - direct).abs().max())}"
+
+
 def test_view_above_one_gib_fails_loudly(gpu_device):
     """Maximum sizes: buffer offsets are 32 bits with out-of-range sentinels, so a tensor slice above 1 GiB must be
     refused with an error (never wrapped around or silently truncated)."""

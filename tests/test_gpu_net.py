@@ -4,7 +4,7 @@ import pytest
 import torch
 
 from oracle import yolo11_oracle as oracle
-from oracle.parity_gate import parity_gate
+from oracle.parity_gate import format_yardstick_ok, parity_gate
 from yololite_amd.nn import arch
 from yololite_amd.nn.engine import HipEngine
 from yololite_amd.nn.synth import synth_state_dict
@@ -12,22 +12,21 @@ from yololite_amd.utils import ops as hops
 
 pytestmark = pytest.mark.gpu
 
-# Two comparisons, two tolerances (profiles/r02_parity_probe.json holds the measurements behind them):
-#
-# (a) HIP path vs the REFERENCE (fp32 goldens / fp32 oracle): the distance is the bf16 storage FORMAT, not the kernels:
-#     the oracle's own bf16-storage mode -- fp32 arithmetic on the CPU, tensors rounded where the HIP path stores bf16 --
-#     sits at the same distance from the fp32 reference (tests/test_oracle_golden.py::test_bf16_storage_format_error:
-#     max |dscore| 0.074, boxes 0.22 strides at 640x640; class-logit std ~5 from the synthetic cls_gain 8).
-#       measured HIP vs fp32: per-layer rel L2 <= 0.0059, max |dscore| 0.075, boxes 0.21 strides.
+# Tolerances of the bf16 network against the REFERENCE (fp32 goldens / fp32 oracle).  The distance is the bf16 storage
+# FORMAT, not the kernels: the oracle's own bf16-storage mode -- fp32 arithmetic on the CPU, tensors rounded where the
+# HIP path stores bf16 -- sits at the same distance from the fp32 reference (tests/test_oracle_golden.py::
+# test_bf16_storage_format_error; profiles/r02_parity_probe.json: level rel L2 0.0022 / 0.0016 / 0.0015 for the HIP
+# path AND for the emulation at 640x640; max |dscore| 0.064 / 0.074; class-logit std ~5 from the synthetic cls_gain 8).
+# Rounding noise is chaotic (one flipped bf16 rounding perturbs ~600 outputs of the next 3x3 conv), so the HIP path and
+# the emulation are as far from EACH OTHER as each is from fp32: the testable statement is that the HIP path's error
+# has the size of the format's own.  Hence two kinds of bounds:
+#   * fixed, stated format tolerances (measured maxima x ~1.3):
 LAYER_REL_L2 = 0.015
 SCORE_ATOL = 0.08
 BOX_ATOL_STRIDES = 0.35  # box coordinate error allowed, in units of the level stride
-# (b) HIP path vs the bf16-storage oracle: what is left to the kernels themselves (MFMA accumulation order, hardware
-#     exp / rcp in SiLU and softmax); a tensor element differs only where such a 1e-6 difference crosses a bf16
-#     rounding boundary.  Bounds = measured maxima x ~2 (tools/parity_probe.py).
-BF16_LEVEL_REL_L2 = 0.004
-BF16_SCORE_ATOL = 0.03
-BF16_BOX_ATOL_STRIDES = 0.12
+#   * relative to the format error measured in the same test on the same input (test_error_has_the_size_of_the_format_error,
+#     oracle.parity_gate.format_yardstick_ok): HIP error <= FMT_RATIO x format error for rms-type statistics.
+FMT_RATIO = 1.5
 
 
 def _engine(scale, sd, b, h, w, dev, keep_layers=False):
@@ -226,25 +225,37 @@ def test_end_to_end_640_vs_golden(gpu_device, golden):
 
 @pytest.mark.parametrize("scale,h,w,seed,key", [("n", 64, 64, 0, "net_n_64x64"), ("n", 96, 128, 1, "net_n_96x128"),
                                                 ("s", 64, 64, 2, "net_s_64x64"), ("x", 64, 64, 4, "net_x_64x64")])
-def test_net_vs_bf16_storage_oracle(gpu_device, golden, scale, h, w, seed, key):
-    """Comparison (b): the HIP network against the oracle's bf16-storage mode on the golden inputs."""
+def test_error_has_the_size_of_the_format_error(gpu_device, golden, scale, h, w, seed, key):
+    """HIP network vs the reference's golden outputs, measured against the yardstick of the bf16 storage format: the
+    oracle's bf16-storage mode vs the same goldens (CPU, no kernel involved)."""
     sd = synth_state_dict(scale, seed, cls_bias=list(golden[key + "_bias"]), cls_gain=8.0)
     x = torch.from_numpy(golden[key + "_x"])
     eng = _engine(scale, sd, x.shape[0], h, w, gpu_device)
     y = eng.forward(x.to(gpu_device)).cpu()
+    lv = [t.cpu() for t in eng.raw_levels()]
     with torch.inference_mode():
-        yr, raw = oracle.forward(sd, x, scale, storage="bf16")
-    st = _stride_per_anchor(h, w)
-    box_err = float(((y[:, :4] - yr[:, :4]).abs() / st).max())
-    score_err = float((y[:, 4:] - yr[:, 4:]).abs().max())
-    rels = [float((a.cpu() - b).norm() / b.norm()) for a, b in zip(eng.raw_levels(), raw)]
-    print(f"{key} vs bf16-storage oracle: score {score_err:.4f} box {box_err:.4f} strides, level rel L2 {rels}")
-    assert box_err < BF16_BOX_ATOL_STRIDES and score_err < BF16_SCORE_ATOL
-    assert max(rels) < BF16_LEVEL_REL_L2, rels
+        yf, rawf = oracle.forward(sd, x, scale, storage="bf16")
+    ref = torch.from_numpy(golden[key + "_y"])
+    raws = [torch.from_numpy(golden[f"{key}_raw{i}"]) for i in range(3)]
+
+    def stats(yy, levels):
+        return dict(score_rms=float((yy[:, 4:] - ref[:, 4:]).pow(2).mean().sqrt()),
+                    score_max=float((yy[:, 4:] - ref[:, 4:]).abs().max()),
+                    box_max=float(((yy[:, :4] - ref[:, :4]).abs() / _stride_per_anchor(h, w)).max()),
+                    rel=[float((a - b).norm() / b.norm()) for a, b in zip(levels, raws)])
+
+    hip, fmt = stats(y, lv), stats(yf, rawf)
+    print(f"{key}: HIP {hip}\n{' ' * len(key)}  format {fmt}")
+    assert hip["score_rms"] <= FMT_RATIO * fmt["score_rms"] + 1e-5
+    for a, b in zip(hip["rel"], fmt["rel"]):
+        assert a <= FMT_RATIO * b + 2e-4, (hip["rel"], fmt["rel"])
+    # maxima over a few thousand values are noisy: 2.5 x
+    assert hip["score_max"] <= 2.5 * fmt["score_max"] + 0.003 and hip["box_max"] <= 2.5 * fmt["box_max"] + 0.02
 
 
-def test_end_to_end_640_vs_bf16_storage_oracle(gpu_device, golden):
-    """Comparison (b) after NMS, 4 images at 640x640: the gate with the kernels' own (tight) band."""
+def test_end_to_end_640_vs_oracle_with_format_yardstick(gpu_device, golden):
+    """Post-NMS, 4 images at 640x640: the HIP path's detections against the fp32 oracle's, judged by the gate's fixed
+    band AND against what the bf16 format itself costs on the same images (oracle.parity_gate.format_yardstick_ok)."""
     sd = synth_state_dict("n", 0, cls_bias=list(golden["net_n_640_bias"]), cls_gain=8.0)
     x = torch.rand(4, 3, 640, 640, generator=torch.Generator().manual_seed(300))
     eng = _engine("n", sd, 4, 640, 640, gpu_device)
@@ -252,11 +263,14 @@ def test_end_to_end_640_vs_bf16_storage_oracle(gpu_device, golden):
     got = [out[i, : int(cnt[i])].cpu() for i in range(4)]
     torch.set_num_threads(8)
     with torch.inference_mode():
+        y32, _ = oracle.forward(sd, x, "n")
         y16, _ = oracle.forward(sd, x, "n", storage="bf16")
-    ref = oracle.non_max_suppression(y16, 0.25, 0.7)
-    stats = parity_gate(ref, got, 0.25, 0.7, band=BF16_SCORE_ATOL, ref_y=y16, verbose=True)
-    print("e2e 640 vs bf16-storage oracle:", stats)
-    assert stats["ok"] and stats["class_near_tie"] <= 1, stats
+    ref = oracle.non_max_suppression(y32, 0.25, 0.7)
+    st_hip = parity_gate(ref, got, 0.25, 0.7, band=SCORE_ATOL, ref_y=y32, verbose=True)
+    st_fmt = parity_gate(ref, oracle.non_max_suppression(y16, 0.25, 0.7), 0.25, 0.7, band=SCORE_ATOL, ref_y=y32)
+    verdict = format_yardstick_ok(st_hip, st_fmt, SCORE_ATOL)
+    print("e2e 640: HIP", st_hip, "\n         format", st_fmt, "\n        ", verdict)
+    assert st_hip["ok"] and verdict["ok"], (st_hip, verdict)
 
 
 @pytest.mark.parametrize("kw", [dict(conf=0.25, iou=0.7), dict(conf=0.25, iou=0.7, classes=[1, 27, 40]),

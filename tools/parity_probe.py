@@ -56,7 +56,7 @@ def main(tag="r02"):
                              box_max_strides=round(float(((y[:, :4] - yr[:, :4]).abs() / st).max()), 4),
                              level_rel_l2=[round(float((a - b).norm() / b.norm()), 5) for a, b in zip(lv, raw)],
                              cls_logit_max=[round(float((a[:, 64:] - b[:, 64:]).abs().max()), 4) for a, b in zip(lv, raw)],
-                             gate=parity_gate(ref, det, 0.25, 0.7, band=0.08 if mode == "fp32" else 0.03, ref_y=yr))
+                             gate=parity_gate(ref, det, 0.25, 0.7, band=0.08, ref_y=yr))
         out[key] = rec
         print(key, json.dumps(rec), flush=True)
         del eng

@@ -11,15 +11,18 @@ from pathlib import Path
 
 # Runtime knobs of the HIP runtime that the hot path's speed depends on.  They are NOT set at import: call
 # ``apply_runtime_knobs()`` (bench.py, tests/conftest.py, __graft_entry__ and AutoBackend do) before the first GPU
-# call of the process; ``runtime_knob_status()`` says whether that happened in time, and ``graph_branch_probe()``
-# measures on the device whether two graph branches really overlap.
-#   DEBUG_HIP_FORCE_GRAPH_QUEUES=2  the hot path replays as a hipGraph with exactly two parallel branches (network
-#       trunk + the 80x80 class branch).  With the runtime's default graph-queue heuristic the branch often ends up
-#       serialised behind the trunk (measured: 27.0 k vs 33.3 k images/s); two forced graph queues make the mapping
-#       deterministic.
-#   GPU_MAX_HW_QUEUES=8  several batches in flight x two graph queues each: give each stream its own hardware queue
+# call of the process; ``runtime_knob_status()`` says whether that happened in time.
+#   GPU_MAX_HW_QUEUES=8  several batches in flight on several streams: give each stream its own hardware queue
 #       (the runtime's default of four makes them share; 37.4 k -> 38.6 k images/s).
-RUNTIME_KNOBS = {"DEBUG_HIP_FORCE_GRAPH_QUEUES": "2", "GPU_MAX_HW_QUEUES": "8"}
+# NOT set any more (round 2): DEBUG_HIP_FORCE_GRAPH_QUEUES=2.  Round 1 forced two graph queues so that the captured
+# graph's class-branch lane would overlap the trunk (27.0 k -> 33.3 k images/s).  tests/test_gpu_dist.py showed that
+# with that debug flag a replay does NOT honour the fork edge of the graph: the branch starts on the second queue
+# before the trunk node it depends on has finished and reads the previous replay's tensor -- invisible while every
+# replay sees the same input (all of round 1's tests and its bench), wrong as soon as the input changes between replays.
+# The hot path's graph is therefore captured as ONE chain (nn/lower.py: side lanes are opt-in), and the overlap comes
+# from several batches in flight on several streams only.  ``graph_branch_probe()`` still reports what the runtime does
+# with a two-branch graph.
+RUNTIME_KNOBS = {"GPU_MAX_HW_QUEUES": "8"}
 _knob_status = {"applied": False, "before_hip_init": None, "values": {}}
 
 

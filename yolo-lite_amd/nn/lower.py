@@ -668,7 +668,12 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
     # inside a hipGraph cost 5-60 us each, so only the longest chain -- five 80x80 kernels that overlap
     # the 80x80 box branch and the 40x40 neck -- is worth a fork; 1.37 -> 1.21 ms end to end).
     # YL_LANES="b0c0b1c1b2c2" (one lane digit per level and branch) overrides it for experiments.
+    # Round 2: OFF by default (YL_SIDE_LANES=1 restores it).  Whether a captured graph's branch really overlaps the trunk is
+    # up to the HIP runtime, and the one setting that made it do so reliably (DEBUG_HIP_FORCE_GRAPH_QUEUES=2) replays the
+    # graph WITHOUT honouring the fork edge (see _lib.RUNTIME_KNOBS): the hot path is captured as one chain, correctness
+    # does not depend on the runtime's multi-queue graph scheduling, and overlap comes from batches in flight.
     import os
+    side_lanes = side_lanes and os.environ.get("YL_SIDE_LANES", "0") == "1"
     nlv = len(det.f)
     lanes = [0] * (2 * nlv)
     if side_lanes and nlv > 1:
