@@ -322,8 +322,9 @@ REG_CASES = [
 ]
 
 
+@pytest.mark.parametrize("pipe", [0, 1])
 @pytest.mark.parametrize("cin,cout,h,w,act,res,nt", REG_CASES)
-def test_conv3_reg_vs_torch_and_direct(gpu_device, monkeypatch, cin, cout, h, w, act, res, nt):
+def test_conv3_reg_vs_torch_and_direct(gpu_device, monkeypatch, cin, cout, h, w, act, res, nt, pipe):
     """The filter-in-registers 3x3 kernel against torch, and against the direct kernel: same k order, same MFMA
     accumulation chain starting from the bias -> bit-identical."""
     g = torch.Generator().manual_seed(cin * 100 + cout + h + nt + 7)
@@ -341,6 +342,7 @@ def test_conv3_reg_vs_torch_and_direct(gpu_device, monkeypatch, cin, cout, h, w,
     monkeypatch.setenv("YL_CONV_REG", "1")
     monkeypatch.setenv("YL_CONV_REG_MIN", "1")
     monkeypatch.setenv("YL_CONV_REG_NT", str(nt))
+    monkeypatch.setenv("YL_CONV_REG_PIPE", str(pipe))  # 1: the previous tile's epilogue interleaved with the MFMAs
     got = run_conv(gpu_device, x, wt, b, 3, 1, act, r, expect_kernel="conv3x3_reg_mfma")
     _assert_close_bf16(got, ref, f"reg conv {cin}->{cout} NT={nt}")
     monkeypatch.setenv("YL_CONV_REG", "0")

@@ -14,7 +14,7 @@ from yololite_amd.nn.lower import BF16, FP8, OP_CONV, Program, _Arena
 
 cin, cout, k, s, H, W = map(int, sys.argv[1:7])
 f8 = len(sys.argv) > 7 and sys.argv[7] == "fp8"
-B = 32
+B = int(os.environ.get("YL_MICRO_B", "32"))
 dev = torch.device("cuda:0")
 ar = _Arena(B)
 prog = Program(B, 32, 32, 80)

@@ -15,6 +15,8 @@
 //     activations (all Cin / 8 planes of a tile at once, no channel phases).  The DMA pieces of tile i + 1 are issued
 //     one per k-step BETWEEN the MFMAs of tile i (a lone wave per SIMD has nobody else to hide their issue cost).
 //   * Persistent workgroups (one per CU) walk the tiles t = wg, wg + G, ...; one barrier per tile.
+#include <type_traits>
+
 #include "conv_common.h"
 
 namespace yl {
@@ -96,6 +98,31 @@ __device__ __forceinline__ void mfma_first(f32x4& acc, const u32x4& wa, const bf
   else
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %3" : "=&v"(acc) : "v"(wa), "v"(xb), "v"(c));
 }
+// The previous tile's epilogue as single VALU instructions in volatile asm, so that they stay exactly where the source puts
+// them BETWEEN the (equally volatile) MFMAs: an MFMA holds the SIMD's issue port for 8 of its 16 cycles, one v_exp /
+// v_rcp (8 cycles) or two plain VALU instructions fit in the rest.  Left to itself hipcc emits the epilogue as one block
+// of ~45 instructions per store, during which the matrix pipe idles (measured: slower than no overlap at all).
+// Same instructions and operand order as silu_f() + the (__bf16) casts compile to, so results are bit-identical.
+// A transcendental's result must not be read by the very next instruction (gfx940 trans forwarding hazard): the
+// stream below always has an independent instruction of the partner value in between.
+__device__ __forceinline__ void e_mul(float& t, float x) { asm volatile("v_mul_f32 %0, 0xbfb8aa3b, %1" : "=v"(t) : "v"(x)); }
+__device__ __forceinline__ void e_exp(float& t) { asm volatile("v_exp_f32 %0, %0" : "+v"(t)); }
+__device__ __forceinline__ void e_add1(float& t) { asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(t)); }
+__device__ __forceinline__ void e_rcp(float& t) { asm volatile("v_rcp_f32 %0, %0" : "+v"(t)); }
+__device__ __forceinline__ void e_mulx(float& t, float x) { asm volatile("v_mul_f32 %0, %1, %0" : "+v"(t) : "v"(x)); }
+__device__ __forceinline__ void e_cvt(unsigned& d, float lo, float hi) {
+  asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(d) : "v"(lo), "v"(hi));
+}
+struct EpiRegs {
+  float t[8];
+  unsigned d[4];
+};
+// The stream is cut into UNITS of at most 8 issue cycles -- what fits beside one MFMA: per pair of values (A, B)
+//   [mul A, mul B] [exp A] [exp B] [add A, add B] [rcp A] [rcp B] [mul A, mul B] [pack (+ store)]
+// i.e. 8 units per pair, 32 per 16-byte store.  (A first version spread single operations evenly, 1.2 per MFMA: gaps
+// holding two transcendentals overran their MFMA by 8 cycles and nothing gave that back -- no gain at all.)
+constexpr int EPI_UNITS = 32;
+
 template <int MT, int NT>
 __device__ __forceinline__ void mfma_drain(f32x4 (&acc)[MT][NT]) {
   asm volatile("s_nop 15");
@@ -107,7 +134,7 @@ __device__ __forceinline__ void mfma_drain(f32x4 (&acc)[MT][NT]) {
 
 // MT * 16 = Cout (32 or 64), NPH * 32 = Cin (32 or 64); a wave owns NT * 16 consecutive guarded positions of the
 // workgroup's tile of L = 64 * NT.
-template <int MT, int NT, int NPH, bool RES>
+template <int MT, int NT, int NPH, bool RES, bool ACT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv3_reg_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int L = 64 * NT;
@@ -115,6 +142,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   constexpr int NPL = 4 * NPH;    // input planes
   constexpr int NPW = NPL / 4;    // planes each wave stages: wave, wave + 4
   constexpr int NSTORE = (MT / 2) * NT;  // 16-byte stores per lane and tile
+  constexpr int EOFF = KS >= 18 ? 4 * MT * NT : 0;  // MFMAs of a tile before the interleaved epilogue stream starts (4 k-steps)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, n = lane & 15;
@@ -133,19 +161,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int nmine = (a.t_ntiles - wg + G - 1) / G;  // tiles wg, wg + G, ... (> 0: grid <= tiles)
   const int ppw = NPW * a.t_ppp;        // DMA pieces per wave and tile
   const unsigned lane16 = (unsigned)lane * 16u;
+  const bool early_dma = ppw <= EOFF / NT && !(a.dbg & 512);  // all pieces go out in the first EOFF MFMAs (one per row)
 
   // Piece j of a wave = 64 positions (1 KiB) of plane wave + 4 * (j / t_ppp); the (plane, piece) counters live in SGPRs.
   struct Dma {
     int pp, src, dst;  // piece inside the plane; byte offset of the piece in the input slice / in LDS
   };
-  auto dma_begin = [&](int t, int buf) {
+  auto dma_begin = [&](int t, int buf) __attribute__((always_inline)) {
     Dma d;
     d.pp = 0;
     d.src = wave * (int)a.in_plane + (a.in_g0 + t * L - a.in_w1 - 1) * 16;  // first staged guarded position (>= 0)
     d.dst = buf * buf_bytes + wave * PLB;
     return d;
   };
-  auto dma_piece = [&](const __amdgpu_buffer_rsrc_t& r, Dma& d) {
+  auto dma_piece = [&](const __amdgpu_buffer_rsrc_t& r, Dma& d) __attribute__((always_inline)) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_r*)(smem + d.dst), 16, (int)(lane16 + (unsigned)d.src), 0, 0, 0);
     d.pp += 1;
     d.src += 1024;
@@ -180,7 +209,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int row_bytes = a.in_w1 * 16;
   const int half_bytes = 4 * PLB;  // planes 4 .. 7 (second half of a 64-channel input)
 
-  auto load_b = [&](const unsigned char* tb, int ks, bf16x8 (&xb)[NT]) {
+  auto load_b = [&](const unsigned char* tb, int ks, bf16x8 (&xb)[NT]) __attribute__((always_inline)) {
     const int tap = ks / NPH, c = ks % NPH;
     const int dy = tap / 3, dx = tap % 3;
     const unsigned char* rb = tb + c * half_bytes + dy * row_bytes;
@@ -188,13 +217,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int nt = 0; nt < NT; ++nt) xb[nt] = *reinterpret_cast<const bf16x8*>(rb + dx * 16 + nt * 256);
   };
 
-  for (int i = 0; i < nmine; ++i) {
+  // Unit u of the interleaved epilogue stream of one finished tile (accumulators ac, output offsets po): store
+  // c = u / EPI_UNITS covers tile pair p = c / NT and column tile nt = c % NT; values j0, j1 of its 8 go through
+  // t = -log2(e) x; t = 2^t; t = 1 + t; t = 1 / t; t = x t; then one pack, the fourth pack brings the store.
+  EpiRegs E;
+  auto epi_op = [&](int u, const f32x4 (&ac)[MT][NT], const unsigned (&po)[NT], EpiRegs& e) __attribute__((always_inline)) {
+    const int c = u / EPI_UNITS, r = u % EPI_UNITS, p = c / NT, nt = c % NT;
+    const int pair = r / 8, k = r % 8, j0 = 2 * pair, j1 = j0 + 1;
+    const float x0 = j0 < 4 ? ac[2 * p][nt][j0] : ac[2 * p + 1][nt][j0 - 4];
+    const float x1 = j1 < 4 ? ac[2 * p][nt][j1] : ac[2 * p + 1][nt][j1 - 4];
+    if (k == 0) {
+      e_mul(e.t[j0], x0);
+      e_mul(e.t[j1], x1);
+    } else if (k == 1) e_exp(e.t[j0]);
+    else if (k == 2) e_exp(e.t[j1]);
+    else if (k == 3) {
+      e_add1(e.t[j0]);
+      e_add1(e.t[j1]);
+    } else if (k == 4) e_rcp(e.t[j0]);
+    else if (k == 5) e_rcp(e.t[j1]);
+    else if (k == 6) {
+      e_mulx(e.t[j0], x0);
+      e_mulx(e.t[j1], x1);
+    } else {
+      e_cvt(e.d[pair], e.t[j0], e.t[j1]);
+      if (pair == 3 && !(a.dbg & 64))
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{e.d[0], e.d[1], e.d[2], e.d[3]}, rout,
+                                               (unsigned)(p * 4 + g) * a.out_plane + po[nt], 0, 0);
+    }
+  };
+
+  // One tile: barrier, k-loop into `acc` with the next tile's DMA pieces and -- PIPE -- the PREVIOUS tile's epilogue
+  // (accumulators `accp`, output offsets `pop`) spread over the k-steps, one store-sized chunk at a time: a lone wave
+  // per SIMD has no partner whose MFMAs could cover its SiLU (v_exp + v_rcp are quarter rate), so it covers it itself.
+  auto tile_body = [&](auto has_prev, int i, f32x4 (&acc)[MT][NT], const f32x4 (&accp)[MT][NT],
+                       const unsigned (&pop)[NT]) __attribute__((always_inline)) {
+    constexpr bool HP = decltype(has_prev)::value;
     const int t = wg + i * G;
     const int buf = i & 1;
-    f32x4 acc[MT][NT];  // first written by the k-step 0 MFMAs (C = bias)
-    // This tile's DMA pieces have landed: they are older than the previous tile's NSTORE epilogue stores, which may stay
-    // in flight (vmcnt retires in order); then every wave has left the previous tile's k-loop -> the other buffer is free.
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
+    // This tile's DMA pieces have landed (every wave waits for its own VMEM operations, then the barrier); every wave
+    // has left the previous tile's k-loop -> the other buffer is free.
+    // The NSTORE youngest VMEM operations are the previous tile's stores (un-pipelined: issued behind the k-loop;
+    // pipelined: the stream starts after the last DMA piece when the pieces fit the first EOFF MFMAs) and may stay in flight.
+    if (!HP || early_dma) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NSTORE) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     const bool more = i + 1 < nmine;
     const __amdgpu_buffer_rsrc_t rnext = more ? rin : rnull;
@@ -203,6 +269,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     bf16x8 xb[2][NT];
     load_b(tb, 0, xb[0]);
     int jd = 0;
+    const int dpk = a.dbg & 512 ? 1 : MT;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       if (ks + 1 < KS) load_b(tb, ks + 1, xb[(ks + 1) & 1]);  // next step's fragments fly under this step's MFMAs
@@ -214,8 +281,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           if (ks == 0) mfma_first<(0 < KA1)>(acc[mt][nt], wr[0][mt], xb[0][nt], bias_r[mt]);
           else if (ks < KA1) mfma_acc<true>(acc[mt][nt], wr[ks][mt], xb[ks & 1][nt]);
           else mfma_acc<false>(acc[mt][nt], wr[ks][mt], xb[ks & 1][nt]);
+          if constexpr (HP) {
+            // this MFMA's share of the previous tile's epilogue stream: units [o0, o1) of NSTORE * EPI_UNITS
+            // (one per MFMA where the tile has that many MFMAs -- Cin = 64 --, up to three where it has not)
+            // The stream starts EOFF MFMAs into the tile: by then every DMA piece of the next tile has been issued (4 per
+            // k-step, see below), so all NSTORE stores are younger than all pieces and may stay in flight across the
+            // next barrier (counted vmcnt, in-order retirement).
+            constexpr int S = KS * MT * NT - EOFF, NU = NSTORE * EPI_UNITS;
+            static_assert(NU <= 3 * S, "at most three epilogue units per MFMA");
+            const int slot = (ks * MT + mt) * NT + nt - EOFF;
+            const int o0 = slot < 0 ? 0 : slot * NU / S, o1 = slot < 0 ? 0 : (slot + 1) * NU / S;
+            // (no inner loop: loops are unrolled innermost first, and only straight-line code folds with the outer ones)
+            if (o0 < o1) epi_op(o0, accp, pop, E);
+            if (o0 + 1 < o1) epi_op(o0 + 1, accp, pop, E);
+            if (o0 + 2 < o1) epi_op(o0 + 2, accp, pop, E);
+          }
         }
-        if (mt == 0 && jd < ppw) {  // one DMA piece of the next tile per k-step, between the MFMAs
+        // The next tile's DMA pieces go out EARLY in this tile, DPK per k-step behind the first two MFMA rows: the last
+        // piece then has (KS - ppw / DPK) k-steps to land before the next barrier needs it.  (One piece per k-step left
+        // the last ones ~4 k-steps = 0.5 us: SQ_WAIT_ANY showed a quarter of every wave's life parked at the barrier.)
+        if (mt < dpk && jd < ppw) {
           dma_piece(rnext, d);
           ++jd;
         }
@@ -223,9 +308,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
     for (; jd < ppw; ++jd) dma_piece(rnext, d);
     mfma_drain<MT, NT>(acc);
-    unsigned po[NT];
-    reg_tile_opix<NT>(a, t * L + wave * (16 * NT), n, po);
-    if (!(a.dbg & 64)) reg_epilogue<MT, NT, RES>(a, rout, rres, g, po, acc);
+  };
+
+  const int ntile_run = (a.dbg & 128) ? 0 : nmine;
+  constexpr bool PIPE = !RES && ACT;
+  if constexpr (PIPE) {
+    // two accumulator sets alternate: tile i computes into one while the other one's tile is being written out
+    f32x4 accA[MT][NT], accB[MT][NT];
+    unsigned poA[NT], poB[NT];
+    int i = 0;
+    if (ntile_run > 0) {
+      tile_body(std::false_type{}, 0, accA, accB, poB);
+      reg_tile_opix<NT>(a, wg * L + wave * (16 * NT), n, poA);
+      for (i = 1; i + 1 < ntile_run; i += 2) {
+        tile_body(std::true_type{}, i, accB, accA, poA);
+        reg_tile_opix<NT>(a, (wg + i * G) * L + wave * (16 * NT), n, poB);
+        tile_body(std::true_type{}, i + 1, accA, accB, poB);
+        reg_tile_opix<NT>(a, (wg + (i + 1) * G) * L + wave * (16 * NT), n, poA);
+      }
+      if (i < ntile_run) {  // one tile left: into B, then both epilogues below
+        tile_body(std::true_type{}, i, accB, accA, poA);
+        reg_tile_opix<NT>(a, (wg + i * G) * L + wave * (16 * NT), n, poB);
+        if (!(a.dbg & 64)) reg_epilogue<MT, NT, false>(a, rout, rres, g, poB, accB);
+      } else {
+        if (!(a.dbg & 64)) reg_epilogue<MT, NT, false>(a, rout, rres, g, poA, accA);
+      }
+    }
+  } else {
+    for (int i = 0; i < ntile_run; ++i) {
+      f32x4 acc[MT][NT];
+      unsigned po[NT];
+      tile_body(std::false_type{}, i, acc, acc, po);
+      reg_tile_opix<NT>(a, (wg + i * G) * L + wave * (16 * NT), n, po);
+      if (!(a.dbg & 64)) reg_epilogue<MT, NT, RES>(a, rout, rres, g, po, acc);
+    }
   }
 }
 
@@ -244,22 +360,32 @@ void conv3_reg_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, i
   if (!enable || k != 3 || stride != 1 || post) return;
   if ((Cin != 32 && Cin != 64) || (Cout != 32 && Cout != 64) || c->ncb != 1 || Cout != c->MT * 16) return;
   const long long nq = (long long)batch * (Ho + 1) * (Wo + 1);
+  // Workgroups are persistent, one per CU, so a launch takes ceil(tiles / 256) rounds of NT units each: pick the tile
+  // width with the fewest units (64 -> 64 @80x80, batch 32: NT = 4 needs 4 rounds = 16 units, NT = 2 seven = 14), the
+  // wider one on a tie (less halo: L + 2 W + 4 positions are staged per L outputs).
+  int best = 0;
+  long long best_units = 0;
   for (int NT = 4; NT >= 2; NT >>= 1) {
     if (NT > want_nt) continue;
     const long long ntiles = (nq + 64 * NT - 1) / (64 * NT);
     const size_t lds = (size_t)2 * (Cin / 8) * reg_PL(NT, Wo) * 16;
-    if (ntiles >= min_tiles && lds <= LDS_MAX_R) {
-      c->reg = NT;
-      c->tile = 0;
-      c->name = "conv3x3_reg_mfma";
-      return;
+    if (ntiles < min_tiles || lds > LDS_MAX_R) continue;
+    const long long units = (ntiles + NUM_CU_R - 1) / NUM_CU_R * NT;
+    if (!best || units < best_units) {
+      best = NT;
+      best_units = units;
     }
+  }
+  if (best) {
+    c->reg = best;
+    c->tile = 0;
+    c->name = "conv3x3_reg_mfma";
   }
 }
 
-template <int MT, int NT, int NPH, bool RES>
+template <int MT, int NT, int NPH, bool RES, bool ACT>
 static int launch_reg_r(const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
-  auto kern = conv3_reg_kernel<MT, NT, NPH, RES>;
+  auto kern = conv3_reg_kernel<MT, NT, NPH, RES, ACT>;
   static bool attr = false;
   if (!attr) {
     YL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -273,7 +399,13 @@ static int launch_reg_r(const ConvArgs& a, int grid, size_t lds, hipStream_t s) 
 
 template <int MT, int NT, int NPH>
 static int launch_reg(const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
-  return a.res ? launch_reg_r<MT, NT, NPH, true>(a, grid, lds, s) : launch_reg_r<MT, NT, NPH, false>(a, grid, lds, s);
+  // (the interleaved epilogue stream exists for the common case: SiLU, no residual)
+  // Opt-in (YL_CONV_REG_PIPE=1): bit-identical and measured EQUAL in time to the plain form on MI355X (64 -> 64 @80x80:
+  // 26-30 us either way, box to box): VALU work placed between one wave's own MFMAs did not overlap with them here.
+  const int pipe = getenv("YL_CONV_REG_PIPE") ? atoi(getenv("YL_CONV_REG_PIPE")) : 0;
+  if (a.res) return launch_reg_r<MT, NT, NPH, true, false>(a, grid, lds, s);
+  return (a.act && pipe) ? launch_reg_r<MT, NT, NPH, false, true>(a, grid, lds, s)
+                         : launch_reg_r<MT, NT, NPH, false, false>(a, grid, lds, s);
 }
 
 int conv3_reg_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s) {
