@@ -132,11 +132,20 @@ class DetectionPredictor:
         else:
             shapes = [tuple(o.shape[:2]) for o in orig_imgs]
             imgs = orig_imgs
-        sc = []
-        for h0, w0 in shapes:
-            gain, pad = ops.scale_boxes_params(tuple(img.shape[2:]), (h0, w0))
-            sc.append([pad[0], pad[1], gain, w0, h0])
-        return shapes, imgs, torch.tensor(sc, dtype=torch.float32, device=device)
+        # the (pad, gain, original size) table of scale_boxes: one small device tensor per distinct shape tuple, cached
+        # (building and uploading it cost more host time than launching the whole network graph)
+        key = (tuple(img.shape[2:]), tuple(shapes), str(device))
+        cache = self.__dict__.setdefault("_scale_cache", {})
+        scale = cache.get(key)
+        if scale is None:
+            sc = []
+            for h0, w0 in shapes:
+                gain, pad = ops.scale_boxes_params(tuple(img.shape[2:]), (h0, w0))
+                sc.append([pad[0], pad[1], gain, w0, h0])
+            if len(cache) > 64:
+                cache.clear()
+            scale = cache[key] = torch.tensor(sc, dtype=torch.float32, device=device)
+        return shapes, imgs, scale
 
     def _detect_fused(self, im, orig_imgs):
         """inference + postprocess in one pass: the (B, 4+nc, A) tensor is never materialised."""
@@ -150,12 +159,12 @@ class DetectionPredictor:
         out, cnt = eng.detect(im.contiguous(), self.args.conf, self.args.iou, max_det=self.args.max_det,
                               classes=self.args.classes, agnostic=self.args.agnostic_nms, scale=scale, graph=graph,
                               stage=graph)
-        counts = cnt.tolist()
+        if graph:  # engine-owned output buffers are overwritten by the next call: ONE copy of the padded records
+            out = out.clone()
+        counts = cnt.tolist()  # the one host sync of the batch
         self.last_preds = None
-        # engine-owned output buffers are overwritten by the next call: Results get their own (small) copies
-        return [Results(imgs[i], path=self.batch[0][i], names=self.model.names,
-                        boxes=out[i, : counts[i]].clone() if graph else out[i, : counts[i]], orig_shape=shapes[i])
-                for i in range(b)]
+        names, paths = self.model.names, self.batch[0]
+        return [Results(imgs[i], path=paths[i], names=names, boxes=out[i, : counts[i]], orig_shape=shapes[i]) for i in range(b)]
 
     # ------------------------------------------------------------------ driver
     def __call__(self, source=None, model=None, stream=False, *args, **kwargs):

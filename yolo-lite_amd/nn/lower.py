@@ -827,6 +827,9 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
         if os.environ.get("YL_FP8_MIRROR", "0") == "1":
             ops[:] = apply_fp8_mirrors(ops, ar, fp8_scales)
         ops[:] = apply_fp8(ops, ar, fp8_scales)
+    drop = [t for t in os.environ.get("YL_DROP_OPS", "").split(",") if t]  # timing ablation only: results are wrong
+    if drop:
+        ops[:] = [o for o in ops if not any(o.get("name", "").startswith(t) for t in drop)]
     a_total = 0
     for lvl in range(len(det.f)):
         prog.levels.append(level_rec[lvl])
