@@ -422,7 +422,7 @@ def test_fused_class_branch_tail_is_bit_identical(gpu_device, monkeypatch, h, w)
     the two-launch form (the 80-channel tensor between the 1x1 convs stays in LDS): every bit of the output."""
     sd = synth_state_dict("n", 8, cls_bias=[-2.0, -2.0, -2.0], cls_gain=4.0)
     x = torch.rand(2, 3, h, w, generator=torch.Generator().manual_seed(h * 3 + w))
-    monkeypatch.setenv("YL_FUSE_DWPW_TAIL", "1")  # opt-in (slower end to end, see nn/lower.py)
+    monkeypatch.setenv("YL_FUSE_DWPW_TAIL", "1")  # the default since round 2 (see nn/lower.py)
     eng = _engine("n", sd, 2, h, w, gpu_device)
     fused = [i for i in range(len(eng.prog.ops)) if eng.op_kernel(i) == "dw3x3+pw1x1+1x1_mfma"]
     assert len(fused) == 3, fused

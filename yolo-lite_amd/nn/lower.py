@@ -809,11 +809,11 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
         ops[:] = fuse_follow_up_convs(ops)
     if fuse_post and os.environ.get("YL_FUSE_DWPW", "1") != "0":
         ops[:] = fuse_depthwise_pointwise(ops)
-        # opt-in: the three class-branch tails take 85 us instead of 110 us one after the other, but the whole step
-        # got SLOWER on MI355X (34.7-37.1 k vs 40.9-41.7 k images/s, one-batch latency 1.47 vs 1.28 ms): the 80x80
-        # class branch runs on the graph's second queue beside the trunk, and the longer, LDS-heavier kernel (53 KB
-        # per workgroup instead of 38) crowds the trunk's kernels out of the CUs
-        if os.environ.get("YL_FUSE_DWPW_TAIL", "0") == "1":
+        # Detect's last class conv joins the fused depthwise + pointwise launch (bit-identical).  Round 1 measured this
+        # SLOWER end to end (34.7-37.1 k vs 40.9-41.7 k images/s) because the 80x80 class branch ran on the graph's side
+        # lane beside the trunk; with the graph captured as one chain (round 2) it is +2.5 % (43.9 k -> 45.0 k images/s,
+        # 72 -> 69 launches).  YL_FUSE_DWPW_TAIL=0 restores the separate 1x1 launches.
+        if os.environ.get("YL_FUSE_DWPW_TAIL", "1") == "1":
             ops[:] = fuse_dwpw_tail(ops)
     if fuse_post and os.environ.get("YL_FUSE_UP", "1") != "0":
         ops[:] = fuse_upsample_into_convs(ops)
