@@ -112,6 +112,51 @@ def cpu_baseline(sd, scale, h, w, conf, iou, sample_b=8, iters=100, eng=None, de
     return out
 
 
+def short_config(scale, batch, imgsz, dtype, streams, steps, dev, conf=0.25, iou=0.7, max_det=300):
+    """A short pipelined run of another BASELINE.json configuration (3: YOLO11s bf16 batch 64; 5: YOLO11x e4m3 1280x1280
+    batch 8) inside the default bench, so that the driver's own run carries a number for them.  Same step, same timing
+    bracket as `value`; fewer steps.  For fp8 the e4m3 program's detections are gated against the bf16 program's."""
+    x = torch.rand(batch, 3, imgsz, imgsz, generator=torch.Generator().manual_seed(0)).to(dev)
+    specs, sd, eng = build_model(scale, dev, batch, imgsz, imgsz, x, fp8=dtype == "fp8")
+    x8 = (x * 255).to(torch.uint8)
+    del x
+    S = streams
+    st = [torch.cuda.Stream(device=dev) for _ in range(S)]
+    xs = [x8] + [torch.randint(0, 256, (batch, 3, imgsz, imgsz), generator=torch.Generator().manual_seed(2000 + j),
+                               dtype=torch.uint8).to(dev) for j in range(1, S)]
+
+    def step(k):
+        with torch.cuda.stream(st[k % S]):
+            return eng.detect(xs[k % S], conf, iou, max_det=max_det, graph=True, slot=k % S)
+
+    for k in range(2 * S):
+        step(k)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        out, cnt = step(k)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    res = {"workload": f"YOLO11{scale} {dtype}, {imgsz}x{imgsz} batch={batch}, {S} batches in flight", "value": round(batch * steps / dt, 1),
+           "unit": "images/sec", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4),
+           "mean_detections_per_image": round(cnt.float().mean().item(), 1)}
+    if dtype == "fp8":
+        from oracle.parity_gate import parity_gate
+        from yololite_amd.nn.engine import HipEngine
+
+        o8, c8 = eng.detect(x8, conf, iou, max_det=max_det, graph=False)
+        e16 = HipEngine.from_model(specs, sd, batch, imgsz, imgsz, dev)
+        o16, c16 = e16.detect(x8, conf, iou, max_det=max_det, graph=False)
+        torch.cuda.synchronize(dev)
+        g = parity_gate([o16[i, : int(c16[i])].cpu() for i in range(batch)], [o8[i, : int(c8[i])].cpu() for i in range(batch)],
+                        conf, iou, band=0.15, min_matched_frac=0.75)
+        res["fp8_vs_bf16"] = {k: g[k] for k in ("ref", "det", "matched", "matched_frac", "class_mismatch", "unexplained", "max_dconf", "ok")}
+        del e16
+    del eng
+    torch.cuda.empty_cache()
+    return res
+
+
 def measured_traffic(kernel, cfg):
     """HBM bytes per launch of a kernel family from a committed PMC summary (profiles/*_traffic.json, written by
     tools/summarize_profile.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench; PMC counters
@@ -194,6 +239,8 @@ def main():
                     help="fp8: dense 3x3 convs in OCP e4m3 (weights + activations, fp32 accumulate) on "
                          "v_mfma_f32_16x16x128_f8f6f4, everything else bf16 (BASELINE.json config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short runs of BASELINE.json configs 3 and 5 that the default bench appends (other_configs)")
     ap.add_argument("--profile-out", default="", help="write the per-op timing table to this JSON file")
     args = ap.parse_args()
 
@@ -415,6 +462,17 @@ def main():
                 res["fp8_vs_bf16"]["fp8_flop_share"] = round(sum(r["flops"] for r in rows if "_f8_" in r["kernel"]) /
                                                              max(1.0, sum(r["flops"] for r in rows)), 4)
                 del e16
+            default_cfg = (args.scale, B, args.imgsz, args.dtype) == ("n", 32, 640, "bf16")
+            if default_cfg and not args.no_other_configs:
+                # BASELINE.json configs 3 and 5, briefly, with the main engine's slots released first
+                del eng._slots[1:]
+                torch.cuda.empty_cache()
+                res["other_configs"] = []
+                for sc_, b_, sz_, dt_, st_, n_ in (("s", 64, 640, "bf16", 8, 100), ("x", 8, 1280, "fp8", 8, 40)):
+                    try:
+                        res["other_configs"].append(short_config(sc_, b_, sz_, dt_, st_, n_, dev))
+                    except Exception as e:  # never at the cost of the main line
+                        res["other_configs"].append({"workload": f"YOLO11{sc_} {dt_} {sz_} batch={b_}", "error": repr(e)})
             if not args.no_cpu_baseline:
                 # bounded sample: about as much host work as 800 images of YOLO11n at 640x640 (~12 s on 8 threads)
                 gf = CONV_GFLOP_AT_640.get(args.scale, 200.0) * (H * W) / (640 * 640)

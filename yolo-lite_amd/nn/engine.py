@@ -92,8 +92,10 @@ class HipEngine:
         streams use different slots of ONE engine (shared packed weights), e.g. bench.py pipelines two."""
         while len(self._slots) <= i:
             with torch.cuda.device(self.device):
-                ws = torch.empty(self.prog.ws_bytes, dtype=torch.uint8, device=self.device)
-                # zero the guard pixels of the planar layout once; no kernel ever writes them
+                # zero the guard pixels of the planar layout once; no kernel ever writes them.  torch.zeros, not
+                # empty + prepare alone: the allocator may hand out the address of a workspace this engine has seen
+                # (and cleared) before, which yl_engine_prepare_workspace would then skip
+                ws = torch.zeros(self.prog.ws_bytes, dtype=torch.uint8, device=self.device)
                 _lib.check(self.lib.yl_engine_prepare_workspace(self._h, ws.data_ptr(),
                                                                 torch.cuda.current_stream(self.device).cuda_stream),
                            "yl_engine_prepare_workspace")
