@@ -263,7 +263,8 @@ def main():
 
     B, H, W = args.batch, args.imgsz, args.imgsz
     conf, iou, max_det = 0.25, 0.7, 300
-    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(rank)).to(dev)
+    # the same calibration batch on every rank (seed 0): the class bias, hence the weights, are identical replicas
+    x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(0)).to(dev)
     specs, sd, eng = build_model(args.scale, dev, B, H, W, x, target_frac=args.cand_frac, fp8=args.dtype == "fp8")
     cfg_key = {"scale": args.scale, "imgsz": args.imgsz, "batch": B, "dtype": args.dtype}
 
