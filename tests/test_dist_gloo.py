@@ -41,18 +41,19 @@ def _worker(rank, world, port, steps, slots, q):
         per = 3
         g = torch.Generator().manual_seed(1234)
         batches = [torch.randint(0, 256, (world * per, 3, 8, 8), generator=g, dtype=torch.uint8) for _ in range(3)]
-        # engine stand-in: one packed record per slot, overwritten every time the slot comes round (like the
-        # engine-owned static outputs of HipEngine.detect_record); the runner must hand the SAME input buffer to a slot
-        recs = [torch.empty(record_floats(per, MAX_DET)) for _ in range(slots)]
+        # engine stand-in: one packed record per lane (two per slot), overwritten every time the lane comes round (like the
+        # engine-owned static outputs of HipEngine.detect_record); the runner must hand the SAME input buffer to a lane
+        recs = [torch.empty(record_floats(per, MAX_DET)) for _ in range(2 * slots)]
         seen_ptr = {}
 
-        def compute(im, slot):
-            assert seen_ptr.setdefault(slot, im.data_ptr()) == im.data_ptr(), "a slot's input buffer must not move"
+        def compute(im, slot, lane):
+            assert lane % slots == slot and 0 <= lane < 2 * slots
+            assert seen_ptr.setdefault(lane, im.data_ptr()) == im.data_ptr(), "a lane's input buffer must not move"
             out, cnt = _fake_compute(im)
-            o, c = pack_views(recs[slot], per, MAX_DET)
+            o, c = pack_views(recs[lane], per, MAX_DET)
             o.copy_(out)
             c.copy_(cnt)
-            return recs[slot]
+            return recs[lane]
 
         runner = ShardedRunner(compute, per, (3, 8, 8), torch.uint8, torch.device("cpu"), record_floats(per, MAX_DET),
                                slots=slots)

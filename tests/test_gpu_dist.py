@@ -56,8 +56,8 @@ def test_scatter_detect_gather_equals_plain_detect(gpu_device, golden, nccl_worl
 
     streams = [torch.cuda.Stream(device=gpu_device) for _ in range(slots)]
 
-    def compute(im, slot):
-        return eng.detect_record(im, 0.25, 0.7, max_det=max_det, slot=slot)
+    def compute(im, slot, lane):
+        return eng.detect_record(im, 0.25, 0.7, max_det=max_det, slot=slot, rec_key=lane)
 
     runner = ShardedRunner(compute, B, (3, H, W), torch.uint8, gpu_device, record_floats(B, max_det), slots=slots,
                            streams=streams)
@@ -74,5 +74,4 @@ def test_scatter_detect_gather_equals_plain_detect(gpu_device, golden, nccl_worl
             assert torch.equal(outs[0][i, :m], ref[k][0][i, :m])
         seen.append(k)
     assert len(set(seen)) == 2  # the two runs ended on different batches
-    # every slot's graph was captured once and kept its baked input pointer (no re-capture thrash)
-    assert all(b.data_ptr() == runner.bufs[j].data_ptr() for j, b in enumerate(runner.bufs))
+    assert len(runner.bufs) == 2 * slots  # two input buffers (and records, and graphs) per slot

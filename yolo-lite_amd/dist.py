@@ -102,36 +102,43 @@ class ShardedRunner:
     """BASELINE.json config 4 / SURVEY 8(e): per step, root scatters the uint8 global batch, every rank runs the
     hot path on its slice, root gathers the packed ``(count, max_det x 6)`` records.
 
-    ``compute(images, slot) -> rec`` is the per-GPU hot path for workspace slot ``slot``; ``images`` is this
-    runner's input buffer of that slot (the SAME tensor every time the slot comes round, so a hipGraph that
-    baked its address stays valid) and ``rec`` is the engine-owned packed record of that slot
-    (``HipEngine.detect_record``).  ``slots`` batches are in flight:
+    ``compute(images, slot, lane) -> rec`` is the per-GPU hot path: ``slot`` = the workspace slot / HIP stream the
+    step runs on (``slots`` batches are in flight), ``lane`` = which of the runner's ``depth * slots`` input buffers
+    ``images`` is -- the SAME tensor every time that lane comes round, so a hipGraph that baked its address stays
+    valid -- and the key of the engine-owned packed record the step must write (``HipEngine.detect_record(images, ...,
+    slot=slot, rec_key=lane)``).  Step k runs on slot k % slots with lane k % (depth * slots).
 
-      * scatter k + slots is issued right after compute k on the slot's stream, so it is ordered behind the
-        compute that still reads the buffer (no WAR hazard) and travels while the other slots compute;
-      * compute k waits for scatter k on the slot's stream (``Work.wait`` = a stream-side event wait on NCCL,
-        a host wait on gloo) and for the gather that still reads the slot's record from the previous round;
+    With ``depth`` = 2 buffers and records per slot, the collectives of a slot are TWO of its steps away from the
+    compute that needs them, so a slot's stream runs compute after compute with no RCCL operation in between:
+
+      * scatter k + depth * slots is issued right behind compute k on the slot's stream (ordered behind the last reader
+        of that buffer: no WAR hazard) and has a whole extra step of the slot to land;
+      * compute k waits for scatter k and for gather k - depth * slots, the last reader of the record it will overwrite
+        (``Work.wait`` = a stream-side event wait on NCCL, a host wait on gloo) -- both long complete;
       * gather k is issued on the slot's stream right behind compute k.
 
+    (``depth`` = 1 put gather k and scatter k + slots between compute k and compute k + slots of the same stream: with a
+    busy GPU the RCCL kernels queue behind running workgroups, and the rehearsal with one rank lost 24 %.)
     ``streams``: one ``torch.cuda.Stream`` per slot on the GPU; None on the CPU (gloo tests).
     """
 
-    def __init__(self, compute: Callable[[torch.Tensor, int], torch.Tensor], per_rank: int,
+    def __init__(self, compute: Callable[[torch.Tensor, int, int], torch.Tensor], per_rank: int,
                  shape: Tuple[int, int, int], dtype: torch.dtype, device: torch.device, record_words: int,
-                 slots: int = 2, src: int = 0, streams: Optional[Sequence] = None, group=None):
+                 slots: int = 2, src: int = 0, streams: Optional[Sequence] = None, group=None, depth: int = 2):
         if streams is not None and len(streams) != slots:
             raise ValueError("one stream per slot")
         self.compute = compute
         self.src = src
         self.slots = slots
+        self.lanes = depth * slots
         self.group = group
         self.streams = list(streams) if streams is not None else None
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
-        self.bufs = [torch.empty((per_rank, *shape), dtype=dtype, device=device) for _ in range(slots)]
+        self.bufs = [torch.empty((per_rank, *shape), dtype=dtype, device=device) for _ in range(self.lanes)]
         self.gathered: List[Optional[List[torch.Tensor]]] = [
             [torch.empty(record_words, dtype=torch.float32, device=device) for _ in range(self.world)]
-            if self.rank == src else None for _ in range(slots)]
+            if self.rank == src else None for _ in range(self.lanes)]
 
     def _on(self, j: int):
         return torch.cuda.stream(self.streams[j]) if self.streams is not None else contextlib.nullcontext()
@@ -141,31 +148,31 @@ class ShardedRunner:
         gathered records (one packed tensor per rank) of the LAST step, None elsewhere.  On the GPU the returned
         tensors are complete once the slot's stream has been synchronised (the caller's timed region ends with a
         device synchronise)."""
-        nb, S = len(batches), self.slots
-        sc = [None] * S
-        ga = [None] * S
+        nb, S, V = len(batches), self.slots, self.lanes
+        sc = [None] * V
+        ga = [None] * V
 
         def scatter(k: int):
-            j = k % S
-            sc[j] = scatter_images(batches[k % nb], self.bufs[j], self.src, async_op=True, group=self.group)
+            v = k % V
+            sc[v] = scatter_images(batches[k % nb], self.bufs[v], self.src, async_op=True, group=self.group)
 
-        for k in range(min(S, steps)):
+        for k in range(min(V, steps)):
             with self._on(k % S):
                 scatter(k)
         last = None
         for k in range(steps):
-            j = k % S
+            j, v = k % S, k % V
             with self._on(j):
-                sc[j].wait()
-                if ga[j] is not None:  # the previous round's gather still reads this slot's record
-                    ga[j].wait()
-                rec = self.compute(self.bufs[j], j)
-                ga[j] = gather_record(rec, self.gathered[j], self.src, async_op=True, group=self.group)
-                if k + S < steps:
-                    scatter(k + S)
-            last = j
-        for j in range(S):
-            if ga[j] is not None:
-                with self._on(j):
-                    ga[j].wait()
+                sc[v].wait()
+                if ga[v] is not None:  # the gather of step k - V still reads the record this step overwrites
+                    ga[v].wait()
+                rec = self.compute(self.bufs[v], j, v)
+                ga[v] = gather_record(rec, self.gathered[v], self.src, async_op=True, group=self.group)
+                if k + V < steps:
+                    scatter(k + V)
+            last = v
+        for v in range(V):
+            if ga[v] is not None:
+                with self._on(v % S):
+                    ga[v].wait()
         return self.gathered[last] if (last is not None and self.rank == self.src) else None

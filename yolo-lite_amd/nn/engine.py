@@ -179,7 +179,7 @@ class HipEngine:
 
     def detect(self, im: torch.Tensor, conf: float = 0.25, iou: float = 0.7, max_det: int = 300,
                classes=None, agnostic: bool = False, max_nms: int = 30000, max_wh: float = 7680.0,
-               scale: Optional[torch.Tensor] = None, graph: bool = True, slot: int = 0, stage: bool = False):
+               scale: Optional[torch.Tensor] = None, graph: bool = True, slot: int = 0, stage: bool = False, rec_key=0):
         """Network + fused Detect decode + NMS; returns padded (out[B, max_det, 6], count[B]).
 
         Bit-identical to ``forward`` followed by ``utils.ops.nms_padded`` but the (B, 4+nc, A) tensor
@@ -189,7 +189,10 @@ class HipEngine:
         Calls with different ``slot`` values may be in flight on different streams at the same time.
         ``stage=True`` (with ``graph=True``): ``im`` is first copied into an engine-owned input buffer of the slot
         (one device-to-device copy), so callers that hand over a fresh tensor every call -- the predictor API -- still
-        replay ONE captured graph instead of re-capturing per input address."""
+        replay ONE captured graph instead of re-capturing per input address.
+        ``rec_key`` (graph mode): which of the slot's engine-owned output records to write -- a slot may own several
+        (``dist.ShardedRunner`` alternates two per slot so that the gather of one step can still read its record while
+        the slot's next step runs); each (input address, record) pair is its own captured graph."""
         self._check_input(im)
         if graph and stage:
             sk = ("in", im.dtype)
@@ -209,15 +212,16 @@ class HipEngine:
         work = st[wk]
         stream = torch.cuda.current_stream(self.device).cuda_stream
         if graph:
-            if max_det not in st:
-                # one packed record per slot (boxes, then the counts as int32 bit patterns): the multi-GPU
-                # gather sends it as ONE message (dist.pack_views / dist.gather_record)
+            ok = (max_det, rec_key)
+            if ok not in st:
+                # one packed record (boxes, then the counts as int32 bit patterns): the multi-GPU gather sends it as
+                # ONE message (dist.pack_views / dist.gather_record)
                 from ..dist import pack_views, record_floats
 
                 rec = torch.empty(record_floats(self.batch, max_det), dtype=torch.float32, device=self.device)
-                st[("rec", max_det)] = rec
-                st[max_det] = pack_views(rec, self.batch, max_det)
-            out, cnt = st[max_det]
+                st[("rec", max_det, rec_key)] = rec
+                st[ok] = pack_views(rec, self.batch, max_det)
+            out, cnt = st[ok]
         else:
             out = torch.empty((self.batch, max_det, 6), dtype=torch.float32, device=self.device)
             cnt = torch.empty((self.batch,), dtype=torch.int32, device=self.device)
@@ -248,12 +252,12 @@ class HipEngine:
         return out, cnt
 
     def detect_record(self, im: torch.Tensor, conf: float = 0.25, iou: float = 0.7, max_det: int = 300, slot: int = 0,
-                      **kw) -> torch.Tensor:
+                      rec_key=0, **kw) -> torch.Tensor:
         """``detect(graph=True)`` returning the slot's packed result record (``dist.record_floats`` fp32 words:
         ``batch * max_det * 6`` box words, then the per-image counts as int32 bit patterns) -- what one rank
         contributes to the per-step gather of the sharded path."""
-        self.detect(im, conf, iou, max_det=max_det, graph=True, slot=slot, **kw)
-        return self._slot(slot)["static"][("rec", max_det)]
+        self.detect(im, conf, iou, max_det=max_det, graph=True, slot=slot, rec_key=rec_key, **kw)
+        return self._slot(slot)["static"][("rec", max_det, rec_key)]
 
     def level_views(self, i: int):
         """(box, cls) arena views of Detect level i (bf16 planar buffers of 64 and nc8 channels)."""
