@@ -350,6 +350,44 @@ def test_conv3_reg_vs_torch_and_direct(gpu_device, monkeypatch, cin, cout, h, w,
     assert torch.equal(got, direct), f"reg vs direct kernel: max diff {float((got - direct).abs().max())}"
 
 
+PAIR_CASES = [
+    # H, W, act, res     conv3_pair_kernel (64 -> 64: filter halves in the registers of two waves per SIMD), forced onto small maps
+    (20, 20, True, False),
+    (20, 20, True, True),
+    (7, 9, True, False),
+    (80, 80, True, False),
+    (33, 90, False, False),    # wide rows (the LDS budget ends at W = 90)
+    (40, 40, True, True),
+]
+
+
+@pytest.mark.parametrize("h,w,act,res", PAIR_CASES)
+def test_conv3_pair_vs_torch_and_direct(gpu_device, monkeypatch, h, w, act, res):
+    """The K-split two-waves-per-SIMD 3x3 kernel against torch, and against the direct kernel: the accumulation is
+    (bias + k-steps 0..8) + (k-steps 9..17) instead of one chain, so the two agree to one bf16 ulp, not bit for bit."""
+    g = torch.Generator().manual_seed(h * 100 + w + 13)
+    B = 3
+    x = _rand(g, B, 64, h, w)
+    wt = _rand(g, 64, 64, 3, 3, scale=1.0 / math.sqrt(64 * 9))
+    b = torch.randn(64, generator=g) * 0.5
+    ref = F.conv2d(x, wt, b, 1, 1)
+    if act:
+        ref = F.silu(ref)
+    r = None
+    if res:
+        r = _rand(g, *ref.shape)
+        ref = ref + r
+    monkeypatch.setenv("YL_CONV_PAIR", "1")
+    monkeypatch.setenv("YL_CONV_PAIR_MIN", "1")
+    got = run_conv(gpu_device, x, wt, b, 3, 1, act, r, expect_kernel="conv3x3_pair_mfma")
+    _assert_close_bf16(got, ref, f"pair conv {h}x{w}")
+    monkeypatch.setenv("YL_CONV_PAIR", "0")
+    monkeypatch.setenv("YL_CONV_REG", "0")
+    direct = run_conv(gpu_device, x, wt, b, 3, 1, act, r, expect_kernel="conv3x3_mfma")
+    assert ((got - direct).abs() <= 2.0 ** -7 * direct.abs().clamp(min=1e-2) + 1e-3).all(), "pair vs direct kernel"
+    assert float((got != direct).float().mean()) < 0.02, "only a few elements may differ by that ulp"
+
+
 def test_view_above_one_gib_fails_loudly(gpu_device):
     """Maximum sizes: buffer offsets are 32 bits with out-of-range sentinels, so a tensor slice above 1 GiB must be
     refused with an error (never wrapped around or silently truncated)."""

@@ -118,6 +118,43 @@ def test_graph_replay_matches_eager(gpu_device, golden):
     assert torch.equal(y0, y)  # same kernels, same order: bit-identical
 
 
+def test_graph_replays_track_changing_inputs(gpu_device, golden):
+    """One captured graph, replayed with DIFFERENT input contents (and different thresholds' graphs side by side): every
+    replay must equal the eager pass on that input, bit for bit.  Round 1 only ever replayed a graph on the input it was
+    captured with, which hid a runtime defect ("Graph / streams"): inputs that change are the test."""
+    sd = synth_state_dict("n", 1, cls_bias=list(golden["net_n_96x128_bias"]), cls_gain=8.0)
+    eng = _engine("n", sd, 2, 96, 128, gpu_device)
+    g = torch.Generator().manual_seed(77)
+    xs = [(torch.from_numpy(golden["net_n_96x128_x"]) * 255).to(torch.uint8).to(gpu_device)]
+    xs += [torch.randint(0, 256, (2, 3, 96, 128), generator=g, dtype=torch.uint8).to(gpu_device) for _ in range(3)]
+    ref = []
+    for x in xs:
+        o, c = eng.detect(x, 0.25, 0.7, graph=False)
+        ref.append((o.clone(), c.clone()))
+    assert len({tuple(c.tolist()) for _, c in ref}) > 1, "the inputs must give different detections"
+    buf = torch.empty_like(xs[0])  # the graph bakes THIS address; its contents change
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        for rep in range(3):
+            for k, x in enumerate(xs):
+                buf.copy_(x)
+                o, c = eng.detect(buf, 0.25, 0.7, graph=True, slot=1)
+                assert torch.equal(c, ref[k][1]), (rep, k)
+                for i in range(2):
+                    assert torch.equal(o[i, : int(c[i])], ref[k][0][i, : int(c[i])]), (rep, k, i)
+    # the predictor API stages its inputs the same way (engine-owned buffer + one graph)
+    from yololite_amd import YOLOLite
+
+    model = YOLOLite("yolo11n.yaml")
+    model.model.load_state_dict(sd)
+    for k in (0, 2, 1, 0):
+        res = model.predict(xs[k], conf=0.25, iou=0.7, device=str(gpu_device), save=False, verbose=False, batch=2)
+        sc = torch.tensor([[0.0, 0.0, 1.0, 128.0, 96.0]] * 2, device=gpu_device)
+        o, c = eng.detect(xs[k], 0.25, 0.7, graph=False, scale=sc)
+        for i, r in enumerate(res):
+            assert torch.equal(r.boxes.data, o[i, : int(c[i])]), (k, i)
+
+
 def test_uint8_and_fp16_inputs(gpu_device, golden):
     sd = synth_state_dict("n", 0)
     eng = _engine("n", sd, 1, 64, 64, gpu_device)

@@ -434,6 +434,7 @@ int conv_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo,
   c->name = k == 3 ? (stride == 2 ? "conv3x3s2_mfma" : "conv3x3_mfma") : "conv1x1_mfma";
   conv3_tile_choose(batch, Cin, Cout, k, stride, Ho, Wo, post, c);  // 3x3 s1 layers that fit: input tile in LDS
   conv3_reg_choose(batch, Cin, Cout, k, stride, Ho, Wo, post, c);   // ... or with the filter in registers
+  conv3_pair_choose(batch, Cin, Cout, k, stride, Ho, Wo, post, c);  // ... 64 -> 64: filter halves in two waves per SIMD
   return 0;
 }
 
@@ -608,6 +609,7 @@ int dwpw_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s) {
 
 // `a` arrives with pointers, plane sizes, geometry, Cin/Cout/stride/act/out_f32 filled in.
 int conv_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s) {
+  if (cfg.pair && !a.out8) return conv3_pair_launch(cfg, a, batch, s);
   if (cfg.reg && !a.out8) return conv3_reg_launch(cfg, a, batch, s);
   if (cfg.tile && a.act) return conv3_tile_launch(cfg, a, batch, s);  // (a conv without SiLU stays on conv_kernel)
   a.ncb = cfg.ncb;

@@ -112,6 +112,7 @@ struct ConvConfig {
   int MT, NT, uniform, post, ncb, cg, ksteps, kchunk, ntaps, npatches, gws, ppw;
   int tile;          // > 0: conv3_tile_kernel with this many 16-pixel column tiles per wave (else conv_kernel)
   int reg;           // > 0: conv3_reg_kernel (filter in registers) with this many 16-pixel column tiles per wave
+  int pair;          // > 0: conv3_pair_kernel (64 -> 64: filter halves in the registers of two waves per SIMD)
   size_t lds_bytes;
   size_t wpk_elems;  // packed weight elements
   const char* name;
@@ -130,6 +131,9 @@ int conv3_tile_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t 
 // conv3_reg.hip: 3x3 stride-1 convs with Cin, Cout in {32, 64}: the filter lives in the registers of every wave
 void conv3_reg_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, int post, ConvConfig* cfg);
 int conv3_reg_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s);
+// conv3_pair.hip: 3x3 stride-1 64 -> 64 convs, K split between the two waves of a SIMD
+void conv3_pair_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, int post, ConvConfig* cfg);
+int conv3_pair_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s);
 int dwpw_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s);
 // conv_f8.hip: e4m3 x e4m3 -> fp32 on v_mfma_f32_16x16x128_f8f6f4
 int conv_f8_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, ConvConfig* cfg);
