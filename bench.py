@@ -232,7 +232,7 @@ def main():
     ap.add_argument("--streams", type=int, default=0,
                     help="batches in flight: consecutive steps are issued round-robin on this many HIP streams "
                          "(one workspace slot each) so one batch's large kernels overlap another's small ones; 0 = try "
-                         "7 and 8 (sharded: 6, 7 and 8) for 80 untimed steps each and keep the fastest: HIP maps streams onto "
+                         "7, 8 and 10 (sharded: 6, 7 and 8) for min(--steps, 80) untimed steps each and keep the fastest: HIP maps streams onto "
                          "GPU_MAX_HW_QUEUES = 8 hardware queues, and a batch stream that has to share one with RCCL's stream "
                          "loses a third of the throughput")
     ap.add_argument("--cand-frac", type=float, default=0.015,
@@ -282,11 +282,14 @@ def main():
     specs, sd, eng = build_model(args.scale, dev, B, H, W, x, target_frac=args.cand_frac, fp8=args.dtype == "fp8")
     cfg_key = {"scale": args.scale, "imgsz": args.imgsz, "batch": B, "dtype": args.dtype}
 
-    cands = [args.streams] if args.streams > 0 else ([6, 7, 8] if sharded else [7, 8])
+    cands = [args.streams] if args.streams > 0 else ([6, 7, 8] if sharded else [7, 8, 10])
     S = max(cands)  # rebound below to the count that wins the trial
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     step_no = [0]
     tried = {}
+    # trial length = the timed region's own (a short run pays for its fill and drain: K = 20 steps with 8 batches in flight is
+    # two and a half rounds), capped at 80 steps
+    n_trial = max(max(cands), min(80, args.steps))
 
     def hot_path(im):
         # one step = network + fused Detect decode / candidate filter / NMS for one batch, ONE hipGraph
@@ -319,10 +322,10 @@ def main():
                 sync_all()
                 step_no[0] = 0
                 tt = time.perf_counter()
-                for k in range(80):
+                for k in range(n_trial):
                     hot_path(xs[k % S])
                 sync_all()
-                tried[S] = round(B * 80 / (time.perf_counter() - tt), 1)
+                tried[S] = round(B * n_trial / (time.perf_counter() - tt), 1)
             S = max(tried, key=tried.get)
         step_no[0] = 0
         for k in range(max(args.warmup, 2 * S)):
@@ -376,11 +379,11 @@ def main():
                 r_.run(batches, 4 * S)
                 sync_all()
                 tt = time.perf_counter()
-                r_.run(batches, 80)
+                r_.run(batches, n_trial)
                 sync_all()
                 tv = torch.tensor([time.perf_counter() - tt], dtype=torch.float64, device=dev)
                 dist.all_reduce(tv, op=dist.ReduceOp.MAX)
-                tried[S] = round(world * B * 80 / float(tv.item()), 1)
+                tried[S] = round(world * B * n_trial / float(tv.item()), 1)
                 del r_
             S = max(tried, key=tried.get)
             torch.cuda.empty_cache()
