@@ -59,7 +59,7 @@ struct yl_engine {
   };
   // Instantiated graphs, least recently used first out.  An executable may still be running on some slot's stream
   // when the cache is full, so eviction waits for the device and then destroys exactly ONE entry (the stalest);
-  // 32 entries = 5-8 slots x a few threshold settings before anything is ever evicted.
+  // 64 entries = 8-10 slots x two lanes x a few settings before anything is ever evicted.
   template <typename K>
   struct GraphCache {
     struct Ent {
@@ -68,7 +68,7 @@ struct yl_engine {
     };
     std::map<K, Ent> m;
     uint64_t tick = 0;
-    size_t cap = 32;
+    size_t cap = 64;
     hipGraphExec_t find(const K& k) {
       auto it = m.find(k);
       if (it == m.end()) return nullptr;
