@@ -473,6 +473,22 @@ def test_fused_class_branch_tail_is_bit_identical(gpu_device, monkeypatch, h, w)
         assert torch.equal(a, b)
 
 
+def test_lds_staged_class_branch_is_bit_identical(gpu_device, monkeypatch):
+    """csrc/dwpw.hip (opt-in YL_DWPW_TILE=1: class-branch input staged through an LDS ring, persistent workgroups over
+    guarded positions) against the default dwpw_kernel: same MFMA order, so every bit of the level maps."""
+    sd = synth_state_dict("n", 8, cls_bias=[-2.0, -2.0, -2.0], cls_gain=4.0)
+    x = torch.rand(2, 3, 96, 128, generator=torch.Generator().manual_seed(77))
+    monkeypatch.setenv("YL_DWPW_TILE", "1")
+    eng = _engine("n", sd, 2, 96, 128, gpu_device)
+    y = eng.forward(x.to(gpu_device)).clone()
+    lv = [t.clone() for t in eng.raw_levels()]
+    monkeypatch.setenv("YL_DWPW_TILE", "0")
+    ref_eng = _engine("n", sd, 2, 96, 128, gpu_device)
+    assert torch.equal(y, ref_eng.forward(x.to(gpu_device)))
+    for a, b in zip(lv, ref_eng.raw_levels()):
+        assert torch.equal(a, b)
+
+
 def test_cross_layer_fusions_bit_identical_at_640(gpu_device, monkeypatch):
     """BASELINE resolution: the fused stem + layer 1 and the three fused C3k2 blocks against the launch-per-conv
     form at 640x640 (full-width tiles, 160 / 80-pixel rows), every bit of the level maps and of the detections."""

@@ -198,8 +198,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
 // The Detect class branch is Sequential(DWConv(c, c, 3), Conv(c, c3, 1)) twice (head.py:41-48).  The
 // depthwise output is consumed by that 1x1 conv only, so a workgroup computes it for its 64*NT pixels
 // straight into LDS (bf16, [plane][pixel][8] = MFMA B-fragment order) and runs the 1x1 GEMM from there:
-// the intermediate tensor is never written to or read from HBM.  Same arithmetic and operation order as
-// dwconv3_kernel followed by conv_kernel (bit-identical results).  Needs all output channels in one
+// the intermediate tensor is never written to or read from HBM.  Needs all output channels in one
 // workgroup (Cout <= 80 here: MT <= 5, ncb == 1).
 // PW2: a further 1x1 conv that consumes ONLY the pointwise conv's output (head.py:47: the nn.Conv2d(c3, nc, 1) that
 // ends the class branch) runs behind it from LDS: the pointwise result is written into the depthwise tile's place in
@@ -211,68 +210,84 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, n = lane & 15;
   const int pblk = xcd_remap(blockIdx.x, gridDim.x);
-  const int C = a.Cin;
   bf16x8* slab = reinterpret_cast<bf16x8*>(smem);
   bf16x8* tile = slab + a.ksteps * MT * 64;                       // [max(cg, cg2)][P]
   const int tile_planes = PW2 ? max(a.cg, a.cg2) : a.cg;
-  float* dww = reinterpret_cast<float*>(tile + tile_planes * P);  // [9][C] filter taps, then [C] bias
-  bf16x8* slab2 = reinterpret_cast<bf16x8*>(dww + 10 * C);        // PW2: [ksteps2][MT][64]
+  bf16x8* slab2 = tile + tile_planes * P;                          // PW2: [ksteps2][MT][64]
   const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, (short)0, a.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.out, (short)0, a.out_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc((void*)nullptr, (short)0, 0, 0x00020000);
 
   copy_slab(reinterpret_cast<const bf16x8*>(a.wpk), slab, a.ksteps * MT * 64, tid);
   if constexpr (PW2) copy_slab(reinterpret_cast<const bf16x8*>(a.wpk2), slab2, a.ksteps2 * MT * 64, tid);
-  for (int i = tid; i < 10 * C; i += 256) dww[i] = i < 9 * C ? a.dw_w[i] : a.dw_b[i - 9 * C];
   __syncthreads();
 
-  // ---- depthwise 3x3 + bias + SiLU of the workgroup's pixels, every plane
-  const unsigned hw = (unsigned)(a.Ho * a.Wo);
-  for (int item = tid; item < P * a.cg; item += 256) {
-    const int px = item & (P - 1), c8 = item / P;
-    const unsigned gp = (unsigned)pblk * P + px;
-    const unsigned b = gp / hw, rem = gp - b * hw;
-    const unsigned y = rem / (unsigned)a.Wo, x = rem - y * a.Wo;
-    const unsigned pix = a.in_g0 + b * a.in_img + y * a.in_w1 + x;
-    const unsigned vo = gp < (unsigned)a.npix ? pix * 16u + (unsigned)c8 * a.in_plane : OOB_LANE;
-    bf16x8 v[9];
+  // ---- depthwise 3x3 + bias + SiLU on the MATRIX pipe, each wave for the 16 * NT pixels its GEMM will consume.
+  // A depthwise conv of 16 channels (two planes) is the GEMM out[16][px] = A[16][K] * B[K][px] with K = 2 planes x 9 taps
+  // x 8 channels = 144 (padded to 5 k-steps of 32) and A block-diagonal: row r holds tap weight w[r][tap] at
+  // k = (plane r / 8, tap, channel r % 8) and zeros elsewhere.  The B fragments are the same 16-byte tap loads a VALU
+  // form makes (lane (n, g) of k-step s reads k-group q = 4 s + g = (plane q / 9, tap q % 9) of pixel n), but the
+  // 144 cvt + fma per lane and pixel become 5 MFMAs per 16 pixels: 94 % of the multiplies hit zeros and the matrix pipe
+  // is still far cheaper than the VALU here because it was idle.  Each lane's A fragment has ONE non-zero element
+  // (row r, element r % 8, when q / 9 == r / 8), so the host packs just that value per (16-channel block, lane, k-step)
+  // (dw_pack_mfma: 16 bytes per lane) and the fragment is rebuilt with four ANDs.  Filter taps are bf16 on this path,
+  // like every dense filter.  No per-item index arithmetic: the pixel offsets are patch_setup's.
+  const int patch = pblk * 4 + wave;
+  const bool live = patch < a.npatches;
+  Patch<NT> Pp;
+  patch_setup<NT>(a, live ? patch : 0, n, 0u, Pp);
+  if (!(a.dbg & 2)) {
+    unsigned toff[5];
 #pragma unroll
-    for (int t = 0; t < 9; ++t)
-      v[t] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
-                                            rin, vo + (unsigned)(((t / 3 - 1) * a.in_w1 + (t % 3 - 1)) * 16), 0, 0));
-    float acc[8];
-    {
-      const f32x4 b0 = *reinterpret_cast<const f32x4*>(dww + 9 * C + c8 * 8);
-      const f32x4 b1 = *reinterpret_cast<const f32x4*>(dww + 9 * C + c8 * 8 + 4);
+    for (int s5 = 0; s5 < 5; ++s5) {
+      const int q = 4 * s5 + g, sel = q >= 9, tap = q - 9 * sel;
+      toff[s5] = q < 18 ? (unsigned)(sel * (int)a.in_plane + ((tap / 3 - 1) * a.in_w1 + (tap % 3 - 1)) * 16) : OOB_K;
+    }
+    const int e = n & 7;  // the lane's A row is channel n of the block: element n % 8 of its k-group
+    unsigned selm[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        acc[j] = b0[j];
-        acc[4 + j] = b1[j];
+    for (int d = 0; d < 4; ++d) selm[d] = (e >> 1) == d ? ((e & 1) ? 0xffff0000u : 0x0000ffffu) : 0u;
+    const u32x4* dwtab = reinterpret_cast<const u32x4*>(a.dw_wpk);
+    unsigned char* tb = reinterpret_cast<unsigned char*>(tile);
+    const int npp = live ? (a.cg >> 1) : 0;
+    for (int pp = 0; pp < npp; ++pp) {
+      const u32x4 t = dwtab[pp * 64 + lane];  // k-steps 0..4 as bf16 halves: {s0 | s1 << 16, s2 | s3 << 16, s4, -}
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(a.dw_b + pp * 16 + 4 * g);
+      const unsigned poff = (unsigned)(2 * pp) * a.in_plane;
+      bf16x8 xb[NT][5];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int s5 = 0; s5 < 5; ++s5)
+          xb[nt][s5] = __builtin_bit_cast(
+              bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rin, ((a.dbg & 1) ? OOB_LANE : Pp.base[nt]) + poff + toff[s5], 0, 0));
+      f32x4 dacc[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) dacc[nt] = bv;
+#pragma unroll
+      for (int s5 = 0; s5 < 5; ++s5) {
+        const unsigned w16 = (s5 & 1) ? (t[s5 >> 1] >> 16) : (t[s5 >> 1] & 0xffffu);
+        const unsigned both = w16 | (w16 << 16);
+        u32x4 wv;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) wv[d] = both & selm[d];
+        const bf16x8 wa = __builtin_bit_cast(bf16x8, wv);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) dacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb[nt][s5], dacc[nt], 0, 0, 0);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        bf16x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = (__bf16)(a.dw_act ? silu_f(dacc[nt][r]) : dacc[nt][r]);
+        *reinterpret_cast<bf16x4*>(tb + ((size_t)(2 * pp + (g >> 1)) * P + wave * 16 * NT + nt * 16 + n) * 16 + (g & 1) * 8) = o;
       }
     }
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const f32x4 w0 = *reinterpret_cast<const f32x4*>(dww + t * C + c8 * 8);
-      const f32x4 w1 = *reinterpret_cast<const f32x4*>(dww + t * C + c8 * 8 + 4);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        acc[j] = __builtin_fmaf((float)v[t][j], w0[j], acc[j]);
-        acc[4 + j] = __builtin_fmaf((float)v[t][4 + j], w1[j], acc[4 + j]);
-      }
-    }
-    bf16x8 o;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (__bf16)(a.dw_act ? silu_f(acc[j]) : acc[j]);
-    tile[c8 * P + px] = o;
   }
   __syncthreads();
 
   // ---- 1x1 GEMM from LDS
-  const int patch = pblk * 4 + wave;
-  const bool live = patch < a.npatches;
   if (!PW2 && !live) return;
-  Patch<NT> Pp;
-  patch_setup<NT>(a, live ? patch : 0, n, 0u, Pp);
   f32x4 acc[MT][NT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -281,7 +296,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
     for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = bv;
   }
   const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int ks = 0; ks < a.ksteps; ++ks) {
+  for (int ks = 0; ks < ((a.dbg & 4) ? 0 : a.ksteps); ++ks) {
     bf16x8 wa[MT], xb[NT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) wa[mt] = slab[(ks * MT + mt) * 64 + lane];
@@ -291,6 +306,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
     mma_step<MT, NT>(wa, xb, acc);
   }
   if constexpr (!PW2) {
+    if (a.dbg & 8) return;
     epilogue<MT, NT>(a, rout, rres, 0, g, Pp.opix, acc);
   } else {
     // pointwise result (SiLU, bf16: exactly what the unfused kernel stores) -> the tile, as planes of 8 channels:
@@ -446,6 +462,19 @@ static inline uint16_t f2bf(float f) {
   return (uint16_t)(u >> 16);
 }
 
+// dwpw_kernel's depthwise filter for its MFMA form: [C / 16][64 lanes][8] bf16.  Lane (row r = lane % 16, k-group
+// g = lane / 16) holds, for k-steps s = 0..4, the ONE non-zero element of its A fragment: tap weight w[r][q % 9] when
+// k-group q = 4 s + g belongs to the row's plane (q < 18 and q / 9 == r / 8), else 0.  w: [C][9] fp32 (folded BN).
+void dw_pack_mfma(const float* w, int C, std::vector<uint16_t>* out) {
+  out->assign((size_t)(C / 16) * 64 * 8, 0);
+  for (int pp = 0; pp < C / 16; ++pp)
+    for (int lane = 0; lane < 64; ++lane)
+      for (int s = 0; s < 5; ++s) {
+        const int row = lane & 15, q = 4 * s + (lane >> 4);
+        if (q < 18 && q / 9 == row / 8) (*out)[((size_t)pp * 64 + lane) * 8 + s] = f2bf(w[(size_t)(pp * 16 + row) * 9 + q % 9]);
+      }
+}
+
 void conv_pack_weights(const float* w, int Cout, int Cin_w, int k, const ConvConfig& c, std::vector<uint16_t>* out) {
   out->assign(c.wpk_elems, 0);
   size_t o = 0;
@@ -569,9 +598,16 @@ static int launch_dwpw(const ConvConfig& cfg, const ConvArgs& a, size_t lds, hip
 }
 
 // depthwise 3x3 + pointwise 1x1 [+ a further 1x1] (see dwpw_kernel); cfg from conv_choose(Cin = C, k = 1)
-int dwpw_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s) {
+int dwpw_launch(const ConvConfig& cfg0, ConvArgs a, int batch, hipStream_t s) {
+  ConvConfig cfg = cfg0;
+  static const int force_nt = getenv("YL_DWPW_NT") ? atoi(getenv("YL_DWPW_NT")) : 0;  // development: 1 or 2 positions tiles per wave
+  if (force_nt == 1 || force_nt == 2) {
+    cfg.NT = force_nt;
+    cfg.npatches = (int)(((long long)batch * a.Ho * a.Wo + 16 * force_nt - 1) / (16 * force_nt));
+  }
   if (cfg.ncb != 1 || cfg.kchunk < cfg.ksteps || cfg.NT > 2)
     return fail(-3, "dwpw: needs all output channels in one workgroup and NT <= 2");
+  if (a.Cin % 16 || !a.dw_wpk) return fail(-3, "dwpw: the depthwise conv runs on 16-channel MFMA tiles (C % 16 == 0)");
   a.ncb = 1;
   a.cg = cfg.cg;
   a.ksteps = cfg.ksteps;
@@ -589,9 +625,15 @@ int dwpw_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s) {
   a.in_bytes = (unsigned)inb;
   a.out_bytes = (unsigned)outb;
   a.nblocks = (cfg.npatches + 3) / 4;
-  a.dbg = 0;
+  static const int dwpw_dbg = getenv("YL_DWPW_DBG") ? atoi(getenv("YL_DWPW_DBG")) : 0;  // timing ablations (wrong results)
+  a.dbg = dwpw_dbg;
+  {  // input staged through LDS (dwpw.hip) where the geometry allows
+    int handled = 0;
+    const int rc = dwpw_tile_launch(cfg, a, batch, s, &handled);
+    if (rc || handled) return rc;
+  }
   const int planes = a.wpk2 && a.cg2 > cfg.cg ? a.cg2 : cfg.cg;
-  const size_t lds = (size_t)cfg.ksteps * cfg.MT * 1024 + (size_t)planes * 64 * cfg.NT * 16 + (size_t)10 * a.Cin * 4 +
+  const size_t lds = (size_t)cfg.ksteps * cfg.MT * 1024 + (size_t)planes * 64 * cfg.NT * 16 +
                      (a.wpk2 ? (size_t)a.ksteps2 * cfg.MT * 1024 : 0);
   if (lds > LDS_MAX) return fail(-3, "dwpw: LDS budget exceeded");
   switch (cfg.MT * 10 + cfg.NT) {

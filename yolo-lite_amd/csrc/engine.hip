@@ -26,6 +26,7 @@ struct OpRec {
   __bf16* d_wpk2 = nullptr;  // fused follow-up 1x1
   float* d_bias2 = nullptr;
   float* d_w = nullptr;     // dwconv weights [9][C]
+  uint16_t* d_dwpk = nullptr;  // fused depthwise + pointwise: the depthwise filter as MFMA A fragments (dw_pack_mfma)
   float* d_bias = nullptr;
   float* d_w0 = nullptr;    // fused stem in front of a conv (stem2.hip): filters [C0][27], bias [C0]
   float* d_b0 = nullptr;
@@ -403,10 +404,17 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
             r.cfg.kchunk = c3.ksteps;  // (kchunk == ksteps was checked above) carries the tail's k-steps to run_op
           }
         }
-        std::vector<float> wt((size_t)9 * C);
-        for (int c = 0; c < C; ++c)
-          for (int t = 0; t < 9; ++t) wt[(size_t)t * C + c] = o.weight[(size_t)c * 9 + t];
-        if (int rc = dev_upload(e.get(), wt, &r.d_w)) return rc;
+        if (pw) {
+          if (C % 16) return fail(-1, tag + ": depthwise + pointwise needs C % 16 == 0");
+          std::vector<uint16_t> dpk;
+          dw_pack_mfma(o.weight, C, &dpk);
+          if (int rc = dev_upload(e.get(), dpk, &r.d_dwpk)) return rc;
+        } else {
+          std::vector<float> wt((size_t)9 * C);
+          for (int c = 0; c < C; ++c)
+            for (int t = 0; t < 9; ++t) wt[(size_t)t * C + c] = o.weight[(size_t)c * 9 + t];
+          if (int rc = dev_upload(e.get(), wt, &r.d_w)) return rc;
+        }
         std::vector<float> bias(o.bias, o.bias + C);
         if (int rc = dev_upload(e.get(), bias, &r.d_bias)) return rc;
         {
@@ -745,7 +753,7 @@ static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s, c
         a.out_g0 = gi.g0;
         a.wpk = r.d_wpk;
         a.bias = r.d_bias2;
-        a.dw_w = r.d_w;
+        a.dw_wpk = r.d_dwpk;
         a.dw_b = r.d_bias;
         a.dw_act = o.act;
         a.Ho = o.out.H;

@@ -76,7 +76,7 @@ struct ConvArgs {
   const float* bias2;  // its bias, padded to MT*16
   int post_cout, post_act;
   int ksteps2, cg2;    // dwpw_kernel with a further 1x1 (wpk2): its k-steps and input planes
-  const float* dw_w;   // dwpw_kernel: depthwise taps [9][C] and bias [C], SiLU flag
+  const void* dw_wpk;  // dwpw_kernel: depthwise taps as block-diagonal MFMA A fragments (dw_pack_mfma), bias [C], SiLU flag
   const float* dw_b;
   int dw_act;
   const float* bias;   // padded to ncb*MT*16
@@ -135,6 +135,8 @@ int conv3_reg_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s
 void conv3_pair_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, int post, ConvConfig* cfg);
 int conv3_pair_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s);
 int dwpw_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s);
+void dw_pack_mfma(const float* w, int C, std::vector<uint16_t>* out);
+int dwpw_tile_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s, int* handled);
 // conv_f8.hip: e4m3 x e4m3 -> fp32 on v_mfma_f32_16x16x128_f8f6f4
 int conv_f8_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, ConvConfig* cfg);
 void conv_f8_pack_weights(const float* w_oihw, int Cout, int Cin, int k, const ConvConfig& cfg, std::vector<uint8_t>* out,

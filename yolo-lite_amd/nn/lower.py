@@ -154,6 +154,8 @@ def fuse_depthwise_pointwise(ops: List[dict]) -> List[dict]:
     for i, a in enumerate(ops):
         if a["kind"] != OP_DWCONV3 or a.get("accumulate") or a.get("grp") or "post_weight" in a:
             continue
+        if a["inp"].C % 16:  # the fused kernel runs the depthwise conv on 16-channel MFMA tiles
+            continue
         mine = planes(a["out"])
         rd = []
         for j, o in enumerate(ops):
