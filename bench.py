@@ -36,7 +36,17 @@ from yololite_amd import _lib as yl_lib  # noqa: E402
 # bench.py is its own launcher: the HIP runtime knobs the hot path depends on are set here, explicitly, before the
 # first GPU call of the process (yololite_amd/_lib.py documents them); the JSON line records whether that was in time
 # and whether two graph branches really overlap on this runtime ("runtime").
+# Hardware queues: one per batch in flight.  The single-GPU path runs best with 16 queues and 16 batches in flight; a rank
+# of the sharded path (RCCL brings streams of its own) with 8 queues and 7 batches -- measured on one MI355X, world size 1
+# rehearsal: 8 / 7 -> 47.0 k images/s, 8 / 8 -> 32.3 k, 16 / 7 -> 39.6 k, 16 / 14 -> 32.6 k, 20 / 18 -> 35.0 k (tools/queue_sweep.sh).
+SHARDED_ENV = int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("YL_BENCH_FORCE_SHARDED", "0") == "1"
+if SHARDED_ENV:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 KNOBS = yl_lib.apply_runtime_knobs()
+# stdout carries exactly ONE line, the JSON record: libraries that print there (RCCL's version banner does, at communicator
+# creation) are sent to stderr at the descriptor level; the record is written to the saved descriptor at the end.
+_REAL_STDOUT = os.dup(1)
+os.dup2(2, 1)
 
 import torch  # noqa: E402
 
@@ -220,6 +230,9 @@ def roofline_from_profile(rows, batch, cfg):
 
 
 def main():
+    if os.environ.get("YL_BENCH_WATCHDOG"):  # development: dump every thread's stack if the run takes this many seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["YL_BENCH_WATCHDOG"]), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500,
@@ -232,9 +245,9 @@ def main():
     ap.add_argument("--streams", type=int, default=0,
                     help="batches in flight: consecutive steps are issued round-robin on this many HIP streams "
                          "(one workspace slot each) so one batch's large kernels overlap another's small ones; 0 = try "
-                         "7, 8 and 10 (sharded: 6, 7 and 8) for min(--steps, 80) untimed steps each and keep the fastest: HIP maps streams onto "
-                         "GPU_MAX_HW_QUEUES = 8 hardware queues, and a batch stream that has to share one with RCCL's stream "
-                         "loses a third of the throughput")
+                         "8, 12 and 16 (sharded: 6, 7 and 8) for min(--steps, 80) untimed steps each and keep the fastest: HIP maps streams onto "
+                         "GPU_MAX_HW_QUEUES hardware queues (16 here, 8 in the sharded path), and a batch stream that has to share one with "
+                         "RCCL's stream loses a third of the throughput")
     ap.add_argument("--cand-frac", type=float, default=0.015,
                     help="fraction of anchors above conf 0.25 the synthetic class bias is calibrated to "
                          "(0.015 = the bench's operating point; 0.05 = the NMS stress point of SURVEY 8d)")
@@ -282,7 +295,7 @@ def main():
     specs, sd, eng = build_model(args.scale, dev, B, H, W, x, target_frac=args.cand_frac, fp8=args.dtype == "fp8")
     cfg_key = {"scale": args.scale, "imgsz": args.imgsz, "batch": B, "dtype": args.dtype}
 
-    cands = [args.streams] if args.streams > 0 else ([6, 7, 8] if sharded else [7, 8, 10])
+    cands = [args.streams] if args.streams > 0 else ([6, 7, 8] if sharded else [8, 12, 16])
     S = max(cands)  # rebound below to the count that wins the trial
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     step_no = [0]
@@ -326,6 +339,7 @@ def main():
                     hot_path(xs[k % S])
                 sync_all()
                 tried[S] = round(B * n_trial / (time.perf_counter() - tt), 1)
+                print(f"[bench] trial, {S} batches in flight: {tried[S]} images/s", file=sys.stderr, flush=True)
             S = max(tried, key=tried.get)
         step_no[0] = 0
         for k in range(max(args.warmup, 2 * S)):
@@ -384,6 +398,8 @@ def main():
                 tv = torch.tensor([time.perf_counter() - tt], dtype=torch.float64, device=dev)
                 dist.all_reduce(tv, op=dist.ReduceOp.MAX)
                 tried[S] = round(world * B * n_trial / float(tv.item()), 1)
+                if rank == 0:
+                    print(f"[bench] sharded trial, {S} batches in flight: {tried[S]} images/s", file=sys.stderr, flush=True)
                 del r_
             S = max(tried, key=tried.get)
             torch.cuda.empty_cache()
@@ -531,7 +547,8 @@ def main():
                 res["cpu_baseline"] = cpu_baseline(sd, args.scale, H, W, conf, iou, sample_b=sb, iters=max(1, n_img // sb),
                                                    eng=eng, dev=dev, max_det=max_det,
                                                    band=0.12 if args.dtype == "fp8" else 0.08)  # stated tolerances
-        print(json.dumps(res), flush=True)
+        sys.stdout.flush()
+        os.write(_REAL_STDOUT, (json.dumps(res) + "\n").encode())
     if sharded:
         dist.barrier()
         dist.destroy_process_group()

@@ -12,8 +12,10 @@ from pathlib import Path
 # Runtime knobs of the HIP runtime that the hot path's speed depends on.  They are NOT set at import: call
 # ``apply_runtime_knobs()`` (bench.py, tests/conftest.py, __graft_entry__ and AutoBackend do) before the first GPU
 # call of the process; ``runtime_knob_status()`` says whether that happened in time.
-#   GPU_MAX_HW_QUEUES=8  several batches in flight on several streams: give each stream its own hardware queue
-#       (the runtime's default of four makes them share; 37.4 k -> 38.6 k images/s).
+#   GPU_MAX_HW_QUEUES=16  several batches in flight on several streams: give each stream its own hardware queue
+#       (the runtime's default of four makes them share: 37.4 k -> 38.6 k images/s with 8; round 2, same box, alternating
+#       runs: 8 queues / 8 streams 43.6-43.9 k, 16 / 16 45.3-45.9 k, 20 / 20 45.8 k, 24 / 24 43.6 k, 32 / 32 32.7 k
+#       images/s -- past ~20 the queues are time-sliced).
 # NOT set any more (round 2): DEBUG_HIP_FORCE_GRAPH_QUEUES=2.  Round 1 forced two graph queues so that the captured
 # graph's class-branch lane would overlap the trunk (27.0 k -> 33.3 k images/s).  tests/test_gpu_dist.py showed that
 # with that debug flag a replay does NOT honour the fork edge of the graph: the branch starts on the second queue
@@ -22,7 +24,7 @@ from pathlib import Path
 # The hot path's graph is therefore captured as ONE chain (nn/lower.py: side lanes are opt-in), and the overlap comes
 # from several batches in flight on several streams only.  ``graph_branch_probe()`` still reports what the runtime does
 # with a two-branch graph.
-RUNTIME_KNOBS = {"GPU_MAX_HW_QUEUES": "8"}
+RUNTIME_KNOBS = {"GPU_MAX_HW_QUEUES": "16"}
 _knob_status = {"applied": False, "before_hip_init": None, "values": {}}
 
 
