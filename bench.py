@@ -36,12 +36,14 @@ from yololite_amd import _lib as yl_lib  # noqa: E402
 # bench.py is its own launcher: the HIP runtime knobs the hot path depends on are set here, explicitly, before the
 # first GPU call of the process (yololite_amd/_lib.py documents them); the JSON line records whether that was in time
 # and whether two graph branches really overlap on this runtime ("runtime").
-# Hardware queues: one per batch in flight.  The single-GPU path runs best with 16 queues and 16 batches in flight; a rank
-# of the sharded path (RCCL brings streams of its own) with 8 queues and 7 batches -- measured on one MI355X, world size 1
-# rehearsal: 8 / 7 -> 47.0 k images/s, 8 / 8 -> 32.3 k, 16 / 7 -> 39.6 k, 16 / 14 -> 32.6 k, 20 / 18 -> 35.0 k (tools/queue_sweep.sh).
+# Hardware queues: exactly one per batch in flight (fewer streams than queues is as bad as more -- tools/queue_sweep.sh on
+# one MI355X, queues / streams -> images/s).  Single-GPU path: 8 / 8 -> 43.6-43.9 k, 16 / 16 -> 46.5-47.1 k, 20 / 20 ->
+# 46.9-47.1 k (and 42.7-43.0 k against 40.0-40.7 k in a 20-step run, which 20 batches in flight cover in one round), 20 / 16
+# -> 37.6 k, 16 / 8 -> 34.5 k, 24 / 24 -> 43.6 k, 32 / 32 -> 32.7 k.  A rank of the sharded path (RCCL brings streams of
+# its own; world size 1 rehearsal): 8 / 7 -> 47.0 k, 8 / 8 -> 32.3 k, 16 / 7 -> 39.6 k, 16 / 14 -> 32.6 k, 20 / 18 -> 35.0 k.
 SHARDED_ENV = int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("YL_BENCH_FORCE_SHARDED", "0") == "1"
-if SHARDED_ENV:
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+SINGLE_IN_FLIGHT = 20
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8" if SHARDED_ENV else str(SINGLE_IN_FLIGHT))
 KNOBS = yl_lib.apply_runtime_knobs()
 # stdout carries exactly ONE line, the JSON record: libraries that print there (RCCL's version banner does, at communicator
 # creation) are sent to stderr at the descriptor level; the record is written to the saved descriptor at the end.
@@ -244,10 +246,10 @@ def main():
     ap.add_argument("--scale", default="n")
     ap.add_argument("--streams", type=int, default=0,
                     help="batches in flight: consecutive steps are issued round-robin on this many HIP streams "
-                         "(one workspace slot each) so one batch's large kernels overlap another's small ones; 0 = try "
-                         "8, 12 and 16 (sharded: 6, 7 and 8) for min(--steps, 80) untimed steps each and keep the fastest: HIP maps streams onto "
-                         "GPU_MAX_HW_QUEUES hardware queues (16 here, 8 in the sharded path), and a batch stream that has to share one with "
-                         "RCCL's stream loses a third of the throughput")
+                         "(one workspace slot each) so one batch's large kernels overlap another's small ones; 0 = 20, one per "
+                         "hardware queue (GPU_MAX_HW_QUEUES = 20, set at the top of this file); sharded path: 8 queues, and 6, 7 and 8 batches "
+                         "in flight are tried for min(--steps, 80) untimed steps each (a batch stream that has to share a queue with RCCL's "
+                         "stream loses a third of the throughput)")
     ap.add_argument("--cand-frac", type=float, default=0.015,
                     help="fraction of anchors above conf 0.25 the synthetic class bias is calibrated to "
                          "(0.015 = the bench's operating point; 0.05 = the NMS stress point of SURVEY 8d)")
@@ -295,7 +297,7 @@ def main():
     specs, sd, eng = build_model(args.scale, dev, B, H, W, x, target_frac=args.cand_frac, fp8=args.dtype == "fp8")
     cfg_key = {"scale": args.scale, "imgsz": args.imgsz, "batch": B, "dtype": args.dtype}
 
-    cands = [args.streams] if args.streams > 0 else ([6, 7, 8] if sharded else [8, 12, 16])
+    cands = [args.streams] if args.streams > 0 else ([6, 7, 8] if sharded else [SINGLE_IN_FLIGHT])
     S = max(cands)  # rebound below to the count that wins the trial
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     step_no = [0]

@@ -14,8 +14,10 @@ from pathlib import Path
 # call of the process; ``runtime_knob_status()`` says whether that happened in time.
 #   GPU_MAX_HW_QUEUES=16  several batches in flight on several streams: give each stream its own hardware queue
 #       (the runtime's default of four makes them share: 37.4 k -> 38.6 k images/s with 8; round 2, same box, alternating
-#       runs: 8 queues / 8 streams 43.6-43.9 k, 16 / 16 45.3-45.9 k, 20 / 20 45.8 k, 24 / 24 43.6 k, 32 / 32 32.7 k
-#       images/s -- past ~20 the queues are time-sliced).
+#       runs: 8 queues / 8 streams 43.6-43.9 k, 16 / 16 46.5-47.1 k, 20 / 20 46.9-47.1 k, 24 / 24 43.6 k, 32 / 32 32.7 k
+#       images/s -- past ~20 the queues are time-sliced; and the stream count should EQUAL the queue count: 16 queues /
+#       8 streams 34.5 k, 20 / 16 37.6 k.  bench.py therefore sets 20 for its 20 batches in flight, 8 for a rank of the
+#       sharded path (7 batch streams beside RCCL's); a caller that pipelines N batches itself should export N.)
 # NOT set any more (round 2): DEBUG_HIP_FORCE_GRAPH_QUEUES=2.  Round 1 forced two graph queues so that the captured
 # graph's class-branch lane would overlap the trunk (27.0 k -> 33.3 k images/s).  tests/test_gpu_dist.py showed that
 # with that debug flag a replay does NOT honour the fork edge of the graph: the branch starts on the second queue
