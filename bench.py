@@ -536,7 +536,7 @@ def main():
                 del eng._slots[1:]
                 torch.cuda.empty_cache()
                 res["other_configs"] = []
-                for sc_, b_, sz_, dt_, st_, n_ in (("s", 64, 640, "bf16", 8, 100), ("x", 8, 1280, "fp8", 8, 40)):
+                for sc_, b_, sz_, dt_, st_, n_ in (("s", 64, 640, "bf16", S, 100), ("x", 8, 1280, "fp8", S, 2 * S)):
                     try:
                         res["other_configs"].append(short_config(sc_, b_, sz_, dt_, st_, n_, dev))
                     except Exception as e:  # never at the cost of the main line
