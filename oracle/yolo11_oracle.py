@@ -139,14 +139,16 @@ def q_store(t: torch.Tensor) -> torch.Tensor:
 
 
 def conv_bn_act(sd: Dict[str, torch.Tensor], p: str, x: torch.Tensor, k: int = 1, s: int = 1,
-                g: int = 1, act: bool = True, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+                g: int = 1, act: bool = True, res: Optional[torch.Tensor] = None, dw_taps_bf16: bool = False) -> torch.Tensor:
     """nn/modules/conv.py:35-49 Conv.forward: SiLU(BN(conv2d(x))), bias-free conv,
     pad = k//2 (autopad conv.py:26-32), BN in eval mode with eps 1e-3.  ``res``: a shortcut added to the result
     (block.py:343, 946-947); in fp32 mode ``conv(x) + res`` is exactly the reference's ``x + conv(x)``."""
     if _STORAGE[0] == "bf16":
         w, b = fuse_conv_bn(sd[p + ".conv.weight"], sd[p + ".bn.weight"], sd[p + ".bn.bias"],
                             sd[p + ".bn.running_mean"], sd[p + ".bn.running_var"])
-        if g == 1:  # dense filters are packed as bf16; the depthwise taps stay fp32 (csrc/engine.hip d_w)
+        # dense filters are packed as bf16; depthwise taps stay fp32 (csrc/engine.hip d_w) except in the Detect class
+        # branch, whose depthwise convs run on the matrix pipe with bf16 taps (csrc/conv_mfma.hip dw_pack_mfma)
+        if g == 1 or dw_taps_bf16:
             w = w.bfloat16().float()
         y = F.conv2d(x, w, b, s, k // 2, 1, g)
         y = F.silu(y) if act else y
@@ -275,9 +277,9 @@ def detect_heads(sd, p, feats: List[torch.Tensor], nc: int = 80) -> List[torch.T
         b = conv_bn_act(sd, f"{p}.cv2.{i}.0", x, 3, 1)
         b = conv_bn_act(sd, f"{p}.cv2.{i}.1", b, 3, 1)
         b = plain_conv(sd, f"{p}.cv2.{i}.2", b)
-        c = conv_bn_act(sd, f"{p}.cv3.{i}.0.0", x, 3, 1, x.shape[1])
+        c = conv_bn_act(sd, f"{p}.cv3.{i}.0.0", x, 3, 1, x.shape[1], dw_taps_bf16=True)
         c = conv_bn_act(sd, f"{p}.cv3.{i}.0.1", c, 1, 1)
-        c = conv_bn_act(sd, f"{p}.cv3.{i}.1.0", c, 3, 1, c.shape[1])
+        c = conv_bn_act(sd, f"{p}.cv3.{i}.1.0", c, 3, 1, c.shape[1], dw_taps_bf16=True)
         c = conv_bn_act(sd, f"{p}.cv3.{i}.1.1", c, 1, 1)
         c = plain_conv(sd, f"{p}.cv3.{i}.2", c)
         outs.append(torch.cat((b, c), 1))
