@@ -214,9 +214,7 @@ void conv3_tile_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, 
   const int min_tiles = getenv("YL_CONV_TILE_MIN") ? atoi(getenv("YL_CONV_TILE_MIN")) : 300;
   const int max_nt = getenv("YL_CONV_TILE_NT") ? atoi(getenv("YL_CONV_TILE_NT")) : 4;
   if (!enable || k != 3 || stride != 1 || post) return;
-  if ((Cin != 32 && Cin != 64) || c->ncb != 1 || (c->MT != 2 && c->MT != 4) || Cout != c->MT * 16 ||
-      c->kchunk < c->ksteps)
-    return;
+  if ((Cin != 32 && Cin != 64) || c->ncb != 1 || (c->MT != 2 && c->MT != 4) || Cout != c->MT * 16) return;
   const long long nq = (long long)batch * (Ho + 1) * (Wo + 1);
   for (int NT = 4; NT >= 1; NT >>= 1) {
     if (NT > max_nt) continue;
@@ -224,6 +222,7 @@ void conv3_tile_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, 
     const size_t lds = (size_t)c->ksteps * c->MT * 1024 + (size_t)2 * 4 * tile_PL(NT, Wo) * 16;
     if (ntiles >= min_tiles && lds <= LDS_MAX) {
       c->tile = NT;
+      // (this kernel stages the whole filter itself, whatever slab budget conv_choose chunked it for)
       c->name = "conv3x3_tile_mfma";
       return;
     }

@@ -374,9 +374,12 @@ int conv_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo,
   const int ntaps = k * k;
   const int cg = Cin / 8;
   const int ksteps = (ntaps * cg + 3) / 4;
-  // slab budget: two workgroups per CU keep their slabs resident side by side
+  // Slab budget.  72 KiB (two workgroups per CU side by side, a 64 -> 64 3x3 filter in one piece) was the best choice
+  // while 8 batches were in flight; with 20 (round 2) the CUs are shared by more launches at a time and a smaller
+  // slab -- bigger filters are restaged in chunks -- leaves them room: 40-56 KiB all give 47.6-49.0 k images/s against
+  // 45.2-46.3 k for 64-72 KiB and 46.1-46.4 k for 100 KiB (tools/env_ab.sh, alternating runs on one box).
   static const size_t slab_max =
-      getenv("YL_CONV_SLAB_KB") ? (size_t)atoi(getenv("YL_CONV_SLAB_KB")) * 1024 : 72 * 1024;
+      getenv("YL_CONV_SLAB_KB") ? (size_t)atoi(getenv("YL_CONV_SLAB_KB")) * 1024 : 48 * 1024;
   // output-channel tiles per wave: as many as divide the layer (B-fragment traffic goes with 1/MT).
   // YL_CONV_CHUNK=0 restores the older policy of shrinking MT until the whole filter fits the slab.
   static const int allow_chunk = getenv("YL_CONV_CHUNK") ? atoi(getenv("YL_CONV_CHUNK")) : 1;
@@ -407,7 +410,8 @@ int conv_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo,
   int kchunk = ksteps;
   if ((size_t)ksteps * MT * 1024 > slab_max) {
     kchunk = (int)(slab_max / ((size_t)MT * 1024)) & ~7;
-    if (kchunk < 8) return fail(-3, "conv: filter slab budget too small");
+    if (kchunk < 8) kchunk = 8;  // the smallest chunk the k-loop takes (eight tiles per wave: a 64 KiB slab whatever the budget)
+    if ((size_t)kchunk * MT * 1024 > 96 * 1024) return fail(-3, "conv: filter slab budget too small");
   }
   const int ncb = cout16 / MT;
   const long long npix = (long long)batch * Ho * Wo;
