@@ -22,6 +22,11 @@
 //  kernel, a persistent weight-stationary kernel -- are recorded in DESIGN.md.)
 #include "conv_common.h"
 
+#ifndef YL_CONV_WPE
+#define YL_CONV_WPE 2  // conv_kernel: at least this many waves per SIMD (caps its registers at 512 / YL_CONV_WPE).  3 (the
+                       // 64-pixel tiles then spill from 177-203 to 168 registers): 47.0-47.1 k images/s against 48.2-48.9 k
+#endif
+
 namespace yl {
 
 // K-steps [kbeg, kbeg + nk) of one patch against the slab currently in LDS (slab row = ks - kbeg).
@@ -71,7 +76,7 @@ __device__ __forceinline__ void run_ksteps(const ConvArgs& a, __amdgpu_buffer_rs
 // O8: the epilogue also stores the e4m3 copy of the output (yl_op.out8, fp8 mode only; a separate instantiation so that the bf16
 // programs run exactly the code they ran before the copy existed).
 template <int KS, int MT, int NT, bool UNIFORM, bool POST, bool UP = false, bool O8 = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(YL_CONV_WPE))) void conv_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, n = lane & 15;
