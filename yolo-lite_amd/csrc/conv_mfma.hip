@@ -282,9 +282,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
       }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
+        // (one wave-uniform branch around the four SiLUs: a select per value made hipcc branch around each of them)
+        if (a.dw_act) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dacc[nt][r] = silu_f(dacc[nt][r]);
+        }
         bf16x4 o;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) o[r] = (__bf16)(a.dw_act ? silu_f(dacc[nt][r]) : dacc[nt][r]);
+        for (int r = 0; r < 4; ++r) o[r] = (__bf16)dacc[nt][r];
         *reinterpret_cast<bf16x4*>(tb + ((size_t)(2 * pp + (g >> 1)) * P + wave * 16 * NT + nt * 16 + n) * 16 + (g & 1) * 8) = o;
       }
     }
@@ -324,9 +329,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
       if (ch < a.cg2 * 8) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
+          if (a.act) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[mt][nt][r] = silu_f(acc[mt][nt][r]);
+          }
           bf16x4 o;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = (__bf16)(a.act ? silu_f(acc[mt][nt][r]) : acc[mt][nt][r]);
+          for (int r = 0; r < 4; ++r) o[r] = (__bf16)acc[mt][nt][r];
           *reinterpret_cast<bf16x4*>(tb + ((size_t)(ch >> 3) * P + wave * 16 * NT + nt * 16 + n) * 16 + (ch & 7) * 2) = o;
         }
       }

@@ -16,6 +16,8 @@
 //      epilogue and follow-up 1x1 -- with its B fragments read from the LDS planes (stride-2 pixels).
 // Same operands, same MFMA sequence: bit-identical to the two-launch path (tests/test_gpu_net.py).
 // Recompute: 5 stem rows per 2 output rows and 161 columns per 80 (1.26x of a 0.9 GFLOP layer).
+#include <type_traits>
+
 #include "conv_common.h"
 
 namespace yl {
@@ -127,6 +129,10 @@ __global__ __launch_bounds__(256) void stem2_kernel(Stem2Args a) {
       unsigned char* const sbase = stile + (size_t)(ch >> 3) * S2_SR * S2_SP * 16 + (ch & 7) * 2;
       // two tiles per trip (t and t + 4): both gathers are requested before the first MFMA, so the LDS latency
       // and the MFMA -> SiLU dependency of one tile hide behind the other
+      // (the SiLU flag is a compile-time constant inside: left as a runtime test of a.act0, hipcc branched around every
+      // single SiLU and shuttled the accumulators through AGPRs between the branches)
+      auto stem_tiles = [&](auto act_tag) __attribute__((always_inline)) {
+      constexpr bool ACT0 = decltype(act_tag)::value;
       for (int t0 = wave; t0 < S2_SR * TPR; t0 += 8) {
         bf16x8 bf[2];
         int rr[2], cc[2], cts[2];
@@ -151,12 +157,15 @@ __global__ __launch_bounds__(256) void stem2_kernel(Stem2Args a) {
           const bool inside = (unsigned)sy < (unsigned)a.H0 && (unsigned)sx < (unsigned)a.W0;
           bf16x4 o;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) o[q] = (__bf16)(a.act0 ? silu_f(acc[u][q]) : acc[u][q]);
+          for (int q = 0; q < 4; ++q) o[q] = (__bf16)(ACT0 ? silu_f(acc[u][q]) : acc[u][q]);
           const bf16x4 z = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
           if (cts[u] * 16 + n < S2_SC)
             *reinterpret_cast<bf16x4*>(sbase + (size_t)(rr[u] * S2_SP + cc[u]) * 16) = inside ? o : z;
         }
       }
+      };
+      if (a.act0) stem_tiles(std::true_type{});
+      else stem_tiles(std::false_type{});
     }
   }
   __syncthreads();
