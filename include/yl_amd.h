@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define YL_ABI_VERSION 12
+#define YL_ABI_VERSION 13
 
 /* element types */
 enum { YL_BF16 = 0, YL_F32 = 1, YL_F16 = 2, YL_U8 = 3, YL_FP8 = 4 /* OCP e4m3 */ };
@@ -197,6 +197,15 @@ int yl_engine_profile_detect(yl_engine* e, const void* input, int in_dtype, void
  * spin_us), 0 when the HIP runtime serialised them (then the hot path's class-branch lane gives no overlap either;
  * see _lib.apply_runtime_knobs for the environment the runtime needs). */
 int yl_graph_branch_probe(void* stream, int spin_us, float* ms_graph, int* concurrent);
+/* A HIP stream confined to the compute units of `cu_mask` (hipExtStreamCreateWithCUMask).  Measured on MI355X
+ * (`yl_xcc_census`, tools/xcd_probe.py): word c of the 8-word mask selects CU c of every (shader engine, XCD) pair; the
+ * dispatcher still spreads a launch over all eight XCDs, so a stream can be given a SLICE of every XCD, not an XCD.  No reference counterpart (the reference runs on cuda:0's default
+ * stream, engine/predictor.py:149).  Destroy with yl_stream_destroy after synchronising it. */
+int yl_stream_create_masked(const uint32_t* cu_mask, int n_words, void** stream_out);
+int yl_stream_destroy(void* stream);
+/* Launches n_workgroups one-wave workgroups on `stream`; each adds 1 to hist_device[xcd * 64 + shader engine * 16 + cu]
+ * of the unit it ran on (512 x uint32 on the device, zeroed by the caller). */
+int yl_xcc_census(unsigned* hist_device, int n_workgroups, void* stream);
 int yl_engine_num_ops(const yl_engine* e);
 /* Algorithmic work of op i: flops (2*MAC), bytes read+written once; name is a static string. */
 int yl_engine_op_info(const yl_engine* e, int i, double* flops, double* bytes, const char** kernel_name);

@@ -66,6 +66,40 @@ def graph_branch_probe(device=None, spin_us: int = 300) -> dict:
     return {"spin_us": spin_us, "graph_ms": round(ms.value, 4), "concurrent": bool(conc.value)}
 
 
+NUM_XCD, CUS_PER_XCD = 8, 32  # MI355X
+
+
+def cu_slice_stream(device, part: int, nparts: int):
+    """A ``torch.cuda.ExternalStream`` whose dispatches are confined to 1 / ``nparts`` of the compute units of EVERY XCD
+    (``yl_stream_create_masked``).  Measured layout of the 256-bit mask on MI355X (tools/xcd_probe.py): bit
+    32 c + u selects CU c (0..7) of one (shader engine, XCD) pair u; a queue cannot be confined to one XCD -- the
+    dispatcher spreads workgroups over all eight regardless, and a mask that leaves an XCD empty is ignored.  The
+    stream is never destroyed (a handful per process)."""
+    import torch
+
+    dev = torch.device(device)
+    words = (C.c_uint32 * (NUM_XCD * CUS_PER_XCD // 32))()
+    for c in range(8):
+        if c % nparts == part % nparts:
+            words[c] = 0xFFFFFFFF
+    out = C.c_void_p()
+    with torch.cuda.device(dev):
+        check(lib().yl_stream_create_masked(words, len(words), C.byref(out)), "yl_stream_create_masked")
+    return torch.cuda.ExternalStream(out.value, device=dev)
+
+
+def xcc_census(stream, n_workgroups: int = 4096):
+    """Workgroups of a probe launch on ``stream`` per (XCD, shader engine, CU): an (8, 4, 16) int tensor."""
+    import torch
+
+    dev = stream.device
+    hist = torch.zeros(512, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib().yl_xcc_census(hist.data_ptr(), int(n_workgroups), stream.cuda_stream), "yl_xcc_census")
+    stream.synchronize()
+    return hist.view(8, 4, 16).cpu()
+
+
 _PKG = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ["YL_AMD_LIB"]) if os.environ.get("YL_AMD_LIB") else _PKG / "libyl_amd.so"  # dev override
 
@@ -77,7 +111,7 @@ EXPORTS = (
     "yl_engine_prepare_workspace", "yl_engine_forward", "yl_engine_forward_graph", "yl_engine_profile", "yl_engine_num_ops",
     "yl_engine_op_info", "yl_engine_detect_graph", "yl_detect_decode", "yl_nms_workspace_bytes", "yl_nms", "yl_decode_nms",
     "yl_preprocess_u8", "yl_letterbox_u8", "yl_nms_ml_workspace_bytes", "yl_nms_ml", "yl_engine_profile_detect",
-    "yl_graph_branch_probe",
+    "yl_graph_branch_probe", "yl_stream_create_masked", "yl_stream_destroy", "yl_xcc_census",
 )
 
 
@@ -186,7 +220,13 @@ def lib() -> C.CDLL:
                                            C.POINTER(f32)]
     L.yl_graph_branch_probe.restype = i32
     L.yl_graph_branch_probe.argtypes = [vp, i32, C.POINTER(f32), C.POINTER(C.c_int)]
-    if L.yl_abi_version() != 12:
+    L.yl_stream_create_masked.restype = i32
+    L.yl_stream_create_masked.argtypes = [C.POINTER(C.c_uint32), i32, C.POINTER(vp)]
+    L.yl_stream_destroy.restype = i32
+    L.yl_stream_destroy.argtypes = [vp]
+    L.yl_xcc_census.restype = i32
+    L.yl_xcc_census.argtypes = [vp, i32, vp]
+    if L.yl_abi_version() != 13:
         raise RuntimeError("libyl_amd.so ABI version mismatch; rebuild it")
     _lib = L
     return L

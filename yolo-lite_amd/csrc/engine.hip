@@ -1103,6 +1103,45 @@ extern "C" int yl_engine_profile_detect(yl_engine* e, const void* input, int in_
   return rc;
 }
 
+// ---- CU-masked streams: a HIP stream whose dispatches are confined to a subset of the compute units
+// (hipExtStreamCreateWithCUMask).  bench.py pins every batch in flight to ONE XCD (32 CUs, one L2): a launch on a 20x20
+// or 40x40 map cannot fill 256 CUs but fills 32, and eight partitions work in parallel.
+extern "C" int yl_stream_create_masked(const uint32_t* cu_mask, int n_words, void** stream_out) {
+  if (!cu_mask || n_words <= 0 || !stream_out) return fail(-1, "yl_stream_create_masked: bad arguments");
+  hipStream_t s = nullptr;
+  YL_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, cu_mask));
+  *stream_out = (void*)s;
+  return 0;
+}
+
+extern "C" int yl_stream_destroy(void* stream) {
+  if (!stream) return fail(-1, "yl_stream_destroy: null stream");
+  YL_HIP(hipStreamDestroy((hipStream_t)stream));
+  return 0;
+}
+
+// Which compute units does a stream's work land on?  Every workgroup adds one to the counter of the (XCD, shader
+// engine, CU) it runs on: bin = xcc * 64 + se * 16 + cu (HW_REG_XCC_ID, HW_REG_HW_ID).  hist: 512 x uint32 on the device,
+// zeroed by the caller.
+__global__ void xcc_census_kernel(unsigned* hist) {
+  if (threadIdx.x == 0) {
+    const unsigned xcc = __builtin_amdgcn_s_getreg((20 /*HW_REG_XCC_ID*/) | (0 << 6) | ((4 - 1) << 11)) & 7u;
+    const unsigned hw = __builtin_amdgcn_s_getreg((4 /*HW_REG_HW_ID*/) | (0 << 6) | ((32 - 1) << 11));
+    const unsigned cu = (hw >> 8) & 15u, se = (hw >> 13) & 3u;
+    atomicAdd(hist + xcc * 64 + se * 16 + cu, 1u);
+    // keep the workgroup alive for a moment so that a probe launch spreads over every unit it may use
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < 500) __builtin_amdgcn_s_sleep(4);
+  }
+}
+
+extern "C" int yl_xcc_census(unsigned* hist8_device /* 512 bins */, int n_workgroups, void* stream) {
+  if (!hist8_device || n_workgroups <= 0) return fail(-1, "yl_xcc_census: bad arguments");
+  hipLaunchKernelGGL(xcc_census_kernel, dim3((unsigned)n_workgroups), dim3(64), 0, (hipStream_t)stream, hist8_device);
+  YL_HIP(hipGetLastError());
+  return 0;
+}
+
 // Do two parallel branches of a captured graph really run concurrently on this runtime?  (The hot path's graph has
 // exactly two; whether the runtime maps them to two hardware queues depends on DEBUG_HIP_FORCE_GRAPH_QUEUES being in
 // the environment before HIP initialised -- _lib.apply_runtime_knobs.)  Two one-wave kernels that each spin for
