@@ -1,0 +1,39 @@
+"""CU-masked streams (yl_stream_create_masked) and the per-unit census probe (yl_xcc_census) on the GPU."""
+import pytest
+import torch
+
+from yololite_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cu_slice_stream_confines_work_to_a_slice_of_every_xcd(gpu_device):
+    full = _lib.xcc_census(torch.cuda.current_stream(gpu_device), 8192)
+    assert int((full > 0).sum()) == _lib.NUM_XCD * _lib.CUS_PER_XCD
+    half = _lib.xcc_census(_lib.cu_slice_stream(gpu_device, 0, 2), 8192)
+    assert int(half.sum()) == 8192
+    assert int((half > 0).sum()) == _lib.NUM_XCD * _lib.CUS_PER_XCD // 2
+    # the dispatcher still uses all eight XCDs: a stream gets a slice of each, never an XCD of its own
+    assert all(int(v) > 0 for v in half.sum((1, 2)))
+    other = _lib.xcc_census(_lib.cu_slice_stream(gpu_device, 1, 2), 8192)
+    assert int(((half > 0) & (other > 0)).sum()) == 0
+
+
+def test_hot_path_on_a_masked_stream_is_bit_identical(gpu_device):
+    """The engine takes whatever stream is current: a CU-masked one changes where the work runs, not the result."""
+    from yololite_amd.nn.synth import synth_state_dict
+    from yololite_amd.nn import arch
+    from yololite_amd.nn.engine import HipEngine
+
+    specs, _ = arch.parse_model(arch.yolo11_dict("n"))
+    sd = synth_state_dict("n", 8, cls_bias=[-2.0, -2.0, -2.0], cls_gain=4.0)
+    eng = HipEngine.from_model(specs, sd, 2, 64, 96, gpu_device)
+    x = torch.rand(2, 3, 64, 96, generator=torch.Generator().manual_seed(5)).to(gpu_device)
+    ref, cref = eng.detect(x, 0.25, 0.7, max_det=50)
+    ref, cref = ref.clone(), cref.clone()
+    st = _lib.cu_slice_stream(gpu_device, 1, 4)
+    st.wait_stream(torch.cuda.current_stream(gpu_device))
+    with torch.cuda.stream(st):
+        out, cnt = eng.detect(x, 0.25, 0.7, max_det=50, slot=1)
+    st.synchronize()
+    assert torch.equal(cnt, cref) and torch.equal(out, ref)
