@@ -35,7 +35,7 @@ constexpr int BN_THREADS = 512;  // 8 waves, two per SIMD: one wave per SIMD lef
 constexpr int BN_WAVES = BN_THREADS / 64;
 
 template <int CP>
-__global__ __launch_bounds__(BN_THREADS) void bneck2_kernel(Bneck2Args a) {
+__global__ __launch_bounds__(BN_THREADS) __attribute__((amdgpu_waves_per_eu(2))) void bneck2_kernel(Bneck2Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char bnmem[];
   constexpr int MT = CP / 2;            // channel tiles of 16
   constexpr int KS = 9 * CP / 4;        // k-steps of a 3x3 conv with c input channels (c % 32 == 0)

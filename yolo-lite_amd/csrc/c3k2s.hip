@@ -33,7 +33,8 @@ constexpr size_t c3k2s_lds() {
 }
 
 template <int CP, int NCB>
-__global__ __launch_bounds__(256) void c3k2s_kernel(C3k2sArgs a) {
+// (waves_per_eu(2): MFMA results in VGPRs, see stem2_kernel)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c3k2s_kernel(C3k2sArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char c3mem[];
   constexpr int MP = CP / 2;                       // planes of the intermediate
   constexpr int KA = (9 * CP + 3) / 4;             // k-steps of Bottleneck.cv1 (c -> c/2), one tile of 16 rows

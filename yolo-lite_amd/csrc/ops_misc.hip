@@ -522,7 +522,7 @@ constexpr int AT_QSPLIT = 4;           // workgroups per (image, head)
 
 constexpr int AT_WAVES = 8;  // waves per workgroup: 4 x 8 = 32 query-tile slots per (image, head) cover the 25 tiles of a
                              // 20x20 map in ONE round (4 waves needed two, the second 9/16 full)
-__global__ __launch_bounds__(64 * AT_WAVES) void attention_kernel(AttnArgs a) {
+__global__ __launch_bounds__(64 * AT_WAVES) __attribute__((amdgpu_waves_per_eu(2))) void attention_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char asm_[];
   __bf16* sK = reinterpret_cast<__bf16*>(asm_);   // [AT_STAGE][AT_KP]
   __bf16* sVt = sK + AT_STAGE * AT_KP;            // [64][AT_VP]

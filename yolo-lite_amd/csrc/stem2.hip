@@ -35,7 +35,9 @@ size_t stem2_lds_bytes(int C0) {
 }
 
 template <typename T, int MT, bool POST, int CG0>
-__global__ __launch_bounds__(256) void stem2_kernel(Stem2Args a) {
+// (waves_per_eu(2): at most 256 registers per lane, so the MFMA results are VGPRs -- without it hipcc parks them in AGPRs
+// and copies every one back with v_accvgpr_read before the SiLU)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void stem2_kernel(Stem2Args a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char s2mem[];
   __bf16* img = reinterpret_cast<__bf16*>(s2mem);                          // [3][S2_IR][S2_IP]
   unsigned char* stile = s2mem + (size_t)3 * S2_IR * S2_IP * 2;            // [C0/8][S2_SR][S2_SP] x 16 B
