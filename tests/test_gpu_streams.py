@@ -36,4 +36,6 @@ def test_hot_path_on_a_masked_stream_is_bit_identical(gpu_device):
     with torch.cuda.stream(st):
         out, cnt = eng.detect(x, 0.25, 0.7, max_det=50, slot=1)
     st.synchronize()
-    assert torch.equal(cnt, cref) and torch.equal(out, ref)
+    assert torch.equal(cnt, cref)
+    for i, n in enumerate(cnt.tolist()):  # rows past the count are padding (not written by the eager form)
+        assert n > 0 and torch.equal(out[i, :n], ref[i, :n])
