@@ -111,7 +111,9 @@ typedef struct yl_op {
      channels come from in2 at pixel (y / up, x / up).  up must be 2; in2.C and in.C multiples of 32;
      `weight` is [Cout][in2.C + in.C]. */
   yl_view in2;
-  int32_t up, reserved;
+  int32_t up;
+  int32_t group;      /* > 0: consecutive ops with the same value that are the same conv on different maps (the three Detect
+                         levels, head.py:59-62) may run as ONE launch; 0 = on its own.  A hint: the results are the same */
   /* 3x3 stride-2 conv that is op 0 only: stem_weight != NULL fuses the network's first layer in front of it
      (Conv(3 -> in.C, 3x3, s2) on the NCHW network input, weight [in.C][3][3][3], bias [in.C], SiLU if stem_act):
      `in` then describes a tensor that is never materialised (its offset is ignored); in.C must be 16 or 32

@@ -461,8 +461,9 @@ def test_fused_class_branch_tail_is_bit_identical(gpu_device, monkeypatch, h, w)
     x = torch.rand(2, 3, h, w, generator=torch.Generator().manual_seed(h * 3 + w))
     monkeypatch.setenv("YL_FUSE_DWPW_TAIL", "1")  # the default since round 2 (see nn/lower.py)
     eng = _engine("n", sd, 2, h, w, gpu_device)
-    fused = [i for i in range(len(eng.prog.ops)) if eng.op_kernel(i) == "dw3x3+pw1x1+1x1_mfma"]
-    assert len(fused) == 3, fused
+    names = [eng.op_kernel(i) for i in range(len(eng.prog.ops))]
+    # the three levels' tails run as ONE group launch (nn/lower.py group_detect_levels): its first member carries the name
+    assert names.count("dw3x3+pw1x1+1x1_mfma[x3]") == 1 and names.count("(in the group launch)") == 5, names
     y = eng.forward(x.to(gpu_device)).clone()
     monkeypatch.setenv("YL_FUSE_DWPW_TAIL", "0")
     ref_eng = _engine("n", sd, 2, h, w, gpu_device)
@@ -470,6 +471,33 @@ def test_fused_class_branch_tail_is_bit_identical(gpu_device, monkeypatch, h, w)
     y_ref = ref_eng.forward(x.to(gpu_device))
     assert torch.equal(y, y_ref)
     for a, b in zip(eng.raw_levels(), ref_eng.raw_levels()):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("h,w,mode", [(640, 640, "1"), (96, 160, "1"), (640, 640, "2")])
+def test_level_group_launches_are_bit_identical(gpu_device, monkeypatch, h, w, mode):
+    """The three Detect levels' copies of one conv in ONE launch (conv_group_kernel / dwpw_group_kernel, yl_op.group)
+    against separate launches: every bit of the level maps and of the detections, and six launches fewer."""
+    sd = synth_state_dict("n", 9, cls_bias=[-3.0, -3.0, -3.0], cls_gain=6.0)
+    x = torch.randint(0, 256, (2, 3, h, w), generator=torch.Generator().manual_seed(h), dtype=torch.uint8).to(gpu_device)
+    monkeypatch.setenv("YL_GROUP_LEVELS", mode)
+    eng = _engine("n", sd, 2, h, w, gpu_device)
+    names = [eng.op_kernel(i) for i in range(len(eng.prog.ops))]
+    assert names.count("(in the group launch)") == (6 if mode == "1" else 5)
+    assert {"conv3x3_mfma[x3]" if mode == "1" else "conv3x3_mfma[x2]", "conv3x3+1x1_mfma[x3]", "dw3x3+pw1x1+1x1_mfma[x3]"} <= set(names)
+    out, cnt = eng.detect(x, 0.25, 0.7, max_det=300)
+    out, cnt = out.clone(), cnt.clone()
+    lv = [t.clone() for t in eng.raw_levels()]
+    out_g, cnt_g = eng.detect(x, 0.25, 0.7, max_det=300, graph=True)
+    assert torch.equal(cnt_g, cnt)
+    monkeypatch.setenv("YL_GROUP_LEVELS", "0")
+    ref = _engine("n", sd, 2, h, w, gpu_device)
+    assert not any("group" in ref.op_kernel(i) or "[x3]" in ref.op_kernel(i) for i in range(len(ref.prog.ops)))
+    o2, c2 = ref.detect(x, 0.25, 0.7, max_det=300)
+    assert torch.equal(cnt, c2)
+    for i, n in enumerate(cnt.tolist()):
+        assert torch.equal(out[i, :n], o2[i, :n]) and torch.equal(out_g[i, :n], o2[i, :n])
+    for a, b in zip(lv, ref.raw_levels()):
         assert torch.equal(a, b)
 
 

@@ -130,7 +130,7 @@ class Op(C.Structure):
                 ("weight", C.c_void_p), ("bias", C.c_void_p),
                 ("post_cin", C.c_int32), ("post_act", C.c_int32),
                 ("post_weight", C.c_void_p), ("post_bias", C.c_void_p),
-                ("inp2", View), ("up", C.c_int32), ("reserved", C.c_int32),
+                ("inp2", View), ("up", C.c_int32), ("group", C.c_int32),
                 ("stem_weight", C.c_void_p), ("stem_bias", C.c_void_p),
                 ("stem_act", C.c_int32), ("reserved2", C.c_int32),
                 ("in_scale", C.c_float), ("out_scale", C.c_float), ("res_scale", C.c_float), ("out8_c0", C.c_int32),

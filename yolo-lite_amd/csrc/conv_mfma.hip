@@ -76,11 +76,11 @@ __device__ __forceinline__ void run_ksteps(const ConvArgs& a, __amdgpu_buffer_rs
 // O8: the epilogue also stores the e4m3 copy of the output (yl_op.out8, fp8 mode only; a separate instantiation so that the bf16
 // programs run exactly the code they ran before the copy existed).
 template <int KS, int MT, int NT, bool UNIFORM, bool POST, bool UP = false, bool O8 = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(YL_CONV_WPE))) void conv_kernel(ConvArgs a) {
+__device__ __forceinline__ void conv_body(const ConvArgs& a, int block) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, n = lane & 15;
-  const int bid = xcd_remap(blockIdx.x, a.nblocks);
+  const int bid = xcd_remap(block, a.nblocks);
   const int cb = bid % a.ncb;
   const int pblk = bid / a.ncb;
   const __amdgpu_buffer_rsrc_t rin =
@@ -199,6 +199,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(YL_CONV_WPE
   }
 }
 
+template <int KS, int MT, int NT, bool UNIFORM, bool POST, bool UP = false, bool O8 = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(YL_CONV_WPE))) void conv_kernel(ConvArgs a) {
+  conv_body<KS, MT, NT, UNIFORM, POST, UP, O8>(a, blockIdx.x);
+}
+
+// Up to three convs of ONE tiling in one launch ("horizontal" fusion): the three Detect levels run the same box / class
+// branch on 80x80, 40x40 and 20x20 maps (reference nn/modules/head.py:59-62: `for i in range(self.nl)`), and a launch on
+// a 20x20 map cannot fill 256 CUs by itself.  Workgroup -> (conv, block inside it) by the running block counts; every
+// conv keeps its own arguments (pointers, geometry, k-steps, slab chunking), only MT / NT / the LDS size are shared.
+struct ConvGroup {
+  ConvArgs a[3];
+  int nb[3];  // workgroups of each member (unused members: 0)
+};
+
+template <int KS, int MT, int NT, bool UNIFORM, bool POST>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(YL_CONV_WPE))) void conv_group_kernel(ConvGroup G) {
+  int block = blockIdx.x, m = 0;
+  if (block >= G.nb[0]) {
+    block -= G.nb[0];
+    m = 1;
+    if (block >= G.nb[1]) {
+      block -= G.nb[1];
+      m = 2;
+    }
+  }
+  conv_body<KS, MT, NT, UNIFORM, POST>(G.a[m], block);
+}
+
 // ------------------------------------------------------- depthwise 3x3 -> pointwise 1x1 in one launch
 // The Detect class branch is Sequential(DWConv(c, c, 3), Conv(c, c3, 1)) twice (head.py:41-48).  The
 // depthwise output is consumed by that 1x1 conv only, so a workgroup computes it for its 64*NT pixels
@@ -209,12 +237,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(YL_CONV_WPE
 // ends the class branch) runs behind it from LDS: the pointwise result is written into the depthwise tile's place in
 // B-fragment order and multiplied by the second filter slab; that tensor is never stored either.
 template <int MT, int NT, bool PW2 = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void dwpw_kernel(ConvArgs a) {
+__device__ __forceinline__ void dwpw_body(const ConvArgs& a, int block) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int P = 64 * NT;  // pixels per workgroup
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, n = lane & 15;
-  const int pblk = xcd_remap(blockIdx.x, gridDim.x);
+  const int pblk = xcd_remap(block, a.nblocks);
   bf16x8* slab = reinterpret_cast<bf16x8*>(smem);
   bf16x8* tile = slab + a.ksteps * MT * 64;                       // [max(cg, cg2)][P]
   const int tile_planes = PW2 ? max(a.cg, a.cg2) : a.cg;
@@ -362,6 +390,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
     a2.act = a.post_act;
     epilogue<MT, NT>(a2, rout, rres, 0, g, Pp.opix, acc);
   }
+}
+
+template <int MT, int NT, bool PW2 = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void dwpw_kernel(ConvArgs a) {
+  dwpw_body<MT, NT, PW2>(a, blockIdx.x);
+}
+
+// the same for up to three launches of one tiling (the class branch's second half is identical on every Detect level)
+template <int MT, int NT, bool PW2>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void dwpw_group_kernel(ConvGroup G) {
+  int block = blockIdx.x, m = 0;
+  if (block >= G.nb[0]) {
+    block -= G.nb[0];
+    m = 1;
+    if (block >= G.nb[1]) {
+      block -= G.nb[1];
+      m = 2;
+    }
+  }
+  dwpw_body<MT, NT, PW2>(G.a[m], block);
 }
 
 // ------------------------------------------------------------------------------------ host
@@ -615,9 +663,8 @@ static int launch_dwpw(const ConvConfig& cfg, const ConvArgs& a, size_t lds, hip
   return a.wpk2 ? launch_dwpw2<MT, NT, true>(cfg, a, lds, s) : launch_dwpw2<MT, NT, false>(cfg, a, lds, s);
 }
 
-// depthwise 3x3 + pointwise 1x1 [+ a further 1x1] (see dwpw_kernel); cfg from conv_choose(Cin = C, k = 1)
-int dwpw_launch(const ConvConfig& cfg0, ConvArgs a, int batch, hipStream_t s) {
-  ConvConfig cfg = cfg0;
+// dwpw_kernel's arguments and LDS size from the tiling; cfg may be retiled (development override of NT)
+static int dwpw_prepare(ConvConfig& cfg, ConvArgs& a, int batch, size_t* lds_out) {
   static const int force_nt = getenv("YL_DWPW_NT") ? atoi(getenv("YL_DWPW_NT")) : 0;  // development: 1 or 2 positions tiles per wave
   if (force_nt == 1 || force_nt == 2) {
     cfg.NT = force_nt;
@@ -645,15 +692,23 @@ int dwpw_launch(const ConvConfig& cfg0, ConvArgs a, int batch, hipStream_t s) {
   a.nblocks = (cfg.npatches + 3) / 4;
   static const int dwpw_dbg = getenv("YL_DWPW_DBG") ? atoi(getenv("YL_DWPW_DBG")) : 0;  // timing ablations (wrong results)
   a.dbg = dwpw_dbg;
+  const int planes = a.wpk2 && a.cg2 > cfg.cg ? a.cg2 : cfg.cg;
+  *lds_out = (size_t)cfg.ksteps * cfg.MT * 1024 + (size_t)planes * 64 * cfg.NT * 16 +
+             (a.wpk2 ? (size_t)a.ksteps2 * cfg.MT * 1024 : 0);
+  if (*lds_out > LDS_MAX) return fail(-3, "dwpw: LDS budget exceeded");
+  return 0;
+}
+
+// depthwise 3x3 + pointwise 1x1 [+ a further 1x1] (see dwpw_kernel); cfg from conv_choose(Cin = C, k = 1)
+int dwpw_launch(const ConvConfig& cfg0, ConvArgs a, int batch, hipStream_t s) {
+  ConvConfig cfg = cfg0;
+  size_t lds = 0;
+  if (int rc = dwpw_prepare(cfg, a, batch, &lds)) return rc;
   {  // input staged through LDS (dwpw.hip) where the geometry allows
     int handled = 0;
     const int rc = dwpw_tile_launch(cfg, a, batch, s, &handled);
     if (rc || handled) return rc;
   }
-  const int planes = a.wpk2 && a.cg2 > cfg.cg ? a.cg2 : cfg.cg;
-  const size_t lds = (size_t)cfg.ksteps * cfg.MT * 1024 + (size_t)planes * 64 * cfg.NT * 16 +
-                     (a.wpk2 ? (size_t)a.ksteps2 * cfg.MT * 1024 : 0);
-  if (lds > LDS_MAX) return fail(-3, "dwpw: LDS budget exceeded");
   switch (cfg.MT * 10 + cfg.NT) {
     case 11: return launch_dwpw<1, 1>(cfg, a, lds, s);
     case 12: return launch_dwpw<1, 2>(cfg, a, lds, s);
@@ -667,11 +722,40 @@ int dwpw_launch(const ConvConfig& cfg0, ConvArgs a, int batch, hipStream_t s) {
   return fail(-3, "dwpw: unsupported tile shape");
 }
 
-// `a` arrives with pointers, plane sizes, geometry, Cin/Cout/stride/act/out_f32 filled in.
-int conv_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s) {
-  if (cfg.pair && !a.out8) return conv3_pair_launch(cfg, a, batch, s);
-  if (cfg.reg && !a.out8) return conv3_reg_launch(cfg, a, batch, s);
-  if (cfg.tile && a.act) return conv3_tile_launch(cfg, a, batch, s);  // (a conv without SiLU stays on conv_kernel)
+template <int MT, int NT>
+static int launch_dwpw_group(const ConvGroup& G, int grid, size_t lds, hipStream_t s) {
+  auto kern = dwpw_group_kernel<MT, NT, true>;
+  static bool attr = false;
+  if (!attr) {
+    YL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
+    attr = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, G);
+  YL_HIP(hipGetLastError());
+  return 0;
+}
+
+// n = 2 or 3 depthwise + pointwise + 1x1 launches of one tiling (five channel tiles, one NT) in one launch
+int dwpw_group_launch(const ConvConfig* cfg0, const ConvArgs* args, int n, int batch, hipStream_t s) {
+  if (n < 2 || n > 3) return fail(-3, "dwpw group: two or three members");
+  ConvGroup G{};
+  size_t lds = 0;
+  int grid = 0;
+  for (int i = 0; i < n; ++i) {
+    ConvConfig cfg = cfg0[i];
+    G.a[i] = args[i];
+    size_t l = 0;
+    if (int rc = dwpw_prepare(cfg, G.a[i], batch, &l)) return rc;
+    if (cfg.MT != 5 || cfg.NT != cfg0[0].NT || !G.a[i].wpk2) return fail(-3, "dwpw group: members need one tiling and a fused tail");
+    G.nb[i] = G.a[i].nblocks;
+    grid += G.nb[i];
+    lds = l > lds ? l : lds;
+  }
+  return cfg0[0].NT == 1 ? launch_dwpw_group<5, 1>(G, grid, lds, s) : launch_dwpw_group<5, 2>(G, grid, lds, s);
+}
+
+// conv_kernel's arguments derived from the tiling (everything conv_launch used to fill in place)
+static int conv_prepare(const ConvConfig& cfg, ConvArgs& a, int batch) {
   a.ncb = cfg.ncb;
   a.cg = cfg.cg;
   a.ksteps = cfg.ksteps;
@@ -707,7 +791,69 @@ int conv_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s) {
     static const int dbg = getenv("YL_CONV_DBG") ? atoi(getenv("YL_CONV_DBG")) : 0;  // ablation, dev only
     a.dbg = dbg;
   }
+  return 0;
+}
+
+// `a` arrives with pointers, plane sizes, geometry, Cin/Cout/stride/act/out_f32 filled in.
+int conv_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s) {
+  if (cfg.pair && !a.out8) return conv3_pair_launch(cfg, a, batch, s);
+  if (cfg.reg && !a.out8) return conv3_reg_launch(cfg, a, batch, s);
+  if (cfg.tile && a.act) return conv3_tile_launch(cfg, a, batch, s);  // (a conv without SiLU stays on conv_kernel)
+  if (int rc = conv_prepare(cfg, a, batch)) return rc;
   return cfg.ntaps == 9 ? launch_m<3>(cfg, a, s) : launch_m<1>(cfg, a, s);
+}
+
+// The tiling of a conv that joins a group launch: plain conv_kernel (no register / tile variants), NT forced to the
+// group's common pixel-tile count, one patch per wave.
+void conv_retile_for_group(ConvConfig* c, int NT, int batch, int Ho, int Wo) {
+  c->reg = c->tile = c->pair = 0;
+  c->NT = NT;
+  c->npatches = (int)(((long long)batch * Ho * Wo + 16 * NT - 1) / (16 * NT));
+  c->ppw = 1;
+  c->gws = (c->npatches + 3) / 4;
+  c->name = c->ntaps == 9 ? "conv3x3_mfma" : "conv1x1_mfma";
+}
+
+bool conv_group_compatible(const ConvConfig* cfg, const ConvArgs* a, int n) {
+  if (n < 2 || n > 3) return false;
+  for (int i = 0; i < n; ++i) {
+    if (cfg[i].ntaps != 9 || cfg[i].MT != 4 || !cfg[i].uniform || cfg[i].post != cfg[0].post || cfg[i].NT != cfg[0].NT ||
+        (cfg[i].NT != 2 && cfg[i].NT != 4) || a[i].in2 || a[i].out8 || a[i].out_f32 || a[i].res || a[i].stride != 1 ||
+        cfg[i].reg || cfg[i].tile || cfg[i].pair)
+      return false;
+  }
+  return true;
+}
+
+template <int NT, bool POST>
+static int launch_group_r(const ConvGroup& G, int grid, size_t lds, hipStream_t s) {
+  auto kern = conv_group_kernel<3, 4, NT, true, POST>;
+  static bool attr = false;
+  if (!attr) {
+    YL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
+    attr = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, G);
+  YL_HIP(hipGetLastError());
+  return 0;
+}
+
+// n = 2 or 3 stride-1 3x3 convs with 64 output channels (conv_group_compatible) in one launch
+int conv_group_launch(const ConvConfig* cfg, const ConvArgs* args, int n, int batch, hipStream_t s) {
+  if (!conv_group_compatible(cfg, args, n)) return fail(-3, "conv group: members need one tiling (3x3, stride 1, 64 output channels)");
+  ConvGroup G{};
+  size_t lds = 0;
+  int grid = 0;
+  for (int i = 0; i < n; ++i) {
+    G.a[i] = args[i];
+    if (int rc = conv_prepare(cfg[i], G.a[i], batch)) return rc;
+    G.nb[i] = G.a[i].nblocks;
+    grid += G.nb[i];
+    lds = cfg[i].lds_bytes > lds ? cfg[i].lds_bytes : lds;
+  }
+  const bool post = cfg[0].post != 0;
+  if (cfg[0].NT == 4) return post ? launch_group_r<4, true>(G, grid, lds, s) : launch_group_r<4, false>(G, grid, lds, s);
+  return post ? launch_group_r<2, true>(G, grid, lds, s) : launch_group_r<2, false>(G, grid, lds, s);
 }
 
 }  // namespace yl

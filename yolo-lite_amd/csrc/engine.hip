@@ -34,6 +34,7 @@ struct OpRec {
   float* d_bias3 = nullptr;
   float* d_alpha = nullptr;  // fp8 conv: in_scale * filter scale per output channel
   bool f8 = false;
+  int group_n = 0;  // group launch (yl_op.group): 2 or 3 on the first member, -1 on the others (run with it), 0 = on its own
   double flops = 0, bytes = 0;
   const char* name = "";
 };
@@ -550,8 +551,148 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
     if (o.lane > e->max_lane) e->max_lane = o.lane;
     e->ops.push_back(r);
   }
+  // ---- group launches: runs of 2-3 consecutive ops with the same yl_op.group > 0 (the lowering puts the three Detect
+  // levels' copies of one conv side by side).  A run that does not fit one tiling simply stays ungrouped.
+  for (size_t i = 0; i < e->ops.size();) {
+    const int gid = e->ops[i].op.group;
+    size_t j = i + 1;
+    if (gid > 0)
+      while (j < e->ops.size() && e->ops[j].op.group == gid) ++j;
+    const int n = (int)(j - i);
+    if (gid > 0 && n >= 2 && n <= 3) {
+      bool ok = true;
+      const bool dw = e->ops[i].op.kind == YL_OP_DWCONV3;
+      for (size_t k = i; k < j && ok; ++k) {
+        const OpRec& r = e->ops[k];
+        const yl_op& o = r.op;
+        ok = o.lane == 0 && !r.f8 && !r.d_w0 && o.in.dtype == YL_BF16 && o.out.dtype == YL_BF16 && o.out8.offset < 0;
+        if (dw) ok = ok && o.kind == YL_OP_DWCONV3 && r.d_wpk && r.d_wpk3 && r.cfg.MT == 5;
+        else
+          ok = ok && o.kind == YL_OP_CONV && o.k == 3 && o.stride == 1 && o.res.offset < 0 && o.in2.offset < 0 && r.cfg.MT == 4 &&
+               r.cfg.uniform && r.cfg.ncb == 1 && (r.cfg.post != 0) == (e->ops[i].cfg.post != 0);
+      }
+      if (ok) {
+        // one pixel-tile count for the group: the largest member's choice (it has most of the workgroups)
+        int NT = e->ops[i].cfg.NT;
+        long long px = 0;
+        for (size_t k = i; k < j; ++k) {
+          const long long p = (long long)e->ops[k].op.out.H * e->ops[k].op.out.W;
+          if (p > px) {
+            px = p;
+            NT = e->ops[k].cfg.reg ? e->ops[k].cfg.reg : e->ops[k].cfg.NT;
+          }
+        }
+        if (dw && NT > 2) NT = 2;
+        if (!dw && NT != 2 && NT != 4) NT = 2;
+        for (size_t k = i; k < j; ++k) {
+          OpRec& r = e->ops[k];
+          if (dw) {
+            r.cfg.NT = NT;
+            r.cfg.npatches = (int)(((long long)batch * r.op.out.H * r.op.out.W + 16 * NT - 1) / (16 * NT));
+          } else {
+            conv_retile_for_group(&r.cfg, NT, batch, r.op.out.H, r.op.out.W);
+          }
+          r.group_n = k == i ? n : -1;
+          r.name = k != i ? "(in the group launch)"
+                          : dw ? (n == 3 ? "dw3x3+pw1x1+1x1_mfma[x3]" : "dw3x3+pw1x1+1x1_mfma[x2]")
+                               : r.cfg.post ? (n == 3 ? "conv3x3+1x1_mfma[x3]" : "conv3x3+1x1_mfma[x2]")
+                                            : (n == 3 ? "conv3x3_mfma[x3]" : "conv3x3_mfma[x2]");
+        }
+      }
+    }
+    i = j;
+  }
   *out = e.release();
   return 0;
+}
+
+// ConvArgs of a plain (bf16, not the fused stem) YL_OP_CONV for workspace `ws`
+static void build_conv_args(const yl_engine* e, const OpRec& r, char* ws, ConvArgs& a) {
+  const yl_op& o = r.op;
+  const int B = e->batch;
+  const Geo gi = geo_of(B, o.in.H, o.in.W), go = geo_of(B, o.out.H, o.out.W);
+  a.in = pview(ws, o.in, B).base;
+  a.in_plane = (unsigned)plane_bytes(gi);
+  a.in_w1 = gi.W1;
+  a.in_img = gi.img;
+  a.in_g0 = gi.g0;
+  a.out_f32 = o.out.dtype == YL_F32;
+  if (a.out_f32) {
+    a.out = ws + o.out.offset;
+    a.out_pitch = o.out.pitch;
+    a.out_coff = o.out.coff;
+  } else {
+    a.out = pview(ws, o.out, B).base;
+    a.out_plane = (unsigned)plane_bytes(go);
+  }
+  a.out_w1 = go.W1;
+  a.out_img = go.img;
+  a.out_g0 = go.g0;
+  if (o.res.offset >= 0) {
+    a.res = pview(ws, o.res, B).base;
+    a.res_plane = (unsigned)plane_bytes(go);
+  }
+  if (o.in2.offset >= 0) {
+    const Geo g2 = geo_of(B, o.in2.H, o.in2.W);
+    a.in2 = pview(ws, o.in2, B).base;
+    a.in2_plane = (unsigned)plane_bytes(g2);
+    a.in2_w1 = g2.W1;
+    a.in2_img = g2.img;
+    a.in2_g0 = g2.g0;
+    a.ks_split = o.in2.C / 32;
+  }
+  a.wpk = r.d_wpk;
+  a.bias = r.d_bias;
+  a.wpk2 = r.d_wpk2;
+  a.bias2 = r.d_bias2;
+  a.post_cout = o.out.C;
+  a.post_act = o.post_act;
+  a.Ho = o.out.H;
+  a.Wo = o.out.W;
+  a.Cin = o.in.C + (o.in2.offset >= 0 ? o.in2.C : 0);
+  a.Cout = r.d_wpk2 ? o.post_cin : o.out.C;
+  a.stride = o.stride;
+  a.act = o.act;
+  fill_out8(a, o, ws, B);
+}
+
+// ConvArgs + tiling of a fused depthwise + pointwise [+ 1x1] YL_OP_DWCONV3 for workspace `ws`
+static void build_dwpw_args(const yl_engine* e, const OpRec& r, char* ws, ConvArgs& a, ConvConfig& cfg) {
+  const yl_op& o = r.op;
+  const int B = e->batch;
+  const Geo gi = geo_of(B, o.in.H, o.in.W);
+  a.in = pview(ws, o.in, B).base;
+  a.in_plane = (unsigned)plane_bytes(gi);
+  a.in_w1 = gi.W1;
+  a.in_img = gi.img;
+  a.in_g0 = gi.g0;
+  a.out = pview(ws, o.out, B).base;
+  a.out_plane = a.in_plane;
+  a.out_w1 = gi.W1;
+  a.out_img = gi.img;
+  a.out_g0 = gi.g0;
+  a.wpk = r.d_wpk;
+  a.bias = r.d_bias2;
+  a.dw_wpk = r.d_dwpk;
+  a.dw_b = r.d_bias;
+  a.dw_act = o.act;
+  a.Ho = o.out.H;
+  a.Wo = o.out.W;
+  a.Cin = o.in.C;
+  a.Cout = o.out.C;
+  a.stride = 1;
+  a.act = o.post_act;
+  cfg = r.cfg;
+  if (r.d_wpk3) {  // a further 1x1 behind the pointwise conv
+    a.Cout = o.reserved2;
+    a.wpk2 = r.d_wpk3;
+    a.bias2 = r.d_bias3;
+    a.post_cout = o.out.C;
+    a.post_act = o.stem_act;
+    a.cg2 = o.reserved2 / 8;
+    a.ksteps2 = r.cfg.kchunk;
+    cfg.kchunk = cfg.ksteps;
+  }
 }
 
 static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s, const void* input = nullptr,
@@ -623,49 +764,7 @@ static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s, c
         fill_out8(a, o, ws, B);
         return conv_f8_launch(r.cfg, a, B, s);
       }
-      a.in = pview(ws, o.in, B).base;
-      a.in_plane = (unsigned)plane_bytes(gi);
-      a.in_w1 = gi.W1;
-      a.in_img = gi.img;
-      a.in_g0 = gi.g0;
-      a.out_f32 = o.out.dtype == YL_F32;
-      if (a.out_f32) {
-        a.out = ws + o.out.offset;
-        a.out_pitch = o.out.pitch;
-        a.out_coff = o.out.coff;
-      } else {
-        a.out = pview(ws, o.out, B).base;
-        a.out_plane = (unsigned)plane_bytes(go);
-      }
-      a.out_w1 = go.W1;
-      a.out_img = go.img;
-      a.out_g0 = go.g0;
-      if (o.res.offset >= 0) {
-        a.res = pview(ws, o.res, B).base;
-        a.res_plane = (unsigned)plane_bytes(go);
-      }
-      if (o.in2.offset >= 0) {
-        const Geo g2 = geo_of(B, o.in2.H, o.in2.W);
-        a.in2 = pview(ws, o.in2, B).base;
-        a.in2_plane = (unsigned)plane_bytes(g2);
-        a.in2_w1 = g2.W1;
-        a.in2_img = g2.img;
-        a.in2_g0 = g2.g0;
-        a.ks_split = o.in2.C / 32;
-      }
-      a.wpk = r.d_wpk;
-      a.bias = r.d_bias;
-      a.wpk2 = r.d_wpk2;
-      a.bias2 = r.d_bias2;
-      a.post_cout = o.out.C;
-      a.post_act = o.post_act;
-      a.Ho = o.out.H;
-      a.Wo = o.out.W;
-      a.Cin = o.in.C + (o.in2.offset >= 0 ? o.in2.C : 0);
-      a.Cout = r.d_wpk2 ? o.post_cin : o.out.C;
-      a.stride = o.stride;
-      a.act = o.act;
-      fill_out8(a, o, ws, B);
+      build_conv_args(e, r, ws, a);
       return conv_launch(r.cfg, a, B, s);
     }
     case YL_OP_QUANT: {
@@ -740,39 +839,8 @@ static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s, c
     case YL_OP_DWCONV3: {
       if (r.d_wpk) {  // fused depthwise + pointwise
         ConvArgs a{};
-        const Geo gi = geo_of(B, o.in.H, o.in.W);
-        a.in = pview(ws, o.in, B).base;
-        a.in_plane = (unsigned)plane_bytes(gi);
-        a.in_w1 = gi.W1;
-        a.in_img = gi.img;
-        a.in_g0 = gi.g0;
-        a.out = pview(ws, o.out, B).base;
-        a.out_plane = a.in_plane;
-        a.out_w1 = gi.W1;
-        a.out_img = gi.img;
-        a.out_g0 = gi.g0;
-        a.wpk = r.d_wpk;
-        a.bias = r.d_bias2;
-        a.dw_wpk = r.d_dwpk;
-        a.dw_b = r.d_bias;
-        a.dw_act = o.act;
-        a.Ho = o.out.H;
-        a.Wo = o.out.W;
-        a.Cin = o.in.C;
-        a.Cout = o.out.C;
-        a.stride = 1;
-        a.act = o.post_act;
-        ConvConfig cfg = r.cfg;
-        if (r.d_wpk3) {  // a further 1x1 behind the pointwise conv
-          a.Cout = o.reserved2;
-          a.wpk2 = r.d_wpk3;
-          a.bias2 = r.d_bias3;
-          a.post_cout = o.out.C;
-          a.post_act = o.stem_act;
-          a.cg2 = o.reserved2 / 8;
-          a.ksteps2 = r.cfg.kchunk;
-          cfg.kchunk = cfg.ksteps;
-        }
+        ConvConfig cfg;
+        build_dwpw_args(e, r, ws, a, cfg);
         return dwpw_launch(cfg, a, B, s);
       }
       DwArgs a{};
@@ -825,6 +893,35 @@ static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s, c
     }
   }
   return fail(-1, "run_op: unknown kind");
+}
+
+// A group launch (yl_op.group): ops [i, i + n) are the same conv on the three Detect levels (reference
+// nn/modules/head.py:59-62), one launch for all of them (conv_group_kernel / dwpw_group_kernel).
+static int run_group(const yl_engine* e, size_t i, int n, char* ws, hipStream_t s) {
+  ConvArgs a[3]{};
+  ConvConfig cfg[3];
+  const bool dw = e->ops[i].op.kind == YL_OP_DWCONV3;
+  for (int k = 0; k < n; ++k) {
+    const OpRec& r = e->ops[i + k];
+    if (dw) {
+      build_dwpw_args(e, r, ws, a[k], cfg[k]);
+    } else {
+      build_conv_args(e, r, ws, a[k]);
+      cfg[k] = r.cfg;
+    }
+  }
+  return dw ? dwpw_group_launch(cfg, a, n, e->batch, s) : conv_group_launch(cfg, a, n, e->batch, s);
+}
+
+// op i or the group that starts at it; *consumed = ops covered (members of a group other than the first are never passed in)
+static int run_at(const yl_engine* e, size_t i, char* ws, hipStream_t s, const void* input, int in_dtype, int* consumed) {
+  const OpRec& r = e->ops[i];
+  if (r.group_n >= 2) {
+    *consumed = r.group_n;
+    return run_group(e, i, r.group_n, ws, s);
+  }
+  *consumed = 1;
+  return run_op(e, r, ws, s, input, in_dtype);
 }
 
 static int run_convert(const yl_engine* e, const void* input, int in_dtype, char* ws, hipStream_t s) {
@@ -898,10 +995,13 @@ extern "C" int yl_engine_forward(yl_engine* e, const void* input, int in_dtype, 
     if (int rc = run_convert(e, input, in_dtype, ws, s)) return rc;
   size_t nev = 0;
   std::vector<char> used((size_t)e->max_lane + 1, 0);
-  for (const OpRec& r : e->ops) {
+  for (size_t oi = 0; oi < e->ops.size(); ++oi) {
+    const OpRec& r = e->ops[oi];
+    if (r.group_n < 0) continue;  // launched with the first member of its group
     const int lane = r.op.lane;
     if (lane == 0) {
-      if (int rc = run_op(e, r, ws, s, input, in_dtype)) return rc;
+      int consumed = 1;
+      if (int rc = run_at(e, oi, ws, s, input, in_dtype, &consumed)) return rc;
     } else {
       hipEvent_t ev = ss.events[nev++];
       YL_HIP(hipEventRecord(ev, s));
@@ -1036,7 +1136,8 @@ extern "C" int yl_engine_profile(yl_engine* e, const void* input, int in_dtype, 
     if (e->ops[0].op.kind != YL_OP_STEM && !e->ops[0].d_w0) rc = run_convert(e, input, in_dtype, ws, s);
     (void)hipEventRecord(ev[1], s);
     for (int i = 0; i < n && !rc; ++i) {
-      rc = run_op(e, e->ops[i], ws, s, input, in_dtype);
+      int consumed = 1;
+      if (e->ops[i].group_n >= 0) rc = run_at(e, (size_t)i, ws, s, input, in_dtype, &consumed);  // (a group's time lands on its first member)
       (void)hipEventRecord(ev[i + 2], s);
     }
     if (y && !e->levels.empty() && !rc) rc = run_decode(e, ws, y, s);
@@ -1078,7 +1179,8 @@ extern "C" int yl_engine_profile_detect(yl_engine* e, const void* input, int in_
     if (!stem) rc = run_convert(e, input, in_dtype, ws, s);
     (void)hipEventRecord(ev[0], s);
     for (int i = 0; i < n && !rc; ++i) {
-      rc = run_op(e, e->ops[i], ws, s, input, in_dtype);
+      int consumed = 1;
+      if (e->ops[i].group_n >= 0) rc = run_at(e, (size_t)i, ws, s, input, in_dtype, &consumed);  // (a group's time lands on its first member)
       (void)hipEventRecord(ev[i + 1], s);
     }
     if (!rc)
@@ -1104,8 +1206,8 @@ extern "C" int yl_engine_profile_detect(yl_engine* e, const void* input, int in_
 }
 
 // ---- CU-masked streams: a HIP stream whose dispatches are confined to a subset of the compute units
-// (hipExtStreamCreateWithCUMask).  bench.py pins every batch in flight to ONE XCD (32 CUs, one L2): a launch on a 20x20
-// or 40x40 map cannot fill 256 CUs but fills 32, and eight partitions work in parallel.
+// (hipExtStreamCreateWithCUMask).  Built to give every batch in flight a part of the chip of its own; measured: a queue
+// cannot be confined to one XCD and static slices are far slower than the hardware's own packing.
 extern "C" int yl_stream_create_masked(const uint32_t* cu_mask, int n_words, void** stream_out) {
   if (!cu_mask || n_words <= 0 || !stream_out) return fail(-1, "yl_stream_create_masked: bad arguments");
   hipStream_t s = nullptr;

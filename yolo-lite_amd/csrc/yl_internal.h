@@ -135,6 +135,11 @@ int conv3_reg_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s
 void conv3_pair_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, int post, ConvConfig* cfg);
 int conv3_pair_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s);
 int dwpw_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s);
+// group launches (the three Detect levels in one launch, conv_mfma.hip)
+void conv_retile_for_group(ConvConfig* c, int NT, int batch, int Ho, int Wo);
+bool conv_group_compatible(const ConvConfig* cfg, const ConvArgs* a, int n);
+int conv_group_launch(const ConvConfig* cfg, const ConvArgs* args, int n, int batch, hipStream_t s);
+int dwpw_group_launch(const ConvConfig* cfg, const ConvArgs* args, int n, int batch, hipStream_t s);
 void dw_pack_mfma(const float* w, int C, std::vector<uint16_t>* out);
 int dwpw_tile_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s, int* handled);
 // conv_f8.hip: e4m3 x e4m3 -> fp32 on v_mfma_f32_16x16x128_f8f6f4

@@ -562,6 +562,40 @@ def _out_hw(h: int, w: int, k: int, s: int) -> Tuple[int, int]:
     return (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
 
 
+def group_detect_levels(ops: List[dict], det_prefix: str, nlv: int, keep_first_box_conv: bool = False) -> List[dict]:
+    """The Detect head runs the same two branches on every level (head.py:59-62, `for i in range(self.nl)`); the 40x40
+    and 20x20 copies cannot fill the chip by themselves.  Moves the head to the end of the program, the levels' copies of
+    each conv side by side, and marks the copies that share one tiling as a GROUP (``yl_op.group``): the engine runs a
+    group as one launch (conv_group_kernel / dwpw_group_kernel).  Buffers are never recycled (``_Arena``), so moving an
+    op later only needs its inputs to exist -- the head reads the neck's outputs and itself.  Same arithmetic per conv:
+    results are bit-identical to separate launches (tests/test_gpu_net.py)."""
+    head = [o for o in ops if o.get("name", "").startswith(det_prefix + ".")]
+    if len(head) != 4 * nlv or any(o.get("lane", 0) for o in head):
+        return ops  # not the fully fused form (box: conv, conv+1x1; class: dw+pw, dw+pw+1x1): leave the program alone
+
+    def role(name: str, lvl: int):
+        for r, pat in enumerate((f"{det_prefix}.cv3.{lvl}.0.0+pw", f"{det_prefix}.cv2.{lvl}.0", f"{det_prefix}.cv2.{lvl}.1+2",
+                                 f"{det_prefix}.cv3.{lvl}.1.0+pw+2")):
+            if name == pat:
+                return r
+        return None
+
+    by_role: Dict[int, List[dict]] = {}
+    for lvl in range(nlv):
+        for o in head:
+            r = role(o["name"], lvl)
+            if r is not None:
+                by_role.setdefault(r, []).append(o)
+    if sorted(by_role) != [0, 1, 2, 3] or any(len(v) != nlv for v in by_role.values()):
+        return ops
+    rest = [o for o in ops if not o.get("name", "").startswith(det_prefix + ".")]
+    for r in (1, 2, 3):  # role 0 (first half of the class branch) differs in width per level: separate launches
+        for lvl, o in enumerate(by_role[r]):
+            if not (keep_first_box_conv and r == 1 and lvl == 0):  # (level 0's first box conv may keep its own kernel)
+                o["group"] = r
+    return rest + by_role[0] + by_role[1] + by_role[2] + by_role[3]
+
+
 def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, in_h: int, in_w: int,
           strides: Sequence[float] = (8.0, 16.0, 32.0), side_lanes: bool = True, fuse_post: bool = True,
           fused_stem: bool = True, fp8_scales: Optional[Dict[str, float]] = None) -> Program:
@@ -817,6 +851,12 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
         # 72 -> 69 launches).  YL_FUSE_DWPW_TAIL=0 restores the separate 1x1 launches.
         if os.environ.get("YL_FUSE_DWPW_TAIL", "1") == "1":
             ops[:] = fuse_dwpw_tail(ops)
+            # The Detect levels' copies of one conv in one launch (round 2): 69 -> 64 launches, one batch at a time 1.106 ->
+            # 1.06 ms.  YL_GROUP_LEVELS=2 (default) leaves level 0's first box conv on its own kernel (conv3_reg_kernel);
+            # =1 groups it too (one launch fewer, -1 % with 20 batches in flight); =0 separate launches.
+            gl = os.environ.get("YL_GROUP_LEVELS", "2")
+            if gl in ("1", "2") and not fp8_scales:
+                ops[:] = group_detect_levels(ops, dp, nlv, keep_first_box_conv=gl == "2")
     if fuse_post and os.environ.get("YL_FUSE_UP", "1") != "0":
         ops[:] = fuse_upsample_into_convs(ops)
     if fuse_post and os.environ.get("YL_FUSE_STEM", "1") != "0":
