@@ -412,6 +412,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
   dwpw_body<MT, NT, PW2>(G.a[m], block);
 }
 
+// Convs AND depthwise + pointwise launches in one: the box branch and the class branch of the Detect head are
+// independent of each other (head.py:61: cat(cv2[i](x), cv3[i](x))), so their launches can share the chip as well as
+// the levels do.  Workgroups [0, n_conv) run conv_body on the members of GC, the rest dwpw_body on the members of GD.
+// The register budget is the larger of the two bodies' (the conv's), the LDS size the larger of the members'.
+template <int NTC, bool POST, int NTD, bool PW2>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void head_group_kernel(ConvGroup GC, ConvGroup GD, int n_conv) {
+  int block = blockIdx.x;
+  if (block < n_conv) {
+    int m = 0;
+    if (block >= GC.nb[0]) {
+      block -= GC.nb[0];
+      m = 1;
+      if (block >= GC.nb[1]) {
+        block -= GC.nb[1];
+        m = 2;
+      }
+    }
+    conv_body<3, 4, NTC, true, POST>(GC.a[m], block);
+  } else {
+    block -= n_conv;
+    int m = 0;
+    if (block >= GD.nb[0]) {
+      block -= GD.nb[0];
+      m = 1;
+      if (block >= GD.nb[1]) {
+        block -= GD.nb[1];
+        m = 2;
+      }
+    }
+    dwpw_body<5, NTD, PW2>(GD.a[m], block);
+  }
+}
+
 // ------------------------------------------------------------------------------------ host
 static unsigned magic_of(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull / (unsigned)d) + 1ull); }
 
@@ -854,6 +887,58 @@ int conv_group_launch(const ConvConfig* cfg, const ConvArgs* args, int n, int ba
   const bool post = cfg[0].post != 0;
   if (cfg[0].NT == 4) return post ? launch_group_r<4, true>(G, grid, lds, s) : launch_group_r<4, false>(G, grid, lds, s);
   return post ? launch_group_r<2, true>(G, grid, lds, s) : launch_group_r<2, false>(G, grid, lds, s);
+}
+
+template <int NTC, bool POST, int NTD>
+static int launch_head_group(const ConvGroup& GC, const ConvGroup& GD, int n_conv, int grid, size_t lds, hipStream_t s) {
+  auto kern = head_group_kernel<NTC, POST, NTD, POST>;
+  static bool attr = false;
+  if (!attr) {
+    YL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
+    attr = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, GC, GD, n_conv);
+  YL_HIP(hipGetLastError());
+  return 0;
+}
+
+// nc (1..3) compatible convs and nd (1..3) depthwise + pointwise launches of one tiling in ONE launch (head_group_kernel).
+// The convs all carry a fused 1x1 and the depthwise launches a fused tail, or none of them does.
+int head_group_launch(const ConvConfig* ccfg, const ConvArgs* cargs, int nc, const ConvConfig* dcfg0, const ConvArgs* dargs, int nd,
+                      int batch, hipStream_t s) {
+  if (nc < 1 || nc > 3 || nd < 1 || nd > 3) return fail(-3, "head group: one to three members of each kind");
+  if (nc >= 2 && !conv_group_compatible(ccfg, cargs, nc)) return fail(-3, "head group: the convs need one tiling");
+  ConvGroup GC{}, GD{};
+  size_t lds = 0;
+  int n_conv = 0, grid = 0;
+  for (int i = 0; i < nc; ++i) {
+    GC.a[i] = cargs[i];
+    if (int rc = conv_prepare(ccfg[i], GC.a[i], batch)) return rc;
+    GC.nb[i] = GC.a[i].nblocks;
+    n_conv += GC.nb[i];
+    lds = ccfg[i].lds_bytes > lds ? ccfg[i].lds_bytes : lds;
+  }
+  const bool post = ccfg[0].post != 0;
+  for (int i = 0; i < nd; ++i) {
+    ConvConfig cfg = dcfg0[i];
+    GD.a[i] = dargs[i];
+    size_t l = 0;
+    if (int rc = dwpw_prepare(cfg, GD.a[i], batch, &l)) return rc;
+    if (cfg.MT != 5 || cfg.NT != dcfg0[0].NT || (GD.a[i].wpk2 != nullptr) != post)
+      return fail(-3, "head group: the depthwise members need one tiling, with a fused tail exactly when the convs carry a fused 1x1");
+    GD.nb[i] = GD.a[i].nblocks;
+    grid += GD.nb[i];
+    lds = l > lds ? l : lds;
+  }
+  grid += n_conv;
+  const int ntc = ccfg[0].NT, ntd = dcfg0[0].NT;
+  if (ccfg[0].ntaps != 9 || ccfg[0].MT != 4 || !ccfg[0].uniform || (ntc != 2 && ntc != 4) || (ntd != 1 && ntd != 2))
+    return fail(-3, "head group: unsupported tiling");
+#define YL_HG(NTC, NTD) \
+  (post ? launch_head_group<NTC, true, NTD>(GC, GD, n_conv, grid, lds, s) : launch_head_group<NTC, false, NTD>(GC, GD, n_conv, grid, lds, s))
+  if (ntc == 4) return ntd == 2 ? YL_HG(4, 2) : YL_HG(4, 1);
+  return ntd == 2 ? YL_HG(2, 2) : YL_HG(2, 1);
+#undef YL_HG
 }
 
 }  // namespace yl

@@ -551,52 +551,69 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
     if (o.lane > e->max_lane) e->max_lane = o.lane;
     e->ops.push_back(r);
   }
-  // ---- group launches: runs of 2-3 consecutive ops with the same yl_op.group > 0 (the lowering puts the three Detect
-  // levels' copies of one conv side by side).  A run that does not fit one tiling simply stays ungrouped.
+  // ---- group launches: runs of consecutive ops with the same yl_op.group > 0 (the lowering puts the Detect levels'
+  // copies of one conv side by side): up to three convs, then up to three depthwise + pointwise launches, each kind of
+  // one tiling.  A run that does not fit simply stays ungrouped.
   for (size_t i = 0; i < e->ops.size();) {
     const int gid = e->ops[i].op.group;
     size_t j = i + 1;
     if (gid > 0)
       while (j < e->ops.size() && e->ops[j].op.group == gid) ++j;
     const int n = (int)(j - i);
-    if (gid > 0 && n >= 2 && n <= 3) {
+    if (gid > 0 && n >= 2 && n <= 6) {
+      int nc = 0, nd = 0;
       bool ok = true;
-      const bool dw = e->ops[i].op.kind == YL_OP_DWCONV3;
       for (size_t k = i; k < j && ok; ++k) {
         const OpRec& r = e->ops[k];
         const yl_op& o = r.op;
         ok = o.lane == 0 && !r.f8 && !r.d_w0 && o.in.dtype == YL_BF16 && o.out.dtype == YL_BF16 && o.out8.offset < 0;
-        if (dw) ok = ok && o.kind == YL_OP_DWCONV3 && r.d_wpk && r.d_wpk3 && r.cfg.MT == 5;
-        else
-          ok = ok && o.kind == YL_OP_CONV && o.k == 3 && o.stride == 1 && o.res.offset < 0 && o.in2.offset < 0 && r.cfg.MT == 4 &&
-               r.cfg.uniform && r.cfg.ncb == 1 && (r.cfg.post != 0) == (e->ops[i].cfg.post != 0);
-      }
-      if (ok) {
-        // one pixel-tile count for the group: the largest member's choice (it has most of the workgroups)
-        int NT = e->ops[i].cfg.NT;
-        long long px = 0;
-        for (size_t k = i; k < j; ++k) {
-          const long long p = (long long)e->ops[k].op.out.H * e->ops[k].op.out.W;
-          if (p > px) {
-            px = p;
-            NT = e->ops[k].cfg.reg ? e->ops[k].cfg.reg : e->ops[k].cfg.NT;
-          }
+        if (o.kind == YL_OP_CONV) {
+          ok = ok && nd == 0 && o.k == 3 && o.stride == 1 && o.res.offset < 0 && o.in2.offset < 0 && r.cfg.MT == 4 && r.cfg.uniform &&
+               r.cfg.ncb == 1 && (r.cfg.post != 0) == (e->ops[i].cfg.post != 0);
+          ++nc;
+        } else if (o.kind == YL_OP_DWCONV3) {
+          const OpRec& d0 = e->ops[i + nc];
+          ok = ok && r.d_wpk && r.cfg.MT == 5 && (r.d_wpk3 != nullptr) == (d0.d_wpk3 != nullptr);
+          ++nd;
+        } else {
+          ok = false;
         }
-        if (dw && NT > 2) NT = 2;
-        if (!dw && NT != 2 && NT != 4) NT = 2;
-        for (size_t k = i; k < j; ++k) {
-          OpRec& r = e->ops[k];
-          if (dw) {
+      }
+      ok = ok && nc <= 3 && nd <= 3;
+      if (ok && nc && nd)  // mixed launch: the convs carry a fused 1x1 exactly when the depthwise members carry a tail
+        ok = (e->ops[i].cfg.post != 0) == (e->ops[i + nc].d_wpk3 != nullptr);
+      if (ok && !nc && !e->ops[i].d_wpk3) ok = false;  // (a depthwise-only group exists for the tailed form only)
+      if (ok) {
+        // one pixel-tile count per kind: the largest member's choice (it has most of the workgroups)
+        auto largest = [&](size_t k0, size_t k1) {
+          size_t best = k0;
+          for (size_t k = k0; k < k1; ++k)
+            if ((long long)e->ops[k].op.out.H * e->ops[k].op.out.W > (long long)e->ops[best].op.out.H * e->ops[best].op.out.W) best = k;
+          return best;
+        };
+        if (nc) {
+          const OpRec& big = e->ops[largest(i, i + nc)];
+          int NT = big.cfg.reg ? big.cfg.reg : big.cfg.NT;
+          if (NT != 2 && NT != 4) NT = 2;
+          for (size_t k = i; k < i + nc; ++k) conv_retile_for_group(&e->ops[k].cfg, NT, batch, e->ops[k].op.out.H, e->ops[k].op.out.W);
+        }
+        if (nd) {
+          int NT = e->ops[largest(i + nc, j)].cfg.NT;
+          if (NT > 2) NT = 2;
+          for (size_t k = i + nc; k < j; ++k) {
+            OpRec& r = e->ops[k];
             r.cfg.NT = NT;
             r.cfg.npatches = (int)(((long long)batch * r.op.out.H * r.op.out.W + 16 * NT - 1) / (16 * NT));
-          } else {
-            conv_retile_for_group(&r.cfg, NT, batch, r.op.out.H, r.op.out.W);
           }
+        }
+        static const char* const cn[2][3] = {{"conv3x3_mfma[x1]", "conv3x3_mfma[x2]", "conv3x3_mfma[x3]"},
+                                             {"conv3x3+1x1_mfma[x1]", "conv3x3+1x1_mfma[x2]", "conv3x3+1x1_mfma[x3]"}};
+        static const char* const dn[3] = {"dw3x3+pw1x1+1x1_mfma[x1]", "dw3x3+pw1x1+1x1_mfma[x2]", "dw3x3+pw1x1+1x1_mfma[x3]"};
+        static const char* const hn[2] = {"head:conv3x3|dw3x3+pw1x1_mfma", "head:conv3x3+1x1|dw3x3+pw1x1+1x1_mfma"};
+        for (size_t k = i; k < j; ++k) {
+          OpRec& r = e->ops[k];
           r.group_n = k == i ? n : -1;
-          r.name = k != i ? "(in the group launch)"
-                          : dw ? (n == 3 ? "dw3x3+pw1x1+1x1_mfma[x3]" : "dw3x3+pw1x1+1x1_mfma[x2]")
-                               : r.cfg.post ? (n == 3 ? "conv3x3+1x1_mfma[x3]" : "conv3x3+1x1_mfma[x2]")
-                                            : (n == 3 ? "conv3x3_mfma[x3]" : "conv3x3_mfma[x2]");
+          r.name = k != i ? "(in the group launch)" : (nc && nd) ? hn[r.cfg.post ? 1 : 0] : nc ? cn[r.cfg.post ? 1 : 0][nc - 1] : dn[nd - 1];
         }
       }
     }
@@ -895,22 +912,27 @@ static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s, c
   return fail(-1, "run_op: unknown kind");
 }
 
-// A group launch (yl_op.group): ops [i, i + n) are the same conv on the three Detect levels (reference
-// nn/modules/head.py:59-62), one launch for all of them (conv_group_kernel / dwpw_group_kernel).
+// A group launch (yl_op.group): ops [i, i + n) are the same conv on the Detect levels (reference nn/modules/head.py:59-62)
+// and / or the independent branches of the head (head.py:61), one launch for all of them (conv_group_kernel /
+// dwpw_group_kernel / head_group_kernel).
 static int run_group(const yl_engine* e, size_t i, int n, char* ws, hipStream_t s) {
-  ConvArgs a[3]{};
-  ConvConfig cfg[3];
-  const bool dw = e->ops[i].op.kind == YL_OP_DWCONV3;
+  ConvArgs ca[3]{}, da[3]{};
+  ConvConfig cc[3], dc[3];
+  int nc = 0, nd = 0;
   for (int k = 0; k < n; ++k) {
     const OpRec& r = e->ops[i + k];
-    if (dw) {
-      build_dwpw_args(e, r, ws, a[k], cfg[k]);
+    if (r.op.kind == YL_OP_DWCONV3) {
+      build_dwpw_args(e, r, ws, da[nd], dc[nd]);
+      dc[nd].NT = r.cfg.NT;  // (the group's tiling: build_dwpw_args copies r.cfg, which already carries it)
+      ++nd;
     } else {
-      build_conv_args(e, r, ws, a[k]);
-      cfg[k] = r.cfg;
+      build_conv_args(e, r, ws, ca[nc]);
+      cc[nc] = r.cfg;
+      ++nc;
     }
   }
-  return dw ? dwpw_group_launch(cfg, a, n, e->batch, s) : conv_group_launch(cfg, a, n, e->batch, s);
+  if (nc && nd) return head_group_launch(cc, ca, nc, dc, da, nd, e->batch, s);
+  return nd ? dwpw_group_launch(dc, da, nd, e->batch, s) : conv_group_launch(cc, ca, nc, e->batch, s);
 }
 
 // op i or the group that starts at it; *consumed = ops covered (members of a group other than the first are never passed in)

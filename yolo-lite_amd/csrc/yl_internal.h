@@ -140,6 +140,8 @@ void conv_retile_for_group(ConvConfig* c, int NT, int batch, int Ho, int Wo);
 bool conv_group_compatible(const ConvConfig* cfg, const ConvArgs* a, int n);
 int conv_group_launch(const ConvConfig* cfg, const ConvArgs* args, int n, int batch, hipStream_t s);
 int dwpw_group_launch(const ConvConfig* cfg, const ConvArgs* args, int n, int batch, hipStream_t s);
+int head_group_launch(const ConvConfig* ccfg, const ConvArgs* cargs, int nc, const ConvConfig* dcfg, const ConvArgs* dargs, int nd,
+                      int batch, hipStream_t s);
 void dw_pack_mfma(const float* w, int C, std::vector<uint16_t>* out);
 int dwpw_tile_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s, int* handled);
 // conv_f8.hip: e4m3 x e4m3 -> fp32 on v_mfma_f32_16x16x128_f8f6f4

@@ -562,7 +562,8 @@ def _out_hw(h: int, w: int, k: int, s: int) -> Tuple[int, int]:
     return (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
 
 
-def group_detect_levels(ops: List[dict], det_prefix: str, nlv: int, keep_first_box_conv: bool = False) -> List[dict]:
+def group_detect_levels(ops: List[dict], det_prefix: str, nlv: int, keep_first_box_conv: bool = False,
+                        join_branches: bool = False) -> List[dict]:
     """The Detect head runs the same two branches on every level (head.py:59-62, `for i in range(self.nl)`); the 40x40
     and 20x20 copies cannot fill the chip by themselves.  Moves the head to the end of the program, the levels' copies of
     each conv side by side, and marks the copies that share one tiling as a GROUP (``yl_op.group``): the engine runs a
@@ -589,6 +590,16 @@ def group_detect_levels(ops: List[dict], det_prefix: str, nlv: int, keep_first_b
     if sorted(by_role) != [0, 1, 2, 3] or any(len(v) != nlv for v in by_role.values()):
         return ops
     rest = [o for o in ops if not o.get("name", "").startswith(det_prefix + ".")]
+    if join_branches and nlv == 3:
+        # The box and the class branch are independent too (head.py:61): their launches join as well (head_group_kernel).
+        # Launch 1 = the first box conv of every level + the class branch's first half of levels 0 and 1 (level 2's has
+        # 256 input channels: its LDS tile would be charged to every workgroup of the launch, so it runs alone, first);
+        # launch 2 = the second box conv + 1x1 of every level + the class branch's second half of every level.
+        for o in by_role[1] + by_role[0][:2]:
+            o["group"] = 1
+        for o in by_role[2] + by_role[3]:
+            o["group"] = 2
+        return rest + by_role[0][2:] + by_role[1] + by_role[0][:2] + by_role[2] + by_role[3]
     for r in (1, 2, 3):  # role 0 (first half of the class branch) differs in width per level: separate launches
         for lvl, o in enumerate(by_role[r]):
             if not (keep_first_box_conv and r == 1 and lvl == 0):  # (level 0's first box conv may keep its own kernel)
@@ -855,8 +866,8 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
             # 1.06 ms.  YL_GROUP_LEVELS=2 (default) leaves level 0's first box conv on its own kernel (conv3_reg_kernel);
             # =1 groups it too (one launch fewer, -1 % with 20 batches in flight); =0 separate launches.
             gl = os.environ.get("YL_GROUP_LEVELS", "2")
-            if gl in ("1", "2") and not fp8_scales:
-                ops[:] = group_detect_levels(ops, dp, nlv, keep_first_box_conv=gl == "2")
+            if gl in ("1", "2", "3") and not fp8_scales:
+                ops[:] = group_detect_levels(ops, dp, nlv, keep_first_box_conv=gl == "2", join_branches=gl == "3")
     if fuse_post and os.environ.get("YL_FUSE_UP", "1") != "0":
         ops[:] = fuse_upsample_into_convs(ops)
     if fuse_post and os.environ.get("YL_FUSE_STEM", "1") != "0":
