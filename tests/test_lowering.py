@@ -160,3 +160,47 @@ def test_fp8_pass_structure(scale, with_1x1, monkeypatch):
         assert n8 == len(cands) and n8 >= (19 if scale == "n" else 70)
         assert sum(o["kind"] == OP_CONV and o["out"].dtype == FP8 for o in p8.ops) >= (6 if scale == "n" else 30)
     assert p8.ws_bytes > p.ws_bytes
+
+
+def test_detect_levels_are_grouped_at_the_end_of_the_program():
+    """nn/lower.py::group_detect_levels: the head moves behind the neck, the levels' copies of a conv stand side by side
+    and carry one yl_op.group id; every op still reads tensors that an earlier op (or the input) wrote."""
+    import os
+
+    from yololite_amd.nn import arch
+    from yololite_amd.nn.lower import lower
+    from yololite_amd.nn.synth import synth_state_dict
+
+    specs, _ = arch.parse_model(arch.yolo11_dict("n"))
+    sd = synth_state_dict("n", 0)
+    for mode, groups in (("2", {1: 2, 2: 3, 3: 3}), ("1", {1: 3, 2: 3, 3: 3}), ("3", {1: 5, 2: 6}), ("0", {})):
+        os.environ["YL_GROUP_LEVELS"] = mode
+        try:
+            p = lower(specs, sd, 2, 128, 128)
+        finally:
+            os.environ.pop("YL_GROUP_LEVELS", None)
+        names = [o["name"] for o in p.ops]
+        head = [i for i, n in enumerate(names) if n.startswith("model.23.")]
+        assert len(head) == 12
+        if mode != "0":
+            assert head == list(range(len(names) - 12, len(names)))  # the whole head is the tail of the program
+        seen = {}
+        for o in p.ops:
+            g = o.get("group", 0)
+            if g:
+                seen[g] = seen.get(g, 0) + 1
+        assert seen == groups, (mode, seen)
+        # members of a group are consecutive
+        for g in seen:
+            idx = [i for i, o in enumerate(p.ops) if o.get("group", 0) == g]
+            assert idx == list(range(idx[0], idx[0] + len(idx)))
+        # dataflow of the moved ops: a head op's input planes were written by an earlier op
+        written = set()
+        for o in p.ops:
+            if o["name"].startswith("model.23."):
+                v = o["inp"]
+                for c in range(v.coff // 8, (v.coff + v.C) // 8):
+                    assert (v.offset, c) in written, (mode, o["name"])
+            v = o["out"]
+            for c in range(v.coff // 8, (v.coff + v.C + 7) // 8):
+                written.add((v.offset, c))
