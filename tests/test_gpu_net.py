@@ -360,6 +360,35 @@ def test_slots_in_flight_on_two_streams(gpu_device, golden):
     assert int(ref[0][1].sum()) > 0
 
 
+@pytest.mark.parametrize("h,w,b,nslots", [(128, 160, 4, 20), (640, 640, 8, 20)])
+def test_twenty_batches_in_flight(gpu_device, h, w, b, nslots):
+    """bench.py's configuration: 20 batches in flight on 20 HIP streams, one workspace slot / graph / NMS scratch each.
+    Every slot sees a DIFFERENT input in every round; each result must equal the one-at-a-time result bit for bit."""
+    sd = synth_state_dict("n", 4, cls_bias=[-3.0, -3.0, -3.0], cls_gain=6.0)
+    eng = _engine("n", sd, b, h, w, gpu_device)
+    g = torch.Generator().manual_seed(h + nslots)
+    rounds = 3
+    xs = [[torch.randint(0, 256, (b, 3, h, w), generator=g, dtype=torch.uint8).to(gpu_device) for _ in range(nslots)]
+          for _ in range(rounds)]
+    ref = [[tuple(t.clone() for t in eng.detect(x, 0.25, 0.7, graph=False)) for x in row] for row in xs]
+    bufs = [torch.empty_like(xs[0][0]) for _ in range(nslots)]  # a slot's graph bakes its input pointer
+    streams = [torch.cuda.Stream(device=gpu_device) for _ in range(nslots)]
+    torch.cuda.synchronize()
+    for r in range(rounds):
+        got = []
+        for j in range(nslots):
+            with torch.cuda.stream(streams[j]):
+                bufs[j].copy_(xs[r][j], non_blocking=True)
+                o, c = eng.detect(bufs[j], 0.25, 0.7, graph=True, slot=j)
+                got.append((o.clone(), c.clone()))  # (engine-owned outputs of a slot are overwritten by its next step)
+        torch.cuda.synchronize()
+        for j in range(nslots):
+            assert torch.equal(got[j][1], ref[r][j][1]), (r, j)
+            for i, n in enumerate(ref[r][j][1].tolist()):
+                assert torch.equal(got[j][0][i, :n], ref[r][j][0][i, :n]), (r, j, i)
+    assert sum(int(c.sum()) for row in ref for _, c in row) > 0
+
+
 @pytest.mark.parametrize("conf,kw", [(0.001, {}), (0.001, dict(agnostic=True)), (0.25, dict(classes=[3, 17])),
                                      (0.05, dict(max_det=50))])
 def test_nms_multi_label_vs_oracle(gpu_device, conf, kw):
