@@ -173,7 +173,7 @@ def test_detect_levels_are_grouped_at_the_end_of_the_program():
 
     specs, _ = arch.parse_model(arch.yolo11_dict("n"))
     sd = synth_state_dict("n", 0)
-    for mode, groups in (("2", {1: 2, 2: 3, 3: 3}), ("1", {1: 3, 2: 3, 3: 3}), ("3", {1: 5, 2: 6}), ("0", {})):
+    for mode, groups in (("2", {1: 2, 2: 3, 3: 3}), ("1", {1: 3, 2: 3, 3: 3}), ("3", {1: 5, 2: 6}), ("4", {1: 5, 2: 3, 3: 3}), ("0", {})):
         os.environ["YL_GROUP_LEVELS"] = mode
         try:
             p = lower(specs, sd, 2, 128, 128)

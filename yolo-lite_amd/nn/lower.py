@@ -563,7 +563,7 @@ def _out_hw(h: int, w: int, k: int, s: int) -> Tuple[int, int]:
 
 
 def group_detect_levels(ops: List[dict], det_prefix: str, nlv: int, keep_first_box_conv: bool = False,
-                        join_branches: bool = False) -> List[dict]:
+                        join_branches: bool = False, join_first_only: bool = False) -> List[dict]:
     """The Detect head runs the same two branches on every level (head.py:59-62, `for i in range(self.nl)`); the 40x40
     and 20x20 copies cannot fill the chip by themselves.  Moves the head to the end of the program, the levels' copies of
     each conv side by side, and marks the copies that share one tiling as a GROUP (``yl_op.group``): the engine runs a
@@ -597,8 +597,14 @@ def group_detect_levels(ops: List[dict], det_prefix: str, nlv: int, keep_first_b
         # launch 2 = the second box conv + 1x1 of every level + the class branch's second half of every level.
         for o in by_role[1] + by_role[0][:2]:
             o["group"] = 1
-        for o in by_role[2] + by_role[3]:
-            o["group"] = 2
+        if join_first_only:  # (the second halves each fill the chip by themselves: separate group launches)
+            for o in by_role[2]:
+                o["group"] = 2
+            for o in by_role[3]:
+                o["group"] = 3
+        else:
+            for o in by_role[2] + by_role[3]:
+                o["group"] = 2
         return rest + by_role[0][2:] + by_role[1] + by_role[0][:2] + by_role[2] + by_role[3]
     for r in (1, 2, 3):  # role 0 (first half of the class branch) differs in width per level: separate launches
         for lvl, o in enumerate(by_role[r]):
@@ -866,8 +872,9 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
             # 1.06 ms.  YL_GROUP_LEVELS=2 (default) leaves level 0's first box conv on its own kernel (conv3_reg_kernel);
             # =1 groups it too (one launch fewer, -1 % with 20 batches in flight); =0 separate launches.
             gl = os.environ.get("YL_GROUP_LEVELS", "2")
-            if gl in ("1", "2", "3") and not fp8_scales:
-                ops[:] = group_detect_levels(ops, dp, nlv, keep_first_box_conv=gl == "2", join_branches=gl == "3")
+            if gl in ("1", "2", "3", "4") and not fp8_scales:
+                ops[:] = group_detect_levels(ops, dp, nlv, keep_first_box_conv=gl == "2", join_branches=gl in ("3", "4"),
+                                             join_first_only=gl == "4")
     if fuse_post and os.environ.get("YL_FUSE_UP", "1") != "0":
         ops[:] = fuse_upsample_into_convs(ops)
     if fuse_post and os.environ.get("YL_FUSE_STEM", "1") != "0":
