@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define YL_ABI_VERSION 13
+#define YL_ABI_VERSION 14
 
 /* element types */
 enum { YL_BF16 = 0, YL_F32 = 1, YL_F16 = 2, YL_U8 = 3, YL_FP8 = 4 /* OCP e4m3 */ };
@@ -209,6 +209,10 @@ int yl_stream_destroy(void* stream);
  * of the unit it ran on (512 x uint32 on the device, zeroed by the caller). */
 int yl_xcc_census(unsigned* hist_device, int n_workgroups, void* stream);
 int yl_engine_num_ops(const yl_engine* e);
+/* 1 when yl_engine_detect_graph at this confidence threshold runs the NMS candidate pre-filter (first stage of
+ * yl_decode_nms) in the epilogue of the launches that write the Detect levels' class logits: one launch fewer and the
+ * class planes are never re-read; 0 when it stays a launch of its own (conf < 0.05, unfused class branch, YL_FUSE_PREFILTER=0). */
+int yl_engine_prefilter_fused(const yl_engine* e, float conf_thres);
 /* Algorithmic work of op i: flops (2*MAC), bytes read+written once; name is a static string. */
 int yl_engine_op_info(const yl_engine* e, int i, double* flops, double* bytes, const char** kernel_name);
 

@@ -535,6 +535,53 @@ def test_level_group_launches_are_bit_identical(gpu_device, monkeypatch, h, w, m
         assert torch.equal(a, b)
 
 
+def test_prefilter_in_the_class_launch_epilogue_is_bit_identical(gpu_device):
+    """The NMS candidate pre-filter in the epilogue of the launches that write the class logits (ConvArgs::pf_*, default)
+    against the separate pre-filter kernel (YL_FUSE_PREFILTER=0, read once per process -> a child process): same detections,
+    bit for bit, eager and graph, at a low and at the default confidence threshold."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+
+    code = """
+import sys, torch
+sys.path.insert(0, %r)
+from yololite_amd import _lib
+_lib.apply_runtime_knobs()
+from yololite_amd.nn import arch
+from yololite_amd.nn.engine import HipEngine
+from yololite_amd.nn.synth import synth_state_dict
+specs, _ = arch.parse_model(arch.yolo11_dict("n"))
+sd = synth_state_dict("n", 9, cls_bias=[-3.0, -3.0, -3.0], cls_gain=6.0)
+dev = torch.device("cuda:0")
+eng = HipEngine.from_model(specs, sd, 2, 320, 448, dev)
+x = torch.randint(0, 256, (2, 3, 320, 448), generator=torch.Generator().manual_seed(11), dtype=torch.uint8).to(dev)
+res = {}
+for conf in (0.25, 0.06):
+    for graph in (False, True):
+        o, c = eng.detect(x, conf, 0.7, max_det=300, graph=graph)
+        res[(conf, graph)] = (o.cpu().clone(), c.cpu().clone())
+torch.save(res, sys.argv[1])
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    with tempfile.TemporaryDirectory() as td:
+        for flag in ("1", "0"):
+            f = os.path.join(td, f"r{flag}.pt")
+            env = dict(os.environ, YL_FUSE_PREFILTER=flag)
+            subprocess.run([sys.executable, "-c", code, f], check=True, env=env, timeout=300)
+            outs.append(torch.load(f))
+    fused, plain = outs
+    assert fused.keys() == plain.keys()
+    total = 0
+    for k in fused:
+        assert torch.equal(fused[k][1], plain[k][1]), k
+        for i, n in enumerate(fused[k][1].tolist()):
+            assert torch.equal(fused[k][0][i, :n], plain[k][0][i, :n]), (k, i)
+            total += n
+    assert total > 0
+
+
 def test_lds_staged_class_branch_is_bit_identical(gpu_device, monkeypatch):
     """csrc/dwpw.hip (opt-in YL_DWPW_TILE=1: class-branch input staged through an LDS ring, persistent workgroups over
     guarded positions) against the default dwpw_kernel: same MFMA order, so every bit of the level maps."""

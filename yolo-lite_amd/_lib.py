@@ -111,7 +111,7 @@ EXPORTS = (
     "yl_engine_prepare_workspace", "yl_engine_forward", "yl_engine_forward_graph", "yl_engine_profile", "yl_engine_num_ops",
     "yl_engine_op_info", "yl_engine_detect_graph", "yl_detect_decode", "yl_nms_workspace_bytes", "yl_nms", "yl_decode_nms",
     "yl_preprocess_u8", "yl_letterbox_u8", "yl_nms_ml_workspace_bytes", "yl_nms_ml", "yl_engine_profile_detect",
-    "yl_graph_branch_probe", "yl_stream_create_masked", "yl_stream_destroy", "yl_xcc_census",
+    "yl_graph_branch_probe", "yl_engine_prefilter_fused", "yl_stream_create_masked", "yl_stream_destroy", "yl_xcc_census",
 )
 
 
@@ -226,7 +226,9 @@ def lib() -> C.CDLL:
     L.yl_stream_destroy.argtypes = [vp]
     L.yl_xcc_census.restype = i32
     L.yl_xcc_census.argtypes = [vp, i32, vp]
-    if L.yl_abi_version() != 13:
+    L.yl_engine_prefilter_fused.restype = i32
+    L.yl_engine_prefilter_fused.argtypes = [vp, f32]
+    if L.yl_abi_version() != 14:
         raise RuntimeError("libyl_amd.so ABI version mismatch; rebuild it")
     _lib = L
     return L

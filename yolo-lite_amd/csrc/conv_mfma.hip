@@ -388,6 +388,42 @@ __device__ __forceinline__ void dwpw_body(const ConvArgs& a, int block) {
     ConvArgs a2 = a;
     a2.Cout = a.post_cout;
     a2.act = a.post_act;
+    if (a.pf_count && a.post_act) {  // (the activation once, here, under ONE branch: a select per value would compute 40 SiLUs for nothing)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[mt][nt][r] = silu_f(acc[mt][nt][r]);
+      a2.act = 0;
+    }
+    if (a.pf_count) {
+      // The NMS candidate pre-filter (nms.hip decode_candidates_sparse_kernel) in the epilogue of the launch that
+      // produces a Detect level's class logits: an anchor whose best STORED logit (bf16, as the level map holds it)
+      // could clear the confidence threshold is appended to its image's sub-list -- the 43 MB of class planes per batch
+      // are then never re-read for it.  Lane (n, g) holds 4 rows of each of the MT channel tiles of pixel n.
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        float m = -__builtin_huge_valf();
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            if (chan_in_block(MT, mt, g, r) < a.post_cout) m = fmaxf(m, (float)(__bf16)acc[mt][nt][r]);
+          }
+        m = fmaxf(m, __shfl_xor(m, 16));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        const int gp = patch * (16 * NT) + nt * 16 + n;  // pixel index over the batch (patch_setup's order)
+        if (g == 0 && gp < a.npix && m > a.pf_logit_lo) {
+          const int hw = a.Ho * a.Wo;
+          const int b = gp / hw;
+          const int an = a.pf_anchor0 + (gp - b * hw);
+          const int sub = b * PF_NSUB + ((an >> 6) & (PF_NSUB - 1));
+          const int slot = atomicAdd(&a.pf_count[sub], 1);
+          if (slot < a.pf_sub_cap) a.pf_list[(long long)sub * a.pf_sub_cap + slot] = an;
+        }
+      }
+    }
     epilogue<MT, NT>(a2, rout, rres, 0, g, Pp.opix, acc);
   }
 }

@@ -297,7 +297,7 @@ int dwpw_tile_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s
   const int enable = getenv("YL_DWPW_TILE") ? atoi(getenv("YL_DWPW_TILE")) : 0;
   static const int want_nt = getenv("YL_DWPW_TILE_NT") ? atoi(getenv("YL_DWPW_TILE_NT")) : 0;
   static const int wg_per_cu = getenv("YL_DWPW_TILE_WPC") ? atoi(getenv("YL_DWPW_TILE_WPC")) : 0;
-  if (!enable || a.in_w1 != a.Wo + 1 || a.in_w1 != a.out_w1 || a.in_img != a.out_img || a.in_g0 != a.out_g0 || a.out_f32)
+  if (!enable || a.pf_count || a.in_w1 != a.Wo + 1 || a.in_w1 != a.out_w1 || a.in_img != a.out_img || a.in_g0 != a.out_g0 || a.out_f32)
     return 0;
   const long long nq = (long long)batch * a.in_img;
   if (nq >= (1LL << 27)) return 0;

@@ -34,6 +34,7 @@ struct OpRec {
   float* d_bias3 = nullptr;
   float* d_alpha = nullptr;  // fp8 conv: in_scale * filter scale per output channel
   bool f8 = false;
+  int cls_level = -1;  // fused depthwise + pointwise + 1x1 that writes the class logits of this Detect level (else -1)
   int group_n = 0;  // group launch (yl_op.group): 2 or 3 on the first member, -1 on the others (run with it), 0 = on its own
   double flops = 0, bytes = 0;
   const char* name = "";
@@ -45,6 +46,7 @@ using namespace yl;
 
 struct yl_engine {
   int batch = 0, in_h = 0, in_w = 0, nc = 0, A = 0;
+  bool cls_tails = false;  // every Detect level's class logits come out of a fused dwpw + 1x1 launch: the NMS pre-filter can ride in its epilogue
   int64_t ws_bytes = 0;
   yl_view input_view{};
   std::vector<yl_level> levels;
@@ -551,6 +553,22 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
     if (o.lane > e->max_lane) e->max_lane = o.lane;
     e->ops.push_back(r);
   }
+  // ---- which launches produce the class logits of the Detect levels (the NMS candidate pre-filter rides in their epilogue)
+  {
+    size_t found = 0;
+    for (OpRec& r : e->ops) {
+      if (r.op.kind != YL_OP_DWCONV3 || !r.d_wpk || !r.d_wpk3 || r.op.lane != 0 || r.op.out.coff != 0) continue;
+      for (size_t li = 0; li < e->levels.size(); ++li) {
+        const yl_level& L = e->levels[li];
+        if (r.op.out.offset == L.offset_cls && r.op.out.C == L.nc8 && r.op.out.H == L.H && r.op.out.W == L.W) {
+          r.cls_level = (int)li;
+          ++found;
+        }
+      }
+    }
+    static const int fuse_pf = getenv("YL_FUSE_PREFILTER") ? atoi(getenv("YL_FUSE_PREFILTER")) : 1;
+    e->cls_tails = fuse_pf && !e->levels.empty() && found == e->levels.size() && e->max_lane == 0;
+  }
   // ---- group launches: runs of consecutive ops with the same yl_op.group > 0 (the lowering puts the Detect levels'
   // copies of one conv side by side): up to three convs, then up to three depthwise + pointwise launches, each kind of
   // one tiling.  A run that does not fit simply stays ungrouped.
@@ -674,9 +692,19 @@ static void build_conv_args(const yl_engine* e, const OpRec& r, char* ws, ConvAr
 }
 
 // ConvArgs + tiling of a fused depthwise + pointwise [+ 1x1] YL_OP_DWCONV3 for workspace `ws`
-static void build_dwpw_args(const yl_engine* e, const OpRec& r, char* ws, ConvArgs& a, ConvConfig& cfg) {
+static void build_dwpw_args(const yl_engine* e, const OpRec& r, char* ws, ConvArgs& a, ConvConfig& cfg,
+                            const PrefilterSink* sink = nullptr) {
   const yl_op& o = r.op;
   const int B = e->batch;
+  if (sink && r.cls_level >= 0) {  // this launch writes a level's class logits: pre-filter them on the way out
+    int a0 = 0;
+    for (int li = 0; li < r.cls_level; ++li) a0 += e->levels[li].H * e->levels[li].W;
+    a.pf_count = sink->pre_count;
+    a.pf_list = sink->pre_list;
+    a.pf_sub_cap = sink->sub_cap;
+    a.pf_logit_lo = sink->logit_lo;
+    a.pf_anchor0 = a0;
+  }
   const Geo gi = geo_of(B, o.in.H, o.in.W);
   a.in = pview(ws, o.in, B).base;
   a.in_plane = (unsigned)plane_bytes(gi);
@@ -713,7 +741,7 @@ static void build_dwpw_args(const yl_engine* e, const OpRec& r, char* ws, ConvAr
 }
 
 static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s, const void* input = nullptr,
-                  int in_dtype = 0) {
+                  int in_dtype = 0, const PrefilterSink* sink = nullptr) {
   const yl_op& o = r.op;
   const int B = e->batch;
   switch (o.kind) {
@@ -857,7 +885,7 @@ static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s, c
       if (r.d_wpk) {  // fused depthwise + pointwise
         ConvArgs a{};
         ConvConfig cfg;
-        build_dwpw_args(e, r, ws, a, cfg);
+        build_dwpw_args(e, r, ws, a, cfg, sink);
         return dwpw_launch(cfg, a, B, s);
       }
       DwArgs a{};
@@ -915,14 +943,14 @@ static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s, c
 // A group launch (yl_op.group): ops [i, i + n) are the same conv on the Detect levels (reference nn/modules/head.py:59-62)
 // and / or the independent branches of the head (head.py:61), one launch for all of them (conv_group_kernel /
 // dwpw_group_kernel / head_group_kernel).
-static int run_group(const yl_engine* e, size_t i, int n, char* ws, hipStream_t s) {
+static int run_group(const yl_engine* e, size_t i, int n, char* ws, hipStream_t s, const PrefilterSink* sink) {
   ConvArgs ca[3]{}, da[3]{};
   ConvConfig cc[3], dc[3];
   int nc = 0, nd = 0;
   for (int k = 0; k < n; ++k) {
     const OpRec& r = e->ops[i + k];
     if (r.op.kind == YL_OP_DWCONV3) {
-      build_dwpw_args(e, r, ws, da[nd], dc[nd]);
+      build_dwpw_args(e, r, ws, da[nd], dc[nd], sink);
       dc[nd].NT = r.cfg.NT;  // (the group's tiling: build_dwpw_args copies r.cfg, which already carries it)
       ++nd;
     } else {
@@ -936,14 +964,15 @@ static int run_group(const yl_engine* e, size_t i, int n, char* ws, hipStream_t 
 }
 
 // op i or the group that starts at it; *consumed = ops covered (members of a group other than the first are never passed in)
-static int run_at(const yl_engine* e, size_t i, char* ws, hipStream_t s, const void* input, int in_dtype, int* consumed) {
+static int run_at(const yl_engine* e, size_t i, char* ws, hipStream_t s, const void* input, int in_dtype, int* consumed,
+                  const PrefilterSink* sink = nullptr) {
   const OpRec& r = e->ops[i];
   if (r.group_n >= 2) {
     *consumed = r.group_n;
-    return run_group(e, i, r.group_n, ws, s);
+    return run_group(e, i, r.group_n, ws, s, sink);
   }
   *consumed = 1;
-  return run_op(e, r, ws, s, input, in_dtype);
+  return run_op(e, r, ws, s, input, in_dtype, sink);
 }
 
 static int run_convert(const yl_engine* e, const void* input, int in_dtype, char* ws, hipStream_t s) {
@@ -1003,8 +1032,17 @@ extern "C" int yl_engine_prepare_workspace(yl_engine* e, void* workspace, void* 
   return prepare_workspace(e, (char*)workspace, (hipStream_t)stream);
 }
 
+static int forward_impl(yl_engine* e, const void* input, int in_dtype, void* workspace, float* y, void* stream,
+                        const PrefilterSink* sink);
+
 extern "C" int yl_engine_forward(yl_engine* e, const void* input, int in_dtype, void* workspace, float* y,
                                  void* stream) {
+  return forward_impl(e, input, in_dtype, workspace, y, stream, nullptr);
+}
+
+// sink != nullptr: the launches that write the Detect levels' class logits also fill the NMS candidate lists
+static int forward_impl(yl_engine* e, const void* input, int in_dtype, void* workspace, float* y, void* stream,
+                        const PrefilterSink* sink) {
   if (!e || !input || !workspace) return fail(-1, "yl_engine_forward: null pointer");
   hipStream_t s = (hipStream_t)stream;
   char* ws = (char*)workspace;
@@ -1023,7 +1061,7 @@ extern "C" int yl_engine_forward(yl_engine* e, const void* input, int in_dtype, 
     const int lane = r.op.lane;
     if (lane == 0) {
       int consumed = 1;
-      if (int rc = run_at(e, oi, ws, s, input, in_dtype, &consumed)) return rc;
+      if (int rc = run_at(e, oi, ws, s, input, in_dtype, &consumed, sink)) return rc;
     } else {
       hipEvent_t ev = ss.events[nev++];
       YL_HIP(hipEventRecord(ev, s));
@@ -1083,9 +1121,18 @@ static int detect_eager(yl_engine* e, const void* input, int in_dtype, void* wor
                         float iou_thres, int max_det, int agnostic, const int32_t* classes, int n_classes,
                         int max_cand, float max_wh, const float* scale, float* out, int32_t* out_count, void* work,
                         void* stream) {
-  if (int rc = yl_engine_forward(e, input, in_dtype, workspace, nullptr, stream)) return rc;
-  return yl_decode_nms(workspace, e->levels.data(), (int)e->levels.size(), e->batch, e->nc, conf_thres, iou_thres,
-                       max_det, agnostic, classes, n_classes, max_cand, max_wh, scale, out, out_count, work, stream);
+  // The candidate pre-filter of yl_decode_nms rides in the epilogue of the launches that write the class logits
+  // (ConvArgs::pf_*) when every level has such a launch and the sparse decode path applies: the counters are zeroed up
+  // front, the network fills the lists, and the decode starts at its second stage.
+  PrefilterSink sink{};
+  int fused = 0;
+  if (e->cls_tails)
+    if (int rc = prefilter_sink_prepare(e->levels.data(), (int)e->levels.size(), e->batch, max_cand, conf_thres, work, stream, &sink,
+                                        &fused))
+      return rc;
+  if (int rc = forward_impl(e, input, in_dtype, workspace, nullptr, stream, fused ? &sink : nullptr)) return rc;
+  return decode_nms_stages(workspace, e->levels.data(), (int)e->levels.size(), e->batch, e->nc, conf_thres, iou_thres, max_det,
+                           agnostic, classes, n_classes, max_cand, max_wh, scale, out, out_count, work, stream, nullptr, fused);
 }
 
 extern "C" int yl_engine_detect_graph(yl_engine* e, const void* input, int in_dtype, void* workspace,
@@ -1129,6 +1176,12 @@ extern "C" int yl_engine_detect_graph(yl_engine* e, const void* input, int in_dt
 }
 
 extern "C" int yl_engine_num_ops(const yl_engine* e) { return e ? (int)e->ops.size() : -1; }
+
+// 1 when yl_engine_detect_graph at this confidence threshold runs the NMS candidate pre-filter inside the launches that
+// write the class logits (one launch fewer, the class planes are not re-read), 0 when it is a launch of its own
+extern "C" int yl_engine_prefilter_fused(const yl_engine* e, float conf_thres) {
+  return e && e->cls_tails && conf_thres >= 0.05f && conf_thres <= 1.f ? 1 : 0;
+}
 
 extern "C" int yl_engine_op_info(const yl_engine* e, int i, double* flops, double* bytes, const char** name) {
   if (!e || i < 0 || i >= (int)e->ops.size()) return fail(-1, "yl_engine_op_info: bad index");
@@ -1199,15 +1252,20 @@ extern "C" int yl_engine_profile_detect(yl_engine* e, const void* input, int in_
   const bool stem = e->ops[0].op.kind == YL_OP_STEM || e->ops[0].d_w0;
   for (int it = 0; it < iters && !rc; ++it) {
     if (!stem) rc = run_convert(e, input, in_dtype, ws, s);
+    PrefilterSink sink{};
+    int fused = 0;  // as detect_eager: the pre-filter in the class launches' epilogue (its stage then times ~0)
+    if (!rc && e->cls_tails)
+      rc = prefilter_sink_prepare(e->levels.data(), (int)e->levels.size(), e->batch, max_cand, conf_thres, work, stream, &sink, &fused);
     (void)hipEventRecord(ev[0], s);
     for (int i = 0; i < n && !rc; ++i) {
       int consumed = 1;
-      if (e->ops[i].group_n >= 0) rc = run_at(e, (size_t)i, ws, s, input, in_dtype, &consumed);  // (a group's time lands on its first member)
+      if (e->ops[i].group_n >= 0)  // (a group's time lands on its first member)
+        rc = run_at(e, (size_t)i, ws, s, input, in_dtype, &consumed, fused ? &sink : nullptr);
       (void)hipEventRecord(ev[i + 1], s);
     }
     if (!rc)
       rc = decode_nms_stages(workspace, e->levels.data(), (int)e->levels.size(), e->batch, e->nc, conf_thres, iou_thres,
-                             max_det, 0, nullptr, 0, max_cand, 7680.f, nullptr, out, out_count, work, stream, pv.data());
+                             max_det, 0, nullptr, 0, max_cand, 7680.f, nullptr, out, out_count, work, stream, pv.data(), fused);
     if (!rc && hipEventSynchronize(pv[5]) != hipSuccess) rc = fail(-2, "hipEventSynchronize failed");
     for (int i = 0; i < n && !rc; ++i) {
       float t = 0.f;

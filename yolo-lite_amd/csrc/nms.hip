@@ -15,7 +15,7 @@
 
 namespace yl {
 
-constexpr int NSUB = 16;
+constexpr int NSUB = PF_NSUB;
 
 struct NmsWs {
   int32_t* count;       // [B]
@@ -664,7 +664,7 @@ __global__ __launch_bounds__(256) void decode_exact_kernel(DecCandArgs a, NmsWs 
 int yl::decode_nms_stages(const void* workspace, const yl_level* levels, int n_levels, int batch, int nc,
                           float conf_thres, float iou_thres, int max_det, int agnostic, const int32_t* classes,
                           int n_classes, int max_cand, float max_wh, const float* scale, float* out,
-                          int32_t* out_count, void* work, void* stream, hipEvent_t* ev) {
+                          int32_t* out_count, void* work, void* stream, hipEvent_t* ev, int prefiltered) {
   if (!workspace || !levels || !out || !out_count || !work) return fail(-1, "yl_decode_nms: null pointer");
   if (batch <= 0 || nc <= 0 || n_levels <= 0 || n_levels > 8 || max_det <= 0 || max_cand <= 0)
     return fail(-1, "yl_decode_nms: bad sizes");
@@ -697,12 +697,13 @@ int yl::decode_nms_stages(const void* workspace, const yl_level* levels, int n_l
   a.logit_lo = conf_thres >= 1.f ? __builtin_huge_valf()
                                  : (float)(std::log((double)conf_thres / (1.0 - (double)conf_thres)) - 0.05);
   hipStream_t s = (hipStream_t)stream;
+  if (prefiltered && !sparse) return fail(-1, "yl_decode_nms: the fused pre-filter exists for the sparse decode path only");
   if (ev) (void)hipEventRecord(ev[0], s);
-  YL_HIP(hipMemsetAsync(w.count, 0, 4 * (size_t)batch * (1 + NSUB), s));  // count + pre_count
+  if (!prefiltered) YL_HIP(hipMemsetAsync(w.count, 0, 4 * (size_t)batch * (1 + NSUB), s));  // count + pre_count
   const dim3 grid((unsigned)((A + 255) / 256), batch);
   if (sparse) {
     w.fused = 1;
-    hipLaunchKernelGGL(decode_candidates_sparse_kernel, grid, dim3(256), 0, s, a, w, levels[0].nc8);
+    if (!prefiltered) hipLaunchKernelGGL(decode_candidates_sparse_kernel, grid, dim3(256), 0, s, a, w, levels[0].nc8);
     if (ev) (void)hipEventRecord(ev[1], s);
     hipLaunchKernelGGL(decode_exact_kernel, dim3(DX_BLOCKS, NSUB, batch), dim3(256), 0, s, a, w);
   } else {
@@ -717,6 +718,25 @@ int yl::decode_nms_stages(const void* workspace, const yl_level* levels, int n_l
   hipLaunchKernelGGL(nms_scan_kernel, dim3(batch), dim3(64), 0, s, max_det, scale, out, out_count, w);
   if (ev) (void)hipEventRecord(ev[5], s);
   YL_HIP(hipGetLastError());
+  return 0;
+}
+
+int yl::prefilter_sink_prepare(const yl_level* levels, int n_levels, int batch, int max_cand, float conf_thres, void* work,
+                               void* stream, PrefilterSink* sink, int* active) {
+  *active = 0;
+  if (!levels || !work || !sink || n_levels <= 0 || n_levels > 8 || batch <= 0 || max_cand <= 0) return fail(-1, "prefilter sink: bad arguments");
+  if (!(conf_thres >= 0.05f) || !(conf_thres <= 1.f)) return 0;  // dense decode path (or an invalid threshold: yl_decode_nms reports it)
+  int A = 0;
+  for (int i = 0; i < n_levels; ++i) A += levels[i].H * levels[i].W;
+  NmsWs w;
+  nms_layout(batch, A, max_cand, (char*)work, &w);
+  YL_HIP(hipMemsetAsync(w.count, 0, 4 * (size_t)batch * (1 + NSUB), (hipStream_t)stream));  // count + pre_count
+  sink->pre_count = w.pre_count;
+  sink->pre_list = w.pre_list;
+  sink->sub_cap = w.sub_cap;
+  // the same bound as decode_nms_stages: logit(conf) - 0.05
+  sink->logit_lo = conf_thres >= 1.f ? __builtin_huge_valf() : (float)(std::log((double)conf_thres / (1.0 - (double)conf_thres)) - 0.05);
+  *active = 1;
   return 0;
 }
 

@@ -77,6 +77,12 @@ struct ConvArgs {
   int post_cout, post_act;
   int ksteps2, cg2;    // dwpw_kernel with a further 1x1 (wpk2): its k-steps and input planes
   const void* dw_wpk;  // dwpw_kernel: depthwise taps as block-diagonal MFMA A fragments (dw_pack_mfma), bias [C], SiLU flag
+  // dwpw_kernel with a fused tail that writes a Detect level's class logits: the NMS candidate pre-filter in its epilogue
+  // (PrefilterSink; pf_count == nullptr: off).  pf_anchor0 = index of the level's first anchor.
+  int32_t* pf_count;
+  int32_t* pf_list;
+  int pf_sub_cap, pf_anchor0;
+  float pf_logit_lo;
   const float* dw_b;
   int dw_act;
   const float* bias;   // padded to ncb*MT*16
@@ -292,11 +298,25 @@ __device__ __forceinline__ void level_load8(const PView& v, int c8, int pix, flo
   for (int j = 0; j < 8; ++j) o[j] = (float)t[j];
 }
 int decode_launch(const DecodeLevel* lv, int n_levels, int batch, int nc, int A, float* y, hipStream_t s);
-// nms.hip: yl_decode_nms with optional stage events (profiling)
+// nms.hip: where the class branch's last launch appends the anchors whose best class logit could clear the threshold
+// (the first stage of yl_decode_nms, decode_candidates_sparse_kernel, done in the producing kernel's epilogue)
+constexpr int PF_NSUB = 16;  // sub-lists per image (= nms.hip NSUB)
+struct PrefilterSink {
+  int32_t* pre_count;  // [B][PF_NSUB], zeroed by prefilter_sink_prepare
+  int32_t* pre_list;   // [B][PF_NSUB][sub_cap]
+  int sub_cap;
+  float logit_lo;
+};
+// Lays out `work` as yl_decode_nms does, zeroes the counters on `stream` and fills `sink`; *active = 0 when the dense
+// decode path applies (conf < 0.05): nothing is done then and the caller must not skip the pre-filter.
+int prefilter_sink_prepare(const yl_level* levels, int n_levels, int batch, int max_cand, float conf_thres, void* work,
+                           void* stream, PrefilterSink* sink, int* active);
+// nms.hip: yl_decode_nms with optional stage events (profiling); prefiltered != 0: the counters were zeroed and the
+// candidate lists filled by the network's own launches (prefilter_sink_prepare + ConvArgs::pf_*)
 int decode_nms_stages(const void* workspace, const yl_level* levels, int n_levels, int batch, int nc, float conf_thres,
                       float iou_thres, int max_det, int agnostic, const int32_t* classes, int n_classes, int max_cand,
                       float max_wh, const float* scale, float* out, int32_t* out_count, void* work, void* stream,
-                      hipEvent_t* ev);
+                      hipEvent_t* ev, int prefiltered = 0);
 
 // nrows contiguous rows of `n` floats -> LDS rows of `pitch` words starting at column c0 (256 threads).
 // Loads are issued in batches of 8 per thread before the first LDS write: one memory round trip per

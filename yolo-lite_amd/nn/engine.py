@@ -361,7 +361,10 @@ class HipEngine:
                 ("nms.sort", "nms_sort", ncand * 16 * 2),
                 ("nms.mask", "nms_mask", ncand * 16 + ncand * 8),
                 ("nms.scan", "nms_scan", ncand * 16 + float(self.batch * max_det * 24))]
+        fused_pf = bool(self.lib.yl_engine_prefilter_fused(self._h, float(conf)))
         for (name, kern, b), t in zip(post, mp):
+            if fused_pf and name == "detect.prefilter":
+                continue  # runs in the epilogue of the launches that write the class logits: not a launch of its own
             rows.append(dict(name=name, kernel=kern, ms=t, flops=0.0, bytes=b))
         return rows
 
