@@ -22,6 +22,11 @@
 //  kernel, a persistent weight-stationary kernel -- are recorded in DESIGN.md.)
 #include "conv_common.h"
 
+#ifndef YL_RING_NT4
+#define YL_RING_NT4 2  // k-steps of activation fragments in flight per wave at 64 pixels per wave (16-byte loads per lane: 4 x this).
+                       // 4 (209-254 registers, still two waves per SIMD): layer 3 58.8 -> 54.8 us, but 48.3-48.9 k against
+                       // 49.2-49.7 k images/s with 20 batches in flight
+#endif
 #ifndef YL_CONV_WPE
 #define YL_CONV_WPE 2  // conv_kernel: at least this many waves per SIMD (caps its registers at 512 / YL_CONV_WPE).  3 (the
                        // 64-pixel tiles then spill from 177-203 to 168 registers): 47.0-47.1 k images/s against 48.2-48.9 k
@@ -91,7 +96,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, int block) {
       __builtin_amdgcn_make_buffer_rsrc((void*)a.res, (short)0, a.res ? a.res_bytes : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rin2 =
       __builtin_amdgcn_make_buffer_rsrc((void*)a.in2, (short)0, UP ? a.in2_bytes : 0, 0x00020000);
-  constexpr int D = NT >= 4 ? 2 : (NT == 2 ? 4 : 8);
+  constexpr int D = NT >= 4 ? YL_RING_NT4 : (NT == 2 ? 4 : 8);
   bf16x8 xr[D][NT];
   Patch<NT> P;
   const unsigned lane_off = UNIFORM ? (unsigned)g * a.in_plane : 0u;
