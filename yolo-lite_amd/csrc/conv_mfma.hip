@@ -814,18 +814,19 @@ int dwpw_group_launch(const ConvConfig* cfg0, const ConvArgs* args, int n, int b
   if (n < 2 || n > 3) return fail(-3, "dwpw group: two or three members");
   ConvGroup G{};
   size_t lds = 0;
-  int grid = 0;
+  int grid = 0, nt0 = 0;
   for (int i = 0; i < n; ++i) {
     ConvConfig cfg = cfg0[i];
     G.a[i] = args[i];
     size_t l = 0;
-    if (int rc = dwpw_prepare(cfg, G.a[i], batch, &l)) return rc;
-    if (cfg.MT != 5 || cfg.NT != cfg0[0].NT || !G.a[i].wpk2) return fail(-3, "dwpw group: members need one tiling and a fused tail");
+    if (int rc = dwpw_prepare(cfg, G.a[i], batch, &l)) return rc;  // (may retile: YL_DWPW_NT)
+    if (i == 0) nt0 = cfg.NT;
+    if (cfg.MT != 5 || cfg.NT != nt0 || !G.a[i].wpk2) return fail(-3, "dwpw group: members need one tiling and a fused tail");
     G.nb[i] = G.a[i].nblocks;
     grid += G.nb[i];
     lds = l > lds ? l : lds;
   }
-  return cfg0[0].NT == 1 ? launch_dwpw_group<5, 1>(G, grid, lds, s) : launch_dwpw_group<5, 2>(G, grid, lds, s);
+  return nt0 == 1 ? launch_dwpw_group<5, 1>(G, grid, lds, s) : launch_dwpw_group<5, 2>(G, grid, lds, s);
 }
 
 // conv_kernel's arguments derived from the tiling (everything conv_launch used to fill in place)
@@ -960,19 +961,21 @@ int head_group_launch(const ConvConfig* ccfg, const ConvArgs* cargs, int nc, con
     lds = ccfg[i].lds_bytes > lds ? ccfg[i].lds_bytes : lds;
   }
   const bool post = ccfg[0].post != 0;
+  int ntd0 = 0;
   for (int i = 0; i < nd; ++i) {
     ConvConfig cfg = dcfg0[i];
     GD.a[i] = dargs[i];
     size_t l = 0;
     if (int rc = dwpw_prepare(cfg, GD.a[i], batch, &l)) return rc;
-    if (cfg.MT != 5 || cfg.NT != dcfg0[0].NT || (GD.a[i].wpk2 != nullptr) != post)
+    if (i == 0) ntd0 = cfg.NT;
+    if (cfg.MT != 5 || cfg.NT != ntd0 || (GD.a[i].wpk2 != nullptr) != post)
       return fail(-3, "head group: the depthwise members need one tiling, with a fused tail exactly when the convs carry a fused 1x1");
     GD.nb[i] = GD.a[i].nblocks;
     grid += GD.nb[i];
     lds = l > lds ? l : lds;
   }
   grid += n_conv;
-  const int ntc = ccfg[0].NT, ntd = dcfg0[0].NT;
+  const int ntc = ccfg[0].NT, ntd = ntd0;
   if (ccfg[0].ntaps != 9 || ccfg[0].MT != 4 || !ccfg[0].uniform || (ntc != 2 && ntc != 4) || (ntd != 1 && ntd != 2))
     return fail(-3, "head group: unsupported tiling");
 #define YL_HG(NTC, NTD) \
