@@ -613,6 +613,10 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
           const OpRec& big = e->ops[largest(i, i + nc)];
           int NT = big.cfg.reg ? big.cfg.reg : big.cfg.NT;
           if (NT != 2 && NT != 4) NT = 2;
+          // a launch shared with depthwise members: 32 pixels per wave (151-156 registers, three waves per SIMD -- the
+          // depthwise bodies run at the conv's register budget; 64 pixels: 187-220 registers, -1.3 % end to end)
+          static const int head_nt = getenv("YL_HEAD_GROUP_NT") ? atoi(getenv("YL_HEAD_GROUP_NT")) : 2;
+          if (nd && (head_nt == 2 || head_nt == 4)) NT = head_nt;
           for (size_t k = i; k < i + nc; ++k) conv_retile_for_group(&e->ops[k].cfg, NT, batch, e->ops[k].op.out.H, e->ops[k].op.out.W);
         }
         if (nd) {
