@@ -31,6 +31,80 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
+
+def _argv_gpus(argv):
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            return int(argv[i + 1])
+        if a.startswith("--gpus="):
+            return int(a.split("=", 1)[1])
+    return 1
+
+
+def self_launch(n):
+    """``python bench.py --gpus N`` with no external launcher: this process -- which has made no GPU call and never
+    will -- starts N fresh children of this file, one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as
+    ``torch.distributed.run`` would set them; never an exec from a process that touched the GPU), relays rank 0's single
+    JSON line on stdout, every rank's stderr on stderr (prefixed), and exits non-zero -- ending the other ranks --
+    as soon as any rank fails."""
+    import socket
+    import subprocess
+    import threading
+
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    lines = []
+
+    def pump(r, stream, is_out):
+        for ln in stream:
+            if is_out and r == 0:
+                lines.append(ln)
+            else:
+                sys.stderr.write(f"[rank {r}] {ln}")
+                sys.stderr.flush()
+
+    th = [threading.Thread(target=pump, args=(r, s_, o), daemon=True)
+          for r, p_ in enumerate(procs) for s_, o in ((p_.stdout, True), (p_.stderr, False))]
+    for t in th:
+        t.start()
+    rc, left = 0, set(range(n))
+    while left:
+        for r in sorted(left):
+            c = procs[r].poll()
+            if c is None:
+                continue
+            left.discard(r)
+            if c != 0 and rc == 0:
+                rc = c if c > 0 else 1
+                sys.stderr.write(f"[bench] rank {r} of {n} exited with status {c}: stopping the other ranks\n")
+                for q in left:
+                    procs[q].terminate()
+        time.sleep(0.05)
+    for t in th:
+        t.join(timeout=5)
+    record = [ln for ln in lines if ln.lstrip().startswith("{")]
+    if rc == 0 and len(record) != 1:
+        sys.stderr.write(f"[bench] expected ONE JSON line from rank 0, got {len(record)}\n")
+        rc = 1
+    if rc == 0:
+        sys.stdout.write(record[0])
+        sys.stdout.flush()
+    else:
+        sys.stderr.write(f"[bench] --gpus {n} FAILED (status {rc}); no record printed\n")
+    raise SystemExit(rc)
+
+
+if __name__ == "__main__" and "WORLD_SIZE" not in os.environ and _argv_gpus(sys.argv) > 1:
+    self_launch(_argv_gpus(sys.argv))
+
 from yololite_amd import _lib as yl_lib  # noqa: E402
 
 # bench.py is its own launcher: the HIP runtime knobs the hot path depends on are set here, explicitly, before the
@@ -268,9 +342,11 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py ...")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE=1: run `python bench.py --gpus N` without WORLD_SIZE (it starts its own "
+                         "ranks) or under torch.distributed.run with --nproc-per-node N")
+    ndev = torch.cuda.device_count()  # does not initialise the GPU
+    if ndev < max(1, local_rank + 1) or not torch.cuda.is_available():
+        raise SystemExit(f"bench.py rank {rank} of {world} needs GPU {local_rank} and sees {ndev} GPU(s): the HIP path has no CPU fallback")
     dev = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(dev)
     import torch.distributed as dist
@@ -356,6 +432,17 @@ def main():
         sync_all()
         dt = time.perf_counter() - t0
         ndet = cnt.float().mean().item()
+        if args.steps < 5 * S:
+            # a run this short is one or two rounds of the S batches in flight -- mostly fill and drain; the same loop over
+            # 500 steps is reported beside it (value itself stays the K steps the caller asked for)
+            n_long = 500
+            step_no[0] = 0
+            tl = time.perf_counter()
+            for k in range(n_long):
+                hot_path(xs[k % S])
+            sync_all()
+            extra["value_steady_state"] = round(B * n_long / (time.perf_counter() - tl), 1)
+            extra["value_steady_state_note"] = f"the same pipelined loop over {n_long} steps (fill and drain of the {S} batches in flight ~1 %)"
         # SURVEY 8(d)'s literal definition: one batch at a time, stream-synchronised once per iteration
         n_sync = max(20, min(200, args.steps))
         st0 = streams[0]
@@ -432,6 +519,28 @@ def main():
         dist.all_reduce(tr, op=dist.ReduceOp.MAX)
         extra["value_resident"] = round(world * B * args.steps / float(tr.item()), 1)
         extra["value_resident_note"] = "same steps on shards resident in each rank's HBM, no per-step collective (replicas)"
+        # like-for-like N = 1 point inside the SAME process group and runtime configuration: rank 0 alone runs the resident
+        # steps while its peers idle at the barrier -- what one GPU of this job does without neighbours and collectives
+        step_no[0] = 0
+        t3 = time.perf_counter()
+        if rank == 0:
+            for k in range(args.steps):
+                hot_path(shards[k % S])
+            torch.cuda.synchronize(dev)
+        dt_alone = time.perf_counter() - t3
+        sync_all()
+        extra["value_rank0_alone"] = round(B * args.steps / dt_alone, 1)
+        extra["value_rank0_alone_note"] = ("rank 0 running the resident steps while the other ranks idle: the N = 1-equivalent rate "
+                                           "under this job's own queue / stream configuration (scaling efficiency like for like = "
+                                           "value / (n_gpus * value_rank0_alone))")
+        # self-diagnosis: did RCCL really connect every rank, and which rank is the slow one (the root pays the scatter)
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        extra["rccl_ranks"] = int(ones.item())
+        mine = torch.tensor([dt * 1e3 / args.steps, dt_res * 1e3 / args.steps], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        extra["per_rank_ms"] = {"sharded": [round(float(t[0]), 4) for t in allr], "resident": [round(float(t[1]), 4) for t in allr]}
         extra["scatter_bytes_per_step"] = (world - 1) * B * 3 * H * W
         extra["gather_bytes_per_step"] = (world - 1) * record_floats(B, max_det) * 4
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)

@@ -196,8 +196,9 @@ int yl_engine_profile_detect(yl_engine* e, const void* input, int in_dtype, void
                              void* stream, int iters, float* ms_ops, float* ms_post);
 /* Runtime self-check: replays a captured graph of two parallel branches, each one wave spinning for spin_us
  * microseconds.  *ms_graph = best of three replays; *concurrent = 1 when the branches overlapped (time < 1.5 x
- * spin_us), 0 when the HIP runtime serialised them (then the hot path's class-branch lane gives no overlap either;
- * see _lib.apply_runtime_knobs for the environment the runtime needs). */
+ * spin_us), 0 when the HIP runtime serialised them.  Diagnostic only: the hot path's graph is captured as ONE chain
+ * (side lanes are opt-in, YL_SIDE_LANES=1) and overlaps batches through several streams, one hardware queue each
+ * (GPU_MAX_HW_QUEUES, see _lib.RUNTIME_KNOBS). */
 int yl_graph_branch_probe(void* stream, int spin_us, float* ms_graph, int* concurrent);
 /* A HIP stream confined to the compute units of `cu_mask` (hipExtStreamCreateWithCUMask).  Measured on MI355X
  * (`yl_xcc_census`, tools/xcd_probe.py): word c of the 8-word mask selects CU c of every (shader engine, XCD) pair; the

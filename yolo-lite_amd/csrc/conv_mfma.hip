@@ -871,9 +871,14 @@ static int conv_prepare(const ConvConfig& cfg, ConvArgs& a, int batch) {
 
 // `a` arrives with pointers, plane sizes, geometry, Cin/Cout/stride/act/out_f32 filled in.
 int conv_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s) {
-  if (cfg.pair && !a.out8) return conv3_pair_launch(cfg, a, batch, s);
-  if (cfg.reg && !a.out8) return conv3_reg_launch(cfg, a, batch, s);
-  if (cfg.tile && a.act) return conv3_tile_launch(cfg, a, batch, s);  // (a conv without SiLU stays on conv_kernel)
+  // The register / pair / tile variants are chosen from (Cin, Cout, k, stride, post) alone and take only a plain stride-1
+  // conv between bf16 planar tensors of ONE geometry; they share conv_kernel's filter packing, so any other view (fp32 or
+  // pitched output, an upsampled second input, an e4m3 copy) simply runs on conv_kernel.
+  const bool plain = a.stride == 1 && !a.out_f32 && !a.in2 && !a.wpk2 && !a.out8 && a.in_w1 == a.out_w1 &&
+                     a.in_img == a.out_img && a.in_g0 == a.out_g0 && a.in_w1 == a.Wo + 1;
+  if (cfg.pair && plain) return conv3_pair_launch(cfg, a, batch, s);
+  if (cfg.reg && plain) return conv3_reg_launch(cfg, a, batch, s);
+  if (cfg.tile && a.act && plain) return conv3_tile_launch(cfg, a, batch, s);  // (a conv without SiLU stays on conv_kernel)
   if (int rc = conv_prepare(cfg, a, batch)) return rc;
   return cfg.ntaps == 9 ? launch_m<3>(cfg, a, s) : launch_m<1>(cfg, a, s);
 }

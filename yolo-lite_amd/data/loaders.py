@@ -35,76 +35,70 @@ def _pil_to_bgr(im: Image.Image) -> np.ndarray:
     return np.ascontiguousarray(np.asarray(im)[:, :, ::-1])
 
 
-class LoadTensor:
-    """BCHW float tensor in [0, 1], H and W divisible by 32 (reference loaders.py:480-548)."""
+class _SingleBatch:
+    """A source that is ONE batch: iterating it yields a single ``(paths, images, info)`` triple.
 
-    def __init__(self, im0) -> None:
-        self.im0 = self._single_check(im0)
-        self.bs = self.im0.shape[0]
-        self.mode = "image"
-        self.paths = [getattr(im, "filename", f"image{i}.jpg") for i, im in enumerate(im0)]
+    The two in-memory sources of the reference (``LoadTensor`` loaders.py:480-548, ``LoadPilAndNumpy`` loaders.py:415-477)
+    are both this: everything is decided in the constructor, the iterator only hands the batch over once.  Subclasses
+    fill ``im0`` (the batch), ``paths`` and ``bs`` through ``_accept``."""
 
-    @staticmethod
-    def _single_check(im, stride=32):
-        s = (f"WARNING torch.Tensor inputs should be BCHW i.e. shape(1, 3, 640, 640) "
-             f"divisible by stride {stride}. Input shape{tuple(im.shape)} is incompatible.")
-        if len(im.shape) != 4:
-            if len(im.shape) != 3:
-                raise ValueError(s)
-            LOGGER.warning(s)
-            im = im.unsqueeze(0)
-        if im.shape[2] % stride or im.shape[3] % stride:
-            raise ValueError(s)
-        if im.dtype.is_floating_point and im.max() > 1.0 + torch.finfo(im.dtype).eps:
-            LOGGER.warning(f"WARNING torch.Tensor inputs should be normalized 0.0-1.0 but max value is {im.max()}. "
-                           f"Dividing input by 255.")
-            im = im.float() / 255.0
-        return im
+    mode = "image"
+
+    def _accept(self, batch, paths):
+        self.im0, self.paths, self.bs = batch, list(paths), len(paths)
 
     def __iter__(self):
-        self.count = 0
-        return self
-
-    def __next__(self):
-        if self.count == 1:
-            raise StopIteration
-        self.count += 1
-        return self.paths, self.im0, [""] * self.bs
+        yield self.paths, self.im0, [""] * self.bs
 
     def __len__(self):
         return self.bs
 
 
-class LoadPilAndNumpy:
-    """PIL images / BGR HWC numpy arrays as one batch (reference loaders.py:415-477)."""
+def _names(items):
+    # a PIL image opened from a file carries its file name; everything else is called image<i>.jpg (loaders.py:433,509)
+    return [getattr(it, "filename", "") or f"image{i}.jpg" for i, it in enumerate(items)]
+
+
+class LoadTensor(_SingleBatch):
+    """BCHW tensor, H and W multiples of 32; float tensors above 1 are taken to be 0..255 (reference loaders.py:511-532)."""
+
+    STRIDE = 32
+
+    def __init__(self, im0) -> None:
+        t = self.checked(im0)
+        self._accept(t, _names(t))
+
+    @classmethod
+    def checked(cls, t: torch.Tensor) -> torch.Tensor:
+        complaint = (f"WARNING torch.Tensor inputs should be BCHW i.e. shape(1, 3, 640, 640) divisible by stride {cls.STRIDE}. "
+                     f"Input shape{tuple(t.shape)} is incompatible.")
+        if t.dim() == 3:  # a single CHW image is tolerated with a warning
+            LOGGER.warning(complaint)
+            t = t[None]
+        if t.dim() != 4 or any(int(n) % cls.STRIDE for n in t.shape[2:]):
+            raise ValueError(complaint)
+        if t.dtype.is_floating_point:
+            top = float(t.max())
+            if top > 1.0 + torch.finfo(t.dtype).eps:
+                LOGGER.warning(f"WARNING torch.Tensor inputs should be normalized 0.0-1.0 but max value is {top}. Dividing input by 255.")
+                t = t.float() / 255.0
+        return t
+
+
+class LoadPilAndNumpy(_SingleBatch):
+    """One PIL image / BGR HWC array, or a list of them, as one batch of BGR arrays (reference loaders.py:426-461)."""
 
     def __init__(self, im0):
-        if not isinstance(im0, list):
-            im0 = [im0]
-        self.paths = [getattr(im, "filename", "") or f"image{i}.jpg" for i, im in enumerate(im0)]
-        self.im0 = [self._single_check(im) for im in im0]
-        self.mode = "image"
-        self.bs = len(self.im0)
+        items = im0 if isinstance(im0, list) else [im0]
+        self._accept([self.as_bgr(it) for it in items], _names(items))
 
     @staticmethod
-    def _single_check(im):
-        assert isinstance(im, (Image.Image, np.ndarray)), f"Expected PIL/np.ndarray image type, but got {type(im)}"
-        if isinstance(im, Image.Image):
-            im = _pil_to_bgr(im)
-        return im
-
-    def __len__(self):
-        return len(self.im0)
-
-    def __iter__(self):
-        self.count = 0
-        return self
-
-    def __next__(self):
-        if self.count == 1:
-            raise StopIteration
-        self.count += 1
-        return self.paths, self.im0, [""] * self.bs
+    def as_bgr(it) -> np.ndarray:
+        if isinstance(it, Image.Image):
+            return _pil_to_bgr(it)
+        if isinstance(it, np.ndarray):
+            return it
+        raise AssertionError(f"Expected PIL/np.ndarray image type, but got {type(it)}")
 
 
 class LoadImagesAndVideos:

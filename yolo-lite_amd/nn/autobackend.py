@@ -39,13 +39,16 @@ class AutoBackend:
                  fuse=True, verbose=True):
         from .. import _lib
 
-        if os.environ.get("YL_AMD_NO_KNOBS", "0") != "1":
-            st = _lib.apply_runtime_knobs()  # explicit, logged; effective only before the HIP runtime initialises
-            if verbose and not st["before_hip_init"]:
-                from ..utils import LOGGER
+        # The one runtime knob left is GPU_MAX_HW_QUEUES, and it only matters to callers that keep SEVERAL batches in
+        # flight on several streams (one hardware queue per stream: _lib.RUNTIME_KNOBS).  predict() runs one stream, so
+        # AutoBackend does not set it; a caller that pipelines exports it (or calls _lib.apply_runtime_knobs()) before
+        # its first GPU call.  All that is done here is to say so when such a request came too late to take effect.
+        st = _lib.runtime_knob_status()
+        if verbose and st["applied"] and st["before_hip_init"] is False:
+            from ..utils import LOGGER
 
-                LOGGER.warning("HIP was initialised before yololite_amd's runtime knobs were set (%s): the graph's class "
-                               "branch may run serialised; call yololite_amd._lib.apply_runtime_knobs() first", st)
+            LOGGER.warning("GPU_MAX_HW_QUEUES was set after the HIP runtime had initialised (%s): streams beyond the runtime's "
+                           "default of four hardware queues will share queues; set it before the first GPU call", st)
         w = weights[0] if isinstance(weights, (list, tuple)) else weights
         if isinstance(w, DetectionModel):
             model = w

@@ -329,7 +329,7 @@ class HipEngine:
         self._check_input(im)
         n = self.lib.yl_engine_num_ops(self._h)
         ms, mp = (C.c_float * n)(), (C.c_float * 5)()
-        max_cand = self.anchors
+        max_cand = min(30000, self.anchors)  # as detect(): the reference's max_nms cap (ops.py:254-255)
         sl = self._slot(0)
         wk = ("work", max_cand)
         if wk not in sl["static"]:

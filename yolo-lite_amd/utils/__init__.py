@@ -24,24 +24,27 @@ def _make_logger(name="yololite_amd"):
 LOGGER = _make_logger()
 
 
-class SimpleClass:
-    """Readable ``str``/``repr`` for result containers (reference utils/__init__.py:236-289)."""
+def _public_state(obj):
+    """(name, value) of every public, non-callable attribute of ``obj`` (properties included), sorted by name."""
+    for name in dir(obj):
+        if name[:1] == "_":
+            continue
+        value = getattr(obj, name)
+        if not callable(value):
+            yield name, value
 
-    def __str__(self):
-        attr = []
-        for a in dir(self):
-            v = getattr(self, a)
-            if not callable(v) and not a.startswith("_"):
-                if isinstance(v, SimpleClass):
-                    s = f"{a}: {v.__module__}.{v.__class__.__name__} object"
-                else:
-                    s = f"{a}: {repr(v)}"
-                attr.append(s)
-        return f"{self.__module__}.{self.__class__.__name__} object with attributes:\n\n" + "\n".join(attr)
+
+class SimpleClass:
+    """Base of the result / metric containers: printing one lists its public state, and a misspelt attribute names the
+    class and shows its documentation instead of a bare ``AttributeError`` (reference utils/__init__.py:236-289)."""
 
     def __repr__(self):
-        return self.__str__()
+        kind = f"{type(self).__module__}.{type(self).__name__}"
+        rows = [f"{n}: {type(v).__module__}.{type(v).__name__} object" if isinstance(v, SimpleClass) else f"{n}: {v!r}"
+                for n, v in _public_state(self)]
+        return "\n".join([f"{kind} object with attributes:", "", *rows])
 
-    def __getattr__(self, attr):
-        name = self.__class__.__name__
-        raise AttributeError(f"'{name}' object has no attribute '{attr}'. See valid attributes below.\n{self.__doc__}")
+    __str__ = __repr__
+
+    def __getattr__(self, attr):  # only reached when normal lookup failed
+        raise AttributeError(f"'{type(self).__name__}' object has no attribute '{attr}'. See valid attributes below.\n{self.__doc__}")
