@@ -206,6 +206,35 @@ def test_out8_copy_from_the_producers_epilogue(gpu_device, producer):
     assert torch.equal(m2.read(y2), yb)
 
 
+def test_out8_copy_from_the_gemm_kernel_is_conv_kernels(gpu_device, monkeypatch):
+    """conv_gemm_kernel writes the e4m3 copy too (wide 1x1 convs in front of fp8 3x3 convs): bf16 output and copy
+    bit-identical to conv_kernel's on the same operands."""
+    from hip_util import OP_CONV
+
+    B, Cin, Cout, H, W, c0, n8, sc8 = 3, 256, 384, 12, 20, 192, 192, 0.03
+    g = torch.Generator().manual_seed(11)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.3
+    x = bf16_round(torch.randn(B, Cin, H, W, generator=g))
+    got = {}
+    for mode, kern in (("1", "conv1x1_gemm_mfma"), ("0", "conv1x1_mfma")):
+        monkeypatch.setenv("YL_CONV_GEMM", mode)
+        monkeypatch.setenv("YL_CONV_GEMM_BLOCKS", "1")
+        m = Mini(B, gpu_device)
+        xin = m.buf(H, W, Cin, BF16)
+        m.fill(xin, x)
+        y = m.buf(H, W, Cout, BF16)
+        y8 = m.buf(H, W, n8, FP8)
+        m.op(kind=OP_CONV, name="p", k=1, stride=1, act=1, inp=xin, out=y, in_scale=0.05, out8=y8, out8_c0=c0, out8_scale=sc8,
+             weight=np.ascontiguousarray(w.numpy()), bias=np.ascontiguousarray(b.numpy()))
+        m.run()
+        assert m.eng.op_kernel(0) == kern, m.eng.op_kernel(0)
+        got[mode] = (m.read(y), m.read(y8))
+    assert torch.equal(got["1"][0], got["0"][0]) and torch.equal(got["1"][1], got["0"][1])
+    want = e4m3_round(got["1"][0][:, c0: c0 + n8] * (torch.tensor(1.0) / torch.tensor(sc8)))
+    assert (got["1"][1] == want).float().mean().item() > 0.97
+
+
 def test_predict_api_in_fp8_mode(gpu_device, monkeypatch):
     """YL_DTYPE=fp8: YOLOLite.predict builds the e4m3 engine, calibrated on the first batch, behind the unchanged API."""
     from yololite_amd import YOLOLite

@@ -66,6 +66,43 @@ def test_conv_eight_tiles_per_wave(gpu_device, monkeypatch, cin, cout, k, s, h, 
     test_conv_vs_torch(gpu_device, cin, cout, k, s, h, w, True, res)
 
 
+GEMM_CASES = [
+    # cin, cout, h, w, act, res
+    (128, 128, 20, 20, True, False),    # 128-channel blocks, four K-slices (= the ring's depth)
+    (160, 128, 20, 12, True, False),    # five K-slices
+    (256, 256, 12, 20, True, True),     # residual
+    (192, 192, 16, 24, True, False),    # 192-channel blocks (YOLO11x widths)
+    (384, 768, 9, 13, False, False),    # qkv of C2PSA: no activation, four blocks of 192
+    (768, 384, 11, 13, True, True),     # 24 K-slices, ragged map
+    (512, 256, 12, 12, True, False),    # SPPF cv2: 256-channel blocks, ring of three 32-channel slices
+    (128, 384, 33, 17, False, True),
+]
+
+
+@pytest.mark.parametrize("cin,cout,h,w,act,res", GEMM_CASES)
+def test_conv_gemm_vs_torch_and_conv_kernel(gpu_device, monkeypatch, cin, cout, h, w, act, res):
+    """conv_gemm_kernel (wide 1x1 convs: both operands staged through LDS by LDS-DMA, 128 / 192 x 128 macro tiles) against
+    torch, and BIT-identical to conv_kernel on the same operands (same packed filters' k order, same accumulation chain)."""
+    g = torch.Generator().manual_seed(cin * 7 + cout + h)
+    B = 5
+    x = _rand(g, B, cin, h, w)
+    wt = _rand(g, cout, cin, 1, 1, scale=1.0 / math.sqrt(cin))
+    b = torch.randn(cout, generator=g) * 0.5
+    ref = F.conv2d(x, wt, b)
+    if act:
+        ref = F.silu(ref)
+    r = None
+    if res:
+        r = _rand(g, *ref.shape)
+        ref = ref + r
+    monkeypatch.setenv("YL_CONV_GEMM_BLOCKS", "1")
+    got = run_conv(gpu_device, x, wt, b, 1, 1, act, r, expect_kernel="conv1x1_gemm_mfma")
+    _assert_close_bf16(got, ref, f"gemm conv {cin}->{cout}")
+    monkeypatch.setenv("YL_CONV_GEMM", "0")
+    direct = run_conv(gpu_device, x, wt, b, 1, 1, act, r, expect_kernel="conv1x1_mfma")
+    assert torch.equal(got, direct), f"gemm vs conv_kernel differ: max {float((got - direct).abs().max())}"
+
+
 @pytest.mark.parametrize("cin,cout,k,s,h,w,act,res", CONV_CASES)
 def test_conv_vs_torch(gpu_device, cin, cout, k, s, h, w, act, res):
     g = torch.Generator().manual_seed(cin * 1000 + cout * 10 + k + s)

@@ -1,0 +1,23 @@
+#!/bin/bash
+# conv_gemm_kernel against conv_kernel on wide 1x1 layers (YOLO11x at 1280x1280 batch 8, YOLO11s at 640x640 batch 64).
+# Usage: tools/gemm_bench.sh > gpurun_out/gemm_bench.log
+cd "$(dirname "$0")/.."
+run() {  # B cin cout H W
+  for gm in 0 1 ${EXTRA_GEMM_MODES}; do
+    echo -n "B=$1 gemm=$gm  "
+    YL_MICRO_B=$1 YL_CONV_GEMM=$gm python tools/conv_micro.py $2 $3 1 1 $4 $5 | tail -1
+  done
+}
+run 8 192 192 320 320
+run 8 384 384 320 320
+run 8 384 384 160 160
+run 8 768 768 160 160
+run 8 768 768 80 80
+run 8 1536 768 80 80
+run 8 768 384 40 40
+run 8 1536 768 40 40
+run 64 128 128 80 80
+run 64 256 256 40 40
+run 64 384 256 40 40
+run 64 512 512 20 20
+run 64 768 512 20 20

@@ -1,0 +1,291 @@
+// GEMM-class 1x1 Conv + (folded BN) bias + SiLU [+ residual] for WIDE layers (Cin, Cout >= 128) on gfx950.
+//
+// Same arithmetic as conv_kernel (reference nn/modules/conv.py:35-53 with the BN folded per utils/torch_utils.py:182-209;
+// the residual is the PSABlock / Bottleneck shortcut of nn/modules/block.py:341-343, 947-950): same packed filters
+// (conv_pack_weights order, rows permuted so that a lane's two adjacent tiles are one 16-byte pixel), same k order, same
+// fp32 accumulation chain from the bias, same epilogue -- results are bit-identical to conv_kernel's.  What changes is the
+// operand delivery.  conv_kernel gives every wave a 64 x 64 tile whose activation fragments it fetches itself from the planes
+// (texture path) while its four waves share one filter slab: on wide layers the activations are re-read once per 64 output
+// channels and the step is bound by the texture addresser + LDS together.  Here a workgroup owns a
+// macro tile of BM = 128, 192 or 256 output channels x BN = 128 pixels and BOTH operands are staged through LDS by LDS-DMA
+// (buffer_load_dwordx4 ... lds, 1 KiB per wave instruction, no VGPRs, no ds_write) through a ring of 3-4 K-slices of 32
+// channels; the four waves form a 2 x 2 grid of (BM / 2) x 64 register tiles, so every activation byte is fetched once per
+// BM channels and shared by two waves, every filter byte once per workgroup and shared by two waves.
+//
+//   * A 1x1 stride-1 conv is pointwise in the guarded planar layout (yl_internal.h): output position q depends on input
+//     position q only, so the pixel tile is simply 128 CONSECUTIVE guarded positions [q0, q0 + 128) of every plane -- guard
+//     pixels included; they are computed and not stored (1-10 % of the positions).  A B stage is 4 planes x 2 KiB, each
+//     plane's run two contiguous 1 KiB DMA pieces; in LDS it is [plane][128 px][16 B] = MFMA B-fragment order, read with
+//     conflict-free ds_read_b128 (16 consecutive lanes = 256 contiguous bytes; the four k-groups of a fragment sit 2 KiB
+//     apart = the same banks, but in different lane groups of the instruction).
+//   * An A stage is one k-step x BM / 16 tiles of the packed filter = one contiguous run of BM / 16 KiB in memory, copied
+//     linearly; fragment order, conflict-free.
+//   * One raw s_barrier per K-slice: a COUNTED wait for my own DMA pieces of slice i (the pieces of the NS - 2 younger
+//     slices stay in flight), barrier (everybody's pieces landed, everybody has finished reading slice i - 1), refill that
+//     buffer with slice i + NS - 1, compute slice i.  Why a ring and why big tiles (measured, first version: 128 x 128,
+//     two buffers of 64 channels, 570-860 TFLOP/s): under load an L2 -> LDS piece takes ~2500 cycles to land, so the rate
+//     is (bytes in flight per CU) / latency -- 64 KiB in flight gave ~22 B/clk per CU -- and only fewer bytes per flop
+//     (bigger macro tiles) or more bytes in flight (deeper rings) raise it.
+//     Two workgroups share a CU (64-80 KiB of LDS, <= 256 registers), so one's epilogue (SiLU is quarter rate) and
+//     barrier waits run under the other's MFMAs.
+#include "conv_common.h"
+
+namespace yl {
+
+typedef __attribute__((address_space(3))) void lds_void_g;
+
+constexpr int GM_BN = 128;                 // pixels per workgroup
+constexpr int GM_BSTEP = 4 * GM_BN * 16;   // bytes of the B operand of one k-step (4 planes)
+
+// Ring shapes (two workgroups per CU): 128 / 192-channel blocks take two K-slices of 64 channels (64 / 80 KiB; fewer barriers:
+// 384 -> 384 @320x320 x 8: 664 against 597 TFLOP/s with four slices of 32), 256-channel blocks three slices of 32 (72 KiB).
+// A K that is not a multiple of 64 takes four slices of 32.
+constexpr int gm_ks(int MTW, bool even) { return (MTW == 8 || !even) ? 1 : 2; }
+constexpr int gm_ns(int MTW, bool even) { return MTW == 8 ? 3 : (even ? 2 : 4); }
+size_t conv_gemm_lds_bytes(int MTW, bool even) {
+  return (size_t)gm_ns(MTW, even) * gm_ks(MTW, even) * ((size_t)MTW * 2048 + GM_BSTEP);
+}
+
+// MTW: 16-channel tiles per wave (4, 6 or 8): BM = 2 * MTW * 16 output channels per workgroup.
+// KS: k-steps (32 channels) per ring slice; NS: slices in the ring.
+// O8: the epilogue also stores the e4m3 copy of channels [out8_c0, out8_c0 + out8_n) (yl_op.out8, fp8 programs), as conv_kernel's does
+template <int MTW, int KS, int NS, bool RES, bool ACT, bool O8>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_gemm_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
+  constexpr int MT = 2 * MTW;                  // tiles per workgroup
+  constexpr int ASTAGE = KS * MT * 1024;       // bytes of one A slice (KS k-steps of the packed filter block: contiguous)
+  constexpr int BSTAGE = KS * GM_BSTEP;
+  constexpr int STAGE = ASTAGE + BSTAGE;
+  constexpr int NPA = ASTAGE / 1024, NPB = BSTAGE / 1024, NP = NPA + NPB;  // 1 KiB DMA pieces per slice
+  constexpr int PW = NP / 4;                   // pieces per wave and slice
+  static_assert(NP % 4 == 0 && NPA % 4 == 0, "pieces divide over four waves");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, n = lane & 15;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int bid = xcd_remap(blockIdx.x, a.nblocks);
+  const int cb = bid % a.ncb;
+  const int q0 = (bid / a.ncb) * GM_BN;        // first guarded position of the tile (from the start of the plane)
+  const int nk = a.ksteps / KS;                // K-slices
+
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, (short)0, a.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, (short)0, (unsigned)a.ncb * a.ksteps * MT * 1024u, 0x00020000);
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const unsigned wbase = (unsigned)cb * a.ksteps * MT * 1024u;
+
+  // K-slice `it` -> ring buffer `buf`: pieces wave, wave + 4, ... (wave-uniform addressing, the lane adds its 16 bytes).
+  // Slices past the end (ring refills of the last iterations) fall outside both descriptors: the pieces move nothing but
+  // still count in vmcnt, so the counted wait below is the same in every iteration.
+  auto issue = [&](int it, int buf) __attribute__((always_inline)) {
+    const unsigned sbase = (unsigned)buf * STAGE;
+    const unsigned past = it < nk ? 0u : OOB_K;
+#pragma unroll
+    for (int i = 0; i < PW; ++i) {
+      const int j = wave + 4 * i;  // scalar
+      if (i < NPA / 4) {  // (NPA is a multiple of 4: the choice is made at compile time)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_g*)(gsm + sbase + (unsigned)j * 1024u), 16,
+                                                 (int)(lane16 + wbase + (unsigned)it * ASTAGE + (unsigned)j * 1024u + past), 0, 0, 0);
+      } else {
+        const int jb = j - NPA, p = jb >> 1, h = jb & 1;   // plane of the slice (4 per k-step), half of the pixel run
+        const unsigned src = (unsigned)(it * (4 * KS) + p) * a.in_plane + (unsigned)(q0 + h * 64) * 16u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void_g*)(gsm + sbase + ASTAGE + (unsigned)jb * 1024u), 16,
+                                                 (int)(lane16 + src + past), 0, 0, 0);
+      }
+    }
+  };
+#pragma unroll
+  for (int st = 0; st < NS - 1; ++st) issue(st, st);
+
+  // per-lane bias of its 4 rows of every tile (the accumulators start from it, as in conv_kernel)
+  f32x4 acc[MTW][4];
+  {
+    const float* bp = a.bias + cb * MT * 16;
+#pragma unroll
+    for (int mt = 0; mt < MTW; ++mt) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(bp + chan_in_block(MT, wm * MTW + mt, g, 0));
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) acc[mt][nt] = bv;
+    }
+  }
+  // output positions of this lane's four pixel tiles: valid pixels only (guards are computed, never stored)
+  unsigned po[4];
+  {
+    const int r0 = q0 + wn * 64 - a.in_g0;                      // position of the wave's first pixel relative to pixel (0, 0, 0)
+    const int b0 = __builtin_amdgcn_readfirstlane((r0 < 0 ? 0 : r0) / a.in_img);  // wave-uniform: one division per tile
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int loc = nt * 16 + n;
+      const int r = r0 + loc;                                    // < 0: in front of the first image (guard row)
+      int t = r - b0 * a.in_img;                                 // position inside image b0, < img + 64 (host: img >= 128)
+      const int wrap = t >= a.in_img;
+      const int b = b0 + wrap;
+      t -= wrap * a.in_img;
+      const int y = (int)__umulhi((unsigned)(t < 0 ? 0 : t), a.magic_w1);
+      const int x = t - y * a.in_w1;
+      const bool ok = r >= 0 && b < a.t_B && y < a.t_H && x < a.t_W;
+      po[nt] = ok ? (unsigned)(q0 + wn * 64 + loc) * 16u : OOB_LANE;
+    }
+  }
+
+  const unsigned char* const abase = gsm + ((unsigned)(wm * MTW) * 64u + (unsigned)lane) * 16u;
+  const unsigned char* const bbase = gsm + ASTAGE + ((unsigned)g * GM_BN + (unsigned)(wn * 64 + n)) * 16u;
+  int buf = 0;
+  for (int it = 0; it < nk; ++it) {
+    // slices it + 1 .. it + NS - 2 may stay in flight; mine of slice `it` have landed, and behind the barrier everybody's;
+    // everybody has also left slice it - 1, whose buffer the next refill overwrites
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PW) : "memory");
+    __builtin_amdgcn_s_barrier();
+    const int nb = buf == 0 ? NS - 1 : buf - 1;  // (it - 1) mod NS = (it + NS - 1) mod NS
+    issue(it + NS - 1, nb);
+    const unsigned char* ab = abase + buf * STAGE;
+    const unsigned char* bb = bbase + buf * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      bf16x8 wa[MTW], xb[4];
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) xb[nt] = *reinterpret_cast<const bf16x8*>(bb + ks * GM_BSTEP + nt * 256);
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt) wa[mt] = *reinterpret_cast<const bf16x8*>(ab + (ks * MT + mt) * 1024);
+#pragma unroll
+      for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[mt], xb[nt], acc[mt][nt], 0, 0, 0);
+    }
+    buf = buf == NS - 1 ? 0 : buf + 1;
+  }
+
+  // epilogue: SiLU, residual, one 16-byte pixel of plane (pair, g) per lane and pixel tile
+  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.out, (short)0, a.out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rres =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.res, (short)0, RES ? a.res_bytes : 0, 0x00020000);
+  const unsigned plane0 = (unsigned)(cb * (MT * 2) + wm * (MTW * 2) + g);  // first output plane of this lane (8 channels per plane)
+#pragma unroll
+  for (int p = 0; p < MTW / 2; ++p) {
+    bf16x8 rv[4];
+    if constexpr (RES) {
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+        rv[nt] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                                                rres, po[nt] == OOB_LANE ? OOB_LANE : (plane0 + 4u * p) * a.res_plane + po[nt], 0, 0));
+    }
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[2 * p][nt][r];
+        v[4 + r] = acc[2 * p + 1][nt][r];
+      }
+      if constexpr (ACT) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = silu_f(v[r]);
+      }
+      if constexpr (RES) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += (float)rv[nt][r];
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(
+          u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])}, rout,
+          po[nt] == OOB_LANE ? OOB_LANE : (plane0 + 4u * p) * a.out_plane + po[nt], 0, 0);
+      if constexpr (O8) {  // this lane's 8 channels = half a 16-byte pixel of an e4m3 plane (16 channels)
+        const __amdgpu_buffer_rsrc_t r8 = __builtin_amdgcn_make_buffer_rsrc(a.out8, (short)0, a.out8_bytes, 0x00020000);
+        const int c = (int)(plane0 + 4u * p) * 8 - a.out8_c0;
+        const bool ok8 = po[nt] != OOB_LANE && c >= 0 && c < a.out8_n;
+        const float is = a.out8_inv_scale;
+        const unsigned v8 = ok8 ? (unsigned)(c >> 4) * a.out8_plane + po[nt] + (unsigned)(c & 15) : OOB_LANE;
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack_f8x4(v[0] * is, v[1] * is, v[2] * is, v[3] * is),
+                                                    pack_f8x4(v[4] * is, v[5] * is, v[6] * is, v[7] * is)},
+                                              r8, v8, 0, 0);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ host
+static unsigned gm_magic(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull / (unsigned)d) + 1ull); }
+
+// Takes over a conv_choose()n tiling when the layer is wide enough: sets cfg->gemm (tiles per wave) and the packing it needs.
+// Only plain bf16 1x1 stride-1 convs (no fused follow-up, second input or fp32 output: the caller checks the views).
+void conv_gemm_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, ConvConfig* c) {
+  c->gemm = 0;
+  // (read at every engine build, not cached: the tests switch them)
+  const int enable = getenv("YL_CONV_GEMM") ? atoi(getenv("YL_CONV_GEMM")) : 1;
+  const int min_c = getenv("YL_CONV_GEMM_MINC") ? atoi(getenv("YL_CONV_GEMM_MINC")) : 128;
+  const int min_blocks = getenv("YL_CONV_GEMM_BLOCKS") ? atoi(getenv("YL_CONV_GEMM_BLOCKS")) : 384;
+  if (!enable || k != 1 || stride != 1 || Cin % 32 || Cin < min_c || Cout < min_c) return;
+  int MTW = 0;
+  if (Cout % 256 == 0) MTW = 8;
+  else if (Cout % 192 == 0) MTW = 6;
+  else if (Cout % 128 == 0) MTW = 4;
+  else return;
+  if ((enable == 4 || enable == 6) && Cout % (32 * enable) == 0) MTW = enable;  // development: force the channel block
+  const Geo gg = geo_of(batch, Ho, Wo);
+  const long long npos = (long long)gg.g0 + (long long)batch * gg.img;
+  const long long ntiles = (npos + GM_BN - 1) / GM_BN;
+  const int ncb = Cout / (32 * MTW);
+  if (ntiles * ncb < min_blocks) return;                       // a grid that cannot fill 256 CUs twice: conv_kernel's finer tiles
+  if ((long long)gg.img * gg.W1 >= (1LL << 32) || gg.img < 128) return;  // exactness of the in-kernel magic division by W1; one image wrap per tile
+  c->gemm = MTW;
+  c->MT = 2 * MTW;
+  c->NT = 4;
+  c->ncb = ncb;
+  c->kchunk = c->ksteps;
+  c->post = 0;
+  c->reg = c->tile = c->pair = 0;
+  c->ppw = 1;
+  c->lds_bytes = conv_gemm_lds_bytes(MTW, c->ksteps % 2 == 0);
+  c->wpk_elems = (size_t)ncb * c->ksteps * c->MT * 64 * 8;
+  c->gws = (int)ntiles;
+  c->name = "conv1x1_gemm_mfma";
+}
+
+template <int MTW, bool EVEN, bool RES, bool ACT, bool O8 = false>
+static int launch_gemm(const ConvArgs& a, size_t lds, hipStream_t s) {
+  if constexpr (!O8) {
+    if (a.out8) return launch_gemm<MTW, EVEN, RES, ACT, true>(a, lds, s);
+  }
+  auto kern = conv_gemm_kernel<MTW, gm_ks(MTW, EVEN), gm_ns(MTW, EVEN), RES, ACT, O8>;
+  static bool attr = false;
+  if (!attr) {
+    YL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.nblocks), dim3(256), lds, s, a);
+  YL_HIP(hipGetLastError());
+  return 0;
+}
+
+int conv_gemm_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s) {
+  const int MTW = cfg.gemm;
+  if ((MTW != 4 && MTW != 6 && MTW != 8) || cfg.ntaps != 1 || a.stride != 1 || a.out_f32 || a.in2 || a.wpk2 || !cfg.uniform ||
+      a.in_w1 != a.out_w1 || a.in_img != a.out_img || a.in_g0 != a.out_g0 || a.in_w1 != a.Wo + 1 || a.Cout != cfg.ncb * 32 * MTW)
+    return fail(-3, "conv_gemm: needs a plain bf16 1x1 stride-1 conv, Cin % 32 == 0, Cout a multiple of the channel block");
+  a.ncb = cfg.ncb;
+  a.cg = cfg.cg;
+  a.ksteps = cfg.ksteps;
+  a.t_B = batch;
+  a.t_H = a.Ho;
+  a.t_W = a.Wo;
+  a.magic_w1 = gm_magic(a.in_w1);
+  const long long lim = 1LL << 30;
+  const long long inb = (long long)cfg.cg * a.in_plane, outb = (long long)(a.Cout / 8) * a.out_plane;
+  const long long resb = a.res ? (long long)(a.Cout / 8) * a.res_plane : 0;
+  if (inb > lim || outb > lim || resb > lim || (long long)cfg.ncb * cfg.ksteps * cfg.MT * 1024 > lim)
+    return fail(-3, "conv_gemm: a tensor slice exceeds 1 GiB (32-bit buffer offsets); lower the batch size");
+  a.in_bytes = (unsigned)inb;
+  a.out_bytes = (unsigned)outb;
+  a.res_bytes = (unsigned)resb;
+  a.nblocks = cfg.gws * cfg.ncb;
+  const bool even = cfg.ksteps % 2 == 0;
+  const size_t lds = conv_gemm_lds_bytes(MTW, even);
+#define YL_GM2(M, E) (a.res ? (a.act ? launch_gemm<M, E, true, true>(a, lds, s) : launch_gemm<M, E, true, false>(a, lds, s)) \
+                         : (a.act ? launch_gemm<M, E, false, true>(a, lds, s) : launch_gemm<M, E, false, false>(a, lds, s)))
+#define YL_GM(M) (even ? YL_GM2(M, true) : YL_GM2(M, false))
+  return MTW == 4 ? YL_GM(4) : MTW == 6 ? YL_GM(6) : YL_GM2(8, true);
+#undef YL_GM2
+#undef YL_GM
+}
+
+}  // namespace yl

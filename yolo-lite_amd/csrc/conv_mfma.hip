@@ -588,6 +588,7 @@ int conv_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo,
   c->ppw = ppw;
   c->gws = (int)(((long long)c->npatches + 4 * ppw - 1) / (4 * ppw));
   c->name = k == 3 ? (stride == 2 ? "conv3x3s2_mfma" : "conv3x3_mfma") : "conv1x1_mfma";
+  c->gemm = 0;
   conv3_tile_choose(batch, Cin, Cout, k, stride, Ho, Wo, post, c);  // 3x3 s1 layers that fit: input tile in LDS
   conv3_reg_choose(batch, Cin, Cout, k, stride, Ho, Wo, post, c);   // ... or with the filter in registers
   conv3_pair_choose(batch, Cin, Cout, k, stride, Ho, Wo, post, c);  // ... 64 -> 64: filter halves in two waves per SIMD
@@ -876,6 +877,7 @@ int conv_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s) {
   // pitched output, an upsampled second input, an e4m3 copy) simply runs on conv_kernel.
   const bool plain = a.stride == 1 && !a.out_f32 && !a.in2 && !a.wpk2 && !a.out8 && a.in_w1 == a.out_w1 &&
                      a.in_img == a.out_img && a.in_g0 == a.out_g0 && a.in_w1 == a.Wo + 1;
+  if (cfg.gemm) return conv_gemm_launch(cfg, a, batch, s);  // chosen by the engine with the views known: no fallback needed
   if (cfg.pair && plain) return conv3_pair_launch(cfg, a, batch, s);
   if (cfg.reg && plain) return conv3_reg_launch(cfg, a, batch, s);
   if (cfg.tile && a.act && plain) return conv3_tile_launch(cfg, a, batch, s);  // (a conv without SiLU stays on conv_kernel)

@@ -119,6 +119,7 @@ struct ConvConfig {
   int tile;          // > 0: conv3_tile_kernel with this many 16-pixel column tiles per wave (else conv_kernel)
   int reg;           // > 0: conv3_reg_kernel (filter in registers) with this many 16-pixel column tiles per wave
   int pair;          // > 0: conv3_pair_kernel (64 -> 64: filter halves in the registers of two waves per SIMD)
+  int gemm;          // > 0: conv_gemm_kernel (wide 1x1: both operands staged through LDS) with this many 16-channel tiles per wave
   size_t lds_bytes;
   size_t wpk_elems;  // packed weight elements
   const char* name;
@@ -140,6 +141,9 @@ int conv3_reg_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s
 // conv3_pair.hip: 3x3 stride-1 64 -> 64 convs, K split between the two waves of a SIMD
 void conv3_pair_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, int post, ConvConfig* cfg);
 int conv3_pair_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s);
+// conv_gemm.hip: wide 1x1 convs (Cin, Cout >= 128) as a 128/192 x 128 macro-tile GEMM, both operands through LDS by LDS-DMA
+void conv_gemm_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, ConvConfig* cfg);
+int conv_gemm_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s);
 int dwpw_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s);
 // group launches (the three Detect levels in one launch, conv_mfma.hip)
 void conv_retile_for_group(ConvConfig* c, int NT, int batch, int Ho, int Wo);
