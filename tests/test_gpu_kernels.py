@@ -79,10 +79,13 @@ GEMM_CASES = [
 ]
 
 
+@pytest.mark.parametrize("w8", ["0", "-1"])
 @pytest.mark.parametrize("cin,cout,h,w,act,res", GEMM_CASES)
-def test_conv_gemm_vs_torch_and_conv_kernel(gpu_device, monkeypatch, cin, cout, h, w, act, res):
-    """conv_gemm_kernel (wide 1x1 convs: both operands staged through LDS by LDS-DMA, 128 / 192 x 128 macro tiles) against
-    torch, and BIT-identical to conv_kernel on the same operands (same packed filters' k order, same accumulation chain)."""
+def test_conv_gemm_vs_torch_and_conv_kernel(gpu_device, monkeypatch, cin, cout, h, w, act, res, w8):
+    """conv_gemm_kernel (wide 1x1 convs: both operands staged through LDS by LDS-DMA rings, 128 / 192 / 256-channel x 128-pixel
+    macro tiles with four waves, x 256 pixels with eight: w8) against torch, and BIT-identical to conv_kernel on the same
+    operands (same packed filters' k order, same accumulation chain)."""
+    monkeypatch.setenv("YL_CONV_GEMM_W8", w8)
     g = torch.Generator().manual_seed(cin * 7 + cout + h)
     B = 5
     x = _rand(g, B, cin, h, w)

@@ -28,44 +28,47 @@
 //     (bigger macro tiles) or more bytes in flight (deeper rings) raise it.
 //     Two workgroups share a CU (64-80 KiB of LDS, <= 256 registers), so one's epilogue (SiLU is quarter rate) and
 //     barrier waits run under the other's MFMAs.
+#include <type_traits>
+
 #include "conv_common.h"
 
 namespace yl {
 
 typedef __attribute__((address_space(3))) void lds_void_g;
 
-constexpr int GM_BN = 128;                 // pixels per workgroup
-constexpr int GM_BSTEP = 4 * GM_BN * 16;   // bytes of the B operand of one k-step (4 planes)
-
-// Ring shapes (two workgroups per CU): 128 / 192-channel blocks take two K-slices of 64 channels (64 / 80 KiB; fewer barriers:
-// 384 -> 384 @320x320 x 8: 664 against 597 TFLOP/s with four slices of 32), 256-channel blocks three slices of 32 (72 KiB).
-// A K that is not a multiple of 64 takes four slices of 32.
-constexpr int gm_ks(int MTW, bool even) { return (MTW == 8 || !even) ? 1 : 2; }
-constexpr int gm_ns(int MTW, bool even) { return MTW == 8 ? 3 : (even ? 2 : 4); }
-size_t conv_gemm_lds_bytes(int MTW, bool even) {
-  return (size_t)gm_ns(MTW, even) * gm_ks(MTW, even) * ((size_t)MTW * 2048 + GM_BSTEP);
+// Ring shapes.  Four waves (2 x 2, BN = 128 pixels), two workgroups per CU: 128 / 192-channel blocks take two K-slices of 64
+// channels (64 / 80 KiB; fewer barriers: 384 -> 384 @320x320 x 8: 664 against 597 TFLOP/s with four slices of 32),
+// 256-channel blocks three slices of 32 (72 KiB); a K that is not a multiple of 64 takes four slices of 32.
+// Eight waves (2 x 4, BN = 256 pixels), one workgroup per CU: 1.3-1.5 x the MACs per staged byte.
+constexpr int gm_ks(int MTW, int NWN, bool even) { return NWN == 4 ? (MTW == 6 ? 2 : 1) : ((MTW == 8 || !even) ? 1 : 2); }
+constexpr int gm_ns(int MTW, int NWN, bool even) { return NWN == 4 ? (MTW == 6 ? 2 : 3) : (MTW == 8 ? 3 : (even ? 2 : 4)); }
+size_t conv_gemm_lds_bytes(int MTW, int NWN, bool even) {
+  return (size_t)gm_ns(MTW, NWN, even) * gm_ks(MTW, NWN, even) * ((size_t)MTW * 2048 + (size_t)4 * 64 * NWN * 16);
 }
 
-// MTW: 16-channel tiles per wave (4, 6 or 8): BM = 2 * MTW * 16 output channels per workgroup.
-// KS: k-steps (32 channels) per ring slice; NS: slices in the ring.
+// MTW: 16-channel tiles per wave (4, 6 or 8): BM = 2 * MTW * 16 output channels per workgroup.  NWN: waves along the pixels
+// (2 or 4; 64 pixels each): BN = 64 * NWN.  KS: k-steps (32 channels) per ring slice; NS: slices in the ring.
 // O8: the epilogue also stores the e4m3 copy of channels [out8_c0, out8_c0 + out8_n) (yl_op.out8, fp8 programs), as conv_kernel's does
-template <int MTW, int KS, int NS, bool RES, bool ACT, bool O8>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_gemm_kernel(ConvArgs a) {
+template <int MTW, int NWN, int KS, int NS, bool RES, bool ACT, bool O8>
+__global__ __launch_bounds__(128 * NWN) __attribute__((amdgpu_waves_per_eu(2))) void conv_gemm_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
+  constexpr int NW = 2 * NWN;                  // waves
+  constexpr int BN = 64 * NWN;                 // pixels per workgroup
+  constexpr int BSTEP = 4 * BN * 16;           // bytes of the B operand of one k-step (4 planes)
   constexpr int MT = 2 * MTW;                  // tiles per workgroup
   constexpr int ASTAGE = KS * MT * 1024;       // bytes of one A slice (KS k-steps of the packed filter block: contiguous)
-  constexpr int BSTAGE = KS * GM_BSTEP;
+  constexpr int BSTAGE = KS * BSTEP;
   constexpr int STAGE = ASTAGE + BSTAGE;
   constexpr int NPA = ASTAGE / 1024, NPB = BSTAGE / 1024, NP = NPA + NPB;  // 1 KiB DMA pieces per slice
-  constexpr int PW = NP / 4;                   // pieces per wave and slice
-  static_assert(NP % 4 == 0 && NPA % 4 == 0, "pieces divide over four waves");
+  constexpr int PW = NP / NW;                  // pieces per wave and slice
+  static_assert(NP % NW == 0 && NPA % NW == 0, "pieces divide over the waves");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, n = lane & 15;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / NWN, wn = wave % NWN;
   const int bid = xcd_remap(blockIdx.x, a.nblocks);
   const int cb = bid % a.ncb;
-  const int q0 = (bid / a.ncb) * GM_BN;        // first guarded position of the tile (from the start of the plane)
+  const int q0 = (bid / a.ncb) * BN;           // first guarded position of the tile (from the start of the plane)
   const int nk = a.ksteps / KS;                // K-slices
 
   const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, (short)0, a.in_bytes, 0x00020000);
@@ -74,7 +77,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
   const unsigned lane16 = (unsigned)lane * 16u;
   const unsigned wbase = (unsigned)cb * a.ksteps * MT * 1024u;
 
-  // K-slice `it` -> ring buffer `buf`: pieces wave, wave + 4, ... (wave-uniform addressing, the lane adds its 16 bytes).
+  // K-slice `it` -> ring buffer `buf`: pieces wave, wave + NW, ... (wave-uniform addressing, the lane adds its 16 bytes).
   // Slices past the end (ring refills of the last iterations) fall outside both descriptors: the pieces move nothing but
   // still count in vmcnt, so the counted wait below is the same in every iteration.
   auto issue = [&](int it, int buf) __attribute__((always_inline)) {
@@ -82,12 +85,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     const unsigned past = it < nk ? 0u : OOB_K;
 #pragma unroll
     for (int i = 0; i < PW; ++i) {
-      const int j = wave + 4 * i;  // scalar
-      if (i < NPA / 4) {  // (NPA is a multiple of 4: the choice is made at compile time)
+      const int j = wave + NW * i;  // scalar
+      if (i < NPA / NW) {  // (NPA is a multiple of NW: the choice is made at compile time)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_g*)(gsm + sbase + (unsigned)j * 1024u), 16,
                                                  (int)(lane16 + wbase + (unsigned)it * ASTAGE + (unsigned)j * 1024u + past), 0, 0, 0);
       } else {
-        const int jb = j - NPA, p = jb >> 1, h = jb & 1;   // plane of the slice (4 per k-step), half of the pixel run
+        const int jb = j - NPA, p = jb / NWN, h = jb % NWN;   // plane of the slice (4 per k-step), 64-pixel part of the run
         const unsigned src = (unsigned)(it * (4 * KS) + p) * a.in_plane + (unsigned)(q0 + h * 64) * 16u;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void_g*)(gsm + sbase + ASTAGE + (unsigned)jb * 1024u), 16,
                                                  (int)(lane16 + src + past), 0, 0, 0);
@@ -129,31 +132,100 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
   }
 
   const unsigned char* const abase = gsm + ((unsigned)(wm * MTW) * 64u + (unsigned)lane) * 16u;
-  const unsigned char* const bbase = gsm + ASTAGE + ((unsigned)g * GM_BN + (unsigned)(wn * 64 + n)) * 16u;
-  int buf = 0;
-  for (int it = 0; it < nk; ++it) {
-    // slices it + 1 .. it + NS - 2 may stay in flight; mine of slice `it` have landed, and behind the barrier everybody's;
-    // everybody has also left slice it - 1, whose buffer the next refill overwrites
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * PW) : "memory");
+  const unsigned char* const bbase = gsm + ASTAGE + ((unsigned)g * BN + (unsigned)(wn * 64 + n)) * 16u;
+  struct Frags {
+    bf16x8 wa[MTW], xb[4];
+  };
+  // Entering slice i: a COUNTED wait for my own DMA pieces of it (slices i + 1 .. i + NS - 2 stay in flight), all my LDS
+  // reads done, barrier -- now everybody's pieces of slice i have landed and nobody reads slice i - 1 any more -- and the
+  // buffer of slice i - 1 is refilled with slice i + NS - 1.
+  auto enter = [&](int i) __attribute__((always_inline)) {
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * PW) : "memory");
     __builtin_amdgcn_s_barrier();
-    const int nb = buf == 0 ? NS - 1 : buf - 1;  // (it - 1) mod NS = (it + NS - 1) mod NS
-    issue(it + NS - 1, nb);
-    const unsigned char* ab = abase + buf * STAGE;
-    const unsigned char* bb = bbase + buf * STAGE;
+    issue(i + NS - 1, (i + NS - 1) % NS);
+  };
+  auto load = [&](int i, int ks, Frags& f) __attribute__((always_inline)) {
+    const unsigned char* ab = abase + (i % NS) * STAGE + ks * (MT * 1024);
+    const unsigned char* bb = bbase + (i % NS) * STAGE + ks * BSTEP;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      bf16x8 wa[MTW], xb[4];
+    for (int nt = 0; nt < 4; ++nt) f.xb[nt] = *reinterpret_cast<const bf16x8*>(bb + nt * 256);
 #pragma unroll
-      for (int nt = 0; nt < 4; ++nt) xb[nt] = *reinterpret_cast<const bf16x8*>(bb + ks * GM_BSTEP + nt * 256);
+    for (int mt = 0; mt < MTW; ++mt) f.wa[mt] = *reinterpret_cast<const bf16x8*>(ab + mt * 1024);
+  };
+  auto mma = [&](const Frags& f) __attribute__((always_inline)) {
 #pragma unroll
-      for (int mt = 0; mt < MTW; ++mt) wa[mt] = *reinterpret_cast<const bf16x8*>(ab + (ks * MT + mt) * 1024);
+    for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
-      for (int mt = 0; mt < MTW; ++mt)
+      for (int nt = 0; nt < 4; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wa[mt], f.xb[nt], acc[mt][nt], 0, 0, 0);
+  };
+  // One k-step on the fragments in F while the fragments of the NEXT k-step (slice i, k-step ks of it) are read from LDS
+  // INTO THE SAME REGISTERS: a filter fragment is reloaded two rows of four MFMAs behind its last use, the four activation
+  // fragments one by one behind their last use in the last row.  A k-step's first MFMA never waits for LDS and the
+  // prefetch costs no second register set (two sets made hipcc ping-pong the accumulators between two register sets as
+  // well: 256 registers and spills at 8 tiles per wave).  ENTER: the next k-step lies in a new slice -- the wait + barrier
+  // + ring refill stand behind the first two rows, so that the reads issued at the end of the previous k-step have had
+  // 8 MFMAs to land before lgkmcnt(0).  The order is pinned (sched_barrier around the slice entry, sched_group_barrier
+  // for the MFMA / LDS-read interleave).
+  auto row = [&](const Frags& f, int mt) __attribute__((always_inline)) {
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[mt], xb[nt], acc[mt][nt], 0, 0, 0);
+    for (int nt = 0; nt < 4; ++nt)
+      acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wa[mt], f.xb[nt], acc[mt][nt], 0, 0, 0);
+  };
+  auto step = [&](Frags& f, int i, int ks, auto enter_tag) __attribute__((always_inline)) {
+    constexpr bool ENTER = decltype(enter_tag)::value;
+    const unsigned char* ab = abase + (i % NS) * STAGE + ks * (MT * 1024);
+    const unsigned char* bb = bbase + (i % NS) * STAGE + ks * BSTEP;
+    row(f, 0);
+    row(f, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (ENTER) {
+      if (a.dbg & 1) __builtin_amdgcn_s_setprio(0);
+      enter(i);
+      if (a.dbg & 1) __builtin_amdgcn_s_setprio(1);
     }
-    buf = buf == NS - 1 ? 0 : buf + 1;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mt = 2; mt < MTW - 1; ++mt) {
+      f.wa[mt - 2] = *reinterpret_cast<const bf16x8*>(ab + (mt - 2) * 1024);
+      row(f, mt);
+    }
+    f.wa[MTW - 3] = *reinterpret_cast<const bf16x8*>(ab + (MTW - 3) * 1024);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      acc[MTW - 1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f.wa[MTW - 1], f.xb[nt], acc[MTW - 1][nt], 0, 0, 0);
+      f.xb[nt] = *reinterpret_cast<const bf16x8*>(bb + nt * 256);
+    }
+    f.wa[MTW - 2] = *reinterpret_cast<const bf16x8*>(ab + (MTW - 2) * 1024);
+    f.wa[MTW - 1] = *reinterpret_cast<const bf16x8*>(ab + (MTW - 1) * 1024);
+#pragma unroll
+    for (int mt = 2; mt < MTW - 1; ++mt) {
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+  };
+  Frags F;
+  enter(0);
+  load(0, 0, F);
+  if constexpr (KS == 2) {
+#pragma clang loop unroll(disable)
+    for (int i = 0; i + 1 < nk; ++i) {
+      step(F, i, 1, std::false_type{});
+      step(F, i + 1, 0, std::true_type{});
+    }
+    step(F, nk - 1, 1, std::false_type{});
+    mma(F);
+  } else {
+#pragma clang loop unroll(disable)
+    for (int i = 0; i + 1 < nk; ++i) step(F, i + 1, 0, std::true_type{});
+    mma(F);
   }
 
   // epilogue: SiLU, residual, one 16-byte pixel of plane (pair, g) per lane and pixel tile
@@ -223,11 +295,22 @@ void conv_gemm_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, i
   if ((enable == 4 || enable == 6) && Cout % (32 * enable) == 0) MTW = enable;  // development: force the channel block
   const Geo gg = geo_of(batch, Ho, Wo);
   const long long npos = (long long)gg.g0 + (long long)batch * gg.img;
-  const long long ntiles = (npos + GM_BN - 1) / GM_BN;
   const int ncb = Cout / (32 * MTW);
-  if (ntiles * ncb < min_blocks) return;                       // a grid that cannot fill 256 CUs twice: conv_kernel's finer tiles
   if ((long long)gg.img * gg.W1 >= (1LL << 32) || gg.img < 128) return;  // exactness of the in-kernel magic division by W1; one image wrap per tile
+  // Eight waves (256 pixels per workgroup, one workgroup per CU): measured (tools/gemm_bench.sh) +3-10 % on 256-channel
+  // blocks (512 -> 512 @20x20 x 64: 24.7 against 27.0 us; 768 -> 768 @160x160 x 8: 909 against 877 TFLOP/s), -4-8 % on
+  // 192-channel blocks, equal on 128.  YL_CONV_GEMM_W8: smallest grid (in 256-pixel workgroups) that takes it; 0: never;
+  // negative: every tile size from that grid up (development).
+  const int w8_blocks = getenv("YL_CONV_GEMM_W8") ? atoi(getenv("YL_CONV_GEMM_W8")) : 128;
+  int NWN = 2;
+  const long long b8 = (npos + 255) / 256 * ncb;
+  if (w8_blocks > 0 && MTW == 8 && b8 >= w8_blocks) NWN = 4;
+  if (w8_blocks < 0 && b8 >= -w8_blocks && (MTW != 6 || c->ksteps % 2 == 0)) NWN = 4;
+  const int BN = 64 * NWN;
+  const long long ntiles = (npos + BN - 1) / BN;
+  if (ntiles * ncb < min_blocks) return;                       // a grid that cannot fill 256 CUs: conv_kernel's finer tiles
   c->gemm = MTW;
+  c->gemm_nwn = NWN;
   c->MT = 2 * MTW;
   c->NT = 4;
   c->ncb = ncb;
@@ -235,24 +318,24 @@ void conv_gemm_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, i
   c->post = 0;
   c->reg = c->tile = c->pair = 0;
   c->ppw = 1;
-  c->lds_bytes = conv_gemm_lds_bytes(MTW, c->ksteps % 2 == 0);
+  c->lds_bytes = conv_gemm_lds_bytes(MTW, NWN, c->ksteps % 2 == 0);
   c->wpk_elems = (size_t)ncb * c->ksteps * c->MT * 64 * 8;
   c->gws = (int)ntiles;
   c->name = "conv1x1_gemm_mfma";
 }
 
-template <int MTW, bool EVEN, bool RES, bool ACT, bool O8 = false>
+template <int MTW, int NWN, bool EVEN, bool RES, bool ACT, bool O8 = false>
 static int launch_gemm(const ConvArgs& a, size_t lds, hipStream_t s) {
   if constexpr (!O8) {
-    if (a.out8) return launch_gemm<MTW, EVEN, RES, ACT, true>(a, lds, s);
+    if (a.out8) return launch_gemm<MTW, NWN, EVEN, RES, ACT, true>(a, lds, s);
   }
-  auto kern = conv_gemm_kernel<MTW, gm_ks(MTW, EVEN), gm_ns(MTW, EVEN), RES, ACT, O8>;
+  auto kern = conv_gemm_kernel<MTW, NWN, gm_ks(MTW, NWN, EVEN), gm_ns(MTW, NWN, EVEN), RES, ACT, O8>;
   static bool attr = false;
   if (!attr) {
     YL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr = true;
   }
-  hipLaunchKernelGGL(kern, dim3(a.nblocks), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(kern, dim3(a.nblocks), dim3(128 * NWN), lds, s, a);
   YL_HIP(hipGetLastError());
   return 0;
 }
@@ -278,14 +361,18 @@ int conv_gemm_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s
   a.out_bytes = (unsigned)outb;
   a.res_bytes = (unsigned)resb;
   a.nblocks = cfg.gws * cfg.ncb;
+  a.dbg = getenv("YL_CONV_DBG") ? atoi(getenv("YL_CONV_DBG")) : 0;  // development switches
   const bool even = cfg.ksteps % 2 == 0;
-  const size_t lds = conv_gemm_lds_bytes(MTW, even);
-#define YL_GM2(M, E) (a.res ? (a.act ? launch_gemm<M, E, true, true>(a, lds, s) : launch_gemm<M, E, true, false>(a, lds, s)) \
-                         : (a.act ? launch_gemm<M, E, false, true>(a, lds, s) : launch_gemm<M, E, false, false>(a, lds, s)))
-#define YL_GM(M) (even ? YL_GM2(M, true) : YL_GM2(M, false))
-  return MTW == 4 ? YL_GM(4) : MTW == 6 ? YL_GM(6) : YL_GM2(8, true);
-#undef YL_GM2
-#undef YL_GM
+  const int NWN = cfg.gemm_nwn;
+  if ((NWN != 2 && NWN != 4) || (NWN == 4 && MTW == 6 && !even)) return fail(-3, "conv_gemm: unsupported wave grid");
+  const size_t lds = conv_gemm_lds_bytes(MTW, NWN, even);
+#define YL_GM3(M, W, E) (a.res ? (a.act ? launch_gemm<M, W, E, true, true>(a, lds, s) : launch_gemm<M, W, E, true, false>(a, lds, s)) \
+                            : (a.act ? launch_gemm<M, W, E, false, true>(a, lds, s) : launch_gemm<M, W, E, false, false>(a, lds, s)))
+  if (NWN == 4) return MTW == 4 ? YL_GM3(4, 4, true) : MTW == 6 ? YL_GM3(6, 4, true) : YL_GM3(8, 4, true);
+  if (MTW == 8) return YL_GM3(8, 2, true);
+  if (MTW == 4) return even ? YL_GM3(4, 2, true) : YL_GM3(4, 2, false);
+  return even ? YL_GM3(6, 2, true) : YL_GM3(6, 2, false);
+#undef YL_GM3
 }
 
 }  // namespace yl

@@ -120,6 +120,7 @@ struct ConvConfig {
   int reg;           // > 0: conv3_reg_kernel (filter in registers) with this many 16-pixel column tiles per wave
   int pair;          // > 0: conv3_pair_kernel (64 -> 64: filter halves in the registers of two waves per SIMD)
   int gemm;          // > 0: conv_gemm_kernel (wide 1x1: both operands staged through LDS) with this many 16-channel tiles per wave
+  int gemm_nwn;      // ... and this many waves along the pixels (2: 128-pixel tiles, 4: 256-pixel tiles)
   size_t lds_bytes;
   size_t wpk_elems;  // packed weight elements
   const char* name;
