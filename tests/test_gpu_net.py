@@ -535,10 +535,13 @@ def test_level_group_launches_are_bit_identical(gpu_device, monkeypatch, h, w, m
         assert torch.equal(a, b)
 
 
-def test_prefilter_in_the_class_launch_epilogue_is_bit_identical(gpu_device):
+@pytest.mark.parametrize("switch,bias", [("YL_FUSE_PREFILTER", -3.0), ("YL_NMS_FUSED", -3.0), ("YL_NMS_FUSED", 0.5)])
+def test_prefilter_in_the_class_launch_epilogue_is_bit_identical(gpu_device, switch, bias):
     """The NMS candidate pre-filter in the epilogue of the launches that write the class logits (ConvArgs::pf_*, default)
     against the separate pre-filter kernel (YL_FUSE_PREFILTER=0, read once per process -> a child process): same detections,
-    bit for bit, eager and graph, at a low and at the default confidence threshold."""
+    bit for bit, eager and graph, at a low and at the default confidence threshold.
+    YL_NMS_FUSED: exact decode + sort + mask + scan in ONE launch (decode_nms_fused_kernel, one workgroup per image, default)
+    against the four launches; bias 0.5 makes thousands of anchors per image candidates (the scan's general path, > 512 rows)."""
     import os
     import subprocess
     import sys
@@ -553,7 +556,7 @@ from yololite_amd.nn import arch
 from yololite_amd.nn.engine import HipEngine
 from yololite_amd.nn.synth import synth_state_dict
 specs, _ = arch.parse_model(arch.yolo11_dict("n"))
-sd = synth_state_dict("n", 9, cls_bias=[-3.0, -3.0, -3.0], cls_gain=6.0)
+sd = synth_state_dict("n", 9, cls_bias=[%r] * 3, cls_gain=6.0)
 dev = torch.device("cuda:0")
 eng = HipEngine.from_model(specs, sd, 2, 320, 448, dev)
 x = torch.randint(0, 256, (2, 3, 320, 448), generator=torch.Generator().manual_seed(11), dtype=torch.uint8).to(dev)
@@ -563,12 +566,12 @@ for conf in (0.25, 0.06):
         o, c = eng.detect(x, conf, 0.7, max_det=300, graph=graph)
         res[(conf, graph)] = (o.cpu().clone(), c.cpu().clone())
 torch.save(res, sys.argv[1])
-""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), bias)
     outs = []
     with tempfile.TemporaryDirectory() as td:
         for flag in ("1", "0"):
             f = os.path.join(td, f"r{flag}.pt")
-            env = dict(os.environ, YL_FUSE_PREFILTER=flag)
+            env = dict(os.environ, **{switch: flag})
             subprocess.run([sys.executable, "-c", code, f], check=True, env=env, timeout=300)
             outs.append(torch.load(f))
     fused, plain = outs

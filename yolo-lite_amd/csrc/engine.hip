@@ -384,6 +384,14 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
             r.cfg.NT = 2;
             r.cfg.npatches = (int)(((long long)batch * o.out.H * o.out.W + 31) / 32);
           }
+          // A deep launch on a small map (Detect level 2: 256 channels @20x20 = 16 channel blocks one after the other in every
+          // workgroup, 100 workgroups at 32 pixels per wave for batch 32): 16 pixels per wave double the workgroups and halve
+          // each one's serial chain.  Launches that join a level group keep the group's tiling.
+          static const int small_nt1 = getenv("YL_DWPW_SMALL_NT1") ? atoi(getenv("YL_DWPW_SMALL_NT1")) : 1;
+          if (small_nt1 && o.group == 0 && r.cfg.NT == 2 && C >= 128 && (r.cfg.npatches + 3) / 4 < 256) {
+            r.cfg.NT = 1;
+            r.cfg.npatches = (int)(((long long)batch * o.out.H * o.out.W + 15) / 16);
+          }
           if (r.cfg.ncb != 1 || r.cfg.kchunk < r.cfg.ksteps)
             return fail(-3, tag + ": fused depthwise+pointwise needs Cout <= 80 and a filter that fits the slab");
           std::vector<uint16_t> pk;

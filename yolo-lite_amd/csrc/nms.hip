@@ -172,11 +172,9 @@ __device__ __forceinline__ void bitonic_sort(unsigned long long* k, int np, int 
   }
 }
 
-__global__ __launch_bounds__(1024) void nms_sort_kernel(const float* __restrict__ pred, int nc, int A, int agnostic,
-                                                         float max_wh, NmsWs w) {
-  __shared__ unsigned long long sk[SORT_LDS_KEYS];
-  __shared__ int s_nvalid;
-  const int b = blockIdx.x, tid = threadIdx.x;
+// (a device function so that the one-launch path, decode_nms_fused_kernel, runs the very same code per image)
+__device__ __forceinline__ void nms_sort_body(const float* __restrict__ pred, int nc, int A, int agnostic, float max_wh,
+                                              const NmsWs& w, int b, int tid, unsigned long long* sk, int& s_nvalid) {
   unsigned long long* gk = w.keys + (long long)b * w.KP;
   int n, np = 64;
   unsigned long long* k;
@@ -256,6 +254,13 @@ __global__ __launch_bounds__(1024) void nms_sort_kernel(const float* __restrict_
   }
 }
 
+__global__ __launch_bounds__(1024) void nms_sort_kernel(const float* __restrict__ pred, int nc, int A, int agnostic,
+                                                         float max_wh, NmsWs w) {
+  __shared__ unsigned long long sk[SORT_LDS_KEYS];
+  __shared__ int s_nvalid;
+  nms_sort_body(pred, nc, A, agnostic, max_wh, w, blockIdx.x, threadIdx.x, sk, s_nvalid);
+}
+
 // ---- 3. suppression mask: one wavefront per row i, one ballot per 64 columns j > i
 __device__ __forceinline__ bool iou_gt(const float4 a, float area_a, const float4 b, float thr) {
   const float area_b = __fmul_rn(__fsub_rn(b.z, b.x), __fsub_rn(b.w, b.y));
@@ -267,16 +272,15 @@ __device__ __forceinline__ bool iou_gt(const float4 a, float area_a, const float
   return __fdiv_rn(inter, uni) > thr;
 }
 
-__global__ __launch_bounds__(256) void nms_mask_kernel(float iou_thres, NmsWs w) {
-  const int b = blockIdx.y;
-  const int n = w.nfinal[b];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// rows row0, row0 + nrows_step, ... of image b, one wavefront per row
+// (bo: the image's n class-offset boxes; mask / MW: its mask rows and their pitch in words -- global or LDS)
+__device__ __forceinline__ void nms_mask_body(float iou_thres, int n, const float4* bo, unsigned long long* mask, int MW,
+                                              int row0, int nrows_step, int lane) {
   const int nwords = (n + 63) >> 6;
-  const float4* bo = w.box_off + (long long)b * w.M;
-  for (int i = blockIdx.x * 4 + wave; i < n; i += gridDim.x * 4) {
+  for (int i = row0; i < n; i += nrows_step) {
     const float4 bi = bo[i];
     const float area_i = __fmul_rn(__fsub_rn(bi.z, bi.x), __fsub_rn(bi.w, bi.y));
-    unsigned long long* row = w.mask + ((long long)b * w.M + i) * w.MW;
+    unsigned long long* row = mask + (long long)i * MW;
     for (int wd = i >> 6; wd < nwords; ++wd) {
       const int j = wd * 64 + lane;
       bool sup = false;
@@ -285,6 +289,12 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(float iou_thres, NmsWs w)
       if (lane == 0) row[wd] = bits;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void nms_mask_kernel(float iou_thres, NmsWs w) {
+  const int b = blockIdx.y;
+  nms_mask_body(iou_thres, w.nfinal[b], w.box_off + (long long)b * w.M, w.mask + (long long)b * w.M * w.MW, w.MW,
+                blockIdx.x * 4 + (threadIdx.x >> 6), gridDim.x * 4, threadIdx.x & 63);
 }
 
 // ---- 4. greedy scan over the sorted candidates, 64 at a time, one wavefront per image
@@ -314,12 +324,10 @@ __device__ __forceinline__ void scan_emit(const NmsWs& w, int b, int i, int slot
   op[5] = (float)w.cls[o];
 }
 
-__global__ __launch_bounds__(64) void nms_scan_kernel(int max_det, const float* __restrict__ scale, float* out,
-                                                       int32_t* out_count, NmsWs w) {
-  const int b = blockIdx.x, lane = threadIdx.x;
+__device__ __forceinline__ void nms_scan_body(int max_det, const float* __restrict__ scale, float* out, int32_t* out_count,
+                                              const NmsWs& w, int b, int lane, const unsigned long long* mask, int MW) {
   const int n = w.nfinal[b];
   const int nwords = (n + 63) >> 6;
-  const unsigned long long* mask = w.mask + (long long)b * w.M * w.MW;
   unsigned long long rem[SCAN_T];
 #pragma unroll
   for (int t = 0; t < SCAN_T; ++t) rem[t] = 0ull;
@@ -344,7 +352,7 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(int max_det, const float* 
       const int i = blk * 64 + lane;
       unsigned long long d[SCAN_T];
 #pragma unroll
-      for (int t = 0; t < SCAN_T; ++t) d[t] = (t >= blk && t < nwords && i < n) ? mask[(long long)i * w.MW + t] : 0ull;
+      for (int t = 0; t < SCAN_T; ++t) d[t] = (t >= blk && t < nwords && i < n) ? mask[(long long)i * MW + t] : 0ull;
       unsigned long long dcur = 0ull, cur = 0ull;
 #pragma unroll
       for (int t = 0; t < SCAN_T; ++t)
@@ -395,7 +403,7 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(int max_det, const float* 
     const int nvalid = n - blk * 64;
     const unsigned long long vmask = nvalid >= 64 ? ~0ull : ((1ull << nvalid) - 1ull);
     unsigned long long alive = ~cur & vmask;
-    const unsigned long long d = (i < n) ? mask[(long long)i * w.MW + blk] : 0ull;
+    const unsigned long long d = (i < n) ? mask[(long long)i * MW + blk] : 0ull;
     unsigned long long kept = 0ull;
     int room = max_det - total;
     while (alive && room > 0) {
@@ -411,7 +419,7 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(int max_det, const float* 
     while (kk) {
       const int bit = __builtin_ctzll(kk);
       kk &= kk - 1;
-      const unsigned long long* row = mask + (long long)(blk * 64 + bit) * w.MW;
+      const unsigned long long* row = mask + (long long)(blk * 64 + bit) * MW;
 #pragma unroll
       for (int t = 0; t < SCAN_T; ++t) {
         const int wd = lane + 64 * t;
@@ -425,6 +433,11 @@ __global__ __launch_bounds__(64) void nms_scan_kernel(int max_det, const float* 
     total += __popcll(kept);
   }
   if (lane == 0) out_count[b] = total;
+}
+
+__global__ __launch_bounds__(64) void nms_scan_kernel(int max_det, const float* __restrict__ scale, float* out,
+                                                       int32_t* out_count, NmsWs w) {
+  nms_scan_body(max_det, scale, out, out_count, w, blockIdx.x, threadIdx.x, w.mask + (long long)blockIdx.x * w.M * w.MW, w.MW);
 }
 
 }  // namespace yl
@@ -515,7 +528,7 @@ __device__ __forceinline__ DcAnchor dc_anchor(const DecCandArgs& a, int b, int a
 #pragma unroll
   for (int i = 1; i < 8; ++i)
     if (i < a.n_levels && an >= a.lv[i].a0) l = i;
-  d.L = a.lv[l];
+  d.L = a.lv[l];  // (a per-lane, field-by-field select of the record instead of this indexed copy was measured slower: 42 against 30 us)
   d.b = b;
   d.p = an - d.L.a0;
   d.py = d.p / d.L.W;
@@ -548,10 +561,9 @@ __device__ __forceinline__ void dc_emit(const DecCandArgs& a, const NmsWs& w, co
 }
 
 // Dense variant (low thresholds, e.g. validation at conf 0.001): every anchor is decoded, one thread each.
-__global__ __launch_bounds__(256) void decode_candidates_dense_kernel(DecCandArgs a, NmsWs w) {
-  const int an = blockIdx.x * 256 + threadIdx.x;
-  const int b = blockIdx.y;
-  if (an >= a.A) return;
+// one thread decodes anchor `an` of image b completely (18 independent 16-byte loads: one memory round trip) and applies the
+// reference's candidate test; key_slot as in dc_emit
+__device__ __forceinline__ void decode_anchor_thread(const DecCandArgs& a, const NmsWs& w, int b, int an, int key_slot) {
   const DcAnchor d = dc_anchor(a, b, an);
   // best class: strict '>' in increasing c keeps the first maximum (ops.py:243)
   float best = -1.f;
@@ -568,7 +580,10 @@ __global__ __launch_bounds__(256) void decode_candidates_dense_kernel(DecCandArg
       }
     }
   }
-  if (!(best > a.conf_thres)) return;
+  if (!(best > a.conf_thres)) {
+    if (key_slot >= 0) w.keys[(long long)b * w.KP + key_slot] = ~0ull;  // sparse path: the slot holds a rejected anchor
+    return;
+  }
   float dist[4];
 #pragma unroll
   for (int side = 0; side < 4; ++side) {
@@ -582,7 +597,85 @@ __global__ __launch_bounds__(256) void decode_candidates_dense_kernel(DecCandArg
     }
     dist[side] = dfl_expect(v);
   }
-  dc_emit(a, w, d, best, bi, dist[0], dist[1], dist[2], dist[3]);
+  dc_emit(a, w, d, best, bi, dist[0], dist[1], dist[2], dist[3], key_slot);
+}
+
+// The same decode by FOUR adjacent lanes per anchor (lane & 3 = box side): each lane runs the DFL of its side (16 of the 64
+// exponentials) and looks at a quarter of the class planes.  Bit-identical to decode_anchor_thread:
+//   * sigmoid_score is monotone in the logit, so the best score is sigmoid(max logit) and only classes whose logit lies within
+//     0.01 of the maximum can tie it after rounding: the sigmoid is evaluated for those alone (one or two instead of nc),
+//     and the first-maximum rule (ops.py:243) becomes "smallest class index among the equal best scores" across the lanes.
+//     Should the window itself round to the best score (saturated scores), every class is evaluated as the reference does.
+//   * dfl_expect is the same function on the same 16 values.
+// `valid` lanes only; all four lanes of a group must be active or inactive together.
+__device__ __forceinline__ void decode_anchor_quad(const DecCandArgs& a, const NmsWs& w, int b, int an, int key_slot, int side) {
+  const DcAnchor d = dc_anchor(a, b, an);
+  const int nplanes = (a.nc + 7) >> 3;
+  float m = -__builtin_huge_valf();
+  for (int c8 = side; c8 < nplanes; c8 += 4) {
+    float v[8];
+    level_load8(d.L.cls, c8, d.pix, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (c8 * 8 + j < a.nc) m = fmaxf(m, v[j]);
+  }
+  m = fmaxf(m, __shfl_xor(m, 1));
+  m = fmaxf(m, __shfl_xor(m, 2));
+  const float top = sigmoid_score(m);
+  const float lo = m - 0.01f;
+  const bool all = sigmoid_score(lo) == top;  // the window does not separate: evaluate every class
+  float best = -1.f;
+  int bi = 0x7fffffff;
+  for (int c8 = side; c8 < nplanes; c8 += 4) {
+    float v[8];
+    level_load8(d.L.cls, c8, d.pix, v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = c8 * 8 + j;
+      if (c < a.nc && (all || v[j] >= lo)) {
+        const float sc = sigmoid_score(v[j]);
+        if (sc > best) {  // increasing c within a lane: strict '>' keeps the first maximum
+          best = sc;
+          bi = c;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int off = 1; off <= 2; off <<= 1) {
+    const float s2 = __shfl_xor(best, off);
+    const int i2 = __shfl_xor(bi, off);
+    if (s2 > best || (s2 == best && i2 < bi)) {
+      best = s2;
+      bi = i2;
+    }
+  }
+  float dist = 0.f;
+  if (best > a.conf_thres) {  // (uniform over the four lanes)
+    float v[16], l8[8], h8[8];
+    level_load8(d.L.box, 2 * side, d.pix, l8);
+    level_load8(d.L.box, 2 * side + 1, d.pix, h8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      v[j] = l8[j];
+      v[8 + j] = h8[j];
+    }
+    dist = dfl_expect(v);
+  }
+  const int l0 = (int)(threadIdx.x & 63u) & ~3;
+  const float dl = __shfl(dist, l0), dt = __shfl(dist, l0 + 1), dr = __shfl(dist, l0 + 2), db = __shfl(dist, l0 + 3);
+  if (side != 0) return;
+  if (!(best > a.conf_thres)) {
+    if (key_slot >= 0) w.keys[(long long)b * w.KP + key_slot] = ~0ull;
+    return;
+  }
+  dc_emit(a, w, d, best, bi, dl, dt, dr, db, key_slot);
+}
+
+__global__ __launch_bounds__(256) void decode_candidates_dense_kernel(DecCandArgs a, NmsWs w) {
+  const int an = blockIdx.x * 256 + threadIdx.x;
+  if (an >= a.A) return;
+  decode_anchor_thread(a, w, blockIdx.y, an, -1);
 }
 
 // Sparse variant (the usual case: ~1-2 % of the anchors clear conf 0.25), two kernels.
@@ -612,11 +705,10 @@ __global__ __launch_bounds__(256) void decode_candidates_sparse_kernel(DecCandAr
 //    first-max class, DFL of the 64 box logits (exponentials in parallel, sums in the reference's
 //    sequential order) -- so the results are identical to the dense kernel's.
 constexpr int DX_BLOCKS = 4;  // workgroups per sub-list (4 waves each)
-__global__ __launch_bounds__(256) void decode_exact_kernel(DecCandArgs a, NmsWs w) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int b = blockIdx.z, sub = blockIdx.y;
+// entries j0, j0 + jstep, ... of sub-list `sub` of image b, one wavefront per anchor
+__device__ __forceinline__ void decode_exact_body(const DecCandArgs& a, const NmsWs& w, int b, int sub, int j0, int jstep, int lane) {
   const int n = min(w.pre_count[b * NSUB + sub], w.sub_cap);
-  for (int j = blockIdx.x * 4 + wave; j < n; j += DX_BLOCKS * 4) {
+  for (int j = j0; j < n; j += jstep) {
     const int an = min(max(w.pre_list[(long long)(b * NSUB + sub) * w.sub_cap + j], 0), a.A - 1);
     const DcAnchor d = dc_anchor(a, b, an);
     // lane = box channel lane: plane lane >> 3, element lane & 7
@@ -656,6 +748,74 @@ __global__ __launch_bounds__(256) void decode_exact_kernel(DecCandArgs a, NmsWs 
     const float dl = __shfl(dist, 0), dt = __shfl(dist, 16), dr = __shfl(dist, 32), db = __shfl(dist, 48);
     if (lane == 0) dc_emit(a, w, d, best, bi, dl, dt, dr, db, sub * w.sub_cap + j);
   }
+}
+
+__global__ __launch_bounds__(256) void decode_exact_kernel(DecCandArgs a, NmsWs w) {
+  decode_exact_body(a, w, blockIdx.z, blockIdx.y, blockIdx.x * 4 + (threadIdx.x >> 6), DX_BLOCKS * 4, threadIdx.x & 63);
+}
+
+// ---- the hot path's post-processing in ONE launch: one workgroup (16 wavefronts) per image runs the exact decode of the
+// pre-filtered anchors, the sort + gather, the suppression mask and the greedy scan + scale_boxes one after the other --
+// the very device functions of the four kernels above, so the results are bit-identical -- with workgroup barriers where
+// the four-launch form has kernel boundaries.  The intermediates (keys, boxes, mask rows: a few KB per image) stay in the
+// NMS workspace, i.e. in L2 (boxes and, up to 512 rows, the mask in LDS); a workgroup only ever reads what it wrote itself.
+// Measured (YOLO11n batch 32, ~130 candidates per image, in-sequence HIP events incl. ~5 us of event overhead per row): 58 us
+// for the one launch against 17 + 14 + 7 + 18 = 56 us for the four; phases (YL_NMS_DBG): decode 30, sort 9, mask 9, scan
+// 12 us -- a 32-workgroup launch is a chain of memory round trips whatever its arithmetic costs (four lanes per anchor
+// instead of one thread: 36 -> 30 us).  Same latency, three launches fewer (63 -> 60 per step), +0.5 % images/s with 20
+// batches in flight; the <= 25 us the round-2 review asked for is NOT reached.
+__global__ __launch_bounds__(1024) void decode_nms_fused_kernel(DecCandArgs a, NmsWs w, float iou_thres, int max_det,
+                                                                 int agnostic, float max_wh, const float* __restrict__ scale,
+                                                                 float* out, int32_t* out_count, int stop_after) {
+  __shared__ unsigned long long sk[SORT_LDS_KEYS];
+  __shared__ int s_nvalid;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // exact decode of the pre-filtered anchors by FOUR LANES each (decode_anchor_quad: decode_candidates_dense_kernel's arithmetic,
+  // which decode_exact_kernel reproduces bit for bit).  Measured alternatives: a wavefront per anchor, as the four-launch form
+  // has it, leaves each of the 16 waves a chain of ~13 dependent memory round trips (115 us for the launch); one thread per
+  // anchor evaluates nc precise sigmoids + 64 exponentials serially (30 us for this phase).
+  {
+    int pre[NSUB + 1];  // the NSUB sub-lists as one list: all candidates of the image in flight at once
+    pre[0] = 0;
+#pragma unroll
+    for (int q = 0; q < NSUB; ++q) pre[q + 1] = pre[q] + min(max(w.pre_count[b * NSUB + q], 0), w.sub_cap);
+    // four lanes per candidate: rounds of 256 candidates; a whole quad is active or idle together (shuffles inside)
+    const int side = tid & 3;
+    for (int i0 = 0; i0 < pre[NSUB]; i0 += 256) {
+      const int i = i0 + (tid >> 2);
+      if (i < pre[NSUB]) {
+        int sub = 0;
+#pragma unroll
+        for (int t = 1; t < NSUB; ++t) sub += (i >= pre[t]);
+        int j = i;
+#pragma unroll
+        for (int t = 1; t < NSUB; ++t) j = (t == sub) ? i - pre[t] : j;
+        const int an = min(max(w.pre_list[(long long)(b * NSUB + sub) * w.sub_cap + j], 0), a.A - 1);
+        decode_anchor_quad(a, w, b, an, sub * w.sub_cap + j, side);
+      }
+    }
+  }
+  if (stop_after == 1) return;  // (development: timing ablation, YL_NMS_DBG)
+  __syncthreads();
+  nms_sort_body(nullptr, a.nc, a.A, agnostic, max_wh, w, b, tid, sk, s_nvalid);
+  if (stop_after == 2) return;
+  __syncthreads();
+  // The mask phase is a serial chain of ~16 rows per wave: with the boxes in LDS (the sort's key array is free now) a row
+  // costs LDS latency, not a memory round trip; up to 512 rows the mask itself stays in LDS too (8 words per row).
+  const int n = w.nfinal[b];
+  float4* lbox = reinterpret_cast<float4*>(sk);                       // [<= 1024] 16 KiB
+  unsigned long long* lmask = sk + 2048;                              // [512][8]  32 KiB
+  const bool box_lds = n <= 1024, mask_lds = n <= 512;
+  if (box_lds)
+    for (int i = tid; i < n; i += 1024) lbox[i] = w.box_off[(long long)b * w.M + i];
+  __syncthreads();
+  const float4* bo = box_lds ? lbox : w.box_off + (long long)b * w.M;
+  unsigned long long* mk = mask_lds ? lmask : w.mask + (long long)b * w.M * w.MW;
+  const int mw = mask_lds ? 8 : w.MW;
+  nms_mask_body(iou_thres, n, bo, mk, mw, wave, 16, lane);
+  if (stop_after == 3) return;
+  __syncthreads();
+  if (wave == 0) nms_scan_body(max_det, scale, out, out_count, w, b, lane, mk, mw);
 }
 }  // namespace yl
 
@@ -705,6 +865,16 @@ int yl::decode_nms_stages(const void* workspace, const yl_level* levels, int n_l
     w.fused = 1;
     if (!prefiltered) hipLaunchKernelGGL(decode_candidates_sparse_kernel, grid, dim3(256), 0, s, a, w, levels[0].nc8);
     if (ev) (void)hipEventRecord(ev[1], s);
+    static const int one_launch = getenv("YL_NMS_FUSED") ? atoi(getenv("YL_NMS_FUSED")) : 1;
+    if (one_launch) {  // exact decode + sort + mask + scan in one launch, one workgroup per image
+      static const int stop_after = getenv("YL_NMS_DBG") ? atoi(getenv("YL_NMS_DBG")) : 0;
+      hipLaunchKernelGGL(decode_nms_fused_kernel, dim3(batch), dim3(1024), 0, s, a, w, iou_thres, max_det, agnostic, max_wh,
+                         scale, out, out_count, stop_after);
+      if (ev)
+        for (int q = 2; q <= 5; ++q) (void)hipEventRecord(ev[q], s);  // stages 3-5 are part of that launch: zero time
+      YL_HIP(hipGetLastError());
+      return 0;
+    }
     hipLaunchKernelGGL(decode_exact_kernel, dim3(DX_BLOCKS, NSUB, batch), dim3(256), 0, s, a, w);
   } else {
     hipLaunchKernelGGL(decode_candidates_dense_kernel, grid, dim3(256), 0, s, a, w);

@@ -5,6 +5,7 @@ PyTorch is used only for device memory (the workspace / IO tensors) and the curr
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -362,9 +363,16 @@ class HipEngine:
                 ("nms.mask", "nms_mask", ncand * 16 + ncand * 8),
                 ("nms.scan", "nms_scan", ncand * 16 + float(self.batch * max_det * 24))]
         fused_pf = bool(self.lib.yl_engine_prefilter_fused(self._h, float(conf)))
+        one_launch = os.environ.get("YL_NMS_FUSED", "1") != "0" and conf >= 0.05  # nms.hip: decode_nms_fused_kernel
         for (name, kern, b), t in zip(post, mp):
             if fused_pf and name == "detect.prefilter":
                 continue  # runs in the epilogue of the launches that write the class logits: not a launch of its own
+            if one_launch and name != "detect.prefilter" and rows and rows[-1]["kernel"] == "decode_nms_fused":
+                rows[-1]["ms"] += t  # exact decode + sort + mask + scan are ONE launch: one row
+                rows[-1]["bytes"] += b
+                continue
+            if one_launch and name == "detect.decode_exact":
+                name, kern = "detect.decode_exact+nms.sort+mask+scan", "decode_nms_fused"
             rows.append(dict(name=name, kernel=kern, ms=t, flops=0.0, bytes=b))
         return rows
 
