@@ -156,7 +156,7 @@ def build_model(scale, device, batch, h, w, x_calib, target_frac=0.015, fp8=Fals
     return specs, sd, HipEngine.from_model(specs, sd, batch, h, w, device, fp8_calib=x_calib if fp8 else None)
 
 
-def cpu_baseline(sd, scale, h, w, conf, iou, sample_b=8, iters=100, eng=None, dev=None, max_det=300, band=0.08):
+def cpu_baseline(sd, scale, h, w, conf, iou, sample_b=32, iters=3, eng=None, dev=None, max_det=300, band=0.08):
     """The oracle (fp32 eager PyTorch restatement of the reference path, unfused Conv->BN->SiLU +
     python-loop NMS) timed on this host's cores: threads = min(8, cores-1) as the reference sets
     (utils/__init__.py:32, torch_utils.py:168-169).  kind = "port".  Its last outputs double as the parity gate of the
@@ -235,8 +235,29 @@ def short_config(scale, batch, imgsz, dtype, streams, steps, dev, conf=0.25, iou
         o16, c16 = e16.detect(x8, conf, iou, max_det=max_det, graph=False)
         torch.cuda.synchronize(dev)
         g = parity_gate([o16[i, : int(c16[i])].cpu() for i in range(batch)], [o8[i, : int(c8[i])].cpu() for i in range(batch)],
-                        conf, iou, band=0.15, min_matched_frac=0.75)
-        res["fp8_vs_bf16"] = {k: g[k] for k in ("ref", "det", "matched", "matched_frac", "class_mismatch", "unexplained", "max_dconf", "ok")}
+                        conf, iou, band=0.15, min_matched_frac=0.75, max_explained_share=0.6)
+        keys = ("ref", "det", "matched", "matched_frac", "class_mismatch", "unexplained", "max_dconf", "explained_share",
+                "max_explained_share", "count_bias", "ok")
+        res["fp8_vs_bf16"] = {k: g[k] for k in keys}
+        # ... and against the REFERENCE arithmetic: the fp32 oracle on the first two images (one host forward each, ~2 s), the
+        # stated e4m3 tolerance (score band 0.12 = 1.5 x the bf16 band), >= 85 % of the reference's boxes paired, classes of
+        # paired boxes exact, nothing unexplained.  max_det is lifted so that the cut at 300 does not create one-sided
+        # boxes of its own.  The synthetic head is dense at the threshold (cls_gain 8): the e4m3 program keeps ~1.9 x
+        # the reference's boxes, all of them within the band of conf -- hence the stated 0.6 cap on the explained share.
+        from oracle import yolo11_oracle as oracle
+
+        n_or, gate_max_det = min(2, batch), 3000
+        o8g, c8g = eng.detect(x8, conf, iou, max_det=gate_max_det, graph=False)
+        torch.cuda.synchronize(dev)
+        torch.set_num_threads(min(8, max(1, (os.cpu_count() or 2) - 1)))
+        t_or = time.time()
+        with torch.inference_mode():
+            y32, _ = oracle.forward(sd, x8[:n_or].float().cpu() / 255.0, scale)
+            ref = oracle.non_max_suppression(y32, conf, iou, max_det=gate_max_det)
+        g2 = parity_gate(ref, [o8g[i, : int(c8g[i])].cpu() for i in range(n_or)], conf, iou, band=0.12, min_matched_frac=0.85,
+                         ref_y=y32, max_explained_share=0.6)
+        res["fp8_vs_fp32_oracle"] = dict({k: g2[k] for k in keys}, images=n_or, oracle_seconds=round(time.time() - t_or, 1),
+                                         near_threshold=g2["near_threshold"], nms_flip=g2["nms_flip"])
         del e16
     del eng
     torch.cuda.empty_cache()
@@ -632,7 +653,7 @@ def main():
                 nb8 = min(B, 8)
                 res["fp8_vs_bf16"] = parity_gate([o16[i, : int(c16[i])].cpu() for i in range(nb8)],
                                                  [o8[i, : int(c8[i])].cpu() for i in range(nb8)], conf, iou, band=0.15,
-                                                 min_matched_frac=0.75)
+                                                 min_matched_frac=0.75, max_explained_share=0.6)
                 if l8 is not None:
                     l16 = e16.raw_levels()
                     res["fp8_vs_bf16"]["level_rel_l2"] = [round(float((a - b).norm() / b.norm()), 4) for a, b in zip(l8, l16)]
@@ -653,11 +674,12 @@ def main():
                     except Exception as e:  # never at the cost of the main line
                         res["other_configs"].append({"workload": f"YOLO11{sc_} {dt_} {sz_} batch={b_}", "error": repr(e)})
             if not args.no_cpu_baseline:
-                # bounded sample: about as much host work as 800 images of YOLO11n at 640x640 (~12 s on 8 threads)
+                                # batch 32, 3 iterations for YOLO11n at 640x640 (96 images after one warm-up iteration, a few
+                # seconds on 8 threads); other configurations: about the same host work
                 gf = CONV_GFLOP_AT_640.get(args.scale, 200.0) * (H * W) / (640 * 640)
-                n_img = max(1, int(800 * CONV_GFLOP_AT_640["n"] / gf))
-                sb = min(8, B, n_img)
-                res["cpu_baseline"] = cpu_baseline(sd, args.scale, H, W, conf, iou, sample_b=sb, iters=max(1, n_img // sb),
+                n_img = max(1, int(96 * CONV_GFLOP_AT_640["n"] / gf))
+                sb = min(32, B, n_img)
+                res["cpu_baseline"] = cpu_baseline(sd, args.scale, H, W, conf, iou, sample_b=sb, iters=max(1, round(n_img / sb)),
                                                    eng=eng, dev=dev, max_det=max_det,
                                                    band=0.12 if args.dtype == "fp8" else 0.08)  # stated tolerances
         sys.stdout.flush()

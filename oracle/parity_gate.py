@@ -9,11 +9,12 @@ an unmatched box); then
   ``class_near_tie`` and only when the reference's pre-NMS tensor is supplied, is an argmax flip between two classes
   that the reference itself scores within ``band`` of each other at that anchor;
 * ``max_dconf`` (largest |score difference| over the pairs) must not exceed ``band``;
-* a box present on one side only must be explained by ONE of two stated mechanisms, counted separately:
+* a box present on one side only must be explained by ONE of the stated mechanisms, counted separately:
   ``near_threshold`` -- its score lies within ``band`` of the confidence threshold, so the other side's score fell
-  below it -- or ``nms_flip`` -- a same-class box of the other side overlaps it with IoU within ``iou_band`` of the
-  NMS threshold (or one of its own side's boxes does: the keep / suppress decision flipped);
-* at least ``min_matched_frac`` of the reference's boxes must be paired.
+  below it --, ``nms_flip`` -- a same-class box of the other side overlaps it with IoU within ``iou_band`` of the
+  NMS threshold -- or ``nms_flip_same_side`` -- a PAIRED box of its own side does (see ``parity_gate``);
+* at least ``min_matched_frac`` of the reference's boxes must be paired, and the explained one-sided boxes must stay
+  below ``max_explained_share`` of the detections.
 
 ``band`` is the stated score tolerance of the bf16 storage format against the fp32 reference (tests/test_gpu_net.py);
 ``format_yardstick_ok`` additionally judges a result against what that format costs on the very same images.
@@ -48,44 +49,43 @@ def _argmax_near_tie(y_img: torch.Tensor, r, d, band: float) -> bool:
 
 def parity_gate(ref_dets: List[torch.Tensor], got_dets: List[torch.Tensor], conf: float, iou: float, band: float,
                 iou_match: float = 0.9, iou_band: float = 0.1, min_matched_frac: float = 0.9,
-                ref_y: Optional[torch.Tensor] = None, verbose: bool = False) -> dict:
+                ref_y: Optional[torch.Tensor] = None, verbose: bool = False, max_explained_share: float = 0.25) -> dict:
     """ref_dets / got_dets: per image (n, 6) [x1, y1, x2, y2, conf, cls] score-descending.  Returns the statistics
-    dict with ``ok``."""
+    dict with ``ok``.
+
+    One-sided boxes are classified AFTER the pairing, so that an explanation can ask whether a neighbour has a partner:
+      near_threshold      score within ``band`` of ``conf`` (the other side's score fell below the threshold);
+      nms_flip            a same-class box of the OTHER side overlaps it with IoU >= iou - iou_band: over there that box is
+                          (or is close to being) its suppressor.  No upper bound is needed: from iou_match up the two
+                          would have been paired, unless that box has a better partner;
+      nms_flip_same_side  a same-class box of its OWN side that is PAIRED (its counterpart exists on the other side and can
+                          suppress there) overlaps it with IoU in [iou - iou_band, iou].  (Round 2 accepted any same-side
+                          neighbour between iou - 0.1 and 0.9, paired or not: two kept boxes at IoU 0.6-0.7 are common in
+                          dense scenes, so that excused genuinely missing boxes.)
+    ``explained_share`` = explained one-sided boxes / detections must stay <= ``max_explained_share``: explanations are for
+    the margin.  The default 0.25 is what the bf16 storage FORMAT itself needs on the synthetic cls_gain-8 head, whose scores
+    crowd the threshold (oracle bf16-storage mode vs fp32 oracle, no kernel involved: 0.16-0.21 over five seeds of 8 images);
+    the e4m3 gates state their own cap.  ``count_bias`` = det / ref - 1 is reported (bf16 storage keeps slightly more
+    boxes than fp32 on the synthetic head: scores cluster at the threshold)."""
     st = dict(ref=0, det=0, matched=0, class_mismatch=0, class_near_tie=0, unexplained=0, near_threshold=0, nms_flip=0,
-              max_dconf=0.0)
+              nms_flip_same_side=0, max_dconf=0.0)
     dconfs: List[float] = []
     for img, (ref, det) in enumerate(zip(ref_dets, got_dets)):
         ref, det = ref.tolist(), det.tolist()
         st["ref"] += len(ref)
         st["det"] += len(det)
-        used = set()
-
-        def one_sided(box, same_side, other_side):
-            if box[4] <= conf + band:
-                st["near_threshold"] += 1
-                return
-            flip = any(o is not box and o[5] == box[5] and iou - iou_band <= box_iou1(o, box) < iou_match
-                       for o in list(other_side) + list(same_side))
-            if flip:
-                st["nms_flip"] += 1
-            else:
-                st["unexplained"] += 1
-                if verbose:
-                    near = max(((box_iou1(o, box), o[4], o[5]) for o in other_side), default=None)
-                    print("unexplained", [round(v, 3) for v in box], "nearest on the other side (iou, conf, cls)", near)
-
-        for r in ref:
+        pair_of_ref, pair_of_det = {}, {}
+        for i, r in enumerate(ref):
             best, hit = iou_match, None
             for j, d in enumerate(det):
-                if j in used:
+                if j in pair_of_det:
                     continue
                 v = box_iou1(d, r)
                 if v >= best:
                     best, hit = v, j
             if hit is None:
-                one_sided(r, ref, det)
                 continue
-            used.add(hit)
+            pair_of_ref[i], pair_of_det[hit] = hit, i
             st["matched"] += 1
             dconfs.append(abs(det[hit][4] - r[4]))
             if det[hit][5] != r[5]:
@@ -93,9 +93,28 @@ def parity_gate(ref_dets: List[torch.Tensor], got_dets: List[torch.Tensor], conf
                     st["class_near_tie"] += 1
                 else:
                     st["class_mismatch"] += 1
-        for j, d in enumerate(det):
-            if j not in used:
-                one_sided(d, det, ref)
+
+        def one_sided(k, same_side, same_pairs, other_side):
+            box = same_side[k]
+            if box[4] <= conf + band:
+                st["near_threshold"] += 1
+            elif any(o[5] == box[5] and box_iou1(o, box) >= iou - iou_band for o in other_side):
+                st["nms_flip"] += 1  # (below iou_match by construction, or that box is taken by a better partner)
+            elif any(q != k and q in same_pairs and o[5] == box[5] and iou - iou_band <= box_iou1(o, box) <= iou
+                     for q, o in enumerate(same_side)):
+                st["nms_flip_same_side"] += 1
+            else:
+                st["unexplained"] += 1
+                if verbose:
+                    near = max(((box_iou1(o, box), o[4], o[5]) for o in other_side), default=None)
+                    print("unexplained", [round(v, 3) for v in box], "nearest on the other side (iou, conf, cls)", near)
+
+        for i in range(len(ref)):
+            if i not in pair_of_ref:
+                one_sided(i, ref, pair_of_ref, det)
+        for j in range(len(det)):
+            if j not in pair_of_det:
+                one_sided(j, det, pair_of_det, ref)
     if dconfs:
         t = torch.tensor(dconfs)
         st["max_dconf"] = round(float(t.max()), 4)
@@ -103,8 +122,13 @@ def parity_gate(ref_dets: List[torch.Tensor], got_dets: List[torch.Tensor], conf
         st["p99_dconf"] = round(float(t.kthvalue(max(1, int(0.99 * len(dconfs)))).values), 4)
     st["matched_frac"] = round(st["matched"] / max(1, st["ref"]), 4)
     st["score_band"] = band
+    explained = st["near_threshold"] + st["nms_flip"] + st["nms_flip_same_side"]
+    st["explained_share"] = round(explained / max(1, st["det"]), 4)
+    st["max_explained_share"] = max_explained_share
+    st["count_bias"] = round(st["det"] / max(1, st["ref"]) - 1.0, 4)
     st["ok"] = bool(st["class_mismatch"] == 0 and st["unexplained"] == 0 and st["matched"] > 0
-                    and st["max_dconf"] <= band and st["matched_frac"] >= min_matched_frac)
+                    and st["max_dconf"] <= band and st["matched_frac"] >= min_matched_frac
+                    and st["explained_share"] <= max_explained_share)
     return st
 
 
@@ -122,6 +146,8 @@ def format_yardstick_ok(got: dict, fmt: dict, band: float) -> dict:
     checks = {
         "class_exact": got["class_mismatch"] == 0,
         "nothing_unexplained": got["unexplained"] <= fmt["unexplained"],
+        "explained_share_vs_format": got.get("explained_share", 0.0) <= max(got.get("max_explained_share", 0.25),
+                                                                              fmt.get("explained_share", 0.0) + 0.05),
         "max_dconf_in_band": got["max_dconf"] <= band,
         "max_dconf_vs_format": got["max_dconf"] <= 1.5 * fmt["max_dconf"] + 0.01,
         "matched_frac_vs_format": got["matched_frac"] >= min(0.9, fmt["matched_frac"] - 0.05),

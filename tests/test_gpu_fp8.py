@@ -154,7 +154,8 @@ def test_fp8_end_to_end_640_vs_reference_golden(gpu_device, golden):
     assert dscore <= FP8_SCORE_ATOL
     det = hops.non_max_suppression(y, 0.25, 0.7)[0].cpu()
     ref = torch.from_numpy(golden["net_n_640_det0"])
-    stats = parity_gate([ref], [det], 0.25, 0.7, band=FP8_SCORE_ATOL, min_matched_frac=0.75, verbose=True)
+    stats = parity_gate([ref], [det], 0.25, 0.7, band=FP8_SCORE_ATOL, min_matched_frac=0.75, verbose=True,
+                        max_explained_share=0.6)  # (the e4m3 mode's stated cap; bf16 gates use 0.2)
     print("fp8 e2e 640 match:", stats)
     assert stats["class_mismatch"] == 0, "class indices of matched boxes must be bit-exact"
     assert stats["ok"], stats

@@ -690,3 +690,25 @@ def test_full_size_properties(gpu_device, scale, B):
         iou_m = inter / (area[:, None] + area[None, :] - inter)
         iou_m.fill_diagonal_(0)
         assert float((iou_m * same).max()) <= iou + 1e-4
+
+
+def test_pre_nms_at_realistic_logit_scale_vs_reference_golden(gpu_device):
+    """SURVEY 8(d)'s proposed pre-NMS tolerance -- |dscore| <= 0.02 -- against the REFERENCE's own output
+    (tests/golden/golden_gain1_v1.npz, cls_gain = 1: class logits of std 0.3-0.6).  The HIP path (bf16 storage, fp32
+    accumulate, fp32 decode) is inside it with a factor of two to spare; the 0.08 band used with the cls_gain = 8
+    vectors is that synthetic head's.  Boxes in strides (DFL logits are stored in bf16: up to ~0.2 bins)."""
+    import numpy as np
+    from pathlib import Path
+
+    G = np.load(Path(__file__).resolve().parent / "golden" / "golden_gain1_v1.npz")
+    sd = synth_state_dict("n", int(G["seed"]), cls_bias=list(G["bias"]), cls_gain=float(G["gain"]))
+    x8 = torch.from_numpy(G["x8"]).to(gpu_device)
+    ref = torch.from_numpy(G["y"])
+    eng = _engine("n", sd, 1, 320, 320, gpu_device)
+    y = eng.forward(x8).cpu()
+    st = torch.tensor([float(s) for s in (8, 16, 32) for _ in range((320 // s) ** 2)])
+    dscore = float((y[:, 4:] - ref[:, 4:]).abs().max())
+    dbox = float(((y[:, :4] - ref[:, :4]).abs() / st).max())
+    print("cls_gain 1: HIP vs reference golden: max |dscore|", dscore, "max box error (strides)", dbox)
+    assert dscore <= 0.02, dscore
+    assert dbox <= BOX_ATOL_STRIDES, dbox
