@@ -633,6 +633,22 @@ def main():
                     res["api_images_per_sec"] = round(B * n_api / (time.perf_counter() - t3), 1)
                     res["api_note"] = ("YOLOLite.predict(uint8 tensor resident in HBM) incl. list[Results] construction and its one "
                                        "host sync per batch; one batch at a time")
+                    # the same API on a source of MANY batches (predict(stream=True) on a LoadTensorBatches loader): the
+                    # predictor keeps S engine slots in flight and yields batch k while k + 1 .. run
+                    from yololite_amd.data.loaders import LoadTensorBatches
+
+                    os.environ["YL_PREDICT_INFLIGHT"] = str(S)
+                    n_st = max(10 * S, 100)  # fill and drain of the S batches in flight ~5 % of the run
+                    src = LoadTensorBatches([xs[j % len(xs)] for j in range(n_st)])
+                    for _ in api.predict(LoadTensorBatches(xs[: min(len(xs), S)]), stream=True, **kw):
+                        pass  # slots + graphs of the stream path
+                    torch.cuda.synchronize(dev)
+                    t4 = time.perf_counter()
+                    n_seen = sum(1 for _ in api.predict(src, stream=True, **kw))
+                    torch.cuda.synchronize(dev)
+                    res["api_stream_images_per_sec"] = round(n_seen / (time.perf_counter() - t4), 1)
+                    res["api_stream_note"] = (f"YOLOLite.predict(LoadTensorBatches of {n_st} resident uint8 batches, stream=True): {S} "
+                                              "batches in flight, one Results object per image built while the next batches run")
                     sc1 = torch.tensor([[0.0, 0.0, 1.0, float(W), float(H)]] * B, dtype=torch.float32, device=dev)
                     o_ref, c_ref = eng.detect(x8, conf, iou, max_det=max_det, graph=False, scale=sc1)  # predictor.py:125 clips
                     res["api_equals_engine"] = all(torch.equal(r.boxes.data, o_ref[i, : int(c_ref[i])]) for i, r in enumerate(r_api))

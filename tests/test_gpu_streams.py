@@ -39,3 +39,33 @@ def test_hot_path_on_a_masked_stream_is_bit_identical(gpu_device):
     assert torch.equal(cnt, cref)
     for i, n in enumerate(cnt.tolist()):  # rows past the count are padding (not written by the eager form)
         assert n > 0 and torch.equal(out[i, :n], ref[i, :n])
+
+
+def test_predict_stream_pipelines_batches_bit_identically(gpu_device, monkeypatch):
+    """predict(stream=True) on a source of several batches keeps YL_PREDICT_INFLIGHT engine slots in flight (reference
+    generator: predictor.py:149-229, one batch at a time).  Every image's boxes must equal what predict() returns for
+    its batch alone, bit for bit, in source order, with the right paths."""
+    from yololite_amd import YOLOLite
+    from yololite_amd.data.loaders import LoadTensorBatches
+
+    monkeypatch.setenv("YL_PREDICT_INFLIGHT", "3")
+    g = torch.Generator().manual_seed(5)
+    batches = [torch.randint(0, 256, (2, 3, 96, 128), generator=g, dtype=torch.uint8).to(gpu_device) for _ in range(7)]
+    model = YOLOLite("yolo11n.yaml")
+    kw = dict(conf=0.001, iou=0.7, device=str(gpu_device), save=False, verbose=False)
+    alone = [model.predict(b, **kw) for b in batches]
+    gen = model.predict(LoadTensorBatches(batches), stream=True, **kw)
+    got = list(gen)
+    assert len(got) == 14
+    k = 0
+    for rs in alone:
+        for r in rs:
+            assert torch.equal(got[k].boxes.data, r.boxes.data), k
+            assert got[k].path == f"image{k}.jpg"
+            k += 1
+    assert sum(len(r.boxes) for r in got) > 0
+    # and a second pass through the same slots / graphs with other inputs
+    again = list(model.predict(LoadTensorBatches(batches[::-1]), stream=True, **kw))
+    for j, rs in enumerate(alone[::-1]):
+        for i, r in enumerate(rs):
+            assert torch.equal(again[2 * j + i].boxes.data, r.boxes.data)

@@ -273,3 +273,19 @@ def test_uint8_scale_by_reciprocal_is_exact_in_bf16():
     div = torch.from_numpy((x / np.float32(255.0)).astype(np.float32)).to(torch.bfloat16)
     mul = torch.from_numpy((x * np.float32(1.0 / 255.0)).astype(np.float32)).to(torch.bfloat16)
     assert torch.equal(div, mul)
+
+
+def test_tensor_batches_loader():
+    """LoadTensorBatches: a sequence of BCHW tensors, each one batch, with running image names; per-element checks as LoadTensor."""
+    from yololite_amd.data import load_inference_source
+    from yololite_amd.data.loaders import LoadTensorBatches
+
+    ds = load_inference_source(LoadTensorBatches([torch.rand(2, 3, 32, 64), torch.rand(2, 3, 32, 64), torch.rand(1, 3, 32, 64)]))
+    assert ds.source_type.tensor and len(ds) == 3 and not getattr(ds, "single_batch", False)
+    got = list(ds)
+    assert [p for b in got for p in b[0]] == [f"image{i}.jpg" for i in range(5)]
+    assert got[2][1].shape == (1, 3, 32, 64)
+    with pytest.raises(ValueError):
+        LoadTensorBatches([torch.rand(1, 3, 30, 64)])
+    with pytest.raises(ValueError):
+        LoadTensorBatches([])

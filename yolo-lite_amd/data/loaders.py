@@ -43,6 +43,7 @@ class _SingleBatch:
     fill ``im0`` (the batch), ``paths`` and ``bs`` through ``_accept``."""
 
     mode = "image"
+    single_batch = True  # nothing for the predictor to pipeline
 
     def _accept(self, batch, paths):
         self.im0, self.paths, self.bs = batch, list(paths), len(paths)
@@ -83,6 +84,30 @@ class LoadTensor(_SingleBatch):
                 LOGGER.warning(f"WARNING torch.Tensor inputs should be normalized 0.0-1.0 but max value is {top}. Dividing input by 255.")
                 t = t.float() / 255.0
         return t
+
+
+class LoadTensorBatches:
+    """A SEQUENCE of BCHW tensors, each one batch (same checks as ``LoadTensor`` per element).  Not in the reference,
+    whose tensor source is always a single batch (loaders.py:539-544): it exists so that ``predict(stream=True)`` has
+    something to pipeline when the images already live on the device -- pass an instance as ``source`` (like every
+    constructed loader, build.py:150-152)."""
+
+    mode = "image"
+    source_type = SourceTypes(tensor=True)
+
+    def __init__(self, batches) -> None:
+        self.batches = [LoadTensor.checked(t) for t in batches]
+        if not self.batches:
+            raise ValueError("LoadTensorBatches needs at least one BCHW tensor")
+        self.bs = int(self.batches[0].shape[0])
+
+    def __iter__(self):
+        for k, t in enumerate(self.batches):
+            n = int(t.shape[0])
+            yield [f"image{k * self.bs + i}.jpg" for i in range(n)], t, [""] * n
+
+    def __len__(self):
+        return len(self.batches)
 
 
 class LoadPilAndNumpy(_SingleBatch):
@@ -167,4 +192,4 @@ def autocast_list(source):
     return files
 
 
-LOADERS = (LoadTensor, LoadPilAndNumpy, LoadImagesAndVideos)
+LOADERS = (LoadTensor, LoadTensorBatches, LoadPilAndNumpy, LoadImagesAndVideos)

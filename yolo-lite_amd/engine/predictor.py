@@ -149,6 +149,11 @@ class DetectionPredictor:
 
     def _detect_fused(self, im, orig_imgs):
         """inference + postprocess in one pass: the (B, 4+nc, A) tensor is never materialised."""
+        return self._harvest_fused(self._launch_fused(im, orig_imgs, slot=0, stream=None))
+
+    def _launch_fused(self, im, orig_imgs, slot: int, stream):
+        """Enqueue one batch on engine slot ``slot`` (on ``stream`` when given) and return what ``_harvest_fused`` needs;
+        no host synchronisation."""
         b, _, h, w = im.shape
         eng = self.model.engine_for(b, h, w, calib=im.contiguous())
         shapes, imgs, scale = self._shapes_and_scale(im, orig_imgs, b, im.device)
@@ -156,15 +161,56 @@ class DetectionPredictor:
         # input and the scale table are staged into engine-owned buffers whose addresses the graph baked in
         # (YL_PREDICT_GRAPH=0: the same kernels launched one by one)
         graph = os.environ.get("YL_PREDICT_GRAPH", "1") != "0"
-        out, cnt = eng.detect(im.contiguous(), self.args.conf, self.args.iou, max_det=self.args.max_det,
-                              classes=self.args.classes, agnostic=self.args.agnostic_nms, scale=scale, graph=graph,
-                              stage=graph)
-        if graph:  # engine-owned output buffers are overwritten by the next call: ONE copy of the padded records
-            out = out.clone()
-        counts = cnt.tolist()  # the one host sync of the batch
+        imc = im.contiguous()
+
+        def go():
+            out, cnt = eng.detect(imc, self.args.conf, self.args.iou, max_det=self.args.max_det,
+                                  classes=self.args.classes, agnostic=self.args.agnostic_nms, scale=scale, graph=graph,
+                                  stage=graph, slot=slot)
+            # engine-owned output buffers are overwritten by the slot's next batch: ONE copy of the padded records,
+            # ordered behind this batch on its stream
+            if not graph:
+                return out, cnt
+            if stream is None:
+                return out.clone(), cnt
+            # the per-image counts travel to PINNED host memory on the batch's own stream: the harvest then waits for the
+            # batch's event only (a .tolist() of the device tensor is a blocking copy on the null stream, which queued
+            # behind every batch in flight: 1.2 ms per batch)
+            pins = self.__dict__.setdefault("_cnt_pins", {})
+            key = (slot, int(cnt.numel()))
+            if key not in pins:
+                pins[key] = torch.empty(cnt.numel(), dtype=cnt.dtype, pin_memory=True)
+            pins[key].copy_(cnt, non_blocking=True)
+            return out.clone(), pins[key]
+
+        ev = None
+        if stream is None:
+            out, cnt = go()
+        else:
+            if os.environ.get("YL_PREDICT_NOWAIT", "0") != "1":  # (development switch)
+                stream.wait_stream(torch.cuda.current_stream(im.device))  # the input was produced on the caller's stream
+            with torch.cuda.stream(stream):
+                out, cnt = go()
+                ev = torch.cuda.Event()
+                ev.record(stream)
+            imc.record_stream(stream)
+        return dict(out=out, cnt=cnt, ev=ev, shapes=shapes, imgs=imgs, paths=self.batch[0], n=b)
+
+    def _harvest_fused(self, job):
+        if job["ev"] is not None:
+            job["ev"].synchronize()
+        counts = job["cnt"].tolist()  # the one host sync of the batch
         self.last_preds = None
-        names, paths = self.model.names, self.batch[0]
-        return [Results(imgs[i], path=paths[i], names=names, boxes=out[i, : counts[i]], orig_shape=shapes[i]) for i in range(b)]
+        names, out, shapes, imgs, paths = self.model.names, job["out"], job["shapes"], job["imgs"], job["paths"]
+        return [Results(imgs[i], path=paths[i], names=names, boxes=out[i, : counts[i]], orig_shape=shapes[i])
+                for i in range(job["n"])]
+
+    def _inflight(self) -> int:
+        """Batches kept in flight by ``stream_inference`` on sources of more than one batch (YL_PREDICT_INFLIGHT, default
+        4; export GPU_MAX_HW_QUEUES to the same number before the first GPU call: one hardware queue per stream)."""
+        n = int(os.environ.get("YL_PREDICT_INFLIGHT", "4"))
+        dev = torch.device(self.device) if self.device is not None else None
+        return max(1, n) if (dev is not None and dev.type == "cuda") else 1
 
     # ------------------------------------------------------------------ driver
     def __call__(self, source=None, model=None, stream=False, *args, **kwargs):
@@ -197,37 +243,67 @@ class DetectionPredictor:
             if self.args.save_txt:
                 (self.save_dir / "labels").mkdir(parents=True, exist_ok=True)
             self.seen, self.batch = 0, None
-            profilers = (ops.Profile(device=self.device), ops.Profile(device=self.device),
-                         ops.Profile(device=self.device))
             im = None
+            # Sources of several batches are PIPELINED on the fused path: up to S batches are in flight on S engine slots /
+            # HIP streams, batch k's Results are built and yielded while batches k + 1 .. k + S - 1 run (the reference
+            # generator, predictor.py:149-229, finishes a batch before it touches the next).  Same kernels, same slots'
+            # buffers as one batch at a time: results are bit-identical.
+            S = self._inflight() if self._can_fuse() and not getattr(self.dataset, "single_batch", False) else 1
+            if S > 1 and len(self.__dict__.setdefault("_streams", [])) < S:
+                self._streams = [torch.cuda.Stream(device=self.device) for _ in range(S)]
+            # stage timers: the reference's Profile synchronises the DEVICE around every stage (ops.py:59-63), which would
+            # serialise the batches in flight -- with S > 1 they are plain wall-clock timers (a batch's "inference" time is
+            # then its enqueue + the wait for its results)
+            pdev = self.device if S == 1 else None
+            profilers = (ops.Profile(device=pdev), ops.Profile(device=pdev), ops.Profile(device=pdev))
+            pending, k = [], 0
+
+            def finish(job):
+                self.batch = job["batch"]
+                paths, im0s, s = self.batch
+                with profilers[1]:
+                    self.results = self._harvest_fused(job)
+                profilers[1].dt += job["t_launch"]
+                profilers[2].dt = 0.0
+                return self._emit(paths, im0s, s, job["im"], profilers, job["t_pre"])
+
             for self.batch in self.dataset:
                 paths, im0s, s = self.batch
                 with profilers[0]:
                     im = self.preprocess(im0s)
                 if self._can_fuse():
                     with profilers[1]:  # network + fused decode / NMS / box rescale, one host sync
-                        self.results = self._detect_fused(im, im0s)
-                    profilers[2].dt = 0.0
-                else:
-                    with profilers[1]:
-                        preds = self.inference(im, *args, **kwargs)
-                    with profilers[2]:
-                        self.results = self.postprocess(preds, im, im0s)
-                n = len(im0s)
-                for i in range(n):
-                    self.seen += 1
-                    self.results[i].speed = {"preprocess": profilers[0].dt * 1e3 / n,
-                                             "inference": profilers[1].dt * 1e3 / n,
-                                             "postprocess": profilers[2].dt * 1e3 / n}
-                    if self.args.verbose or self.args.save_txt or self.args.save or self.args.save_crop:
-                        s[i] += self.write_results(i, Path(paths[i]), im, s)
-                if self.args.verbose:
-                    LOGGER.info("\n".join(s))
-                yield from self.results
+                        job = self._launch_fused(im, im0s, slot=k % S, stream=self._streams[k % S] if S > 1 else None)
+                    job.update(batch=self.batch, im=im, t_launch=profilers[1].dt, t_pre=profilers[0].dt)
+                    pending.append(job)
+                    k += 1
+                    if len(pending) >= S:
+                        yield from finish(pending.pop(0))
+                    continue
+                with profilers[1]:
+                    preds = self.inference(im, *args, **kwargs)
+                with profilers[2]:
+                    self.results = self.postprocess(preds, im, im0s)
+                yield from self._emit(paths, im0s, s, im, profilers, profilers[0].dt)
+            while pending:
+                yield from finish(pending.pop(0))
         if self.args.verbose and self.seen and im is not None:
             t = tuple(x.t / self.seen * 1e3 for x in profilers)
             LOGGER.info("Speed: %.1fms preprocess, %.1fms inference, %.1fms postprocess per image at shape "
                         f"{(min(self.args.batch, self.seen), 3, *im.shape[2:])}" % t)
+
+    def _emit(self, paths, im0s, s, im, profilers, t_pre):
+        """Per-image bookkeeping of one finished batch (speed, sinks, log line); returns its Results."""
+        n = len(im0s)
+        for i in range(n):
+            self.seen += 1
+            self.results[i].speed = {"preprocess": t_pre * 1e3 / n, "inference": profilers[1].dt * 1e3 / n,
+                                     "postprocess": profilers[2].dt * 1e3 / n}
+            if self.args.verbose or self.args.save_txt or self.args.save or self.args.save_crop:
+                s[i] += self.write_results(i, Path(paths[i]), im, s)
+        if self.args.verbose:
+            LOGGER.info("\n".join(s))
+        return self.results
 
     def write_results(self, i, p, im, s):
         """Log line (and optional labels/*.txt) for image i (reference predictor.py:248-285)."""
