@@ -279,8 +279,9 @@ def measured_traffic(kernel, cfg):
             continue
         for fam, v in t.items():
             if not fam.startswith("_") and kernel in fam.split("+"):
-                best = (v["read_bytes_per_launch"] + v["write_bytes_per_launch"], f"{f.name}: {t.get('_source', '')}")
-    return best if best else (None, None)
+                best = (v["read_bytes_per_launch"] + v["write_bytes_per_launch"], f"{f.name}: {t.get('_source', '')}",
+                        v.get("avg_launch_us_rocprof"))
+    return best if best else (None, None, None)
 
 
 def roofline_from_profile(rows, batch, cfg):
@@ -307,10 +308,18 @@ def roofline_from_profile(rows, batch, cfg):
             "launches_per_step": a["launches"], "avg_launch_us": round(a["ms"] * 1e3 / a["launches"], 2),
             "mfma_frac": round(mfma_frac, 4), "hbm_frac": round(hbm_frac, 4),
             "algorithmic_bytes_per_launch": round(a["bytes"] / a["launches"])}
-    roof["traffic"], src = measured_traffic(name, cfg)
+    # `frac` divides by the IN-SEQUENCE HIP-event time of a launch (measured live in this run; it includes the ~2.6 us dispatch gap
+    # in front of a dependent launch); the committed rocprofv3 kernel trace gives the kernel-only duration: both are stated
+    roof["time_source"] = "in-sequence HIP events of this run (dispatch gap included)"
+    roof["traffic"], src, us_rp = measured_traffic(name, cfg)
     if src:
         roof["traffic_unit"] = "HBM bytes per launch (PMC)"
         roof["traffic_source"] = src
+    if us_rp:
+        ach = (a["flops"] / a["launches"] / (us_rp * 1e-6) / 1e12) if bound == "mfma" else (a["bytes"] / a["launches"] / (us_rp * 1e-6) / 1e9)
+        roof["avg_launch_us_rocprof"] = us_rp
+        roof["frac_rocprof"] = round(ach / roof["peak"], 4)
+        roof["frac_rocprof_note"] = "same algorithmic work / the committed rocprofv3 kernel-trace duration of the family (profiles/, kernel only)"
     # best single 3x3 layer against the MFMA roof (the north-star target names the fused 3x3 conv)
     best = None
     for r in rows:

@@ -39,6 +39,14 @@ def family(k):
     """rocprofv3 kernel name -> the kernel family names bench.py's roofline uses (yl_engine_op_info)."""
     if k.startswith("conv_kernel<1,"):
         return "conv1x1_mfma"
+    if k.startswith("conv_gemm_kernel"):
+        return "conv1x1_gemm_mfma"
+    if k.startswith("decode_nms_fused"):
+        return "decode_nms_fused"
+    if k.startswith("conv3_reg_kernel"):
+        return "conv3x3_reg_mfma"
+    if k.startswith("dwpw_group_kernel"):
+        return "dw3x3+pw1x1+1x1_mfma[x3]"
     if k.startswith("conv_kernel<3,"):
         return "conv3x3_mfma+conv3x3s2_mfma"   # one template serves both strides
     if k.startswith("conv_f8_kernel<1,"):
@@ -88,6 +96,9 @@ def main():
         shutil.copy(stats[0], dst / f"{tag}_kernel_stats.csv")
     fetch = pmc(src / "pmc_fetch", "FETCH_SIZE")
     write = pmc(src / "pmc_write", "WRITE_SIZE")
+    miss = pmc(src / "pmc_miss", "TCC_MISS_sum")          # L2 misses: 128-byte lines fetched from the fabric (independent of FETCH_SIZE)
+    rdreq = pmc(src / "pmc_miss", "TCC_EA0_RDREQ_sum")
+    rd32 = pmc(src / "pmc_miss", "TCC_EA0_RDREQ_32B_sum")
     mfma_busy = pmc(src / "pmc_mfma", "SQ_VALU_MFMA_BUSY_CYCLES")
     gui = pmc(src / "pmc_mfma", "GRBM_GUI_ACTIVE")
     bench = None
@@ -102,13 +113,19 @@ def main():
         lines += [f"bench (un-profiled run): **{bench['value']} {bench['unit']}**, {bench['ms_per_step']} ms/step, "
                   f"roofline {json.dumps(bench.get('roofline'))}", ""]
     lines += ["HBM columns: FETCH_SIZE / WRITE_SIZE (KiB) from separate `--pmc` passes, averaged per launch; the read",
-              "side is doubled as MI355X_MICROARCH.md prescribes for gfx950.  That correction matches the algorithmic",
-              "bytes of the streaming kernels (1x1 convs, stem = 1.5x by design); for the 3x3 kernels, whose tap-shifted",
-              "fragments are not 128-byte aligned, it probably over-counts by up to 2x.", "",
+              "side is doubled as MI355X_MICROARCH.md prescribes for gfx950.  Round 3 settles whether that also holds for the 3x3",
+              "kernels' tap-shifted loads (round 2: 'probably over-counts by up to 2x'): it does -- see the cross-check columns.", "",
               "MFMA busy: SQ_VALU_MFMA_BUSY_CYCLES (summed over the 1024 SIMDs) / (1024 x GRBM_GUI_ACTIVE / 8 XCDs), from a",
               "separate pass with one batch in flight.", "",
-              "| kernel | calls | avg us | total % | HBM read MB/launch (2 x FETCH_SIZE) | HBM write MB/launch | MFMA busy % |",
-              "|---|---|---|---|---|---|---|"]
+              "Read cross-check (round 3, separate pass): TCC_MISS_sum counts the L2 misses of reads AND writes in 128-byte lines --",
+              "for every kernel below `misses x 128 B` = `2 x FETCH_SIZE + WRITE_SIZE` within 1-2 % (stem2: 92.3 = 39.7 + 52.8;",
+              "c3k2s<2,1>: 158.8 = 53.4 + 105.6; model.3, conv_kernel<3,4,4,true,true>: 251.3 = 225.1 + 26.6), and TCC_EA0_RDREQ x",
+              "128 B equals 2 x FETCH_SIZE too (model.3: 1.76 M requests = 225 MB), none of them 32-byte requests.  So the doubled",
+              "FETCH_SIZE IS the read traffic beyond L2 for the tap-shifted 3x3 loads as well: model.3 (3x3 stride 2, 64 -> 64 @160x160",
+              "-> 80x80, batch 32) really fetches 225 MB for a 105 MB input = 2.14 x (its nine taps sweep a footprint of ~11 MB per XCD",
+              "against 4 MB of L2; the re-reads are served by the Infinity Cache, which these counters include).", "",
+              "| kernel | calls | avg us | total % | HBM read MB/launch (2 x FETCH_SIZE) | read MB/launch (L2 misses x 128 B) | RDREQ M (32 B share) | HBM write MB/launch | MFMA busy % |",
+              "|---|---|---|---|---|---|---|---|---|"]
     for r in rows:
         if float(r["Percentage"]) < 0.05:
             continue
@@ -118,8 +135,10 @@ def main():
         mb = ""
         if k in mfma_busy and gui.get(k):
             mb = f"{100.0 * mfma_busy[k] / (1024.0 * gui[k] / 8.0):.1f}"
+        ms_ = "" if k not in miss else f"{miss[k] * 128 / 1e6:.1f}"
+        rq = "" if k not in rdreq else f"{rdreq[k] / 1e6:.2f} ({100.0 * rd32.get(k, 0.0) / max(rdreq[k], 1.0):.0f} %)"
         lines.append(f"| `{k}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} | "
-                     f"{'' if rd is None else f'{2 * rd * 1024 / 1e6:.1f}'} | {'' if wr is None else f'{wr * 1024 / 1e6:.1f}'} | {mb} |")
+                     f"{'' if rd is None else f'{2 * rd * 1024 / 1e6:.1f}'} | {ms_} | {rq} | {'' if wr is None else f'{wr * 1024 / 1e6:.1f}'} | {mb} |")
     (dst / f"{tag}_summary.md").write_text("\n".join(lines) + "\n")
     # per-family HBM bytes per launch (launch-weighted over the template instances), read by bench.py
     fam = {}
@@ -128,13 +147,15 @@ def main():
         f = family(k)
         if f is None or k not in fetch or k not in write:
             continue
-        a = fam.setdefault(f, dict(launches=0, read=0.0, write=0.0))
+        a = fam.setdefault(f, dict(launches=0, read=0.0, write=0.0, ns=0.0))
         n = int(r["Calls"])
         a["launches"] += n
         a["read"] += n * 2 * fetch[k] * 1024
         a["write"] += n * write[k] * 1024
+        a["ns"] += n * float(r["AverageNs"])
     traffic = {f: {"read_bytes_per_launch": round(a["read"] / a["launches"]),
                    "write_bytes_per_launch": round(a["write"] / a["launches"]),
+                   "avg_launch_us_rocprof": round(a["ns"] / a["launches"] / 1e3, 2),  # kernel-trace duration, launch-weighted
                    "launches_in_trace": a["launches"]} for f, a in fam.items()}
     traffic["_source"] = (f"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of bench.py, {tag}; "
                           "read side = 2 x FETCH_SIZE (gfx950 correction, MI355X_MICROARCH.md)")
