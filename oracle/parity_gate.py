@@ -142,15 +142,21 @@ def format_yardstick_ok(got: dict, fmt: dict, band: float) -> dict:
     than each agrees with fp32 (measured: profiles/r02_parity_probe.json); the meaningful statement is that the HIP
     path's error has the SIZE of the format's own.  Requirements: classes of paired boxes bit-exact, nothing
     unexplained, max |dconf| within ``band`` AND within 1.5 x the format's (+0.01), paired fraction no more than 0.05
-    below the format's."""
+    (or two binomial standard deviations on a small sample) below the format's."""
+    # sampling slack: on a handful of boxes (config 1: one image, ~30 boxes in clusters of near-identical candidates) one
+    # pairing more or less moves the fractions by several per cent -- two standard deviations of a binomial share, at least 0.05
+    n_ref, n_det = max(1, got.get("ref", 1)), max(1, got.get("det", 1))
+    f = min(max(fmt["matched_frac"], 0.0), 1.0)
+    slack_m = max(0.05, 2.0 * (f * (1.0 - f) / n_ref) ** 0.5)
+    slack_e = max(0.05, 2.0 / n_det ** 0.5)
     checks = {
         "class_exact": got["class_mismatch"] == 0,
         "nothing_unexplained": got["unexplained"] <= fmt["unexplained"],
         "explained_share_vs_format": got.get("explained_share", 0.0) <= max(got.get("max_explained_share", 0.25),
-                                                                              fmt.get("explained_share", 0.0) + 0.05),
+                                                                              fmt.get("explained_share", 0.0) + slack_e),
         "max_dconf_in_band": got["max_dconf"] <= band,
         "max_dconf_vs_format": got["max_dconf"] <= 1.5 * fmt["max_dconf"] + 0.01,
-        "matched_frac_vs_format": got["matched_frac"] >= min(0.9, fmt["matched_frac"] - 0.05),
+        "matched_frac_vs_format": got["matched_frac"] >= min(0.9, fmt["matched_frac"] - slack_m),
         "paired_something": got["matched"] > 0,
     }
     return {"ok": all(checks.values()), "checks": checks, "format_max_dconf": fmt["max_dconf"],

@@ -113,8 +113,14 @@ __device__ __forceinline__ void fetch_b(const ConvArgs& a, __amdgpu_buffer_rsrc_
     off = ks < a.ksteps ? (unsigned)tap_offset<KS>(a, tap) + (unsigned)(kk * 4) * a.in_plane : OOB_K;
   } else {
     const int k8 = ks * 4 + g;
-    const int tap = KS == 1 ? 0 : fastdiv(k8, a.cg, a.magic_cg);
-    const int c8 = k8 - tap * a.cg;
+    int tap, c8;
+    if (KS == 3 && a.kord) {  // plane-major: the nine taps of a plane are consecutive k-groups (wave-uniform choice)
+      c8 = (int)__umulhi((unsigned)k8, 477218589u);  // k8 / 9
+      tap = k8 - 9 * c8;
+    } else {
+      tap = KS == 1 ? 0 : fastdiv(k8, a.cg, a.magic_cg);
+      c8 = k8 - tap * a.cg;
+    }
     off = k8 < a.ntaps * a.cg ? (unsigned)tap_offset<KS>(a, tap) + (unsigned)c8 * a.in_plane : OOB_K;
   }
 #pragma unroll

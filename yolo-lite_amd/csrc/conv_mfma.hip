@@ -589,6 +589,14 @@ int conv_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo,
   c->gws = (int)(((long long)c->npatches + 4 * ppw - 1) / (4 * ppw));
   c->name = k == 3 ? (stride == 2 ? "conv3x3s2_mfma" : "conv3x3_mfma") : "conv1x1_mfma";
   c->gemm = 0;
+  // K order of the stride-2 3x3 convs with >= 64 input channels (layers 3, 5, 7, 17, 20): PLANE-major.  In tap-major order a
+  // workgroup sweeps its whole input footprint (8-32 planes) once per tap, nine times in all, with a reuse distance far beyond
+  // L1 and -- 64 workgroups per XCD -- beyond the 4 MB L2: rocprofv3 (profiles/r03_summary.md) shows model.3 fetching 225 MB for
+  // a 105 MB input.  Plane-major touches one plane's footprint with all nine taps back to back and never again.  Costs the
+  // per-lane (tap, plane) arithmetic of the non-UNIFORM fetch (~10 VALU per k-step); the sum order changes (same operands).
+  static const int kord_min_cin = getenv("YL_CONV_KORD") ? atoi(getenv("YL_CONV_KORD")) : 64;  // 0: never
+  c->kord = (kord_min_cin > 0 && k == 3 && stride == 2 && Cin >= kord_min_cin && MT <= 5 && !g_even_only) ? 1 : 0;
+  if (c->kord) c->uniform = 0;
   conv3_tile_choose(batch, Cin, Cout, k, stride, Ho, Wo, post, c);  // 3x3 s1 layers that fit: input tile in LDS
   conv3_reg_choose(batch, Cin, Cout, k, stride, Ho, Wo, post, c);   // ... or with the filter in registers
   conv3_pair_choose(batch, Cin, Cout, k, stride, Ho, Wo, post, c);  // ... 64 -> 64: filter halves in two waves per SIMD
@@ -625,7 +633,7 @@ void conv_pack_weights(const float* w, int Cout, int Cin_w, int k, const ConvCon
         for (int lane = 0; lane < 64; ++lane) {
           const int co = cb * c.MT * 16 + chan_in_block(c.MT, mt, (lane & 15) >> 2, lane & 3);
           const int k8 = ks * 4 + (lane >> 4);
-          const int tap = k8 / c.cg, c8 = k8 % c.cg;
+          const int tap = c.kord ? k8 % c.ntaps : k8 / c.cg, c8 = c.kord ? k8 / c.ntaps : k8 % c.cg;
           for (int j = 0; j < 8; ++j, ++o) {
             const int ci = c8 * 8 + j;
             if (co < Cout && tap < c.ntaps && ci < Cin_w) {
@@ -837,6 +845,7 @@ static int conv_prepare(const ConvConfig& cfg, ConvArgs& a, int batch) {
   a.ksteps = cfg.ksteps;
   a.kchunk = cfg.kchunk;
   a.ntaps = cfg.ntaps;
+  a.kord = cfg.kord;
   a.kkn = cfg.cg >> 2;
   a.magic_kkn = magic_of(cfg.cg >> 2);
   a.magic_cg = magic_of(cfg.cg);
