@@ -166,7 +166,7 @@ def test_uint8_and_fp16_inputs(gpu_device, golden):
     assert torch.equal(y_u8, y_f32)  # both round x/255 to the same bf16
     # fp16 inputs round x/255 twice (fp16 then bf16): one-ulp input changes, propagated chaotically like any other bf16 rounding
     # difference -- the result stays inside the format tolerances (boxes in strides, scores)
-    st = torch.tensor(_stride_per_anchor(64, 64), device=gpu_device)
+    st = _stride_per_anchor(64, 64).to(gpu_device)
     assert float(((y_f16 - y_f32)[:, :4].abs() / st).max()) < BOX_ATOL_STRIDES
     assert float((y_f16 - y_f32)[:, 4:].abs().max()) < SCORE_ATOL
 
