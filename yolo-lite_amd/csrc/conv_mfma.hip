@@ -288,30 +288,41 @@ __device__ __forceinline__ void dwpw_body(const ConvArgs& a, int block) {
     const u32x4* dwtab = reinterpret_cast<const u32x4*>(a.dw_wpk);
     unsigned char* tb = reinterpret_cast<unsigned char*>(tile);
     const int npp = live ? (a.cg >> 1) : 0;
-    for (int pp = 0; pp < npp; ++pp) {
-      const u32x4 t = dwtab[pp * 64 + lane];  // k-steps 0..4 as bf16 halves: {s0 | s1 << 16, s2 | s3 << 16, s4, -}
-      const f32x4 bv = *reinterpret_cast<const f32x4*>(a.dw_b + pp * 16 + 4 * g);
-      const unsigned poff = (unsigned)(2 * pp) * a.in_plane;
+    // NT == 1: the tap fragments, the packed taps and the bias of channel block pp + 1 are requested BEFORE block pp is
+    // computed (two named register sets): a deep launch on a small map (256 channels @20x20: 16 blocks per workgroup, the
+    // chip half empty) is a chain of memory round trips otherwise (24.1 -> 21.2 us).  A block index past the end is
+    // clamped: the loads repeat the last block's.
+    struct DwIn {
+      u32x4 t;       // k-steps 0..4 as bf16 halves: {s0 | s1 << 16, s2 | s3 << 16, s4, -}
+      f32x4 bv;
       bf16x8 xb[NT][5];
+    };
+    auto request = [&](int pp, DwIn& q) __attribute__((always_inline)) {
+      pp = min(pp, npp - 1);
+      q.t = dwtab[pp * 64 + lane];
+      q.bv = *reinterpret_cast<const f32x4*>(a.dw_b + pp * 16 + 4 * g);
+      const unsigned poff = (unsigned)(2 * pp) * a.in_plane;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int s5 = 0; s5 < 5; ++s5)
-          xb[nt][s5] = __builtin_bit_cast(
+          q.xb[nt][s5] = __builtin_bit_cast(
               bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rin, ((a.dbg & 1) ? OOB_LANE : Pp.base[nt]) + poff + toff[s5], 0, 0));
+    };
+    auto compute = [&](int pp, const DwIn& q) __attribute__((always_inline)) {
       f32x4 dacc[NT];
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) dacc[nt] = bv;
+      for (int nt = 0; nt < NT; ++nt) dacc[nt] = q.bv;
 #pragma unroll
       for (int s5 = 0; s5 < 5; ++s5) {
-        const unsigned w16 = (s5 & 1) ? (t[s5 >> 1] >> 16) : (t[s5 >> 1] & 0xffffu);
+        const unsigned w16 = (s5 & 1) ? (q.t[s5 >> 1] >> 16) : (q.t[s5 >> 1] & 0xffffu);
         const unsigned both = w16 | (w16 << 16);
         u32x4 wv;
 #pragma unroll
         for (int d = 0; d < 4; ++d) wv[d] = both & selm[d];
         const bf16x8 wa = __builtin_bit_cast(bf16x8, wv);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) dacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, xb[nt][s5], dacc[nt], 0, 0, 0);
+        for (int nt = 0; nt < NT; ++nt) dacc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, q.xb[nt][s5], dacc[nt], 0, 0, 0);
       }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
@@ -324,6 +335,27 @@ __device__ __forceinline__ void dwpw_body(const ConvArgs& a, int block) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = (__bf16)dacc[nt][r];
         *reinterpret_cast<bf16x4*>(tb + ((size_t)(2 * pp + (g >> 1)) * P + wave * 16 * NT + nt * 16 + n) * 16 + (g & 1) * 8) = o;
+      }
+    };
+    if constexpr (NT == 1) {  // (16 pixels per wave = the deep launches on small maps, see yl_engine_create)
+      if (npp > 0) {
+        DwIn q0, q1;
+        request(0, q0);
+        for (int pp = 0; pp < npp; pp += 2) {
+          request(pp + 1, q1);
+          compute(pp, q0);
+          if (pp + 1 < npp) {
+            request(pp + 2, q0);
+            compute(pp + 1, q1);
+          }
+        }
+      }
+    } else {  // 32 pixels per wave: the chip-filling launches are bound by L1 tap traffic, and the second register set costs
+              // a wave per SIMD (64 -> 80 @80x80: 28.4 -> 31.3 us with the prefetch)
+      for (int pp = 0; pp < npp; ++pp) {
+        DwIn q;
+        request(pp, q);
+        compute(pp, q);
       }
     }
   }
