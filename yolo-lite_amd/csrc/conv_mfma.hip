@@ -627,11 +627,17 @@ int conv_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo,
   // a 105 MB input.  Plane-major touches one plane's footprint with all nine taps back to back and never again.  Costs the
   // per-lane (tap, plane) arithmetic of the non-UNIFORM fetch (~10 VALU per k-step); the sum order changes (same operands).
   static const int kord_min_cin = getenv("YL_CONV_KORD") ? atoi(getenv("YL_CONV_KORD")) : 64;  // 0: never
+  static const int kord_s1_cin = getenv("YL_CONV_KORD_S1") ? atoi(getenv("YL_CONV_KORD_S1")) : 0;  // stride 1 too, from this Cin (0: never)
   c->kord = (kord_min_cin > 0 && k == 3 && stride == 2 && Cin >= kord_min_cin && MT <= 5 && !g_even_only) ? 1 : 0;
+  if (kord_s1_cin > 0 && k == 3 && stride == 1 && Cin >= kord_s1_cin && MT <= 5 && !g_even_only && Cin % 8 == 0) c->kord = 1;
   if (c->kord) c->uniform = 0;
   conv3_tile_choose(batch, Cin, Cout, k, stride, Ho, Wo, post, c);  // 3x3 s1 layers that fit: input tile in LDS
   conv3_reg_choose(batch, Cin, Cout, k, stride, Ho, Wo, post, c);   // ... or with the filter in registers
   conv3_pair_choose(batch, Cin, Cout, k, stride, Ho, Wo, post, c);  // ... 64 -> 64: filter halves in two waves per SIMD
+  if (c->kord && (c->reg || c->tile || c->pair)) {  // those kernels read the filter tap-major
+    c->kord = 0;
+    c->uniform = (cg % 4 == 0);
+  }
   return 0;
 }
 
@@ -940,7 +946,7 @@ void conv_retile_for_group(ConvConfig* c, int NT, int batch, int Ho, int Wo) {
 bool conv_group_compatible(const ConvConfig* cfg, const ConvArgs* a, int n) {
   if (n < 2 || n > 3) return false;
   for (int i = 0; i < n; ++i) {
-    if (cfg[i].ntaps != 9 || cfg[i].MT != 4 || !cfg[i].uniform || cfg[i].post != cfg[0].post || cfg[i].NT != cfg[0].NT ||
+    if (cfg[i].ntaps != 9 || cfg[i].MT != 4 || cfg[i].uniform != cfg[0].uniform || cfg[i].post != cfg[0].post || cfg[i].NT != cfg[0].NT ||
         (cfg[i].NT != 2 && cfg[i].NT != 4) || a[i].in2 || a[i].out8 || a[i].out_f32 || a[i].res || a[i].stride != 1 ||
         cfg[i].reg || cfg[i].tile || cfg[i].pair)
       return false;
@@ -948,9 +954,9 @@ bool conv_group_compatible(const ConvConfig* cfg, const ConvArgs* a, int n) {
   return true;
 }
 
-template <int NT, bool POST>
+template <int NT, bool POST, bool U = true>
 static int launch_group_r(const ConvGroup& G, int grid, size_t lds, hipStream_t s) {
-  auto kern = conv_group_kernel<3, 4, NT, true, POST>;
+  auto kern = conv_group_kernel<3, 4, NT, U, POST>;
   static bool attr = false;
   if (!attr) {
     YL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
@@ -975,6 +981,10 @@ int conv_group_launch(const ConvConfig* cfg, const ConvArgs* args, int n, int ba
     lds = cfg[i].lds_bytes > lds ? cfg[i].lds_bytes : lds;
   }
   const bool post = cfg[0].post != 0;
+  if (!cfg[0].uniform) {  // (plane-major K order or a channel count that is not a multiple of 32)
+    if (cfg[0].NT == 4) return post ? launch_group_r<4, true, false>(G, grid, lds, s) : launch_group_r<4, false, false>(G, grid, lds, s);
+    return post ? launch_group_r<2, true, false>(G, grid, lds, s) : launch_group_r<2, false, false>(G, grid, lds, s);
+  }
   if (cfg[0].NT == 4) return post ? launch_group_r<4, true>(G, grid, lds, s) : launch_group_r<4, false>(G, grid, lds, s);
   return post ? launch_group_r<2, true>(G, grid, lds, s) : launch_group_r<2, false>(G, grid, lds, s);
 }
