@@ -22,6 +22,6 @@ rocprofv3 --pmc TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --output-fo
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -- python3 $R/bench.py $BA --steps 5 --warmup 2 --streams 1 --no-cpu-baseline --no-other-configs > $OUT/pmc_mfma.log 2>&1
 # keep only the small CSVs
 find $OUT -name "*.db" -delete
-find $OUT -name "*kernel_trace.csv" -size +20M -delete
+find $OUT -name "*kernel_trace.csv" -delete
 ls -la $OUT $OUT/trace/* | head -30
 tail -1 $OUT/bench.json

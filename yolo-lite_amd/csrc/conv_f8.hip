@@ -75,10 +75,21 @@ __device__ __forceinline__ void fetch_b8(const ConvArgs& a, __amdgpu_buffer_rsrc
     off1 = off0 + a.in_plane;
   } else {
     const int q0 = ks * 8 + 2 * g, q1 = q0 + 1;
-    const int t0 = KS == 1 ? 0 : fastdiv(q0, a.cg, a.magic_cg), t1 = KS == 1 ? 0 : fastdiv(q1, a.cg, a.magic_cg);
     const int nq = a.ntaps * a.cg;
-    off0 = q0 < nq ? (unsigned)tap_offset<KS>(a, t0) + (unsigned)(q0 - t0 * a.cg) * a.in_plane : OOB_K;
-    off1 = q1 < nq ? (unsigned)tap_offset<KS>(a, t1) + (unsigned)(q1 - t1 * a.cg) * a.in_plane : OOB_K;
+    int t0, t1, c0, c1;
+    if (KS == 3 && a.kord) {  // plane-major (see conv_f8_choose): k-group = plane * 9 + tap
+      c0 = (int)__umulhi((unsigned)q0, 477218589u);  // q / 9
+      c1 = (int)__umulhi((unsigned)q1, 477218589u);
+      t0 = q0 - 9 * c0;
+      t1 = q1 - 9 * c1;
+    } else {
+      t0 = KS == 1 ? 0 : fastdiv(q0, a.cg, a.magic_cg);
+      t1 = KS == 1 ? 0 : fastdiv(q1, a.cg, a.magic_cg);
+      c0 = q0 - t0 * a.cg;
+      c1 = q1 - t1 * a.cg;
+    }
+    off0 = q0 < nq ? (unsigned)tap_offset<KS>(a, t0) + (unsigned)c0 * a.in_plane : OOB_K;
+    off1 = q1 < nq ? (unsigned)tap_offset<KS>(a, t1) + (unsigned)c1 * a.in_plane : OOB_K;
   }
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
@@ -274,6 +285,17 @@ int conv_f8_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int 
   c->cg = cg;
   c->ntaps = ntaps;
   c->uniform = cg % 8 == 0;
+  // Plane-major K order (k-group = plane * 9 + tap) for the 3x3 convs on big maps: in tap-major order a workgroup sweeps its
+  // input footprint once per tap, nine times, with a reuse distance beyond the 4 MB of an XCD's L2 -- rocprofv3
+  // (profiles/x8fp8_r03_summary.md, YOLO11x 1280x1280 batch 8) shows the stride-2 convs fetching 424 MB per launch for
+  // 80-160 MB of input and `model.23.cv2.0.0` 402 MB for 79 MB.  Same cure as conv_mfma.hip's: one plane's nine taps back to
+  // back (the per-lane tap / plane arithmetic of the non-UNIFORM fetch).  YL_F8_KORD = smallest map (pixels per image) that
+  // takes it; 0: never.
+  static const int kord_px = getenv("YL_F8_KORD") ? atoi(getenv("YL_F8_KORD")) : 1600;
+  c->kord = (kord_px > 0 && k == 3 && (long long)Ho * Wo >= kord_px) ? 1 : 0;
+  if (c->kord) c->uniform = 0;
+  c->gemm = 0;
+  c->reg = c->pair = 0;
   c->ksteps = ksteps;
   c->kchunk = kchunk;
   c->lds_bytes = (size_t)kchunk * step_bytes;
@@ -311,9 +333,9 @@ void conv_f8_pack_weights(const float* w, int Cout, int Cin, int k, const ConvCo
           for (int lane = 0; lane < 64; ++lane) {
             const int co = cb * c.MT * 16 + mt * 16 + (lane & 15);
             const int q = ks * 8 + 2 * (lane >> 4) + h;
-            const int tap = q / c.cg, c16 = q % c.cg;
+            const int tap = c.kord ? q % c.ntaps : q / c.cg, c16 = c.kord ? q / c.ntaps : q % c.cg;
             for (int j = 0; j < 16; ++j, ++o) {
-              if (co < Cout && tap < c.ntaps) {
+              if (co < Cout && tap < c.ntaps && c16 < c.cg) {  // (plane-major: the k tail lies past the last plane)
                 const int ci = c16 * 16 + j, kh = tap / k, kw = tap % k;
                 (*out)[o] = f32_to_e4m3(w[(((size_t)co * Cin + ci) * k + kh) * k + kw] / (*wscale)[co]);
               }
@@ -358,6 +380,7 @@ int conv_f8_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s) 
   a.ksteps = cfg.ksteps;
   a.kchunk = cfg.kchunk;
   a.ntaps = cfg.ntaps;
+  a.kord = cfg.kord;
   a.kkn = cfg.cg >> 3;
   a.magic_kkn = magic8(cfg.cg >> 3);
   a.magic_cg = magic8(cfg.cg);
