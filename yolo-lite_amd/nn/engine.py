@@ -363,7 +363,8 @@ class HipEngine:
                 ("nms.mask", "nms_mask", ncand * 16 + ncand * 8),
                 ("nms.scan", "nms_scan", ncand * 16 + float(self.batch * max_det * 24))]
         fused_pf = bool(self.lib.yl_engine_prefilter_fused(self._h, float(conf)))
-        one_launch = os.environ.get("YL_NMS_FUSED", "1") != "0" and conf >= 0.05  # nms.hip: decode_nms_fused_kernel
+        env = os.environ.get("YL_NMS_FUSED")  # nms.hip: decode_nms_fused_kernel from 16 images per batch up
+        one_launch = (env != "0" if env is not None else self.batch >= 16) and conf >= 0.05
         for (name, kern, b), t in zip(post, mp):
             if fused_pf and name == "detect.prefilter":
                 continue  # runs in the epilogue of the launches that write the class logits: not a launch of its own
