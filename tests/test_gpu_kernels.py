@@ -183,6 +183,35 @@ def test_conv_reads_through_upsample_concat(gpu_device):
     _assert_close_bf16(m.read(out), ref, "conv over upsample+concat")
 
 
+@pytest.mark.parametrize("clo,cskip,cout,h,w,w8", [(128, 64, 128, 10, 14, "0"), (256, 128, 384, 12, 22, "0"), (128, 128, 256, 12, 22, "1"),
+                                                    (64, 192, 256, 9, 15, "-1")])
+def test_conv_gemm_reads_through_upsample_concat(gpu_device, monkeypatch, clo, cskip, cout, h, w, w8):
+    """conv_gemm_kernel with an upsampled second input (yl_op.in2: the LDS-DMA source address is per lane, pixel (y / 2, x / 2) of
+    the low-resolution map): against torch and bit-identical to conv_kernel's read-through."""
+    g = torch.Generator().manual_seed(clo + cskip + h)
+    B = 3
+    lo, skip = _rand(g, B, clo, h, w), _rand(g, B, cskip, 2 * h, 2 * w)
+    wt = _rand(g, cout, clo + cskip, 1, 1, scale=1.0 / math.sqrt(clo + cskip))
+    b = torch.randn(cout, generator=g) * 0.3
+    ref = F.silu(F.conv2d(torch.cat([F.interpolate(lo, scale_factor=2.0), skip], 1), wt, b))
+    got = {}
+    for mode, kern in (("1", "conv1x1_gemm_mfma"), ("0", "conv1x1_mfma")):
+        monkeypatch.setenv("YL_CONV_GEMM", mode)
+        monkeypatch.setenv("YL_CONV_GEMM_BLOCKS", "1")
+        monkeypatch.setenv("YL_CONV_GEMM_W8", w8)
+        m = Mini(B, gpu_device)
+        vlo, cat, out = m.buf(h, w, clo), m.buf(2 * h, 2 * w, clo + cskip), m.buf(2 * h, 2 * w, cout)
+        m.fill(vlo, lo)
+        m.fill(cat.slice(clo, cskip), skip)
+        m.op(kind=OP_CONV, name="t", k=1, stride=1, act=1, inp=cat.slice(clo, cskip), inp2=vlo, up=2, out=out,
+             weight=np.ascontiguousarray(wt.numpy()), bias=np.ascontiguousarray(b.numpy()))
+        m.run()
+        assert m.eng.op_kernel(0) == kern, m.eng.op_kernel(0)
+        got[mode] = m.read(out)
+    _assert_close_bf16(got["1"], ref, "gemm conv over upsample+concat")
+    assert torch.equal(got["1"], got["0"])
+
+
 @pytest.mark.parametrize("staged", [0, 1])
 @pytest.mark.parametrize("c,cout,h,w,act2", [(64, 80, 20, 20, True), (80, 80, 13, 9, True), (32, 32, 40, 40, False)])
 def test_depthwise_pointwise_fused(gpu_device, monkeypatch, c, cout, h, w, act2, staged):

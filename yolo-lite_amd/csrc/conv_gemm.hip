@@ -49,7 +49,10 @@ size_t conv_gemm_lds_bytes(int MTW, int NWN, bool even) {
 // MTW: 16-channel tiles per wave (4, 6 or 8): BM = 2 * MTW * 16 output channels per workgroup.  NWN: waves along the pixels
 // (2 or 4; 64 pixels each): BN = 64 * NWN.  KS: k-steps (32 channels) per ring slice; NS: slices in the ring.
 // O8: the epilogue also stores the e4m3 copy of channels [out8_c0, out8_c0 + out8_n) (yl_op.out8, fp8 programs), as conv_kernel's does
-template <int MTW, int NWN, int KS, int NS, bool RES, bool ACT, bool O8>
+// UP: the first 32 * ks_split input channels are a nearest-neighbour 2x upsampling of a low-resolution map (nn.Upsample + Concat in
+// front of the conv, yolo11.yaml:31-36) and are read from that map itself at pixel (y / 2, x / 2): the LDS-DMA source address is
+// per lane (the LDS destination stays linear), so the gather costs one address per lane and tile.
+template <int MTW, int NWN, int KS, int NS, bool RES, bool ACT, bool O8, bool UP = false>
 __global__ __launch_bounds__(128 * NWN) __attribute__((amdgpu_waves_per_eu(2))) void conv_gemm_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
   constexpr int NW = 2 * NWN;                  // waves
@@ -77,6 +80,26 @@ __global__ __launch_bounds__(128 * NWN) __attribute__((amdgpu_waves_per_eu(2))) 
   const unsigned lane16 = (unsigned)lane * 16u;
   const unsigned wbase = (unsigned)cb * a.ksteps * MT * 1024u;
 
+  // UP: byte offset of this lane's pixel in a plane of the low-resolution source.  Piece j = wave + NW * i of a slice always
+  // covers pixel part h = wave % NWN of the tile (NW and the A piece count are multiples of NWN): one offset per lane.
+  const __amdgpu_buffer_rsrc_t rin2 =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.in2, (short)0, UP ? a.in2_bytes : 0, 0x00020000);
+  unsigned off2 = 0;
+  if constexpr (UP) {
+    const int rb = q0 - a.in_g0;                                  // tile start relative to pixel (0, 0, 0)
+    const int b0 = __builtin_amdgcn_readfirstlane((rb < 0 ? 0 : rb) / a.in_img);
+    const int r = rb + wn * 64 + lane;
+    int t = r - b0 * a.in_img;                                    // < img + BN: at most one wrap (host: img >= BN)
+    const int wrap = t >= a.in_img;
+    const int b = b0 + wrap;
+    t -= wrap * a.in_img;
+    const int y = (int)__umulhi((unsigned)(t < 0 ? 0 : t), a.magic_w1);
+    const int x = t - y * a.in_w1;
+    const bool ok = r >= 0 && b < a.t_B && y < a.t_H && x < a.t_W;
+    off2 = ok ? (unsigned)(a.in2_g0 + b * a.in2_img + (y >> 1) * a.in2_w1 + (x >> 1)) * 16u : 0u;  // (position 0 is a zero guard)
+  }
+  const int split_planes = UP ? 4 * a.ks_split : 0;
+
   // K-slice `it` -> ring buffer `buf`: pieces wave, wave + NW, ... (wave-uniform addressing, the lane adds its 16 bytes).
   // Slices past the end (ring refills of the last iterations) fall outside both descriptors: the pieces move nothing but
   // still count in vmcnt, so the counted wait below is the same in every iteration.
@@ -91,9 +114,15 @@ __global__ __launch_bounds__(128 * NWN) __attribute__((amdgpu_waves_per_eu(2))) 
                                                  (int)(lane16 + wbase + (unsigned)it * ASTAGE + (unsigned)j * 1024u + past), 0, 0, 0);
       } else {
         const int jb = j - NPA, p = jb / NWN, h = jb % NWN;   // plane of the slice (4 per k-step), 64-pixel part of the run
-        const unsigned src = (unsigned)(it * (4 * KS) + p) * a.in_plane + (unsigned)(q0 + h * 64) * 16u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void_g*)(gsm + sbase + ASTAGE + (unsigned)jb * 1024u), 16,
-                                                 (int)(lane16 + src + past), 0, 0, 0);
+        const int gp = it * (4 * KS) + p;                     // plane of the whole input (scalar)
+        if (UP && gp < split_planes) {
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rin2, (lds_void_g*)(gsm + sbase + ASTAGE + (unsigned)jb * 1024u), 16,
+                                                   (int)(off2 + (unsigned)gp * a.in2_plane + past), 0, 0, 0);
+        } else {
+          const unsigned src = (unsigned)(gp - split_planes) * a.in_plane + (unsigned)(q0 + h * 64) * 16u;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void_g*)(gsm + sbase + ASTAGE + (unsigned)jb * 1024u), 16,
+                                                   (int)(lane16 + src + past), 0, 0, 0);
+        }
       }
     }
   };
@@ -280,7 +309,7 @@ static unsigned gm_magic(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ul
 
 // Takes over a conv_choose()n tiling when the layer is wide enough: sets cfg->gemm (tiles per wave) and the packing it needs.
 // Only plain bf16 1x1 stride-1 convs (no fused follow-up, second input or fp32 output: the caller checks the views).
-void conv_gemm_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, ConvConfig* c) {
+void conv_gemm_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, ConvConfig* c, int cin2) {
   c->gemm = 0;
   // (read at every engine build, not cached: the tests switch them)
   const int enable = getenv("YL_CONV_GEMM") ? atoi(getenv("YL_CONV_GEMM")) : 1;
@@ -307,6 +336,11 @@ void conv_gemm_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, i
   if (w8_blocks > 0 && MTW == 8 && b8 >= w8_blocks) NWN = 4;
   if (w8_blocks < 0 && b8 >= -w8_blocks && (MTW != 6 || c->ksteps % 2 == 0)) NWN = 4;
   const int BN = 64 * NWN;
+  if (cin2) {  // upsampled second input: whole ring slices on either side of the split, one image wrap per pixel tile
+    const bool even = c->ksteps % 2 == 0;
+    const int ks_per_slice = NWN == 4 ? (MTW == 6 ? 2 : 1) : ((MTW == 8 || !even) ? 1 : 2);  // = gm_ks
+    if (cin2 % 32 || (cin2 / 32) % ks_per_slice || gg.img < BN) return;
+  }
   const long long ntiles = (npos + BN - 1) / BN;
   if (ntiles * ncb < min_blocks) return;                       // a grid that cannot fill 256 CUs: conv_kernel's finer tiles
   c->gemm = MTW;
@@ -324,12 +358,16 @@ void conv_gemm_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, i
   c->name = "conv1x1_gemm_mfma";
 }
 
-template <int MTW, int NWN, bool EVEN, bool RES, bool ACT, bool O8 = false>
+template <int MTW, int NWN, bool EVEN, bool RES, bool ACT, bool O8 = false, bool UP = false>
 static int launch_gemm(const ConvArgs& a, size_t lds, hipStream_t s) {
   if constexpr (!O8) {
-    if (a.out8) return launch_gemm<MTW, NWN, EVEN, RES, ACT, true>(a, lds, s);
+    if (a.out8) return launch_gemm<MTW, NWN, EVEN, RES, ACT, true, UP>(a, lds, s);
   }
-  auto kern = conv_gemm_kernel<MTW, NWN, gm_ks(MTW, NWN, EVEN), gm_ns(MTW, NWN, EVEN), RES, ACT, O8>;
+  if constexpr (!UP && !RES) {  // (the convs behind Upsample + Concat carry no residual)
+    if (a.in2) return launch_gemm<MTW, NWN, EVEN, RES, ACT, O8, true>(a, lds, s);
+  }
+  if (a.in2 && !UP) return fail(-3, "conv_gemm: an upsampled second input cannot be combined with a residual");
+  auto kern = conv_gemm_kernel<MTW, NWN, gm_ks(MTW, NWN, EVEN), gm_ns(MTW, NWN, EVEN), RES, ACT, O8, UP>;
   static bool attr = false;
   if (!attr) {
     YL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -342,7 +380,7 @@ static int launch_gemm(const ConvArgs& a, size_t lds, hipStream_t s) {
 
 int conv_gemm_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s) {
   const int MTW = cfg.gemm;
-  if ((MTW != 4 && MTW != 6 && MTW != 8) || cfg.ntaps != 1 || a.stride != 1 || a.out_f32 || a.in2 || a.wpk2 || !cfg.uniform ||
+  if ((MTW != 4 && MTW != 6 && MTW != 8) || cfg.ntaps != 1 || a.stride != 1 || a.out_f32 || a.wpk2 || !cfg.uniform ||
       a.in_w1 != a.out_w1 || a.in_img != a.out_img || a.in_g0 != a.out_g0 || a.in_w1 != a.Wo + 1 || a.Cout != cfg.ncb * 32 * MTW)
     return fail(-3, "conv_gemm: needs a plain bf16 1x1 stride-1 conv, Cin % 32 == 0, Cout a multiple of the channel block");
   a.ncb = cfg.ncb;
@@ -353,7 +391,12 @@ int conv_gemm_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s
   a.t_W = a.Wo;
   a.magic_w1 = gm_magic(a.in_w1);
   const long long lim = 1LL << 30;
-  const long long inb = (long long)cfg.cg * a.in_plane, outb = (long long)(a.Cout / 8) * a.out_plane;
+  const long long inb = (long long)(cfg.cg - (a.in2 ? 4 * a.ks_split : 0)) * a.in_plane, outb = (long long)(a.Cout / 8) * a.out_plane;
+  if (a.in2) {
+    const long long in2b = (long long)(4 * a.ks_split) * a.in2_plane;
+    if (in2b > (1LL << 30)) return fail(-3, "conv_gemm: a tensor slice exceeds 1 GiB (32-bit buffer offsets); lower the batch size");
+    a.in2_bytes = (unsigned)in2b;
+  }
   const long long resb = a.res ? (long long)(a.Cout / 8) * a.res_plane : 0;
   if (inb > lim || outb > lim || resb > lim || (long long)cfg.ncb * cfg.ksteps * cfg.MT * 1024 > lim)
     return fail(-3, "conv_gemm: a tensor slice exceeds 1 GiB (32-bit buffer offsets); lower the batch size");

@@ -301,8 +301,8 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
           return fail(-1, tag + ": fused follow-up conv needs a bias, no residual and out.C <= post_cin");
         if (int rc = conv_choose(batch, cin_total, cout1, o.k, o.stride, Ho, Wo, post, &r.cfg)) return rc;
         // wide plain 1x1 convs: the GEMM-class kernel (both operands through LDS); it has its own filter packing (BM / 16 tiles)
-        if (!post && !up && !o.stem_weight && !o.cin_weight && o.out.dtype == YL_BF16 && o.in.C == cin_total)
-          conv_gemm_choose(batch, cin_total, cout1, o.k, o.stride, Ho, Wo, &r.cfg);
+        if (!post && !o.stem_weight && !o.cin_weight && o.out.dtype == YL_BF16 && !(up && o.res.offset >= 0))
+          conv_gemm_choose(batch, cin_total, cout1, o.k, o.stride, Ho, Wo, &r.cfg, up ? o.in2.C : 0);
         if (o.out8.offset >= 0) {
           if (int rc = check_out8(o, batch, workspace_bytes, tag)) return rc;
           if (post || o.stem_weight) return fail(-1, tag + ": out8 needs a plain conv");

@@ -145,7 +145,7 @@ int conv3_reg_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s
 void conv3_pair_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, int post, ConvConfig* cfg);
 int conv3_pair_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s);
 // conv_gemm.hip: wide 1x1 convs (Cin, Cout >= 128) as a 128/192 x 128 macro-tile GEMM, both operands through LDS by LDS-DMA
-void conv_gemm_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, ConvConfig* cfg);
+void conv_gemm_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, ConvConfig* cfg, int cin2 = 0);
 int conv_gemm_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s);
 int dwpw_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s);
 // group launches (the three Detect levels in one launch, conv_mfma.hip)
