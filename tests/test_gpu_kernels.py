@@ -422,6 +422,43 @@ def test_conv3_reg_vs_torch_and_direct(gpu_device, monkeypatch, cin, cout, h, w,
     assert torch.equal(got, direct), f"reg vs direct kernel: max diff {float((got - direct).abs().max())}"
 
 
+CS_CASES = [
+    # H, W, act, res     conv3_cs_kernel (64 -> 64: output channels split between wave pairs), forced onto small maps
+    (20, 20, True, False),
+    (20, 20, True, True),
+    (7, 9, True, False),          # images shorter than a tile
+    (80, 80, True, False),        # the layer it is for (Detect box branch, level 0)
+    (33, 150, False, True),       # wide rows: a tile is less than one row; no activation
+    (40, 40, True, False),
+]
+
+
+@pytest.mark.parametrize("h,w,act,res", CS_CASES)
+def test_conv3_cs_vs_torch_and_direct(gpu_device, monkeypatch, h, w, act, res):
+    """The Cout-split filter-in-registers kernel (csrc/conv3_cs.hip, two persistent workgroups per CU) against torch, and
+    against conv_kernel: same operands, same k order and accumulation chain from the bias -> bit-identical."""
+    g = torch.Generator().manual_seed(6400 + h + w)
+    B = 3
+    x = _rand(g, B, 64, h, w)
+    wt = _rand(g, 64, 64, 3, 3, scale=1.0 / math.sqrt(64 * 9))
+    b = torch.randn(64, generator=g) * 0.5
+    ref = F.conv2d(x, wt, b, 1, 1)
+    if act:
+        ref = F.silu(ref)
+    r = None
+    if res:
+        r = _rand(g, *ref.shape)
+        ref = ref + r
+    monkeypatch.setenv("YL_CONV_CS", "1")
+    monkeypatch.setenv("YL_CONV_CS_MIN", "1")
+    got = run_conv(gpu_device, x, wt, b, 3, 1, act, r, expect_kernel="conv3x3_cs_mfma")
+    _assert_close_bf16(got, ref, f"cs conv {h}x{w}")
+    monkeypatch.setenv("YL_CONV_CS", "0")
+    monkeypatch.setenv("YL_CONV_REG", "0")
+    direct = run_conv(gpu_device, x, wt, b, 3, 1, act, r, expect_kernel="conv3x3_mfma")
+    assert torch.equal(got, direct), f"cs vs direct kernel: max diff {float((got - direct).abs().max())}"
+
+
 PAIR_CASES = [
     # H, W, act, res     conv3_pair_kernel (64 -> 64: filter halves in the registers of two waves per SIMD), forced onto small maps
     (20, 20, True, False),

@@ -1,0 +1,193 @@
+// 3x3 stride-1 Conv 64 -> 64 + (folded BN) bias + SiLU [+ residual] with the filter in registers and the OUTPUT CHANNELS
+// SPLIT between wave pairs ("Cout split", round 3; reference nn/modules/conv.py:35-53, nn/modules/head.py:29-57, block.py:341-343).
+//
+// conv3_reg_kernel keeps the whole 64 -> 64 filter (288 registers) in ONE wave per SIMD; its SiLU epilogue (quarter-rate
+// v_exp / v_rcp) then has no partner wave to hide behind, and 7.7 of its ~30 us are that epilogue (NOTEBOOK.md section 4).
+// Here a wave owns 32 of the 64 output channels: 18 k-steps x 2 tiles x 4 registers = 144 VGPRs of filter, 32 of
+// accumulators -- under 256 registers, so TWO workgroups (4 waves each) share a CU, plain MFMA builtins (no AGPR operands,
+// no inline asm), and one workgroup's epilogue and LDS-DMA wait run under the other's MFMAs.  No partial sums, no exchange
+// (conv3_pair_kernel split K and paid for one).  Waves (h, c) of a workgroup: h = channel half, c = 64-position column of the
+// 128-position tile; both halves read the same activation fragments from LDS.
+//
+// Same operands, same k order (tap-major, 32 channels per k-step), same accumulation chain from the bias and the same
+// epilogue as conv_kernel: bit-identical results.
+//
+// Input staging as conv3_reg / conv3_tile: in the guarded planar layout a 3x3 tap is a constant offset of the linear
+// guarded index, so a tile needs ONE contiguous run of L + 2 (W + 1) + 2 positions of each of the 8 input planes, copied by
+// LDS-DMA in 1 KiB pieces.  Persistent workgroups (two per CU) load their filter half once and walk tiles t = wg, wg + G, ..:
+//   wait for the tile's pieces + barrier -> 144 MFMAs per wave -> barrier (everybody has left the buffer) -> the NEXT tile's
+//   pieces are issued -> epilogue of this tile (its stores and the DMA's flight overlap).
+#include "conv_common.h"
+
+namespace yl {
+
+typedef __attribute__((address_space(3))) void lds_void_c;
+
+constexpr int CS_L = 128;  // positions per tile (two 64-position columns)
+
+static __host__ __device__ inline int cs_PL(int W) { return (CS_L + 2 * (W + 1) + 2 + 63) & ~63; }  // staged positions per plane
+
+template <bool RES, bool ACT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv3_cs_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char csm[];
+  constexpr int KS = 18, NT = 4;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = wave >> 1, c = wave & 1;  // channel half, column of the tile
+  const int g = lane >> 4, n = lane & 15;
+  const int G = gridDim.x;
+  const int wg = xcd_remap(blockIdx.x, G);
+  const int PL = a.t_PL, PLB = PL * 16;
+  const int ppp = PL >> 6;                       // 1 KiB pieces per plane
+  const int nmine = (a.t_ntiles - wg + G - 1) / G;
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, (short)0, a.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.out, (short)0, a.out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rres =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.res, (short)0, RES ? a.res_bytes : 0, 0x00020000);
+  const unsigned lane16 = (unsigned)lane * 16u;
+
+  // tile t -> LDS: wave w copies planes w and w + 4 (ppp pieces each); a run past the slice reads zeros
+  auto stage = [&](int t) __attribute__((always_inline)) {
+    const int src0 = (a.in_g0 + t * CS_L - a.in_w1 - 1) * 16;  // first staged guarded position (>= 0)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int plane = wave + 4 * q;
+      for (int j = 0; j < ppp; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void_c*)(csm + plane * PLB + j * 1024), 16,
+                                                 (int)(lane16 + (unsigned)(plane * (int)a.in_plane + src0 + j * 1024)), 0, 0, 0);
+    }
+  };
+  if (nmine > 0 && !(a.dbg & 1)) stage(wg);  // (a.dbg: timing ablations, YL_CONV_DBG -- wrong results)
+
+  // this wave's half of the filter, conv_pack_weights order (4 tiles per k-step): tiles 2h, 2h + 1
+  bf16x8 wf[KS][2];
+  {
+    const bf16x8* wsrc = reinterpret_cast<const bf16x8*>(a.wpk) + lane;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) wf[ks][mt] = wsrc[(ks * 4 + 2 * h + mt) * 64];
+  }
+  f32x4 bias_r[2];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) bias_r[mt] = *reinterpret_cast<const f32x4*>(a.bias + chan_in_block(4, 2 * h + mt, g, 0));
+  const unsigned char* const tb = csm + (g * PL + c * 64 + n) * 16;  // the lane's position 0 of plane g (taps add offsets)
+  const int row_bytes = a.in_w1 * 16, half_bytes = 4 * PLB;           // planes 4..7 = input channels 32..63
+  const unsigned oplane = (unsigned)(4 * h + g);                      // the lane's output plane (8 channels)
+
+  for (int i = 0; i < nmine; ++i) {
+    const int t = wg + i * G;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces of this tile (and the previous tile's stores)
+    __builtin_amdgcn_s_barrier();
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = bias_r[mt];
+    if (!(a.dbg & 4))
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int tap = ks >> 1, ch = ks & 1, dy = tap / 3, dx = tap % 3;
+      const unsigned char* rb = tb + ch * half_bytes + dy * row_bytes + dx * 16;
+      bf16x8 xb[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) xb[nt] = *reinterpret_cast<const bf16x8*>(rb + nt * 256);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][mt], xb[nt], acc[mt][nt], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // everybody has read the tile: the buffer may be refilled
+    if (i + 1 < nmine && !(a.dbg & 1)) stage(t + G);
+    if (a.dbg & 2) continue;
+    // epilogue: valid positions only (guards are computed, never stored)
+    const int r0 = t * CS_L + c * 64;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int r = r0 + nt * 16 + n;  // position relative to g0
+      const int b = (int)__umulhi((unsigned)r, a.magic_img);
+      const int rr = r - b * a.in_img;
+      const int y = (int)__umulhi((unsigned)rr, a.magic_w1);
+      const int x = rr - y * a.in_w1;
+      const unsigned po = (b < a.t_B && y < a.t_H && x < a.t_W) ? (unsigned)(a.in_g0 + r) * 16u : OOB_LANE;
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        v[q] = acc[0][nt][q];
+        v[4 + q] = acc[1][nt][q];
+      }
+      if constexpr (ACT) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = silu_f(v[q]);
+      }
+      if constexpr (RES) {
+        const bf16x8 rv = __builtin_bit_cast(
+            bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rres, po == OOB_LANE ? OOB_LANE : oplane * a.res_plane + po, 0, 0));
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] += (float)rv[q];
+      }
+      __builtin_amdgcn_raw_buffer_store_b128(
+          u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])}, rout,
+          po == OOB_LANE ? OOB_LANE : oplane * a.out_plane + po, 0, 0);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ host
+static unsigned cs_magic(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull / (unsigned)d) + 1ull); }
+
+// sets cfg->cs for 64 -> 64 3x3 stride-1 convs with enough tiles for two persistent workgroups per CU
+void conv3_cs_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, int post, ConvConfig* c) {
+  c->cs = 0;
+  const int enable = getenv("YL_CONV_CS") ? atoi(getenv("YL_CONV_CS")) : 1;
+  const int min_tiles = getenv("YL_CONV_CS_MIN") ? atoi(getenv("YL_CONV_CS_MIN")) : 1024;
+  if (!enable || k != 3 || stride != 1 || post || Cin != 64 || Cout != 64 || c->ncb != 1 || c->MT != 4) return;
+  const long long img = (long long)(Ho + 1) * (Wo + 1), nq = (long long)batch * img;
+  if (nq * img >= (1LL << 32) || img * (Wo + 1) >= (1LL << 32)) return;  // exactness of the magic divisions
+  if ((nq + CS_L - 1) / CS_L < min_tiles || (size_t)8 * cs_PL(Wo) * 16 > 80 * 1024) return;
+  c->cs = 1;
+  c->reg = c->tile = c->pair = 0;
+  c->name = "conv3x3_cs_mfma";
+}
+
+template <bool RES, bool ACT>
+static int launch_cs(const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
+  auto kern = conv3_cs_kernel<RES, ACT>;
+  static bool attr = false;
+  if (!attr) {
+    YL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
+  YL_HIP(hipGetLastError());
+  return 0;
+}
+
+int conv3_cs_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s) {
+  if (a.stride != 1 || a.out_f32 || a.in2 || a.wpk2 || a.out8 || a.in_w1 != a.out_w1 || a.in_img != a.out_img ||
+      a.in_g0 != a.out_g0 || a.in_w1 != a.Wo + 1 || a.Cin != 64 || a.Cout != 64)
+    return fail(-3, "conv3_cs: needs a plain 64 -> 64 3x3 stride-1 conv between planar tensors of one geometry");
+  a.t_B = batch;
+  a.t_H = a.Ho;
+  a.t_W = a.Wo;
+  a.t_PL = cs_PL(a.Wo);
+  a.magic_img = cs_magic(a.in_img);
+  a.magic_w1 = cs_magic(a.in_w1);
+  const long long nq = (long long)batch * a.in_img;
+  a.t_ntiles = (int)((nq + CS_L - 1) / CS_L);
+  const long long lim = 1LL << 30;
+  const long long inb = 8LL * a.in_plane, outb = 8LL * a.out_plane, resb = a.res ? 8LL * a.res_plane : 0;
+  if (inb > lim || outb > lim || resb > lim) return fail(-3, "conv3_cs: a tensor slice exceeds 1 GiB; lower the batch size");
+  a.in_bytes = (unsigned)inb;
+  a.out_bytes = (unsigned)outb;
+  a.res_bytes = (unsigned)resb;
+  a.dbg = getenv("YL_CONV_DBG") ? atoi(getenv("YL_CONV_DBG")) : 0;
+  const size_t lds = (size_t)8 * a.t_PL * 16;
+  const int grid = a.t_ntiles < 512 ? a.t_ntiles : 512;  // two persistent workgroups per CU
+  if (a.res) return a.act ? launch_cs<true, true>(a, grid, lds, s) : launch_cs<true, false>(a, grid, lds, s);
+  return a.act ? launch_cs<false, true>(a, grid, lds, s) : launch_cs<false, false>(a, grid, lds, s);
+}
+
+}  // namespace yl

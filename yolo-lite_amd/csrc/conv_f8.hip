@@ -295,7 +295,7 @@ int conv_f8_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int 
   c->kord = (kord_px > 0 && k == 3 && (long long)Ho * Wo >= kord_px) ? 1 : 0;
   if (c->kord) c->uniform = 0;
   c->gemm = 0;
-  c->reg = c->pair = 0;
+  c->reg = c->pair = c->cs = 0;
   c->ksteps = ksteps;
   c->kchunk = kchunk;
   c->lds_bytes = (size_t)kchunk * step_bytes;

@@ -350,7 +350,7 @@ void conv_gemm_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, i
   c->ncb = ncb;
   c->kchunk = c->ksteps;
   c->post = 0;
-  c->reg = c->tile = c->pair = 0;
+  c->reg = c->tile = c->pair = c->cs = 0;
   c->ppw = 1;
   c->lds_bytes = conv_gemm_lds_bytes(MTW, NWN, c->ksteps % 2 == 0);
   c->wpk_elems = (size_t)ncb * c->ksteps * c->MT * 64 * 8;

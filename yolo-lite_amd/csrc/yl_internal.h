@@ -120,6 +120,7 @@ struct ConvConfig {
   int tile;          // > 0: conv3_tile_kernel with this many 16-pixel column tiles per wave (else conv_kernel)
   int reg;           // > 0: conv3_reg_kernel (filter in registers) with this many 16-pixel column tiles per wave
   int pair;          // > 0: conv3_pair_kernel (64 -> 64: filter halves in the registers of two waves per SIMD)
+  int cs;            // 1: conv3_cs_kernel (64 -> 64 3x3: filter in registers, output channels split between wave pairs)
   int kord;          // 1: K runs plane-major (k-group = plane * 9 + tap) instead of tap-major (tap * planes + plane), see conv_choose
   int gemm;          // > 0: conv_gemm_kernel (wide 1x1: both operands staged through LDS) with this many 16-channel tiles per wave
   int gemm_nwn;      // ... and this many waves along the pixels (2: 128-pixel tiles, 4: 256-pixel tiles)
@@ -141,6 +142,9 @@ int conv3_tile_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t 
 // conv3_reg.hip: 3x3 stride-1 convs with Cin, Cout in {32, 64}: the filter lives in the registers of every wave
 void conv3_reg_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, int post, ConvConfig* cfg);
 int conv3_reg_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s);
+// conv3_cs.hip: 3x3 stride-1 64 -> 64 convs, output channels split between wave pairs, two workgroups per CU
+void conv3_cs_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, int post, ConvConfig* cfg);
+int conv3_cs_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s);
 // conv3_pair.hip: 3x3 stride-1 64 -> 64 convs, K split between the two waves of a SIMD
 void conv3_pair_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, int post, ConvConfig* cfg);
 int conv3_pair_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s);
