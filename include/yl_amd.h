@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define YL_ABI_VERSION 14
+#define YL_ABI_VERSION 15
 
 /* element types */
 enum { YL_BF16 = 0, YL_F32 = 1, YL_F16 = 2, YL_U8 = 3, YL_FP8 = 4 /* OCP e4m3 */ };
@@ -264,6 +264,19 @@ int yl_engine_detect_graph(yl_engine* e, const void* input, int in_dtype, void* 
                            float conf_thres, float iou_thres, int max_det, int agnostic,
                            const int32_t* classes, int n_classes, int max_cand, float max_wh,
                            const float* scale, float* out, int32_t* out_count, void* work, void* stream);
+
+/* The graph of yl_engine_detect_graph for this argument tuple WITHOUT launching it (captured on first use; that first call runs
+ * the path once eagerly on `stream`): *graph_out is a handle for yl_graph_launch_many, owned by the engine and valid until
+ * yl_engine_destroy.  Replaces nothing in the reference (its predictor finishes a batch before it touches the next,
+ * engine/predictor.py:178-212); it exists so that a serving loop can issue many prepared steps from native code. */
+int yl_engine_detect_graph_prepare(yl_engine* e, const void* input, int in_dtype, void* workspace, float conf_thres,
+                                   float iou_thres, int max_det, int agnostic, const int32_t* classes, int n_classes,
+                                   int max_cand, float max_wh, const float* scale, float* out, int32_t* out_count, void* work,
+                                   void* stream, void** graph_out);
+/* Issues n prepared steps back to back: graphs[i] (from yl_engine_detect_graph_prepare) on HIP stream streams[i].  The host
+ * side of the reference's `for batch in dataset:` loop (engine/predictor.py:178) for batches whose inputs are already staged:
+ * one native call per round of batches in flight instead of one trip through Python per batch (~80 us each). */
+int yl_graph_launch_many(void* const* graphs, void* const* streams, int n);
 
 /* uint8 HWC BGR letterboxed images -> float NCHW RGB / 255 (engine/predictor.py:77-84). */
 int yl_preprocess_u8(const uint8_t* bgr_hwc, int batch, int h, int w, float* out_nchw, void* stream);

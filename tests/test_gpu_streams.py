@@ -69,3 +69,43 @@ def test_predict_stream_pipelines_batches_bit_identically(gpu_device, monkeypatc
     for j, rs in enumerate(alone[::-1]):
         for i, r in enumerate(rs):
             assert torch.equal(again[2 * j + i].boxes.data, r.boxes.data)
+
+
+def test_native_multi_step_launch_equals_detect(gpu_device):
+    """yl_engine_detect_graph_prepare + yl_graph_launch_many (one native call issuing the prepared steps of several slots on
+    their streams, what bench.py's timed loop uses): every slot's records equal a plain eager detect on that slot's input,
+    also after the inputs changed in place and over two rounds."""
+    from yololite_amd.nn import arch
+    from yololite_amd.nn.engine import HipEngine
+    from yololite_amd.nn.synth import synth_state_dict
+
+    specs, _ = arch.parse_model(arch.yolo11_dict("n"))
+    sd = synth_state_dict("n", 3, cls_bias=[-3.0, -3.0, -3.0], cls_gain=6.0)
+    eng = HipEngine.from_model(specs, sd, 2, 96, 128, gpu_device)
+    g = torch.Generator().manual_seed(21)
+    S = 3
+    xs = [torch.randint(0, 256, (2, 3, 96, 128), generator=g, dtype=torch.uint8).to(gpu_device) for _ in range(S)]
+    streams = [torch.cuda.Stream(device=gpu_device) for _ in range(S)]
+    outs, handles = [], []
+    for j in range(S):
+        with torch.cuda.stream(streams[j]):
+            o, c, h = eng.prepare_detect(xs[j], 0.25, 0.7, slot=j)
+        outs.append((o, c))
+        handles.append(h)
+    torch.cuda.synchronize()
+    for rnd in range(2):
+        for j in range(S):  # new contents in the SAME input tensors (the graphs baked their addresses)
+            xs[j].copy_(torch.randint(0, 256, (2, 3, 96, 128), generator=g, dtype=torch.uint8))
+        torch.cuda.synchronize()
+        eng.launch_many([handles[k % S] for k in range(2 * S)], [streams[k % S] for k in range(2 * S)])  # two steps per slot
+        torch.cuda.synchronize()
+        total = 0
+        for j in range(S):
+            ro, rc = eng.detect(xs[j], 0.25, 0.7, graph=False, slot=j)
+            torch.cuda.synchronize()
+            assert torch.equal(outs[j][1], rc), (rnd, j)
+            for i in range(2):
+                n = int(rc[i])
+                total += n
+                assert torch.equal(outs[j][0][i, :n], ro[i, :n]), (rnd, j, i)
+        assert total > 0

@@ -112,6 +112,7 @@ EXPORTS = (
     "yl_engine_op_info", "yl_engine_detect_graph", "yl_detect_decode", "yl_nms_workspace_bytes", "yl_nms", "yl_decode_nms",
     "yl_preprocess_u8", "yl_letterbox_u8", "yl_nms_ml_workspace_bytes", "yl_nms_ml", "yl_engine_profile_detect",
     "yl_graph_branch_probe", "yl_engine_prefilter_fused", "yl_stream_create_masked", "yl_stream_destroy", "yl_xcc_census",
+    "yl_engine_detect_graph_prepare", "yl_graph_launch_many",
 )
 
 
@@ -211,6 +212,10 @@ def lib() -> C.CDLL:
                                 vp, vp]
     L.yl_engine_detect_graph.restype = i32
     L.yl_engine_detect_graph.argtypes = [vp, vp, i32, vp, f32, f32, i32, i32, vp, i32, i32, f32, vp, vp, vp, vp, vp]
+    L.yl_engine_detect_graph_prepare.restype = i32
+    L.yl_engine_detect_graph_prepare.argtypes = L.yl_engine_detect_graph.argtypes + [C.POINTER(vp)]
+    L.yl_graph_launch_many.restype = i32
+    L.yl_graph_launch_many.argtypes = [C.POINTER(vp), C.POINTER(vp), i32]
     L.yl_preprocess_u8.restype = i32
     L.yl_preprocess_u8.argtypes = [vp, i32, i32, i32, vp, vp]
     L.yl_letterbox_u8.restype = i32
@@ -228,7 +233,7 @@ def lib() -> C.CDLL:
     L.yl_xcc_census.argtypes = [vp, i32, vp]
     L.yl_engine_prefilter_fused.restype = i32
     L.yl_engine_prefilter_fused.argtypes = [vp, f32]
-    if L.yl_abi_version() != 14:
+    if L.yl_abi_version() != 15:
         raise RuntimeError("libyl_amd.so ABI version mismatch; rebuild it")
     _lib = L
     return L

@@ -1150,10 +1150,11 @@ static int detect_eager(yl_engine* e, const void* input, int in_dtype, void* wor
                            agnostic, classes, n_classes, max_cand, max_wh, scale, out, out_count, work, stream, nullptr, fused);
 }
 
-extern "C" int yl_engine_detect_graph(yl_engine* e, const void* input, int in_dtype, void* workspace,
-                                      float conf_thres, float iou_thres, int max_det, int agnostic,
-                                      const int32_t* classes, int n_classes, int max_cand, float max_wh,
-                                      const float* scale, float* out, int32_t* out_count, void* work, void* stream) {
+// the captured graph of one argument tuple (captured on first use); launch != 0: also launched on `stream`
+static int detect_graph_get(yl_engine* e, const void* input, int in_dtype, void* workspace, float conf_thres, float iou_thres,
+                            int max_det, int agnostic, const int32_t* classes, int n_classes, int max_cand, float max_wh,
+                            const float* scale, float* out, int32_t* out_count, void* work, void* stream, int launch,
+                            hipGraphExec_t* exec_out) {
   if (!e || !input || !workspace || !out || !out_count || !work)
     return fail(-1, "yl_engine_detect_graph: null pointer");
   if (e->levels.empty()) return fail(-1, "yl_engine_detect_graph: engine has no Detect levels");
@@ -1186,7 +1187,43 @@ extern "C" int yl_engine_detect_graph(yl_engine* e, const void* input, int in_dt
     e->dgraphs.insert(key, ge);
     exec = ge;
   }
-  YL_HIP(hipGraphLaunch(exec, s));
+  if (exec_out) *exec_out = exec;
+  if (launch) YL_HIP(hipGraphLaunch(exec, s));
+  return 0;
+}
+
+extern "C" int yl_engine_detect_graph(yl_engine* e, const void* input, int in_dtype, void* workspace,
+                                      float conf_thres, float iou_thres, int max_det, int agnostic,
+                                      const int32_t* classes, int n_classes, int max_cand, float max_wh,
+                                      const float* scale, float* out, int32_t* out_count, void* work, void* stream) {
+  return detect_graph_get(e, input, in_dtype, workspace, conf_thres, iou_thres, max_det, agnostic, classes, n_classes, max_cand,
+                          max_wh, scale, out, out_count, work, stream, 1, nullptr);
+}
+
+// The same graph WITHOUT launching it: a handle for yl_graph_launch_many.  (The first call for an argument tuple runs the
+// path once eagerly on `stream` -- argument checks, workspace preparation -- and captures it.)
+extern "C" int yl_engine_detect_graph_prepare(yl_engine* e, const void* input, int in_dtype, void* workspace,
+                                              float conf_thres, float iou_thres, int max_det, int agnostic,
+                                              const int32_t* classes, int n_classes, int max_cand, float max_wh,
+                                              const float* scale, float* out, int32_t* out_count, void* work, void* stream,
+                                              void** graph_out) {
+  if (!graph_out) return fail(-1, "yl_engine_detect_graph_prepare: null pointer");
+  hipGraphExec_t ex = nullptr;
+  const int rc = detect_graph_get(e, input, in_dtype, workspace, conf_thres, iou_thres, max_det, agnostic, classes, n_classes,
+                                  max_cand, max_wh, scale, out, out_count, work, stream, 0, &ex);
+  *graph_out = (void*)ex;
+  return rc;
+}
+
+// n prepared steps issued back to back: graphs[i] on streams[i].  One native call instead of n trips through the host
+// language: a step of the hot path is ONE graph launch (~10 us of host time); issued from Python it costs ~80 us, which in a
+// short run (20 steps on 20 streams) is a fill ramp of 1.6 ms in front of 13 ms of GPU work.
+extern "C" int yl_graph_launch_many(void* const* graphs, void* const* streams, int n) {
+  if (!graphs || !streams || n < 0) return fail(-1, "yl_graph_launch_many: bad arguments");
+  for (int i = 0; i < n; ++i) {
+    if (!graphs[i]) return fail(-1, "yl_graph_launch_many: null graph");
+    YL_HIP(hipGraphLaunch((hipGraphExec_t)graphs[i], (hipStream_t)streams[i]));
+  }
   return 0;
 }
 

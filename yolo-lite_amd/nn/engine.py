@@ -242,6 +242,12 @@ class HipEngine:
                 cls_t.data_ptr() if cls_t is not None else None, int(cls_t.numel()) if cls_t is not None else 0,
                 max_cand, float(max_wh), scale.data_ptr() if scale is not None else None, out.data_ptr(),
                 cnt.data_ptr(), work.data_ptr(), stream)
+        if graph == "prepare":  # the captured graph's handle, not launched (prepare_detect / launch_many)
+            h = C.c_void_p()
+            rc = self.lib.yl_engine_detect_graph_prepare(self._h, im.data_ptr(), _TORCH2YL[im.dtype], sl["ws"].data_ptr(),
+                                                         *args, C.byref(h))
+            _lib.check(rc, "yl_engine_detect_graph_prepare")
+            return out, cnt, h.value
         if graph:
             rc = self.lib.yl_engine_detect_graph(self._h, im.data_ptr(), _TORCH2YL[im.dtype], sl["ws"].data_ptr(),
                                                  *args)
@@ -252,6 +258,28 @@ class HipEngine:
                                         *args)
             _lib.check(rc, "yl_decode_nms")
         return out, cnt
+
+    def prepare_detect(self, im: torch.Tensor, conf: float = 0.25, iou: float = 0.7, max_det: int = 300, slot: int = 0, **kw):
+        """``detect(graph=True)`` without the launch: returns ``(out, cnt, graph_handle)`` -- the slot's engine-owned result
+        buffers and the handle of the captured hipGraph of exactly this call (same input tensor, thresholds, slot) for
+        ``launch_many``.  The first call for a given argument tuple runs the path once on the current stream and captures it."""
+        return self.detect(im, conf, iou, max_det=max_det, graph="prepare", slot=slot, **kw)
+
+    def launch_many(self, handles: Sequence[int], streams: Sequence["torch.cuda.Stream"]) -> None:
+        """Issue prepared steps back to back from native code (``yl_graph_launch_many``): ``handles[i]`` on ``streams[i]``.
+        One call for a whole round of batches in flight instead of one trip through Python per batch (~80 us each, which in
+        a 20-step run on 20 streams is a 1.6 ms fill ramp in front of 13 ms of GPU work).  No host synchronisation."""
+        n = len(handles)
+        if n != len(streams):
+            raise ValueError("one stream per step")
+        key = (tuple(handles), tuple(s.cuda_stream for s in streams))
+        cache = self.__dict__.setdefault("_many", {})
+        arr = cache.get(key)
+        if arr is None:
+            if len(cache) > 16:
+                cache.clear()
+            arr = cache[key] = ((C.c_void_p * n)(*handles), (C.c_void_p * n)(*[s.cuda_stream for s in streams]))
+        _lib.check(self.lib.yl_graph_launch_many(arr[0], arr[1], n), "yl_graph_launch_many")
 
     def detect_record(self, im: torch.Tensor, conf: float = 0.25, iou: float = 0.7, max_det: int = 300, slot: int = 0,
                       rec_key=0, **kw) -> torch.Tensor:
