@@ -26,7 +26,7 @@ w = (np.random.randn(cout, cin, k, k) / np.sqrt(cin * k * k)).astype(np.float32)
 b = np.zeros(cout, np.float32)
 for r in range(NREP):
     x, y = ar.alloc(H, W, cin, FP8 if f8 else BF16), ar.alloc(Ho, Wo, cout)
-    prog.ops.append(dict(kind=OP_CONV, name=f"c{r}", k=k, stride=s, act=1, inp=x, out=y, res=None, weight=w, bias=b, in_scale=0.05))
+    prog.ops.append(dict(kind=OP_CONV, name=f"c{r}", k=k, stride=s, act=int(os.environ.get("YL_MICRO_ACT", "1")), inp=x, out=y, res=None, weight=w, bias=b, in_scale=0.05))
 prog.ws_bytes = ar.top + 256
 eng = HipEngine(prog, dev)
 for o in prog.ops:

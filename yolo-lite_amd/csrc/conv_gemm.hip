@@ -32,6 +32,9 @@
 
 #include "conv_common.h"
 
+#ifndef YL_GEMM_ABL
+#define YL_GEMM_ABL 0  // development build switch: timing ablations of the main loop (wrong results)
+#endif
 namespace yl {
 
 typedef __attribute__((address_space(3))) void lds_void_g;
@@ -69,66 +72,107 @@ __global__ __launch_bounds__(128 * NWN) __attribute__((amdgpu_waves_per_eu(2))) 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int g = lane >> 4, n = lane & 15;
   const int wm = wave / NWN, wn = wave % NWN;
-  const int bid = xcd_remap(blockIdx.x, a.nblocks);
-  const int cb = bid % a.ncb;
-  const int q0 = (bid / a.ncb) * BN;           // first guarded position of the tile (from the start of the plane)
-  const int nk = a.ksteps / KS;                // K-slices
+  const int nk = a.ksteps / KS;                // K-slices per tile
 
   const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, (short)0, a.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rw =
       __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, (short)0, (unsigned)a.ncb * a.ksteps * MT * 1024u, 0x00020000);
-  const unsigned lane16 = (unsigned)lane * 16u;
-  const unsigned wbase = (unsigned)cb * a.ksteps * MT * 1024u;
-
-  // UP: byte offset of this lane's pixel in a plane of the low-resolution source.  Piece j = wave + NW * i of a slice always
-  // covers pixel part h = wave % NWN of the tile (NW and the A piece count are multiples of NWN): one offset per lane.
   const __amdgpu_buffer_rsrc_t rin2 =
       __builtin_amdgcn_make_buffer_rsrc((void*)a.in2, (short)0, UP ? a.in2_bytes : 0, 0x00020000);
-  unsigned off2 = 0;
-  if constexpr (UP) {
-    const int rb = q0 - a.in_g0;                                  // tile start relative to pixel (0, 0, 0)
-    const int b0 = __builtin_amdgcn_readfirstlane((rb < 0 ? 0 : rb) / a.in_img);
-    const int r = rb + wn * 64 + lane;
-    int t = r - b0 * a.in_img;                                    // < img + BN: at most one wrap (host: img >= BN)
-    const int wrap = t >= a.in_img;
-    const int b = b0 + wrap;
-    t -= wrap * a.in_img;
-    const int y = (int)__umulhi((unsigned)(t < 0 ? 0 : t), a.magic_w1);
-    const int x = t - y * a.in_w1;
-    const bool ok = r >= 0 && b < a.t_B && y < a.t_H && x < a.t_W;
-    off2 = ok ? (unsigned)(a.in2_g0 + b * a.in2_img + (y >> 1) * a.in2_w1 + (x >> 1)) * 16u : 0u;  // (position 0 is a zero guard)
-  }
+  const unsigned lane16 = (unsigned)lane * 16u;
   const int split_planes = UP ? 4 * a.ks_split : 0;
 
-  // K-slice `it` -> ring buffer `buf`: pieces wave, wave + NW, ... (wave-uniform addressing, the lane adds its 16 bytes).
-  // Slices past the end (ring refills of the last iterations) fall outside both descriptors: the pieces move nothing but
-  // still count in vmcnt, so the counted wait below is the same in every iteration.
-  auto issue = [&](int it, int buf) __attribute__((always_inline)) {
+  // Persistent workgroups: the grid is min(tiles, resident workgroups) and workgroup w takes tile j * grid + remap(w) in
+  // round j.  The ring of K-slices runs THROUGH the tile boundaries -- the last NS - 1 refills of a tile fetch the first
+  // slices of the next one -- so a tile's epilogue (SiLU + stores) runs with the next tile's operands in flight instead of
+  // in front of a cold prologue.  (Measured on 384 / 768 / 1536 -> 768 @160x160 x 8 with one tile per workgroup:
+  // 191 / 279 / 461 us = 1.34 PFLOP/s marginal + 103 us that do not depend on K.)
+  // Within a round the tiles of one XCD are consecutive (the channel blocks of a pixel tile share its L2).
+  const int G = (int)gridDim.x;
+  auto tile_of = [&](int j) __attribute__((always_inline)) {
+    const int left = a.nblocks - j * G;
+    const int cnt = left < G ? left : G;
+    return (int)blockIdx.x < cnt ? j * G + xcd_remap((int)blockIdx.x, cnt) : -1;
+  };
+  // Where a tile's operands come from: q0 = first guarded position (from the start of the plane), wbase = byte offset of the
+  // filter block, past = OOB_K for "no tile" (the pieces then move nothing but still count in vmcnt).
+  // UP: off2 = byte offset of this lane's pixel in a plane of the low-resolution source.  Piece j = wave + NW * i of a slice
+  // always covers pixel part h = wave % NWN of the tile (NW and the A piece count are multiples of NWN): one offset per lane.
+  struct Src {
+    int q0, cb;
+    unsigned wbase, past, off2;
+  };
+  auto src_of = [&](int tile) __attribute__((always_inline)) {
+    Src x;
+    const int t = tile < 0 ? 0 : tile;
+    x.cb = t % a.ncb;
+    x.q0 = (t / a.ncb) * BN;
+    x.wbase = (unsigned)x.cb * a.ksteps * MT * 1024u;
+    x.past = tile < 0 ? OOB_K : 0u;
+    x.off2 = 0;
+    if constexpr (UP) {
+      const int rb = x.q0 - a.in_g0;                                // tile start relative to pixel (0, 0, 0)
+      const int b0 = __builtin_amdgcn_readfirstlane((rb < 0 ? 0 : rb) / a.in_img);
+      const int r = rb + wn * 64 + lane;
+      int t2 = r - b0 * a.in_img;                                   // < img + BN: at most one wrap (host: img >= BN)
+      const int wrap = t2 >= a.in_img;
+      const int b = b0 + wrap;
+      t2 -= wrap * a.in_img;
+      const int y = (int)__umulhi((unsigned)(t2 < 0 ? 0 : t2), a.magic_w1);
+      const int xx = t2 - y * a.in_w1;
+      const bool ok = r >= 0 && b < a.t_B && y < a.t_H && xx < a.t_W;
+      x.off2 = ok ? (unsigned)(a.in2_g0 + b * a.in2_img + (y >> 1) * a.in2_w1 + (xx >> 1)) * 16u : 0u;  // (position 0 is a zero guard)
+    }
+    return x;
+  };
+
+  // K-slice `it` of the tile at `x` -> ring buffer `buf`: pieces wave, wave + NW, ... (wave-uniform addressing, the lane adds
+  // its 16 bytes).
+  auto issue = [&](const Src& x, int it, int buf) __attribute__((always_inline)) {
     const unsigned sbase = (unsigned)buf * STAGE;
-    const unsigned past = it < nk ? 0u : OOB_K;
+    const unsigned past = (YL_GEMM_ABL & 2) ? OOB_K : x.past;  // (ABL 2: timing ablation, no operand traffic)
 #pragma unroll
     for (int i = 0; i < PW; ++i) {
       const int j = wave + NW * i;  // scalar
       if (i < NPA / NW) {  // (NPA is a multiple of NW: the choice is made at compile time)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_g*)(gsm + sbase + (unsigned)j * 1024u), 16,
-                                                 (int)(lane16 + wbase + (unsigned)it * ASTAGE + (unsigned)j * 1024u + past), 0, 0, 0);
+                                                 (int)(lane16 + x.wbase + (unsigned)it * ASTAGE + (unsigned)j * 1024u + past), 0, 0, 0);
       } else {
         const int jb = j - NPA, p = jb / NWN, h = jb % NWN;   // plane of the slice (4 per k-step), 64-pixel part of the run
         const int gp = it * (4 * KS) + p;                     // plane of the whole input (scalar)
         if (UP && gp < split_planes) {
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rin2, (lds_void_g*)(gsm + sbase + ASTAGE + (unsigned)jb * 1024u), 16,
-                                                   (int)(off2 + (unsigned)gp * a.in2_plane + past), 0, 0, 0);
+                                                   (int)(x.off2 + (unsigned)gp * a.in2_plane + past), 0, 0, 0);
         } else {
-          const unsigned src = (unsigned)(gp - split_planes) * a.in_plane + (unsigned)(q0 + h * 64) * 16u;
+          const unsigned src = (unsigned)(gp - split_planes) * a.in_plane + (unsigned)(x.q0 + h * 64) * 16u;
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void_g*)(gsm + sbase + ASTAGE + (unsigned)jb * 1024u), 16,
                                                    (int)(lane16 + src + past), 0, 0, 0);
         }
       }
     }
   };
+  int tile = tile_of(0);  // (the grid never exceeds the tile count)
+  Src cur = src_of(tile);
+  if ((a.dbg >> 4) && (int)blockIdx.x >= G / 2)  // development: start the second workgroup of every CU out of phase
+    for (int k = 0; k < (a.dbg >> 4); ++k) __builtin_amdgcn_s_sleep(32);
 #pragma unroll
-  for (int st = 0; st < NS - 1; ++st) issue(st, st);
+  for (int st = 0; st < NS - 1; ++st) issue(cur, st, st);  // (host: at least NS - 1 slices per tile)
+  int gs0 = 0;    // ring position of the tile's slice 0
+  int round = 0;
 
+  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.out, (short)0, a.out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rres =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.res, (short)0, RES ? a.res_bytes : 0, 0x00020000);
+  const unsigned char* const abase = gsm + ((unsigned)(wm * MTW) * 64u + (unsigned)lane) * 16u;
+  const unsigned char* const bbase = gsm + ASTAGE + ((unsigned)g * BN + (unsigned)(wn * 64 + n)) * 16u;
+  struct Frags {
+    bf16x8 wa[MTW], xb[4];
+  };
+#pragma clang loop unroll(disable)
+  while (tile >= 0) {
+  const int ntile = tile_of(++round);
+  const Src nxt = src_of(ntile);
+  const int cb = cur.cb, q0 = cur.q0;
   // per-lane bias of its 4 rows of every tile (the accumulators start from it, as in conv_kernel)
   f32x4 acc[MTW][4];
   {
@@ -156,26 +200,29 @@ __global__ __launch_bounds__(128 * NWN) __attribute__((amdgpu_waves_per_eu(2))) 
       const int y = (int)__umulhi((unsigned)(t < 0 ? 0 : t), a.magic_w1);
       const int x = t - y * a.in_w1;
       const bool ok = r >= 0 && b < a.t_B && y < a.t_H && x < a.t_W;
-      po[nt] = ok ? (unsigned)(q0 + wn * 64 + loc) * 16u : OOB_LANE;
+      po[nt] = (ok && !(YL_GEMM_ABL & 8)) ? (unsigned)(q0 + wn * 64 + loc) * 16u : OOB_LANE;  // (ABL 8: nothing stored)
     }
   }
 
-  const unsigned char* const abase = gsm + ((unsigned)(wm * MTW) * 64u + (unsigned)lane) * 16u;
-  const unsigned char* const bbase = gsm + ASTAGE + ((unsigned)g * BN + (unsigned)(wn * 64 + n)) * 16u;
-  struct Frags {
-    bf16x8 wa[MTW], xb[4];
-  };
-  // Entering slice i: a COUNTED wait for my own DMA pieces of it (slices i + 1 .. i + NS - 2 stay in flight), all my LDS
-  // reads done, barrier -- now everybody's pieces of slice i have landed and nobody reads slice i - 1 any more -- and the
-  // buffer of slice i - 1 is refilled with slice i + NS - 1.
+  // Entering slice i of the tile (ring position gs0 + i): a COUNTED wait for my own DMA pieces of it (the NS - 2 younger
+  // slices stay in flight; epilogue stores of the previous tile that are still on their way only make the wait stricter),
+  // all my LDS reads done, barrier -- now everybody's pieces of slice i have landed and nobody reads the slice before it
+  // any more -- and that slice's buffer is refilled with slice i + NS - 1: of this tile, or of the next one.
   auto enter = [&](int i) __attribute__((always_inline)) {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * PW) : "memory");
     __builtin_amdgcn_s_barrier();
-    issue(i + NS - 1, (i + NS - 1) % NS);
+    const int sl = i + NS - 1;
+    const bool here = sl < nk;  // (wave-uniform: scalar selects)
+    Src x;
+    x.q0 = here ? cur.q0 : nxt.q0;
+    x.wbase = here ? cur.wbase : nxt.wbase;
+    x.past = here ? cur.past : nxt.past;
+    x.off2 = here ? cur.off2 : nxt.off2;
+    issue(x, here ? sl : sl - nk, (gs0 + sl) % NS);
   };
   auto load = [&](int i, int ks, Frags& f) __attribute__((always_inline)) {
-    const unsigned char* ab = abase + (i % NS) * STAGE + ks * (MT * 1024);
-    const unsigned char* bb = bbase + (i % NS) * STAGE + ks * BSTEP;
+    const unsigned char* ab = abase + ((gs0 + i) % NS) * STAGE + ks * (MT * 1024);
+    const unsigned char* bb = bbase + ((gs0 + i) % NS) * STAGE + ks * BSTEP;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) f.xb[nt] = *reinterpret_cast<const bf16x8*>(bb + nt * 256);
 #pragma unroll
@@ -203,8 +250,13 @@ __global__ __launch_bounds__(128 * NWN) __attribute__((amdgpu_waves_per_eu(2))) 
   };
   auto step = [&](Frags& f, int i, int ks, auto enter_tag) __attribute__((always_inline)) {
     constexpr bool ENTER = decltype(enter_tag)::value;
-    const unsigned char* ab = abase + (i % NS) * STAGE + ks * (MT * 1024);
-    const unsigned char* bb = bbase + (i % NS) * STAGE + ks * BSTEP;
+    const unsigned char* ab = abase + ((gs0 + i) % NS) * STAGE + ks * (MT * 1024);
+    const unsigned char* bb = bbase + ((gs0 + i) % NS) * STAGE + ks * BSTEP;
+    if constexpr ((YL_GEMM_ABL & 4) != 0) {  // (timing ablation: no fragment reads, the MFMAs re-use the registers)
+      if constexpr (ENTER) enter(i);
+      mma(f);
+      return;
+    }
     row(f, 0);
     row(f, 1);
     __builtin_amdgcn_sched_barrier(0);
@@ -258,9 +310,6 @@ __global__ __launch_bounds__(128 * NWN) __attribute__((amdgpu_waves_per_eu(2))) 
   }
 
   // epilogue: SiLU, residual, one 16-byte pixel of plane (pair, g) per lane and pixel tile
-  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.out, (short)0, a.out_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rres =
-      __builtin_amdgcn_make_buffer_rsrc((void*)a.res, (short)0, RES ? a.res_bytes : 0, 0x00020000);
   const unsigned plane0 = (unsigned)(cb * (MT * 2) + wm * (MTW * 2) + g);  // first output plane of this lane (8 channels per plane)
 #pragma unroll
   for (int p = 0; p < MTW / 2; ++p) {
@@ -302,6 +351,10 @@ __global__ __launch_bounds__(128 * NWN) __attribute__((amdgpu_waves_per_eu(2))) 
       }
     }
   }
+  tile = ntile;
+  cur = nxt;
+  gs0 = (gs0 + nk) % NS;
+  }  // tiles
 }
 
 // ------------------------------------------------------------------------------------ host
@@ -373,7 +426,12 @@ static int launch_gemm(const ConvArgs& a, size_t lds, hipStream_t s) {
     YL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr = true;
   }
-  hipLaunchKernelGGL(kern, dim3(a.nblocks), dim3(128 * NWN), lds, s, a);
+  if (a.ksteps / gm_ks(MTW, NWN, EVEN) < gm_ns(MTW, NWN, EVEN) - 1) return fail(-3, "conv_gemm: too few K-slices for the ring");
+  // persistent: as many workgroups as stay resident (256 CUs x two 4-wave or one 8-wave workgroup), each walks its tiles
+  static const int persist = getenv("YL_CONV_GEMM_PERSIST") ? atoi(getenv("YL_CONV_GEMM_PERSIST")) : 1;
+  const int resident = 256 * (NWN == 2 ? 2 : 1);
+  const int grid = persist && a.nblocks > resident ? resident : a.nblocks;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * NWN), lds, s, a);
   YL_HIP(hipGetLastError());
   return 0;
 }
