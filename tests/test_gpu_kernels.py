@@ -241,6 +241,35 @@ def test_depthwise_pointwise_fused(gpu_device, monkeypatch, c, cout, h, w, act2,
     assert bool(((got - ref).abs() <= tol).all()), float(((got - ref).abs() - tol).max())
 
 
+@pytest.mark.parametrize("c,cout,h,w", [(256, 80, 20, 20), (128, 80, 13, 9), (256, 64, 10, 10), (160, 72, 7, 5)])
+def test_depthwise_pointwise_deep_launch(gpu_device, monkeypatch, c, cout, h, w):
+    """Deep depthwise + pointwise launches on small maps (Detect level 2: 256 channels @20x20): dwpw_deep_kernel -- one
+    16-pixel patch per workgroup, the four waves split the channel blocks of the depthwise conv and the channel-tile pairs of
+    the GEMM -- against torch and, bit for bit, against dwpw_kernel (YL_DWPW_DEEP=0)."""
+    g = torch.Generator().manual_seed(c * 3 + cout)
+    x = _rand(g, 2, c, h, w)
+    wd = torch.randn(c, 1, 3, 3, generator=g) * 0.3
+    bd = torch.randn(c, generator=g) * 0.2
+    wp = _rand(g, cout, c, 1, 1, scale=1.0 / math.sqrt(c))
+    bp = torch.randn(cout, generator=g) * 0.3
+    mid = bf16_round(F.silu(F.conv2d(x, wd, bd, 1, 1, 1, c)))
+    ref = F.silu(F.conv2d(mid, wp, bp))
+    got = {}
+    for deep in ("1", "0"):
+        monkeypatch.setenv("YL_DWPW_DEEP", deep)
+        m = Mini(2, gpu_device)
+        xin, out = m.buf(h, w, c), m.buf(h, w, cout)
+        m.fill(xin, x)
+        m.op(kind=OP_DWCONV3, name="t", act=1, inp=xin, out=out, weight=np.ascontiguousarray(wd.numpy()),
+             bias=np.ascontiguousarray(bd.numpy()), post_weight=np.ascontiguousarray(wp.numpy().reshape(cout, c)),
+             post_bias=np.ascontiguousarray(bp.numpy()), post_act=1)
+        m.run()
+        got[deep] = m.read(out)
+    tol = 2.0 ** -7 * ref.abs() + 2.0 ** -7 * F.conv2d(mid.abs(), wp.abs()) + 1e-3
+    assert bool(((got["1"] - ref).abs() <= tol).all()), float(((got["1"] - ref).abs() - tol).max())
+    assert torch.equal(got["1"], got["0"])
+
+
 def test_conv_stem_cin3(gpu_device):
     g = torch.Generator().manual_seed(8)
     x3 = bf16_round(torch.rand(2, 3, 64, 64, generator=g))

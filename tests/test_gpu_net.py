@@ -594,10 +594,14 @@ def test_lds_staged_class_branch_is_bit_identical(gpu_device, monkeypatch):
     sd = synth_state_dict("n", 8, cls_bias=[-2.0, -2.0, -2.0], cls_gain=4.0)
     x = torch.rand(2, 3, 96, 128, generator=torch.Generator().manual_seed(77))
     monkeypatch.setenv("YL_DWPW_TILE", "1")
+    # the grouped launches of the class tails (YL_GROUP_LEVELS=2, the default) have no LDS-staged form: ungrouped here, so that
+    # every depthwise + pointwise launch of the branch goes through csrc/dwpw.hip
+    monkeypatch.setenv("YL_GROUP_LEVELS", "0")
     eng = _engine("n", sd, 2, 96, 128, gpu_device)
     y = eng.forward(x.to(gpu_device)).clone()
     lv = [t.clone() for t in eng.raw_levels()]
     monkeypatch.setenv("YL_DWPW_TILE", "0")
+    monkeypatch.delenv("YL_GROUP_LEVELS")
     ref_eng = _engine("n", sd, 2, 96, 128, gpu_device)
     assert torch.equal(y, ref_eng.forward(x.to(gpu_device)))
     for a, b in zip(lv, ref_eng.raw_levels()):

@@ -470,6 +470,133 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void d
   dwpw_body<MT, NT, PW2>(a, blockIdx.x);
 }
 
+// Deep launches on small maps (Detect level 2 of YOLO11n: 256 channels @20x20, 12 800 pixels per batch of 32): dwpw_kernel
+// gives every wave ALL channel blocks of its 16 pixels -- 16 dependent rounds of tap loads + 5 MFMAs -- and fills 200
+// workgroups.  Here a workgroup owns ONE 16-pixel patch and its four waves split the work: wave w the channel blocks
+// w, w + 4, ... of the depthwise conv (into the LDS tile), then the channel-tile PAIR w of the pointwise GEMM (its filter
+// fragments straight from global memory, requested before the depthwise phase; no 40 KB slab per workgroup).  Four times
+// the workgroups, a quarter of the serial chain.  Same MFMAs in the same order as dwpw_kernel: bit-identical.
+// A pair of tiles (2 w, 2 w + 1) of an MT-tile block stores exactly what block w of a two-tile tiling stores, the odd last
+// tile what block MT - 1 of a one-tile tiling stores (chan_in_block): the shared epilogue is called that way.
+template <int MT>
+__global__ __launch_bounds__(256) void dwpw_deep_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int P = 16;
+  constexpr int UNITS = (MT + 1) / 2;
+  static_assert(UNITS <= 4, "one pair of channel tiles per wave");
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = lane >> 4, n = lane & 15;
+  const int patch = xcd_remap(blockIdx.x, a.npatches);
+  bf16x8* tile = reinterpret_cast<bf16x8*>(smem);  // [cg][16]
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, (short)0, a.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.out, (short)0, a.out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc((void*)nullptr, (short)0, 0, 0x00020000);
+  Patch<1> Pp;
+  patch_setup<1>(a, patch, n, 0u, Pp);
+
+  const bool has = wave < UNITS;
+  const int mt0 = 2 * wave;
+  const bool two = mt0 + 1 < MT;
+  const bf16x8* wsrc = reinterpret_cast<const bf16x8*>(a.wpk);
+  const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  bf16x8 w[8][2];
+  auto loadw = [&](int ks0) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ks = min(ks0 + j, a.ksteps - 1);
+      w[j][0] = wsrc[(ks * MT + mt0) * 64 + lane];
+      w[j][1] = two ? wsrc[(ks * MT + mt0 + 1) * 64 + lane] : zero;
+    }
+  };
+  if (has) loadw(0);
+
+  {  // ---- depthwise 3x3 + bias + SiLU on the matrix pipe (dwpw_body's scheme), this wave's channel blocks
+    unsigned toff[5];
+#pragma unroll
+    for (int s5 = 0; s5 < 5; ++s5) {
+      const int q = 4 * s5 + g, sel = q >= 9, tap = q - 9 * sel;
+      toff[s5] = q < 18 ? (unsigned)(sel * (int)a.in_plane + ((tap / 3 - 1) * a.in_w1 + (tap % 3 - 1)) * 16) : OOB_K;
+    }
+    const int e = n & 7;
+    unsigned selm[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) selm[d] = (e >> 1) == d ? ((e & 1) ? 0xffff0000u : 0x0000ffffu) : 0u;
+    const u32x4* dwtab = reinterpret_cast<const u32x4*>(a.dw_wpk);
+    unsigned char* tb = reinterpret_cast<unsigned char*>(tile);
+    const int npp = a.cg >> 1;
+    struct DwIn {
+      u32x4 t;
+      f32x4 bv;
+      bf16x8 xb[5];
+    };
+    auto request = [&](int pp, DwIn& q) __attribute__((always_inline)) {
+      pp = min(pp, npp - 1);
+      q.t = dwtab[pp * 64 + lane];
+      q.bv = *reinterpret_cast<const f32x4*>(a.dw_b + pp * 16 + 4 * g);
+      const unsigned poff = (unsigned)(2 * pp) * a.in_plane;
+#pragma unroll
+      for (int s5 = 0; s5 < 5; ++s5)
+        q.xb[s5] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rin, Pp.base[0] + poff + toff[s5], 0, 0));
+    };
+    auto compute = [&](int pp, const DwIn& q) __attribute__((always_inline)) {
+      f32x4 dacc = q.bv;
+#pragma unroll
+      for (int s5 = 0; s5 < 5; ++s5) {
+        const unsigned w16 = (s5 & 1) ? (q.t[s5 >> 1] >> 16) : (q.t[s5 >> 1] & 0xffffu);
+        const unsigned both = w16 | (w16 << 16);
+        u32x4 wv;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) wv[d] = both & selm[d];
+        dacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv), q.xb[s5], dacc, 0, 0, 0);
+      }
+      if (a.dw_act) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dacc[r] = silu_f(dacc[r]);
+      }
+      bf16x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = (__bf16)dacc[r];
+      *reinterpret_cast<bf16x4*>(tb + ((size_t)(2 * pp + (g >> 1)) * P + n) * 16 + (g & 1) * 8) = o;
+    };
+    // four channel blocks requested at once (four register sets: 256 channels = ONE round of loads per wave)
+    for (int pp0 = wave; pp0 < npp; pp0 += 16) {
+      DwIn q[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) request(pp0 + 4 * j, q[j]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (pp0 + 4 * j < npp) compute(pp0 + 4 * j, q[j]);
+    }
+  }
+  __syncthreads();
+  if (!has) return;
+
+  // ---- 1x1 GEMM: B from the LDS tile, this wave's pair of channel tiles
+  f32x4 acc[2][1];
+  acc[0][0] = *reinterpret_cast<const f32x4*>(a.bias + chan_in_block(MT, mt0, g, 0));
+  acc[1][0] = two ? *reinterpret_cast<const f32x4*>(a.bias + chan_in_block(MT, mt0 + 1, g, 0)) : f32x4{0, 0, 0, 0};
+  for (int ks0 = 0; ks0 < a.ksteps; ks0 += 8) {
+    if (ks0) loadw(ks0);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (ks0 + j < a.ksteps) {
+        const int k8 = (ks0 + j) * 4 + g;
+        const bf16x8 xb = k8 < a.cg ? tile[k8 * P + n] : zero;
+        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j][0], xb, acc[0][0], 0, 0, 0);
+        if (two) acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[j][1], xb, acc[1][0], 0, 0, 0);
+      }
+    }
+  }
+  if (two) {
+    epilogue<2, 1>(a, rout, rres, wave, g, Pp.opix, acc);
+  } else {
+    f32x4 acc1[1][1];
+    acc1[0][0] = acc[0][0];
+    epilogue<1, 1>(a, rout, rres, MT - 1, g, Pp.opix, acc1);
+  }
+}
+
 // the same for up to three launches of one tiling (the class branch's second half is identical on every Detect level)
 template <int MT, int NT, bool PW2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void dwpw_group_kernel(ConvGroup G) {
@@ -831,6 +958,22 @@ int dwpw_launch(const ConvConfig& cfg0, ConvArgs a, int batch, hipStream_t s) {
     int handled = 0;
     const int rc = dwpw_tile_launch(cfg, a, batch, s, &handled);
     if (rc || handled) return rc;
+  }
+  {  // deep launches on small maps: one 16-pixel patch per workgroup, the waves split channels (dwpw_deep_kernel)
+    const int deep = getenv("YL_DWPW_DEEP") ? atoi(getenv("YL_DWPW_DEEP")) : 1;  // (read per launch: the tests switch it)
+    if (deep && cfg.NT == 1 && !a.wpk2 && cfg.cg >= 16 && !a.dbg) {
+      a.nblocks = a.npatches;
+      const size_t lds_deep = (size_t)cfg.cg * 256;
+      switch (cfg.MT) {
+        case 2: hipLaunchKernelGGL(dwpw_deep_kernel<2>, dim3(a.npatches), dim3(256), lds_deep, s, a); break;
+        case 4: hipLaunchKernelGGL(dwpw_deep_kernel<4>, dim3(a.npatches), dim3(256), lds_deep, s, a); break;
+        case 5: hipLaunchKernelGGL(dwpw_deep_kernel<5>, dim3(a.npatches), dim3(256), lds_deep, s, a); break;
+        case 8: hipLaunchKernelGGL(dwpw_deep_kernel<8>, dim3(a.npatches), dim3(256), lds_deep, s, a); break;
+        default: return fail(-3, "dwpw: unsupported tile shape");
+      }
+      YL_HIP(hipGetLastError());
+      return 0;
+    }
   }
   switch (cfg.MT * 10 + cfg.NT) {
     case 11: return launch_dwpw<1, 1>(cfg, a, lds, s);

@@ -388,7 +388,8 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
           // workgroup, 100 workgroups at 32 pixels per wave for batch 32): 16 pixels per wave double the workgroups and halve
           // each one's serial chain.  Launches that join a level group keep the group's tiling.
           static const int small_nt1 = getenv("YL_DWPW_SMALL_NT1") ? atoi(getenv("YL_DWPW_SMALL_NT1")) : 1;
-          if (small_nt1 && o.group == 0 && r.cfg.NT == 2 && C >= 128 && (r.cfg.npatches + 3) / 4 < 256) {
+          const int small_blocks = small_nt1 > 1 ? small_nt1 : 256;  // (> 1: the workgroup count below which it applies, development)
+          if (small_nt1 && o.group == 0 && r.cfg.NT == 2 && C >= 128 && (r.cfg.npatches + 3) / 4 < small_blocks) {
             r.cfg.NT = 1;
             r.cfg.npatches = (int)(((long long)batch * o.out.H * o.out.W + 15) / 16);
           }
