@@ -304,7 +304,12 @@ int conv_f8_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int 
   c->wpk_elems = (size_t)ncb * ksteps * MT * 2048;  // bytes
   c->npatches = (int)((npix + 16 * NT - 1) / (16 * NT));
   long long blocks1 = ((long long)c->npatches + 3) / 4 * ncb;
-  int ppw = (int)(blocks1 / (8 * 256));
+  // Patches per wave so that a launch has ~3 workgroups per CU: each workgroup stages its 40-80 KB filter slab once and the
+  // k-loops are short (7-14 steps), so fewer, longer workgroups cost less of the chip per launch.  YOLO11x 1280x1280 batch 8
+  // with 20 batches in flight: 8 per CU 1 042-1 053 images/s, 4: 1 058, 3: 1 072, 2: 1 066-1 070 (but one batch at a time
+  // 867 -> 820), 1: 1 066.  YL_F8_PPW_DIV overrides.
+  static const int ppw_div = getenv("YL_F8_PPW_DIV") ? atoi(getenv("YL_F8_PPW_DIV")) : 3;
+  int ppw = (int)(blocks1 / (ppw_div * 256));
   if (ppw < 1) ppw = 1;
   if (ppw > 32) ppw = 32;
   if (kchunk < ksteps) ppw = 1;
