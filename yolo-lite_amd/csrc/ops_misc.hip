@@ -518,19 +518,23 @@ constexpr int AT_KD = 32, AT_HD = 64;
 constexpr int AT_STAGE = 512;          // keys resident in LDS at a time
 constexpr int AT_KP = AT_KD + 8;       // K row pitch (elements): 80-byte rows
 constexpr int AT_VP = AT_STAGE + 8;    // V^T row pitch (elements)
-constexpr int AT_QSPLIT = 4;           // workgroups per (image, head)
-
 constexpr int AT_WAVES = 8;  // waves per workgroup: 4 x 8 = 32 query-tile slots per (image, head) cover the 25 tiles of a
                              // 20x20 map in ONE round (4 waves needed two, the second 9/16 full)
-__global__ __launch_bounds__(64 * AT_WAVES) __attribute__((amdgpu_waves_per_eu(2))) void attention_kernel(AttnArgs a) {
+
+// R = query tiles per wave.  The key / value stages are the OUTER loop and a wave carries the softmax state of its R query
+// tiles through them, so K and V^T are staged once per workgroup however many rounds it has (round 3; before, every round
+// restaged every stage: 16 stagings per workgroup at 40x40 = 1600 tokens, YOLO11x at 1280x1280: 187 us).  Per query tile
+// the keys are visited in the same order as before: results are bit-identical.
+template <int R>
+__global__ __launch_bounds__(64 * AT_WAVES) __attribute__((amdgpu_waves_per_eu(2))) void attention_kernel(AttnArgs a, int qsplit) {
   extern __shared__ __attribute__((aligned(16))) unsigned char asm_[];
   __bf16* sK = reinterpret_cast<__bf16*>(asm_);   // [AT_STAGE][AT_KP]
   __bf16* sVt = sK + AT_STAGE * AT_KP;            // [64][AT_VP]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, n = lane & 15;
   int bid = blockIdx.x;
-  const int qs = bid % AT_QSPLIT;
-  bid /= AT_QSPLIT;
+  const int qs = bid % qsplit;
+  bid /= qsplit;
   const int head = bid % a.heads;
   const int b = bid / a.heads;
   const int hstride = 2 * AT_KD + AT_HD;
@@ -542,84 +546,89 @@ __global__ __launch_bounds__(64 * AT_WAVES) __attribute__((amdgpu_waves_per_eu(2
   };
   const int nqt = (a.N + 15) / 16;                       // query tiles
   const int nstage = (a.N + AT_STAGE - 1) / AT_STAGE;
-  const int wslot = qs * AT_WAVES + wave;                // this wave takes q tiles wslot, wslot + AT_WAVES * AT_QSPLIT, ...
-  const int rounds = (nqt + AT_WAVES * AT_QSPLIT - 1) / (AT_WAVES * AT_QSPLIT);
+  const int wslot = qs * AT_WAVES + wave;                // this wave takes q tiles wslot, wslot + AT_WAVES * qsplit, ...
   const float ninf = -__builtin_huge_valf();
 
-  for (int rd = 0; rd < rounds; ++rd) {
-    const int qt = wslot + rd * AT_WAVES * AT_QSPLIT;
-    const bool active = qt < nqt;
-    const int q = qt * 16 + n;
-    bf16x8 qf = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (active && q < a.N) qf = *reinterpret_cast<const bf16x8*>(pv_ptr(a.in, hplane + g, tok(q)));
-    float m = ninf, l = 0.f;
-    f32x4 acc[4];
+  bool active[R];
+  int q[R];
+  bf16x8 qf[R];
+  float m[R], l[R];
+  f32x4 acc[R][4];
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int r = 0; r < R; ++r) {
+    const int qt = wslot + r * AT_WAVES * qsplit;
+    active[r] = qt < nqt;
+    q[r] = qt * 16 + n;
+    qf[r] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    if (active[r] && q[r] < a.N) qf[r] = *reinterpret_cast<const bf16x8*>(pv_ptr(a.in, hplane + g, tok(q[r])));
+    m[r] = ninf;
+    l[r] = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) acc[r][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
-    for (int st = 0; st < nstage; ++st) {
-      const int k0s = st * AT_STAGE;
-      const int nk = min(AT_STAGE, a.N - k0s);
-      const int nk32 = (nk + 31) & ~31;
-      if (nstage > 1 || rd == 0) {
-        __syncthreads();  // previous users of the stage buffers are done
-        // loads are issued in batches of 8 per thread before the first LDS write (one memory round
-        // trip per batch instead of one per vector)
-        for (int i0 = tid; i0 < nk32 * 4; i0 += 64 * AT_WAVES * 8) {
-          bf16x8 v[8];
+  for (int st = 0; st < nstage; ++st) {
+    const int k0s = st * AT_STAGE;
+    const int nk = min(AT_STAGE, a.N - k0s);
+    const int nk32 = (nk + 31) & ~31;
+    if (st) __syncthreads();  // previous users of the stage buffers are done
+    // loads are issued in batches of 8 per thread before the first LDS write (one memory round
+    // trip per batch instead of one per vector)
+    for (int i0 = tid; i0 < nk32 * 4; i0 += 64 * AT_WAVES * 8) {
+      bf16x8 v[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int i = i0 + u * 64 * AT_WAVES, key = i >> 2, c8 = i & 3;
-            v[u] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            if (i < nk32 * 4 && key < nk)
-              v[u] = *reinterpret_cast<const bf16x8*>(pv_ptr(a.in, hplane + AT_KD / 8 + c8, tok(k0s + key)));
-          }
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int i = i0 + u * 64 * AT_WAVES, key = i >> 2, c8 = i & 3;
-            if (i < nk32 * 4) *reinterpret_cast<bf16x8*>(sK + key * AT_KP + c8 * 8) = v[u];
-          }
-        }
-        for (int i0 = tid; i0 < nk32 * 8; i0 += 64 * AT_WAVES * 8) {
-          bf16x8 v[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int i = i0 + u * 64 * AT_WAVES, key = i >> 3, c8 = i & 7;
-            v[u] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            if (i < nk32 * 8 && key < nk)
-              v[u] = *reinterpret_cast<const bf16x8*>(pv_ptr(a.in, hplane + 2 * AT_KD / 8 + c8, tok(k0s + key)));
-          }
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int i = i0 + u * 64 * AT_WAVES, key = i >> 3, c8 = i & 7;
-            if (i < nk32 * 8) {
-#pragma unroll
-              for (int j = 0; j < 8; ++j) sVt[(c8 * 8 + j) * AT_VP + key] = v[u][j];
-            }
-          }
-        }
-        __syncthreads();
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * 64 * AT_WAVES, key = i >> 2, c8 = i & 3;
+        v[u] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (i < nk32 * 4 && key < nk)
+          v[u] = *reinterpret_cast<const bf16x8*>(pv_ptr(a.in, hplane + AT_KD / 8 + c8, tok(k0s + key)));
       }
-      if (!active) continue;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + u * 64 * AT_WAVES, key = i >> 2, c8 = i & 3;
+        if (i < nk32 * 4) *reinterpret_cast<bf16x8*>(sK + key * AT_KP + c8 * 8) = v[u];
+      }
+    }
+    // V^T: a thread takes 8 CONSECUTIVE keys of one plane (8 channels), transposes the 8 x 8 block in registers and writes
+    // eight 16-byte rows (before: 64 two-byte LDS writes per thread and batch)
+    for (int it = tid; it < nk32; it += 64 * AT_WAVES) {  // item = (key group of 8, plane)
+      const int kg = it >> 3, c8 = it & 7;
+      bf16x8 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int key = kg * 8 + u;
+        v[u] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (key < nk) v[u] = *reinterpret_cast<const bf16x8*>(pv_ptr(a.in, hplane + 2 * AT_KD / 8 + c8, tok(k0s + key)));
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bf16x8 wv = {v[0][j], v[1][j], v[2][j], v[3][j], v[4][j], v[5][j], v[6][j], v[7][j]};
+        *reinterpret_cast<bf16x8*>(sVt + (c8 * 8 + j) * AT_VP + kg * 8) = wv;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (!active[r]) continue;
       for (int k0 = 0; k0 < nk32; k0 += 32) {
         const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(sK + (k0 + n) * AT_KP + g * 8);
         const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(sK + (k0 + 16 + n) * AT_KP + g * 8);
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        const f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, qf, z, 0, 0, 0);
-        const f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf, z, 0, 0, 0);
+        const f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, qf[r], z, 0, 0, 0);
+        const f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf[r], z, 0, 0, 0);
         float v[8];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          v[r] = (k0 + 4 * g + r < nk) ? s0[r] * a.scale : ninf;
-          v[4 + r] = (k0 + 16 + 4 * g + r < nk) ? s1[r] * a.scale : ninf;
+        for (int rr = 0; rr < 4; ++rr) {
+          v[rr] = (k0 + 4 * g + rr < nk) ? s0[rr] * a.scale : ninf;
+          v[4 + rr] = (k0 + 16 + 4 * g + rr < nk) ? s1[rr] * a.scale : ninf;
         }
         float lm = v[0];
 #pragma unroll
         for (int j = 1; j < 8; ++j) lm = fmaxf(lm, v[j]);
         lm = fmaxf(lm, __shfl_xor(lm, 16));
         lm = fmaxf(lm, __shfl_xor(lm, 32));
-        const float mn = fmaxf(m, lm);  // finite: every processed step has at least one real key
-        const float alpha = __expf(m - mn);
+        const float mn = fmaxf(m[r], lm);  // finite: every processed step has at least one real key
+        const float alpha = __expf(m[r] - mn);
         float ps = 0.f;
         bf16x8 pb;
 #pragma unroll
@@ -628,8 +637,8 @@ __global__ __launch_bounds__(64 * AT_WAVES) __attribute__((amdgpu_waves_per_eu(2
           ps += e;
           pb[j] = (__bf16)e;
         }
-        l = l * alpha + ps;
-        m = mn;
+        l[r] = l[r] * alpha + ps;
+        m[r] = mn;
 #pragma unroll
         for (int dt = 0; dt < 4; ++dt) {
           const __bf16* vr = sVt + (dt * 16 + n) * AT_VP + k0 + 4 * g;
@@ -637,39 +646,59 @@ __global__ __launch_bounds__(64 * AT_WAVES) __attribute__((amdgpu_waves_per_eu(2
           const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vr + 16);
           const bf16x8 av = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[dt][r] *= alpha;
-          acc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, pb, acc[dt], 0, 0, 0);
+          for (int rr = 0; rr < 4; ++rr) acc[r][dt][rr] *= alpha;
+          acc[r][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, pb, acc[r][dt], 0, 0, 0);
         }
       }
     }
-    if (active) {
-      l += __shfl_xor(l, 16);
-      l += __shfl_xor(l, 32);
-      if (q < a.N) {
-        const float inv = 1.0f / l;
-        const int qy = q / a.W;
-        const int po = pv_pix(a.out, b, qy, q - qy * a.W);
+  }
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-          *reinterpret_cast<bf16x4*>(pv_ptr(a.out, (head * AT_HD + dt * 16 + 4 * g) >> 3, po) + ((4 * g) & 7)) =
-              bf16x4{(__bf16)(acc[dt][0] * inv), (__bf16)(acc[dt][1] * inv), (__bf16)(acc[dt][2] * inv),
-                     (__bf16)(acc[dt][3] * inv)};
-      }
+  for (int r = 0; r < R; ++r) {
+    if (!active[r]) continue;
+    float lr = l[r];
+    lr += __shfl_xor(lr, 16);
+    lr += __shfl_xor(lr, 32);
+    if (q[r] < a.N) {
+      const float inv = 1.0f / lr;
+      const int qy = q[r] / a.W;
+      const int po = pv_pix(a.out, b, qy, q[r] - qy * a.W);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        *reinterpret_cast<bf16x4*>(pv_ptr(a.out, (head * AT_HD + dt * 16 + 4 * g) >> 3, po) + ((4 * g) & 7)) =
+            bf16x4{(__bf16)(acc[r][dt][0] * inv), (__bf16)(acc[r][dt][1] * inv), (__bf16)(acc[r][dt][2] * inv),
+                   (__bf16)(acc[r][dt][3] * inv)};
     }
   }
 }
 
-int attention_launch(const AttnArgs& a, hipStream_t s) {
-  const size_t lds = ((size_t)AT_STAGE * AT_KP + (size_t)AT_HD * AT_VP) * 2;
+template <int R>
+static int launch_attention(const AttnArgs& a, int qsplit, size_t lds, hipStream_t s) {
+  auto kern = attention_kernel<R>;
   static bool attr = false;
   if (!attr) {
-    YL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    YL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr = true;
   }
-  hipLaunchKernelGGL(attention_kernel, dim3(a.batch * a.heads * AT_QSPLIT), dim3(64 * AT_WAVES), lds, s, a);
+  hipLaunchKernelGGL(kern, dim3(a.batch * a.heads * qsplit), dim3(64 * AT_WAVES), lds, s, a, qsplit);
   YL_HIP(hipGetLastError());
   return 0;
+}
+
+int attention_launch(const AttnArgs& a, hipStream_t s) {
+  const size_t lds = ((size_t)AT_STAGE * AT_KP + (size_t)AT_HD * AT_VP) * 2;
+  // workgroups per (image, head): four; more only when a wave would carry more than four query tiles (every workgroup
+  // stages ALL keys and values of its head: 40x40 tokens, YOLO11x batch 8: 4 workgroups 105 us per launch, 7: 150 us)
+  const int nqt = (a.N + 15) / 16;
+  static const int qs_env = getenv("YL_ATTN_QSPLIT") ? atoi(getenv("YL_ATTN_QSPLIT")) : 0;  // development
+  int qsplit = qs_env > 0 ? qs_env : 4;
+  auto rounds_of = [&](int qs) { return (nqt + AT_WAVES * qs - 1) / (AT_WAVES * qs); };
+  while (qs_env <= 0 && rounds_of(qsplit) > 4 && qsplit < 16) ++qsplit;
+  const int rounds = rounds_of(qsplit);
+  if (rounds <= 1) return launch_attention<1>(a, qsplit, lds, s);
+  if (rounds == 2) return launch_attention<2>(a, qsplit, lds, s);
+  if (rounds <= 4) return launch_attention<4>(a, qsplit, lds, s);
+  if (rounds <= 8) return launch_attention<8>(a, qsplit, lds, s);
+  return fail(-3, "attention: more than 16384 tokens per image");
 }
 
 // ---------------------------------------------------------------------------- Detect decode
