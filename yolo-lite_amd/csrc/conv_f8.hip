@@ -24,6 +24,9 @@
 
 #include <cmath>
 
+#ifndef YL_F8_D
+#define YL_F8_D 2  // build switch (development): prefetch depth of conv_f8_kernel for MT <= 3
+#endif
 namespace yl {
 
 typedef int v8i __attribute__((ext_vector_type(8)));
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
   const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.out, (short)0, a.out_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rres =
       __builtin_amdgcn_make_buffer_rsrc((void*)a.res, (short)0, a.res ? a.res_bytes : 0, 0x00020000);
-  constexpr int D = 2;
+  constexpr int D = MT <= 3 ? YL_F8_D : 2;  // k-steps of activation fragments in flight (narrow tiles can afford more)
   v8i xr[D][NT];
   Patch<NT> P;
   const unsigned lane_off = UNIFORM ? (unsigned)(2 * g) * a.in_plane : 0u;
@@ -278,7 +281,8 @@ int conv_f8_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int 
   if ((size_t)ksteps * step_bytes > slab_max) kchunk = (int)(slab_max / step_bytes) & ~1;  // multiple of the ring depth
   const long long npix = (long long)batch * Ho * Wo;
   const int ncb = cout16 / MT;
-  const int NT = (npix + 63) / 64 * ncb / 4 >= 256 || MT == 6 ? 4 : 2;
+  const int force_nt = getenv("YL_F8_NT") ? atoi(getenv("YL_F8_NT")) : 0;  // development: pixel tiles per wave for MT <= 4
+  const int NT = (force_nt == 2 || force_nt == 4) && MT != 6 ? force_nt : ((npix + 63) / 64 * ncb / 4 >= 256 || MT == 6 ? 4 : 2);
   c->MT = MT;
   c->NT = NT;
   c->ncb = ncb;
