@@ -106,6 +106,45 @@ def test_conv_gemm_vs_torch_and_conv_kernel(gpu_device, monkeypatch, cin, cout, 
     assert torch.equal(got, direct), f"gemm vs conv_kernel differ: max {float((got - direct).abs().max())}"
 
 
+GEMM3_CASES = [
+    # Cin, Cout, stride, H, W, act, res      conv_gemm_kernel on 3x3 convs (nine shifted GEMMs; stride 2: per-lane source pixel)
+    (64, 128, 2, 24, 32, True, False),     # YOLO11s layer 3 (64 -> 128): K = 18 k-steps, 128-channel blocks
+    (128, 256, 2, 26, 22, True, False),    # layer 5: 256-channel blocks (ring of three slices)
+    (128, 128, 2, 21, 35, True, False),    # odd input size: the last output row / column read the guards
+    (128, 128, 1, 12, 12, True, True),     # stride 1 with the Bottleneck residual
+    (64, 192, 1, 13, 11, False, False),    # 192-channel blocks, no activation
+    (96, 128, 2, 30, 18, True, False),     # 96 channels: 27 k-steps (odd: ring of four)
+]
+
+
+@pytest.mark.parametrize("w8", ["0", "-1"])
+@pytest.mark.parametrize("cin,cout,s,h,w,act,res", GEMM3_CASES)
+def test_conv_gemm_3x3_vs_torch_and_conv_kernel(gpu_device, monkeypatch, cin, cout, s, h, w, act, res, w8):
+    """The GEMM-class kernel on 3x3 convs against torch and against conv_kernel (YL_CONV_GEMM3=0).  Its K order -- (block
+    of four planes, tap) -- differs from conv_kernel's, so the two agree to fp32 summation order, not bit for bit."""
+    monkeypatch.setenv("YL_CONV_GEMM_W8", w8)
+    monkeypatch.setenv("YL_CONV_GEMM_BLOCKS", "1")
+    g = torch.Generator().manual_seed(cin * 3 + cout + h + s)
+    B = 5
+    x = _rand(g, B, cin, h, w)
+    wt = _rand(g, cout, cin, 3, 3, scale=1.0 / math.sqrt(cin * 9))
+    b = torch.randn(cout, generator=g) * 0.5
+    ref = F.conv2d(x, wt, b, s, 1)
+    if act:
+        ref = F.silu(ref)
+    r = None
+    if res:
+        r = _rand(g, *ref.shape)
+        ref = ref + r
+    name = "conv3x3s2_gemm_mfma" if s == 2 else "conv3x3_gemm_mfma"
+    got = run_conv(gpu_device, x, wt, b, 3, s, act, r, expect_kernel=name)
+    _assert_close_bf16(got, ref, f"gemm 3x3 conv {cin}->{cout} s{s}")
+    monkeypatch.setenv("YL_CONV_GEMM3", "0")
+    direct = run_conv(gpu_device, x, wt, b, 3, s, act, r)
+    # same operands, different summation order: one bf16 ulp of the result plus the fp32 reordering noise
+    assert bool(((got - direct).abs() <= 2.0 ** -7 * direct.abs() + 2e-3).all()), float((got - direct).abs().max())
+
+
 @pytest.mark.parametrize("cin,cout,k,s,h,w,act,res", CONV_CASES)
 def test_conv_vs_torch(gpu_device, cin, cout, k, s, h, w, act, res):
     g = torch.Generator().manual_seed(cin * 1000 + cout * 10 + k + s)

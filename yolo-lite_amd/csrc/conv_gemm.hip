@@ -55,8 +55,14 @@ size_t conv_gemm_lds_bytes(int MTW, int NWN, bool even) {
 // UP: the first 32 * ks_split input channels are a nearest-neighbour 2x upsampling of a low-resolution map (nn.Upsample + Concat in
 // front of the conv, yolo11.yaml:31-36) and are read from that map itself at pixel (y / 2, x / 2): the LDS-DMA source address is
 // per lane (the LDS destination stays linear), so the gather costs one address per lane and tile.
-template <int MTW, int NWN, int KS, int NS, bool RES, bool ACT, bool O8, bool UP = false>
+// GEO: 0 = 1x1 conv; 1 = 3x3 stride 1; 2 = 3x3 stride 2 (round 3).  A 3x3 conv is nine shifted 1x1 GEMMs accumulated: in the
+// guarded layout a tap is a constant offset of the source position (stride 1) or of a per-lane source position (stride 2:
+// the lane's output pixel (y, x) reads input pixel (2y + dy, 2x + dx); one offset per lane and tile, as for UP).  K order:
+// k-step = (block of 4 planes, tap), the nine taps of a plane block back to back -- a workgroup's input footprint is swept
+// once per plane block, not once per tap (the reuse distance that made the tap-major conv_kernel fetch layer 3 twice).
+template <int MTW, int NWN, int KS, int NS, bool RES, bool ACT, bool O8, bool UP = false, int GEO = 0>
 __global__ __launch_bounds__(128 * NWN) __attribute__((amdgpu_waves_per_eu(2))) void conv_gemm_kernel(ConvArgs a) {
+  static_assert(GEO == 0 || (!UP && !O8), "3x3: plain bf16 convs");
   extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
   constexpr int NW = 2 * NWN;                  // waves
   constexpr int BN = 64 * NWN;                 // pixels per workgroup
@@ -110,6 +116,19 @@ __global__ __launch_bounds__(128 * NWN) __attribute__((amdgpu_waves_per_eu(2))) 
     x.wbase = (unsigned)x.cb * a.ksteps * MT * 1024u;
     x.past = tile < 0 ? OOB_K : 0u;
     x.off2 = 0;
+    if constexpr (GEO == 2) {  // byte offset of input pixel (2y, 2x) of this lane's output position, in a plane
+      const int rb = x.q0 - a.out_g0 + wn * 64;                     // the wave's 64 positions (wave-uniform start)
+      const int b0 = __builtin_amdgcn_readfirstlane((rb < 0 ? 0 : rb) / a.out_img);
+      const int r = rb + lane;
+      int t2 = r - b0 * a.out_img;                                  // < img + 64: at most one wrap (host: img >= 128)
+      const int wrap = t2 >= a.out_img;
+      const int b = b0 + wrap;
+      t2 -= wrap * a.out_img;
+      const int y = (int)__umulhi((unsigned)(t2 < 0 ? 0 : t2), a.magic_w1);
+      const int xx = t2 - y * a.out_w1;
+      const bool ok = r >= 0 && b < a.t_B && y < a.t_H && xx < a.t_W;
+      x.off2 = ok ? (unsigned)(a.in_g0 + b * a.in_img + 2 * y * a.in_w1 + 2 * xx) * 16u : 0u;  // (position 0 is a zero guard)
+    }
     if constexpr (UP) {
       const int rb = x.q0 - a.in_g0;                                // tile start relative to pixel (0, 0, 0)
       const int b0 = __builtin_amdgcn_readfirstlane((rb < 0 ? 0 : rb) / a.in_img);
@@ -139,6 +158,20 @@ __global__ __launch_bounds__(128 * NWN) __attribute__((amdgpu_waves_per_eu(2))) 
                                                  (int)(lane16 + x.wbase + (unsigned)it * ASTAGE + (unsigned)j * 1024u + past), 0, 0, 0);
       } else {
         const int jb = j - NPA, p = jb / NWN, h = jb % NWN;   // plane of the slice (4 per k-step), 64-pixel part of the run
+        if constexpr (GEO != 0) {
+          const int ksg = it * KS + (p >> 2);                                // k-step of the conv: (plane block, tap)
+          const int pb = (int)__umulhi((unsigned)ksg, 477218589u);            // ksg / 9
+          const int tapoff = tap_offset<3>(a, ksg - 9 * pb);                  // bytes, may be negative (wraps out of range -> zeros)
+          const unsigned src = (unsigned)(pb * 4 + (p & 3)) * a.in_plane + (unsigned)tapoff;
+          if constexpr (GEO == 1) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void_g*)(gsm + sbase + ASTAGE + (unsigned)jb * 1024u), 16,
+                                                     (int)(lane16 + src + (unsigned)(x.q0 + h * 64) * 16u + past), 0, 0, 0);
+          } else {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void_g*)(gsm + sbase + ASTAGE + (unsigned)jb * 1024u), 16,
+                                                     (int)(x.off2 + src + past), 0, 0, 0);
+          }
+          continue;
+        }
         const int gp = it * (4 * KS) + p;                     // plane of the whole input (scalar)
         if (UP && gp < split_planes) {
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rin2, (lds_void_g*)(gsm + sbase + ASTAGE + (unsigned)jb * 1024u), 16,
@@ -187,18 +220,19 @@ __global__ __launch_bounds__(128 * NWN) __attribute__((amdgpu_waves_per_eu(2))) 
   // output positions of this lane's four pixel tiles: valid pixels only (guards are computed, never stored)
   unsigned po[4];
   {
-    const int r0 = q0 + wn * 64 - a.in_g0;                      // position of the wave's first pixel relative to pixel (0, 0, 0)
-    const int b0 = __builtin_amdgcn_readfirstlane((r0 < 0 ? 0 : r0) / a.in_img);  // wave-uniform: one division per tile
+    // (output geometry: the same as the input's except behind a stride-2 conv)
+    const int r0 = q0 + wn * 64 - a.out_g0;                     // position of the wave's first pixel relative to pixel (0, 0, 0)
+    const int b0 = __builtin_amdgcn_readfirstlane((r0 < 0 ? 0 : r0) / a.out_img);  // wave-uniform: one division per tile
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       const int loc = nt * 16 + n;
       const int r = r0 + loc;                                    // < 0: in front of the first image (guard row)
-      int t = r - b0 * a.in_img;                                 // position inside image b0, < img + 64 (host: img >= 128)
-      const int wrap = t >= a.in_img;
+      int t = r - b0 * a.out_img;                                // position inside image b0, < img + 64 (host: img >= 128)
+      const int wrap = t >= a.out_img;
       const int b = b0 + wrap;
-      t -= wrap * a.in_img;
+      t -= wrap * a.out_img;
       const int y = (int)__umulhi((unsigned)(t < 0 ? 0 : t), a.magic_w1);
-      const int x = t - y * a.in_w1;
+      const int x = t - y * a.out_w1;
       const bool ok = r >= 0 && b < a.t_B && y < a.t_H && x < a.t_W;
       po[nt] = (ok && !(YL_GEMM_ABL & 8)) ? (unsigned)(q0 + wn * 64 + loc) * 16u : OOB_LANE;  // (ABL 8: nothing stored)
     }
@@ -368,7 +402,10 @@ void conv_gemm_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, i
   const int enable = getenv("YL_CONV_GEMM") ? atoi(getenv("YL_CONV_GEMM")) : 1;
   const int min_c = getenv("YL_CONV_GEMM_MINC") ? atoi(getenv("YL_CONV_GEMM_MINC")) : 128;
   const int min_blocks = getenv("YL_CONV_GEMM_BLOCKS") ? atoi(getenv("YL_CONV_GEMM_BLOCKS")) : 384;
-  if (!enable || k != 1 || stride != 1 || Cin % 32 || Cin < min_c || Cout < min_c) return;
+  // 3x3 convs (stride 1 or 2; YL_CONV_GEMM3=0 turns them off): K = 9 x Cin, so 64 input channels are deep enough
+  const int enable3 = getenv("YL_CONV_GEMM3") ? atoi(getenv("YL_CONV_GEMM3")) : 1;
+  const bool k3 = k == 3 && enable3 && (stride == 1 || stride == 2) && !cin2 && Cin >= 64;
+  if (!enable || !(k3 || (k == 1 && stride == 1 && Cin >= min_c)) || Cin % 32 || Cout < min_c) return;
   int MTW = 0;
   if (Cout % 256 == 0) MTW = 8;
   else if (Cout % 192 == 0) MTW = 6;
@@ -398,6 +435,8 @@ void conv_gemm_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, i
   if (ntiles * ncb < min_blocks) return;                       // a grid that cannot fill 256 CUs: conv_kernel's finer tiles
   c->gemm = MTW;
   c->gemm_nwn = NWN;
+  c->kord = k3 ? 2 : 0;  // 3x3: k-step = (block of 4 planes, tap), see conv_pack_weights
+  c->uniform = 1;
   c->MT = 2 * MTW;
   c->NT = 4;
   c->ncb = ncb;
@@ -408,19 +447,29 @@ void conv_gemm_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, i
   c->lds_bytes = conv_gemm_lds_bytes(MTW, NWN, c->ksteps % 2 == 0);
   c->wpk_elems = (size_t)ncb * c->ksteps * c->MT * 64 * 8;
   c->gws = (int)ntiles;
-  c->name = "conv1x1_gemm_mfma";
+  c->name = k3 ? (stride == 2 ? "conv3x3s2_gemm_mfma" : "conv3x3_gemm_mfma") : "conv1x1_gemm_mfma";
 }
 
-template <int MTW, int NWN, bool EVEN, bool RES, bool ACT, bool O8 = false, bool UP = false>
+template <int MTW, int NWN, bool EVEN, bool RES, bool ACT, bool O8 = false, bool UP = false, int GEO = 0>
 static int launch_gemm(const ConvArgs& a, size_t lds, hipStream_t s) {
-  if constexpr (!O8) {
+  if constexpr (GEO == 0 && !O8 && !UP) {
+    if (a.ntaps == 9) {
+      if (a.out8 || a.in2) return fail(-3, "conv_gemm: a 3x3 conv takes neither an e4m3 copy nor a second input");
+      if constexpr (!RES) {  // (no stride-2 conv carries a residual)
+        if (a.stride == 2) return launch_gemm<MTW, NWN, EVEN, RES, ACT, false, false, 2>(a, lds, s);
+      }
+      if (a.stride == 2) return fail(-3, "conv_gemm: a stride-2 conv with a residual");
+      return launch_gemm<MTW, NWN, EVEN, RES, ACT, false, false, 1>(a, lds, s);
+    }
+  }
+  if constexpr (!O8 && GEO == 0) {
     if (a.out8) return launch_gemm<MTW, NWN, EVEN, RES, ACT, true, UP>(a, lds, s);
   }
-  if constexpr (!UP && !RES) {  // (the convs behind Upsample + Concat carry no residual)
+  if constexpr (!UP && !RES && GEO == 0) {  // (the convs behind Upsample + Concat carry no residual)
     if (a.in2) return launch_gemm<MTW, NWN, EVEN, RES, ACT, O8, true>(a, lds, s);
   }
   if (a.in2 && !UP) return fail(-3, "conv_gemm: an upsampled second input cannot be combined with a residual");
-  auto kern = conv_gemm_kernel<MTW, NWN, gm_ks(MTW, NWN, EVEN), gm_ns(MTW, NWN, EVEN), RES, ACT, O8, UP>;
+  auto kern = conv_gemm_kernel<MTW, NWN, gm_ks(MTW, NWN, EVEN), gm_ns(MTW, NWN, EVEN), RES, ACT, O8, UP, GEO>;
   static bool attr = false;
   if (!attr) {
     YL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -438,16 +487,19 @@ static int launch_gemm(const ConvArgs& a, size_t lds, hipStream_t s) {
 
 int conv_gemm_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s) {
   const int MTW = cfg.gemm;
-  if ((MTW != 4 && MTW != 6 && MTW != 8) || cfg.ntaps != 1 || a.stride != 1 || a.out_f32 || a.wpk2 || !cfg.uniform ||
-      a.in_w1 != a.out_w1 || a.in_img != a.out_img || a.in_g0 != a.out_g0 || a.in_w1 != a.Wo + 1 || a.Cout != cfg.ncb * 32 * MTW)
-    return fail(-3, "conv_gemm: needs a plain bf16 1x1 stride-1 conv, Cin % 32 == 0, Cout a multiple of the channel block");
+  const bool k3 = cfg.ntaps == 9;
+  if ((MTW != 4 && MTW != 6 && MTW != 8) || (cfg.ntaps != 1 && !k3) || (a.stride != 1 && !(k3 && a.stride == 2)) || a.out_f32 ||
+      a.wpk2 || !cfg.uniform || (k3 && cfg.kord != 2) || a.out_w1 != a.Wo + 1 || a.Cout != cfg.ncb * 32 * MTW ||
+      (a.stride == 1 && (a.in_w1 != a.out_w1 || a.in_img != a.out_img || a.in_g0 != a.out_g0)))
+    return fail(-3, "conv_gemm: needs a plain bf16 1x1 or 3x3 conv, Cin % 32 == 0, Cout a multiple of the channel block");
+  a.ntaps = cfg.ntaps;
   a.ncb = cfg.ncb;
   a.cg = cfg.cg;
   a.ksteps = cfg.ksteps;
   a.t_B = batch;
   a.t_H = a.Ho;
   a.t_W = a.Wo;
-  a.magic_w1 = gm_magic(a.in_w1);
+  a.magic_w1 = gm_magic(a.out_w1);  // (tiles run over OUTPUT positions)
   const long long lim = 1LL << 30;
   const long long inb = (long long)(cfg.cg - (a.in2 ? 4 * a.ks_split : 0)) * a.in_plane, outb = (long long)(a.Cout / 8) * a.out_plane;
   if (a.in2) {

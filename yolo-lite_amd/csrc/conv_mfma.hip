@@ -800,7 +800,11 @@ void conv_pack_weights(const float* w, int Cout, int Cin_w, int k, const ConvCon
         for (int lane = 0; lane < 64; ++lane) {
           const int co = cb * c.MT * 16 + chan_in_block(c.MT, mt, (lane & 15) >> 2, lane & 3);
           const int k8 = ks * 4 + (lane >> 4);
-          const int tap = c.kord ? k8 % c.ntaps : k8 / c.cg, c8 = c.kord ? k8 / c.ntaps : k8 % c.cg;
+          int tap = c.kord ? k8 % c.ntaps : k8 / c.cg, c8 = c.kord ? k8 / c.ntaps : k8 % c.cg;
+          if (c.kord == 2) {  // conv_gemm_kernel's 3x3 order: k-step = (block of 4 planes, tap)
+            tap = ks % c.ntaps;
+            c8 = (ks / c.ntaps) * 4 + (lane >> 4);
+          }
           for (int j = 0; j < 8; ++j, ++o) {
             const int ci = c8 * 8 + j;
             if (co < Cout && tap < c.ntaps && ci < Cin_w) {
