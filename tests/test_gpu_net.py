@@ -446,8 +446,6 @@ def test_fused_stem_conv_is_bit_identical(gpu_device, monkeypatch, scale, h, w, 
         x = torch.randint(0, 256, (2, 3, h, w), generator=g, dtype=torch.uint8)
     else:
         x = torch.rand(2, 3, h, w, generator=g).to(dtype)
-    if scale != "n":
-        monkeypatch.setenv("YL_FUSE_STEM_WIDE", "1")  # the 32-channel stem of YOLO11s: supported, opt-in (neutral)
     eng = _engine(scale, sd, 2, h, w, gpu_device)
     assert eng.op_kernel(0) == "stem+conv3x3s2_mfma", eng.op_kernel(0)
     y = eng.forward(x.to(gpu_device)).clone()

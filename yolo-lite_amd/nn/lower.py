@@ -280,9 +280,10 @@ def fuse_stem_into_conv(ops: List[dict], in_w: int) -> List[dict]:
     if (b["kind"] != OP_CONV or b.get("k") != 3 or b.get("stride") != 2 or b.get("res") is not None
             or b.get("inp2") is not None or b.get("cin_weight", 0) or b.get("lane", 0)
             or (b["inp"].offset, b["inp"].coff, b["inp"].C) != (y.offset, 0, y.C) or y.pitch != y.C
-            or y.C not in ((16, 32) if os.environ.get("YL_FUSE_STEM_WIDE") == "1" else (16,)) or cout1 not in (32, 64)):
-        # the 32-channel stem of YOLO11s is supported (bit-identical) but measured neutral at batch 64 (20.46 k images/s
-        # either way: 206 VGPRs and 75 KB of LDS per workgroup eat what the 0.8 GB less traffic buys): opt-in
+            or y.C not in ((16, 32) if os.environ.get("YL_FUSE_STEM_WIDE", "1") == "1" else (16,)) or cout1 not in (32, 64)):
+        # the 32-channel stem of YOLO11s (bit-identical): neutral in round 2 (206 VGPRs and 75 KB of LDS per workgroup ate
+        # what the 0.8 GB less traffic bought), +0.6-1.4 % with the round-3 kernels around it (24.12 -> 24.26-24.48 k images/s
+        # at batch 64, one batch at a time +2 %): on; YL_FUSE_STEM_WIDE=0 restores the two launches
         return ops
     b["stem_weight"], b["stem_bias"], b["stem_act"] = st["weight"], st["bias"], st.get("act", 1)
     b["name"] = f"{st.get('name', '')}+{b.get('name', '')}"
