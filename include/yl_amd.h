@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define YL_ABI_VERSION 15
+#define YL_ABI_VERSION 16
 
 /* element types */
 enum { YL_BF16 = 0, YL_F32 = 1, YL_F16 = 2, YL_U8 = 3, YL_FP8 = 4 /* OCP e4m3 */ };
@@ -273,6 +273,15 @@ int yl_engine_detect_graph_prepare(yl_engine* e, const void* input, int in_dtype
                                    float iou_thres, int max_det, int agnostic, const int32_t* classes, int n_classes,
                                    int max_cand, float max_wh, const float* scale, float* out, int32_t* out_count, void* work,
                                    void* stream, void** graph_out);
+/* yl_engine_detect_graph for a caller whose input address changes from call to call -- the reference API hands the predictor a
+ * fresh tensor per batch (engine/predictor.py:178-196, data/loaders.py:415-477) -- without a staging copy: ONE captured graph per
+ * argument tuple regardless of `input`; before a launch with a new address the kernel nodes that read the input get it written
+ * into their parameters (hipGraphExecKernelNodeSetParams).  Contract: no earlier launch of the same tuple is still pending
+ * (one workspace slot = one batch at a time); `input` must stay valid until the launch has finished. */
+int yl_engine_detect_graph_rebind(yl_engine* e, const void* input, int in_dtype, void* workspace, float conf_thres,
+                                  float iou_thres, int max_det, int agnostic, const int32_t* classes, int n_classes, int max_cand,
+                                  float max_wh, const float* scale, float* out, int32_t* out_count, void* work, void* stream);
+
 /* Issues n prepared steps back to back: graphs[i] (from yl_engine_detect_graph_prepare) on HIP stream streams[i].  The host
  * side of the reference's `for batch in dataset:` loop (engine/predictor.py:178) for batches whose inputs are already staged:
  * one native call per round of batches in flight instead of one trip through Python per batch (~80 us each). */

@@ -21,7 +21,7 @@ def test_header_symbols_exported():
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/yl_amd.h but not exported"
     assert set(names) == set(_lib.EXPORTS), "python binding list and header drifted apart"
-    assert L.yl_abi_version() == 15
+    assert L.yl_abi_version() == 16
 
 
 def test_struct_layouts_match_header():

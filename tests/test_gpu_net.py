@@ -142,7 +142,23 @@ def test_graph_replays_track_changing_inputs(gpu_device, golden):
                 assert torch.equal(c, ref[k][1]), (rep, k)
                 for i in range(2):
                     assert torch.equal(o[i, : int(c[i])], ref[k][0][i, : int(c[i])]), (rep, k, i)
-    # the predictor API stages its inputs the same way (engine-owned buffer + one graph)
+    # stage="rebind": ONE graph for the slot, the DIFFERENT tensors' addresses written into the stem launch's node
+    # (yl_engine_detect_graph_rebind); fp32 and uint8 inputs are different graphs of the same slot
+    xf = [x.float() / 255 for x in xs[:2]]
+    with torch.cuda.stream(st):
+        for rep in range(2):
+            for k, x in enumerate(xs):
+                o, c = eng.detect(x, 0.25, 0.7, graph=True, stage="rebind", slot=2)
+                assert torch.equal(c, ref[k][1]), (rep, k)
+                for i in range(2):
+                    assert torch.equal(o[i, : int(c[i])], ref[k][0][i, : int(c[i])]), (rep, k, i)
+            for k, x in enumerate(xf):
+                o, c = eng.detect(x, 0.25, 0.7, graph=True, stage="rebind", slot=2)
+                o2, c2 = eng.detect(x, 0.25, 0.7, graph=False)
+                assert torch.equal(c, c2), (rep, k)
+                for i in range(2):
+                    assert torch.equal(o[i, : int(c[i])], o2[i, : int(c[i])]), (rep, k, i)
+    # the predictor API hands over a fresh tensor per call: the same rebinding (YL_PREDICT_REBIND=0: a staging copy)
     from yololite_amd import YOLOLite
 
     model = YOLOLite("yolo11n.yaml")

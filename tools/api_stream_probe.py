@@ -48,3 +48,11 @@ for rep in range(2):
     dt = time.perf_counter() - t
 print("engine.detect on", S, "streams: images/s", round(200 * 32 / dt, 1))
 
+# where the host time of one pass goes
+pr = cProfile.Profile()
+pr.enable()
+n = sum(1 for _ in m.predict(src, stream=True, **kw))
+torch.cuda.synchronize()
+pr.disable()
+st = pstats.Stats(pr)
+st.sort_stats("cumulative").print_stats(28)

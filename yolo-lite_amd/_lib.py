@@ -112,7 +112,7 @@ EXPORTS = (
     "yl_engine_op_info", "yl_engine_detect_graph", "yl_detect_decode", "yl_nms_workspace_bytes", "yl_nms", "yl_decode_nms",
     "yl_preprocess_u8", "yl_letterbox_u8", "yl_nms_ml_workspace_bytes", "yl_nms_ml", "yl_engine_profile_detect",
     "yl_graph_branch_probe", "yl_engine_prefilter_fused", "yl_stream_create_masked", "yl_stream_destroy", "yl_xcc_census",
-    "yl_engine_detect_graph_prepare", "yl_graph_launch_many",
+    "yl_engine_detect_graph_prepare", "yl_graph_launch_many", "yl_engine_detect_graph_rebind",
 )
 
 
@@ -212,6 +212,8 @@ def lib() -> C.CDLL:
                                 vp, vp]
     L.yl_engine_detect_graph.restype = i32
     L.yl_engine_detect_graph.argtypes = [vp, vp, i32, vp, f32, f32, i32, i32, vp, i32, i32, f32, vp, vp, vp, vp, vp]
+    L.yl_engine_detect_graph_rebind.restype = i32
+    L.yl_engine_detect_graph_rebind.argtypes = L.yl_engine_detect_graph.argtypes
     L.yl_engine_detect_graph_prepare.restype = i32
     L.yl_engine_detect_graph_prepare.argtypes = L.yl_engine_detect_graph.argtypes + [C.POINTER(vp)]
     L.yl_graph_launch_many.restype = i32
@@ -233,7 +235,7 @@ def lib() -> C.CDLL:
     L.yl_xcc_census.argtypes = [vp, i32, vp]
     L.yl_engine_prefilter_fused.restype = i32
     L.yl_engine_prefilter_fused.argtypes = [vp, f32]
-    if L.yl_abi_version() != 15:
+    if L.yl_abi_version() != 16:
         raise RuntimeError("libyl_amd.so ABI version mismatch; rebuild it")
     _lib = L
     return L

@@ -101,6 +101,17 @@ struct yl_engine {
                      void*, void*>
       DetectKey;
   GraphCache<DetectKey> dgraphs;
+  // The same graphs keyed WITHOUT the input address (yl_engine_detect_graph_rebind): the kernel nodes that read the input
+  // get the new address written into their parameters before a launch, so a caller that hands over a fresh tensor per
+  // batch replays one captured graph per slot without staging copies.  The source graph is kept: its node handles address
+  // the executable's nodes.
+  struct Rebindable {
+    hipGraph_t g = nullptr;
+    hipGraphExec_t exec = nullptr;
+    std::vector<hipGraphNode_t> nodes;  // kernel nodes whose first parameter starts with the input address
+    const void* cur = nullptr;
+  };
+  std::map<DetectKey, Rebindable> rgraphs;
   // Per workspace (= per batch in flight): a private capture stream, one non-blocking stream per side
   // lane (yl_op.lane > 0) and a pool of fork/join events.  Batches that are in flight on different
   // caller streams use different workspaces; giving each its own lane streams keeps their graphs from
@@ -192,6 +203,11 @@ extern "C" void yl_engine_destroy(yl_engine* e) {
   if (!e) return;
   e->graphs.clear();
   e->dgraphs.clear();
+  for (auto& kv : e->rgraphs) {
+    if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+    if (kv.second.g) (void)hipGraphDestroy(kv.second.g);
+  }
+  e->rgraphs.clear();
   for (auto& kv : e->sets) {
     if (kv.second.cap) (void)hipStreamDestroy(kv.second.cap);
     for (hipStream_t st : kv.second.lanes)
@@ -1214,6 +1230,79 @@ extern "C" int yl_engine_detect_graph_prepare(yl_engine* e, const void* input, i
                                   max_cand, max_wh, scale, out, out_count, work, stream, 0, &ex);
   *graph_out = (void*)ex;
   return rc;
+}
+
+// yl_engine_detect_graph for callers whose input address changes from call to call (the predictor API: a fresh tensor per
+// batch).  One graph per argument tuple WITHOUT the input address; before a launch with a new address the parameters of the
+// kernel nodes that read the input (the stem launch) are updated in the executable (hipGraphExecKernelNodeSetParams).
+// Contract: no earlier launch of the same tuple is still pending when this is called (one slot = one batch at a time).
+extern "C" int yl_engine_detect_graph_rebind(yl_engine* e, const void* input, int in_dtype, void* workspace,
+                                             float conf_thres, float iou_thres, int max_det, int agnostic,
+                                             const int32_t* classes, int n_classes, int max_cand, float max_wh,
+                                             const float* scale, float* out, int32_t* out_count, void* work, void* stream) {
+  if (!e || !input || !workspace || !out || !out_count || !work)
+    return fail(-1, "yl_engine_detect_graph_rebind: null pointer");
+  if (e->levels.empty()) return fail(-1, "yl_engine_detect_graph_rebind: engine has no Detect levels");
+  hipStream_t s = (hipStream_t)stream;
+  yl_engine::DetectKey key(nullptr, in_dtype, workspace, conf_thres, iou_thres, max_det, agnostic, classes, n_classes,
+                           max_cand, max_wh, scale, out, out_count, work);
+  auto it = e->rgraphs.find(key);
+  if (it == e->rgraphs.end()) {
+    if (int rc = detect_eager(e, input, in_dtype, workspace, conf_thres, iou_thres, max_det, agnostic, classes,
+                              n_classes, max_cand, max_wh, scale, out, out_count, work, stream))
+      return rc;
+    YL_HIP(hipStreamSynchronize(s));
+    hipStream_t cap = nullptr;
+    if (int rc = capture_stream(e, workspace, &cap)) return rc;
+    yl_engine::Rebindable rb;
+    YL_HIP(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
+    int rc = detect_eager(e, input, in_dtype, workspace, conf_thres, iou_thres, max_det, agnostic, classes, n_classes,
+                          max_cand, max_wh, scale, out, out_count, work, (void*)cap);
+    hipError_t ce = hipStreamEndCapture(cap, &rb.g);
+    if (rc) {
+      if (rb.g) (void)hipGraphDestroy(rb.g);
+      return rc;
+    }
+    if (ce != hipSuccess) return fail(-2, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
+    size_t nn = 0;
+    YL_HIP(hipGraphGetNodes(rb.g, nullptr, &nn));
+    std::vector<hipGraphNode_t> all(nn);
+    if (nn) YL_HIP(hipGraphGetNodes(rb.g, all.data(), &nn));
+    for (hipGraphNode_t nd : all) {
+      hipGraphNodeType ty;
+      YL_HIP(hipGraphNodeGetType(nd, &ty));
+      if (ty != hipGraphNodeTypeKernel) continue;
+      hipKernelNodeParams kp{};
+      YL_HIP(hipGraphKernelNodeGetParams(nd, &kp));
+      if (!kp.kernelParams || !kp.kernelParams[0]) continue;
+      const void* first = nullptr;
+      memcpy(&first, kp.kernelParams[0], sizeof(first));  // every input-reading launch takes the address first
+      if (first == input) rb.nodes.push_back(nd);
+    }
+    if (rb.nodes.empty()) {
+      (void)hipGraphDestroy(rb.g);
+      return fail(-3, "yl_engine_detect_graph_rebind: no kernel node of the captured graph reads the input address");
+    }
+    hipError_t ie = hipGraphInstantiate(&rb.exec, rb.g, nullptr, nullptr, 0);
+    if (ie != hipSuccess) {
+      (void)hipGraphDestroy(rb.g);
+      return fail(-2, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie));
+    }
+    rb.cur = input;
+    it = e->rgraphs.emplace(key, rb).first;
+  }
+  yl_engine::Rebindable& rb = it->second;
+  if (rb.cur != input) {
+    for (hipGraphNode_t nd : rb.nodes) {
+      hipKernelNodeParams kp{};
+      YL_HIP(hipGraphKernelNodeGetParams(nd, &kp));
+      memcpy(kp.kernelParams[0], &input, sizeof(input));  // the node's own copy of its first parameter
+      YL_HIP(hipGraphExecKernelNodeSetParams(rb.exec, nd, &kp));
+    }
+    rb.cur = input;
+  }
+  YL_HIP(hipGraphLaunch(rb.exec, s));
+  return 0;
 }
 
 // n prepared steps issued back to back: graphs[i] on streams[i].  One native call instead of n trips through the host

@@ -94,6 +94,7 @@ class LoadTensorBatches:
 
     mode = "image"
     source_type = SourceTypes(tensor=True)
+    resident = True  # the tensors exist before iteration starts: the predictor orders them in front of its batches ONCE
 
     def __init__(self, batches) -> None:
         self.batches = [LoadTensor.checked(t) for t in batches]

@@ -151,9 +151,10 @@ class DetectionPredictor:
         """inference + postprocess in one pass: the (B, 4+nc, A) tensor is never materialised."""
         return self._harvest_fused(self._launch_fused(im, orig_imgs, slot=0, stream=None))
 
-    def _launch_fused(self, im, orig_imgs, slot: int, stream):
+    def _launch_fused(self, im, orig_imgs, slot: int, stream, after=None):
         """Enqueue one batch on engine slot ``slot`` (on ``stream`` when given) and return what ``_harvest_fused`` needs;
-        no host synchronisation."""
+        no host synchronisation.  ``after``: an event that already orders the input in front of this batch (then the batch's
+        stream waits for it instead of for the current stream's tail)."""
         b, _, h, w = im.shape
         eng = self.model.engine_for(b, h, w, calib=im.contiguous())
         shapes, imgs, scale = self._shapes_and_scale(im, orig_imgs, b, im.device)
@@ -162,11 +163,15 @@ class DetectionPredictor:
         # (YL_PREDICT_GRAPH=0: the same kernels launched one by one)
         graph = os.environ.get("YL_PREDICT_GRAPH", "1") != "0"
         imc = im.contiguous()
+        # the graph reads the caller's tensor in place: its address is written into the stem launch's node before the
+        # launch (YL_PREDICT_REBIND=0: one device-to-device copy into an engine-owned input buffer instead, 39 MB per batch
+        # of 32 at 640x640).  The job keeps the tensor alive until the batch is harvested.
+        stage = "rebind" if graph and os.environ.get("YL_PREDICT_REBIND", "1") != "0" else graph
 
         def go():
             out, cnt = eng.detect(imc, self.args.conf, self.args.iou, max_det=self.args.max_det,
                                   classes=self.args.classes, agnostic=self.args.agnostic_nms, scale=scale, graph=graph,
-                                  stage=graph, slot=slot)
+                                  stage=stage, slot=slot)
             # engine-owned output buffers are overwritten by the slot's next batch: ONE copy of the padded records,
             # ordered behind this batch on its stream
             if not graph:
@@ -187,14 +192,16 @@ class DetectionPredictor:
         if stream is None:
             out, cnt = go()
         else:
-            if os.environ.get("YL_PREDICT_NOWAIT", "0") != "1":  # (development switch)
+            if after is not None:
+                stream.wait_event(after)
+            elif os.environ.get("YL_PREDICT_NOWAIT", "0") != "1":  # (development switch)
                 stream.wait_stream(torch.cuda.current_stream(im.device))  # the input was produced on the caller's stream
             with torch.cuda.stream(stream):
                 out, cnt = go()
                 ev = torch.cuda.Event()
                 ev.record(stream)
             imc.record_stream(stream)
-        return dict(out=out, cnt=cnt, ev=ev, shapes=shapes, imgs=imgs, paths=self.batch[0], n=b)
+        return dict(out=out, cnt=cnt, ev=ev, shapes=shapes, imgs=imgs, paths=self.batch[0], n=b, input=imc)
 
     def _harvest_fused(self, job):
         if job["ev"] is not None:
@@ -257,6 +264,15 @@ class DetectionPredictor:
             pdev = self.device if S == 1 else None
             profilers = (ops.Profile(device=pdev), ops.Profile(device=pdev), ops.Profile(device=pdev))
             pending, k = [], 0
+            # everything the caller enqueued on the current stream before predict() -- e.g. the kernels that produced the
+            # tensors of a tensor source -- is ordered in front of every batch by ONE event recorded here; a batch whose
+            # preprocess stage enqueued device work of its own (upload, letterbox, dtype conversion) waits for the current
+            # stream's tail instead (a cross-stream wait per batch on the stream that also carries the per-batch uploads
+            # cost 5 % of the pipelined rate)
+            entry_ev = None
+            if S > 1:
+                entry_ev = torch.cuda.Event()
+                entry_ev.record(torch.cuda.current_stream(self.device))
 
             def finish(job):
                 self.batch = job["batch"]
@@ -273,7 +289,9 @@ class DetectionPredictor:
                     im = self.preprocess(im0s)
                 if self._can_fuse():
                     with profilers[1]:  # network + fused decode / NMS / box rescale, one host sync
-                        job = self._launch_fused(im, im0s, slot=k % S, stream=self._streams[k % S] if S > 1 else None)
+                        untouched = isinstance(im0s, torch.Tensor) and im is im0s and getattr(self.dataset, "resident", False)
+                        job = self._launch_fused(im, im0s, slot=k % S, stream=self._streams[k % S] if S > 1 else None,
+                                                 after=entry_ev if untouched else None)
                     job.update(batch=self.batch, im=im, t_launch=profilers[1].dt, t_pre=profilers[0].dt)
                     pending.append(job)
                     k += 1

@@ -192,11 +192,15 @@ class HipEngine:
         ``stage=True`` (with ``graph=True``): ``im`` is first copied into an engine-owned input buffer of the slot
         (one device-to-device copy), so callers that hand over a fresh tensor every call -- the predictor API -- still
         replay ONE captured graph instead of re-capturing per input address.
+        ``stage="rebind"``: no copy either -- the slot's ONE captured graph gets ``im``'s address written into the kernel nodes
+        that read the input (``yl_engine_detect_graph_rebind``); the caller keeps ``im`` alive until the batch has finished and
+        has at most one batch per slot pending.
         ``rec_key`` (graph mode): which of the slot's engine-owned output records to write -- a slot may own several
         (``dist.ShardedRunner`` alternates two per slot so that the gather of one step can still read its record while
         the slot's next step runs); each (input address, record) pair is its own captured graph."""
         self._check_input(im)
-        if graph and stage:
+        rebind = graph and stage == "rebind"  # (no staging copy: the captured graph's input-reading nodes take im's address)
+        if graph and stage and not rebind:
             sk = ("in", im.dtype)
             st0 = self._slot(slot)["static"]
             if sk not in st0:
@@ -248,7 +252,11 @@ class HipEngine:
                                                          *args, C.byref(h))
             _lib.check(rc, "yl_engine_detect_graph_prepare")
             return out, cnt, h.value
-        if graph:
+        if rebind:
+            rc = self.lib.yl_engine_detect_graph_rebind(self._h, im.data_ptr(), _TORCH2YL[im.dtype], sl["ws"].data_ptr(),
+                                                        *args)
+            _lib.check(rc, "yl_engine_detect_graph_rebind")
+        elif graph:
             rc = self.lib.yl_engine_detect_graph(self._h, im.data_ptr(), _TORCH2YL[im.dtype], sl["ws"].data_ptr(),
                                                  *args)
             _lib.check(rc, "yl_engine_detect_graph")
