@@ -142,7 +142,9 @@ static unsigned cs_magic(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ul
 void conv3_cs_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, int post, ConvConfig* c) {
   c->cs = 0;
   const int enable = getenv("YL_CONV_CS") ? atoi(getenv("YL_CONV_CS")) : 1;
-  const int min_tiles = getenv("YL_CONV_CS_MIN") ? atoi(getenv("YL_CONV_CS_MIN")) : 1024;
+  // (512 tiles = one per resident workgroup: YOLO11s's 64 -> 64 Bottleneck convs @40x40 batch 64 have 840, +0.5-1.1 % end to end
+  // against conv3_reg_kernel; YOLO11n batch 32 has none between 512 and 1024)
+  const int min_tiles = getenv("YL_CONV_CS_MIN") ? atoi(getenv("YL_CONV_CS_MIN")) : 512;
   if (!enable || k != 3 || stride != 1 || post || Cin != 64 || Cout != 64 || c->ncb != 1 || c->MT != 4) return;
   const long long img = (long long)(Ho + 1) * (Wo + 1), nq = (long long)batch * img;
   if (nq * img >= (1LL << 32) || img * (Wo + 1) >= (1LL << 32)) return;  // exactness of the magic divisions
