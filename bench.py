@@ -198,7 +198,7 @@ def cpu_baseline(sd, scale, h, w, conf, iou, sample_b=32, iters=3, eng=None, dev
     return out
 
 
-def short_config(scale, batch, imgsz, dtype, streams, steps, dev, conf=0.25, iou=0.7, max_det=300):
+def short_config(scale, batch, imgsz, dtype, streams, steps, dev, conf=0.25, iou=0.7, max_det=300, stream_pool=None):
     """A short pipelined run of another BASELINE.json configuration (3: YOLO11s bf16 batch 64; 5: YOLO11x e4m3 1280x1280
     batch 8) inside the default bench, so that the driver's own run carries a number for them.  Same step, same timing
     bracket as `value`; fewer steps.  For fp8 the e4m3 program's detections are gated against the bf16 program's."""
@@ -207,7 +207,9 @@ def short_config(scale, batch, imgsz, dtype, streams, steps, dev, conf=0.25, iou
     x8 = (x * 255).to(torch.uint8)
     del x
     S = streams
-    st = [torch.cuda.Stream(device=dev) for _ in range(S)]
+    # the main run's streams when given: new ones would share the 20 hardware queues with the 40 streams this process
+    # already owns (main loop + the API predictor's) unevenly (YOLO11s: 23.9 instead of 25.1 k images/s)
+    st = list(stream_pool[:S]) if stream_pool is not None and len(stream_pool) >= S else [torch.cuda.Stream(device=dev) for _ in range(S)]
     xs = [x8] + [torch.randint(0, 256, (batch, 3, imgsz, imgsz), generator=torch.Generator().manual_seed(2000 + j),
                                dtype=torch.uint8).to(dev) for j in range(1, S)]
 
@@ -726,7 +728,7 @@ def main():
                 res["other_configs"] = []
                 for sc_, b_, sz_, dt_, st_, n_ in (("s", 64, 640, "bf16", S, 10 * S), ("x", 8, 1280, "fp8", S, 3 * S)):
                     try:
-                        res["other_configs"].append(short_config(sc_, b_, sz_, dt_, st_, n_, dev))
+                        res["other_configs"].append(short_config(sc_, b_, sz_, dt_, st_, n_, dev, stream_pool=streams))
                     except Exception as e:  # never at the cost of the main line
                         res["other_configs"].append({"workload": f"YOLO11{sc_} {dt_} {sz_} batch={b_}", "error": repr(e)})
             if not args.no_cpu_baseline:
