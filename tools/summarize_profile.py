@@ -118,12 +118,14 @@ def main():
               "MFMA busy: SQ_VALU_MFMA_BUSY_CYCLES (summed over the 1024 SIMDs) / (1024 x GRBM_GUI_ACTIVE / 8 XCDs), from a",
               "separate pass with one batch in flight.", "",
               "Read cross-check (round 3, separate pass): TCC_MISS_sum counts the L2 misses of reads AND writes in 128-byte lines --",
-              "for every kernel below `misses x 128 B` = `2 x FETCH_SIZE + WRITE_SIZE` within 1-2 % (stem2: 92.3 = 39.7 + 52.8;",
-              "c3k2s<2,1>: 158.8 = 53.4 + 105.6; model.3, conv_kernel<3,4,4,true,true>: 251.3 = 225.1 + 26.6), and TCC_EA0_RDREQ x",
-              "128 B equals 2 x FETCH_SIZE too (model.3: 1.76 M requests = 225 MB), none of them 32-byte requests.  So the doubled",
-              "FETCH_SIZE IS the read traffic beyond L2 for the tap-shifted 3x3 loads as well: model.3 (3x3 stride 2, 64 -> 64 @160x160",
-              "-> 80x80, batch 32) really fetches 225 MB for a 105 MB input = 2.14 x (its nine taps sweep a footprint of ~11 MB per XCD",
-              "against 4 MB of L2; the re-reads are served by the Infinity Cache, which these counters include).", "",
+              "for every kernel below `misses x 128 B` = `2 x FETCH_SIZE + WRITE_SIZE` within 1-2 % (compare the two read columns with the",
+              "write column) and TCC_EA0_RDREQ x 128 B equals 2 x FETCH_SIZE too, none of them 32-byte requests.  So the doubled",
+              "FETCH_SIZE IS the read traffic beyond L2 for the tap-shifted 3x3 loads as well."] + ([
+              "The first profile of this round (tap-major",
+              "K order everywhere) showed model.3 (3x3 stride 2, 64 -> 64 @160x160 -> 80x80, batch 32: `conv_kernel<3, 4, 4, true, true>`)",
+              "fetching 225 MB for a 105 MB input = 2.14 x: its nine taps swept a footprint of ~11 MB per XCD against 4 MB of L2, the",
+              "re-reads served by the Infinity Cache, which these counters include.  With the plane-major K order that layer is the row",
+              "`conv_kernel<3, 4, 4, false, true>` below: ~108 MB."] if tag.startswith("r") else []) + ["",
               "| kernel | calls | avg us | total % | HBM read MB/launch (2 x FETCH_SIZE) | read MB/launch (L2 misses x 128 B) | RDREQ M (32 B share) | HBM write MB/launch | MFMA busy % |",
               "|---|---|---|---|---|---|---|---|---|"]
     for r in rows:
