@@ -20,6 +20,9 @@
 
 #include "conv_common.h"
 
+#ifndef YL_STEM2_ABL
+#define YL_STEM2_ABL 0  // development build switch
+#endif
 namespace yl {
 
 constexpr int S2_TR = 2, S2_TC = 80;                 // layer-1 output tile
@@ -79,7 +82,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
         if (idx < TOTAL) {
           const int rowi = idx / DW, d = idx - rowi * DW;
           __bf16* dst = img + rowi * S2_IP + d * VW;
-          if constexpr (sizeof(T) == 1) {
+          if constexpr ((YL_STEM2_ABL & 2) != 0) {  // (timing ablation: no conversion)
+            *reinterpret_cast<unsigned*>(dst) = v[u];
+            *reinterpret_cast<unsigned*>(dst + 2) = v[u];
+          } else if constexpr (sizeof(T) == 1) {
             // byte / 255 (predictor.py:84), rounded to bf16 at once.  A true fp32 division costs ~12 VALU
             // instructions per pixel and made this kernel VALU bound; byte * (1 / 255.f) differs from it in the last
             // fp32 bit for 126 of the 256 byte values, but NEVER after the bf16 rounding
@@ -147,8 +153,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
           cc[u] = c;
           cts[u] = (t0 + 4 * u < S2_SR * TPR) ? ct : TPR;    // TPR: nothing of this tile is stored
           const __bf16* corner = img + 2 * r * S2_IP + 2 * c;
+#if YL_STEM2_ABL & 1  // (timing ablation, wrong results: one aligned 16-byte read instead of the eight-element im2col gather)
+          bf[u] = *reinterpret_cast<const bf16x8*>(img + ((2 * r * S2_IP + 2 * c) & ~7));
+#else
 #pragma unroll
           for (int j = 0; j < 8; ++j) bf[u][j] = corner[koff[j]];
+#endif
         }
         f32x4 acc[2];
 #pragma unroll
@@ -159,7 +169,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
           const bool inside = (unsigned)sy < (unsigned)a.H0 && (unsigned)sx < (unsigned)a.W0;
           bf16x4 o;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) o[q] = (__bf16)(ACT0 ? silu_f(acc[u][q]) : acc[u][q]);
+          for (int q = 0; q < 4; ++q) o[q] = (__bf16)((ACT0 && !(YL_STEM2_ABL & 4)) ? silu_f(acc[u][q]) : acc[u][q]);
           const bf16x4 z = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
           if (cts[u] * 16 + n < S2_SC)
             *reinterpret_cast<bf16x4*>(sbase + (size_t)(rr[u] * S2_SP + cc[u]) * 16) = inside ? o : z;
@@ -229,7 +239,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
           v[r] = acc[2 * p][r];
           v[4 + r] = acc[2 * p + 1][r];
         }
-        if (a.act) {
+        if (a.act && !(YL_STEM2_ABL & 8)) {
 #pragma unroll
           for (int r = 0; r < 8; ++r) v[r] = silu_f(v[r]);
         }
@@ -254,7 +264,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
         v[r] = acc[2 * p][r];
         v[4 + r] = acc[2 * p + 1][r];
       }
-      if (act_last) {
+      if (act_last && !(YL_STEM2_ABL & 8)) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] = silu_f(v[r]);
       }
