@@ -13,7 +13,11 @@ __device__ __forceinline__ int fastdiv(int x, int d, unsigned magic) {
 // rounding): an IEEE divide here costs ~10 VALU instructions per element and made the epilogue, not
 // memory, the bottleneck of the streaming layers.
 __device__ __forceinline__ float silu_f(float v) {
+#ifdef YL_ABL_NO_SILU  // (development build switch, wrong results: what the activations' VALU work costs end to end)
+  return v;
+#else
   return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * v));
+#endif
 }
 
 // Output-channel order inside a block of MT*16 channels.  The MFMA leaves lane (pixel n, quad g)
