@@ -228,6 +228,20 @@ def short_config(scale, batch, imgsz, dtype, streams, steps, dev, conf=0.25, iou
     res = {"workload": f"YOLO11{scale} {dtype}, {imgsz}x{imgsz} batch={batch}, {S} batches in flight", "value": round(batch * steps / dt, 1),
            "unit": "images/sec", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4),
            "mean_detections_per_image": round(cnt.float().mean().item(), 1)}
+    try:  # the best 3x3 conv of this configuration against its MFMA roof (in-sequence HIP events, one batch in flight)
+        rows = eng.profile_detect(x8, conf, iou, max_det=max_det, iters=10)
+        best, tot_fl = None, 0.0
+        for r in rows:
+            tot_fl += r["flops"]
+            if r["kernel"].startswith("conv3x3") and r["ms"] > 0:
+                f = r["flops"] / (r["ms"] * 1e-3) / 1e12 / (PEAK_FP8_TFLOPS if "_f8_" in r["kernel"] else PEAK_BF16_TFLOPS)
+                if best is None or f > best[1]:
+                    best = (r["name"], f, r["ms"], r["kernel"])
+        if best:
+            res["best_conv3x3_layer"] = {"layer": best[0], "kernel": best[3], "mfma_frac": round(best[1], 4), "us": round(best[2] * 1e3, 2)}
+        res["e2e_tflops"] = round(tot_fl / (dt / steps) / 1e12, 1)
+    except Exception as e:  # (a diagnostic: never in the way of the number)
+        res["best_conv3x3_layer"] = {"error": repr(e)}
     if dtype == "fp8":
         from oracle.parity_gate import parity_gate
         from yololite_amd.nn.engine import HipEngine

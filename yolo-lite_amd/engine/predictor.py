@@ -166,12 +166,20 @@ class DetectionPredictor:
         # the graph reads the caller's tensor in place: its address is written into the stem launch's node before the
         # launch (YL_PREDICT_REBIND=0: one device-to-device copy into an engine-owned input buffer instead, 39 MB per batch
         # of 32 at 640x640).  The job keeps the tensor alive until the batch is harvested.
-        stage = "rebind" if graph and os.environ.get("YL_PREDICT_REBIND", "1") != "0" else graph
+        stage = "rebind" if graph and os.environ.get("YL_PREDICT_REBIND", "1") != "0" and not getattr(self, "_no_rebind", False) else graph
 
         def go():
-            out, cnt = eng.detect(imc, self.args.conf, self.args.iou, max_det=self.args.max_det,
-                                  classes=self.args.classes, agnostic=self.args.agnostic_nms, scale=scale, graph=graph,
-                                  stage=stage, slot=slot)
+            kw = dict(max_det=self.args.max_det, classes=self.args.classes, agnostic=self.args.agnostic_nms, scale=scale,
+                      graph=graph, slot=slot)
+            try:
+                out, cnt = eng.detect(imc, self.args.conf, self.args.iou, stage=stage, **kw)
+            except RuntimeError as e:
+                if stage != "rebind" or "rebind" not in str(e):
+                    raise
+                # a runtime that cannot update the captured graph's node: the staging copy instead (same kernels, same results)
+                LOGGER.warning(f"input rebinding unavailable ({e}); staging the input through an engine-owned buffer")
+                self._no_rebind = True
+                out, cnt = eng.detect(imc, self.args.conf, self.args.iou, stage=True, **kw)
             # engine-owned output buffers are overwritten by the slot's next batch: ONE copy of the padded records,
             # ordered behind this batch on its stream
             if not graph:
