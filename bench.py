@@ -745,6 +745,32 @@ def main():
                         res["other_configs"].append(short_config(sc_, b_, sz_, dt_, st_, n_, dev, stream_pool=streams))
                     except Exception as e:  # never at the cost of the main line
                         res["other_configs"].append({"workload": f"YOLO11{sc_} {dt_} {sz_} batch={b_}", "error": repr(e)})
+                # BASELINE.json configs[0] on the GPU: ONE image file-sized frame through the reference API -- 1080x1920 BGR array
+                # -> device letterbox to 384x640 -> batch-1 engine -> NMS -> Results -- as a latency (the reference runs this
+                # case on the CPU; tests/test_gpu_config1.py checks its parity)
+                try:
+                    import numpy as np
+                    from yololite_amd import YOLOLite
+
+                    api1 = YOLOLite(f"yolo11{args.scale}.yaml")
+                    api1.model.load_state_dict(sd)
+                    frame = np.random.default_rng(1).integers(0, 256, (1080, 1920, 3), dtype=np.uint8)
+                    kw1 = dict(conf=conf, iou=iou, max_det=max_det, device=str(dev), save=False, verbose=False, imgsz=640)
+                    for _ in range(3):
+                        api1.predict(frame, **kw1)
+                    torch.cuda.synchronize(dev)
+                    t5 = time.perf_counter()
+                    for _ in range(20):
+                        r1 = api1.predict(frame, **kw1)
+                    torch.cuda.synchronize(dev)
+                    lat = (time.perf_counter() - t5) / 20
+                    res["other_configs"].append({"workload": f"YOLO11{args.scale} bf16, one 1080x1920 frame -> 384x640, batch=1 through YOLOLite.predict "
+                                                             "(host array in, upload + device letterbox + network + NMS + Results)",
+                                                 "latency_ms": round(lat * 1e3, 3), "value": round(1.0 / lat, 1), "unit": "images/sec",
+                                                 "detections": int(len(r1[0].boxes))})
+                    del api1
+                except Exception as e:
+                    res["other_configs"].append({"workload": "config 1 (one frame through predict)", "error": repr(e)})
             if not args.no_cpu_baseline:
                                 # batch 32, 3 iterations for YOLO11n at 640x640 (96 images after one warm-up iteration, a few
                 # seconds on 8 threads); other configurations: about the same host work
