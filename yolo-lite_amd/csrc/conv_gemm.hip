@@ -186,8 +186,6 @@ __global__ __launch_bounds__(128 * NWN) __attribute__((amdgpu_waves_per_eu(2))) 
   };
   int tile = tile_of(0);  // (the grid never exceeds the tile count)
   Src cur = src_of(tile);
-  if ((a.dbg >> 4) && (int)blockIdx.x >= G / 2)  // development: start the second workgroup of every CU out of phase
-    for (int k = 0; k < (a.dbg >> 4); ++k) __builtin_amdgcn_s_sleep(32);
 #pragma unroll
   for (int st = 0; st < NS - 1; ++st) issue(cur, st, st);  // (host: at least NS - 1 slices per tile)
   int gs0 = 0;    // ring position of the tile's slice 0
@@ -294,11 +292,7 @@ __global__ __launch_bounds__(128 * NWN) __attribute__((amdgpu_waves_per_eu(2))) 
     row(f, 0);
     row(f, 1);
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (ENTER) {
-      if (a.dbg & 1) __builtin_amdgcn_s_setprio(0);
-      enter(i);
-      if (a.dbg & 1) __builtin_amdgcn_s_setprio(1);
-    }
+    if constexpr (ENTER) enter(i);  // (s_setprio 1 around the MFMA rows: measured, no change)
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int mt = 2; mt < MTW - 1; ++mt) {
@@ -516,7 +510,7 @@ int conv_gemm_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s
   a.out_bytes = (unsigned)outb;
   a.res_bytes = (unsigned)resb;
   a.nblocks = cfg.gws * cfg.ncb;
-  a.dbg = getenv("YL_CONV_DBG") ? atoi(getenv("YL_CONV_DBG")) : 0;  // development switches
+  a.dbg = 0;
   const bool even = cfg.ksteps % 2 == 0;
   const int NWN = cfg.gemm_nwn;
   if ((NWN != 2 && NWN != 4) || (NWN == 4 && MTW == 6 && !even)) return fail(-3, "conv_gemm: unsupported wave grid");
