@@ -275,6 +275,28 @@ def short_config(scale, batch, imgsz, dtype, streams, steps, dev, conf=0.25, iou
         res["fp8_vs_fp32_oracle"] = dict({k: g2[k] for k in keys}, images=n_or, oracle_seconds=round(time.time() - t_or, 1),
                                          near_threshold=g2["near_threshold"], nms_flip=g2["nms_flip"])
         del e16
+    else:
+        # bf16 configurations: the HIP detections of the first two images against the fp32 oracle (one host forward, a few
+        # seconds), the same gate and band as the main configuration's cpu_baseline leg
+        try:
+            from oracle import yolo11_oracle as oracle
+            from oracle.parity_gate import parity_gate
+
+            n_or = min(2, batch)
+            og, cg = eng.detect(x8, conf, iou, max_det=3000, graph=False)
+            torch.cuda.synchronize(dev)
+            torch.set_num_threads(min(8, max(1, (os.cpu_count() or 2) - 1)))
+            t_or = time.time()
+            with torch.inference_mode():
+                y32, _ = oracle.forward(sd, x8[:n_or].float().cpu() / 255.0, scale)
+                ref = oracle.non_max_suppression(y32, conf, iou, max_det=3000)
+            y_hip = eng.forward(x8, graph=False)[:n_or].float().cpu()  # the HIP path's own pre-NMS tensor (near-tied arg-maxes)
+            g3 = parity_gate(ref, [og[i, : int(cg[i])].cpu() for i in range(n_or)], conf, iou, band=0.08, ref_y=y32, got_y=y_hip)
+            res["vs_fp32_oracle"] = dict({k: g3[k] for k in ("ref", "det", "matched", "matched_frac", "class_mismatch", "unexplained",
+                                                              "max_dconf", "explained_share", "max_explained_share", "count_bias", "argmax_flip", "ok")},
+                                         images=n_or, oracle_seconds=round(time.time() - t_or, 1))
+        except Exception as e:
+            res["vs_fp32_oracle"] = {"error": repr(e)}
     del eng
     torch.cuda.empty_cache()
     return res

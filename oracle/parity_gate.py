@@ -47,9 +47,29 @@ def _argmax_near_tie(y_img: torch.Tensor, r, d, band: float) -> bool:
     return False
 
 
+def _argmax_flip_elsewhere(y_img: torch.Tensor, box, band: float, iou_match: float) -> bool:
+    """y_img: the OTHER side's pre-NMS tensor of the image, (4 + nc, A).  True when an anchor over there decodes to this very box
+    (IoU >= iou_match) but carries ANOTHER class there, with this box's class scored within ``band`` of that anchor's best:
+    the two sides disagree on a near-tied arg-max, so over there the anchor competed (and lost, or it would have been paired)
+    in a different class's NMS."""
+    cx, cy, w, h = y_img[0], y_img[1], y_img[2], y_img[3]
+    x1, y1, x2, y2 = cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2
+    iw = (torch.minimum(x2, torch.tensor(float(box[2]))) - torch.maximum(x1, torch.tensor(float(box[0])))).clamp(min=0)
+    ih = (torch.minimum(y2, torch.tensor(float(box[3]))) - torch.maximum(y1, torch.tensor(float(box[1])))).clamp(min=0)
+    inter = iw * ih
+    union = (x2 - x1) * (y2 - y1) + (float(box[2]) - float(box[0])) * (float(box[3]) - float(box[1])) - inter
+    hit = ((inter / union.clamp(min=1e-9)) >= iou_match).nonzero().flatten().tolist()
+    for a in hit:
+        sc = y_img[4:, a]
+        if int(sc.argmax()) != int(box[5]) and float(sc[int(box[5])]) >= float(sc.max()) - band:
+            return True
+    return False
+
+
 def parity_gate(ref_dets: List[torch.Tensor], got_dets: List[torch.Tensor], conf: float, iou: float, band: float,
                 iou_match: float = 0.9, iou_band: float = 0.1, min_matched_frac: float = 0.9,
-                ref_y: Optional[torch.Tensor] = None, verbose: bool = False, max_explained_share: float = 0.25) -> dict:
+                ref_y: Optional[torch.Tensor] = None, verbose: bool = False, max_explained_share: float = 0.25,
+                got_y: Optional[torch.Tensor] = None) -> dict:
     """ref_dets / got_dets: per image (n, 6) [x1, y1, x2, y2, conf, cls] score-descending.  Returns the statistics
     dict with ``ok``.
 
@@ -58,6 +78,11 @@ def parity_gate(ref_dets: List[torch.Tensor], got_dets: List[torch.Tensor], conf
       nms_flip            a same-class box of the OTHER side overlaps it with IoU >= iou - iou_band: over there that box is
                           (or is close to being) its suppressor.  No upper bound is needed: from iou_match up the two
                           would have been paired, unless that box has a better partner;
+      argmax_flip         (only with the OTHER side's pre-NMS tensor: ``ref_y`` for boxes of ``got_dets``, ``got_y`` for boxes of
+                          ``ref_dets``) the anchor that decodes to this box exists over there too but carries ANOTHER class,
+                          this box's class being within ``band`` of its best score: a near-tied arg-max went the other way and the
+                          anchor entered a different class's NMS.  (YOLO11s on the synthetic head: 3 of 394 boxes; the bf16-storage
+                          emulation produces the same kind.)
       nms_flip_same_side  a same-class box of its OWN side that is PAIRED (its counterpart exists on the other side and can
                           suppress there) overlaps it with IoU in [iou - iou_band, iou].  (Round 2 accepted any same-side
                           neighbour between iou - 0.1 and 0.9, paired or not: two kept boxes at IoU 0.6-0.7 are common in
@@ -68,7 +93,7 @@ def parity_gate(ref_dets: List[torch.Tensor], got_dets: List[torch.Tensor], conf
     the e4m3 gates state their own cap.  ``count_bias`` = det / ref - 1 is reported (bf16 storage keeps slightly more
     boxes than fp32 on the synthetic head: scores cluster at the threshold)."""
     st = dict(ref=0, det=0, matched=0, class_mismatch=0, class_near_tie=0, unexplained=0, near_threshold=0, nms_flip=0,
-              nms_flip_same_side=0, max_dconf=0.0)
+              nms_flip_same_side=0, argmax_flip=0, max_dconf=0.0)
     dconfs: List[float] = []
     for img, (ref, det) in enumerate(zip(ref_dets, got_dets)):
         ref, det = ref.tolist(), det.tolist()
@@ -94,7 +119,7 @@ def parity_gate(ref_dets: List[torch.Tensor], got_dets: List[torch.Tensor], conf
                 else:
                     st["class_mismatch"] += 1
 
-        def one_sided(k, same_side, same_pairs, other_side):
+        def one_sided(k, same_side, same_pairs, other_side, other_y=None):
             box = same_side[k]
             if box[4] <= conf + band:
                 st["near_threshold"] += 1
@@ -103,6 +128,8 @@ def parity_gate(ref_dets: List[torch.Tensor], got_dets: List[torch.Tensor], conf
             elif any(q != k and q in same_pairs and o[5] == box[5] and iou - iou_band <= box_iou1(o, box) <= iou
                      for q, o in enumerate(same_side)):
                 st["nms_flip_same_side"] += 1
+            elif other_y is not None and _argmax_flip_elsewhere(other_y, box, band, iou_match):
+                st["argmax_flip"] += 1
             else:
                 st["unexplained"] += 1
                 if verbose:
@@ -111,10 +138,10 @@ def parity_gate(ref_dets: List[torch.Tensor], got_dets: List[torch.Tensor], conf
 
         for i in range(len(ref)):
             if i not in pair_of_ref:
-                one_sided(i, ref, pair_of_ref, det)
+                one_sided(i, ref, pair_of_ref, det, got_y[img] if got_y is not None else None)
         for j in range(len(det)):
             if j not in pair_of_det:
-                one_sided(j, det, pair_of_det, ref)
+                one_sided(j, det, pair_of_det, ref, ref_y[img] if ref_y is not None else None)
     if dconfs:
         t = torch.tensor(dconfs)
         st["max_dconf"] = round(float(t.max()), 4)
@@ -122,7 +149,7 @@ def parity_gate(ref_dets: List[torch.Tensor], got_dets: List[torch.Tensor], conf
         st["p99_dconf"] = round(float(t.kthvalue(max(1, int(0.99 * len(dconfs)))).values), 4)
     st["matched_frac"] = round(st["matched"] / max(1, st["ref"]), 4)
     st["score_band"] = band
-    explained = st["near_threshold"] + st["nms_flip"] + st["nms_flip_same_side"]
+    explained = st["near_threshold"] + st["nms_flip"] + st["nms_flip_same_side"] + st["argmax_flip"]
     st["explained_share"] = round(explained / max(1, st["det"]), 4)
     st["max_explained_share"] = max_explained_share
     st["count_bias"] = round(st["det"] / max(1, st["ref"]) - 1.0, 4)
