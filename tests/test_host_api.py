@@ -1,6 +1,7 @@
 """CPU: host-side mirror of the reference API (cfg, sources, letterbox, results, .pt loading)."""
 import sys
 import types
+from pathlib import Path
 
 import numpy as np
 import pytest
@@ -289,3 +290,27 @@ def test_tensor_batches_loader():
         LoadTensorBatches([torch.rand(1, 3, 30, 64)])
     with pytest.raises(ValueError):
         LoadTensorBatches([])
+
+
+def test_image_file_loader_walks_files_dirs_globs_and_lists(tmp_path):
+    """LoadImagesAndVideos (reference loaders.py:268-330): a directory, a glob and a .txt list give sorted files, batches of
+    ``batch`` with a ragged last one, the reference's log prefixes; video files raise; unreadable images raise."""
+    from PIL import Image
+
+    for k in range(3):
+        Image.fromarray(np.full((8, 10, 3), 40 * k, np.uint8)).save(tmp_path / f"im{k}.jpg")
+    (tmp_path / "list.txt").write_text("\n".join(str(tmp_path / f"im{k}.jpg") for k in (2, 0)))
+    batches = list(LoadImagesAndVideos(str(tmp_path), batch=2))
+    assert [len(b[0]) for b in batches] == [2, 1] and len(LoadImagesAndVideos(str(tmp_path), batch=2)) == 2
+    assert [Path(p).name for b in batches for p in b[0]] == ["im0.jpg", "im1.jpg", "im2.jpg"]
+    assert batches[0][1][0].shape == (8, 10, 3) and batches[0][1][0].dtype == np.uint8
+    assert batches[1][2][0].startswith("image 3/3 ")
+    assert [Path(p).name for p in next(iter(LoadImagesAndVideos(str(tmp_path / "*.jpg"), batch=8)))[0]] == ["im0.jpg", "im1.jpg", "im2.jpg"]
+    assert [Path(p).name for p in next(iter(LoadImagesAndVideos(str(tmp_path / "list.txt"), batch=8)))[0]] == ["im0.jpg", "im2.jpg"]
+    (tmp_path / "clip.mp4").write_bytes(b"x")
+    with pytest.raises(NotImplementedError):
+        LoadImagesAndVideos(str(tmp_path))
+    (tmp_path / "clip.mp4").unlink()
+    (tmp_path / "bad.png").write_bytes(b"not an image")
+    with pytest.raises(FileNotFoundError):
+        list(LoadImagesAndVideos(str(tmp_path / "bad.png")))

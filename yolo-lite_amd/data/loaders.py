@@ -6,8 +6,6 @@ section 8, out of scope) and raise ``NotImplementedError``.
 from __future__ import annotations
 
 import glob
-import math
-import os
 from dataclasses import dataclass
 from pathlib import Path
 
@@ -127,70 +125,74 @@ class LoadPilAndNumpy(_SingleBatch):
         raise AssertionError(f"Expected PIL/np.ndarray image type, but got {type(it)}")
 
 
+def _expand_source(spec) -> list:
+    """One source spec -- a file, a directory, a glob pattern, a .txt list of those, or a list / tuple of them -- as a sorted list
+    of absolute file names (what the reference's loader walks, loaders.py:268-292)."""
+    if isinstance(spec, (list, tuple)):
+        return [f for item in sorted(spec) for f in _expand_source(item)]
+    here = Path(spec)
+    if isinstance(spec, str) and here.suffix == ".txt":
+        return _expand_source(here.read_text().splitlines())  # (a list: sorted, as the reference does)
+    full = str(here.absolute())
+    if "*" in full:
+        return sorted(glob.glob(full, recursive=True))
+    if here.is_dir():
+        return sorted(str(q) for q in here.absolute().glob("*.*"))
+    if here.is_file():
+        return [full]
+    raise FileNotFoundError(f"{spec} does not exist")
+
+
 class LoadImagesAndVideos:
-    """Image files / directories / globs in batches (reference loaders.py:248-412, images only)."""
+    """Image files / directories / globs in batches of ``batch`` (reference loaders.py:248-412; video files are outside the
+    accelerated predict path and raise).  Iteration is a generator over slices of the file list: every batch is
+    ``(paths, BGR arrays, log prefixes)``."""
+
+    mode = "image"
 
     def __init__(self, path, batch=1, vid_stride=1):
-        if isinstance(path, str) and Path(path).suffix == ".txt":
-            path = Path(path).read_text().splitlines()
-        files = []
-        for p in sorted(path) if isinstance(path, (list, tuple)) else [path]:
-            a = str(Path(p).absolute())
-            if "*" in a:
-                files.extend(sorted(glob.glob(a, recursive=True)))
-            elif os.path.isdir(a):
-                files.extend(sorted(glob.glob(os.path.join(a, "*.*"))))
-            elif os.path.isfile(a):
-                files.append(a)
-            else:
-                raise FileNotFoundError(f"{p} does not exist")
-        images = [f for f in files if f.split(".")[-1].lower() in IMG_FORMATS]
-        videos = [f for f in files if f.split(".")[-1].lower() in VID_FORMATS]
-        if videos:
+        by_kind = {"image": [], "video": []}
+        for f in _expand_source(path):
+            ext = f.rsplit(".", 1)[-1].lower()
+            if ext in IMG_FORMATS:
+                by_kind["image"].append(f)
+            elif ext in VID_FORMATS:
+                by_kind["video"].append(f)
+        if by_kind["video"]:
             raise NotImplementedError("video sources are outside the accelerated predict path")
-        if not images:
+        if not by_kind["image"]:
             raise FileNotFoundError(f"No images found in {path}")
-        self.files, self.nf, self.bs, self.mode = images, len(images), batch, "image"
+        self.files, self.bs = by_kind["image"], int(batch)
+        self.nf = len(self.files)
+
+    @staticmethod
+    def _read(path: str) -> np.ndarray:
+        try:
+            return _pil_to_bgr(Image.open(path))
+        except Exception as e:  # same contract as the reference: an unreadable image is a FileNotFoundError
+            raise FileNotFoundError(f"Image Read Error {path}") from e
 
     def __iter__(self):
-        self.count = 0
-        return self
-
-    def __next__(self):
-        paths, imgs, info = [], [], []
-        while len(imgs) < self.bs:
-            if self.count >= self.nf:
-                if imgs:
-                    return paths, imgs, info
-                raise StopIteration
-            path = self.files[self.count]
-            try:
-                im0 = _pil_to_bgr(Image.open(path))
-            except Exception as e:  # same contract as the reference: unreadable image
-                raise FileNotFoundError(f"Image Read Error {path}") from e
-            self.count += 1
-            paths.append(path)
-            imgs.append(im0)
-            info.append(f"image {self.count}/{self.nf} {path}: ")
-        return paths, imgs, info
+        for first in range(0, self.nf, self.bs):
+            names = self.files[first: first + self.bs]
+            yield names, [self._read(f) for f in names], [f"image {first + k + 1}/{self.nf} {f}: " for k, f in enumerate(names)]
 
     def __len__(self):
-        return math.ceil(self.nf / self.bs)
+        return -(-self.nf // self.bs)
 
 
 def autocast_list(source):
-    """List of paths / PIL / numpy -> list of PIL / numpy (reference loaders.py:551-564)."""
-    files = []
-    for im in source:
-        if isinstance(im, (str, Path)):
-            if str(im).startswith("http"):
+    """A list of paths / PIL images / arrays as a list of PIL images / arrays (reference loaders.py:551-564)."""
+    def one(item):
+        if isinstance(item, (Image.Image, np.ndarray)):
+            return item
+        if isinstance(item, (str, Path)):
+            if str(item).startswith("http"):
                 raise NotImplementedError("remote sources need network access")
-            files.append(Image.open(im))
-        elif isinstance(im, (Image.Image, np.ndarray)):
-            files.append(im)
-        else:
-            raise TypeError(f"type {type(im).__name__} is not a supported prediction source type.")
-    return files
+            return Image.open(item)
+        raise TypeError(f"type {type(item).__name__} is not a supported prediction source type.")
+
+    return [one(item) for item in source]
 
 
 LOADERS = (LoadTensor, LoadTensorBatches, LoadPilAndNumpy, LoadImagesAndVideos)
