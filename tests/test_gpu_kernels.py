@@ -385,7 +385,7 @@ def test_upsample_and_copy(gpu_device):
     np.testing.assert_array_equal(m.read(cp.slice(16, 64)).numpy(), x.numpy())
 
 
-@pytest.mark.parametrize("nh,h,w", [(2, 20, 20), (1, 7, 5), (4, 20, 12), (2, 40, 40), (1, 48, 40), (1, 80, 80)])  # 1, 2 and 4 query tiles per wave
+@pytest.mark.parametrize("nh,h,w", [(2, 20, 20), (1, 7, 5), (4, 20, 12), (2, 40, 40), (1, 48, 40), (1, 80, 80), (1, 96, 96)])  # 1, 2, 4 and 8 query tiles per wave
 def test_attention_vs_torch(gpu_device, nh, h, w):
     """reference nn/modules/block.py:905-912 on the per-head [q|k|v] channel layout."""
     g = torch.Generator().manual_seed(nh * 100 + h)
