@@ -214,7 +214,9 @@ int yl_engine_num_ops(const yl_engine* e);
  * yl_decode_nms) in the epilogue of the launches that write the Detect levels' class logits: one launch fewer and the
  * class planes are never re-read; 0 when it stays a launch of its own (conf < 0.05, unfused class branch, YL_FUSE_PREFILTER=0). */
 int yl_engine_prefilter_fused(const yl_engine* e, float conf_thres);
-/* Algorithmic work of op i: flops (2*MAC), bytes read+written once; name is a static string. */
+/* Algorithmic work of op i: flops (2*MAC), bytes read+written once; name is a static string.  The network input's dtype is a
+ * call-time argument: the op that reads it prices it at 4 bytes per value (callers that know the dtype subtract the difference,
+ * as HipEngine.profile_detect does). */
 int yl_engine_op_info(const yl_engine* e, int i, double* flops, double* bytes, const char** kernel_name);
 
 /* Detect decode alone (device pointers): raw level maps -> y[B][4+nc][A].  head.py:95-126. */

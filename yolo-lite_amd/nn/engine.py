@@ -390,7 +390,12 @@ class HipEngine:
                 rows[-1]["flops"] += fl.value
                 rows[-1]["bytes"] += by.value
                 continue
-            rows.append(dict(name=self.prog.ops[i].get("name", ""), kernel=kern, ms=ms[i], flops=fl.value, bytes=by.value))
+            nbytes = by.value
+            if i == 0 and kern.startswith("stem"):
+                # yl_engine_op_info prices the network input at 4 bytes per value (its dtype is a call-time argument): the
+                # launch that reads THIS input reads im.element_size() bytes per value
+                nbytes -= float(im.numel()) * (4 - im.element_size())
+            rows.append(dict(name=self.prog.ops[i].get("name", ""), kernel=kern, ms=ms[i], flops=fl.value, bytes=nbytes))
         ncand = float(cnt.sum().item())  # detections, a lower bound of the candidates the later stages touch
         nc8 = self.prog.levels[0]["nc8"] if self.prog.levels else self.nc
         post = [("detect.prefilter", "decode_candidates_sparse", float(self.batch * self.anchors * nc8 * 2)),
