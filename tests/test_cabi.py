@@ -1,4 +1,5 @@
-"""CPU: the C-ABI library builds/loads and exports every symbol include/yl_amd.h declares."""
+"""CPU: the C-ABI library builds/loads and exports every symbol include/yl_amd.h (product ABI) and include/yl_amd_diag.h
+(diagnostics) declare."""
 import ctypes
 import re
 from pathlib import Path
@@ -6,8 +7,8 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 
 
-def _declared():
-    txt = (ROOT / "include" / "yl_amd.h").read_text()
+def _declared(header="yl_amd.h"):
+    txt = (ROOT / "include" / header).read_text()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(yl_[a-z0-9_]+)\s*\(", txt)))
 
@@ -21,6 +22,11 @@ def test_header_symbols_exported():
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/yl_amd.h but not exported"
     assert set(names) == set(_lib.EXPORTS), "python binding list and header drifted apart"
+    diag = _declared("yl_amd_diag.h")
+    for n in diag:
+        assert hasattr(L, n), f"{n} declared in include/yl_amd_diag.h but not exported"
+    assert set(diag) == set(_lib.DIAG_EXPORTS), "diagnostic binding list and header drifted apart"
+    assert not set(diag) & set(names), "a diagnostic entry point leaked into the product header"
     assert L.yl_abi_version() == 16
 
 

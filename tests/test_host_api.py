@@ -37,6 +37,14 @@ def test_check_imgsz_and_device():
     assert check_imgsz(640, 32, min_dim=2) == [640, 640]
     assert check_imgsz([600, 630], 32) == [608, 640]
     assert check_imgsz("[320,640]", 32) == [320, 640]
+    assert check_imgsz("640", 32) == 640 and check_imgsz(641, 32) == 672
+    assert check_imgsz(100, torch.tensor([8.0, 16.0, 32.0]), floor=160) == 160
+    assert check_imgsz([600, 630], 32, max_dim=1) == 640   # the larger one wins when only one size is allowed
+    assert check_imgsz([64], 32, min_dim=0) == [64]
+    with pytest.raises(ValueError):
+        check_imgsz([320, 640, 960], 32)
+    with pytest.raises(TypeError):
+        check_imgsz(None, 32)
     assert select_device("cpu", verbose=False).type == "cpu"
     if not torch.cuda.is_available():
         with pytest.raises(ValueError):

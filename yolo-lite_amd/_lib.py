@@ -106,13 +106,15 @@ LIB_PATH = Path(os.environ["YL_AMD_LIB"]) if os.environ.get("YL_AMD_LIB") else _
 YL_BF16, YL_F32, YL_F16, YL_U8, YL_FP8 = 0, 1, 2, 3, 4
 OP_CONV, OP_DWCONV3, OP_SPPF_POOL, OP_UPSAMPLE, OP_ATTENTION, OP_STEM = 1, 2, 3, 4, 5, 6
 
-EXPORTS = (
+EXPORTS = (  # include/yl_amd.h: the product ABI
     "yl_last_error", "yl_abi_version", "yl_device_count", "yl_engine_create", "yl_engine_destroy",
     "yl_engine_prepare_workspace", "yl_engine_forward", "yl_engine_forward_graph", "yl_engine_profile", "yl_engine_num_ops",
     "yl_engine_op_info", "yl_engine_detect_graph", "yl_detect_decode", "yl_nms_workspace_bytes", "yl_nms", "yl_decode_nms",
     "yl_preprocess_u8", "yl_letterbox_u8", "yl_nms_ml_workspace_bytes", "yl_nms_ml", "yl_engine_profile_detect",
-    "yl_graph_branch_probe", "yl_engine_prefilter_fused", "yl_stream_create_masked", "yl_stream_destroy", "yl_xcc_census",
-    "yl_engine_detect_graph_prepare", "yl_graph_launch_many", "yl_engine_detect_graph_rebind",
+    "yl_engine_prefilter_fused", "yl_engine_detect_graph_prepare", "yl_graph_launch_many", "yl_engine_detect_graph_rebind",
+)
+DIAG_EXPORTS = (  # include/yl_amd_diag.h: probes for tools/ and the runtime self-checks, not part of the product ABI
+    "yl_graph_branch_probe", "yl_stream_create_masked", "yl_stream_destroy", "yl_xcc_census",
 )
 
 

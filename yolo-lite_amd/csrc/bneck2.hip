@@ -204,11 +204,8 @@ template <int CP>
 static int bneck2_launch_t(const Bneck2Args& a, hipStream_t s) {
   auto kern = bneck2_kernel<CP>;
   constexpr size_t lds = bneck2_lds<CP>();
-  static bool attr = false;
-  if (lds > 64 * 1024 && !attr) {
-    YL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr = true;
-  }
+  if (lds > 64 * 1024)
+    if (int rc = allow_big_lds(reinterpret_cast<const void*>(kern), (int)(160 * 1024))) return rc;
   hipLaunchKernelGGL(kern, dim3((unsigned)(a.B * a.tiles_y * a.tiles_x)), dim3(BN_THREADS), lds, s, a);
   YL_HIP(hipGetLastError());
   return 0;

@@ -157,11 +157,7 @@ void conv3_cs_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, in
 template <bool RES, bool ACT>
 static int launch_cs(const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
   auto kern = conv3_cs_kernel<RES, ACT>;
-  static bool attr = false;
-  if (!attr) {
-    YL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr = true;
-  }
+  if (int rc = allow_big_lds(reinterpret_cast<const void*>(kern), (int)(160 * 1024))) return rc;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
   YL_HIP(hipGetLastError());
   return 0;
@@ -187,7 +183,8 @@ int conv3_cs_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s)
   a.res_bytes = (unsigned)resb;
   a.dbg = getenv("YL_CONV_DBG") ? atoi(getenv("YL_CONV_DBG")) : 0;
   const size_t lds = (size_t)8 * a.t_PL * 16;
-  const int grid = a.t_ntiles < 512 ? a.t_ntiles : 512;  // two persistent workgroups per CU
+  const int resident = 2 * device_cu_count();  // two persistent workgroups per CU
+  const int grid = a.t_ntiles < resident ? a.t_ntiles : resident;
   if (a.res) return a.act ? launch_cs<true, true>(a, grid, lds, s) : launch_cs<true, false>(a, grid, lds, s);
   return a.act ? launch_cs<false, true>(a, grid, lds, s) : launch_cs<false, false>(a, grid, lds, s);
 }

@@ -239,12 +239,7 @@ void conv3_pair_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, 
 template <bool RES>
 static int launch_pair(const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
   auto kern = conv3_pair_kernel<RES>;
-  static bool attr = false;
-  if (!attr) {
-    YL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)LDS_MAX_P));
-    attr = true;
-  }
+  if (int rc = allow_big_lds(reinterpret_cast<const void*>(kern), (int)((int)LDS_MAX_P))) return rc;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a);
   YL_HIP(hipGetLastError());
   return 0;

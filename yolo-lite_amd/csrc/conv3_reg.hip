@@ -386,12 +386,7 @@ void conv3_reg_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, i
 template <int MT, int NT, int NPH, bool RES, bool ACT>
 static int launch_reg_r(const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
   auto kern = conv3_reg_kernel<MT, NT, NPH, RES, ACT>;
-  static bool attr = false;
-  if (!attr) {
-    YL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)LDS_MAX_R));
-    attr = true;
-  }
+  if (int rc = allow_big_lds(reinterpret_cast<const void*>(kern), (int)((int)LDS_MAX_R))) return rc;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
   YL_HIP(hipGetLastError());
   return 0;

@@ -312,7 +312,7 @@ int conv_f8_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int 
   // k-loops are short (7-14 steps), so fewer, longer workgroups cost less of the chip per launch.  YOLO11x 1280x1280 batch 8
   // with 20 batches in flight: 8 per CU 1 042-1 053 images/s, 4: 1 058, 3: 1 072, 2: 1 066-1 070 (but one batch at a time
   // 867 -> 820), 1: 1 066.  YL_F8_PPW_DIV overrides.
-  static const int ppw_div = getenv("YL_F8_PPW_DIV") ? atoi(getenv("YL_F8_PPW_DIV")) : 3;
+  static const int ppw_div = getenv("YL_F8_PPW_DIV") ? std::max(1, atoi(getenv("YL_F8_PPW_DIV"))) : 3;
   int ppw = (int)(blocks1 / (ppw_div * 256));
   if (ppw < 1) ppw = 1;
   if (ppw > 32) ppw = 32;
@@ -355,11 +355,7 @@ void conv_f8_pack_weights(const float* w, int Cout, int Cin, int k, const ConvCo
 template <int KS, int MT, int NT, bool U>
 static int launch8(const ConvConfig& cfg, const ConvArgs& a, hipStream_t s) {
   auto kern = conv_f8_kernel<KS, MT, NT, U>;
-  static bool attr = false;
-  if (!attr) {
-    YL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr = true;
-  }
+  if (int rc = allow_big_lds(reinterpret_cast<const void*>(kern), (int)(160 * 1024))) return rc;
   hipLaunchKernelGGL(kern, dim3(a.nblocks), dim3(256), cfg.lds_bytes, s, a);
   YL_HIP(hipGetLastError());
   return 0;

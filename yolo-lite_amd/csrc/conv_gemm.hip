@@ -466,15 +466,11 @@ static int launch_gemm(const ConvArgs& a, size_t lds, hipStream_t s) {
   }
   if (a.in2 && !UP) return fail(-3, "conv_gemm: an upsampled second input cannot be combined with a residual");
   auto kern = conv_gemm_kernel<MTW, NWN, gm_ks(MTW, NWN, EVEN), gm_ns(MTW, NWN, EVEN), RES, ACT, O8, UP, GEO>;
-  static bool attr = false;
-  if (!attr) {
-    YL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr = true;
-  }
+  if (int rc = allow_big_lds(reinterpret_cast<const void*>(kern), (int)(160 * 1024))) return rc;
   if (a.ksteps / gm_ks(MTW, NWN, EVEN) < gm_ns(MTW, NWN, EVEN) - 1) return fail(-3, "conv_gemm: too few K-slices for the ring");
-  // persistent: as many workgroups as stay resident (256 CUs x two 4-wave or one 8-wave workgroup), each walks its tiles
+  // persistent: as many workgroups as stay resident (every CU x two 4-wave or one 8-wave workgroup), each walks its tiles
   static const int persist = getenv("YL_CONV_GEMM_PERSIST") ? atoi(getenv("YL_CONV_GEMM_PERSIST")) : 1;
-  const int resident = 256 * (NWN == 2 ? 2 : 1);
+  const int resident = device_cu_count() * (NWN == 2 ? 2 : 1);
   const int grid = persist && a.nblocks > resident ? resident : a.nblocks;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * NWN), lds, s, a);
   YL_HIP(hipGetLastError());

@@ -995,11 +995,7 @@ int dwpw_launch(const ConvConfig& cfg0, ConvArgs a, int batch, hipStream_t s) {
 template <int MT, int NT>
 static int launch_dwpw_group(const ConvGroup& G, int grid, size_t lds, hipStream_t s) {
   auto kern = dwpw_group_kernel<MT, NT, true>;
-  static bool attr = false;
-  if (!attr) {
-    YL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
-    attr = true;
-  }
+  if (int rc = allow_big_lds(reinterpret_cast<const void*>(kern), (int)((int)LDS_MAX))) return rc;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, G);
   YL_HIP(hipGetLastError());
   return 0;
@@ -1107,11 +1103,7 @@ bool conv_group_compatible(const ConvConfig* cfg, const ConvArgs* a, int n) {
 template <int NT, bool POST, bool U = true>
 static int launch_group_r(const ConvGroup& G, int grid, size_t lds, hipStream_t s) {
   auto kern = conv_group_kernel<3, 4, NT, U, POST>;
-  static bool attr = false;
-  if (!attr) {
-    YL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
-    attr = true;
-  }
+  if (int rc = allow_big_lds(reinterpret_cast<const void*>(kern), (int)((int)LDS_MAX))) return rc;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, G);
   YL_HIP(hipGetLastError());
   return 0;
@@ -1142,11 +1134,7 @@ int conv_group_launch(const ConvConfig* cfg, const ConvArgs* args, int n, int ba
 template <int NTC, bool POST, int NTD>
 static int launch_head_group(const ConvGroup& GC, const ConvGroup& GD, int n_conv, int grid, size_t lds, hipStream_t s) {
   auto kern = head_group_kernel<NTC, POST, NTD, POST>;
-  static bool attr = false;
-  if (!attr) {
-    YL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
-    attr = true;
-  }
+  if (int rc = allow_big_lds(reinterpret_cast<const void*>(kern), (int)((int)LDS_MAX))) return rc;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, GC, GD, n_conv);
   YL_HIP(hipGetLastError());
   return 0;

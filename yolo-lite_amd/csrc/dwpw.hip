@@ -271,11 +271,7 @@ static size_t dwpw_tile_lds(const ConvConfig& cfg, const ConvArgs& a, int NT) {
 template <int MT, int NT, bool PW2>
 static int launch_dt(const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
   auto kern = dwpw_tile_kernel<MT, NT, PW2, DW_RING>;
-  static bool attr = false;
-  if (!attr) {
-    YL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX_D));
-    attr = true;
-  }
+  if (int rc = allow_big_lds(reinterpret_cast<const void*>(kern), (int)((int)LDS_MAX_D))) return rc;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
   YL_HIP(hipGetLastError());
   return 0;

@@ -6,6 +6,8 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
+#include <set>
 #include <tuple>
 
 #include "yl_internal.h"
@@ -17,6 +19,32 @@ void set_error(const std::string& s) { g_err = s; }
 int fail(int code, const std::string& s) {
   g_err = s;
   return code;
+}
+
+int allow_big_lds(const void* kernel, int bytes) {
+  static std::mutex mu;
+  static std::set<std::pair<int, const void*>> done;
+  int dev = 0;
+  YL_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(mu);
+  if (done.count({dev, kernel})) return 0;
+  YL_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  done.insert({dev, kernel});
+  return 0;
+}
+
+int device_cu_count() {
+  static std::mutex mu;
+  static std::map<int, int> cus;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 256;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = cus.find(dev);
+  if (it != cus.end()) return it->second;
+  int n = 0;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  cus[dev] = n;
+  return n;
 }
 
 struct OpRec {
@@ -69,26 +97,32 @@ struct yl_engine {
     struct Ent {
       hipGraphExec_t exec;
       uint64_t used;
+      bool pinned;  // handed out by yl_engine_detect_graph_prepare: the caller holds the handle until yl_engine_destroy
     };
     std::map<K, Ent> m;
     uint64_t tick = 0;
     size_t cap = 64;
-    hipGraphExec_t find(const K& k) {
+    hipGraphExec_t find(const K& k, bool pin = false) {
       auto it = m.find(k);
       if (it == m.end()) return nullptr;
       it->second.used = ++tick;
+      if (pin) it->second.pinned = true;
       return it->second.exec;
     }
-    void insert(const K& k, hipGraphExec_t ge) {
+    // Pinned entries are never evicted (a caller may launch them at any time without going through find()); when every
+    // entry is pinned the cache simply grows.
+    void insert(const K& k, hipGraphExec_t ge, bool pin = false) {
       if (m.size() >= cap) {
-        (void)hipDeviceSynchronize();
-        auto lru = m.begin();
+        auto lru = m.end();
         for (auto it = m.begin(); it != m.end(); ++it)
-          if (it->second.used < lru->second.used) lru = it;
-        (void)hipGraphExecDestroy(lru->second.exec);
-        m.erase(lru);
+          if (!it->second.pinned && (lru == m.end() || it->second.used < lru->second.used)) lru = it;
+        if (lru != m.end()) {
+          (void)hipDeviceSynchronize();
+          (void)hipGraphExecDestroy(lru->second.exec);
+          m.erase(lru);
+        }
       }
-      m[k] = Ent{ge, ++tick};
+      m[k] = Ent{ge, ++tick, pin};
     }
     void clear() {
       for (auto& kv : m) (void)hipGraphExecDestroy(kv.second.exec);
@@ -110,8 +144,13 @@ struct yl_engine {
     hipGraphExec_t exec = nullptr;
     std::vector<hipGraphNode_t> nodes;  // kernel nodes whose first parameter starts with the input address
     const void* cur = nullptr;
+    uint64_t used = 0;
   };
+  // Bounded like `dgraphs` (a service that varies conf / iou / classes / max_det would otherwise grow without limit): at
+  // `rcap` entries the least recently launched one is destroyed (device synchronised first), graph and executable.
   std::map<DetectKey, Rebindable> rgraphs;
+  uint64_t rtick = 0;
+  size_t rcap = 64;
   // Per workspace (= per batch in flight): a private capture stream, one non-blocking stream per side
   // lane (yl_op.lane > 0) and a pool of fork/join events.  Batches that are in flight on different
   // caller streams use different workspaces; giving each its own lane streams keeps their graphs from
@@ -316,8 +355,11 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
         if (post && (!o.post_bias || o.res.offset >= 0 || o.out.C > o.post_cin))
           return fail(-1, tag + ": fused follow-up conv needs a bias, no residual and out.C <= post_cin");
         if (int rc = conv_choose(batch, cin_total, cout1, o.k, o.stride, Ho, Wo, post, &r.cfg)) return rc;
-        // wide plain 1x1 convs: the GEMM-class kernel (both operands through LDS); it has its own filter packing (BM / 16 tiles)
-        if (!post && !o.stem_weight && !o.cin_weight && o.out.dtype == YL_BF16 && !(up && o.res.offset >= 0))
+        // wide plain convs (1x1, and 3x3 with Cin >= 64, Cout % 128 == 0): the GEMM-class kernel (both operands through LDS);
+        // it has its own filter packing (BM / 16 tiles).  Its 3x3 route cannot write an e4m3 copy (out8): such a conv
+        // stays on conv_kernel.
+        if (!post && !o.stem_weight && !o.cin_weight && o.out.dtype == YL_BF16 && !(up && o.res.offset >= 0) &&
+            !(o.k == 3 && o.out8.offset >= 0))
           conv_gemm_choose(batch, cin_total, cout1, o.k, o.stride, Ho, Wo, &r.cfg, up ? o.in2.C : 0);
         if (o.out8.offset >= 0) {
           if (int rc = check_out8(o, batch, workspace_bytes, tag)) return rc;
@@ -1171,14 +1213,14 @@ static int detect_eager(yl_engine* e, const void* input, int in_dtype, void* wor
 static int detect_graph_get(yl_engine* e, const void* input, int in_dtype, void* workspace, float conf_thres, float iou_thres,
                             int max_det, int agnostic, const int32_t* classes, int n_classes, int max_cand, float max_wh,
                             const float* scale, float* out, int32_t* out_count, void* work, void* stream, int launch,
-                            hipGraphExec_t* exec_out) {
+                            hipGraphExec_t* exec_out, bool pin = false) {
   if (!e || !input || !workspace || !out || !out_count || !work)
     return fail(-1, "yl_engine_detect_graph: null pointer");
   if (e->levels.empty()) return fail(-1, "yl_engine_detect_graph: engine has no Detect levels");
   hipStream_t s = (hipStream_t)stream;
   yl_engine::DetectKey key(input, in_dtype, workspace, conf_thres, iou_thres, max_det, agnostic, classes, n_classes,
                            max_cand, max_wh, scale, out, out_count, work);
-  hipGraphExec_t exec = e->dgraphs.find(key);
+  hipGraphExec_t exec = e->dgraphs.find(key, pin);
   if (!exec) {
     // eager first: argument checks, workspace preparation and lazy function attributes happen here
     if (int rc = detect_eager(e, input, in_dtype, workspace, conf_thres, iou_thres, max_det, agnostic, classes,
@@ -1201,7 +1243,7 @@ static int detect_graph_get(yl_engine* e, const void* input, int in_dtype, void*
     hipError_t ie = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
     (void)hipGraphDestroy(g);
     if (ie != hipSuccess) return fail(-2, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie));
-    e->dgraphs.insert(key, ge);
+    e->dgraphs.insert(key, ge, pin);
     exec = ge;
   }
   if (exec_out) *exec_out = exec;
@@ -1227,7 +1269,7 @@ extern "C" int yl_engine_detect_graph_prepare(yl_engine* e, const void* input, i
   if (!graph_out) return fail(-1, "yl_engine_detect_graph_prepare: null pointer");
   hipGraphExec_t ex = nullptr;
   const int rc = detect_graph_get(e, input, in_dtype, workspace, conf_thres, iou_thres, max_det, agnostic, classes, n_classes,
-                                  max_cand, max_wh, scale, out, out_count, work, stream, 0, &ex);
+                                  max_cand, max_wh, scale, out, out_count, work, stream, 0, &ex, /*pin=*/true);
   *graph_out = (void*)ex;
   return rc;
 }
@@ -1259,10 +1301,16 @@ extern "C" int yl_engine_detect_graph_rebind(yl_engine* e, const void* input, in
     int rc = detect_eager(e, input, in_dtype, workspace, conf_thres, iou_thres, max_det, agnostic, classes, n_classes,
                           max_cand, max_wh, scale, out, out_count, work, (void*)cap);
     hipError_t ce = hipStreamEndCapture(cap, &rb.g);
-    if (rc) {
-      if (rb.g) (void)hipGraphDestroy(rb.g);
-      return rc;
-    }
+    // every exit below that does not hand rb to the table destroys the captured graph (and the executable, if any)
+    struct Guard {
+      yl_engine::Rebindable* r;
+      ~Guard() {
+        if (!r) return;
+        if (r->exec) (void)hipGraphExecDestroy(r->exec);
+        if (r->g) (void)hipGraphDestroy(r->g);
+      }
+    } guard{&rb};
+    if (rc) return rc;
     if (ce != hipSuccess) return fail(-2, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
     size_t nn = 0;
     YL_HIP(hipGraphGetNodes(rb.g, nullptr, &nn));
@@ -1279,19 +1327,25 @@ extern "C" int yl_engine_detect_graph_rebind(yl_engine* e, const void* input, in
       memcpy(&first, kp.kernelParams[0], sizeof(first));  // every input-reading launch takes the address first
       if (first == input) rb.nodes.push_back(nd);
     }
-    if (rb.nodes.empty()) {
-      (void)hipGraphDestroy(rb.g);
+    if (rb.nodes.empty())
       return fail(-3, "yl_engine_detect_graph_rebind: no kernel node of the captured graph reads the input address");
-    }
     hipError_t ie = hipGraphInstantiate(&rb.exec, rb.g, nullptr, nullptr, 0);
-    if (ie != hipSuccess) {
-      (void)hipGraphDestroy(rb.g);
-      return fail(-2, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie));
-    }
+    if (ie != hipSuccess) return fail(-2, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie));
     rb.cur = input;
+    if (e->rgraphs.size() >= e->rcap) {  // evict the least recently launched tuple
+      auto lru = e->rgraphs.begin();
+      for (auto jt = e->rgraphs.begin(); jt != e->rgraphs.end(); ++jt)
+        if (jt->second.used < lru->second.used) lru = jt;
+      (void)hipDeviceSynchronize();
+      if (lru->second.exec) (void)hipGraphExecDestroy(lru->second.exec);
+      if (lru->second.g) (void)hipGraphDestroy(lru->second.g);
+      e->rgraphs.erase(lru);
+    }
+    guard.r = nullptr;
     it = e->rgraphs.emplace(key, rb).first;
   }
   yl_engine::Rebindable& rb = it->second;
+  rb.used = ++e->rtick;
   if (rb.cur != input) {
     for (hipGraphNode_t nd : rb.nodes) {
       hipKernelNodeParams kp{};

@@ -674,11 +674,7 @@ __global__ __launch_bounds__(64 * AT_WAVES) __attribute__((amdgpu_waves_per_eu(2
 template <int R>
 static int launch_attention(const AttnArgs& a, int qsplit, size_t lds, hipStream_t s) {
   auto kern = attention_kernel<R>;
-  static bool attr = false;
-  if (!attr) {
-    YL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr = true;
-  }
+  if (int rc = allow_big_lds(reinterpret_cast<const void*>(kern), (int)(160 * 1024))) return rc;
   hipLaunchKernelGGL(kern, dim3(a.batch * a.heads * qsplit), dim3(64 * AT_WAVES), lds, s, a, qsplit);
   YL_HIP(hipGetLastError());
   return 0;

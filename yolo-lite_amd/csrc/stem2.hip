@@ -281,13 +281,8 @@ static int stem2_launch_c(const Stem2Args& a, int MT, size_t lds, hipStream_t s)
   const dim3 grid((unsigned)(a.B * a.tiles_y * a.tiles_x));
   const bool post = a.wpk2 != nullptr;
   auto go = [&](auto kern) {
-    static bool attr = false;  // per instantiation (one lambda instance per call site below)
-    if (lds > 64 * 1024 && !attr) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
-          hipSuccess)
-        return fail(-2, "stem2: hipFuncSetAttribute failed");
-      attr = true;
-    }
+    if (lds > 64 * 1024)
+      if (int rc = allow_big_lds(reinterpret_cast<const void*>(kern), 160 * 1024)) return rc;
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
     YL_HIP(hipGetLastError());
     return 0;

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "../../include/yl_amd.h"
+#include "../../include/yl_amd_diag.h"
 
 namespace yl {
 
@@ -16,6 +17,12 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 void set_error(const std::string& s);
 int fail(int code, const std::string& s);
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute of a kernel: set once per (device, kernel), so a process
+// that drives a second GPU launches there with the attribute in place too (engine.hip).
+int allow_big_lds(const void* kernel, int bytes);
+// compute units of the current device (cached per device); the persistent-grid sizes derive from it
+int device_cu_count();
 
 #define YL_HIP(expr)                                                                         \
   do {                                                                                       \

@@ -214,6 +214,9 @@ class DetectionPredictor:
     def _harvest_fused(self, job):
         if job["ev"] is not None:
             job["ev"].synchronize()
+            # the records were cloned on the batch's side stream and are consumed on the caller's stream from here on:
+            # tell the caching allocator, so the block is not handed out again under a pending reader
+            job["out"].record_stream(torch.cuda.current_stream(job["out"].device))
         counts = job["cnt"].tolist()  # the one host sync of the batch
         self.last_preds = None
         names, out, shapes, imgs, paths = self.model.names, job["out"], job["shapes"], job["imgs"], job["paths"]
@@ -297,7 +300,10 @@ class DetectionPredictor:
                     im = self.preprocess(im0s)
                 if self._can_fuse():
                     with profilers[1]:  # network + fused decode / NMS / box rescale, one host sync
-                        untouched = isinstance(im0s, torch.Tensor) and im is im0s and getattr(self.dataset, "resident", False)
+                        # (a non-contiguous tensor gets a .contiguous() copy enqueued on the CURRENT stream in
+                        # _launch_fused: that batch must wait for the current stream's tail, not for the entry event)
+                        untouched = (isinstance(im0s, torch.Tensor) and im is im0s and im.is_contiguous()
+                                     and getattr(self.dataset, "resident", False))
                         job = self._launch_fused(im, im0s, slot=k % S, stream=self._streams[k % S] if S > 1 else None,
                                                  after=entry_ev if untouched else None)
                     job.update(batch=self.batch, im=im, t_launch=profilers[1].dt, t_pre=profilers[0].dt)
