@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define YL_ABI_VERSION 16
+#define YL_ABI_VERSION 17
 
 /* element types */
 enum { YL_BF16 = 0, YL_F32 = 1, YL_F16 = 2, YL_U8 = 3, YL_FP8 = 4 /* OCP e4m3 */ };
@@ -42,6 +42,14 @@ enum {
                          weight / bias = cv1 [c][c][3][3], post_weight / post_bias = cv2 (post_cin = 9c).  `in` and `out`
                          must be different buffers (a workgroup reads a halo of `in`).  The tensor between the convs lives
                          in LDS; bit-identical to the two YL_OP_CONV ops it replaces.                                */
+  YL_OP_C3K = 10,     /* body of a C3k block (nn/modules/block.py:731-739 C3k; :245-259 C3.forward; :330-343 Bottleneck) with inner
+                         width c_ = 64 on a map small enough for one workgroup's LDS (20x20 at 640x640: layers 8 and 22 of
+                         YOLO11n), ONE launch, one workgroup per image (csrc/resident.hip):
+                           u = SiLU(cv1|cv2(in))  (weight / bias = C3.cv1 and C3.cv2 stacked, [2 c_][in.C], 1x1),
+                           a = u[0:c_] through two Bottlenecks a + SiLU(cv2(SiLU(cv1(a)))) (extra_weight[0..3] = m.0.cv1, m.0.cv2,
+                           m.1.cv1, m.1.cv2, each [c_][c_][3][3]), out = SiLU(cv3(cat(a, u[c_:2 c_]))) (extra_weight[4],
+                           [out.C][2 c_], 1x1).  in.C = out.C = 2 c_ = 128; in and out have the same H, W.  Every tensor between
+                           `in` and `out` lives in LDS or registers; bit-identical to the six YL_OP_CONV ops it replaces.  */
   YL_OP_C3K2S = 7     /* body of a narrow C3k2 block in one launch (nn/modules/block.py:220-235, 330-343), half width
                          c = 16 or 32: `in` = the block's concat buffer [a | b | ...] (a, b = halves of C3k2.cv1's output,
                          c channels each); c_out = b + SiLU(cv2(SiLU(cv1(b)))) with the Bottleneck's two 3x3 convs
@@ -134,6 +142,11 @@ typedef struct yl_op {
   yl_view out8;
   float out8_scale;
   int32_t out8_only;
+  /* ops made of more than three convs (YL_OP_C3K): n_extra further BN-folded fp32 filters / biases, arrays of HOST pointers
+     (read by yl_engine_create only, like weight / bias) */
+  int32_t n_extra, reserved3;
+  const float* const* extra_weight;
+  const float* const* extra_bias;
   /* YL_OP_DWCONV3 with post_weight (depthwise 3x3 -> pointwise 1x1 in one launch) AND stem_weight: a further 1x1
      conv behind the pointwise one (the nn.Conv2d(c3, nc, 1) that ends Detect's class branch, head.py:47), also in
      that launch: reserved2 = output channels of the pointwise conv (post_weight [reserved2][in.C]), stem_weight

@@ -29,6 +29,10 @@ int yl_stream_destroy(void* stream);
 /* Launches n_workgroups one-wave workgroups on `stream`; each adds 1 to hist_device[xcd * 64 + shader engine * 16 + cu]
  * of the unit it ran on (512 x uint32 on the device, zeroed by the caller). */
 int yl_xcc_census(unsigned* hist_device, int n_workgroups, void* stream);
+/* In-kernel phase stamps (development): device_buffer receives {shader clock, 100 MHz clock} pairs from the instrumented
+ * kernels of a library built with -DYL_STAMPS ([workgroup][wave][32 phases][2] x uint64); NULL switches them off.  Returns 1
+ * when the library is such a build, 0 when it is the production build (the call then has no effect).  tools/res_stamps.py. */
+int yl_diag_set_stamps(void* device_buffer);
 #ifdef __cplusplus
 }
 #endif

@@ -27,7 +27,7 @@ def test_header_symbols_exported():
         assert hasattr(L, n), f"{n} declared in include/yl_amd_diag.h but not exported"
     assert set(diag) == set(_lib.DIAG_EXPORTS), "diagnostic binding list and header drifted apart"
     assert not set(diag) & set(names), "a diagnostic entry point leaked into the product header"
-    assert L.yl_abi_version() == 16
+    assert L.yl_abi_version() == 17
 
 
 def test_struct_layouts_match_header():
@@ -36,7 +36,7 @@ def test_struct_layouts_match_header():
     assert ctypes.sizeof(_lib.View) == 32       # int64 + 6 x int32
     assert ctypes.sizeof(_lib.Level) == 32
     # yl_op: 13 x int32/float (52) + pad to 8 (56) + 3 views (96) + 2 pointers (16)
-    assert ctypes.sizeof(_lib.Op) == 56 + 96 + 16 + 8 + 16 + 32 + 8 + 16 + 8 + 16 + 40  # + post_*, in2, up, reserved, stem_*, fp8 scales, out8
+    assert ctypes.sizeof(_lib.Op) == 56 + 96 + 16 + 8 + 16 + 32 + 8 + 16 + 8 + 16 + 40 + 24  # + post_*, in2, up, reserved, stem_*, fp8 scales, out8, extra filters
 
 
 def test_no_gpu_calls_fail_loudly():

@@ -1,0 +1,119 @@
+"""-m gpu: the per-image resident stage kernels (csrc/resident.hip) against the launches they replace (bit for bit) and
+against plain torch fp32 of the same block (reference nn/modules/block.py:245-259, 330-343, 731-739)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from hip_util import Mini, bf16_round
+from yololite_amd.nn import arch
+from yololite_amd.nn.engine import HipEngine
+from yololite_amd.nn.lower import OP_C3K, OP_CONV, c3k_resident_fits
+from yololite_amd.nn.synth import synth_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_block(gen, c_=64):
+    """BN-folded filters of a C3k block of inner width c_ (values bf16-representable, scaled so activations stay O(1))."""
+    c = 2 * c_
+
+    def wb(co, ci, k):
+        w = bf16_round(torch.randn(co, ci, k, k, generator=gen) * (1.5 / (ci * k * k) ** 0.5))
+        return w, torch.randn(co, generator=gen) * 0.2
+
+    return dict(cv12=wb(c, c, 1), m=[wb(c_, c_, 3) for _ in range(4)], cv3=wb(c, c, 1))
+
+
+def _torch_block(x, blk, storage_bf16=True):
+    """fp32 arithmetic, every stored tensor rounded to bf16 where the HIP path stores bf16 (so only summation order differs)."""
+    r = bf16_round if storage_bf16 else (lambda t: t)
+
+    def conv(t, wb_, k):
+        return r(F.silu(F.conv2d(t, wb_[0], wb_[1], padding=k // 2)))
+
+    u = conv(x, blk["cv12"], 1)
+    c_ = u.shape[1] // 2
+    a, b = u[:, :c_], u[:, c_:]
+    for j in range(2):
+        t = conv(a, blk["m"][2 * j], 3)
+        a = r(F.silu(F.conv2d(t, blk["m"][2 * j + 1][0], blk["m"][2 * j + 1][1], padding=1)) + a)
+    return conv(torch.cat([a, b], 1), blk["cv3"], 1)
+
+
+def _np(t):
+    return np.ascontiguousarray(t.numpy(), dtype=np.float32)
+
+
+def _run_resident(dev, x, blk):
+    B, c, H, W = x.shape
+    m = Mini(B, dev)
+    tin = m.buf(H, W, 3 * c)          # the block reads a channel slice of a wider buffer, as in C3k2 (block.py:231-235)
+    xin = tin.slice(c, c)
+    yv = tin.slice(2 * c, c)
+    m.fill(xin, x)
+    m.op(kind=OP_C3K, name="c3k", act=1, inp=xin, out=yv,
+         weight=_np(blk["cv12"][0].reshape(c, -1)), bias=_np(blk["cv12"][1]),
+         extra_weight=[_np(w) for w, _ in blk["m"]] + [_np(blk["cv3"][0].reshape(c, -1))],
+         extra_bias=[_np(b) for _, b in blk["m"]] + [_np(blk["cv3"][1])])
+    m.run()
+    assert m.eng.op_kernel(0) == "c3k_resident_mfma"
+    return m.read(yv)
+
+
+def _run_chain(dev, x, blk):
+    """The same block as the six conv launches of the unfused program (nn/lower.py::c3k_block)."""
+    B, c, H, W = x.shape
+    c_ = c // 2
+    m = Mini(B, dev)
+    xin, u, t, yv = m.buf(H, W, c), m.buf(H, W, c), m.buf(H, W, c_), m.buf(H, W, c)
+    m.fill(xin, x)
+    a = u.slice(0, c_)
+    m.op(kind=OP_CONV, name="cv12", k=1, stride=1, act=1, inp=xin, out=u, weight=_np(blk["cv12"][0]), bias=_np(blk["cv12"][1]))
+    for j in range(2):
+        m.op(kind=OP_CONV, name=f"m{j}.cv1", k=3, stride=1, act=1, inp=a, out=t, weight=_np(blk["m"][2 * j][0]), bias=_np(blk["m"][2 * j][1]))
+        m.op(kind=OP_CONV, name=f"m{j}.cv2", k=3, stride=1, act=1, inp=t, out=a, res=a, weight=_np(blk["m"][2 * j + 1][0]),
+             bias=_np(blk["m"][2 * j + 1][1]))
+    m.op(kind=OP_CONV, name="cv3", k=1, stride=1, act=1, inp=u, out=yv, weight=_np(blk["cv3"][0]), bias=_np(blk["cv3"][1]))
+    m.run()
+    return m.read(yv)
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 20, 20), (3, 12, 20), (1, 10, 10), (2, 5, 7), (2, 16, 16), (1, 2, 3), (2, 12, 12), (2, 16, 20), (1, 19, 19)])
+def test_c3k_resident_vs_chain_and_torch(gpu_device, B, H, W):
+    """One launch per block == the six launches, every bit; and both within bf16 rounding of torch fp32.  The sizes cover
+    every tile-count instantiation (1 .. 7 tiles per wave quarter), ragged last tiles, non-square maps and the largest map that fits."""
+    assert c3k_resident_fits(64, H, W)
+    gen = torch.Generator().manual_seed(1000 * H + W)
+    blk = _rand_block(gen)
+    x = bf16_round(torch.randn(B, 128, H, W, generator=gen))
+    got = _run_resident(gpu_device, x, blk)
+    chain = _run_chain(gpu_device, x, blk)
+    assert torch.equal(got, chain), f"max |d| {float((got - chain).abs().max())}"
+    ref = _torch_block(x, blk)
+    # same operands, fp32 accumulation in another order: a few outputs land on the other side of a bf16 rounding boundary
+    err = (got - ref).abs()
+    assert float(err.max()) <= 0.05 * float(ref.abs().max()), float(err.max())
+    assert float((err > 1e-6).float().mean()) < 0.2
+
+
+@pytest.mark.parametrize("h,w,b", [(640, 640, 8), (384, 640, 8), (320, 320, 9), (640, 640, 32)])
+def test_network_with_resident_c3k_is_bit_identical(gpu_device, monkeypatch, h, w, b):
+    """YOLO11n with layers 8 and 22 as ONE launch each against the program with their six launches: level maps and decoded
+    predictions, every bit."""
+    sd = synth_state_dict("n", 5, cls_bias=[-2.0, -2.0, -2.0], cls_gain=4.0)
+    x = torch.randint(0, 256, (b, 3, h, w), generator=torch.Generator().manual_seed(h + 3 * w), dtype=torch.uint8).to(gpu_device)
+    specs, _ = arch.parse_model(arch.yolo11_dict("n"))
+    monkeypatch.setenv("YL_FUSE_C3K", "1")
+    eng = HipEngine.from_model(specs, sd, b, h, w, gpu_device)
+    names = [eng.op_kernel(i) for i in range(len(eng.prog.ops))]
+    assert names.count("c3k_resident_mfma") == 2, names
+    y = eng.forward(x).clone()
+    lv = [t.clone() for t in eng.raw_levels()]
+    monkeypatch.setenv("YL_FUSE_C3K", "0")
+    ref = HipEngine.from_model(specs, sd, b, h, w, gpu_device)
+    assert "c3k_resident_mfma" not in [ref.op_kernel(i) for i in range(len(ref.prog.ops))]
+    assert len(ref.prog.ops) == len(eng.prog.ops) + 10
+    assert torch.equal(y, ref.forward(x))
+    for p, q in zip(lv, ref.raw_levels()):
+        assert torch.equal(p, q)

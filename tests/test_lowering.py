@@ -204,3 +204,28 @@ def test_detect_levels_are_grouped_at_the_end_of_the_program():
             v = o["out"]
             for c in range(v.coff // 8, (v.coff + v.C + 7) // 8):
                 written.add((v.offset, c))
+
+
+def test_c3k_resident_limits():
+    """Which C3k blocks the per-image resident kernel takes (mirror of c3k_resident_fits in csrc/resident.hip)."""
+    from yololite_amd.nn.lower import c3k_resident_fits
+
+    assert c3k_resident_fits(64, 20, 20) and c3k_resident_fits(64, 12, 20) and c3k_resident_fits(64, 19, 19)
+    assert not c3k_resident_fits(64, 21, 21) and not c3k_resident_fits(64, 40, 40)   # LDS
+    assert not c3k_resident_fits(32, 20, 20) and not c3k_resident_fits(128, 10, 10)  # inner width 64 only
+
+
+def test_lowering_uses_resident_c3k_from_batch_8(monkeypatch):
+    from yololite_amd.nn import arch
+    from yololite_amd.nn.lower import OP_C3K, lower
+    from yololite_amd.nn.synth import synth_state_dict
+
+    monkeypatch.delenv("YL_FUSE_C3K", raising=False)
+    specs, _ = arch.parse_model(arch.yolo11_dict("n"))
+    sd = synth_state_dict("n", 0)
+    big = lower(specs, sd, 32, 640, 640)
+    assert [o["name"] for o in big.ops if o["kind"] == OP_C3K] == ["model.8.m.0", "model.22.m.0"]
+    small = lower(specs, sd, 1, 640, 640)
+    assert not [o for o in small.ops if o["kind"] == OP_C3K] and len(small.ops) == len(big.ops) + 10
+    s_scale = lower(arch.parse_model(arch.yolo11_dict("s"))[0], synth_state_dict("s", 0), 32, 640, 640)
+    assert not [o for o in s_scale.ops if o["kind"] == OP_C3K]   # inner width 128: the maps do not fit

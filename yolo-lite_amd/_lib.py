@@ -114,7 +114,7 @@ EXPORTS = (  # include/yl_amd.h: the product ABI
     "yl_engine_prefilter_fused", "yl_engine_detect_graph_prepare", "yl_graph_launch_many", "yl_engine_detect_graph_rebind",
 )
 DIAG_EXPORTS = (  # include/yl_amd_diag.h: probes for tools/ and the runtime self-checks, not part of the product ABI
-    "yl_graph_branch_probe", "yl_stream_create_masked", "yl_stream_destroy", "yl_xcc_census",
+    "yl_graph_branch_probe", "yl_stream_create_masked", "yl_stream_destroy", "yl_xcc_census", "yl_diag_set_stamps",
 )
 
 
@@ -137,7 +137,8 @@ class Op(C.Structure):
                 ("stem_weight", C.c_void_p), ("stem_bias", C.c_void_p),
                 ("stem_act", C.c_int32), ("reserved2", C.c_int32),
                 ("in_scale", C.c_float), ("out_scale", C.c_float), ("res_scale", C.c_float), ("out8_c0", C.c_int32),
-                ("out8", View), ("out8_scale", C.c_float), ("out8_only", C.c_int32)]
+                ("out8", View), ("out8_scale", C.c_float), ("out8_only", C.c_int32),
+                ("n_extra", C.c_int32), ("reserved3", C.c_int32), ("extra_weight", C.c_void_p), ("extra_bias", C.c_void_p)]
 
 
 class Level(C.Structure):
@@ -235,9 +236,11 @@ def lib() -> C.CDLL:
     L.yl_stream_destroy.argtypes = [vp]
     L.yl_xcc_census.restype = i32
     L.yl_xcc_census.argtypes = [vp, i32, vp]
+    L.yl_diag_set_stamps.restype = i32
+    L.yl_diag_set_stamps.argtypes = [vp]
     L.yl_engine_prefilter_fused.restype = i32
     L.yl_engine_prefilter_fused.argtypes = [vp, f32]
-    if L.yl_abi_version() != 16:
+    if L.yl_abi_version() != 17:
         raise RuntimeError("libyl_amd.so ABI version mismatch; rebuild it")
     _lib = L
     return L

@@ -21,6 +21,8 @@ int fail(int code, const std::string& s) {
   return code;
 }
 
+unsigned long long* g_stamp_buf = nullptr;
+
 int allow_big_lds(const void* kernel, int bytes) {
   static std::mutex mu;
   static std::set<std::pair<int, const void*>> done;
@@ -61,6 +63,8 @@ struct OpRec {
   __bf16* d_wpk3 = nullptr;  // YL_OP_C3K2S: the block's 1x1 conv (d_wpk / d_wpk2 = the Bottleneck's two 3x3 convs)
   float* d_bias3 = nullptr;
   float* d_alpha = nullptr;  // fp8 conv: in_scale * filter scale per output channel
+  __bf16* d_xw[6] = {};      // YL_OP_C3K: the six packed filters (cv1|cv2, m.0.cv1, m.0.cv2, m.1.cv1, m.1.cv2, cv3) and biases
+  float* d_xb[6] = {};
   bool f8 = false;
   int cls_level = -1;  // fused depthwise + pointwise + 1x1 that writes the class logits of this Detect level (else -1)
   int group_n = 0;  // group launch (yl_op.group): 2 or 3 on the first member, -1 on the others (run with it), 0 = on its own
@@ -536,6 +540,41 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
         r.name = "bottleneck_fused_mfma";
         break;
       }
+      case YL_OP_C3K: {
+        const int c = o.in.C, c_ = c / 2;
+        if (!o.weight || !o.bias || o.n_extra != 5 || !o.extra_weight || !o.extra_bias)
+          return fail(-1, tag + ": c3k needs the stacked cv1|cv2 filter and five extra filters (two Bottlenecks, cv3)");
+        for (int q = 0; q < 5; ++q)
+          if (!o.extra_weight[q] || !o.extra_bias[q]) return fail(-1, tag + ": c3k: null extra filter");
+        if (o.in.dtype != YL_BF16 || o.out.dtype != YL_BF16 || o.in.H != o.out.H || o.in.W != o.out.W || o.out.C != c || c != 128 ||
+            o.lane != 0 || !c3k_resident_fits(c_, o.in.H, o.in.W))
+          return fail(-3, tag + ": c3k: needs 128 channels in and out (inner width 64) on a map that fits one workgroup's LDS");
+        // every conv as 64-channel blocks of four tiles (conv_pack_weights order), biases padded to the blocks
+        const float* ws[6] = {o.weight, o.extra_weight[0], o.extra_weight[1], o.extra_weight[2], o.extra_weight[3], o.extra_weight[4]};
+        const float* bs[6] = {o.bias, o.extra_bias[0], o.extra_bias[1], o.extra_bias[2], o.extra_bias[3], o.extra_bias[4]};
+        const int cin[6] = {c, c_, c_, c_, c_, c}, cout[6] = {c, c_, c_, c_, c_, c}, ks[6] = {1, 3, 3, 3, 3, 1};
+        for (int q = 0; q < 6; ++q) {
+          ConvConfig cc{};
+          cc.MT = 4;
+          cc.ncb = cout[q] / 64;
+          cc.cg = cin[q] / 8;
+          cc.ntaps = ks[q] * ks[q];
+          cc.ksteps = cc.ntaps * cc.cg / 4;
+          cc.wpk_elems = (size_t)cc.ncb * cc.ksteps * cc.MT * 64 * 8;
+          std::vector<uint16_t> pk;
+          conv_pack_weights(ws[q], cout[q], cin[q], ks[q], cc, &pk);
+          uint16_t* d = nullptr;
+          if (int rc = dev_upload(e.get(), pk, &d)) return rc;
+          r.d_xw[q] = reinterpret_cast<__bf16*>(d);
+          std::vector<float> bias((size_t)cout[q] + 16, 0.f);
+          for (int ch = 0; ch < cout[q]; ++ch) bias[ch] = bs[q][ch];
+          if (int rc = dev_upload(e.get(), bias, &r.d_xb[q])) return rc;
+        }
+        r.flops = 2.0 * px_out * (2.0 * c * c + 4.0 * 9.0 * c_ * c_);
+        r.bytes = px_out * 2.0 * c * 2 + 2.0 * (2.0 * c * c + 36.0 * c_ * c_);
+        r.name = "c3k_resident_mfma";
+        break;
+      }
       case YL_OP_C3K2S: {
         if (!o.weight || !o.bias || !o.post_weight || !o.post_bias || !o.stem_weight || !o.stem_bias)
           return fail(-1, tag + ": c3k2 needs the three convs' weights and biases");
@@ -908,6 +947,27 @@ static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s, c
       q.in_bytes = q.out_bytes = (unsigned)nb;
       q.plane_px = gq.plane_px;
       return bneck2_launch(q, s);
+    }
+    case YL_OP_C3K: {
+      C3kArgs q{};
+      const Geo gq = geo_of(B, o.out.H, o.out.W);
+      const long long nb = (long long)(o.in.C / 8) * plane_bytes(gq);
+      if (nb > (1LL << 30)) return fail(-3, "c3k: a tensor slice exceeds 1 GiB; lower the batch size");
+      q.x = pview(ws, o.in, B).base;
+      q.y = pview(ws, o.out, B).base;
+      q.x_plane = q.y_plane = (unsigned)plane_bytes(gq);
+      q.x_bytes = q.y_bytes = (unsigned)nb;
+      q.B = B;
+      q.H = o.out.H;
+      q.W = o.out.W;
+      q.W1 = gq.W1;
+      q.img = gq.img;
+      q.g0 = gq.g0;
+      for (int k = 0; k < 6; ++k) {
+        q.w[k] = r.d_xw[k];
+        q.bias[k] = r.d_xb[k];
+      }
+      return c3k_resident_launch(q, s);
     }
     case YL_OP_C3K2S: {
       C3k2sArgs q{};
@@ -1528,6 +1588,16 @@ extern "C" int yl_xcc_census(unsigned* hist8_device /* 512 bins */, int n_workgr
 __global__ void spin_kernel(unsigned long long ticks) {
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+// Diagnostic builds only (-DYL_STAMPS): where the instrumented kernels store their phase stamps (nullptr: off)
+extern "C" int yl_diag_set_stamps(void* device_buffer) {
+  g_stamp_buf = reinterpret_cast<unsigned long long*>(device_buffer);
+#ifdef YL_STAMPS
+  return 1;
+#else
+  return 0;
+#endif
 }
 
 extern "C" int yl_graph_branch_probe(void* stream, int spin_us, float* ms_graph, int* concurrent) {

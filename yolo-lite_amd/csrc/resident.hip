@@ -1,0 +1,429 @@
+// Per-image RESIDENT stage kernels for the small maps (20x20 at 640x640): one workgroup owns one image's map in LDS and runs a
+// whole chain of convs on it, workgroup barriers between the layers instead of kernel boundaries.
+//
+// c3k_resident_kernel: the body of a C3k block (reference nn/modules/block.py:731-739 C3k(C3), :245-259 C3.forward,
+// :330-343 Bottleneck, conv.py:35-53 Conv with the BN folded per utils/torch_utils.py:182-209), c_ = 64 channels inside:
+//
+//     u  = SiLU(cv1|cv2(x))            1x1, 128 -> 128 (C3.cv1 and C3.cv2 stacked: both read x; a = u[0:64], b = u[64:128])
+//     a  = a + SiLU(m0.cv2(SiLU(m0.cv1(a))))     two 3x3 convs 64 -> 64 and the shortcut add
+//     a  = a + SiLU(m1.cv2(SiLU(m1.cv1(a))))
+//     y  = SiLU(cv3(cat(a, b)))        1x1, 128 -> 128
+//
+// Six launches of the unfused program (layers 8 and 22 of YOLO11n: 70 us in sequence for 4.6 GFLOP per batch of 32, every one
+// of them a 9-14 us launch whatever its work) become one.  Eight waves (two per SIMD); x, a and the tensor between a
+// Bottleneck's convs live in LDS, b never leaves the registers of the wave that computed it:
+//
+//   LDS   region 0: x, dense [16 planes][HWp px][16 B]  (HWp = pixels rounded up to 16)     -> later T, guarded [8 planes]
+//         region 1: A, guarded [8 planes][(H + 2) * (W + 1) + 2 px][16 B]
+//   The guarded plane is the activation layout of HBM cut down to one image (yl_internal.h): a 3x3 tap is a constant byte
+//   offset that lands on data or on a zero, so the B fragments of the 3x3 convs are plain ds_read_b128 of 16 consecutive
+//   pixels (256 contiguous bytes per lane group: conflict-free), no predicates.
+//   Filters come straight from L2 into registers (packed fragment order, conv_pack_weights with four tiles per block),
+//   three k-steps ahead; all 32 workgroups of a batch read the same bytes.
+//   1x1 convs: a wave owns an EIGHTH of the pixel tiles and every output channel (64 at a time): the b half of u stays in
+//             its registers as the B fragments of cv3's last two k-steps.
+//   3x3 convs: a wave owns a QUARTER of the pixel tiles and HALF of the output channels (M-half x N-quarter: 2 filter loads
+//             and 7 LDS reads per 14 MFMAs), the two waves of a SIMD taking different quarters.
+// Arithmetic is conv_kernel's: the same packed filters, k order (tap-major, 32 channels per k-step), fp32 accumulation
+// chain starting from the bias, SiLU (silu_f), residual add after the activation, one rounding to bf16 per layer --
+// results are BIT-IDENTICAL to the six launches (tests/test_gpu_resident.py).
+#include "conv_common.h"
+
+namespace yl {
+
+typedef __attribute__((address_space(3))) void lds_void_r;
+
+constexpr int RC_THREADS = 512;
+constexpr int RC_WAVES = RC_THREADS / 64;
+
+// first tile / tile count of part `i` of `parts` when `ntiles` are dealt as evenly as possible (the first ntiles % parts get one more)
+__device__ __forceinline__ void even_split(int ntiles, int parts, int i, int& t0, int& cnt) {
+  const int base = ntiles / parts, rem = ntiles - base * parts;
+  t0 = i * base + (i < rem ? i : rem);
+  cnt = base + (i < rem ? 1 : 0);
+}
+
+struct PixMap {
+  int H, W, W1, HW;
+};
+// dense pixel index -> guarded index inside one image's plane (0 = the pixel above-left of (0, 0)); clamped for i >= HW
+__device__ __forceinline__ int guarded_index(const PixMap& m, int i, bool& valid) {
+  valid = i < m.HW;
+  const int ic = valid ? i : m.HW - 1;
+  const int y = ic / m.W, x = ic - y * m.W;
+  return m.W1 + 1 + y * m.W1 + x;
+}
+
+// ---- one 3x3 conv 64 -> 64 from a guarded LDS map: this wave's M-half (tiles 2 mh, 2 mh + 1 of the 4-tile filter block) x NT
+// pixel tiles.  src: LDS region + this lane's k-group plane (g * apl).  tb[nt]: byte offset of the lane's pixel in a plane.
+constexpr int RC_D = 3;  // k-steps of filter fragments in flight per wave (3x3 steps)
+
+// the first RC_D k-steps of a 3x3 filter (this wave's two tiles): issued BEFORE the barrier in front of the step
+__device__ __forceinline__ void preload3(bf16x8 (&wa)[RC_D][2], const bf16x8* __restrict__ wp) {
+#pragma unroll
+  for (int d = 0; d < RC_D; ++d)
+#pragma unroll
+    for (int m = 0; m < 2; ++m) wa[d][m] = wp[(d * 4 + m) * 64];
+}
+
+template <int NT>
+__device__ __forceinline__ void conv3_from_lds(f32x4 (&acc)[2][NT], bf16x8 (&wa)[RC_D][2], const bf16x8* __restrict__ wp,
+                                               const unsigned char* src, const unsigned (&tb)[NT], int W1, int apl) {
+  constexpr int NKS = 18, KKN = 2, D = RC_D;
+  bf16x8 xb[2][NT];
+  auto load_b = [&](int ks, bf16x8 (&dst)[NT]) __attribute__((always_inline)) {
+    const int tap = ks / KKN, kk = ks - tap * KKN;
+    const int kh = tap / 3, kw = tap - 3 * kh;
+    const int off = ((kh - 1) * W1 + (kw - 1)) * 16 + kk * 4 * apl;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) dst[nt] = *reinterpret_cast<const bf16x8*>(src + (int)tb[nt] + off);
+  };
+  load_b(0, xb[0]);
+#pragma unroll
+  for (int ks = 0; ks < NKS; ++ks) {
+    if (ks + 1 < NKS) load_b(ks + 1, xb[(ks + 1) & 1]);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+        acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ks % D][m], xb[ks & 1][nt], acc[m][nt], 0, 0, 0);
+    if (ks + D < NKS) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) wa[ks % D][m] = wp[((ks + D) * 4 + m) * 64];
+    }
+  }
+}
+
+// A 3x3 step for this wave: acc = bias; conv from `src` map; SiLU; optional residual from map `res` (same plane / pixel the lane
+// writes); bf16; 16-byte LDS store into map `dst`.
+template <int NT, int NTQ>
+__device__ __forceinline__ void step3(const C3kArgs& a, const PixMap& pm, unsigned char* lds, int src_off, int dst_off, int res_off,
+                                      const __bf16* w, const float* bias, int mh, const unsigned (&tbq)[NTQ], unsigned okmask, int g,
+                                      int lane, bf16x8 (&wa)[RC_D][2]) {
+  unsigned tb[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) tb[nt] = tbq[nt];
+  f32x4 acc[2][NT];
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + chan_in_block(4, 2 * mh + m, g, 0));
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[m][nt] = bv;
+  }
+  conv3_from_lds<NT>(acc, wa, reinterpret_cast<const bf16x8*>(w) + (2 * mh) * 64 + lane, lds + src_off + g * a.apl, tb, pm.W1, a.apl);
+  const int pl = (mh * 4 + g) * a.apl;  // the lane's 8 output channels = plane mh * 4 + g
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    float v[8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      v[r] = silu_f(acc[0][nt][r]);
+      v[4 + r] = silu_f(acc[1][nt][r]);
+    }
+    if (res_off >= 0) {
+      const bf16x8 rv = *reinterpret_cast<const bf16x8*>(lds + res_off + pl + (int)tb[nt]);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] += (float)rv[r];
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) o[r] = (__bf16)v[r];
+    if ((okmask >> nt) & 1u) *reinterpret_cast<bf16x8*>(lds + dst_off + pl + (int)tb[nt]) = o;
+  }
+}
+
+// The 1x1 convs (128 -> 128) run as the sequence j = (channel block cb, k-step ks) = 0 .. 7 with the filter fragments of three
+// j ahead in registers; ring1 is filled BEFORE the barrier in front of the step.
+constexpr int RC_D1 = 3;
+__device__ __forceinline__ void preload1(bf16x8 (&wa)[RC_D1][4], const bf16x8* __restrict__ wp) {
+#pragma unroll
+  for (int d = 0; d < RC_D1; ++d)
+#pragma unroll
+    for (int m = 0; m < 4; ++m) wa[d][m] = wp[(d * 4 + m) * 64];
+}
+
+// cv1|cv2 (1x1, 128 -> 128) on this wave's NT tiles: channels [0, 64) -> map A (region 1), [64, 128) -> breg (B fragments of cv3)
+template <int NT, int NTE>
+__device__ __forceinline__ void step_in(const C3kArgs& a, const PixMap& pm, unsigned char* lds, int t0, int n, int g, int lane,
+                                        bf16x8 (&breg)[2][NTE], bf16x8 (&wa)[RC_D1][4]) {
+  // x fragments: read per k-step, one step ahead (both channel blocks read them: 2 x 4 LDS reads per tile instead of 64 registers)
+  bf16x8 xb[2][NT];
+  auto load_x = [&](int ks, bf16x8 (&dst)[NT]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      dst[nt] = *reinterpret_cast<const bf16x8*>(lds + (ks * 4 + g) * a.xpl + ((t0 + nt) * 16 + n) * 16);
+  };
+  load_x(0, xb[0]);
+  const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.w[0]) + lane;
+  int gi[NT];
+  bool ok[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) gi[nt] = guarded_index(pm, (t0 + nt) * 16 + n, ok[nt]);
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias[0] + cb * 64 + chan_in_block(4, m, g, 0));
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[m][nt] = bv;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int j = cb * 4 + ks;
+      if (j + 1 < 8) load_x((ks + 1) & 3, xb[(j + 1) & 1]);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j % RC_D1][m], xb[j & 1][nt], acc[m][nt], 0, 0, 0);
+      if (j + RC_D1 < 8) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) wa[j % RC_D1][m] = wp[((j + RC_D1) * 4 + m) * 64];
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        bf16x8 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          o[r] = (__bf16)silu_f(acc[2 * p][nt][r]);
+          o[4 + r] = (__bf16)silu_f(acc[2 * p + 1][nt][r]);
+        }
+        if (cb == 0) {
+          if (ok[nt]) *reinterpret_cast<bf16x8*>(lds + a.r1 + (p * 4 + g) * a.apl + gi[nt] * 16) = o;
+        } else {
+          breg[p][nt] = o;
+        }
+      }
+  }
+}
+
+// cv3 (1x1, 128 -> 128): k-steps 0, 1 from map A, k-steps 2, 3 from breg; 16-byte stores into the output planes in HBM
+template <int NT, int NTE>
+__device__ __forceinline__ void step_out(const C3kArgs& a, const PixMap& pm, const unsigned char* lds, int t0, int n, int g, int lane,
+                                         int b, const bf16x8 (&breg)[2][NTE], bf16x8 (&wa)[RC_D1][4]) {
+  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, (short)0, a.y_bytes, 0x00020000);
+  bf16x8 xa[2][NT];
+  unsigned opix[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    bool ok;
+    const int gi = guarded_index(pm, (t0 + nt) * 16 + n, ok);
+    opix[nt] = ok ? (unsigned)(b * a.img + gi) * 16u : OOB_LANE;  // (g0 of the HBM layout == W1 + 1 == the LDS map's origin)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) xa[ks][nt] = *reinterpret_cast<const bf16x8*>(lds + a.r1 + (ks * 4 + g) * a.apl + gi * 16);
+  }
+  const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.w[5]) + lane;
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias[5] + cb * 64 + chan_in_block(4, m, g, 0));
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[m][nt] = bv;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int j = cb * 4 + ks;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const bf16x8 xf = ks < 2 ? xa[ks & 1][nt] : breg[ks & 1][nt];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j % RC_D1][m], xf, acc[m][nt], 0, 0, 0);
+      }
+      if (j + RC_D1 < 8) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m) wa[j % RC_D1][m] = wp[((j + RC_D1) * 4 + m) * 64];
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = silu_f(acc[2 * p][nt][r]);
+          v[4 + r] = silu_f(acc[2 * p + 1][nt][r]);
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(
+            u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])}, rout,
+            opix[nt] == OOB_LANE ? OOB_LANE : (unsigned)(cb * 8 + p * 4 + g) * a.y_plane + opix[nt], 0, 0);
+      }
+  }
+}
+
+// NTQ = ceil(ntiles / 4): tiles of the largest pixel quarter (the others have NTQ or NTQ - 1); NTE = ceil(ntiles / 8)
+template <int NTQ>
+__global__ __launch_bounds__(RC_THREADS) void c3k_resident_kernel(C3kArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
+  constexpr int NTE = (NTQ + 1) / 2;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, g = lane >> 4;
+  const int b = blockIdx.x;
+  PixMap pm{a.H, a.W, a.W1, a.H * a.W};
+  const int HWp = a.ntiles * 16;
+#define RC_STAMP(id) YL_STAMP(a.stamps, RC_WAVES, wave, lane, id)
+  RC_STAMP(0);
+
+  // ---- 0. x -> region 0 (dense planes; one pixel per thread, its 16 planes in flight together); A's guard pixels := 0.
+  // Behind the x loads every filter byte of the block is touched once (one dword per 128-byte line, by LDS-DMA into a
+  // scratch word: no registers, nothing waits for it): the filters were last read a whole network step ago and have left
+  // L2 by now; the k-loops below then find them there instead of paying an HBM round trip per k-step.
+  const int mh = wave & 1;
+  int tq0, tqcnt;
+  even_split(a.ntiles, 4, wave >> 1, tq0, tqcnt);
+  unsigned tbq[NTQ], okq = 0;  // this wave's pixel tiles of the 3x3 steps: byte offset of the lane's pixel in a guarded plane
+#pragma unroll
+  for (int nt = 0; nt < NTQ; ++nt) {
+    bool ok;
+    tbq[nt] = (unsigned)guarded_index(pm, (tq0 + nt) * 16 + n, ok) * 16u;
+    okq |= (ok && nt < tqcnt) ? (1u << nt) : 0u;
+  }
+  bf16x8 wa1[RC_D1][4];
+  preload1(wa1, reinterpret_cast<const bf16x8*>(a.w[0]) + lane);
+  {
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, (short)0, a.x_bytes, 0x00020000);
+    bool ok;
+    const int gi = guarded_index(pm, tid, ok);
+    const unsigned src = ok ? (unsigned)(b * a.img + gi) * 16u : OOB_LANE;
+    bf16x8 v[16];
+#pragma unroll
+    for (int p = 0; p < 16; ++p)
+      v[p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rin, src == OOB_LANE ? OOB_LANE : (unsigned)p * a.x_plane + src, 0, 0));
+    if (!(a.dbg & 1)) {
+      // warm-up: filter q has wbytes[q] bytes; thread t touches lines t, t + 512, ...
+#pragma unroll 1
+      for (int q = 0; q < 6; ++q) {
+        const int nlines = (q == 0 || q == 5 ? 32768 : 73728) / 128;
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w[q], (short)0, (unsigned)nlines * 128u, 0x00020000);
+        for (int l = tid; l < nlines; l += RC_THREADS)  // (the LDS destination is M0-based and the same for every lane group: a scratch area)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_r*)(rsm + a.scratch), 4, (unsigned)l * 128u, 0, 0, 0);
+      }
+    }
+    // guard pixels of map A (everything of a guarded plane that is not pixel (y, x) of the image)
+    for (int q = tid; q * 16 < a.apl; q += RC_THREADS) {
+      const int r = q - (pm.W1 + 1), y = r / pm.W1, x = r - y * pm.W1;
+      if (!(r >= 0 && y < pm.H && x < pm.W)) {
+        const bf16x8 z = {};
+#pragma unroll
+        for (int p = 0; p < 8; ++p) *reinterpret_cast<bf16x8*>(rsm + a.r1 + p * a.apl + q * 16) = z;
+      }
+    }
+    if (tid < HWp) {
+#pragma unroll
+      for (int p = 0; p < 16; ++p) *reinterpret_cast<bf16x8*>(rsm + p * a.xpl + tid * 16) = v[p];
+    }
+  }
+  RC_STAMP(1);
+  __syncthreads();
+  RC_STAMP(2);
+
+  // ---- 1. u = SiLU(cv1|cv2(x)): a -> map A, b -> registers
+  int te0, tecnt;
+  even_split(a.ntiles, RC_WAVES, wave, te0, tecnt);
+  bf16x8 breg[2][NTE];
+  if (tecnt == NTE) step_in<NTE, NTE>(a, pm, rsm, te0, n, g, lane, breg, wa1);
+  else if (NTE > 1 && tecnt == NTE - 1) step_in<(NTE > 1 ? NTE - 1 : 1), NTE>(a, pm, rsm, te0, n, g, lane, breg, wa1);
+  bf16x8 wa[RC_D][2];
+  preload3(wa, reinterpret_cast<const bf16x8*>(a.w[1]) + (2 * mh) * 64 + lane);
+  RC_STAMP(3);
+  __syncthreads();  // everybody is done with x
+  RC_STAMP(4);
+
+  // ---- region 0 becomes map T: its guard pixels must read as zero (the interior is written by the first 3x3 step)
+  for (int q = tid; q * 16 < a.apl; q += RC_THREADS) {
+    const int r = q - (pm.W1 + 1), y = r / pm.W1, x = r - y * pm.W1;
+    if (!(r >= 0 && y < pm.H && x < pm.W)) {
+      const bf16x8 z = {};
+#pragma unroll
+      for (int p = 0; p < 8; ++p) *reinterpret_cast<bf16x8*>(rsm + p * a.apl + q * 16) = z;
+    }
+  }
+  RC_STAMP(5);
+
+  // ---- 2-5. the two Bottlenecks: A -> T, T (+ A) -> A, twice.  The next step's first filter fragments are requested before
+  // the barrier that ends a step.
+  auto run3 = [&](int s) __attribute__((always_inline)) {
+    const int src_off = (s & 1) ? 0 : a.r1, dst_off = (s & 1) ? a.r1 : 0, res_off = (s & 1) ? a.r1 : -1;
+    if (tqcnt == NTQ) step3<NTQ, NTQ>(a, pm, rsm, src_off, dst_off, res_off, a.w[1 + s], a.bias[1 + s], mh, tbq, okq, g, lane, wa);
+    else if (NTQ > 1 && tqcnt == NTQ - 1)
+      step3<(NTQ > 1 ? NTQ - 1 : 1), NTQ>(a, pm, rsm, src_off, dst_off, res_off, a.w[1 + s], a.bias[1 + s], mh, tbq, okq, g, lane, wa);
+  };
+#pragma unroll 1
+  for (int s = 0; s < 3; ++s) {
+    run3(s);
+    preload3(wa, reinterpret_cast<const bf16x8*>(a.w[2 + s]) + (2 * mh) * 64 + lane);
+    RC_STAMP(6 + 2 * s);
+    __syncthreads();
+    RC_STAMP(7 + 2 * s);
+  }
+  run3(3);
+  bf16x8 wa6[RC_D1][4];
+  preload1(wa6, reinterpret_cast<const bf16x8*>(a.w[5]) + lane);
+  RC_STAMP(12);
+  __syncthreads();
+  RC_STAMP(13);
+
+  // ---- 6. y = SiLU(cv3(cat(a, b)))
+  if (tecnt == NTE) step_out<NTE, NTE>(a, pm, rsm, te0, n, g, lane, b, breg, wa6);
+  else if (NTE > 1 && tecnt == NTE - 1) step_out<(NTE > 1 ? NTE - 1 : 1), NTE>(a, pm, rsm, te0, n, g, lane, b, breg, wa6);
+  RC_STAMP(14);
+#undef RC_STAMP
+}
+
+size_t c3k_resident_lds(int H, int W, int* xpl_out, int* apl_out, int* r1_out, int* ntiles_out) {
+  const int ntiles = (H * W + 15) / 16;
+  const int xpl = ntiles * 16 * 16;
+  const int apx = (((H + 2) * (W + 1) + 2) + 15) & ~15;
+  const int apl = apx * 16;
+  const int r0 = 16 * xpl > 8 * apl ? 16 * xpl : 8 * apl;
+  if (xpl_out) *xpl_out = xpl;
+  if (apl_out) *apl_out = apl;
+  if (r1_out) *r1_out = r0;
+  if (ntiles_out) *ntiles_out = ntiles;
+  return (size_t)r0 + (size_t)8 * apl + 256;  // + the scratch line of the filter warm-up (one dword per lane)
+}
+
+// Whether the resident kernel takes a C3k block of inner width c_ on an H x W map
+bool c3k_resident_fits(int c_, int H, int W) {
+  if (c_ != 64) return false;
+  int nt = 0;
+  const size_t lds = c3k_resident_lds(H, W, nullptr, nullptr, nullptr, &nt);
+  return lds <= 160 * 1024 && nt >= 1 && nt <= 28 && nt * 16 <= RC_THREADS;
+}
+
+template <int NTQ>
+static int c3k_launch_t(const C3kArgs& a, size_t lds, hipStream_t s) {
+  auto kern = c3k_resident_kernel<NTQ>;
+  if (int rc = allow_big_lds(reinterpret_cast<const void*>(kern), 160 * 1024)) return rc;
+  hipLaunchKernelGGL(kern, dim3((unsigned)a.B), dim3(RC_THREADS), lds, s, a);
+  YL_HIP(hipGetLastError());
+  return 0;
+}
+
+int c3k_resident_launch(C3kArgs a, hipStream_t s) {
+  if (!c3k_resident_fits(64, a.H, a.W)) return fail(-3, "c3k_resident: the map does not fit one workgroup's LDS");
+  const size_t lds = c3k_resident_lds(a.H, a.W, &a.xpl, &a.apl, &a.r1, &a.ntiles);
+  a.stamps = g_stamp_buf;
+  a.scratch = a.r1 + 8 * a.apl;
+  static const int dbg = getenv("YL_RES_DBG") ? atoi(getenv("YL_RES_DBG")) : 0;  // development: 1 = no filter warm-up
+  a.dbg = dbg;
+  switch ((a.ntiles + 3) / 4) {
+    case 1: return c3k_launch_t<1>(a, lds, s);
+    case 2: return c3k_launch_t<2>(a, lds, s);
+    case 3: return c3k_launch_t<3>(a, lds, s);
+    case 4: return c3k_launch_t<4>(a, lds, s);
+    case 5: return c3k_launch_t<5>(a, lds, s);
+    case 6: return c3k_launch_t<6>(a, lds, s);
+    case 7: return c3k_launch_t<7>(a, lds, s);
+  }
+  return fail(-3, "c3k_resident: unsupported map size");
+}
+
+}  // namespace yl

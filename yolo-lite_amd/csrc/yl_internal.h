@@ -24,6 +24,23 @@ int allow_big_lds(const void* kernel, int bytes);
 // compute units of the current device (cached per device); the persistent-grid sizes derive from it
 int device_cu_count();
 
+// In-kernel phase stamps of a DIAGNOSTIC build (make EXTRA=-DYL_STAMPS; include/yl_amd_diag.h yl_diag_set_stamps): lane 0 of
+// every wave stores {shader clock, 100 MHz clock} at phase boundaries into a buffer no other code reads.  The production
+// build compiles the macro away.
+extern unsigned long long* g_stamp_buf;
+#ifdef YL_STAMPS
+#define YL_STAMP(buf, waves, wave, lane, id)                                                             \
+  do {                                                                                                   \
+    if ((buf) && (lane) == 0) {                                                                          \
+      unsigned long long* _p = (buf) + (((size_t)blockIdx.x * (waves) + (wave)) * 32 + (id)) * 2;        \
+      _p[0] = __builtin_amdgcn_s_memtime();                                                              \
+      _p[1] = __builtin_amdgcn_s_memrealtime();                                                          \
+    }                                                                                                    \
+  } while (0)
+#else
+#define YL_STAMP(buf, waves, wave, lane, id) do { } while (0)
+#endif
+
 #define YL_HIP(expr)                                                                         \
   do {                                                                                       \
     hipError_t _e = (expr);                                                                  \
@@ -282,6 +299,25 @@ struct Bneck2Args {
   int tiles_x, tiles_y;
 };
 int bneck2_launch(const Bneck2Args& a, hipStream_t s);
+
+// resident.hip: the body of a C3k block (inner width 64) in one launch, one workgroup per image, the maps in LDS
+struct C3kArgs {
+  const __bf16* x;  // first plane of the block's input slice (128 channels)
+  __bf16* y;        // first plane of its output slice (128 channels)
+  unsigned x_plane, y_plane;  // bytes per plane in HBM
+  unsigned x_bytes, y_bytes;  // buffer-descriptor sizes
+  int B, H, W, W1, img, g0;   // guarded geometry of the map in HBM (input and output share it)
+  const __bf16* w[6];         // packed filters: cv1|cv2, m0.cv1, m0.cv2, m1.cv1, m1.cv2, cv3  ([cb][k-step][4 tiles][64 lanes][8])
+  const float* bias[6];       // padded to 64-channel blocks
+  int ntiles;                 // 16-pixel tiles per image
+  int xpl, apl;               // LDS bytes per dense plane / per guarded plane
+  int r1;                     // LDS byte offset of region 1
+  int scratch;                // LDS byte offset of a 64-byte scratch area (target of the filter warm-up loads)
+  int dbg;                    // development switches (YL_RES_DBG), 0 in production
+  unsigned long long* stamps; // diagnostic builds (-DYL_STAMPS): [workgroup][wave][32] x {s_memtime, s_memrealtime}; else unused
+};
+bool c3k_resident_fits(int c_, int H, int W);
+int c3k_resident_launch(C3kArgs a, hipStream_t s);
 
 struct DecodeLevel {
   PView box;     // 8 planes: DFL logits (head.py:64 cv2)

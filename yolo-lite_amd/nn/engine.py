@@ -39,7 +39,7 @@ class HipEngine:
         self.anchors = self.prog.anchors
         ops = self.prog.ops
         arr = (_lib.Op * len(ops))()
-        self._keep: List[np.ndarray] = []
+        self._keep: list = []
         for i, o in enumerate(ops):
             c = arr[i]
             c.kind = o["kind"]
@@ -69,6 +69,13 @@ class HipEngine:
                 self._keep += [w0, b0]
                 c.stem_weight, c.stem_bias, c.stem_act = w0.ctypes.data, b0.ctypes.data, int(o.get("stem_act", 1))
                 c.reserved2 = int(o.get("mid_c", 0))
+            if "extra_weight" in o:  # ops of more than three convs: arrays of host pointers
+                xw = [np.ascontiguousarray(w, dtype=np.float32) for w in o["extra_weight"]]
+                xb = [np.ascontiguousarray(b, dtype=np.float32) for b in o["extra_bias"]]
+                pw = (C.c_void_p * len(xw))(*[w.ctypes.data for w in xw])
+                pb = (C.c_void_p * len(xb))(*[b.ctypes.data for b in xb])
+                self._keep += xw + xb + [pw, pb]
+                c.n_extra, c.extra_weight, c.extra_bias = len(xw), C.cast(pw, C.c_void_p), C.cast(pb, C.c_void_p)
             if "post_weight" in o:
                 w2 = np.ascontiguousarray(o["post_weight"], dtype=np.float32).reshape(o["post_weight"].shape[0], -1)
                 b2 = np.ascontiguousarray(o["post_bias"], dtype=np.float32)

@@ -22,7 +22,7 @@ from .arch import LayerSpec, detect_mid_channels
 
 BN_EPS = 1e-3
 BF16, F32, FP8 = 0, 1, 4  # yl_amd.h element types (FP8 = OCP e4m3, planes of 16 channels)
-OP_CONV, OP_DWCONV3, OP_SPPF_POOL, OP_UPSAMPLE, OP_ATTENTION, OP_STEM, OP_C3K2S, OP_BNECK2, OP_QUANT = 1, 2, 3, 4, 5, 6, 7, 8, 9
+OP_CONV, OP_DWCONV3, OP_SPPF_POOL, OP_UPSAMPLE, OP_ATTENTION, OP_STEM, OP_C3K2S, OP_BNECK2, OP_QUANT, OP_C3K = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
 
 
 @dataclass
@@ -90,6 +90,17 @@ class _Arena:
         v = TView(self.top, H, W, C, C, 0, dtype)
         self.top += (view_bytes(self.batch, v) + 255) // 256 * 256
         return v
+
+
+def c3k_resident_fits(c_: int, H: int, W: int) -> bool:
+    """Mirror of ``c3k_resident_fits`` (csrc/resident.hip): a C3k block of inner width 64 whose map fits one workgroup's
+    LDS -- x as 16 dense planes (later the 8 guarded planes between a Bottleneck's convs) + the 8 guarded planes of `a`."""
+    if c_ != 64:
+        return False
+    ntiles = (H * W + 15) // 16
+    xpl = ntiles * 16 * 16
+    apl = (((H + 2) * (W + 1) + 2) + 15) // 16 * 16 * 16
+    return max(16 * xpl, 8 * apl) + 8 * apl <= 160 * 1024 and 1 <= ntiles <= 28
 
 
 def fuse_follow_up_convs(ops: List[dict]) -> List[dict]:
@@ -687,6 +698,26 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
         u = ar.alloc(x.H, x.W, 2 * c_)
         w1, b1 = fold_conv_bn(sd, p + ".cv1")
         w2, b2 = fold_conv_bn(sd, p + ".cv2")
+        # the whole block in ONE launch, one workgroup per image, every tensor between x and y in LDS / registers
+        # (csrc/resident.hip; YOLO11n layers 8 and 22 at 640x640: 6 launches -> 1, bit-identical).  A workgroup per image
+        # fills the chip only with a batch behind it: small batches keep the six launches (YL_FUSE_C3K_MIN_BATCH).
+        if (fuse_post and os.environ.get("YL_FUSE_C3K", "1") != "0" and c3k_resident_fits(c_, x.H, x.W)
+                and c == 2 * c_ and y.C == c and batch >= int(os.environ.get("YL_FUSE_C3K_MIN_BATCH", "8")) and not fp8_scales):
+            w3, b3 = fold_conv_bn(sd, p + ".cv3")
+            xw, xb, names = [], [], [p + ".cv1+cv2"]
+            for j in range(2):
+                for q in ("cv1", "cv2"):
+                    wj, bj = fold_conv_bn(sd, f"{p}.m.{j}.{q}")
+                    xw.append(wj)
+                    xb.append(bj)
+                    names.append(f"{p}.m.{j}.{q}")
+            xw.append(w3.reshape(w3.shape[0], -1))
+            xb.append(b3)
+            names.append(p + ".cv3")
+            ops.append(dict(kind=OP_C3K, name=p, act=1, inp=x, out=y, res=None,
+                            weight=np.concatenate([w1, w2], 0).reshape(2 * c_, -1), bias=np.concatenate([b1, b2], 0),
+                            extra_weight=xw, extra_bias=xb, fused_names=names))
+            return
         # C3.cv1 and C3.cv2 read the same input (block.py:259): one conv with stacked filters
         conv(p + ".cv1+cv2", x, u, 1, 1, wb=(np.concatenate([w1, w2], 0), np.concatenate([b1, b2], 0)))
         a = u.slice(0, c_)
