@@ -156,6 +156,32 @@ def build_model(scale, device, batch, h, w, x_calib, target_frac=0.015, fp8=Fals
     return specs, sd, HipEngine.from_model(specs, sd, batch, h, w, device, fp8_calib=x_calib if fp8 else None)
 
 
+def config5_target_frac(imgsz: int, per_image: float = 0.0) -> float:
+    """Fraction of anchors the synthetic head lets over conf 0.25: 1.5 % at 640x640 (126 of 8 400 anchors, ~100 detections
+    after NMS: the headline configuration).  Larger images keep the candidate COUNT per image, not the fraction
+    (``per_image``, default C5_CANDIDATES_PER_IMAGE): at 1280x1280 (33 600 anchors) 1.5 % of white-noise anchors meant 500
+    scattered candidates and every image cut at max_det = 300 (round-3 review)."""
+    anchors = sum((imgsz // s) ** 2 for s in (8, 16, 32))
+    if anchors <= 8400:
+        return 0.015
+    return min(0.015, (per_image or C5_CANDIDATES_PER_IMAGE) / anchors)
+
+
+# BASELINE.json config 5 (YOLO11x, 1280x1280): candidates per image over conf 0.25 -- the headline configuration's own count, so
+# that an image keeps ~60-140 boxes after NMS and none is cut at max_det
+C5_CANDIDATES_PER_IMAGE = float(os.environ.get("YL_C5_PER_IMAGE", "126"))
+
+
+def config5_images(batch: int, imgsz: int, seed: int = 0):
+    """Inputs of config 5: white noise, like the headline run's.  Measured alternative (tools/synth_input_probe.py): images
+    with spatial structure (nn/synth.py::synth_images) spread YOLO11x's per-anchor class maxima from 0.3 to 1.7 logit between
+    the 98.5 % and 99.6 % quantiles -- the box COUNT then agrees between fp32, bf16 and e4m3 (35 / 36 / 43 boxes) where white
+    noise gives 60 / 93 / 135 -- but the wider logits also show e4m3's real error (max |dconf| 0.15-0.19, half of the boxes
+    paired): white noise is the gentler input for the scores and the harsher one for the count.  Kept: white noise, with the
+    count bias reported and the e4m3 FORMAT's own count bias (CPU emulation) beside it."""
+    return torch.rand(batch, 3, imgsz, imgsz, generator=torch.Generator().manual_seed(seed))
+
+
 def cpu_baseline(sd, scale, h, w, conf, iou, sample_b=32, iters=3, eng=None, dev=None, max_det=300, band=0.08):
     """The oracle (fp32 eager PyTorch restatement of the reference path, unfused Conv->BN->SiLU +
     python-loop NMS) timed on this host's cores: threads = min(8, cores-1) as the reference sets
@@ -202,8 +228,9 @@ def short_config(scale, batch, imgsz, dtype, streams, steps, dev, conf=0.25, iou
     """A short pipelined run of another BASELINE.json configuration (3: YOLO11s bf16 batch 64; 5: YOLO11x e4m3 1280x1280
     batch 8) inside the default bench, so that the driver's own run carries a number for them.  Same step, same timing
     bracket as `value`; fewer steps.  For fp8 the e4m3 program's detections are gated against the bf16 program's."""
-    x = torch.rand(batch, 3, imgsz, imgsz, generator=torch.Generator().manual_seed(0)).to(dev)
-    specs, sd, eng = build_model(scale, dev, batch, imgsz, imgsz, x, fp8=dtype == "fp8")
+    x = config5_images(batch, imgsz).to(dev)
+    tfrac = config5_target_frac(imgsz)  # (0.015 at 640x640: the headline configuration's own calibration)
+    specs, sd, eng = build_model(scale, dev, batch, imgsz, imgsz, x, target_frac=tfrac, fp8=dtype == "fp8")
     x8 = (x * 255).to(torch.uint8)
     del x
     S = streams
@@ -227,7 +254,8 @@ def short_config(scale, batch, imgsz, dtype, streams, steps, dev, conf=0.25, iou
     dt = time.perf_counter() - t0
     res = {"workload": f"YOLO11{scale} {dtype}, {imgsz}x{imgsz} batch={batch}, {S} batches in flight", "value": round(batch * steps / dt, 1),
            "unit": "images/sec", "steps": steps, "ms_per_step": round(dt / steps * 1e3, 4),
-           "mean_detections_per_image": round(cnt.float().mean().item(), 1)}
+           "mean_detections_per_image": round(cnt.float().mean().item(), 1), "images_cut_at_max_det": int((cnt >= max_det).sum().item()),
+           "candidate_fraction_target": round(tfrac, 5)}
     try:  # the best 3x3 conv of this configuration against its MFMA roof (in-sequence HIP events, one batch in flight)
         rows = eng.profile_detect(x8, conf, iou, max_det=max_det, iters=10)
         best, tot_fl = None, 0.0
@@ -252,15 +280,15 @@ def short_config(scale, batch, imgsz, dtype, streams, steps, dev, conf=0.25, iou
         o16, c16 = e16.detect(x8, conf, iou, max_det=gate_max_det, graph=False)
         torch.cuda.synchronize(dev)
         g = parity_gate([o16[i, : int(c16[i])].cpu() for i in range(batch)], [o8[i, : int(c8[i])].cpu() for i in range(batch)],
-                        conf, iou, band=0.15, min_matched_frac=0.75, max_explained_share=0.6)
+                        conf, iou, band=0.15, min_matched_frac=0.85, max_explained_share=0.35)
         keys = ("ref", "det", "matched", "matched_frac", "class_mismatch", "unexplained", "max_dconf", "explained_share",
                 "max_explained_share", "count_bias", "ok")
         res["fp8_vs_bf16"] = {k: g[k] for k in keys}
         # ... and against the REFERENCE arithmetic: the fp32 oracle on the first two images (one host forward each, ~2 s), the
         # stated e4m3 tolerance (score band 0.12 = 1.5 x the bf16 band), >= 85 % of the reference's boxes paired, classes of
         # paired boxes exact, nothing unexplained.  max_det is lifted so that the cut at 300 does not create one-sided
-        # boxes of its own.  The synthetic head is dense at the threshold (cls_gain 8): the e4m3 program keeps ~1.9 x
-        # the reference's boxes, all of them within the band of conf -- hence the stated 0.6 cap on the explained share.
+        # boxes of its own.  Round 4: the head is calibrated to ~130 candidates per image (config5_target_frac; round 3's 1.5 %
+        # of 33 600 anchors cut every image at max_det), and the one-sided share is capped at 0.35 (was 0.6).
         from oracle import yolo11_oracle as oracle
 
         n_or = min(2, batch)
@@ -270,10 +298,21 @@ def short_config(scale, batch, imgsz, dtype, streams, steps, dev, conf=0.25, iou
         with torch.inference_mode():
             y32, _ = oracle.forward(sd, x8[:n_or].float().cpu() / 255.0, scale)
             ref = oracle.non_max_suppression(y32, conf, iou, max_det=gate_max_det)
+        y8 = eng.forward(x8, graph=False)[:n_or].float().cpu()  # the e4m3 program's own pre-NMS tensor (near-tied arg-maxes)
         g2 = parity_gate(ref, [o8g[i, : int(c8g[i])].cpu() for i in range(n_or)], conf, iou, band=0.12, min_matched_frac=0.85,
-                         ref_y=y32, max_explained_share=0.6)
+                         ref_y=y32, got_y=y8, max_explained_share=0.35)
         res["fp8_vs_fp32_oracle"] = dict({k: g2[k] for k in keys}, images=n_or, oracle_seconds=round(time.time() - t_or, 1),
                                          near_threshold=g2["near_threshold"], nms_flip=g2["nms_flip"])
+        # the FORMAT's own distance from fp32: the oracle with the same convs emulated in e4m3 on the CPU (no kernel involved);
+        # the HIP e4m3 program may be as far from the reference as that, and no farther (format_yardstick_ok)
+        from oracle.parity_gate import format_yardstick_ok
+
+        with torch.inference_mode():
+            y8e, _ = oracle.forward(sd, x8[:n_or].float().cpu() / 255.0, scale, storage="bf16", fp8_scales=eng.fp8_conv_scales())
+            det8e = oracle.non_max_suppression(y8e, conf, iou, max_det=gate_max_det)
+        g3 = parity_gate(ref, det8e, conf, iou, band=0.12, min_matched_frac=0.85, ref_y=y32, got_y=y8e, max_explained_share=0.35)
+        res["format_error_e4m3"] = {k: g3[k] for k in keys}
+        res["format_yardstick_e4m3"] = format_yardstick_ok(g2, g3, 0.12)
         del e16
     else:
         # bf16 configurations: the HIP detections of the first two images against the fp32 oracle (one host forward, a few
@@ -392,9 +431,10 @@ def main():
                          "hardware queue (GPU_MAX_HW_QUEUES = 20, set at the top of this file); sharded path: 8 queues, and 6, 7 and 8 batches "
                          "in flight are tried for min(--steps, 80) untimed steps each (a batch stream that has to share a queue with RCCL's "
                          "stream loses a third of the throughput)")
-    ap.add_argument("--cand-frac", type=float, default=0.015,
-                    help="fraction of anchors above conf 0.25 the synthetic class bias is calibrated to "
-                         "(0.015 = the bench's operating point; 0.05 = the NMS stress point of SURVEY 8d)")
+    ap.add_argument("--cand-frac", type=float, default=0.0,
+                    help="fraction of anchors above conf 0.25 the synthetic class bias is calibrated to; 0 (default) = ~126 "
+                         "candidates per image whatever the image size (config5_target_frac: 0.015 at 640x640, the bench's "
+                         "operating point; 0.05 = the NMS stress point of SURVEY 8d)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"],
                     help="fp8: dense 3x3 convs in OCP e4m3 (weights + activations, fp32 accumulate) on "
                          "v_mfma_f32_16x16x128_f8f6f4, everything else bf16 (BASELINE.json config 5)")
@@ -438,6 +478,8 @@ def main():
     conf, iou, max_det = 0.25, 0.7, 300
     # the same calibration batch on every rank (seed 0): the class bias, hence the weights, are identical replicas
     x = torch.rand(B, 3, H, W, generator=torch.Generator().manual_seed(0)).to(dev)
+    if args.cand_frac <= 0:
+        args.cand_frac = config5_target_frac(args.imgsz)
     specs, sd, eng = build_model(args.scale, dev, B, H, W, x, target_frac=args.cand_frac, fp8=args.dtype == "fp8")
     cfg_key = {"scale": args.scale, "imgsz": args.imgsz, "batch": B, "dtype": args.dtype}
 
@@ -747,7 +789,7 @@ def main():
                 nb8 = min(B, 8)
                 res["fp8_vs_bf16"] = parity_gate([o16[i, : int(c16[i])].cpu() for i in range(nb8)],
                                                  [o8[i, : int(c8[i])].cpu() for i in range(nb8)], conf, iou, band=0.15,
-                                                 min_matched_frac=0.75, max_explained_share=0.6)
+                                                 min_matched_frac=0.85, max_explained_share=0.35)
                 if l8 is not None:
                     l16 = e16.raw_levels()
                     res["fp8_vs_bf16"]["level_rel_l2"] = [round(float((a - b).norm() / b.norm()), 4) for a, b in zip(l8, l16)]

@@ -38,6 +38,15 @@ format, a CPU-only property measured in ``tests/test_oracle_golden.py`` against 
 (b) the kernels' own deviation (accumulation order, hardware exp / rcp), which the GPU tests bound tightly against
 this mode.  fp32 mode is the pinned one; bf16 mode differs from it ONLY by those roundings (and by folding the BN
 into the filters first, utils/torch_utils.py:182-209, as the product does).
+
+e4m3 emulation (``forward(..., storage="bf16", fp8_scales={conv name: input scale})``)
+--------------------------------------------------------------------------------------
+BASELINE.json config 5 runs the dense 3x3 convs in OCP e4m3 (csrc/conv_f8.hip).  For the convs named in ``fp8_scales`` the
+bf16-storage mode additionally rounds what that kernel rounds: the conv's INPUT to e4m3(x / scale) (saturating at 448, round to
+nearest even) with the calibrated per-tensor scale, and its BN-folded FILTER to e4m3 per output channel (scale = absmax / 448,
+conv_f8_pack_weights); the products and sums stay fp32, as on the matrix pipe.  It measures what the e4m3 FORMAT costs
+against the pinned fp32 mode, with no kernel involved -- the yardstick for the HIP e4m3 program (tests/test_gpu_fp8.py,
+bench.py ``format_error_e4m3``).
 """
 from __future__ import annotations
 
@@ -131,6 +140,13 @@ def plan(scale: str, nc: int = 80, ch: int = 3) -> List[dict]:
 
 # --------------------------------------------------------------------------- modules
 _STORAGE = ["fp32"]  # "fp32" (the pinned restatement) or "bf16" (storage emulation, see the module docstring)
+_FP8_SCALES: Dict[str, float] = {}  # bf16 mode only: convs emulated in e4m3 (name -> calibrated input scale)
+E4M3_MAX = 448.0
+
+
+def e4m3_round(t: torch.Tensor) -> torch.Tensor:
+    """Saturating round-to-nearest-even onto the OCP e4m3 grid (v_cvt_pk_fp8_f32 behind a clamp, csrc/conv_common.h pack_f8x4)."""
+    return t.float().clamp(-E4M3_MAX, E4M3_MAX).to(torch.float8_e4m3fn).float()
 
 
 def q_store(t: torch.Tensor) -> torch.Tensor:
@@ -150,6 +166,12 @@ def conv_bn_act(sd: Dict[str, torch.Tensor], p: str, x: torch.Tensor, k: int = 1
         # branch, whose depthwise convs run on the matrix pipe with bf16 taps (csrc/conv_mfma.hip dw_pack_mfma)
         if g == 1 or dw_taps_bf16:
             w = w.bfloat16().float()
+        if p in _FP8_SCALES and g == 1:  # an e4m3 conv of config 5: input and filter as csrc/conv_f8.hip sees them
+            sc = float(_FP8_SCALES[p])
+            x = e4m3_round(x / sc) * sc
+            m = w.abs().flatten(1).amax(1)
+            ws = torch.where(m > 0, m / E4M3_MAX, torch.ones_like(m)).view(-1, 1, 1, 1)
+            w = e4m3_round(w / ws) * ws
         y = F.conv2d(x, w, b, s, k // 2, 1, g)
         y = F.silu(y) if act else y
         return q_store(y if res is None else y + res)
@@ -299,20 +321,28 @@ def detect_decode(raw: List[torch.Tensor], strides: Sequence[float], nc: int = 8
 
 
 def forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, scale: str = "n", nc: int = 80,
-            strides: Sequence[float] = (8.0, 16.0, 32.0), return_layers: bool = False, storage: str = "fp32"):
+            strides: Sequence[float] = (8.0, 16.0, 32.0), return_layers: bool = False, storage: str = "fp32",
+            fp8_scales: Optional[Dict[str, float]] = None):
     """nn/tasks.py:118-145 BaseModel._predict_once over the 24 layers of yolo11.yaml.
 
     Returns (y[B, 4+nc, A], [raw level maps (B, 64+nc, H, W)]) like Detect.forward (head.py:59-69).
-    ``storage="bf16"``: the bf16-storage emulation described in the module docstring.
+    ``storage="bf16"``: the bf16-storage emulation described in the module docstring; with ``fp8_scales`` the named convs are
+    emulated in e4m3 on top of it.
     """
     if storage not in ("fp32", "bf16"):
         raise ValueError(storage)
-    prev = _STORAGE[0]
+    if fp8_scales and storage != "bf16":
+        raise ValueError("the e4m3 emulation sits on top of the bf16-storage mode")
+    prev, prev8 = _STORAGE[0], dict(_FP8_SCALES)
     _STORAGE[0] = storage
+    _FP8_SCALES.clear()
+    _FP8_SCALES.update(fp8_scales or {})
     try:
         return _forward(sd, q_store(x), scale, nc, strides, return_layers)
     finally:
         _STORAGE[0] = prev
+        _FP8_SCALES.clear()
+        _FP8_SCALES.update(prev8)
 
 
 def _forward(sd, x, scale, nc, strides, return_layers):

@@ -149,6 +149,10 @@ class HipEngine:
                 scales[o["name"]] = max(m, 1e-6) * headroom / 448.0
         return scales
 
+    def fp8_conv_scales(self) -> Dict[str, float]:
+        """{conv name: input scale} of the convs THIS program runs in e4m3 (empty for a bf16 program)."""
+        return {o["name"]: float(o["in_scale"]) for o in self.prog.ops if o["kind"] == 1 and o["inp"].dtype == FP8}
+
     def __del__(self):
         h = getattr(self, "_h", None)
         if h:
