@@ -575,3 +575,35 @@ def test_view_above_one_gib_fails_loudly(gpu_device):
          weight=np.zeros((16, 8, 1, 1), np.float32), bias=np.zeros(16, np.float32))
     with pytest.raises(RuntimeError, match="1 GiB"):
         m.run()
+
+
+@pytest.mark.parametrize("B,H,W", [(3, 40, 40), (2, 24, 40), (2, 32, 32), (1, 38, 26), (2, 48, 80)])
+def test_conv3_band_vs_conv_kernel(gpu_device, monkeypatch, B, H, W):
+    """conv3_band_kernel (csrc/conv3_band.hip: a band of rows per workgroup, input in LDS, filter streamed from L2) on the pair
+    Detect runs it on -- 128 -> 64 on an H x W map and 256 -> 64 on the H/2 x W/2 map (head.py:36-40) -- against the same two
+    convs on conv_kernel: every bit; and against torch fp32."""
+    gen = torch.Generator().manual_seed(H * 100 + W)
+    shapes = [(128, H, W), (256, H // 2, W // 2)]
+    xs = [bf16_round(torch.randn(B, c, h, w, generator=gen)) for c, h, w in shapes]
+    ws = [bf16_round(torch.randn(64, c, 3, 3, generator=gen) / (c * 9) ** 0.5 * 1.5) for c, _, _ in shapes]
+    bs = [torch.randn(64, generator=gen) * 0.3 for _ in shapes]
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("YL_CONV_BAND", mode)
+        m = Mini(B, gpu_device)
+        outs = []
+        for (c, h, w), x, wt, b in zip(shapes, xs, ws, bs):
+            xin, y = m.buf(h, w, c), m.buf(h, w, 64)
+            m.fill(xin, x)
+            m.op(kind=OP_CONV, name=f"c{c}", k=3, stride=1, act=1, inp=xin, out=y, group=1,
+                 weight=np.ascontiguousarray(wt.numpy()), bias=np.ascontiguousarray(b.numpy()))
+            outs.append(y)
+        m.run()
+        kern = m.eng.op_kernel(0)
+        assert kern == ("conv3x3_band_mfma[x2]" if mode == "1" else "conv3x3_mfma[x2]"), kern
+        got[mode] = [m.read(y) for y in outs]
+    for a, b in zip(got["1"], got["0"]):
+        assert torch.equal(a, b), float((a - b).abs().max())
+    for y, x, wt, b in zip(got["1"], xs, ws, bs):
+        ref = F.silu(F.conv2d(x, wt, b, padding=1))
+        assert float((y - ref).abs().max()) <= 0.02 * float(ref.abs().max()) + 0.02

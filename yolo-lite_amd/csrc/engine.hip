@@ -68,6 +68,7 @@ struct OpRec {
   bool f8 = false;
   int cls_level = -1;  // fused depthwise + pointwise + 1x1 that writes the class logits of this Detect level (else -1)
   int group_n = 0;  // group launch (yl_op.group): 2 or 3 on the first member, -1 on the others (run with it), 0 = on its own
+  bool band = false;  // (first member of a group) the group runs on conv3_band_kernel: deep-K 3x3 convs, 64 output channels
   double flops = 0, bytes = 0;
   const char* name = "";
 };
@@ -710,6 +711,26 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
       if (ok && nc && nd)  // mixed launch: the convs carry a fused 1x1 exactly when the depthwise members carry a tail
         ok = (e->ops[i].cfg.post != 0) == (e->ops[i + nc].d_wpk3 != nullptr);
       if (ok && !nc && !e->ops[i].d_wpk3) ok = false;  // (a depthwise-only group exists for the tailed form only)
+      // Two plain convs with a deep K and 64 output channels on small maps (Detect's first box convs on the 40x40 and 20x20 levels,
+      // 128 -> 64 and 256 -> 64): conv3_band_kernel -- the input band in LDS, the filter streamed from L2 -- instead of
+      // conv_group_kernel, which restages the 144 / 288 KB filters per 256 pixels (YL_CONV_BAND=0: off)
+      const int band_on = getenv("YL_CONV_BAND") ? atoi(getenv("YL_CONV_BAND")) : 1;  // (read at every engine build: tests switch it)
+      bool band = ok && band_on && nc == 2 && nd == 0 && !e->ops[i].cfg.post;
+      for (size_t k = i; k < j && band; ++k) {
+        const OpRec& r = e->ops[k];
+        band = r.cfg.MT == 4 && r.cfg.ncb == 1 && !r.cfg.kord && r.op.act && r.op.out.C == 64 &&
+               r.op.in.C == (k == i ? 128 : 256) && r.op.in.H == r.op.out.H && r.op.in.W == r.op.out.W &&
+               conv3_band_plan(r.op.in.C, 64, r.op.out.H, r.op.out.W, nullptr);
+      }
+      if (band) {
+        for (size_t k = i; k < j; ++k) {
+          OpRec& r = e->ops[k];
+          r.group_n = k == i ? n : -1;
+          r.band = k == i;
+          r.name = k == i ? "conv3x3_band_mfma[x2]" : "(in the group launch)";
+        }
+        ok = false;  // (handled)
+      }
       if (ok) {
         // one pixel-tile count per kind: the largest member's choice (it has most of the workgroups)
         auto largest = [&](size_t k0, size_t k1) {
@@ -1078,6 +1099,32 @@ static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s, c
 // and / or the independent branches of the head (head.py:61), one launch for all of them (conv_group_kernel /
 // dwpw_group_kernel / head_group_kernel).
 static int run_group(const yl_engine* e, size_t i, int n, char* ws, hipStream_t s, const PrefilterSink* sink) {
+  if (e->ops[i].band) {
+    BandArgs ba[2]{};
+    for (int k = 0; k < n && k < 2; ++k) {
+      const OpRec& r = e->ops[i + k];
+      const yl_op& o = r.op;
+      const Geo gq = geo_of(e->batch, o.out.H, o.out.W);
+      BandArgs& q = ba[k];
+      q.x = pview(ws, o.in, e->batch).base;
+      q.y = pview(ws, o.out, e->batch).base;
+      q.x_plane = q.y_plane = (unsigned)plane_bytes(gq);
+      const long long ib = (long long)(o.in.C / 8) * plane_bytes(gq), ob = (long long)(o.out.C / 8) * plane_bytes(gq);
+      if (ib > (1LL << 30) || ob > (1LL << 30)) return fail(-3, "conv3_band: a tensor slice exceeds 1 GiB; lower the batch size");
+      q.x_bytes = (unsigned)ib;
+      q.y_bytes = (unsigned)ob;
+      q.H = o.out.H;
+      q.W = o.out.W;
+      q.W1 = gq.W1;
+      q.img = gq.img;
+      q.g0 = gq.g0;
+      q.Cin = o.in.C;
+      q.act = o.act;
+      q.w = r.d_wpk;
+      q.bias = r.d_bias;
+    }
+    return conv3_band_launch(ba, n, e->batch, s);
+  }
   ConvArgs ca[3]{}, da[3]{};
   ConvConfig cc[3], dc[3];
   int nc = 0, nd = 0;

@@ -27,7 +27,7 @@
 // Arithmetic is conv_kernel's: the same packed filters, k order (tap-major, 32 channels per k-step), fp32 accumulation
 // chain starting from the bias, SiLU (silu_f), residual add after the activation, one rounding to bf16 per layer --
 // results are BIT-IDENTICAL to the six launches (tests/test_gpu_resident.py).
-#include "conv_common.h"
+#include "lds_conv.h"
 
 namespace yl {
 
@@ -35,13 +35,6 @@ typedef __attribute__((address_space(3))) void lds_void_r;
 
 constexpr int RC_THREADS = 512;
 constexpr int RC_WAVES = RC_THREADS / 64;
-
-// first tile / tile count of part `i` of `parts` when `ntiles` are dealt as evenly as possible (the first ntiles % parts get one more)
-__device__ __forceinline__ void even_split(int ntiles, int parts, int i, int& t0, int& cnt) {
-  const int base = ntiles / parts, rem = ntiles - base * parts;
-  t0 = i * base + (i < rem ? i : rem);
-  cnt = base + (i < rem ? 1 : 0);
-}
 
 struct PixMap {
   int H, W, W1, HW;
@@ -56,44 +49,6 @@ __device__ __forceinline__ int guarded_index(const PixMap& m, int i, bool& valid
 
 // ---- one 3x3 conv 64 -> 64 from a guarded LDS map: this wave's M-half (tiles 2 mh, 2 mh + 1 of the 4-tile filter block) x NT
 // pixel tiles.  src: LDS region + this lane's k-group plane (g * apl).  tb[nt]: byte offset of the lane's pixel in a plane.
-constexpr int RC_D = 3;  // k-steps of filter fragments in flight per wave (3x3 steps)
-
-// the first RC_D k-steps of a 3x3 filter (this wave's two tiles): issued BEFORE the barrier in front of the step
-__device__ __forceinline__ void preload3(bf16x8 (&wa)[RC_D][2], const bf16x8* __restrict__ wp) {
-#pragma unroll
-  for (int d = 0; d < RC_D; ++d)
-#pragma unroll
-    for (int m = 0; m < 2; ++m) wa[d][m] = wp[(d * 4 + m) * 64];
-}
-
-template <int NT>
-__device__ __forceinline__ void conv3_from_lds(f32x4 (&acc)[2][NT], bf16x8 (&wa)[RC_D][2], const bf16x8* __restrict__ wp,
-                                               const unsigned char* src, const unsigned (&tb)[NT], int W1, int apl) {
-  constexpr int NKS = 18, KKN = 2, D = RC_D;
-  bf16x8 xb[2][NT];
-  auto load_b = [&](int ks, bf16x8 (&dst)[NT]) __attribute__((always_inline)) {
-    const int tap = ks / KKN, kk = ks - tap * KKN;
-    const int kh = tap / 3, kw = tap - 3 * kh;
-    const int off = ((kh - 1) * W1 + (kw - 1)) * 16 + kk * 4 * apl;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) dst[nt] = *reinterpret_cast<const bf16x8*>(src + (int)tb[nt] + off);
-  };
-  load_b(0, xb[0]);
-#pragma unroll
-  for (int ks = 0; ks < NKS; ++ks) {
-    if (ks + 1 < NKS) load_b(ks + 1, xb[(ks + 1) & 1]);
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-        acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ks % D][m], xb[ks & 1][nt], acc[m][nt], 0, 0, 0);
-    if (ks + D < NKS) {
-#pragma unroll
-      for (int m = 0; m < 2; ++m) wa[ks % D][m] = wp[((ks + D) * 4 + m) * 64];
-    }
-  }
-}
-
 // A 3x3 step for this wave: acc = bias; conv from `src` map; SiLU; optional residual from map `res` (same plane / pixel the lane
 // writes); bf16; 16-byte LDS store into map `dst`.
 template <int NT, int NTQ>
@@ -331,7 +286,7 @@ __global__ __launch_bounds__(RC_THREADS) void c3k_resident_kernel(C3kArgs a) {
   if (tecnt == NTE) step_in<NTE, NTE>(a, pm, rsm, te0, n, g, lane, breg, wa1);
   else if (NTE > 1 && tecnt == NTE - 1) step_in<(NTE > 1 ? NTE - 1 : 1), NTE>(a, pm, rsm, te0, n, g, lane, breg, wa1);
   bf16x8 wa[RC_D][2];
-  preload3(wa, reinterpret_cast<const bf16x8*>(a.w[1]) + (2 * mh) * 64 + lane);
+  preload3<RC_D>(wa, reinterpret_cast<const bf16x8*>(a.w[1]) + (2 * mh) * 64 + lane);
   RC_STAMP(3);
   __syncthreads();  // everybody is done with x
   RC_STAMP(4);
@@ -358,7 +313,7 @@ __global__ __launch_bounds__(RC_THREADS) void c3k_resident_kernel(C3kArgs a) {
 #pragma unroll 1
   for (int s = 0; s < 3; ++s) {
     run3(s);
-    preload3(wa, reinterpret_cast<const bf16x8*>(a.w[2 + s]) + (2 * mh) * 64 + lane);
+    preload3<RC_D>(wa, reinterpret_cast<const bf16x8*>(a.w[2 + s]) + (2 * mh) * 64 + lane);
     RC_STAMP(6 + 2 * s);
     __syncthreads();
     RC_STAMP(7 + 2 * s);

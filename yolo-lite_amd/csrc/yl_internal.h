@@ -319,6 +319,22 @@ struct C3kArgs {
 bool c3k_resident_fits(int c_, int H, int W);
 int c3k_resident_launch(C3kArgs a, hipStream_t s);
 
+// conv3_band.hip: 3x3 stride-1 conv, 64 output channels, 64 / 128 / 256 input channels, a band of rows per workgroup with its
+// input in LDS and the filter streamed from L2 (Detect's first box convs on the small levels)
+struct BandArgs {
+  const __bf16* x;
+  __bf16* y;
+  unsigned x_plane, y_plane, x_bytes, y_bytes;
+  int H, W, W1, img, g0;  // guarded geometry (input and output share it)
+  int Cin, act;
+  const __bf16* w;        // conv_pack_weights order, one block of four tiles: [k-step][4][64 lanes][8]
+  const float* bias;      // padded to 64
+  int TR, nbands, ntiles, tpl;  // filled by conv3_band_launch: rows per band, bands per image, 16-pixel tiles per band, LDS bytes per plane
+  unsigned long long* stamps;   // diagnostic builds (-DYL_STAMPS)
+};
+bool conv3_band_plan(int Cin, int Cout, int H, int W, BandArgs* a);
+int conv3_band_launch(const BandArgs* args, int n, int batch, hipStream_t s);
+
 struct DecodeLevel {
   PView box;     // 8 planes: DFL logits (head.py:64 cv2)
   PView cls;     // nc8 / 8 planes: class logits (cv3); padding channels hold large negative values
