@@ -607,3 +607,40 @@ def test_conv3_band_vs_conv_kernel(gpu_device, monkeypatch, B, H, W):
     for y, x, wt, b in zip(got["1"], xs, ws, bs):
         ref = F.silu(F.conv2d(x, wt, b, padding=1))
         assert float((y - ref).abs().max()) <= 0.02 * float(ref.abs().max()) + 0.02
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 80, 80), (1, 48, 80), (2, 64, 104)])
+def test_conv3_band64_with_follow_up_vs_conv_kernel(gpu_device, monkeypatch, B, H, W):
+    """conv3_band64_kernel (opt-in, YL_CONV_BAND64=1): the three Detect levels' 64 -> 64 3x3 convs with the 1x1 conv 64 -> 64
+    behind each fused into the launch (head.py:36-40 cv2[i][1], cv2[i][2]) against conv_kernel's form of the same group: every
+    bit; and against torch."""
+    monkeypatch.setenv("YL_CONV_BAND64", "1")
+    gen = torch.Generator().manual_seed(H * 7 + W)
+    dims = [(H, W), (H // 2, W // 2), (H // 4, W // 4)]
+    xs = [bf16_round(torch.randn(B, 64, h, w, generator=gen)) for h, w in dims]
+    w1 = [bf16_round(torch.randn(64, 64, 3, 3, generator=gen) / 24 * 1.5) for _ in dims]
+    b1 = [torch.randn(64, generator=gen) * 0.3 for _ in dims]
+    w2 = [bf16_round(torch.randn(64, 64, 1, 1, generator=gen) / 8) for _ in dims]
+    b2 = [torch.randn(64, generator=gen) * 0.3 for _ in dims]
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("YL_CONV_BAND", mode)
+        m = Mini(B, gpu_device)
+        outs = []
+        for (h, w), x, wa, ba, wb, bb in zip(dims, xs, w1, b1, w2, b2):
+            xin, y = m.buf(h, w, 64), m.buf(h, w, 64)
+            m.fill(xin, x)
+            m.op(kind=OP_CONV, name=f"l{h}", k=3, stride=1, act=1, inp=xin, out=y, group=2, weight=np.ascontiguousarray(wa.numpy()),
+                 bias=np.ascontiguousarray(ba.numpy()), post_weight=np.ascontiguousarray(wb.numpy().reshape(64, 64)),
+                 post_bias=np.ascontiguousarray(bb.numpy()), post_act=0)
+            outs.append(y)
+        m.run()
+        kern = m.eng.op_kernel(0)
+        assert kern == ("conv3x3+1x1_band_mfma[x3]" if mode == "1" else "conv3x3+1x1_mfma[x3]"), kern
+        got[mode] = [m.read(y) for y in outs]
+    for a, b in zip(got["1"], got["0"]):
+        assert torch.equal(a, b), float((a - b).abs().max())
+    for y, x, wa, ba, wb, bb in zip(got["1"], xs, w1, b1, w2, b2):
+        mid = bf16_round(F.silu(F.conv2d(x, wa, ba, padding=1)))
+        ref = F.conv2d(mid, wb, bb)
+        assert float((y - ref).abs().max()) <= 0.02 * float(ref.abs().max()) + 0.03

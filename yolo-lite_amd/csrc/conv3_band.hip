@@ -20,6 +20,13 @@
 namespace yl {
 
 constexpr int BD_THREADS = 512;
+#ifndef YL_BAND_SCHED
+#define YL_BAND_SCHED 0  // 1: one LDS read pinned behind every MFMA (sched_group_barrier): 128 -> 64 @40x40 9.2 -> 8.5 us, 256 -> 64 @20x20 9.9 -> 10.1 us
+#endif
+#ifndef YL_BAND_ABL
+#define YL_BAND_ABL 0  // development build switch: timing ablations of the k-loop (wrong results): 1 no barrier, 2 no ring refill, 4 no
+                      // filter-fragment reads, 8 no activation-fragment reads, 16 no counted wait
+#endif
 
 // LDS bytes per plane of the band tile: rows y0 - 1 .. y0 + TR of W1 pixels (+ the pixel in front of the first row and one
 // behind the last), rounded to 16 pixels (plane pitch a multiple of 256 bytes: conflict-free ds_read_b128)
@@ -37,7 +44,10 @@ __device__ __forceinline__ void ring_issue(__amdgpu_buffer_rsrc_t rw, unsigned c
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_b*)(ring + (sl % BD_NS) * BD_SLICE + wave * 1024), 16, (int)off, 0, 0, 0);
 }
 
-template <int KKN, int NT>
+// POST: a 1x1 conv 64 -> 64 that consumes ONLY this conv's output (Detect's cv2[i][1] -> cv2[i][2], head.py:36-40) runs behind it
+// in the same launch: the 3x3 conv's output tile goes to LDS (bf16, dense planes = B-fragment order), one workgroup barrier,
+// two k-steps from there; that tensor is never stored.  Same arithmetic as conv_kernel's POST epilogue.
+template <int KKN, int NT, bool POST = false>
 __device__ __forceinline__ void band_compute(const BandArgs& a, unsigned char* lds, unsigned char* ring, __amdgpu_buffer_rsrc_t rw, int b,
                                              int y0, int mh, int t0, int n, int g, int lane, int wave) {
   const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)a.y, (short)0, a.y_bytes, 0x00020000);
@@ -88,10 +98,10 @@ __device__ __forceinline__ void band_compute(const BandArgs& a, unsigned char* l
     // my own piece of slice sl + 1 has landed (the younger ones stay in flight); after the barrier everybody's has, and
     // nobody reads slice sl - 1 any more (its fragments were consumed by the MFMAs of the previous iteration): its buffer takes
     // slice sl + BD_NS - 1
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BD_NS - 3) : "memory");
-    __builtin_amdgcn_s_barrier();
-    ring_issue(rw, ring, sl + BD_NS - 1, NSL, wave, lane);
-    if (sl + 1 < NSL) load_a(sl + 1, wa[(sl + 1) & 1]);
+    if (!(YL_BAND_ABL & 16)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BD_NS - 3) : "memory");
+    if (!(YL_BAND_ABL & 1)) __builtin_amdgcn_s_barrier();
+    if (!(YL_BAND_ABL & 2)) ring_issue(rw, ring, sl + BD_NS - 1, NSL, wave, lane);
+    if (sl + 1 < NSL && !(YL_BAND_ABL & 4)) load_a(sl + 1, wa[(sl + 1) & 1]);
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
@@ -99,17 +109,63 @@ __device__ __forceinline__ void band_compute(const BandArgs& a, unsigned char* l
 #pragma unroll
         for (int m = 0; m < 2; ++m)
           acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[sl & 1][kk][m], xb[kk][nt], acc[m][nt], 0, 0, 0);
-      if (2 * sl + 2 + kk < NKS) load_b(2 * sl + 2 + kk, xb[kk]);
+      if (2 * sl + 2 + kk < NKS && !(YL_BAND_ABL & 8)) load_b(2 * sl + 2 + kk, xb[kk]);
     }
+#if YL_BAND_SCHED
+    // pin the interleave: one LDS read (of the NEXT slice's fragments) behind every MFMA, so that the reads are issued in the
+    // shadow of the matrix pipe instead of in a block of their own (the two waves of a SIMD run this loop in lockstep)
+#pragma unroll
+    for (int q = 0; q < 4 * NT; ++q) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // one DS read
+    }
+#endif
   }
   YL_STAMP(a.stamps, 8, wave, lane, 3);
+  if constexpr (POST) {
+    unsigned char* const mid = ring + BD_NS * BD_SLICE;  // [8 planes][ntiles * 16 px][16 B]
+    const int mpl = a.ntiles * 256;
+    // the follow-up filter's fragments (two k-steps x this wave's two tiles) are on their way while the tile is written
+    bf16x8 w2[2][2];
+    const bf16x8* wp2 = reinterpret_cast<const bf16x8*>(a.w2) + (2 * mh) * 64 + lane;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) w2[ks][m] = wp2[(ks * 4 + m) * 64];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      bf16x8 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        o[r] = (__bf16)(a.act ? silu_f(acc[0][nt][r]) : acc[0][nt][r]);
+        o[4 + r] = (__bf16)(a.act ? silu_f(acc[1][nt][r]) : acc[1][nt][r]);
+      }
+      *reinterpret_cast<bf16x8*>(mid + (mh * 4 + g) * mpl + ((t0 + nt) * 16 + n) * 16) = o;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(a.bias2 + chan_in_block(4, 2 * mh + m, g, 0));
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[m][nt] = bv;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const bf16x8 xm = *reinterpret_cast<const bf16x8*>(mid + (ks * 4 + g) * mpl + ((t0 + nt) * 16 + n) * 16);
+#pragma unroll
+        for (int m = 0; m < 2; ++m) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2[ks][m], xm, acc[m][nt], 0, 0, 0);
+      }
+  }
+  const bool act_out = POST ? a.post_act != 0 : a.act != 0;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     float v[8];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      v[r] = a.act ? silu_f(acc[0][nt][r]) : acc[0][nt][r];
-      v[4 + r] = a.act ? silu_f(acc[1][nt][r]) : acc[1][nt][r];
+      v[r] = act_out ? silu_f(acc[0][nt][r]) : acc[0][nt][r];
+      v[4 + r] = act_out ? silu_f(acc[1][nt][r]) : acc[1][nt][r];
     }
     __builtin_amdgcn_raw_buffer_store_b128(
         u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])}, rout,
@@ -118,7 +174,8 @@ __device__ __forceinline__ void band_compute(const BandArgs& a, unsigned char* l
 }
 
 // KKN = input channels / 32; NTQ = ceil(tiles per band / 4): tiles of the largest pixel quarter (the others have NTQ or NTQ - 1)
-template <int KKN, int NTQ>
+// NTQ == 0: the tile count of this wave is dispatched at run time over 1 .. 5 (the 64-channel members: short k-loops, small code)
+template <int KKN, int NTQ, bool POST = false>
 __device__ __forceinline__ void band_body(const BandArgs& a, int block) {
   extern __shared__ __attribute__((aligned(16))) unsigned char bsm[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -161,8 +218,18 @@ __device__ __forceinline__ void band_body(const BandArgs& a, int block) {
   int t0, cnt;
   even_split(a.ntiles, 4, wave >> 1, t0, cnt);
   // (every wave takes part in the ring's barriers: a wave without tiles still runs the loop shell)
-  if (cnt == NTQ) band_compute<KKN, NTQ>(a, bsm, ring, rw, b, y0, mh, t0, n, g, lane, wave);
-  else band_compute<KKN, (NTQ > 1 ? NTQ - 1 : 1)>(a, bsm, ring, rw, b, y0, mh, t0, n, g, lane, wave);
+  if constexpr (NTQ == 0) {
+    switch (cnt) {
+      case 5: band_compute<KKN, 5, POST>(a, bsm, ring, rw, b, y0, mh, t0, n, g, lane, wave); break;
+      case 4: band_compute<KKN, 4, POST>(a, bsm, ring, rw, b, y0, mh, t0, n, g, lane, wave); break;
+      case 3: band_compute<KKN, 3, POST>(a, bsm, ring, rw, b, y0, mh, t0, n, g, lane, wave); break;
+      case 2: band_compute<KKN, 2, POST>(a, bsm, ring, rw, b, y0, mh, t0, n, g, lane, wave); break;
+      default: band_compute<KKN, 1, POST>(a, bsm, ring, rw, b, y0, mh, t0, n, g, lane, wave); break;
+    }
+  } else {
+    if (cnt == NTQ) band_compute<KKN, (NTQ > 0 ? NTQ : 1), POST>(a, bsm, ring, rw, b, y0, mh, t0, n, g, lane, wave);
+    else band_compute<KKN, (NTQ > 1 ? NTQ - 1 : 1), POST>(a, bsm, ring, rw, b, y0, mh, t0, n, g, lane, wave);
+  }
   YL_STAMP(a.stamps, 8, wave, lane, 4);
 }
 
@@ -178,14 +245,34 @@ __global__ __launch_bounds__(BD_THREADS) void conv3_band_kernel(BandGroup G) {
   else band_body<KB, NB>(G.m[1], block - G.nb0);
 }
 
+// Up to three 64 -> 64 convs (the Detect levels' copies of cv2[i][1] + cv2[i][2]) in one launch
+struct BandGroup3 {
+  BandArgs m[3];
+  int nb[3];
+};
+
+template <bool POST>
+__global__ __launch_bounds__(BD_THREADS) void conv3_band64_kernel(BandGroup3 G) {
+  int block = blockIdx.x, mi = 0;
+  if (block >= G.nb[0]) {
+    block -= G.nb[0];
+    mi = 1;
+    if (block >= G.nb[1]) {
+      block -= G.nb[1];
+      mi = 2;
+    }
+  }
+  band_body<2, 0, POST>(G.m[mi], block);
+}
+
 // Tiling of one member: the largest band (rows) whose pixel tiles fit NTQ <= 5 per wave quarter and whose input fits the LDS budget
-bool conv3_band_plan(int Cin, int Cout, int H, int W, BandArgs* a) {
+bool conv3_band_plan(int Cin, int Cout, int H, int W, BandArgs* a, bool post) {
   if (Cout != 64 || (Cin != 64 && Cin != 128 && Cin != 256)) return false;
   const int planes = Cin / 8;
   int best = 0;
   for (int TR = 1; TR <= H; ++TR) {
     const int ntiles = (TR * W + 15) / 16;
-    if (ntiles > 20 || (size_t)planes * band_tpl(TR, W) + (size_t)BD_NS * BD_SLICE > 160 * 1024) break;
+    if (ntiles > 20 || (size_t)planes * band_tpl(TR, W) + (size_t)BD_NS * BD_SLICE + (post ? (size_t)8 * ntiles * 256 : 0) > 160 * 1024) break;
     best = TR;
   }
   if (best < 1) return false;
@@ -193,7 +280,7 @@ bool conv3_band_plan(int Cin, int Cout, int H, int W, BandArgs* a) {
   const int nbands = (H + best - 1) / best;
   const int TR = (H + nbands - 1) / nbands;
   const int ntiles = (TR * W + 15) / 16, ntq = (ntiles + 3) / 4;
-  if (ntq < 2 || ntq > 5) return false;  // (the instantiated tile counts)
+  if (ntq < 2 || ntq > 5) return false;  // (the instantiated tile counts; at least one tile per wave)
   if (a) {
     a->TR = TR;
     a->nbands = nbands;
@@ -221,7 +308,7 @@ int conv3_band_launch(const BandArgs* args, int n, int batch, hipStream_t s) {
   for (int i = 0; i < n; ++i) {
     G.m[i] = args[i];
     G.m[i].stamps = g_stamp_buf;
-    if (!conv3_band_plan(args[i].Cin, 64, args[i].H, args[i].W, &G.m[i])) return fail(-3, "conv3_band: member does not fit the band tiling");
+    if (!conv3_band_plan(args[i].Cin, 64, args[i].H, args[i].W, &G.m[i], false)) return fail(-3, "conv3_band: member does not fit the band tiling");
     kk[i] = args[i].Cin / 32;
     nq[i] = (G.m[i].ntiles + 3) / 4;
     const size_t l = (size_t)(args[i].Cin / 8) * G.m[i].tpl + (size_t)BD_NS * BD_SLICE;
@@ -243,6 +330,36 @@ int conv3_band_launch(const BandArgs* args, int n, int batch, hipStream_t s) {
 #undef YL_BAND_ROW
 #undef YL_BAND_CASE
   return fail(-3, "conv3_band: unsupported member tiling");
+}
+
+// one to three 64 -> 64 convs, each with (post != 0: all of them) or without a fused follow-up 1x1 conv 64 -> 64
+int conv3_band64_launch(const BandArgs* args, int n, int batch, int post, hipStream_t s) {
+  if (n < 1 || n > 3) return fail(-1, "conv3_band64: one to three members");
+  BandGroup3 G{};
+  size_t lds = 0;
+  int grid = 0;
+  for (int i = 0; i < n; ++i) {
+    G.m[i] = args[i];
+    G.m[i].stamps = g_stamp_buf;
+    if (args[i].Cin != 64 || !conv3_band_plan(64, 64, args[i].H, args[i].W, &G.m[i], post != 0))
+      return fail(-3, "conv3_band64: member does not fit the band tiling");
+    if (post && (!args[i].w2 || !args[i].bias2)) return fail(-1, "conv3_band64: follow-up filter missing");
+    const size_t l = (size_t)8 * G.m[i].tpl + (size_t)BD_NS * BD_SLICE + (post ? (size_t)8 * G.m[i].ntiles * 256 : 0);
+    lds = l > lds ? l : lds;
+    G.nb[i] = batch * G.m[i].nbands;
+    grid += G.nb[i];
+  }
+  if (post) {
+    auto kern = conv3_band64_kernel<true>;
+    if (int rc = allow_big_lds(reinterpret_cast<const void*>(kern), 160 * 1024)) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BD_THREADS), lds, s, G);
+  } else {
+    auto kern = conv3_band64_kernel<false>;
+    if (int rc = allow_big_lds(reinterpret_cast<const void*>(kern), 160 * 1024)) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BD_THREADS), lds, s, G);
+  }
+  YL_HIP(hipGetLastError());
+  return 0;
 }
 
 }  // namespace yl

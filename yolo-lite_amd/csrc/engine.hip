@@ -69,6 +69,7 @@ struct OpRec {
   int cls_level = -1;  // fused depthwise + pointwise + 1x1 that writes the class logits of this Detect level (else -1)
   int group_n = 0;  // group launch (yl_op.group): 2 or 3 on the first member, -1 on the others (run with it), 0 = on its own
   bool band = false;  // (first member of a group) the group runs on conv3_band_kernel: deep-K 3x3 convs, 64 output channels
+  bool band64 = false;  // ... on conv3_band64_kernel: 64 -> 64 3x3 convs with a fused follow-up 1x1 (the levels' cv2[i][1] + cv2[i][2])
   double flops = 0, bytes = 0;
   const char* name = "";
 };
@@ -731,6 +732,27 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
         }
         ok = false;  // (handled)
       }
+      // The levels' 64 -> 64 3x3 convs with their fused follow-up 1x1 (cv2[i][1] + cv2[i][2]) on conv3_band64_kernel: OPT-IN
+      // (YL_CONV_BAND64=1).  Bit-identical, but not faster: 58.6 against 59.9 us in sequence and 53.5 k against 54.1 k images/s
+      // with 20 batches in flight -- with 18 k-steps a band's k-loop (4.6 us) is shorter than what surrounds it (input
+      // staging 2.8 us, epilogue + 1x1 + stores 2.5 us), and a 152 KB workgroup owns its CU, so nothing overlaps those phases.
+      const int band64_on = getenv("YL_CONV_BAND64") ? atoi(getenv("YL_CONV_BAND64")) : 0;
+      bool band64 = ok && band_on && band64_on && nc >= 2 && nd == 0 && e->ops[i].cfg.post;
+      for (size_t k = i; k < j && band64; ++k) {
+        const OpRec& r = e->ops[k];
+        band64 = r.cfg.MT == 4 && r.cfg.ncb == 1 && !r.cfg.kord && r.op.in.C == 64 && r.op.post_cin == 64 && r.op.out.C == 64 && r.d_wpk2 &&
+                 r.op.in.H == r.op.out.H && r.op.in.W == r.op.out.W && conv3_band_plan(64, 64, r.op.out.H, r.op.out.W, nullptr, true);
+      }
+      if (band64) {
+        static const char* const bn[3] = {"conv3x3+1x1_band_mfma[x1]", "conv3x3+1x1_band_mfma[x2]", "conv3x3+1x1_band_mfma[x3]"};
+        for (size_t k = i; k < j; ++k) {
+          OpRec& r = e->ops[k];
+          r.group_n = k == i ? n : -1;
+          r.band64 = k == i;
+          r.name = k == i ? bn[n - 1] : "(in the group launch)";
+        }
+        ok = false;  // (handled)
+      }
       if (ok) {
         // one pixel-tile count per kind: the largest member's choice (it has most of the workgroups)
         auto largest = [&](size_t k0, size_t k1) {
@@ -1099,9 +1121,9 @@ static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s, c
 // and / or the independent branches of the head (head.py:61), one launch for all of them (conv_group_kernel /
 // dwpw_group_kernel / head_group_kernel).
 static int run_group(const yl_engine* e, size_t i, int n, char* ws, hipStream_t s, const PrefilterSink* sink) {
-  if (e->ops[i].band) {
-    BandArgs ba[2]{};
-    for (int k = 0; k < n && k < 2; ++k) {
+  if (e->ops[i].band || e->ops[i].band64) {
+    BandArgs ba[3]{};
+    for (int k = 0; k < n && k < 3; ++k) {
       const OpRec& r = e->ops[i + k];
       const yl_op& o = r.op;
       const Geo gq = geo_of(e->batch, o.out.H, o.out.W);
@@ -1122,7 +1144,11 @@ static int run_group(const yl_engine* e, size_t i, int n, char* ws, hipStream_t 
       q.act = o.act;
       q.w = r.d_wpk;
       q.bias = r.d_bias;
+      q.w2 = r.d_wpk2;
+      q.bias2 = r.d_bias2;
+      q.post_act = o.post_act;
     }
+    if (e->ops[i].band64) return conv3_band64_launch(ba, n, e->batch, 1, s);
     return conv3_band_launch(ba, n, e->batch, s);
   }
   ConvArgs ca[3]{}, da[3]{};

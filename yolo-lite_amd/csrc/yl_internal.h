@@ -331,9 +331,15 @@ struct BandArgs {
   const float* bias;      // padded to 64
   int TR, nbands, ntiles, tpl;  // filled by conv3_band_launch: rows per band, bands per image, 16-pixel tiles per band, LDS bytes per plane
   unsigned long long* stamps;   // diagnostic builds (-DYL_STAMPS)
+  // conv3_band64_kernel with a fused follow-up 1x1 conv 64 -> 64 (conv_kernel's POST): its filter ([2 k-steps][4 tiles][64 lanes][8]),
+  // bias (padded to 64) and activation flag; `y` is then the follow-up conv's output
+  const __bf16* w2;
+  const float* bias2;
+  int post_act;
 };
-bool conv3_band_plan(int Cin, int Cout, int H, int W, BandArgs* a);
+bool conv3_band_plan(int Cin, int Cout, int H, int W, BandArgs* a, bool post = false);
 int conv3_band_launch(const BandArgs* args, int n, int batch, hipStream_t s);
+int conv3_band64_launch(const BandArgs* args, int n, int batch, int post, hipStream_t s);
 
 struct DecodeLevel {
   PView box;     // 8 planes: DFL logits (head.py:64 cv2)
