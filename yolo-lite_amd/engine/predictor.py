@@ -27,7 +27,7 @@ from ..nn.autobackend import AutoBackend
 from ..utils import LOGGER, ops
 from ..utils.checks import check_imgsz
 from ..utils.torch_utils import select_device, smart_inference_mode
-from .results import Results
+from .results import Boxes, Results
 
 
 class DetectionPredictor:
@@ -220,8 +220,9 @@ class DetectionPredictor:
         counts = job["cnt"].tolist()  # the one host sync of the batch
         self.last_preds = None
         names, out, shapes, imgs, paths = self.model.names, job["out"], job["shapes"], job["imgs"], job["paths"]
-        return [Results(imgs[i], path=paths[i], names=names, boxes=out[i, : counts[i]], orig_shape=shapes[i])
-                for i in range(job["n"])]
+        recs = out.unbind(0)  # one call: the per-image (max_det, 6) records; rows are cut to the count on first use
+        return [Results(imgs[i], path=paths[i], names=names, boxes=Boxes.from_record(recs[i], counts[i], shapes[i]),
+                        orig_shape=shapes[i]) for i in range(job["n"])]
 
     def _inflight(self) -> int:
         """Batches kept in flight by ``stream_inference`` on sources of more than one batch (YL_PREDICT_INFLIGHT, default
@@ -235,7 +236,13 @@ class DetectionPredictor:
         self.stream = stream
         if stream:
             return self.stream_inference(source, model, *args, **kwargs)
-        return list(self.stream_inference(source, model, *args, **kwargs))
+        # one inference-mode context around the whole call and one generator step per BATCH: resuming a decorated
+        # generator re-enters the context per yielded Results (33 times per batch of 32, ~35 us of host time)
+        with torch.inference_mode():
+            out = []
+            for batch_results in self._batches(source, model, *args, **kwargs):
+                out.extend(batch_results)
+            return out
 
     def setup_source(self, source):
         self.imgsz = check_imgsz(self.args.imgsz, stride=self.model.stride, min_dim=2)
@@ -254,6 +261,12 @@ class DetectionPredictor:
 
     @smart_inference_mode()
     def stream_inference(self, source=None, model=None, *args, **kwargs):
+        """Generator of Results, one image at a time (reference predictor.py:149-229)."""
+        for batch_results in self._batches(source, model, *args, **kwargs):
+            yield from batch_results
+
+    def _batches(self, source=None, model=None, *args, **kwargs):
+        """The predict loop: yields the list of Results of one batch at a time."""
         if not self.model:
             self.setup_model(model)
         with self._lock:
@@ -272,7 +285,10 @@ class DetectionPredictor:
             # stage timers: the reference's Profile synchronises the DEVICE around every stage (ops.py:59-63), which would
             # serialise the batches in flight -- with S > 1 they are plain wall-clock timers (a batch's "inference" time is
             # then its enqueue + the wait for its results)
-            pdev = self.device if S == 1 else None
+            # (and on the fused path with one batch at a time: its ONE host synchronisation -- the counts' D2H copy in
+            # _harvest_fused -- already ends the "inference" timer with the batch finished; six device synchronisations per call
+            # around the three stages cost ~60 us of host time per batch for the same numbers)
+            pdev = self.device if S == 1 and not self._can_fuse() else None
             profilers = (ops.Profile(device=pdev), ops.Profile(device=pdev), ops.Profile(device=pdev))
             pending, k = [], 0
             # everything the caller enqueued on the current stream before predict() -- e.g. the kernels that produced the
@@ -310,15 +326,15 @@ class DetectionPredictor:
                     pending.append(job)
                     k += 1
                     if len(pending) >= S:
-                        yield from finish(pending.pop(0))
+                        yield finish(pending.pop(0))
                     continue
                 with profilers[1]:
                     preds = self.inference(im, *args, **kwargs)
                 with profilers[2]:
                     self.results = self.postprocess(preds, im, im0s)
-                yield from self._emit(paths, im0s, s, im, profilers, profilers[0].dt)
+                yield self._emit(paths, im0s, s, im, profilers, profilers[0].dt)
             while pending:
-                yield from finish(pending.pop(0))
+                yield finish(pending.pop(0))
         if self.args.verbose and self.seen and im is not None:
             t = tuple(x.t / self.seen * 1e3 for x in profilers)
             LOGGER.info("Speed: %.1fms preprocess, %.1fms inference, %.1fms postprocess per image at shape "

@@ -55,6 +55,29 @@ class Boxes(BaseTensor):
         super().__init__(boxes, orig_shape)
         self.orig_shape = orig_shape
 
+    @classmethod
+    def from_record(cls, record, count: int, orig_shape) -> "Boxes":
+        """The first ``count`` rows of a padded (max_det, 6) record of the fused NMS (``HipEngine.detect``), sliced on first
+        use: the predictor builds one Results per image per call, and 32 tensor slices per batch cost more host time than
+        launching the network (the reference slices eagerly, predictor.py:110-127; the values are the same)."""
+        self = cls.__new__(cls)
+        self.__dict__["_record"] = (record, int(count))
+        self.orig_shape = orig_shape
+        return self
+
+    def __getattr__(self, name):  # only reached while ``data`` has not been materialised yet
+        if name == "data":
+            rec = self.__dict__.get("_record")
+            if rec is not None:
+                data = rec[0][: rec[1]]
+                self.__dict__["data"] = data
+                return data
+        raise AttributeError(name)
+
+    def __len__(self):
+        rec = self.__dict__.get("_record")
+        return rec[1] if rec is not None and "data" not in self.__dict__ else len(self.data)
+
     @property
     def xyxy(self):
         return self.data[:, :4]
@@ -101,7 +124,7 @@ class Results(SimpleClass):
     def __init__(self, orig_img, path, names, boxes=None, speed=None, orig_shape=None) -> None:
         self.orig_img = orig_img
         self.orig_shape = tuple(orig_img.shape[:2]) if orig_img is not None else tuple(orig_shape)
-        self.boxes = Boxes(boxes, self.orig_shape) if boxes is not None else None
+        self.boxes = boxes if isinstance(boxes, Boxes) else (Boxes(boxes, self.orig_shape) if boxes is not None else None)
         self.speed = speed if speed is not None else {"preprocess": None, "inference": None, "postprocess": None}
         self.names = names
         self.path = path
