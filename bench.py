@@ -681,6 +681,36 @@ def main():
         extra["per_rank_ms"] = {"sharded": [round(float(t[0]), 4) for t in allr], "resident": [round(float(t[1]), 4) for t in allr]}
         extra["scatter_bytes_per_step"] = (world - 1) * B * 3 * H * W
         extra["gather_bytes_per_step"] = (world - 1) * record_floats(B, max_det) * 4
+        # The scatter ALONE, outside the timed region, nothing else on the GPUs: the root pushes one slice per peer over that
+        # peer's xGMI link, so bytes of ONE slice / time of a scatter = the one-direction rate each link sustained.  The design
+        # needs slice bytes x (value_rank0_alone / B) per link; a link slower than that makes the
+        # sharded step scatter-bound whatever the kernels do.
+        from yololite_amd.dist import scatter_images
+
+        probe = torch.empty((B, 3, H, W), dtype=torch.uint8, device=dev)
+        n_sc = 10
+        for _ in range(3):
+            scatter_images(batches[0], probe, 0)
+        sync_all()
+        t4 = time.perf_counter()
+        for _ in range(n_sc):
+            scatter_images(batches[0], probe, 0)
+        sync_all()
+        t_sc = torch.tensor([(time.perf_counter() - t4) / n_sc], dtype=torch.float64, device=dev)
+        dist.all_reduce(t_sc, op=dist.ReduceOp.MAX)
+        slice_bytes = B * 3 * H * W
+        extra["scatter_ms_alone"] = round(float(t_sc.item()) * 1e3, 4)
+        extra["scatter_gbps_per_link"] = round(slice_bytes / float(t_sc.item()) / 1e9, 2) if world > 1 else None
+        need = slice_bytes * extra["value_rank0_alone"] / B / 1e9
+        extra["scatter_gbps_per_link_needed"] = round(need, 2)
+        v_sh = world * B * args.steps / float(max(dt, 1e-9))
+        if world > 1:
+            slow_link = extra["scatter_gbps_per_link"] is not None and extra["scatter_gbps_per_link"] < 1.1 * need
+            extra["bound"] = "scatter" if (slow_link or v_sh < 0.9 * extra["value_resident"]) else "compute"
+            extra["bound_note"] = ("scatter: a link sustains less than 1.1 x the rate the compute consumes, or the sharded rate is more "
+                                   "than 10 % below the resident (no per-step collective) rate of the same ranks; compute otherwise")
+        else:
+            extra["bound"] = "compute"
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if sharded:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
