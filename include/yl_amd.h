@@ -50,6 +50,14 @@ enum {
                            m.1.cv1, m.1.cv2, each [c_][c_][3][3]), out = SiLU(cv3(cat(a, u[c_:2 c_]))) (extra_weight[4],
                            [out.C][2 c_], 1x1).  in.C = out.C = 2 c_ = 128; in and out have the same H, W.  Every tensor between
                            `in` and `out` lives in LDS or registers; bit-identical to the six YL_OP_CONV ops it replaces.  */
+  YL_OP_PSA = 11,     /* a PSABlock (nn/modules/block.py:919-953; Attention :863-916) with c = 128 channels, 2 heads, key_dim 32,
+                         head_dim 64 on a map of at most 400 pixels (layer 10 of YOLO11n at 640x640), ONE launch, one workgroup per
+                         image (csrc/resident.hip): in == out = the block's residual stream b, rewritten in place:
+                           qkv = conv1x1(b) (weight / bias [256][128], no activation); per head o = v . softmax(q^T k * scale)^T;
+                           o += dwconv3x3(v) (extra_weight[0] [128][1][3][3], the positional encoding); b += conv1x1(o)
+                           (extra_weight[1] [128][128]); b += conv1x1(SiLU(conv1x1(b))) (extra_weight[2] [256][128],
+                           extra_weight[3] [128][256]); heads / key_dim / head_dim / scale as YL_OP_ATTENTION.  Bit-identical to the
+                           six ops it replaces (YL_OP_CONV, YL_OP_ATTENTION, YL_OP_DWCONV3 with accumulate, three YL_OP_CONV). */
   YL_OP_C3K2S = 7     /* body of a narrow C3k2 block in one launch (nn/modules/block.py:220-235, 330-343), half width
                          c = 16 or 32: `in` = the block's concat buffer [a | b | ...] (a, b = halves of C3k2.cv1's output,
                          c channels each); c_out = b + SiLU(cv2(SiLU(cv1(b)))) with the Bottleneck's two 3x3 convs

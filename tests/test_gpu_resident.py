@@ -8,7 +8,7 @@ import torch.nn.functional as F
 from hip_util import Mini, bf16_round
 from yololite_amd.nn import arch
 from yololite_amd.nn.engine import HipEngine
-from yololite_amd.nn.lower import OP_C3K, OP_CONV, c3k_resident_fits
+from yololite_amd.nn.lower import OP_ATTENTION, OP_C3K, OP_CONV, OP_DWCONV3, OP_PSA, c3k_resident_fits, psa_resident_fits
 from yololite_amd.nn.synth import synth_state_dict
 
 pytestmark = pytest.mark.gpu
@@ -114,6 +114,93 @@ def test_network_with_resident_c3k_is_bit_identical(gpu_device, monkeypatch, h, 
     ref = HipEngine.from_model(specs, sd, b, h, w, gpu_device)
     assert "c3k_resident_mfma" not in [ref.op_kernel(i) for i in range(len(ref.prog.ops))]
     assert len(ref.prog.ops) == len(eng.prog.ops) + 10
+    assert torch.equal(y, ref.forward(x))
+    for p, q in zip(lv, ref.raw_levels()):
+        assert torch.equal(p, q)
+
+
+# ------------------------------------------------------------------------------------------------ PSABlock (C2PSA)
+def _rand_psa(gen, c=128):
+    def wb(co, ci, k=1, gain=1.0, groups=1):
+        w = bf16_round(torch.randn(co, ci // groups, k, k, generator=gen) * (gain / ((ci // groups) * k * k) ** 0.5))
+        return w, torch.randn(co, generator=gen) * 0.2
+
+    return dict(qkv=wb(2 * c, c, gain=1.5), pe=wb(c, c, 3, gain=1.0, groups=c), proj=wb(c, c, gain=0.8),
+                ffn0=wb(2 * c, c, gain=1.4), ffn1=wb(c, 2 * c, gain=0.8))
+
+
+def _psa_ops(m, bview, blk, H, W, fused, c=128, nh=2, kd=32, hd=64):
+    scale = float(kd ** -0.5)
+    if fused:
+        m.op(kind=OP_PSA, name="psa", act=0, heads=nh, key_dim=kd, head_dim=hd, scale=scale, inp=bview, out=bview,
+             weight=_np(blk["qkv"][0].reshape(2 * c, -1)), bias=_np(blk["qkv"][1]),
+             extra_weight=[_np(blk["pe"][0]), _np(blk["proj"][0].reshape(c, -1)), _np(blk["ffn0"][0].reshape(2 * c, -1)),
+                           _np(blk["ffn1"][0].reshape(c, -1))],
+             extra_bias=[_np(blk["pe"][1]), _np(blk["proj"][1]), _np(blk["ffn0"][1]), _np(blk["ffn1"][1])])
+        return
+    qkv, o, f1 = m.buf(H, W, 2 * c), m.buf(H, W, c), m.buf(H, W, 2 * c)
+    m.op(kind=OP_CONV, name="qkv", k=1, stride=1, act=0, inp=bview, out=qkv, weight=_np(blk["qkv"][0]), bias=_np(blk["qkv"][1]))
+    m.op(kind=OP_ATTENTION, name="attn", heads=nh, key_dim=kd, head_dim=hd, scale=scale, inp=qkv, out=o)
+    m.op(kind=OP_DWCONV3, name="pe", k=3, stride=1, act=0, accumulate=1, grp=hd, grp_stride=2 * kd + hd, grp_off=2 * kd, inp=qkv, out=o,
+         weight=_np(blk["pe"][0]), bias=_np(blk["pe"][1]))
+    m.op(kind=OP_CONV, name="proj", k=1, stride=1, act=0, inp=o, out=bview, res=bview, weight=_np(blk["proj"][0]), bias=_np(blk["proj"][1]))
+    m.op(kind=OP_CONV, name="ffn0", k=1, stride=1, act=1, inp=bview, out=f1, weight=_np(blk["ffn0"][0]), bias=_np(blk["ffn0"][1]))
+    m.op(kind=OP_CONV, name="ffn1", k=1, stride=1, act=0, inp=f1, out=bview, res=bview, weight=_np(blk["ffn1"][0]), bias=_np(blk["ffn1"][1]))
+
+
+def _torch_psa(x, blk, nh=2, kd=32, hd=64):
+    """fp32 PSABlock (block.py:919-953, 905-916)."""
+    B, C, H, W = x.shape
+    N = H * W
+    qkv = F.conv2d(x, *blk["qkv"])
+    q, k, v = qkv.view(B, nh, 2 * kd + hd, N).split([kd, kd, hd], dim=2)
+    attn = ((q.transpose(-2, -1) @ k) * kd ** -0.5).softmax(-1)
+    o = (v @ attn.transpose(-2, -1)).view(B, C, H, W) + F.conv2d(v.reshape(B, C, H, W), blk["pe"][0], blk["pe"][1], padding=1, groups=C)
+    x = x + F.conv2d(o, *blk["proj"])
+    return x + F.conv2d(F.silu(F.conv2d(x, *blk["ffn0"])), *blk["ffn1"])
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 20, 20), (3, 12, 20), (1, 10, 10), (2, 5, 7), (2, 16, 16), (1, 19, 19), (2, 3, 3)])
+def test_psa_resident_vs_chain_and_torch(gpu_device, B, H, W):
+    """The PSABlock in one launch == its six launches, every bit; both close to torch fp32.  Sizes: one to four query tiles per
+    wave, ragged last tiles, key counts that are not multiples of 32, waves without any tile."""
+    assert psa_resident_fits(128, 2, 32, 64, H, W)
+    gen = torch.Generator().manual_seed(77 * H + W)
+    blk = _rand_psa(gen)
+    x = bf16_round(torch.randn(B, 128, H, W, generator=gen))
+    got = {}
+    for fused in (True, False):
+        m = Mini(B, gpu_device)
+        u = m.buf(H, W, 256)
+        bv = u.slice(128, 128)  # the block works on the second half of C2PSA.cv1's output (block.py:1035-1037)
+        m.fill(bv, x)
+        _psa_ops(m, bv, blk, H, W, fused)
+        m.run()
+        if fused:
+            assert m.eng.op_kernel(0) == "psa_resident_mfma"
+        got[fused] = m.read(bv)
+    assert torch.equal(got[True], got[False]), f"max |d| {float((got[True] - got[False]).abs().max())}"
+    ref = _torch_psa(x, blk)
+    err = (got[True] - ref).abs()
+    assert float(err.max()) <= 0.06 * float(ref.abs().max()), (float(err.max()), float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("h,w,b", [(640, 640, 8), (384, 640, 8), (320, 320, 9)])
+def test_network_with_resident_psa_is_bit_identical(gpu_device, monkeypatch, h, w, b):
+    """YOLO11n with layer 10's PSABlock as ONE launch against the program with its six launches: level maps and decoded
+    predictions, every bit."""
+    sd = synth_state_dict("n", 6, cls_bias=[-2.0, -2.0, -2.0], cls_gain=4.0)
+    x = torch.randint(0, 256, (b, 3, h, w), generator=torch.Generator().manual_seed(h + 5 * w), dtype=torch.uint8).to(gpu_device)
+    specs, _ = arch.parse_model(arch.yolo11_dict("n"))
+    monkeypatch.setenv("YL_FUSE_PSA", "1")
+    eng = HipEngine.from_model(specs, sd, b, h, w, gpu_device)
+    assert [eng.op_kernel(i) for i in range(len(eng.prog.ops))].count("psa_resident_mfma") == 1
+    y = eng.forward(x).clone()
+    lv = [t.clone() for t in eng.raw_levels()]
+    monkeypatch.setenv("YL_FUSE_PSA", "0")
+    ref = HipEngine.from_model(specs, sd, b, h, w, gpu_device)
+    assert "psa_resident_mfma" not in [ref.op_kernel(i) for i in range(len(ref.prog.ops))]
+    assert len(ref.prog.ops) == len(eng.prog.ops) + 5
     assert torch.equal(y, ref.forward(x))
     for p, q in zip(lv, ref.raw_levels()):
         assert torch.equal(p, q)

@@ -217,7 +217,7 @@ def test_c3k_resident_limits():
 
 def test_lowering_uses_resident_c3k_from_batch_8(monkeypatch):
     from yololite_amd.nn import arch
-    from yololite_amd.nn.lower import OP_C3K, lower
+    from yololite_amd.nn.lower import OP_C3K, OP_PSA, lower
     from yololite_amd.nn.synth import synth_state_dict
 
     monkeypatch.delenv("YL_FUSE_C3K", raising=False)
@@ -225,7 +225,8 @@ def test_lowering_uses_resident_c3k_from_batch_8(monkeypatch):
     sd = synth_state_dict("n", 0)
     big = lower(specs, sd, 32, 640, 640)
     assert [o["name"] for o in big.ops if o["kind"] == OP_C3K] == ["model.8.m.0", "model.22.m.0"]
+    assert [o["name"] for o in big.ops if o["kind"] == OP_PSA] == ["model.10.m.0"]
     small = lower(specs, sd, 1, 640, 640)
-    assert not [o for o in small.ops if o["kind"] == OP_C3K] and len(small.ops) == len(big.ops) + 10
+    assert not [o for o in small.ops if o["kind"] in (OP_C3K, OP_PSA)] and len(small.ops) == len(big.ops) + 15
     s_scale = lower(arch.parse_model(arch.yolo11_dict("s"))[0], synth_state_dict("s", 0), 32, 640, 640)
     assert not [o for o in s_scale.ops if o["kind"] == OP_C3K]   # inner width 128: the maps do not fit

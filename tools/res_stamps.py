@@ -26,6 +26,42 @@ NAMES = ["start", "x staged", "barrier", "cv1|cv2 done", "barrier", "T cleared",
          "m1.cv1 done", "barrier", "m1.cv2 done", "barrier", "cv3 done"]
 
 
+PSA_NAMES = ["start", "qkv h0 done", "barrier", "attention h0 done", "barrier", "o map + pe h0", "qkv h1 done", "barrier", "attention h1 done",
+             "barrier", "o map + pe h1", "tail filters landed", "barrier", "proj done", "ffn done"]
+
+
+def psa(B=32, H=20, W=20, iters=5):
+    """The same for the resident PSABlock kernel."""
+    from test_gpu_resident import _psa_ops, _rand_psa
+
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(0)
+    blk = _rand_psa(gen)
+    m = Mini(B, dev)
+    u = m.buf(H, W, 256)
+    bv = u.slice(128, 128)
+    m.fill(bv, bf16_round(torch.randn(B, 128, H, W, generator=gen)))
+    _psa_ops(m, bv, blk, H, W, True)
+    buf = torch.zeros(B * 8 * 32 * 2, dtype=torch.int64, device=dev)
+    L = _lib.lib()
+    if not L.yl_diag_set_stamps(C.c_void_p(buf.data_ptr())):
+        print("this libyl_amd.so is the production build: rebuild with EXTRA=-DYL_STAMPS")
+        return
+    m.run()
+    im = torch.zeros(B, 3, 32, 32, device=dev)
+    for _ in range(iters):
+        m.eng.forward(im, decode=False)
+        torch.cuda.synchronize()
+    st = buf.view(B, 8, 32, 2).cpu().numpy().astype(np.int64)
+    ns = (st[..., 1] - st[:, :, :1, 1].min(axis=1, keepdims=True)) * 10
+    prev = 0.0
+    for i, name in enumerate(PSA_NAMES):
+        t = ns[:, :, i] / 1e3
+        print(f"{i:2d} {name:20s} median {np.median(t):7.2f} us  (+{np.median(t) - prev:6.2f})  max {t.max():7.2f} us   per-wave spread {np.median(t.max(axis=1) - t.min(axis=1)):5.2f} us")
+        prev = float(np.median(t))
+    L.yl_diag_set_stamps(None)
+
+
 def main(B=32, H=20, W=20, iters=5):
     dev = torch.device("cuda:0")
     gen = torch.Generator().manual_seed(0)
@@ -69,4 +105,7 @@ def main(B=32, H=20, W=20, iters=5):
 
 
 if __name__ == "__main__":
-    main(*[int(v) for v in sys.argv[1:]])
+    if len(sys.argv) > 1 and sys.argv[1] == "psa":
+        psa(*[int(v) for v in sys.argv[2:]])
+    else:
+        main(*[int(v) for v in sys.argv[1:]])

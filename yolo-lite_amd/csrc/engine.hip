@@ -64,7 +64,7 @@ struct OpRec {
   float* d_bias3 = nullptr;
   float* d_alpha = nullptr;  // fp8 conv: in_scale * filter scale per output channel
   __bf16* d_xw[6] = {};      // YL_OP_C3K: the six packed filters (cv1|cv2, m.0.cv1, m.0.cv2, m.1.cv1, m.1.cv2, cv3) and biases
-  float* d_xb[6] = {};
+  float* d_xb[6] = {};       // YL_OP_PSA: d_xw[0] = qkv, d_xw[1] = proj | ffn.0 | ffn.1 (160 KiB); d_xb = qkv, pe, proj, ffn.0, ffn.1 biases; d_w = pe taps
   bool f8 = false;
   int cls_level = -1;  // fused depthwise + pointwise + 1x1 that writes the class logits of this Detect level (else -1)
   int group_n = 0;  // group launch (yl_op.group): 2 or 3 on the first member, -1 on the others (run with it), 0 = on its own
@@ -577,6 +577,61 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
         r.name = "c3k_resident_mfma";
         break;
       }
+      case YL_OP_PSA: {
+        const int c = o.in.C;
+        if (!o.weight || !o.bias || o.n_extra != 4 || !o.extra_weight || !o.extra_bias)
+          return fail(-1, tag + ": psa needs the qkv filter and four extra filters (pe, proj, ffn.0, ffn.1)");
+        for (int q = 0; q < 4; ++q)
+          if (!o.extra_weight[q] || !o.extra_bias[q]) return fail(-1, tag + ": psa: null extra filter");
+        if (o.in.dtype != YL_BF16 || o.out.dtype != YL_BF16 || o.in.offset != o.out.offset || o.in.coff != o.out.coff || o.out.C != c ||
+            o.lane != 0 || !psa_resident_fits(c, o.heads, o.key_dim, o.head_dim, o.in.H, o.in.W))
+          return fail(-3, tag + ": psa: in == out, 128 channels, 2 heads (key_dim 32, head_dim 64), at most 400 pixels per image");
+        auto pack = [&](const float* w, int cout, int cin, std::vector<uint16_t>* pk) {
+          ConvConfig cc{};
+          cc.MT = 4;
+          cc.ncb = cout / 64;
+          cc.cg = cin / 8;
+          cc.ntaps = 1;
+          cc.ksteps = cin / 32;
+          cc.wpk_elems = (size_t)cc.ncb * cc.ksteps * cc.MT * 64 * 8;
+          conv_pack_weights(w, cout, cin, 1, cc, pk);
+        };
+        {
+          std::vector<uint16_t> pk;
+          pack(o.weight, 2 * c, c, &pk);
+          uint16_t* d = nullptr;
+          if (int rc = dev_upload(e.get(), pk, &d)) return rc;
+          r.d_xw[0] = reinterpret_cast<__bf16*>(d);
+          std::vector<uint16_t> tail, part;
+          pack(o.extra_weight[1], c, c, &part);
+          tail.insert(tail.end(), part.begin(), part.end());
+          pack(o.extra_weight[2], 2 * c, c, &part);
+          tail.insert(tail.end(), part.begin(), part.end());
+          pack(o.extra_weight[3], c, 2 * c, &part);
+          tail.insert(tail.end(), part.begin(), part.end());
+          if (tail.size() * 2 != 160 * 1024) return fail(-3, tag + ": psa: unexpected tail filter size");
+          if (int rc = dev_upload(e.get(), tail, &d)) return rc;
+          r.d_xw[1] = reinterpret_cast<__bf16*>(d);
+        }
+        {
+          const float* bs[5] = {o.bias, o.extra_bias[0], o.extra_bias[1], o.extra_bias[2], o.extra_bias[3]};
+          const int nb[5] = {2 * c, c, c, 2 * c, c};
+          for (int q = 0; q < 5; ++q) {
+            std::vector<float> bias((size_t)nb[q] + 16, 0.f);
+            for (int ch = 0; ch < nb[q]; ++ch) bias[ch] = bs[q][ch];
+            if (int rc = dev_upload(e.get(), bias, &r.d_xb[q])) return rc;
+          }
+          std::vector<float> wt((size_t)9 * c);  // depthwise taps as dwconv3_kernel reads them: [tap][channel], fp32
+          for (int ch = 0; ch < c; ++ch)
+            for (int t = 0; t < 9; ++t) wt[(size_t)t * c + ch] = o.extra_weight[0][(size_t)ch * 9 + t];
+          if (int rc = dev_upload(e.get(), wt, &r.d_w)) return rc;
+        }
+        const double n_tok = (double)o.in.H * o.in.W;
+        r.flops = 2.0 * px_out * (2.0 * c * c + c * c + 4.0 * c * c + 9.0 * c) + 2.0 * batch * o.heads * n_tok * n_tok * (o.key_dim + o.head_dim);
+        r.bytes = px_out * 2.0 * c * 2 + 2.0 * (7.0 * c * c);
+        r.name = "psa_resident_mfma";
+        break;
+      }
       case YL_OP_C3K2S: {
         if (!o.weight || !o.bias || !o.post_weight || !o.post_bias || !o.stem_weight || !o.stem_bias)
           return fail(-1, tag + ": c3k2 needs the three convs' weights and biases");
@@ -1011,6 +1066,31 @@ static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s, c
         q.bias[k] = r.d_xb[k];
       }
       return c3k_resident_launch(q, s);
+    }
+    case YL_OP_PSA: {
+      PsaArgs q{};
+      const Geo gq = geo_of(B, o.in.H, o.in.W);
+      const long long nb = (long long)(o.in.C / 8) * plane_bytes(gq);
+      if (nb > (1LL << 30)) return fail(-3, "psa: a tensor slice exceeds 1 GiB; lower the batch size");
+      q.b = pview(ws, o.in, B).base;
+      q.b_plane = (unsigned)plane_bytes(gq);
+      q.b_bytes = (unsigned)nb;
+      q.B = B;
+      q.H = o.in.H;
+      q.W = o.in.W;
+      q.W1 = gq.W1;
+      q.img = gq.img;
+      q.g0 = gq.g0;
+      q.scale = o.scale;
+      q.w_qkv = r.d_xw[0];
+      q.w_tail = r.d_xw[1];
+      q.b_qkv = r.d_xb[0];
+      q.b_pe = r.d_xb[1];
+      q.b_proj = r.d_xb[2];
+      q.b_ffn0 = r.d_xb[3];
+      q.b_ffn1 = r.d_xb[4];
+      q.w_pe = r.d_w;
+      return psa_resident_launch(q, s);
     }
     case YL_OP_C3K2S: {
       C3k2sArgs q{};

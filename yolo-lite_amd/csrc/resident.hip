@@ -332,6 +332,454 @@ __global__ __launch_bounds__(RC_THREADS) void c3k_resident_kernel(C3kArgs a) {
 #undef RC_STAMP
 }
 
+// ================================================================================================== C2PSA's PSABlock, resident
+// psa_resident_kernel: the PSABlock of a C2PSA layer (reference nn/modules/block.py:919-953 PSABlock, :863-916 Attention, with
+// c = 128 channels, 2 heads, key_dim 32, head_dim 64: layer 10 of YOLO11n) on ONE image per workgroup, six launches -> one:
+//
+//     qkv = conv1x1(b)  (128 -> 256, no activation)                    per head [q(32) | k(32) | v(64)]
+//     o   = v . softmax(q^T k * scale)^T  per head                     block.py:905-912
+//     o   = o + dwconv3x3(v)                                           the positional encoding `pe` (block.py:913)
+//     b   = b + conv1x1(o)           (`proj`, 128 -> 128)              PSABlock.forward: x = x + attn(x)
+//     b   = b + conv1x1(SiLU(conv1x1(b)))  (`ffn`: 128 -> 256 -> 128)  x = x + ffn(x)
+//
+// Eight waves; wave w owns an EIGHTH of the image's 16-pixel tiles from the first conv to the last store -- everything after
+// the attention is pointwise, so the tensors between proj, ffn.0 and ffn.1 never leave that wave's registers (the accumulator
+// layout of one conv IS the B-fragment layout of the next, conv_kernel's POST trick), and the residual stream b is its
+// B fragments of the first conv.  Only the attention needs other pixels: per head the keys and the transposed values are
+// written to LDS by the qkv conv's own epilogue in attention_kernel's layout (ops_misc.hip), and the attention loop is that
+// kernel's, instruction for instruction: same key order, same online softmax, same roundings.  The depthwise `pe` reads v
+// from dense LDS planes (bounds tests instead of guard pixels) with dwconv3_kernel's tap order.  The three tail convs'
+// filters (160 KB) are staged into the whole LDS at once after the attention -- streamed from L2 by every wave they would be
+// 2.5 MB of L1 traffic per workgroup.  Results are BIT-IDENTICAL to the six launches (tests/test_gpu_resident.py).
+constexpr int PS_KP = 40;    // sK row pitch in elements (attention_kernel's AT_KP)
+
+struct PsaLds {
+  int sk, svt, vpl, omap, vp, hwp, nk32, total;
+};
+__host__ __device__ static inline PsaLds psa_lds_plan(int N) {
+  PsaLds L;
+  L.hwp = (N + 15) / 16 * 16;
+  L.nk32 = (N + 31) & ~31;
+  L.vp = L.nk32 + 8;
+  L.sk = 0;
+  L.svt = L.sk + L.nk32 * PS_KP * 2;
+  L.vpl = L.svt + 64 * L.vp * 2;
+  L.omap = 0;  // aliases sK / sVt once a head's attention is done
+  const int front = L.vpl + 8 * L.hwp * 16;
+  const int tail = 160 * 1024;  // the three tail filters: 32 + 64 + 64 KiB
+  L.total = front > tail ? front : tail;
+  return L;
+}
+
+// this wave's tiles t0 .. t0 + NT - 1 (tiles past `cnt` are inactive: clamped addresses, nothing stored)
+template <int NT>
+struct PsaTiles {
+  int pix[NT];    // dense pixel index of the lane's pixel (clamped into the image)
+  bool ok[NT];    // the lane's pixel exists
+};
+
+template <int NT>
+__device__ __forceinline__ void psa_body(const PsaArgs& a, unsigned char* lds, const PsaLds& L, int t0, int cnt, int b, int tid, int lane,
+                                         int wave, int n, int g) {
+  const int N = a.H * a.W;
+  PsaTiles<NT> T;
+  unsigned gpix[NT];  // byte offset of the lane's pixel in a plane of the HBM layout (OOB_LANE: none)
+  int ty[NT], tx[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int i = (t0 + nt) * 16 + n;
+    T.ok[nt] = nt < cnt && i < N;
+    T.pix[nt] = T.ok[nt] ? i : N - 1;
+    const int y = T.pix[nt] / a.W, x = T.pix[nt] - y * a.W;
+    ty[nt] = y;
+    tx[nt] = x;
+    gpix[nt] = T.ok[nt] ? (unsigned)(a.g0 + b * a.img + y * a.W1 + x) * 16u : OOB_LANE;
+  }
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)a.b, (short)0, a.b_bytes, 0x00020000);
+  // (three identical loads of b -- the two heads' qkv convs and the residual stream -- 64 registers each: an opaque zero in
+  // the scalar offset keeps the compiler from merging them into ONE load that stays live through the whole kernel)
+  auto load_b = [&](bf16x8 (&dst)[4][NT]) __attribute__((always_inline)) {
+    int zero = 0;
+    asm volatile("" : "+s"(zero));
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        dst[ks][nt] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                                                     rb, gpix[nt] == OOB_LANE ? OOB_LANE : (unsigned)(ks * 4 + g) * a.b_plane + gpix[nt], zero, 0));
+  };
+  __bf16* const sK = reinterpret_cast<__bf16*>(lds + L.sk);
+  __bf16* const sVt = reinterpret_cast<__bf16*>(lds + L.svt);
+  unsigned char* const vpl = lds + L.vpl;
+  unsigned char* const omap = lds + L.omap;
+  const int vplane = L.hwp * 16;
+  const float ninf = -__builtin_huge_valf();
+  bf16x8 oh[2][2][NT];  // [head][k-step within the head][tile]: attention output + pe as proj's B fragments
+#define PS_STAMP(id) YL_STAMP(a.stamps, RC_WAVES, wave, lane, id)
+  PS_STAMP(0);
+
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {  // (unrolled: oh[h] must stay in registers)
+    // ---- qkv conv of head h: channel blocks 2 h (q | k) and 2 h + 1 (v) of the packed filter, K = 128
+    bf16x8 qf[NT];
+    {
+      bf16x8 bfr[4][NT];
+      load_b(bfr);
+      const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.w_qkv) + (size_t)(2 * h) * 4 * 4 * 64 + lane;
+      bf16x8 wa[RC_D1][4];
+      preload1(wa, wp);
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        f32x4 acc[4][NT];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const f32x4 bv = *reinterpret_cast<const f32x4*>(a.b_qkv + (2 * h + cb) * 64 + chan_in_block(4, m, g, 0));
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[m][nt] = bv;
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const int j = cb * 4 + ks;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+              acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j % RC_D1][m], bfr[ks][nt], acc[m][nt], 0, 0, 0);
+          if (j + RC_D1 < 8) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) wa[j % RC_D1][m] = wp[((j + RC_D1) * 4 + m) * 64];
+          }
+        }
+        if (cb == 0 && h == 1) __syncthreads();  // (B1) everybody is done with head 0's keys / values / output map
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            bf16x8 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              o[r] = (__bf16)acc[2 * p][nt][r];
+              o[4 + r] = (__bf16)acc[2 * p + 1][nt][r];
+            }
+            if (cb == 0) {
+              if (p == 0) qf[nt] = T.ok[nt] ? o : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};     // q: channels 8 g .. of the lane's query
+              else if (T.ok[nt]) *reinterpret_cast<bf16x8*>(sK + T.pix[nt] * PS_KP + g * 8) = o;  // k: row = key
+            } else if (T.ok[nt]) {
+              *reinterpret_cast<bf16x8*>(vpl + (p * 4 + g) * vplane + T.pix[nt] * 16) = o;  // v as planes (for pe)
+#pragma unroll
+              for (int jj = 0; jj < 8; ++jj) sVt[((p * 4 + g) * 8 + jj) * L.vp + T.pix[nt]] = o[jj];  // and transposed (for P.V)
+            }
+          }
+      }
+    }
+    PS_STAMP(1 + 5 * h);
+    __syncthreads();  // (B2) keys and values of head h complete
+    PS_STAMP(2 + 5 * h);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- attention of head h for this wave's query tiles: attention_kernel's loop (ops_misc.hip), one stage (N <= 512)
+    {
+      float mrun[NT], lrun[NT];
+      f32x4 acc[NT][4];
+#pragma unroll
+      for (int r = 0; r < NT; ++r) {
+        mrun[r] = ninf;
+        lrun[r] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) acc[r][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      const int nk = N;
+#pragma unroll
+      for (int r = 0; r < NT; ++r) {
+        if (r >= cnt) continue;
+        for (int k0 = 0; k0 < L.nk32; k0 += 32) {
+          const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(sK + (k0 + n) * PS_KP + g * 8);
+          const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(sK + (k0 + 16 + n) * PS_KP + g * 8);
+          const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+          const f32x4 s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, qf[r], z, 0, 0, 0);
+          const f32x4 s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf[r], z, 0, 0, 0);
+          float v[8];
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            v[rr] = (k0 + 4 * g + rr < nk) ? s0[rr] * a.scale : ninf;
+            v[4 + rr] = (k0 + 16 + 4 * g + rr < nk) ? s1[rr] * a.scale : ninf;
+          }
+          float lm = v[0];
+#pragma unroll
+          for (int j = 1; j < 8; ++j) lm = fmaxf(lm, v[j]);
+          lm = fmaxf(lm, __shfl_xor(lm, 16));
+          lm = fmaxf(lm, __shfl_xor(lm, 32));
+          const float mn = fmaxf(mrun[r], lm);
+          const float alpha = __expf(mrun[r] - mn);
+          float ps = 0.f;
+          bf16x8 pb;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float e = __expf(v[j] - mn);
+            ps += e;
+            pb[j] = (__bf16)e;
+          }
+          lrun[r] = lrun[r] * alpha + ps;
+          mrun[r] = mn;
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) {
+            const __bf16* vr = sVt + (dt * 16 + n) * L.vp + k0 + 4 * g;
+            const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vr);
+            const bf16x4 hi = *reinterpret_cast<const bf16x4*>(vr + 16);
+            const bf16x8 av = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) acc[r][dt][rr] *= alpha;
+            acc[r][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, pb, acc[r][dt], 0, 0, 0);
+          }
+        }
+      }
+      PS_STAMP(3 + 5 * h);
+      __syncthreads();  // (B3) nobody reads the keys / transposed values of head h any more: their place takes the output map
+      PS_STAMP(4 + 5 * h);
+#pragma unroll
+      for (int r = 0; r < NT; ++r) {
+        float lr = lrun[r];
+        lr += __shfl_xor(lr, 16);
+        lr += __shfl_xor(lr, 32);
+        if (T.ok[r]) {
+          const float inv = 1.0f / lr;
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt)
+            *reinterpret_cast<bf16x4*>(omap + ((dt * 16 + 4 * g) >> 3) * vplane + T.pix[r] * 16 + ((4 * g) & 7) * 2) =
+                bf16x4{(__bf16)(acc[r][dt][0] * inv), (__bf16)(acc[r][dt][1] * inv), (__bf16)(acc[r][dt][2] * inv),
+                       (__bf16)(acc[r][dt][3] * inv)};
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- o += pe(v) on this wave's own pixels (dwconv3_kernel's arithmetic: bias first, taps in row-major order, then the
+    // stored attention output), straight into proj's B fragments.  The map entries read here were written by this wave.
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int pl = ks * 4 + g;              // plane of the head's 64 channels
+      const int c = h * 64 + pl * 8;          // first of the lane's 8 channels
+      float acc8[NT][8];
+      {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.b_pe + c), b1 = *reinterpret_cast<const f32x4*>(a.b_pe + c + 4);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            acc8[nt][j] = b0[j];
+            acc8[nt][4 + j] = b1[j];
+          }
+      }
+#pragma unroll 1
+      for (int t = 0; t < 9; ++t) {  // (a real loop: the body is small, unrolled it only adds register pressure)
+        const float* wq = a.w_pe + t * 128 + c;
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wq), w1 = *reinterpret_cast<const f32x4*>(wq + 4);
+        const int dy = t / 3 - 1, dx = t - 3 * (t / 3) - 1;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const bool in = (unsigned)(ty[nt] + dy) < (unsigned)a.H && (unsigned)(tx[nt] + dx) < (unsigned)a.W;
+          // (an out-of-range tap reads the lane's own pixel and multiplies it by zero: fmaf(v, 0, acc) == acc, no branch)
+          const bf16x8 vv = *reinterpret_cast<const bf16x8*>(vpl + pl * vplane + (T.pix[nt] + (in ? dy * a.W + dx : 0)) * 16);
+          const float sel = in ? 1.0f : 0.0f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            acc8[nt][j] = in ? __builtin_fmaf((float)vv[j], w0[j], acc8[nt][j]) : acc8[nt][j];
+            acc8[nt][4 + j] = in ? __builtin_fmaf((float)vv[4 + j], w1[j], acc8[nt][4 + j]) : acc8[nt][4 + j];
+          }
+          (void)sel;
+        }
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const bf16x8 prev = *reinterpret_cast<const bf16x8*>(omap + pl * vplane + T.pix[nt] * 16);
+        bf16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (__bf16)(acc8[nt][j] + (float)prev[j]);
+        oh[h][ks][nt] = o;
+      }
+    }
+    PS_STAMP(5 + 5 * h);
+  }
+
+  // ---- the three tail filters -> LDS (all of it), each wave its share of the 160 1-KiB pieces
+  __builtin_amdgcn_sched_barrier(0);  // (phase fences for the instruction scheduler: without them it hoists the later phases'
+                                      // bias and filter loads across the unrolled head code and spills > 1000 registers)
+  __syncthreads();
+  {
+    const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w_tail, (short)0, 160u * 1024u, 0x00020000);
+#pragma unroll 4
+    for (int pc = wave; pc < 160; pc += RC_WAVES)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_r*)(lds + pc * 1024), 16, (unsigned)(pc * 1024 + lane * 16), 0, 0, 0);
+  }
+  bf16x8 bp[4][NT];  // the residual stream b of this wave's pixels: first the block's input, then b + proj(o)
+  load_b(bp);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PS_STAMP(11);
+  __syncthreads();
+  PS_STAMP(12);
+  const bf16x8* const wproj = reinterpret_cast<const bf16x8*>(lds) + lane;              // [cb 2][ks 4][4][64]
+  const bf16x8* const wf0 = reinterpret_cast<const bf16x8*>(lds + 32 * 1024) + lane;   // [cb 4][ks 4][4][64]
+  const bf16x8* const wf1 = reinterpret_cast<const bf16x8*>(lds + 96 * 1024) + lane;   // [cb 2][ks 8][4][64]
+  // ---- b = b + proj(o)
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int cb = 0; cb < 2; ++cb) {
+    f32x4 acc[4][NT];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(a.b_proj + cb * 64 + chan_in_block(4, m, g, 0));
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[m][nt] = bv;
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 wa[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) wa[m] = wproj[((cb * 4 + ks) * 4 + m) * 64];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[m], oh[ks >> 1][ks & 1][nt], acc[m][nt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const bf16x8 rv = bp[cb * 2 + p][nt];
+        bf16x8 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          o[r] = (__bf16)(acc[2 * p][nt][r] + (float)rv[r]);
+          o[4 + r] = (__bf16)(acc[2 * p + 1][nt][r] + (float)rv[4 + r]);
+        }
+        bp[cb * 2 + p][nt] = o;
+      }
+  }
+  PS_STAMP(13);
+  // ---- b = b + ffn.1(SiLU(ffn.0(b))), two pixel tiles at a time: ffn.0's 64-channel blocks feed ffn.1's k-steps in order
+  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)a.b, (short)0, a.b_bytes, 0x00020000);
+#pragma unroll
+  for (int n0 = 0; n0 < NT; n0 += 2) {  // (unrolled: bp[..][n0 + q] must stay in registers)
+    __builtin_amdgcn_sched_barrier(0);
+    constexpr int NP2 = 2;
+    f32x4 acc1[8][NP2];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(a.b_ffn1 + (m >> 2) * 64 + chan_in_block(4, m & 3, g, 0));
+#pragma unroll
+      for (int q = 0; q < NP2; ++q) acc1[m][q] = bv;
+    }
+#pragma unroll 1
+    for (int mb = 0; mb < 4; ++mb) {  // (a real loop: fully unrolled, the scheduler hoists the filter reads of all blocks and spills)
+      f32x4 acc0[4][NP2];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(a.b_ffn0 + mb * 64 + chan_in_block(4, m, g, 0));
+#pragma unroll
+        for (int q = 0; q < NP2; ++q) acc0[m][q] = bv;
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        bf16x8 wa[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) wa[m] = wf0[((mb * 4 + ks) * 4 + m) * 64];
+#pragma unroll
+        for (int q = 0; q < NP2; ++q)
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+            acc0[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[m], bp[ks][n0 + q < NT ? n0 + q : NT - 1], acc0[m][q], 0, 0, 0);
+      }
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        bf16x8 f[NP2];
+#pragma unroll
+        for (int q = 0; q < NP2; ++q)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            f[q][r] = (__bf16)silu_f(acc0[2 * p][q][r]);
+            f[q][4 + r] = (__bf16)silu_f(acc0[2 * p + 1][q][r]);
+          }
+        const int ks1 = 2 * mb + p;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+          const bf16x8 w1 = wf1[(((m >> 2) * 8 + ks1) * 4 + (m & 3)) * 64];
+#pragma unroll
+          for (int q = 0; q < NP2; ++q) acc1[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1, f[q], acc1[m][q], 0, 0, 0);
+        }
+      }
+    }
+#pragma unroll
+    for (int m2 = 0; m2 < 4; ++m2)  // tile pair m2 = 64-channel block m2 / 2, pair m2 % 2 -> plane m2 * 4 + g
+#pragma unroll
+      for (int q = 0; q < NP2; ++q) {
+        if (n0 + q >= NT) continue;
+        const bf16x8 rv = bp[m2][n0 + q];
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = acc1[2 * m2][q][r] + (float)rv[r];
+          v[4 + r] = acc1[2 * m2 + 1][q][r] + (float)rv[4 + r];
+        }
+        const unsigned gp = gpix[n0 + q];
+        __builtin_amdgcn_raw_buffer_store_b128(
+            u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])}, rout,
+            gp == OOB_LANE ? OOB_LANE : (unsigned)(m2 * 4 + g) * a.b_plane + gp, 0, 0);
+      }
+  }
+  PS_STAMP(14);
+#undef PS_STAMP
+}
+
+template <int NTE>
+__global__ __launch_bounds__(RC_THREADS) void psa_resident_kernel(PsaArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, g = lane >> 4;
+  const int N = a.H * a.W;
+  const PsaLds L = psa_lds_plan(N);
+  // the transposed values' padding columns (keys N .. nk32 - 1) must read as zero: clear keys and values once
+  {
+    const bf16x8 z = {};
+    for (int i = tid * 16; i < L.vpl; i += RC_THREADS * 16) *reinterpret_cast<bf16x8*>(psm + i) = z;
+  }
+  __syncthreads();
+  int t0, cnt;
+  even_split((N + 15) / 16, RC_WAVES, wave, t0, cnt);
+  if (cnt == NTE) psa_body<NTE>(a, psm, L, t0, cnt, blockIdx.x, tid, lane, wave, n, g);
+  else psa_body<(NTE > 1 ? NTE - 1 : 1)>(a, psm, L, t0, cnt, blockIdx.x, tid, lane, wave, n, g);
+}
+
+bool psa_resident_fits(int c, int heads, int key_dim, int head_dim, int H, int W) {
+  const int N = H * W;
+  return c == 128 && heads == 2 && key_dim == 32 && head_dim == 64 && N >= 8 && N <= 400 && psa_lds_plan(N).total <= 160 * 1024;
+}
+
+template <int NTE>
+static int psa_launch_t(const PsaArgs& a, size_t lds, hipStream_t s) {
+  auto kern = psa_resident_kernel<NTE>;
+  if (int rc = allow_big_lds(reinterpret_cast<const void*>(kern), 160 * 1024)) return rc;
+  hipLaunchKernelGGL(kern, dim3((unsigned)a.B), dim3(RC_THREADS), lds, s, a);
+  YL_HIP(hipGetLastError());
+  return 0;
+}
+
+int psa_resident_launch(const PsaArgs& a0, hipStream_t s) {
+  PsaArgs a = a0;
+  a.stamps = g_stamp_buf;
+  if (!psa_resident_fits(128, 2, 32, 64, a.H, a.W)) return fail(-3, "psa_resident: the map does not fit one workgroup");
+  const PsaLds L = psa_lds_plan(a.H * a.W);
+  const int ntiles = (a.H * a.W + 15) / 16;
+  switch ((ntiles + 7) / 8) {
+    case 1: return psa_launch_t<1>(a, (size_t)L.total, s);
+    case 2: return psa_launch_t<2>(a, (size_t)L.total, s);
+    case 3: return psa_launch_t<3>(a, (size_t)L.total, s);
+    case 4: return psa_launch_t<4>(a, (size_t)L.total, s);
+  }
+  return fail(-3, "psa_resident: unsupported map size");
+}
+
+
 size_t c3k_resident_lds(int H, int W, int* xpl_out, int* apl_out, int* r1_out, int* ntiles_out) {
   const int ntiles = (H * W + 15) / 16;
   const int xpl = ntiles * 16 * 16;

@@ -341,6 +341,25 @@ bool conv3_band_plan(int Cin, int Cout, int H, int W, BandArgs* a, bool post = f
 int conv3_band_launch(const BandArgs* args, int n, int batch, hipStream_t s);
 int conv3_band64_launch(const BandArgs* args, int n, int batch, int post, hipStream_t s);
 
+// resident.hip: the PSABlock of a C2PSA layer (c = 128, two heads) in one launch, one workgroup per image
+struct PsaArgs {
+  __bf16* b;                // first plane of the block's residual stream (128 channels), read and rewritten in place
+  unsigned b_plane, b_bytes;
+  int B, H, W, W1, img, g0;
+  float scale;              // attention score scale (key_dim ** -0.5)
+  const __bf16* w_qkv;      // packed [4 blocks][4 k-steps][4 tiles][64 lanes][8]; bias padded to 256
+  const float* b_qkv;
+  const float* w_pe;        // depthwise taps [9][128] fp32, bias [128]
+  const float* b_pe;
+  const __bf16* w_tail;     // proj (32 KiB) | ffn.0 (64 KiB) | ffn.1 (64 KiB), each packed in 64-channel blocks
+  const float* b_proj;
+  const float* b_ffn0;
+  const float* b_ffn1;
+  unsigned long long* stamps;  // diagnostic builds (-DYL_STAMPS)
+};
+bool psa_resident_fits(int c, int heads, int key_dim, int head_dim, int H, int W);
+int psa_resident_launch(const PsaArgs& a, hipStream_t s);
+
 struct DecodeLevel {
   PView box;     // 8 planes: DFL logits (head.py:64 cv2)
   PView cls;     // nc8 / 8 planes: class logits (cv3); padding channels hold large negative values

@@ -22,7 +22,7 @@ from .arch import LayerSpec, detect_mid_channels
 
 BN_EPS = 1e-3
 BF16, F32, FP8 = 0, 1, 4  # yl_amd.h element types (FP8 = OCP e4m3, planes of 16 channels)
-OP_CONV, OP_DWCONV3, OP_SPPF_POOL, OP_UPSAMPLE, OP_ATTENTION, OP_STEM, OP_C3K2S, OP_BNECK2, OP_QUANT, OP_C3K = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
+OP_CONV, OP_DWCONV3, OP_SPPF_POOL, OP_UPSAMPLE, OP_ATTENTION, OP_STEM, OP_C3K2S, OP_BNECK2, OP_QUANT, OP_C3K, OP_PSA = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 
 
 @dataclass
@@ -101,6 +101,11 @@ def c3k_resident_fits(c_: int, H: int, W: int) -> bool:
     xpl = ntiles * 16 * 16
     apl = (((H + 2) * (W + 1) + 2) + 15) // 16 * 16 * 16
     return max(16 * xpl, 8 * apl) + 8 * apl <= 160 * 1024 and 1 <= ntiles <= 28
+
+
+def psa_resident_fits(c: int, nh: int, kd: int, hd: int, H: int, W: int) -> bool:
+    """Mirror of ``psa_resident_fits`` (csrc/resident.hip): the PSABlock of YOLO11n's C2PSA on a map of at most 400 pixels."""
+    return c == 128 and nh == 2 and kd == 32 and hd == 64 and 8 <= H * W <= 400
 
 
 def fuse_follow_up_convs(ops: List[dict]) -> List[dict]:
@@ -863,6 +868,21 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
             b = u.slice(c, c)
             for j in range(sp.n):
                 q = f"{p}.m.{j}"
+                # the whole PSABlock in ONE launch, one workgroup per image (csrc/resident.hip psa_resident_kernel: 6 launches ->
+                # 1, bit-identical); small batches keep the six launches, like the resident C3k block
+                if (fuse_post and os.environ.get("YL_FUSE_PSA", "1") != "0" and psa_resident_fits(c, nh, kd, hd, src.H, src.W)
+                        and batch >= int(os.environ.get("YL_FUSE_C3K_MIN_BATCH", "8")) and not fp8_scales):
+                    wq, bq = fold_conv_bn(sd, q + ".attn.qkv")
+                    names, xw, xb = [q + ".attn.qkv", q + ".attn"], [], []
+                    for part in (".attn.pe", ".attn.proj", ".ffn.0", ".ffn.1"):
+                        wj, bj = fold_conv_bn(sd, q + part)
+                        xw.append(wj.reshape(wj.shape[0], -1) if wj.shape[2] == 1 else wj)
+                        xb.append(bj)
+                        names.append(q + part)
+                    ops.append(dict(kind=OP_PSA, name=q, act=0, heads=nh, key_dim=kd, head_dim=hd, scale=float(kd ** -0.5),
+                                    inp=b, out=b, res=None, weight=wq.reshape(wq.shape[0], -1), bias=bq, extra_weight=xw,
+                                    extra_bias=xb, fused_names=names))
+                    continue
                 qkv = ar.alloc(src.H, src.W, c + 2 * nh * kd)
                 conv(q + ".attn.qkv", b, qkv, 1, 1, act=False)
                 o = ar.alloc(src.H, src.W, c)
