@@ -42,7 +42,7 @@ def psa(B=32, H=20, W=20, iters=5):
     bv = u.slice(128, 128)
     m.fill(bv, bf16_round(torch.randn(B, 128, H, W, generator=gen)))
     _psa_ops(m, bv, blk, H, W, True)
-    buf = torch.zeros(B * 8 * 32 * 2, dtype=torch.int64, device=dev)
+    buf = torch.zeros(4 * B * 8 * 32 * 2, dtype=torch.int64, device=dev)
     L = _lib.lib()
     if not L.yl_diag_set_stamps(C.c_void_p(buf.data_ptr())):
         print("this libyl_amd.so is the production build: rebuild with EXTRA=-DYL_STAMPS")
@@ -52,7 +52,9 @@ def psa(B=32, H=20, W=20, iters=5):
     for _ in range(iters):
         m.eng.forward(im, decode=False)
         torch.cuda.synchronize()
-    st = buf.view(B, 8, 32, 2).cpu().numpy().astype(np.int64)
+    st = buf.view(4 * B, 8, 32, 2).cpu().numpy().astype(np.int64)
+    st = st[st[:, 0, 14, 1] > 0]  # the workgroups that ran (B x workgroups per image)
+    print(f'{len(st)} workgroups')
     ns = (st[..., 1] - st[:, :, :1, 1].min(axis=1, keepdims=True)) * 10
     prev = 0.0
     for i, name in enumerate(PSA_NAMES):

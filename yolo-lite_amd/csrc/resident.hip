@@ -354,7 +354,7 @@ __global__ __launch_bounds__(RC_THREADS) void c3k_resident_kernel(C3kArgs a) {
 constexpr int PS_KP = 40;    // sK row pitch in elements (attention_kernel's AT_KP)
 
 struct PsaLds {
-  int sk, svt, vpl, omap, vp, hwp, nk32, total;
+  int sk, svt, vpl, omap, zslot, vp, hwp, nk32, total;
 };
 __host__ __device__ static inline PsaLds psa_lds_plan(int N) {
   PsaLds L;
@@ -365,7 +365,8 @@ __host__ __device__ static inline PsaLds psa_lds_plan(int N) {
   L.svt = L.sk + L.nk32 * PS_KP * 2;
   L.vpl = L.svt + 64 * L.vp * 2;
   L.omap = 0;  // aliases sK / sVt once a head's attention is done
-  const int front = L.vpl + 8 * L.hwp * 16;
+  L.zslot = L.vpl + 8 * L.hwp * 16;  // sixteen zero bytes: what an out-of-range pe tap reads
+  const int front = L.zslot + 16;
   const int tail = 160 * 1024;  // the three tail filters: 32 + 64 + 64 KiB
   L.total = front > tail ? front : tail;
   return L;
@@ -374,39 +375,73 @@ __host__ __device__ static inline PsaLds psa_lds_plan(int N) {
 // this wave's tiles t0 .. t0 + NT - 1 (tiles past `cnt` are inactive: clamped addresses, nothing stored)
 template <int NT>
 struct PsaTiles {
-  int pix[NT];    // dense pixel index of the lane's pixel (clamped into the image)
-  bool ok[NT];    // the lane's pixel exists
-};
-
-template <int NT>
-__device__ __forceinline__ void psa_body(const PsaArgs& a, unsigned char* lds, const PsaLds& L, int t0, int cnt, int b, int tid, int lane,
-                                         int wave, int n, int g) {
-  const int N = a.H * a.W;
-  PsaTiles<NT> T;
+  int pix[NT];        // dense pixel index of the lane's pixel (clamped into the image)
+  bool ok[NT];        // the lane's pixel exists
   unsigned gpix[NT];  // byte offset of the lane's pixel in a plane of the HBM layout (OOB_LANE: none)
   int ty[NT], tx[NT];
+};
+template <int NT>
+__device__ __forceinline__ void psa_tiles(const PsaArgs& a, int b, int t0, int cnt, int n, PsaTiles<NT>& T) {
+  const int N = a.H * a.W;
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int i = (t0 + nt) * 16 + n;
     T.ok[nt] = nt < cnt && i < N;
     T.pix[nt] = T.ok[nt] ? i : N - 1;
     const int y = T.pix[nt] / a.W, x = T.pix[nt] - y * a.W;
-    ty[nt] = y;
-    tx[nt] = x;
-    gpix[nt] = T.ok[nt] ? (unsigned)(a.g0 + b * a.img + y * a.W1 + x) * 16u : OOB_LANE;
+    T.ty[nt] = y;
+    T.tx[nt] = x;
+    T.gpix[nt] = T.ok[nt] ? (unsigned)(a.g0 + b * a.img + y * a.W1 + x) * 16u : OOB_LANE;
   }
+}
+
+// MTW tiles (m0 .. m0 + MTW - 1 of one 64-channel block of a packed 128-input-channel filter) x NT pixel tiles, K = 128
+template <int MTW, int NT>
+__device__ __forceinline__ void psa_conv128(f32x4 (&acc)[MTW][NT], const bf16x8* __restrict__ wblk, int m0, const float* bias, int g,
+                                            const bf16x8 (&bfr)[4][NT]) {
+#pragma unroll
+  for (int m = 0; m < MTW; ++m) {
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + chan_in_block(4, m0 + m, g, 0));
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[m][nt] = bv;
+  }
+  bf16x8 wa[4][MTW];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+    for (int m = 0; m < MTW; ++m) wa[ks][m] = wblk[(ks * 4 + m0 + m) * 64];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int m = 0; m < MTW; ++m) acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[ks][m], bfr[ks][nt], acc[m][nt], 0, 0, 0);
+}
+
+// NTA: tiles per wave of the key / value conv, which every workgroup of an image runs over ALL its pixels (a wave owns an eighth
+// of them); NTB: tiles per wave of this workgroup's OWN share of the image (queries, pe, proj, ffn), an eighth of that share.
+template <int NTA, int NTB>
+__device__ __forceinline__ void psa_body(const PsaArgs& a, unsigned char* lds, const PsaLds& L, int t0a, int cnta, int t0, int cnt, int b,
+                                         int tid, int lane, int wave, int n, int g) {
+  constexpr int NT = NTB;
+  const int N = a.H * a.W;
+  PsaTiles<NTA> TA;
+  PsaTiles<NT> T;
+  psa_tiles<NTA>(a, b, t0a, cnta, n, TA);
+  psa_tiles<NT>(a, b, t0, cnt, n, T);
   const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)a.b, (short)0, a.b_bytes, 0x00020000);
-  // (three identical loads of b -- the two heads' qkv convs and the residual stream -- 64 registers each: an opaque zero in
-  // the scalar offset keeps the compiler from merging them into ONE load that stays live through the whole kernel)
-  auto load_b = [&](bf16x8 (&dst)[4][NT]) __attribute__((always_inline)) {
+  // (the loads of b repeat -- both heads' convs and the residual stream: an opaque zero in the scalar offset keeps the compiler
+  // from merging them into ONE set of registers that stays live through the whole kernel)
+  auto load_b = [&](auto& dst, const auto& TT) __attribute__((always_inline)) {
     int zero = 0;
     asm volatile("" : "+s"(zero));
+    constexpr int NX = sizeof(TT.pix) / sizeof(int);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt)
+      for (int nt = 0; nt < NX; ++nt)
         dst[ks][nt] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
-                                                     rb, gpix[nt] == OOB_LANE ? OOB_LANE : (unsigned)(ks * 4 + g) * a.b_plane + gpix[nt], zero, 0));
+                                                     rb, TT.gpix[nt] == OOB_LANE ? OOB_LANE : (unsigned)(ks * 4 + g) * a.b_plane + TT.gpix[nt], zero, 0));
   };
   __bf16* const sK = reinterpret_cast<__bf16*>(lds + L.sk);
   __bf16* const sVt = reinterpret_cast<__bf16*>(lds + L.svt);
@@ -420,56 +455,60 @@ __device__ __forceinline__ void psa_body(const PsaArgs& a, unsigned char* lds, c
 
 #pragma unroll
   for (int h = 0; h < 2; ++h) {  // (unrolled: oh[h] must stay in registers)
-    // ---- qkv conv of head h: channel blocks 2 h (q | k) and 2 h + 1 (v) of the packed filter, K = 128
+    // ---- the head's part of the qkv conv (channel blocks 2 h = q | k and 2 h + 1 = v of the packed filter, K = 128): keys and
+    // values for ALL pixels (this wave: an eighth of them), queries for this workgroup's own pixels
     bf16x8 qf[NT];
+    const bf16x8* const wqk = reinterpret_cast<const bf16x8*>(a.w_qkv) + (size_t)(2 * h) * 4 * 4 * 64 + lane;
+    const bf16x8* const wv = wqk + 4 * 4 * 64;
+    {
+      bf16x8 bfr[4][NTA];
+      load_b(bfr, TA);
+      f32x4 acck[2][NTA];
+      psa_conv128<2, NTA>(acck, wqk, 2, a.b_qkv + (2 * h) * 64, g, bfr);
+      if (h == 1) __syncthreads();  // (B1) everybody is done with head 0's keys / values / output map
+#pragma unroll
+      for (int nt = 0; nt < NTA; ++nt) {
+        bf16x8 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          o[r] = (__bf16)acck[0][nt][r];
+          o[4 + r] = (__bf16)acck[1][nt][r];
+        }
+        if (TA.ok[nt]) *reinterpret_cast<bf16x8*>(sK + TA.pix[nt] * PS_KP + g * 8) = o;  // k: row = key, channels 8 g ..
+      }
+      f32x4 accv[4][NTA];
+      psa_conv128<4, NTA>(accv, wv, 0, a.b_qkv + (2 * h + 1) * 64, g, bfr);
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int nt = 0; nt < NTA; ++nt) {
+          bf16x8 o;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            o[r] = (__bf16)accv[2 * p][nt][r];
+            o[4 + r] = (__bf16)accv[2 * p + 1][nt][r];
+          }
+          if (TA.ok[nt]) {
+            *reinterpret_cast<bf16x8*>(vpl + (p * 4 + g) * vplane + TA.pix[nt] * 16) = o;  // v as planes (for pe)
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) sVt[((p * 4 + g) * 8 + jj) * L.vp + TA.pix[nt]] = o[jj];  // and transposed (for P.V)
+          }
+        }
+    }
     {
       bf16x8 bfr[4][NT];
-      load_b(bfr);
-      const bf16x8* wp = reinterpret_cast<const bf16x8*>(a.w_qkv) + (size_t)(2 * h) * 4 * 4 * 64 + lane;
-      bf16x8 wa[RC_D1][4];
-      preload1(wa, wp);
+      load_b(bfr, T);
+      f32x4 accq[2][NT];
+      psa_conv128<2, NT>(accq, wqk, 0, a.b_qkv + (2 * h) * 64, g, bfr);
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb) {
-        f32x4 acc[4][NT];
+      for (int nt = 0; nt < NT; ++nt) {
+        bf16x8 o;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
-          const f32x4 bv = *reinterpret_cast<const f32x4*>(a.b_qkv + (2 * h + cb) * 64 + chan_in_block(4, m, g, 0));
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) acc[m][nt] = bv;
+        for (int r = 0; r < 4; ++r) {
+          o[r] = (__bf16)accq[0][nt][r];
+          o[4 + r] = (__bf16)accq[1][nt][r];
         }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const int j = cb * 4 + ks;
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-              acc[m][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa[j % RC_D1][m], bfr[ks][nt], acc[m][nt], 0, 0, 0);
-          if (j + RC_D1 < 8) {
-#pragma unroll
-            for (int m = 0; m < 4; ++m) wa[j % RC_D1][m] = wp[((j + RC_D1) * 4 + m) * 64];
-          }
-        }
-        if (cb == 0 && h == 1) __syncthreads();  // (B1) everybody is done with head 0's keys / values / output map
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            bf16x8 o;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              o[r] = (__bf16)acc[2 * p][nt][r];
-              o[4 + r] = (__bf16)acc[2 * p + 1][nt][r];
-            }
-            if (cb == 0) {
-              if (p == 0) qf[nt] = T.ok[nt] ? o : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};     // q: channels 8 g .. of the lane's query
-              else if (T.ok[nt]) *reinterpret_cast<bf16x8*>(sK + T.pix[nt] * PS_KP + g * 8) = o;  // k: row = key
-            } else if (T.ok[nt]) {
-              *reinterpret_cast<bf16x8*>(vpl + (p * 4 + g) * vplane + T.pix[nt] * 16) = o;  // v as planes (for pe)
-#pragma unroll
-              for (int jj = 0; jj < 8; ++jj) sVt[((p * 4 + g) * 8 + jj) * L.vp + T.pix[nt]] = o[jj];  // and transposed (for P.V)
-            }
-          }
+        qf[nt] = T.ok[nt] ? o : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};  // q: channels 8 g .. of the lane's query
       }
     }
     PS_STAMP(1 + 5 * h);
@@ -576,16 +615,14 @@ __device__ __forceinline__ void psa_body(const PsaArgs& a, unsigned char* lds, c
         const int dy = t / 3 - 1, dx = t - 3 * (t / 3) - 1;
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-          const bool in = (unsigned)(ty[nt] + dy) < (unsigned)a.H && (unsigned)(tx[nt] + dx) < (unsigned)a.W;
-          // (an out-of-range tap reads the lane's own pixel and multiplies it by zero: fmaf(v, 0, acc) == acc, no branch)
-          const bf16x8 vv = *reinterpret_cast<const bf16x8*>(vpl + pl * vplane + (T.pix[nt] + (in ? dy * a.W + dx : 0)) * 16);
-          const float sel = in ? 1.0f : 0.0f;
+          const bool in = (unsigned)(T.ty[nt] + dy) < (unsigned)a.H && (unsigned)(T.tx[nt] + dx) < (unsigned)a.W;
+          // an out-of-range tap reads a zero (what dwconv3_kernel reads from the guard pixels) and goes through the same fma
+          const bf16x8 vv = *reinterpret_cast<const bf16x8*>(in ? vpl + pl * vplane + (T.pix[nt] + dy * a.W + dx) * 16 : lds + L.zslot);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            acc8[nt][j] = in ? __builtin_fmaf((float)vv[j], w0[j], acc8[nt][j]) : acc8[nt][j];
-            acc8[nt][4 + j] = in ? __builtin_fmaf((float)vv[4 + j], w1[j], acc8[nt][4 + j]) : acc8[nt][4 + j];
+            acc8[nt][j] = __builtin_fmaf((float)vv[j], w0[j], acc8[nt][j]);
+            acc8[nt][4 + j] = __builtin_fmaf((float)vv[4 + j], w1[j], acc8[nt][4 + j]);
           }
-          (void)sel;
         }
       }
 #pragma unroll
@@ -611,7 +648,7 @@ __device__ __forceinline__ void psa_body(const PsaArgs& a, unsigned char* lds, c
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_r*)(lds + pc * 1024), 16, (unsigned)(pc * 1024 + lane * 16), 0, 0, 0);
   }
   bf16x8 bp[4][NT];  // the residual stream b of this wave's pixels: first the block's input, then b + proj(o)
-  load_b(bp);
+  load_b(bp, T);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   PS_STAMP(11);
   __syncthreads();
@@ -720,7 +757,7 @@ __device__ __forceinline__ void psa_body(const PsaArgs& a, unsigned char* lds, c
           v[r] = acc1[2 * m2][q][r] + (float)rv[r];
           v[4 + r] = acc1[2 * m2 + 1][q][r] + (float)rv[4 + r];
         }
-        const unsigned gp = gpix[n0 + q];
+        const unsigned gp = T.gpix[n0 + q];
         __builtin_amdgcn_raw_buffer_store_b128(
             u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])}, rout,
             gp == OOB_LANE ? OOB_LANE : (unsigned)(m2 * 4 + g) * a.b_plane + gp, 0, 0);
@@ -730,7 +767,7 @@ __device__ __forceinline__ void psa_body(const PsaArgs& a, unsigned char* lds, c
 #undef PS_STAMP
 }
 
-template <int NTE>
+template <int NTA, int NTB>
 __global__ __launch_bounds__(RC_THREADS) void psa_resident_kernel(PsaArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char psm[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -738,16 +775,20 @@ __global__ __launch_bounds__(RC_THREADS) void psa_resident_kernel(PsaArgs a) {
   const int n = lane & 15, g = lane >> 4;
   const int N = a.H * a.W;
   const PsaLds L = psa_lds_plan(N);
-  // the transposed values' padding columns (keys N .. nk32 - 1) must read as zero: clear keys and values once
+  // the transposed values' padding columns (keys N .. nk32 - 1) and the zero slot must read as zero: clear the front once
   {
     const bf16x8 z = {};
-    for (int i = tid * 16; i < L.vpl; i += RC_THREADS * 16) *reinterpret_cast<bf16x8*>(psm + i) = z;
+    for (int i = tid * 16; i < L.zslot + 16; i += RC_THREADS * 16) *reinterpret_cast<bf16x8*>(psm + i) = z;
   }
   __syncthreads();
-  int t0, cnt;
-  even_split((N + 15) / 16, RC_WAVES, wave, t0, cnt);
-  if (cnt == NTE) psa_body<NTE>(a, psm, L, t0, cnt, blockIdx.x, tid, lane, wave, n, g);
-  else psa_body<(NTE > 1 ? NTE - 1 : 1)>(a, psm, L, t0, cnt, blockIdx.x, tid, lane, wave, n, g);
+  // a.split workgroups per image: each runs the key / value conv over the whole image and everything else on its share of the tiles
+  const int b = blockIdx.x / a.split, part = blockIdx.x - b * a.split;
+  const int ntiles = (N + 15) / 16;
+  int t0a, cnta, p0, pc, t0, cnt;
+  even_split(ntiles, RC_WAVES, wave, t0a, cnta);
+  even_split(ntiles, a.split, part, p0, pc);
+  even_split(pc, RC_WAVES, wave, t0, cnt);
+  psa_body<NTA, NTB>(a, psm, L, t0a, cnta, p0 + t0, cnt, b, tid, lane, wave, n, g);
 }
 
 bool psa_resident_fits(int c, int heads, int key_dim, int head_dim, int H, int W) {
@@ -755,11 +796,11 @@ bool psa_resident_fits(int c, int heads, int key_dim, int head_dim, int H, int W
   return c == 128 && heads == 2 && key_dim == 32 && head_dim == 64 && N >= 8 && N <= 400 && psa_lds_plan(N).total <= 160 * 1024;
 }
 
-template <int NTE>
+template <int NTA, int NTB>
 static int psa_launch_t(const PsaArgs& a, size_t lds, hipStream_t s) {
-  auto kern = psa_resident_kernel<NTE>;
+  auto kern = psa_resident_kernel<NTA, NTB>;
   if (int rc = allow_big_lds(reinterpret_cast<const void*>(kern), 160 * 1024)) return rc;
-  hipLaunchKernelGGL(kern, dim3((unsigned)a.B), dim3(RC_THREADS), lds, s, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.B * a.split)), dim3(RC_THREADS), lds, s, a);
   YL_HIP(hipGetLastError());
   return 0;
 }
@@ -770,15 +811,26 @@ int psa_resident_launch(const PsaArgs& a0, hipStream_t s) {
   if (!psa_resident_fits(128, 2, 32, 64, a.H, a.W)) return fail(-3, "psa_resident: the map does not fit one workgroup");
   const PsaLds L = psa_lds_plan(a.H * a.W);
   const int ntiles = (a.H * a.W + 15) / 16;
-  switch ((ntiles + 7) / 8) {
-    case 1: return psa_launch_t<1>(a, (size_t)L.total, s);
-    case 2: return psa_launch_t<2>(a, (size_t)L.total, s);
-    case 3: return psa_launch_t<3>(a, (size_t)L.total, s);
-    case 4: return psa_launch_t<4>(a, (size_t)L.total, s);
+  // Workgroups per image.  One workgroup per image is the cheapest in chip time (the key / value conv runs once), but a batch
+  // of 32 then occupies 32 of the 256 CUs for ~90 us; two halve that time for ~10 % more work (YL_PSA_SPLIT overrides).
+  const int split_env = getenv("YL_PSA_SPLIT") ? atoi(getenv("YL_PSA_SPLIT")) : 0;  // (read per launch: the tests switch it)
+  int split = split_env > 0 ? split_env : (ntiles > 16 ? 2 : 1);
+  if (split > ntiles) split = ntiles;
+  if (split < 1 || split > 4) split = 1;
+  while (split < 4 && ((ntiles + split - 1) / split + 7) / 8 > 2) ++split;  // the own share: at most two tiles per wave
+  a.split = split;
+  const int nta = (ntiles + 7) / 8, ntb = ((ntiles + split - 1) / split + 7) / 8;
+  switch (nta * 10 + ntb) {
+    case 11: return psa_launch_t<1, 1>(a, (size_t)L.total, s);
+    case 21: return psa_launch_t<2, 1>(a, (size_t)L.total, s);
+    case 22: return psa_launch_t<2, 2>(a, (size_t)L.total, s);
+    case 31: return psa_launch_t<3, 1>(a, (size_t)L.total, s);
+    case 32: return psa_launch_t<3, 2>(a, (size_t)L.total, s);
+    case 41: return psa_launch_t<4, 1>(a, (size_t)L.total, s);
+    case 42: return psa_launch_t<4, 2>(a, (size_t)L.total, s);
   }
   return fail(-3, "psa_resident: unsupported map size");
 }
-
 
 size_t c3k_resident_lds(int H, int W, int* xpl_out, int* apl_out, int* r1_out, int* ntiles_out) {
   const int ntiles = (H * W + 15) / 16;

@@ -356,6 +356,7 @@ struct PsaArgs {
   const float* b_ffn0;
   const float* b_ffn1;
   unsigned long long* stamps;  // diagnostic builds (-DYL_STAMPS)
+  int split;                   // workgroups per image (filled by psa_resident_launch)
 };
 bool psa_resident_fits(int c, int heads, int key_dim, int head_dim, int H, int W);
 int psa_resident_launch(const PsaArgs& a, hipStream_t s);
