@@ -52,7 +52,9 @@ enum {
                            `in` and `out` lives in LDS or registers; bit-identical to the six YL_OP_CONV ops it replaces.  */
   YL_OP_PSA = 11,     /* a PSABlock (nn/modules/block.py:919-953; Attention :863-916) with c = 128 channels, 2 heads, key_dim 32,
                          head_dim 64 on a map of at most 400 pixels (layer 10 of YOLO11n at 640x640), ONE launch, one workgroup per
-                         image (csrc/resident.hip): in == out = the block's residual stream b, rewritten in place:
+                         image or two (csrc/resident.hip): in = cat(a, b) = C2PSA.cv1's output (256 channels), out = cat(a, b') in
+                         a DIFFERENT buffer (the workgroups of an image read all of b at times of their own, so the input is
+                         never written; a is copied), b = the block's residual stream:
                            qkv = conv1x1(b) (weight / bias [256][128], no activation); per head o = v . softmax(q^T k * scale)^T;
                            o += dwconv3x3(v) (extra_weight[0] [128][1][3][3], the positional encoding); b += conv1x1(o)
                            (extra_weight[1] [128][128]); b += conv1x1(SiLU(conv1x1(b))) (extra_weight[2] [256][128],

@@ -129,10 +129,10 @@ def _rand_psa(gen, c=128):
                 ffn0=wb(2 * c, c, gain=1.4), ffn1=wb(c, 2 * c, gain=0.8))
 
 
-def _psa_ops(m, bview, blk, H, W, fused, c=128, nh=2, kd=32, hd=64):
+def _psa_ops(m, bview, blk, H, W, fused, c=128, nh=2, kd=32, hd=64, u=None, u2=None):
     scale = float(kd ** -0.5)
     if fused:
-        m.op(kind=OP_PSA, name="psa", act=0, heads=nh, key_dim=kd, head_dim=hd, scale=scale, inp=bview, out=bview,
+        m.op(kind=OP_PSA, name="psa", act=0, heads=nh, key_dim=kd, head_dim=hd, scale=scale, inp=u, out=u2,
              weight=_np(blk["qkv"][0].reshape(2 * c, -1)), bias=_np(blk["qkv"][1]),
              extra_weight=[_np(blk["pe"][0]), _np(blk["proj"][0].reshape(c, -1)), _np(blk["ffn0"][0].reshape(2 * c, -1)),
                            _np(blk["ffn1"][0].reshape(c, -1))],
@@ -168,17 +168,22 @@ def test_psa_resident_vs_chain_and_torch(gpu_device, B, H, W):
     gen = torch.Generator().manual_seed(77 * H + W)
     blk = _rand_psa(gen)
     x = bf16_round(torch.randn(B, 128, H, W, generator=gen))
+    xa = bf16_round(torch.randn(B, 128, H, W, generator=gen))
     got = {}
     for fused in (True, False):
         m = Mini(B, gpu_device)
-        u = m.buf(H, W, 256)
+        u, u2 = m.buf(H, W, 256), m.buf(H, W, 256)
         bv = u.slice(128, 128)  # the block works on the second half of C2PSA.cv1's output (block.py:1035-1037)
+        m.fill(u.slice(0, 128), xa)
         m.fill(bv, x)
-        _psa_ops(m, bv, blk, H, W, fused)
+        _psa_ops(m, bv, blk, H, W, fused, u=u, u2=u2)
         m.run()
-        if fused:
+        if fused:  # in -> out: cat(a, b') in the second buffer, the input untouched
             assert m.eng.op_kernel(0) == "psa_resident_mfma"
-        got[fused] = m.read(bv)
+            assert torch.equal(m.read(u2.slice(0, 128)), xa) and torch.equal(m.read(bv), x)
+            got[fused] = m.read(u2.slice(128, 128))
+        else:
+            got[fused] = m.read(bv)
     assert torch.equal(got[True], got[False]), f"max |d| {float((got[True] - got[False]).abs().max())}"
     ref = _torch_psa(x, blk)
     err = (got[True] - ref).abs()

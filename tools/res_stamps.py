@@ -38,10 +38,10 @@ def psa(B=32, H=20, W=20, iters=5):
     gen = torch.Generator().manual_seed(0)
     blk = _rand_psa(gen)
     m = Mini(B, dev)
-    u = m.buf(H, W, 256)
+    u, u2 = m.buf(H, W, 256), m.buf(H, W, 256)
     bv = u.slice(128, 128)
     m.fill(bv, bf16_round(torch.randn(B, 128, H, W, generator=gen)))
-    _psa_ops(m, bv, blk, H, W, True)
+    _psa_ops(m, bv, blk, H, W, True, u=u, u2=u2)
     buf = torch.zeros(4 * B * 8 * 32 * 2, dtype=torch.int64, device=dev)
     L = _lib.lib()
     if not L.yl_diag_set_stamps(C.c_void_p(buf.data_ptr())):

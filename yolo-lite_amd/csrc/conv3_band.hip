@@ -121,6 +121,10 @@ __device__ __forceinline__ void band_compute(const BandArgs& a, unsigned char* l
     }
 #endif
   }
+  // the ring's last refills moved nothing (slices past the end resolve to the out-of-range offset), but an LDS-DMA operation
+  // that is still in flight when the workgroup ends would land -- as zeros -- in LDS that already belongs to another workgroup:
+  // they must retire here (found by tests/test_gpu_net.py::test_twenty_batches_in_flight: boxes of OTHER batches moved)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   YL_STAMP(a.stamps, 8, wave, lane, 3);
   if constexpr (POST) {
     unsigned char* const mid = ring + BD_NS * BD_SLICE;  // [8 planes][ntiles * 16 px][16 B]

@@ -578,14 +578,15 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
         break;
       }
       case YL_OP_PSA: {
-        const int c = o.in.C;
+        const int c = o.in.C / 2;  // in / out = cat(a, b): the block works on b and copies a
         if (!o.weight || !o.bias || o.n_extra != 4 || !o.extra_weight || !o.extra_bias)
           return fail(-1, tag + ": psa needs the qkv filter and four extra filters (pe, proj, ffn.0, ffn.1)");
         for (int q = 0; q < 4; ++q)
           if (!o.extra_weight[q] || !o.extra_bias[q]) return fail(-1, tag + ": psa: null extra filter");
-        if (o.in.dtype != YL_BF16 || o.out.dtype != YL_BF16 || o.in.offset != o.out.offset || o.in.coff != o.out.coff || o.out.C != c ||
-            o.lane != 0 || !psa_resident_fits(c, o.heads, o.key_dim, o.head_dim, o.in.H, o.in.W))
-          return fail(-3, tag + ": psa: in == out, 128 channels, 2 heads (key_dim 32, head_dim 64), at most 400 pixels per image");
+        if (o.in.dtype != YL_BF16 || o.out.dtype != YL_BF16 || o.in.offset == o.out.offset || o.out.C != 2 * c || o.in.C != 2 * c ||
+            o.in.H != o.out.H || o.in.W != o.out.W || o.lane != 0 || !psa_resident_fits(c, o.heads, o.key_dim, o.head_dim, o.in.H, o.in.W))
+          return fail(-3, tag + ": psa: in and out are DIFFERENT buffers of 256 channels (cat(a, b)), 2 heads (key_dim 32, head_dim 64), "
+                            "at most 400 pixels per image");
         auto pack = [&](const float* w, int cout, int cin, std::vector<uint16_t>* pk) {
           ConvConfig cc{};
           cc.MT = 4;
@@ -628,7 +629,7 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
         }
         const double n_tok = (double)o.in.H * o.in.W;
         r.flops = 2.0 * px_out * (2.0 * c * c + c * c + 4.0 * c * c + 9.0 * c) + 2.0 * batch * o.heads * n_tok * n_tok * (o.key_dim + o.head_dim);
-        r.bytes = px_out * 2.0 * c * 2 + 2.0 * (7.0 * c * c);
+        r.bytes = px_out * 4.0 * c * 2 + 2.0 * (7.0 * c * c);
         r.name = "psa_resident_mfma";
         break;
       }
@@ -1070,9 +1071,12 @@ static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s, c
     case YL_OP_PSA: {
       PsaArgs q{};
       const Geo gq = geo_of(B, o.in.H, o.in.W);
-      const long long nb = (long long)(o.in.C / 8) * plane_bytes(gq);
-      if (nb > (1LL << 30)) return fail(-3, "psa: a tensor slice exceeds 1 GiB; lower the batch size");
-      q.b = pview(ws, o.in, B).base;
+      const long long nb = (long long)(o.in.C / 16) * plane_bytes(gq);  // bytes of ONE half (a or b)
+      if (2 * nb > (1LL << 30)) return fail(-3, "psa: a tensor slice exceeds 1 GiB; lower the batch size");
+      q.a_in = pview(ws, o.in, B).base;
+      q.a_out = pview(ws, o.out, B).base;
+      q.b = reinterpret_cast<const __bf16*>(reinterpret_cast<const char*>(q.a_in) + nb);
+      q.b_out = reinterpret_cast<__bf16*>(reinterpret_cast<char*>(q.a_out) + nb);
       q.b_plane = (unsigned)plane_bytes(gq);
       q.b_bytes = (unsigned)nb;
       q.B = B;

@@ -341,6 +341,7 @@ __global__ __launch_bounds__(RC_THREADS) void c3k_resident_kernel(C3kArgs a) {
 //     o   = o + dwconv3x3(v)                                           the positional encoding `pe` (block.py:913)
 //     b   = b + conv1x1(o)           (`proj`, 128 -> 128)              PSABlock.forward: x = x + attn(x)
 //     b   = b + conv1x1(SiLU(conv1x1(b)))  (`ffn`: 128 -> 256 -> 128)  x = x + ffn(x)
+// Input: cat(a, b) = C2PSA.cv1's output; output: cat(a, b') in a second buffer (the input is never written, see psa_body).
 //
 // Eight waves; wave w owns an EIGHTH of the image's 16-pixel tiles from the first conv to the last store -- everything after
 // the attention is pointwise, so the tensors between proj, ffn.0 and ffn.1 never leave that wave's registers (the accumulator
@@ -452,6 +453,26 @@ __device__ __forceinline__ void psa_body(const PsaArgs& a, unsigned char* lds, c
   bf16x8 oh[2][2][NT];  // [head][k-step within the head][tile]: attention output + pe as proj's B fragments
 #define PS_STAMP(id) YL_STAMP(a.stamps, RC_WAVES, wave, lane, id)
   PS_STAMP(0);
+  // The block's input is never written: the workgroups of one image all read the whole residual stream b (keys and values) at
+  // times of their own, so the result goes to a SECOND buffer -- and the untouched half `a` of C2PSA.cv1's output is copied
+  // there for this workgroup's pixels, so that C2PSA.cv2 finds cat(a, b) in one place (block.py:1035-1038).
+  {
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)a.a_in, (short)0, a.b_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rao = __builtin_amdgcn_make_buffer_rsrc((void*)a.a_out, (short)0, a.b_bytes, 0x00020000);
+    bf16x8 av[4][NT];  // lane (n, g): planes g, 4 + g, 8 + g, 12 + g of its pixel
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        av[q][nt] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                                                   ra, T.gpix[nt] == OOB_LANE ? OOB_LANE : (unsigned)(q * 4 + g) * a.b_plane + T.gpix[nt], 0, 0));
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, av[q][nt]), rao,
+                                               T.gpix[nt] == OOB_LANE ? OOB_LANE : (unsigned)(q * 4 + g) * a.b_plane + T.gpix[nt], 0, 0);
+  }
 
 #pragma unroll
   for (int h = 0; h < 2; ++h) {  // (unrolled: oh[h] must stay in registers)
@@ -694,7 +715,7 @@ __device__ __forceinline__ void psa_body(const PsaArgs& a, unsigned char* lds, c
   }
   PS_STAMP(13);
   // ---- b = b + ffn.1(SiLU(ffn.0(b))), two pixel tiles at a time: ffn.0's 64-channel blocks feed ffn.1's k-steps in order
-  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)a.b, (short)0, a.b_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void*)a.b_out, (short)0, a.b_bytes, 0x00020000);
 #pragma unroll
   for (int n0 = 0; n0 < NT; n0 += 2) {  // (unrolled: bp[..][n0 + q] must stay in registers)
     __builtin_amdgcn_sched_barrier(0);

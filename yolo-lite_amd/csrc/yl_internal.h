@@ -343,7 +343,10 @@ int conv3_band64_launch(const BandArgs* args, int n, int batch, int post, hipStr
 
 // resident.hip: the PSABlock of a C2PSA layer (c = 128, two heads) in one launch, one workgroup per image
 struct PsaArgs {
-  __bf16* b;                // first plane of the block's residual stream (128 channels), read and rewritten in place
+  const __bf16* b;          // first plane of the block's residual stream in the INPUT buffer (128 channels; never written)
+  __bf16* b_out;            // ... in the output buffer
+  const __bf16* a_in;       // first plane of the other half of C2PSA.cv1's output (128 channels): copied to a_out
+  __bf16* a_out;
   unsigned b_plane, b_bytes;
   int B, H, W, W1, img, g0;
   float scale;              // attention score scale (key_dim ** -0.5)

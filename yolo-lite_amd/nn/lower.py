@@ -879,9 +879,13 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
                         xw.append(wj.reshape(wj.shape[0], -1) if wj.shape[2] == 1 else wj)
                         xb.append(bj)
                         names.append(q + part)
+                    # (in -> out, never in place: cat(a, b) of this block's input buffer becomes cat(a, b') in a fresh one)
+                    u2 = ar.alloc(src.H, src.W, 2 * c)
                     ops.append(dict(kind=OP_PSA, name=q, act=0, heads=nh, key_dim=kd, head_dim=hd, scale=float(kd ** -0.5),
-                                    inp=b, out=b, res=None, weight=wq.reshape(wq.shape[0], -1), bias=bq, extra_weight=xw,
+                                    inp=u, out=u2, res=None, weight=wq.reshape(wq.shape[0], -1), bias=bq, extra_weight=xw,
                                     extra_bias=xb, fused_names=names))
+                    u = u2
+                    b = u.slice(c, c)
                     continue
                 qkv = ar.alloc(src.H, src.W, c + 2 * nh * kd)
                 conv(q + ".attn.qkv", b, qkv, 1, 1, act=False)
