@@ -172,6 +172,24 @@ __device__ __forceinline__ void bitonic_sort(unsigned long long* k, int np, int 
   }
 }
 
+// Sort of at most 1024 keys held in LDS by RANK: thread i counts the keys smaller than its own (every real key is unique: its
+// low word is the candidate's index) and writes it to that slot of `out`; the sentinels ~0 of rejected candidates are equal to
+// each other and stay where the pre-fill put them, behind the real keys.  One barrier instead of the bitonic network's
+// log^2(n) / 2 (55 at 1024 keys): 9 -> 2 us per image at ~130 candidates (YOLO11n batch 32).  Same total order, same result.
+__device__ __forceinline__ void rank_sort(const unsigned long long* k, unsigned long long* out, int n, int tid) {
+  if (tid < n) out[tid] = ~0ull;
+  __syncthreads();
+  if (tid < n) {
+    const unsigned long long x = k[tid];
+    if (x != ~0ull) {
+      int r = 0;
+      for (int j = 0; j < n; ++j) r += k[j] < x ? 1 : 0;
+      out[r] = x;
+    }
+  }
+  __syncthreads();
+}
+
 // (a device function so that the one-launch path, decode_nms_fused_kernel, runs the very same code per image)
 __device__ __forceinline__ void nms_sort_body(const float* __restrict__ pred, int nc, int A, int agnostic, float max_wh,
                                               const NmsWs& w, int b, int tid, unsigned long long* sk, int& s_nvalid) {
@@ -221,7 +239,13 @@ __device__ __forceinline__ void nms_sort_body(const float* __restrict__ pred, in
   }
   if (tid == 0) s_nvalid = 0;
   __syncthreads();
-  if (n > 1) bitonic_sort(k, np, tid, 1024);
+  static_assert(SORT_LDS_KEYS >= 2048, "rank_sort writes its output behind the input keys");
+  if (n > 1 && n <= 1024 && k == sk) {
+    rank_sort(sk, sk + 1024, n, tid);
+    k = sk + 1024;
+  } else if (n > 1) {
+    bitonic_sort(k, np, tid, 1024);
+  }
   // sentinels (fused path: anchors the exact test rejected) sort last: count the real keys
   for (int i = tid; i < n; i += 1024)
     if (k[i] != ~0ull && (i + 1 == n || k[i + 1] == ~0ull)) s_nvalid = i + 1;
@@ -611,8 +635,29 @@ __device__ __forceinline__ void decode_anchor_thread(const DecCandArgs& a, const
 __device__ __forceinline__ void decode_anchor_quad(const DecCandArgs& a, const NmsWs& w, int b, int an, int key_slot, int side) {
   const DcAnchor d = dc_anchor(a, b, an);
   const int nplanes = (a.nc + 7) >> 3;
+  // every load of the lane is requested up front -- its class planes (side, side + 4, ...: up to QP of them are kept in
+  // registers for both passes) and its two DFL planes -- so that the quad pays ONE memory round trip instead of three (first
+  // class pass, second class pass, box planes); the arithmetic is unchanged
+  constexpr int QP = 4;
+  float cv[QP][8], l8[8], h8[8];
+#pragma unroll
+  for (int q = 0; q < QP; ++q) {
+    const int c8 = side + 4 * q;
+    if (c8 < nplanes) level_load8(d.L.cls, c8, d.pix, cv[q]);
+  }
+  level_load8(d.L.box, 2 * side, d.pix, l8);
+  level_load8(d.L.box, 2 * side + 1, d.pix, h8);
   float m = -__builtin_huge_valf();
-  for (int c8 = side; c8 < nplanes; c8 += 4) {
+#pragma unroll
+  for (int q = 0; q < QP; ++q) {
+    const int c8 = side + 4 * q;
+    if (c8 < nplanes) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (c8 * 8 + j < a.nc) m = fmaxf(m, cv[q][j]);
+    }
+  }
+  for (int c8 = side + 4 * QP; c8 < nplanes; c8 += 4) {  // (more than 128 classes: the remaining planes, not cached)
     float v[8];
     level_load8(d.L.cls, c8, d.pix, v);
 #pragma unroll
@@ -626,9 +671,7 @@ __device__ __forceinline__ void decode_anchor_quad(const DecCandArgs& a, const N
   const bool all = sigmoid_score(lo) == top;  // the window does not separate: evaluate every class
   float best = -1.f;
   int bi = 0x7fffffff;
-  for (int c8 = side; c8 < nplanes; c8 += 4) {
-    float v[8];
-    level_load8(d.L.cls, c8, d.pix, v);
+  auto scan8 = [&](int c8, const float (&v)[8]) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int c = c8 * 8 + j;
@@ -640,6 +683,16 @@ __device__ __forceinline__ void decode_anchor_quad(const DecCandArgs& a, const N
         }
       }
     }
+  };
+#pragma unroll
+  for (int q = 0; q < QP; ++q) {
+    const int c8 = side + 4 * q;
+    if (c8 < nplanes) scan8(c8, cv[q]);
+  }
+  for (int c8 = side + 4 * QP; c8 < nplanes; c8 += 4) {
+    float v[8];
+    level_load8(d.L.cls, c8, d.pix, v);
+    scan8(c8, v);
   }
 #pragma unroll
   for (int off = 1; off <= 2; off <<= 1) {
@@ -652,9 +705,7 @@ __device__ __forceinline__ void decode_anchor_quad(const DecCandArgs& a, const N
   }
   float dist = 0.f;
   if (best > a.conf_thres) {  // (uniform over the four lanes)
-    float v[16], l8[8], h8[8];
-    level_load8(d.L.box, 2 * side, d.pix, l8);
-    level_load8(d.L.box, 2 * side + 1, d.pix, h8);
+    float v[16];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       v[j] = l8[j];
