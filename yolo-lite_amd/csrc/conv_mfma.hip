@@ -992,9 +992,9 @@ int dwpw_launch(const ConvConfig& cfg0, ConvArgs a, int batch, hipStream_t s) {
   return fail(-3, "dwpw: unsupported tile shape");
 }
 
-template <int MT, int NT>
+template <int MT, int NT, bool PW2 = true>
 static int launch_dwpw_group(const ConvGroup& G, int grid, size_t lds, hipStream_t s) {
-  auto kern = dwpw_group_kernel<MT, NT, true>;
+  auto kern = dwpw_group_kernel<MT, NT, PW2>;
   if (int rc = allow_big_lds(reinterpret_cast<const void*>(kern), (int)((int)LDS_MAX))) return rc;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, G);
   YL_HIP(hipGetLastError());
@@ -1013,11 +1013,13 @@ int dwpw_group_launch(const ConvConfig* cfg0, const ConvArgs* args, int n, int b
     size_t l = 0;
     if (int rc = dwpw_prepare(cfg, G.a[i], batch, &l)) return rc;  // (may retile: YL_DWPW_NT)
     if (i == 0) nt0 = cfg.NT;
-    if (cfg.MT != 5 || cfg.NT != nt0 || !G.a[i].wpk2) return fail(-3, "dwpw group: members need one tiling and a fused tail");
+    if (cfg.MT != 5 || cfg.NT != nt0 || (G.a[i].wpk2 != nullptr) != (G.a[0].wpk2 != nullptr))
+      return fail(-3, "dwpw group: members need one tiling and all of them, or none, a fused tail");
     G.nb[i] = G.a[i].nblocks;
     grid += G.nb[i];
     lds = l > lds ? l : lds;
   }
+  if (!G.a[0].wpk2) return nt0 == 1 ? launch_dwpw_group<5, 1, false>(G, grid, lds, s) : launch_dwpw_group<5, 2, false>(G, grid, lds, s);
   return nt0 == 1 ? launch_dwpw_group<5, 1>(G, grid, lds, s) : launch_dwpw_group<5, 2>(G, grid, lds, s);
 }
 

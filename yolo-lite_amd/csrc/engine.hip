@@ -767,7 +767,8 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
       ok = ok && nc <= 3 && nd <= 3;
       if (ok && nc && nd)  // mixed launch: the convs carry a fused 1x1 exactly when the depthwise members carry a tail
         ok = (e->ops[i].cfg.post != 0) == (e->ops[i + nc].d_wpk3 != nullptr);
-      if (ok && !nc && !e->ops[i].d_wpk3) ok = false;  // (a depthwise-only group exists for the tailed form only)
+      // (a depthwise-only group without the tail: the class branch's first halves of levels 0 and 1 -- opt-in from the lowering,
+      // YL_GROUP_CLS0=1; dwpw_group_launch takes both forms)
       // Two plain convs with a deep K and 64 output channels on small maps (Detect's first box convs on the 40x40 and 20x20 levels,
       // 128 -> 64 and 256 -> 64): conv3_band_kernel -- the input band in LDS, the filter streamed from L2 -- instead of
       // conv_group_kernel, which restages the 144 / 288 KB filters per 256 pixels (YL_CONV_BAND=0: off)
@@ -839,11 +840,12 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
         static const char* const cn[2][3] = {{"conv3x3_mfma[x1]", "conv3x3_mfma[x2]", "conv3x3_mfma[x3]"},
                                              {"conv3x3+1x1_mfma[x1]", "conv3x3+1x1_mfma[x2]", "conv3x3+1x1_mfma[x3]"}};
         static const char* const dn[3] = {"dw3x3+pw1x1+1x1_mfma[x1]", "dw3x3+pw1x1+1x1_mfma[x2]", "dw3x3+pw1x1+1x1_mfma[x3]"};
+        static const char* const dn0[3] = {"dw3x3+pw1x1_mfma[x1]", "dw3x3+pw1x1_mfma[x2]", "dw3x3+pw1x1_mfma[x3]"};
         static const char* const hn[2] = {"head:conv3x3|dw3x3+pw1x1_mfma", "head:conv3x3+1x1|dw3x3+pw1x1+1x1_mfma"};
         for (size_t k = i; k < j; ++k) {
           OpRec& r = e->ops[k];
           r.group_n = k == i ? n : -1;
-          r.name = k != i ? "(in the group launch)" : (nc && nd) ? hn[r.cfg.post ? 1 : 0] : nc ? cn[r.cfg.post ? 1 : 0][nc - 1] : dn[nd - 1];
+          r.name = k != i ? "(in the group launch)" : (nc && nd) ? hn[r.cfg.post ? 1 : 0] : nc ? cn[r.cfg.post ? 1 : 0][nc - 1] : (e->ops[i].d_wpk3 ? dn[nd - 1] : dn0[nd - 1]);
         }
       }
     }

@@ -623,6 +623,11 @@ def group_detect_levels(ops: List[dict], det_prefix: str, nlv: int, keep_first_b
             for o in by_role[2] + by_role[3]:
                 o["group"] = 2
         return rest + by_role[0][2:] + by_role[1] + by_role[0][:2] + by_role[2] + by_role[3]
+    if os.environ.get("YL_GROUP_CLS0", "0") == "1" and nlv >= 2:
+        # the first halves of the class branch on levels 0 and 1 as one launch (level 2's 256 input channels would charge its
+        # LDS tile to every workgroup: it keeps its own launch)
+        for o in by_role[0][:2]:
+            o["group"] = 4
     for r in (1, 2, 3):  # role 0 (first half of the class branch) differs in width per level: separate launches
         for lvl, o in enumerate(by_role[r]):
             if not (keep_first_box_conv and r == 1 and lvl == 0):  # (level 0's first box conv may keep its own kernel)
