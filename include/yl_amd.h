@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define YL_ABI_VERSION 17
+#define YL_ABI_VERSION 18
 
 /* element types */
 enum { YL_BF16 = 0, YL_F32 = 1, YL_F16 = 2, YL_U8 = 3, YL_FP8 = 4 /* OCP e4m3 */ };
@@ -60,6 +60,13 @@ enum {
                            (extra_weight[1] [128][128]); b += conv1x1(SiLU(conv1x1(b))) (extra_weight[2] [256][128],
                            extra_weight[3] [128][256]); heads / key_dim / head_dim / scale as YL_OP_ATTENTION.  Bit-identical to the
                            six ops it replaces (YL_OP_CONV, YL_OP_ATTENTION, YL_OP_DWCONV3 with accumulate, three YL_OP_CONV). */
+  YL_OP_SPPF = 12,    /* a whole SPPF layer (nn/modules/block.py:165-184) with 256 channels in and out (hidden width 128: YOLO11n's
+                         layer 9) on a map of at most 448 pixels and, optionally, the 1x1 conv that alone consumes its output (C2PSA.cv1,
+                         block.py:1009-1038, 256 -> 256), ONE launch, one or two workgroups per image (csrc/sppf_resident.hip):
+                           x = SiLU(cv1(in)) (weight / bias [128][256]); y5, y9, y13 = the three chained 5x5 max pools of x;
+                           s = SiLU(cv2(cat(x, y5, y9, y13))) (extra_weight[0] [256][512]); out = s, or with n_extra = 2
+                           out = SiLU(conv1x1(s)) (extra_weight[1] [256][256]) and s is never stored.  x and the pooled maps live in
+                           LDS; bit-identical to the YL_OP_CONV, YL_OP_SPPF_POOL, YL_OP_CONV [, YL_OP_CONV] ops it replaces.        */
   YL_OP_C3K2S = 7     /* body of a narrow C3k2 block in one launch (nn/modules/block.py:220-235, 330-343), half width
                          c = 16 or 32: `in` = the block's concat buffer [a | b | ...] (a, b = halves of C3k2.cv1's output,
                          c channels each); c_out = b + SiLU(cv2(SiLU(cv1(b)))) with the Bottleneck's two 3x3 convs

@@ -8,7 +8,8 @@ import torch.nn.functional as F
 from hip_util import Mini, bf16_round
 from yololite_amd.nn import arch
 from yololite_amd.nn.engine import HipEngine
-from yololite_amd.nn.lower import OP_ATTENTION, OP_C3K, OP_CONV, OP_DWCONV3, OP_PSA, c3k_resident_fits, psa_resident_fits
+from yololite_amd.nn.lower import (OP_ATTENTION, OP_C3K, OP_CONV, OP_DWCONV3, OP_PSA, OP_SPPF, OP_SPPF_POOL, c3k_resident_fits,
+                                   psa_resident_fits, sppf_resident_fits)
 from yololite_amd.nn.synth import synth_state_dict
 
 pytestmark = pytest.mark.gpu
@@ -206,6 +207,88 @@ def test_network_with_resident_psa_is_bit_identical(gpu_device, monkeypatch, h, 
     ref = HipEngine.from_model(specs, sd, b, h, w, gpu_device)
     assert "psa_resident_mfma" not in [ref.op_kernel(i) for i in range(len(ref.prog.ops))]
     assert len(ref.prog.ops) == len(eng.prog.ops) + 5
+    assert torch.equal(y, ref.forward(x))
+    for p, q in zip(lv, ref.raw_levels()):
+        assert torch.equal(p, q)
+
+
+# ------------------------------------------------------------------------------------------------ SPPF (+ C2PSA.cv1)
+def _rand_sppf(gen):
+    def wb(co, ci, gain):
+        w = bf16_round(torch.randn(co, ci, 1, 1, generator=gen) * (gain / ci ** 0.5))
+        return w, torch.randn(co, generator=gen) * 0.2
+
+    return dict(cv1=wb(128, 256, 1.6), cv2=wb(256, 512, 1.6), tail=wb(256, 256, 1.6))
+
+
+def _torch_sppf(x, blk, tail):
+    """fp32 SPPF (block.py:165-184) [+ the 1x1 conv behind it], stored tensors rounded to bf16 like the HIP path's."""
+    def conv(t, wb_):
+        return bf16_round(F.silu(F.conv2d(t, *wb_)))
+
+    y = [conv(x, blk["cv1"])]
+    for _ in range(3):
+        y.append(F.max_pool2d(y[-1], 5, 1, 2))
+    s = conv(torch.cat(y, 1), blk["cv2"])
+    return conv(s, blk["tail"]) if tail else s
+
+
+@pytest.mark.parametrize("tail", [True, False])
+@pytest.mark.parametrize("B,H,W", [(2, 20, 20), (3, 12, 20), (1, 10, 10), (2, 5, 7), (2, 16, 16), (1, 19, 19), (2, 3, 3), (1, 1, 1), (2, 21, 21), (1, 13, 32)])
+def test_sppf_resident_vs_chain_and_torch(gpu_device, B, H, W, tail):
+    """SPPF [+ the follow-up 1x1 conv] in one launch == its three [four] launches, every bit; both close to torch fp32.  Sizes: one
+    to four cv1 tiles per wave, one and two workgroups per image, ragged last tiles, maps smaller than the 13x13 window, waves
+    without any tile."""
+    assert sppf_resident_fits(256, 256, 256 if tail else 0, H, W)
+    gen = torch.Generator().manual_seed(31 * H + W)
+    blk = _rand_sppf(gen)
+    x = bf16_round(torch.randn(B, 256, H, W, generator=gen))
+    got = {}
+    for fused in (True, False):
+        m = Mini(B, gpu_device)
+        tin = m.buf(H, W, 512)  # the layer reads a channel slice of a wider buffer
+        xin = tin.slice(256, 256)
+        out = m.buf(H, W, 256)
+        m.fill(xin, x)
+        if fused:
+            m.op(kind=OP_SPPF, name="sppf", act=1, inp=xin, out=out, weight=_np(blk["cv1"][0].reshape(128, -1)), bias=_np(blk["cv1"][1]),
+                 extra_weight=[_np(blk["cv2"][0].reshape(256, -1))] + ([_np(blk["tail"][0].reshape(256, -1))] if tail else []),
+                 extra_bias=[_np(blk["cv2"][1])] + ([_np(blk["tail"][1])] if tail else []))
+        else:
+            sbuf = m.buf(H, W, 512)
+            mid = m.buf(H, W, 256) if tail else out
+            m.op(kind=OP_CONV, name="cv1", k=1, stride=1, act=1, inp=xin, out=sbuf.slice(0, 128), weight=_np(blk["cv1"][0]), bias=_np(blk["cv1"][1]))
+            m.op(kind=OP_SPPF_POOL, name="m", inp=sbuf.slice(0, 128), out=sbuf.slice(0, 128))
+            m.op(kind=OP_CONV, name="cv2", k=1, stride=1, act=1, inp=sbuf, out=mid, weight=_np(blk["cv2"][0]), bias=_np(blk["cv2"][1]))
+            if tail:
+                m.op(kind=OP_CONV, name="tail", k=1, stride=1, act=1, inp=mid, out=out, weight=_np(blk["tail"][0]), bias=_np(blk["tail"][1]))
+        m.run()
+        if fused:
+            assert m.eng.op_kernel(0) == "sppf_resident_mfma"
+            assert torch.equal(m.read(xin), x)
+        got[fused] = m.read(out)
+    assert torch.equal(got[True], got[False]), f"max |d| {float((got[True] - got[False]).abs().max())}"
+    ref = _torch_sppf(x, blk, tail)
+    err = (got[True] - ref).abs()
+    assert float(err.max()) <= 0.03 * max(1.0, float(ref.abs().max())), (float(err.max()), float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("h,w,b", [(640, 640, 8), (384, 640, 8), (320, 320, 9), (640, 640, 32)])
+def test_network_with_resident_sppf_is_bit_identical(gpu_device, monkeypatch, h, w, b):
+    """YOLO11n with layer 9 and layer 10's first conv as ONE launch against the program with the four launches: level maps and
+    decoded predictions, every bit."""
+    sd = synth_state_dict("n", 6, cls_bias=[-2.0, -2.0, -2.0], cls_gain=4.0)
+    x = torch.randint(0, 256, (b, 3, h, w), generator=torch.Generator().manual_seed(h + 3 * w), dtype=torch.uint8).to(gpu_device)
+    specs, _ = arch.parse_model(arch.yolo11_dict("n"))
+    monkeypatch.setenv("YL_FUSE_SPPF", "1")
+    eng = HipEngine.from_model(specs, sd, b, h, w, gpu_device)
+    assert [eng.op_kernel(i) for i in range(len(eng.prog.ops))].count("sppf_resident_mfma") == 1
+    y = eng.forward(x).clone()
+    lv = [t.clone() for t in eng.raw_levels()]
+    monkeypatch.setenv("YL_FUSE_SPPF", "0")
+    ref = HipEngine.from_model(specs, sd, b, h, w, gpu_device)
+    assert "sppf_resident_mfma" not in [ref.op_kernel(i) for i in range(len(ref.prog.ops))]
+    assert len(ref.prog.ops) == len(eng.prog.ops) + 3
     assert torch.equal(y, ref.forward(x))
     for p, q in zip(lv, ref.raw_levels()):
         assert torch.equal(p, q)

@@ -215,18 +215,37 @@ def test_c3k_resident_limits():
     assert not c3k_resident_fits(32, 20, 20) and not c3k_resident_fits(128, 10, 10)  # inner width 64 only
 
 
+def test_sppf_resident_limits():
+    """Which SPPF layers the resident kernel takes (mirror of sppf_resident_fits in csrc/sppf_resident.hip)."""
+    from yololite_amd.nn.lower import sppf_resident_fits
+
+    assert sppf_resident_fits(256, 256, 256, 20, 20) and sppf_resident_fits(256, 256, 0, 12, 20) and sppf_resident_fits(256, 256, 256, 21, 21)
+    assert not sppf_resident_fits(256, 256, 256, 22, 22) and not sppf_resident_fits(256, 256, 0, 40, 40)  # LDS: 16 planes + the filter ring
+    assert not sppf_resident_fits(512, 512, 512, 20, 20) and not sppf_resident_fits(256, 256, 128, 20, 20)  # YOLO11n's widths only
+
+
 def test_lowering_uses_resident_c3k_from_batch_8(monkeypatch):
     from yololite_amd.nn import arch
-    from yololite_amd.nn.lower import OP_C3K, OP_PSA, lower
+    from yololite_amd.nn.lower import OP_C3K, OP_PSA, OP_SPPF, lower
     from yololite_amd.nn.synth import synth_state_dict
 
     monkeypatch.delenv("YL_FUSE_C3K", raising=False)
+    monkeypatch.delenv("YL_FUSE_SPPF", raising=False)
     specs, _ = arch.parse_model(arch.yolo11_dict("n"))
     sd = synth_state_dict("n", 0)
     big = lower(specs, sd, 32, 640, 640)
     assert [o["name"] for o in big.ops if o["kind"] == OP_C3K] == ["model.8.m.0", "model.22.m.0"]
     assert [o["name"] for o in big.ops if o["kind"] == OP_PSA] == ["model.10.m.0"]
+    sppf = [o for o in big.ops if o["kind"] == OP_SPPF]  # layer 9 with C2PSA.cv1 behind it: its own output is never stored
+    assert [o["name"] for o in sppf] == ["model.9"] and len(sppf[0]["extra_weight"]) == 2
+    assert sppf[0]["fused_names"] == ["model.9.cv1", "model.9.m", "model.9.cv2", "model.10.cv1"]
+    assert sppf[0]["out"] == [o for o in big.ops if o["kind"] == OP_PSA][0]["inp"]
+    assert not [o for o in big.ops if o["name"] == "model.10.cv1"]
     small = lower(specs, sd, 1, 640, 640)
-    assert not [o for o in small.ops if o["kind"] in (OP_C3K, OP_PSA)] and len(small.ops) == len(big.ops) + 15
+    assert not [o for o in small.ops if o["kind"] in (OP_C3K, OP_PSA, OP_SPPF)] and len(small.ops) == len(big.ops) + 18
+    monkeypatch.setenv("YL_FUSE_PSA", "0")  # without the resident PSABlock the SPPF launch still carries C2PSA.cv1
+    nopsa = lower(specs, sd, 32, 640, 640)
+    assert [len(o["extra_weight"]) for o in nopsa.ops if o["kind"] == OP_SPPF] == [2] and len(nopsa.ops) == len(big.ops) + 5
+    monkeypatch.delenv("YL_FUSE_PSA")
     s_scale = lower(arch.parse_model(arch.yolo11_dict("s"))[0], synth_state_dict("s", 0), 32, 640, 640)
     assert not [o for o in s_scale.ops if o["kind"] == OP_C3K]   # inner width 128: the maps do not fit

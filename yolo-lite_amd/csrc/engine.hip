@@ -577,6 +577,41 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
         r.name = "c3k_resident_mfma";
         break;
       }
+      case YL_OP_SPPF: {
+        const bool tail = o.n_extra == 2;
+        if (!o.weight || !o.bias || (o.n_extra != 1 && o.n_extra != 2) || !o.extra_weight || !o.extra_bias)
+          return fail(-1, tag + ": sppf needs cv1's filter and one or two extra filters (cv2, the follow-up 1x1 conv)");
+        for (int q = 0; q < o.n_extra; ++q)
+          if (!o.extra_weight[q] || !o.extra_bias[q]) return fail(-1, tag + ": sppf: null extra filter");
+        if (o.in.dtype != YL_BF16 || o.out.dtype != YL_BF16 || o.in.H != o.out.H || o.in.W != o.out.W || o.lane != 0 ||
+            !sppf_resident_fits(o.in.C, o.out.C, tail ? o.out.C : 0, o.in.H, o.in.W))
+          return fail(-3, tag + ": sppf: 256 channels in and out (hidden width 128) on a map of at most 448 pixels");
+        const int c1 = o.in.C, c_ = c1 / 2, c2 = o.out.C;
+        const float* ws[3] = {o.weight, o.extra_weight[0], tail ? o.extra_weight[1] : nullptr};
+        const float* bs[3] = {o.bias, o.extra_bias[0], tail ? o.extra_bias[1] : nullptr};
+        const int cin[3] = {c1, 4 * c_, c2}, cout[3] = {c_, c2, c2};
+        for (int q = 0; q < (tail ? 3 : 2); ++q) {
+          ConvConfig cc{};
+          cc.MT = 4;
+          cc.ncb = cout[q] / 64;
+          cc.cg = cin[q] / 8;
+          cc.ntaps = 1;
+          cc.ksteps = cin[q] / 32;
+          cc.wpk_elems = (size_t)cc.ncb * cc.ksteps * cc.MT * 64 * 8;
+          std::vector<uint16_t> pk;
+          conv_pack_weights(ws[q], cout[q], cin[q], 1, cc, &pk);
+          uint16_t* d = nullptr;
+          if (int rc = dev_upload(e.get(), pk, &d)) return rc;
+          r.d_xw[q] = reinterpret_cast<__bf16*>(d);
+          std::vector<float> bias((size_t)cout[q] + 16, 0.f);
+          for (int ch = 0; ch < cout[q]; ++ch) bias[ch] = bs[q][ch];
+          if (int rc = dev_upload(e.get(), bias, &r.d_xb[q])) return rc;
+        }
+        r.flops = 2.0 * px_out * ((double)c1 * c_ + 4.0 * c_ * c2 + (tail ? (double)c2 * c2 : 0.0));
+        r.bytes = px_out * 2.0 * (c1 + c2) + 2.0 * ((double)c1 * c_ + 4.0 * c_ * c2 + (tail ? (double)c2 * c2 : 0.0));
+        r.name = "sppf_resident_mfma";
+        break;
+      }
       case YL_OP_PSA: {
         const int c = o.in.C / 2;  // in / out = cat(a, b): the block works on b and copies a
         if (!o.weight || !o.bias || o.n_extra != 4 || !o.extra_weight || !o.extra_bias)
@@ -1069,6 +1104,30 @@ static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s, c
         q.bias[k] = r.d_xb[k];
       }
       return c3k_resident_launch(q, s);
+    }
+    case YL_OP_SPPF: {
+      SppfArgs q{};
+      const Geo gq = geo_of(B, o.out.H, o.out.W);
+      const long long ib = (long long)(o.in.C / 8) * plane_bytes(gq), ob = (long long)(o.out.C / 8) * plane_bytes(gq);
+      if (ib > (1LL << 30) || ob > (1LL << 30)) return fail(-3, "sppf: a tensor slice exceeds 1 GiB; lower the batch size");
+      q.x = pview(ws, o.in, B).base;
+      q.y = pview(ws, o.out, B).base;
+      q.x_plane = q.y_plane = (unsigned)plane_bytes(gq);
+      q.x_bytes = (unsigned)ib;
+      q.y_bytes = (unsigned)ob;
+      q.B = B;
+      q.H = o.out.H;
+      q.W = o.out.W;
+      q.W1 = gq.W1;
+      q.img = gq.img;
+      q.g0 = gq.g0;
+      q.w1 = r.d_xw[0];
+      q.w2 = r.d_xw[1];
+      q.w3 = r.d_xw[2];
+      q.b1 = r.d_xb[0];
+      q.b2 = r.d_xb[1];
+      q.b3 = r.d_xb[2];
+      return sppf_resident_launch(q, s);
     }
     case YL_OP_PSA: {
       PsaArgs q{};

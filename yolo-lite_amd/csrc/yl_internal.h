@@ -364,6 +364,24 @@ struct PsaArgs {
 bool psa_resident_fits(int c, int heads, int key_dim, int head_dim, int H, int W);
 int psa_resident_launch(const PsaArgs& a, hipStream_t s);
 
+// sppf_resident.hip: an SPPF layer (256 -> 128, pools, 512 -> 256) and optionally the 1x1 conv 256 -> 256 that alone consumes its
+// output, in one launch, one or two workgroups per image
+struct SppfArgs {
+  const __bf16* x;          // first plane of the layer's input (256 channels)
+  __bf16* y;                // first plane of the output (256 channels): the tail conv's output, or SPPF's own without a tail
+  unsigned x_plane, y_plane, x_bytes, y_bytes;
+  int B, H, W, W1, img, g0;
+  const __bf16* w1;         // SPPF.cv1, packed [2 blocks][8 k-steps][4 tiles][64 lanes][8]
+  const __bf16* w2;         // SPPF.cv2, packed [4][16][4][64][8] (256 KiB)
+  const __bf16* w3;         // the follow-up conv, packed [4][8][4][64][8] (128 KiB); null: none
+  const float *b1, *b2, *b3;
+  unsigned long long* stamps;  // diagnostic builds (-DYL_STAMPS)
+  int split;                   // workgroups per image (filled by sppf_resident_launch)
+  int dbg;                     // development switches (YL_SPPF_DBG), 0 in production
+};
+bool sppf_resident_fits(int c1, int c2, int tail, int H, int W);
+int sppf_resident_launch(const SppfArgs& a, hipStream_t s);
+
 struct DecodeLevel {
   PView box;     // 8 planes: DFL logits (head.py:64 cv2)
   PView cls;     // nc8 / 8 planes: class logits (cv3); padding channels hold large negative values

@@ -22,7 +22,7 @@ from .arch import LayerSpec, detect_mid_channels
 
 BN_EPS = 1e-3
 BF16, F32, FP8 = 0, 1, 4  # yl_amd.h element types (FP8 = OCP e4m3, planes of 16 channels)
-OP_CONV, OP_DWCONV3, OP_SPPF_POOL, OP_UPSAMPLE, OP_ATTENTION, OP_STEM, OP_C3K2S, OP_BNECK2, OP_QUANT, OP_C3K, OP_PSA = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
+OP_CONV, OP_DWCONV3, OP_SPPF_POOL, OP_UPSAMPLE, OP_ATTENTION, OP_STEM, OP_C3K2S, OP_BNECK2, OP_QUANT, OP_C3K, OP_PSA, OP_SPPF = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12
 
 
 @dataclass
@@ -106,6 +106,13 @@ def c3k_resident_fits(c_: int, H: int, W: int) -> bool:
 def psa_resident_fits(c: int, nh: int, kd: int, hd: int, H: int, W: int) -> bool:
     """Mirror of ``psa_resident_fits`` (csrc/resident.hip): the PSABlock of YOLO11n's C2PSA on a map of at most 400 pixels."""
     return c == 128 and nh == 2 and kd == 32 and hd == 64 and 8 <= H * W <= 400
+
+
+def sppf_resident_fits(c1: int, c2: int, tail: int, H: int, W: int) -> bool:
+    """Mirror of ``sppf_resident_fits`` (csrc/sppf_resident.hip): an SPPF layer 256 -> 256 (hidden width 128), optionally with
+    the 1x1 conv 256 -> 256 behind it, on a map whose 16 planes + the three-slot filter ring fit one workgroup's LDS."""
+    ntiles = (H * W + 15) // 16
+    return c1 == 256 and c2 == 256 and tail in (0, 256) and 1 <= ntiles <= 28 and ntiles * 256 * 16 + 3 * 16384 <= 160 * 1024  # (small maps: + 32 KB, < 144 KB)
 
 
 def fuse_follow_up_convs(ops: List[dict]) -> List[dict]:
@@ -828,6 +835,7 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
                               stride=float(strides[lvl]))
 
     views: Dict[int, TView] = {}
+    sppf_tail: Dict[int, TView] = {}  # C2PSA layer -> its cat(a, b) buffer, when the SPPF launch in front of it ran its cv1
     prog.input_view = ar.alloc(in_h, in_w, 8)
     x = prog.input_view
     for sp in specs[:-1]:
@@ -856,20 +864,50 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
                     bottleneck(f"{p}.m.{j}", xin, xout, int(c * 0.5))
             conv(p + ".cv2", t, y, 1, 1)
         elif sp.kind == "SPPF":
-            y = out_view(sp.i)
             c_ = sp.c1 // 2
-            sbuf = ar.alloc(src.H, src.W, 4 * c_)
-            conv(p + ".cv1", src, sbuf.slice(0, c_), 1, 1)
-            ops.append(dict(kind=OP_SPPF_POOL, name=p + ".m", inp=sbuf.slice(0, c_), out=sbuf.slice(0, c_), res=None))
-            conv(p + ".cv2", sbuf, y, 1, 1)
+            # the whole layer in ONE launch, one or two workgroups per image (csrc/sppf_resident.hip: x and the pooled maps in
+            # LDS) -- and C2PSA.cv1 with it when that conv is the only reader of this layer's output (YOLO11: layer 9 -> 10;
+            # 4 launches -> 1, bit-identical); small batches keep the separate launches, like the other resident kernels
+            nxt = specs[sp.i + 1] if sp.i + 1 < len(specs) - 1 else None
+            only_reader = (nxt is not None and nxt.kind == "C2PSA" and nxt.f == -1 and sp.i not in dest and sp.i not in level_of
+                           and not any(sp.i in (q.f if isinstance(q.f, (list, tuple)) else [q.f]) for q in specs))
+            tail_c = 2 * int(nxt.c1 * 0.5) if only_reader else 0
+            if (fuse_post and os.environ.get("YL_FUSE_SPPF", "1") != "0" and not fp8_scales
+                    and batch >= int(os.environ.get("YL_FUSE_C3K_MIN_BATCH", "8"))
+                    and (sppf_resident_fits(sp.c1, sp.c2, tail_c, src.H, src.W) or sppf_resident_fits(sp.c1, sp.c2, 0, src.H, src.W))):
+                if not sppf_resident_fits(sp.c1, sp.c2, tail_c, src.H, src.W):
+                    tail_c = 0
+                w1, b1 = fold_conv_bn(sd, p + ".cv1")
+                w2, b2 = fold_conv_bn(sd, p + ".cv2")
+                xw, xb, names = [w2.reshape(w2.shape[0], -1)], [b2], [p + ".cv1", p + ".m", p + ".cv2"]
+                if tail_c:
+                    w3, b3 = fold_conv_bn(sd, f"model.{nxt.i}.cv1")
+                    xw.append(w3.reshape(w3.shape[0], -1))
+                    xb.append(b3)
+                    names.append(f"model.{nxt.i}.cv1")
+                    y = ar.alloc(src.H, src.W, tail_c)  # = C2PSA's cat(a, b) buffer; this layer's own output is never stored
+                    sppf_tail[nxt.i] = y
+                else:
+                    y = out_view(sp.i)
+                ops.append(dict(kind=OP_SPPF, name=p, act=1, inp=src, out=y, res=None, weight=w1.reshape(w1.shape[0], -1), bias=b1,
+                                extra_weight=xw, extra_bias=xb, fused_names=names))
+            else:
+                y = out_view(sp.i)
+                sbuf = ar.alloc(src.H, src.W, 4 * c_)
+                conv(p + ".cv1", src, sbuf.slice(0, c_), 1, 1)
+                ops.append(dict(kind=OP_SPPF_POOL, name=p + ".m", inp=sbuf.slice(0, c_), out=sbuf.slice(0, c_), res=None))
+                conv(p + ".cv2", sbuf, y, 1, 1)
         elif sp.kind == "C2PSA":
             y = out_view(sp.i)
             c = int(sp.c1 * 0.5)
             nh = c // 64
             hd = c // nh
             kd = int(hd * 0.5)
-            u = ar.alloc(src.H, src.W, 2 * c)
-            conv(p + ".cv1", src, u, 1, 1)
+            if sp.i in sppf_tail:  # cv1 ran in the SPPF layer's launch: `src` already is its output
+                u = sppf_tail[sp.i]
+            else:
+                u = ar.alloc(src.H, src.W, 2 * c)
+                conv(p + ".cv1", src, u, 1, 1)
             b = u.slice(c, c)
             for j in range(sp.n):
                 q = f"{p}.m.{j}"
