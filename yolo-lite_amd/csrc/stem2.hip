@@ -6,16 +6,16 @@
 // of the network and has exactly one reader.  stem_kernel + conv_kernel write and re-read it through HBM
 // (0.21 GB of the ~2.3 GB a batch moves); here it only ever exists as a bf16 tile in LDS.
 //
-// One workgroup (256 threads) = TR x TC = 2 x 80 output pixels of layer 1 for one image:
-//   1. the 11 x 324 input window (3 channels) is read with aligned dword buffer loads (zeros outside the image),
+// One workgroup (256 threads) = TR x TC = 5 x 32 output pixels of layer 1 for one image:
+//   1. the 23 x 132 input window (3 channels) is read with aligned dword buffer loads (zeros outside the image),
 //      converted (/255 for uint8, true division) and rounded to bf16 into LDS;
-//   2. the 5 x 161 stem outputs the tile needs are computed from it exactly as stem_kernel does (MFMA with K = 27
+//   2. the 11 x 65 stem outputs the tile needs are computed from it exactly as stem_kernel does (MFMA with K = 27
 //      taps padded to 32, im2col gathered from LDS), SiLU'd, rounded to bf16 and parked in LDS as C8 planes; stem
 //      positions outside the stem map (layer 1's zero padding) are written as zeros;
 //   3. layer 1 runs as conv_kernel would -- same packed filters, same k order (tap-major, 8-channel groups), same
 //      epilogue and follow-up 1x1 -- with its B fragments read from the LDS planes (stride-2 pixels).
 // Same operands, same MFMA sequence: bit-identical to the two-launch path (tests/test_gpu_net.py).
-// Recompute: 5 stem rows per 2 output rows and 161 columns per 80 (1.26x of a 0.9 GFLOP layer).
+// Recompute: 11 stem rows per 5 output rows and 65 columns per 32 (1.12x of a 0.9 GFLOP layer).
 #include <type_traits>
 
 #include "conv_common.h"
@@ -25,13 +25,15 @@
 #endif
 namespace yl {
 
-constexpr int S2_TR = 2, S2_TC = 80;                 // layer-1 output tile
-constexpr int S2_SR = 2 * S2_TR + 1;                 // stem rows (5)
-constexpr int S2_SC = 2 * S2_TC + 1;                 // stem columns (161)
+constexpr int S2_TR = 5, S2_TC = 32;                 // layer-1 output tile (round 4: 2 x 80 before -- the squarer tile recomputes
+                                                     // 715 stem pixels per 160 outputs instead of 805, and a window row is four
+                                                     // 16-pixel tiles + one column: one tile column per wave)
+constexpr int S2_SR = 2 * S2_TR + 1;                 // stem rows (11)
+constexpr int S2_SC = 2 * S2_TC + 1;                 // stem columns (65)
 constexpr int S2_SP = S2_SC + 1;                     // stem tile pitch in pixels
-constexpr int S2_IR = 2 * S2_SR + 1;                 // input rows (11)
-constexpr int S2_IC = 2 * S2_SC + 2;                 // input columns incl. one alignment column (324)
-constexpr int S2_IP = 352;                           // input tile pitch in elements (>= S2_IC; 32 mod 64: rows alternate LDS bank halves)
+constexpr int S2_IR = 2 * S2_SR + 1;                 // input rows (23)
+constexpr int S2_IC = 2 * S2_SC + 2;                 // input columns incl. one alignment column (132)
+constexpr int S2_IP = 160;                           // input tile pitch in elements (>= S2_IC; 32 mod 64: rows alternate LDS bank halves)
 
 size_t stem2_lds_bytes(int C0) {
   return (size_t)3 * S2_IR * S2_IP * 2 + (size_t)(C0 / 8) * S2_SR * S2_SP * 16;
@@ -54,6 +56,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
   const int ty = bid % a.tiles_y;
   const int b = bid / a.tiles_y;
   const int y0 = ty * S2_TR, x0 = tx * S2_TC;
+#define S2_STAMP(id) YL_STAMP(a.stamps, 4, wave, lane, id)
+  S2_STAMP(0);
 
   // ---- 1. input window -> LDS (bf16).  Local (ir, ic) <-> image (4*y0 - 3 + ir, 4*x0 - 4 + ic).
   {
@@ -62,6 +66,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
         (void*)in, (short)0, (int)((long long)3 * a.H * a.W * (long long)sizeof(T)), 0x00020000);
     constexpr int DW = S2_IC / VW;  // dwords per row
     constexpr int TOTAL = 3 * S2_IR * DW;
+    if constexpr (sizeof(T) == 1 && 6 * DW <= 256 && !(YL_STEM2_ABL & 2)) {
+      // uint8 (the predictor's input): a thread = one dword column of one channel, one half of its rows, all of them in flight at
+      // once -- the (row, column) arithmetic once per thread instead of twice per dword (the kernel is bound by instruction
+      // issue, and the generic loop below spent ~45 instructions per dword, a fifth of the kernel)
+      constexpr int RH = (S2_IR + 1) / 2;  // rows per half
+      const int col = tid % (3 * DW), half = tid / (3 * DW);
+      const int ch = col / DW, d = col - ch * DW;
+      const int ix = 4 * x0 - 4 + d * 4;
+      const bool mine = tid < 6 * DW;
+      const bool okx = mine && ix >= 0 && ix + 4 <= a.W;
+      const int ir0 = half * RH, iy0 = 4 * y0 - 3 + ir0;
+      unsigned v[RH];
+#pragma unroll
+      for (int i = 0; i < RH; ++i) {
+        const int iy = iy0 + i;
+        v[i] = __builtin_amdgcn_raw_buffer_load_b32(rs, (okx && ir0 + i < S2_IR && (unsigned)iy < (unsigned)a.H) ? (unsigned)((ch * a.H + iy) * a.W + ix) : 0x80000000u, 0, 0);
+      }
+      if (mine) {
+        typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+        const float k = 1.0f / 255.0f;  // (see below: exact after the bf16 rounding)
+        __bf16* dst = img + (ch * S2_IR + ir0) * S2_IP + d * 4;
+#pragma unroll
+        for (int i = 0; i < RH; ++i) {
+          const bf16x4_t o = {(__bf16)((float)(v[i] & 0xffu) * k), (__bf16)((float)((v[i] >> 8) & 0xffu) * k),
+                              (__bf16)((float)((v[i] >> 16) & 0xffu) * k), (__bf16)((float)(v[i] >> 24) * k)};
+          if (ir0 + i < S2_IR) *reinterpret_cast<bf16x4_t*>(dst + i * S2_IP) = o;
+        }
+      }
+    } else {
     // 12 loads in flight per thread: the whole uint8 window (2673 dwords) is ONE memory round trip
     constexpr int CH = 12;
     for (int i0 = tid; i0 < TOTAL; i0 += 256 * CH) {
@@ -106,25 +139,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
         }
       }
     }
+    }
   }
+  S2_STAMP(1);
   __syncthreads();
+  S2_STAMP(2);
 
   // ---- 2. stem outputs of the window -> LDS planes.  Local (r, c) <-> stem pixel (2*y0 - 1 + r, 2*x0 - 1 + c);
   //         it reads input rows 2r + kh and columns 2c + kw + 1 of the window.
+  // The kernel is bound by instruction ISSUE (in-kernel stamps, NOTEBOOK section 13: 2 100 instructions per wave, half of them
+  // here, 75 per 16-pixel tile for ONE MFMA -- and SiLU's two transcendentals are quarter rate), so this phase counts
+  // instructions: read pointers built once with the tile as an immediate offset (they were rebuilt, shifts included, for every
+  // tile), the pixels of the window's last column as ONE tile, the zero-padding test only for tiles at the stem map's edge.
   {
-    // LDS element of tap k = (ch*3 + kh)*3 + kw relative to the pixel's (2r, 2c) corner; taps >= 27 (zero
+    // LDS byte offset of tap k = (ch*3 + kh)*3 + kw relative to the pixel's (2r, 2c) corner; taps >= 27 (zero
     // filter values) read tap 0's element, which is initialised and finite
-    int koff[8];
+    unsigned koffb[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int k = g * 8 + j;
       const int kk = k < 27 ? k : 0;
       const int ch = kk / 9, kh = (kk - ch * 9) / 3, kw = kk - ch * 9 - kh * 3;
-      koff[j] = (ch * S2_IR + kh) * S2_IP + kw + 1;
+      koffb[j] = (unsigned)(((ch * S2_IR + kh) * S2_IP + kw + 1) * 2);
     }
-    // 16-pixel tiles aligned to the window's rows (11 per row, the last one 1 pixel wide): row and column tile are
-    // wave-uniform, so the address arithmetic per tile is a handful of scalar instructions plus one add per gather
-    constexpr int TPR = (S2_SC + 15) / 16;
+    constexpr int TPRF = S2_SC / 16;          // full 16-pixel tiles per window row
+    static_assert(S2_SC == TPRF * 16 + 1 && S2_SR <= 16 && TPRF == 4, "four tile columns = four waves, + one column with a lane per row");
+    constexpr int ROWB = 2 * S2_IP * 2;       // bytes between the input rows of consecutive stem rows
+    const unsigned char* const imgb = reinterpret_cast<const unsigned char*>(img);
+    // Tile (r, ct) = window row r, columns 16 ct .. 16 ct + 15; wave w owns tile column ct = w.  Its eight read pointers are built
+    // ONCE; the row is an immediate offset of the LDS instructions (the loop over the rows is unrolled).
+    const unsigned char* rp[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) rp[j] = imgb + koffb[j] + 4u * (unsigned)n + 64u * (unsigned)wave;
+    const int sx0 = 2 * x0 - 1 + wave * 16;
+    const bool col_in = sx0 >= 0 && sx0 + 15 < a.W0;  // scalar: no pixel of this tile column is layer 1's zero padding
     for (int mb = 0; mb < a.C0; mb += 16) {
       bf16x8 af;
 #pragma unroll
@@ -135,52 +183,67 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
       const f32x4 bv = *reinterpret_cast<const f32x4*>(a.b0 + mb + g * 4);
       const int ch = mb + g * 4;
       unsigned char* const sbase = stile + (size_t)(ch >> 3) * S2_SR * S2_SP * 16 + (ch & 7) * 2;
-      // two tiles per trip (t and t + 4): both gathers are requested before the first MFMA, so the LDS latency
-      // and the MFMA -> SiLU dependency of one tile hide behind the other
+      unsigned char* const wp = sbase + (size_t)((wave * 16 + n) * 16);
       // (the SiLU flag is a compile-time constant inside: left as a runtime test of a.act0, hipcc branched around every
       // single SiLU and shuttled the accumulators through AGPRs between the branches)
       auto stem_tiles = [&](auto act_tag) __attribute__((always_inline)) {
-      constexpr bool ACT0 = decltype(act_tag)::value;
-      for (int t0 = wave; t0 < S2_SR * TPR; t0 += 8) {
-        bf16x8 bf[2];
-        int rr[2], cc[2], cts[2];
+        constexpr bool ACT0 = decltype(act_tag)::value;
+        const bf16x4 z = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+        // two rows per trip: both gathers are requested before the first MFMA, so the LDS latency and the MFMA -> SiLU
+        // dependency of one tile hide behind the other
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int t = min(t0 + 4 * u, S2_SR * TPR - 1);    // scalar; a missing second tile repeats the last one
-          const int r = t / TPR, ct = t - r * TPR;
-          const int c = min(ct * 16 + n, S2_SC - 1);         // the ragged last tile recomputes the last pixel
-          rr[u] = r;
-          cc[u] = c;
-          cts[u] = (t0 + 4 * u < S2_SR * TPR) ? ct : TPR;    // TPR: nothing of this tile is stored
-          const __bf16* corner = img + 2 * r * S2_IP + 2 * c;
-#if YL_STEM2_ABL & 1  // (timing ablation, wrong results: one aligned 16-byte read instead of the eight-element im2col gather)
-          bf[u] = *reinterpret_cast<const bf16x8*>(img + ((2 * r * S2_IP + 2 * c) & ~7));
+        for (int r0 = 0; r0 < S2_SR; r0 += 2) {
+          constexpr int NU = 2;
+          bf16x8 bf[NU];
+#pragma unroll
+          for (int u = 0; u < NU; ++u) {
+            const int r = r0 + u < S2_SR ? r0 + u : S2_SR - 1;  // (a missing second row repeats the last one, nothing stored)
+#if YL_STEM2_ABL & 1  // (timing ablation, wrong results: one 16-byte read instead of the eight-element im2col gather)
+            bf[u] = *reinterpret_cast<const bf16x8*>(imgb + ((r * ROWB + 64u * wave + 4u * n) & ~15u));
 #else
 #pragma unroll
-          for (int j = 0; j < 8; ++j) bf[u][j] = corner[koff[j]];
+            for (int j = 0; j < 8; ++j) bf[u][j] = *reinterpret_cast<const __bf16*>(rp[j] + r * ROWB);
 #endif
+          }
+          f32x4 acc[NU];
+#pragma unroll
+          for (int u = 0; u < NU; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[u], bv, 0, 0, 0);
+#pragma unroll
+          for (int u = 0; u < NU; ++u) {
+            const int r = r0 + u;
+            if (r >= S2_SR) continue;
+            bf16x4 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = (__bf16)((ACT0 && !(YL_STEM2_ABL & 4)) ? silu_f(acc[u][q]) : acc[u][q]);
+            const bool row_in = (unsigned)(2 * y0 - 1 + r) < (unsigned)a.H0;  // scalar
+            if (!(row_in && col_in)) {  // (scalar branch) stem positions outside the stem map are layer 1's zero padding
+              if (!(row_in && (unsigned)(sx0 + n) < (unsigned)a.W0)) o = z;
+            }
+            *reinterpret_cast<bf16x4*>(wp + r * (S2_SP * 16)) = o;
+          }
         }
-        f32x4 acc[2];
+        // the window's last column (c = S2_SC - 1), one lane per row: a tile of its own
+        if (wave == 3) {
+          const int r = min(n, S2_SR - 1), c = S2_SC - 1;
+          const unsigned char* corner = imgb + (2 * r * S2_IP + 2 * c) * 2;
+          bf16x8 bl;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[u], bv, 0, 0, 0);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int sy = 2 * y0 - 1 + rr[u], sx = 2 * x0 - 1 + cc[u];
-          const bool inside = (unsigned)sy < (unsigned)a.H0 && (unsigned)sx < (unsigned)a.W0;
+          for (int j = 0; j < 8; ++j) bl[j] = *reinterpret_cast<const __bf16*>(corner + koffb[j]);
+          const f32x4 al = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bl, bv, 0, 0, 0);
           bf16x4 o;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) o[q] = (__bf16)((ACT0 && !(YL_STEM2_ABL & 4)) ? silu_f(acc[u][q]) : acc[u][q]);
-          const bf16x4 z = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
-          if (cts[u] * 16 + n < S2_SC)
-            *reinterpret_cast<bf16x4*>(sbase + (size_t)(rr[u] * S2_SP + cc[u]) * 16) = inside ? o : z;
+          for (int q = 0; q < 4; ++q) o[q] = (__bf16)((ACT0 && !(YL_STEM2_ABL & 4)) ? silu_f(al[q]) : al[q]);
+          const bool inside = (unsigned)(2 * y0 - 1 + r) < (unsigned)a.H0 && (unsigned)(2 * x0 - 1 + c) < (unsigned)a.W0;
+          if (n < S2_SR) *reinterpret_cast<bf16x4*>(sbase + (size_t)(r * S2_SP + c) * 16) = inside ? o : z;
         }
-      }
       };
       if (a.act0) stem_tiles(std::true_type{});
       else stem_tiles(std::false_type{});
     }
   }
+  S2_STAMP(3);
   __syncthreads();
+  S2_STAMP(4);
 
   // ---- 3. layer 1 from the LDS planes: 16-pixel tiles aligned to the output rows (TC / 16 per row)
   constexpr int cg0 = CG0;                 // planes of the stem's output (2: 16 channels, YOLO11n; 4: 32, YOLO11s)
@@ -214,6 +277,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
   const unsigned out_plane = (unsigned)(a.out.plane * 2);
   const int act_last = POST ? a.post_act : a.act;
   constexpr int TPR1 = S2_TC / 16;
+  S2_STAMP(5);
   for (int t = wave; t < S2_TR * TPR1; t += 4) {
     const int ly = t / TPR1, ct = t - ly * TPR1;  // scalar
     const int oy = y0 + ly, ox = x0 + ct * 16 + n;
@@ -274,6 +338,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
           rout, co < cout_last ? (unsigned)(p * 4 + g) * out_plane + po : OOB_LANE, 0, 0);
     }
   }
+  S2_STAMP(6);
+#undef S2_STAMP
 }
 
 template <typename T, int CG0>
@@ -301,6 +367,7 @@ static int stem2_launch_t(const Stem2Args& a, int MT, size_t lds, hipStream_t s)
 
 int stem2_launch(const Stem2Args& a0, int MT, int in_dtype, hipStream_t s) {
   Stem2Args a = a0;
+  a.stamps = g_stamp_buf;
   if ((a.C0 != 16 && a.C0 != 32) || a.ksteps != (9 * (a.C0 / 8) + 3) / 4)
     return fail(-3, "stem2: the stem must have 16 or 32 output channels");
   const int esz = in_dtype == YL_F32 ? 4 : in_dtype == YL_F16 ? 2 : 1;

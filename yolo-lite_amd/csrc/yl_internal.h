@@ -265,6 +265,7 @@ struct Stem2Args {
   PView out;
   unsigned out_bytes;
   int tiles_x, tiles_y;
+  unsigned long long* stamps;  // diagnostic builds (-DYL_STAMPS)
 };
 int stem2_launch(const Stem2Args& a, int MT, int in_dtype, hipStream_t s);
 
