@@ -64,6 +64,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     constexpr int NL = (NB + NA + 255) / 256;
     bf16x8 v[NL];
     unsigned dst[NL];
+    const int pix0 = (int)a.tin.g0 + b * (int)a.tin.img, w1 = (int)a.tin.W1, ppx = (int)a.plane_px;
 #pragma unroll
     for (int u = 0; u < NL; ++u) {
       const int i = tid + u * 256;
@@ -85,9 +86,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
         xx = x0 + rx;
         d = (int)(ta - tb) + j * 16;
       }
-      // guarded index; may be negative for image 0 (-> out of range -> zeros)
-      const long long pix = (long long)a.tin.g0 + (long long)b * a.tin.img + (long long)yy * a.tin.W1 + xx;
-      const bool ok = i < NB + NA && pix >= 0 && pix < a.plane_px;
+      // guarded index; may be negative for image 0 (-> out of range -> zeros).  32-bit: a view is at most 1 GiB (engine.hip)
+      const int pix = pix0 + yy * w1 + xx;
+      const bool ok = i < NB + NA && pix >= 0 && pix < ppx;
       v[u] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
                                             rin, ok ? (unsigned)pl * in_plane + (unsigned)pix * 16u : OOB_LANE, 0, 0));
       dst[u] = i < NB + NA ? (unsigned)d : 0xffffffffu;
@@ -120,23 +121,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
       const int kh = tap / 3, kw = tap - kh * 3;
       boff[ks] = ((c8 * C3_BR + kh) * C3_BC + kw + n) * 16;
     }
-    constexpr int TPR = (C3_MC + 15) / 16;  // 3 tiles per row, the last 2 pixels wide
-    for (int t = wave; t < C3_MR * TPR; t += 4) {
-      const int r = t / TPR, ct = t - r * TPR;  // scalar
-      const int c = ct * 16 + n;
-      const int cl = min(c, C3_MC - 1);
-      const unsigned char* corner = tb + (r * C3_BC + ct * 16) * 16 - (c - cl) * 16;
+    // 16-pixel tiles: two per row (columns 0 .. 31) and the two remaining columns of ALL rows gathered into tiles of their own
+    // (pixel q of them = row q / 2, column 32 + q % 2) -- as a third, 2-pixel-wide tile per row they were a third of this phase's
+    // MFMAs, SiLUs and stores for a sixteenth of its pixels (the kernel is bound by instruction issue, NOTEBOOK section 13)
+    constexpr int TPRF = C3_MC / 16, NFULL = C3_MR * TPRF;
+    constexpr int NRAG = (C3_MC - TPRF * 16) * C3_MR, NTILES = NFULL + (NRAG + 15) / 16;
+    static_assert(C3_MC - TPRF * 16 == 2, "two ragged columns");
+    for (int t = wave; t < NTILES; t += 4) {
+      int r, c;     // the lane's pixel of the intermediate
+      bool live;
+      if (t < NFULL) {  // scalar branch
+        const int rs = t / TPRF, ct = t - rs * TPRF;
+        r = rs;
+        c = ct * 16 + n;
+        live = true;
+      } else {
+        const int q = (t - NFULL) * 16 + n;
+        live = q < NRAG;
+        const int qc = live ? q : NRAG - 1;
+        r = qc >> 1;
+        c = TPRF * 16 + (qc & 1);
+      }
+      const unsigned char* corner = tb + (r * C3_BC + c - n) * 16;  // (boff carries the lane's + n)
       f32x4 acc = biasA;
 #pragma unroll
       for (int ks = 0; ks < KA; ++ks)
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wA[ks], *reinterpret_cast<const bf16x8*>(corner + boff[ks]), acc, 0, 0, 0);
-      const int my = y0 - 1 + r, mx = x0 - 1 + cl;
+      const int my = y0 - 1 + r, mx = x0 - 1 + c;
       const bool inside = (unsigned)my < (unsigned)a.H && (unsigned)mx < (unsigned)a.W;
       bf16x4 o;
 #pragma unroll
       for (int q = 0; q < 4; ++q) o[q] = inside ? (__bf16)silu_f(acc[q]) : (__bf16)0.f;
       // rows 4g..4g+3 = channels 4g..4g+3 of the c/2 = 4*CP the conv has
-      if (g < CP && c < C3_MC)
+      if (g < CP && live)
         *reinterpret_cast<bf16x4*>(tm + (((g >> 1) * C3_MR + r) * C3_MC + c) * 16 + (g & 1) * 8) = o;
     }
   }
