@@ -252,11 +252,13 @@ def test_conv_gemm_reads_through_upsample_concat(gpu_device, monkeypatch, clo, c
 
 
 @pytest.mark.parametrize("staged", [0, 1])
-@pytest.mark.parametrize("c,cout,h,w,act2", [(64, 80, 20, 20, True), (80, 80, 13, 9, True), (32, 32, 40, 40, False)])
+@pytest.mark.parametrize("c,cout,h,w,act2", [(64, 80, 20, 20, True), (80, 80, 13, 9, True), (32, 32, 40, 40, False),
+                                             (128, 128, 40, 40, True), (256, 128, 20, 20, True), (128, 128, 13, 9, False)])
 def test_depthwise_pointwise_fused(gpu_device, monkeypatch, c, cout, h, w, act2, staged):
     """DWConv 3x3 + SiLU -> 1x1 conv in one launch (Detect class branch); the depthwise result only exists
     in LDS, rounded to bf16 like a stored activation.  The depthwise conv runs on the matrix pipe (block-diagonal
-    filter, bf16 taps).  staged = 1: the opt-in variant that stages the input through LDS (csrc/dwpw.hip)."""
+    filter, bf16 taps).  staged = 1: the opt-in variant that stages the input through LDS (csrc/dwpw.hip).  128 output channels
+    (YOLO11s' class branch): eight channel tiles per wave, one block."""
     monkeypatch.setenv("YL_DWPW_TILE", str(staged))
     g = torch.Generator().manual_seed(c * 7 + cout)
     x = _rand(g, 2, c, h, w)

@@ -11,15 +11,23 @@ OUT=$R/gpurun_out/$TAG
 rm -rf $OUT
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-python3 $R/bench.py $BA --profile-out $OUT/per_op.json > $OUT/bench.json 2> $OUT/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py $BA --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > $OUT/trace.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py $BA --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py $BA --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs > $OUT/pmc_write.log 2>&1
+echo "bench $(date +%T)"
+timeout -k 10 ${LIMIT:-500} python3 $R/bench.py $BA --profile-out $OUT/per_op.json > $OUT/bench.json 2> $OUT/bench.err
+echo "pass --stats $(date +%T)"
+timeout -k 10 ${LIMIT:-300} rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py $BA --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > $OUT/trace.log 2>&1
+echo "pass FETCH_SIZE $(date +%T)"
+timeout -k 10 ${LIMIT:-300} rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py $BA --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs > $OUT/pmc_fetch.log 2>&1
+echo "pass WRITE_SIZE $(date +%T)"
+timeout -k 10 ${LIMIT:-300} rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py $BA --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs > $OUT/pmc_write.log 2>&1
 # independent read-side count (round 3): L2 misses x 128-byte lines, and the fabric read requests with their 32-byte share
-rocprofv3 --pmc TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --output-format csv -d $OUT/pmc_miss -- python3 $R/bench.py $BA --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs > $OUT/pmc_miss.log 2>&1
+echo "pass TCC_MISS_sum $(date +%T)"
+timeout -k 10 ${LIMIT:-300} rocprofv3 --pmc TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --output-format csv -d $OUT/pmc_miss -- python3 $R/bench.py $BA --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs > $OUT/pmc_miss.log 2>&1
 # matrix-pipe occupancy per kernel: busy cycles summed over the 1024 SIMDs / (1024 x kernel cycles); one batch at a time
 # (--streams 1) so that GRBM_GUI_ACTIVE of a dispatch is that kernel's own duration
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -- python3 $R/bench.py $BA --steps 5 --warmup 2 --streams 1 --no-cpu-baseline --no-other-configs > $OUT/pmc_mfma.log 2>&1
+echo "pass SQ_VALU_MFMA_BUSY_CYCLES $(date +%T)"
+timeout -k 10 ${LIMIT:-300} rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -- python3 $R/bench.py $BA --steps 5 --warmup 2 --streams 1 --no-cpu-baseline --no-other-configs > $OUT/pmc_mfma.log 2>&1
+# (every pass under its own time limit and announced on stdout: a pass that hangs -- one did, after a profiler-side memory fault two
+# seconds into the process -- must not take the call with it)
 # keep only the small CSVs
 find $OUT -name "*.db" -delete
 find $OUT -name "*kernel_trace.csv" -delete

@@ -988,6 +988,8 @@ int dwpw_launch(const ConvConfig& cfg0, ConvArgs a, int batch, hipStream_t s) {
     case 42: return launch_dwpw<4, 2>(cfg, a, lds, s);
     case 51: return launch_dwpw<5, 1>(cfg, a, lds, s);
     case 52: return launch_dwpw<5, 2>(cfg, a, lds, s);
+    case 81: return launch_dwpw2<8, 1, false>(cfg, a, lds, s);  // (128 pointwise channels: no fused tail)
+    case 82: return launch_dwpw2<8, 2, false>(cfg, a, lds, s);
   }
   return fail(-3, "dwpw: unsupported tile shape");
 }

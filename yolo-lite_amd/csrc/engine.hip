@@ -444,6 +444,19 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
           if (tail && (!o.stem_bias || pw_cout <= 0 || pw_cout % 8))
             return fail(-1, tag + ": depthwise+pointwise+1x1 needs stem_bias and reserved2 = pointwise channels (% 8 == 0)");
           if (int rc = conv_choose(batch, C, pw_cout, 1, 1, o.out.H, o.out.W, 0, &r.cfg)) return rc;
+          // 128 pointwise channels (YOLO11s' class branch, head.py:41: c3 = max(ch[0], min(nc, 100)) = 128): conv_choose gives two
+          // blocks of four tiles; the fused launch needs every output channel in ONE workgroup (the depthwise tile in LDS is its
+          // GEMM's B operand) -- eight tiles per wave, one block, while the filter (C / 32 k-steps x 8 KiB) fits the slab
+          if (r.cfg.ncb == 2 && r.cfg.MT == 4 && pw_cout == 128 && !tail && C % 32 == 0 && C <= 256 && !r.cfg.gemm) {
+            r.cfg.MT = 8;
+            r.cfg.ncb = 1;
+            r.cfg.kchunk = r.cfg.ksteps;
+            r.cfg.NT = 2;
+            r.cfg.npatches = (int)(((long long)batch * o.out.H * o.out.W + 31) / 32);
+            r.cfg.wpk_elems = (size_t)r.cfg.ksteps * 8 * 64 * 8;
+            r.cfg.lds_bytes = (size_t)r.cfg.ksteps * 8 * 1024;
+            r.cfg.tile = r.cfg.reg = r.cfg.pair = r.cfg.cs = r.cfg.kord = 0;
+          }
           if (r.cfg.NT > 2) {
             r.cfg.NT = 2;
             r.cfg.npatches = (int)(((long long)batch * o.out.H * o.out.W + 31) / 32);

@@ -194,7 +194,12 @@ def fuse_depthwise_pointwise(ops: List[dict]) -> List[dict]:
         y = a["out"]
         if (b["kind"] != OP_CONV or b.get("k") != 1 or b.get("stride", 1) != 1 or b.get("res") is not None
                 or "post_weight" in b or "inp2" in b or b.get("cin_weight", 0)
-                or (b["out"].C + 15) // 16 not in (1, 2, 4, 5)
+                or ((b["out"].C + 15) // 16 not in (1, 2, 4, 5)
+                    # 128 pointwise channels (YOLO11s' class branch) as eight tiles per wave: built, bit-exact against torch
+                    # (tests/test_gpu_kernels.py), and SLOWER than the two launches (116 against 57 + 43 us @80x80 batch 64: a
+                    # 64 KB workgroup, one 32 KB slab restaged per 128 pixels): opt-in
+                    and not (os.environ.get("YL_FUSE_DWPW128", "0") == "1" and b["out"].C == 128 and a["inp"].C % 32 == 0
+                             and a["inp"].C <= 256))
                 or b.get("lane", 0) != a.get("lane", 0)
                 or (b["inp"].offset, b["inp"].coff, b["inp"].C) != (y.offset, y.coff, y.C)):
             continue
