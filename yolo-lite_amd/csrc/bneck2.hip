@@ -147,10 +147,11 @@ __global__ __launch_bounds__(BN_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
 #pragma unroll
         for (int p = 0; p < MT / 2; ++p) {  // tile pair p = the 8 channels of plane p*4 + g
           bf16x8 o;
+          const f32x4 s0 = silu4(acc[2 * p][u]), s1 = silu4(acc[2 * p + 1][u]);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            o[q] = inside ? (__bf16)silu_f(acc[2 * p][u][q]) : (__bf16)0.f;
-            o[4 + q] = inside ? (__bf16)silu_f(acc[2 * p + 1][u][q]) : (__bf16)0.f;
+            o[q] = inside ? (__bf16)s0[q] : (__bf16)0.f;
+            o[4 + q] = inside ? (__bf16)s1[q] : (__bf16)0.f;
           }
           if (c >= 0) *reinterpret_cast<bf16x8*>(tm + (((p * 4 + g) * BN_MR + rr[u]) * BN_MC + c) * 16) = o;
         }
@@ -186,10 +187,11 @@ __global__ __launch_bounds__(BN_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
         for (int p = 0; p < MT / 2; ++p) {
           const bf16x8 rx = *reinterpret_cast<const bf16x8*>(tx + (((p * 4 + g) * BN_XR + ly[u] + 2) * BN_XC + lx[u] + 2) * 16);
           float v[8];
+          const f32x4 s0 = silu4(acc[2 * p][u]), s1 = silu4(acc[2 * p + 1][u]);
 #pragma unroll
           for (int q = 0; q < 4; ++q) {  // conv_kernel's epilogue order: SiLU, then += residual
-            v[q] = silu_f(acc[2 * p][u][q]) + (float)rx[q];
-            v[4 + q] = silu_f(acc[2 * p + 1][u][q]) + (float)rx[4 + q];
+            v[q] = s0[q] + (float)rx[q];
+            v[4 + q] = s1[q] + (float)rx[4 + q];
           }
           __builtin_amdgcn_raw_buffer_store_b128(
               u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])},

@@ -150,8 +150,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
       const int my = y0 - 1 + r, mx = x0 - 1 + c;
       const bool inside = (unsigned)my < (unsigned)a.H && (unsigned)mx < (unsigned)a.W;
       bf16x4 o;
+      const f32x4 sa = silu4(acc);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) o[q] = inside ? (__bf16)silu_f(acc[q]) : (__bf16)0.f;
+      for (int q = 0; q < 4; ++q) o[q] = inside ? (__bf16)sa[q] : (__bf16)0.f;
       // rows 4g..4g+3 = channels 4g..4g+3 of the c/2 = 4*CP the conv has
       if (g < CP && live)
         *reinterpret_cast<bf16x4*>(tm + (((g >> 1) * C3_MR + r) * C3_MC + c) * 16 + (g & 1) * 8) = o;
@@ -187,16 +188,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
       if constexpr (MTB == 1) {  // lane = channels 4g..4g+3: half a pixel of plane g >> 1
         const bf16x4 rb = *reinterpret_cast<const bf16x4*>(tb + (((g >> 1) * C3_BR + ly + 2) * C3_BC + lx + 2) * 16 + (g & 1) * 8);
         bf16x4 o;
+        const f32x4 s0 = silu4(acc[0]);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) o[q] = (__bf16)(silu_f(acc[0][q]) + (float)rb[q]);
+        for (int q = 0; q < 4; ++q) o[q] = (__bf16)(s0[q] + (float)rb[q]);
         *reinterpret_cast<bf16x4*>(tc + (((g >> 1) * C3_TR + ly) * C3_TC + lx) * 16 + (g & 1) * 8) = o;
       } else {                   // two tiles: channels 8g..8g+7 (chan_in_block(2, ..)) = the pixel of plane g
         const bf16x8 rb = *reinterpret_cast<const bf16x8*>(tb + ((g * C3_BR + ly + 2) * C3_BC + lx + 2) * 16);
         bf16x8 o;
+        const f32x4 s0 = silu4(acc[0]), s1 = silu4(acc[MTB - 1]);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          o[q] = (__bf16)(silu_f(acc[0][q]) + (float)rb[q]);
-          o[4 + q] = (__bf16)(silu_f(acc[MTB - 1][q]) + (float)rb[4 + q]);
+          o[q] = (__bf16)(s0[q] + (float)rb[q]);
+          o[4 + q] = (__bf16)(s1[q] + (float)rb[4 + q]);
         }
         *reinterpret_cast<bf16x8*>(tc + ((g * C3_TR + ly) * C3_TC + lx) * 16) = o;
       }
@@ -245,10 +248,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
           float v[8];
+          const f32x4 s0 = silu4(acc[2 * p]), s1 = silu4(acc[2 * p + 1]);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            v[r] = silu_f(acc[2 * p][r]);
-            v[4 + r] = silu_f(acc[2 * p + 1][r]);
+            v[r] = s0[r];
+            v[4 + r] = s1[r];
           }
           __builtin_amdgcn_raw_buffer_store_b128(
               u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])},

@@ -139,10 +139,11 @@ __device__ __forceinline__ void band_compute(const BandArgs& a, unsigned char* l
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       bf16x8 o;
+      const f32x4 s0 = a.act ? silu4(acc[0][nt]) : acc[0][nt], s1 = a.act ? silu4(acc[1][nt]) : acc[1][nt];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        o[r] = (__bf16)(a.act ? silu_f(acc[0][nt][r]) : acc[0][nt][r]);
-        o[4 + r] = (__bf16)(a.act ? silu_f(acc[1][nt][r]) : acc[1][nt][r]);
+        o[r] = (__bf16)s0[r];
+        o[4 + r] = (__bf16)s1[r];
       }
       *reinterpret_cast<bf16x8*>(mid + (mh * 4 + g) * mpl + ((t0 + nt) * 16 + n) * 16) = o;
     }
@@ -166,10 +167,11 @@ __device__ __forceinline__ void band_compute(const BandArgs& a, unsigned char* l
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     float v[8];
+    const f32x4 s0 = act_out ? silu4(acc[0][nt]) : acc[0][nt], s1 = act_out ? silu4(acc[1][nt]) : acc[1][nt];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      v[r] = act_out ? silu_f(acc[0][nt][r]) : acc[0][nt][r];
-      v[4 + r] = act_out ? silu_f(acc[1][nt][r]) : acc[1][nt][r];
+      v[r] = s0[r];
+      v[4 + r] = s1[r];
     }
     __builtin_amdgcn_raw_buffer_store_b128(
         u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])}, rout,

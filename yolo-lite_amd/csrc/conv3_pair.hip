@@ -136,8 +136,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
           v[4 + r] = acc[2 * p + 1][nt][r];
         }
         if (a.act && !(a.dbg & 8)) {
-#pragma unroll
-          for (int r = 0; r < 8; ++r) v[r] = silu_f(v[r]);
+          silu8(v);
         }
         if constexpr (RES) {
           const bf16x8 rv = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(

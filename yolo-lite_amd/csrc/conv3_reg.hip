@@ -60,8 +60,7 @@ __device__ __forceinline__ void reg_epilogue(const ConvArgs& a, __amdgpu_buffer_
         v[4 + r] = acc[2 * p + 1][nt][r];
       }
       if (a.act && !(a.dbg & 8)) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = silu_f(v[r]);
+        silu8(v);
       }
       if constexpr (RES) {
 #pragma unroll

@@ -97,8 +97,7 @@ __device__ __forceinline__ void epilogue_planar(const ConvArgs& a, __amdgpu_buff
         v[4 + r] = acc[2 * p + 1][nt][r];
       }
       if (!(a.dbg & 8)) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = silu_f(v[r]);  // the kernel is only launched for act == SiLU
+        silu8(v);  // the kernel is only launched for act == SiLU
       }
       if constexpr (RES) {
 #pragma unroll

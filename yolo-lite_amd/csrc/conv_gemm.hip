@@ -357,8 +357,7 @@ __global__ __launch_bounds__(128 * NWN) __attribute__((amdgpu_waves_per_eu(2))) 
         v[4 + r] = acc[2 * p + 1][nt][r];
       }
       if constexpr (ACT) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = silu_f(v[r]);
+        silu8(v);
       }
       if constexpr (RES) {
 #pragma unroll

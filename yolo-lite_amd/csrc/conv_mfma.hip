@@ -172,8 +172,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, int block) {
             v[4 + r] = acc[2 * p + 1][nt][r];
           }
           if (a.act) {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) v[r] = silu_f(v[r]);
+            silu8(v);
           }
 #pragma unroll
           for (int r = 0; r < 8; ++r) xb2[p][nt][r] = (__bf16)v[r];
@@ -328,8 +327,7 @@ __device__ __forceinline__ void dwpw_body(const ConvArgs& a, int block) {
       for (int nt = 0; nt < NT; ++nt) {
         // (one wave-uniform branch around the four SiLUs: a select per value made hipcc branch around each of them)
         if (a.dw_act) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) dacc[nt][r] = silu_f(dacc[nt][r]);
+          dacc[nt] = silu4(dacc[nt]);
         }
         bf16x4 o;
 #pragma unroll
@@ -395,8 +393,7 @@ __device__ __forceinline__ void dwpw_body(const ConvArgs& a, int block) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           if (a.act) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) acc[mt][nt][r] = silu_f(acc[mt][nt][r]);
+            acc[mt][nt] = silu4(acc[mt][nt]);
           }
           bf16x4 o;
 #pragma unroll
@@ -430,8 +427,7 @@ __device__ __forceinline__ void dwpw_body(const ConvArgs& a, int block) {
       for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[mt][nt][r] = silu_f(acc[mt][nt][r]);
+          acc[mt][nt] = silu4(acc[mt][nt]);
       a2.act = 0;
     }
     if (a.pf_count) {
@@ -551,8 +547,7 @@ __global__ __launch_bounds__(256) void dwpw_deep_kernel(ConvArgs a) {
         dacc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv), q.xb[s5], dacc, 0, 0, 0);
       }
       if (a.dw_act) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dacc[r] = silu_f(dacc[r]);
+        dacc = silu4(dacc);
       }
       bf16x4 o;
 #pragma unroll

@@ -159,8 +159,7 @@ __global__ __launch_bounds__(256) void dwpw_tile_kernel(ConvArgs a) {
       for (int nt = 0; nt < NT; ++nt) {
         // (one wave-uniform branch around the four SiLUs: a select per value made hipcc branch around each of them)
         if (a.dw_act) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) dacc[nt][r] = silu_f(dacc[nt][r]);
+          dacc[nt] = silu4(dacc[nt]);
         }
         bf16x4 o;
 #pragma unroll
@@ -215,8 +214,7 @@ __global__ __launch_bounds__(256) void dwpw_tile_kernel(ConvArgs a) {
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
             if (a.act) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) acc[mt][nt][r] = silu_f(acc[mt][nt][r]);
+              acc[mt][nt] = silu4(acc[mt][nt]);
             }
             bf16x4 o;
 #pragma unroll

@@ -213,8 +213,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
             const int r = r0 + u;
             if (r >= S2_SR) continue;
             bf16x4 o;
+            const f32x4 sv = (ACT0 && !(YL_STEM2_ABL & 4)) ? silu4(acc[u]) : acc[u];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) o[q] = (__bf16)((ACT0 && !(YL_STEM2_ABL & 4)) ? silu_f(acc[u][q]) : acc[u][q]);
+            for (int q = 0; q < 4; ++q) o[q] = (__bf16)sv[q];
             const bool row_in = (unsigned)(2 * y0 - 1 + r) < (unsigned)a.H0;  // scalar
             if (!(row_in && col_in)) {  // (scalar branch) stem positions outside the stem map are layer 1's zero padding
               if (!(row_in && (unsigned)(sx0 + n) < (unsigned)a.W0)) o = z;
@@ -231,8 +232,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
           for (int j = 0; j < 8; ++j) bl[j] = *reinterpret_cast<const __bf16*>(corner + koffb[j]);
           const f32x4 al = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bl, bv, 0, 0, 0);
           bf16x4 o;
+          const f32x4 sl = (ACT0 && !(YL_STEM2_ABL & 4)) ? silu4(al) : al;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) o[q] = (__bf16)((ACT0 && !(YL_STEM2_ABL & 4)) ? silu_f(al[q]) : al[q]);
+          for (int q = 0; q < 4; ++q) o[q] = (__bf16)sl[q];
           const bool inside = (unsigned)(2 * y0 - 1 + r) < (unsigned)a.H0 && (unsigned)(2 * x0 - 1 + c) < (unsigned)a.W0;
           if (n < S2_SR) *reinterpret_cast<bf16x4*>(sbase + (size_t)(r * S2_SP + c) * 16) = inside ? o : z;
         }
@@ -304,8 +306,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
           v[4 + r] = acc[2 * p + 1][r];
         }
         if (a.act && !(YL_STEM2_ABL & 8)) {
+          const f32x4 s0 = silu4(acc[2 * p]), s1 = silu4(acc[2 * p + 1]);
 #pragma unroll
-          for (int r = 0; r < 8; ++r) v[r] = silu_f(v[r]);
+          for (int r = 0; r < 4; ++r) {
+            v[r] = s0[r];
+            v[4 + r] = s1[r];
+          }
         }
 #pragma unroll
         for (int r = 0; r < 8; ++r) xb2[p][r] = (__bf16)v[r];
@@ -329,8 +335,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
         v[4 + r] = acc[2 * p + 1][r];
       }
       if (act_last && !(YL_STEM2_ABL & 8)) {
+        const f32x4 s0 = silu4(acc[2 * p]), s1 = silu4(acc[2 * p + 1]);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = silu_f(v[r]);
+        for (int r = 0; r < 4; ++r) {
+          v[r] = s0[r];
+          v[4 + r] = s1[r];
+        }
       }
       const int co = (p * 4 + g) * 8;
       __builtin_amdgcn_raw_buffer_store_b128(
