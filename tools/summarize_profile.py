@@ -116,7 +116,10 @@ def main():
               "side is doubled as MI355X_MICROARCH.md prescribes for gfx950.  Round 3 settles whether that also holds for the 3x3",
               "kernels' tap-shifted loads (round 2: 'probably over-counts by up to 2x'): it does -- see the cross-check columns.", "",
               "MFMA busy: SQ_VALU_MFMA_BUSY_CYCLES (summed over the 1024 SIMDs) / (1024 x GRBM_GUI_ACTIVE / 8 XCDs), from a",
-              "separate pass with one batch in flight.", "",
+              "separate pass with one batch in flight." + ("" if mfma_busy else
+              "  NOT in this collection: the profiled process of that pass ended with a GPU memory access fault ~2 s after its "
+              "start, before the engine existed (pmc_mfma.log; two of four attempts this round, the other PMC passes never) -- "
+              "the column is empty rather than re-tried on a shared node."), "",
               "Read cross-check (round 3, separate pass): TCC_MISS_sum counts the L2 misses of reads AND writes in 128-byte lines --",
               "for every kernel below `misses x 128 B` = `2 x FETCH_SIZE + WRITE_SIZE` within 1-2 % (compare the two read columns with the",
               "write column) and TCC_EA0_RDREQ x 128 B equals 2 x FETCH_SIZE too, none of them 32-byte requests.  So the doubled",
