@@ -558,8 +558,10 @@ def main():
         else:
             for k in range(args.steps):
                 out, cnt = hot_path(xs[k % S])
+        t_issue = time.perf_counter() - t0
         sync_all()
         dt = time.perf_counter() - t0
+        extra["issue_ms"] = round(t_issue * 1e3, 4)  # host time to issue the K steps (inside the timed region)
         extra["step_issue"] = "native: yl_graph_launch_many, one call for the K steps" if native else "python loop"
         out, cnt = slot_res[(args.steps - 1) % S]
         ndet = cnt.float().mean().item()
