@@ -10,9 +10,9 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ( while true; do sleep 60; echo "heartbeat $(date +%T)"; done ) &
 HB=$!
-timeout -k 10 ${LIMIT:-400} rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py $BA --steps 10 --warmup 2 --streams 2 --no-cpu-baseline > $OUT/trace.log 2>&1
+timeout -k 10 ${LIMIT:-400} rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py $BA --steps 10 --warmup 2 --no-cpu-baseline > $OUT/trace.log 2>&1
 echo "trace rc $?"
-timeout -k 10 ${LIMIT:-400} rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -- python3 $R/bench.py $BA --steps 3 --warmup 1 --streams 1 --no-cpu-baseline > $OUT/pmc_mfma.log 2>&1
+timeout -k 10 ${LIMIT:-400} rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -- python3 $R/bench.py $BA --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_mfma.log 2>&1
 echo "pmc rc $?"
 kill $HB
 find $OUT -name "*.db" -delete
