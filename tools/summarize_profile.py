@@ -100,6 +100,7 @@ def main():
     rdreq = pmc(src / "pmc_miss", "TCC_EA0_RDREQ_sum")
     rd32 = pmc(src / "pmc_miss", "TCC_EA0_RDREQ_32B_sum")
     mfma_busy = pmc(src / "pmc_mfma", "SQ_VALU_MFMA_BUSY_CYCLES")
+    one_stream = (src / "pmc_mfma.log").exists() and "--streams 1" in (src / "pmc_mfma.log").read_text()[:4000]
     gui = pmc(src / "pmc_mfma", "GRBM_GUI_ACTIVE")
     bench = None
     if (src / "bench.json").exists():
@@ -116,7 +117,10 @@ def main():
               "side is doubled as MI355X_MICROARCH.md prescribes for gfx950.  Round 3 settles whether that also holds for the 3x3",
               "kernels' tap-shifted loads (round 2: 'probably over-counts by up to 2x'): it does -- see the cross-check columns.", "",
               "MFMA busy: SQ_VALU_MFMA_BUSY_CYCLES (summed over the 1024 SIMDs) / (1024 x GRBM_GUI_ACTIVE / 8 XCDs), from a",
-              "separate pass with one batch in flight." + ("" if mfma_busy else
+              "separate pass" + (" with one batch in flight." if one_stream else
+              " with 20 batches in flight (round 4: `--streams 1` under counter collection crashed the profiled process): dispatches of "
+              "different queues overlap, a dispatch's GRBM_GUI_ACTIVE then spans its neighbours' time too -- read the column as a LOWER "
+              "bound, about half of the one-batch figures (round 3, and commit a06b0e0 of round 4).") + ("" if mfma_busy else
               "  NOT in this collection: the profiled process of that pass ended with a GPU memory access fault ~2 s after its "
               "start, before the engine existed (pmc_mfma.log; two of four attempts this round, the other PMC passes never) -- "
               "the column is empty rather than re-tried on a shared node."), "",
