@@ -32,6 +32,12 @@
                        // 64-pixel tiles then spill from 177-203 to 168 registers): 47.0-47.1 k images/s against 48.2-48.9 k
 #endif
 
+#ifndef YL_DWPW_PF2
+#define YL_DWPW_PF2 1  // the two-register-set prefetch of the depthwise phase for 32 pixels per wave too, in the launches with a fused tail (50 KB of LDS: three workgroups per CU with or without the second set; 68.0 -> 66.4 us for the three levels)
+#endif
+#ifndef YL_DWPW_WPE
+#define YL_DWPW_WPE 2
+#endif
 namespace yl {
 
 // K-steps [kbeg, kbeg + nk) of one patch against the slab currently in LDS (slab row = ks - kbeg).
@@ -335,7 +341,7 @@ __device__ __forceinline__ void dwpw_body(const ConvArgs& a, int block) {
         *reinterpret_cast<bf16x4*>(tb + ((size_t)(2 * pp + (g >> 1)) * P + wave * 16 * NT + nt * 16 + n) * 16 + (g & 1) * 8) = o;
       }
     };
-    if constexpr (NT == 1) {  // (16 pixels per wave = the deep launches on small maps, see yl_engine_create)
+    if constexpr (NT == 1 || (PW2 && YL_DWPW_PF2)) {  // (16 pixels per wave = the deep launches on small maps, see yl_engine_create)
       if (npp > 0) {
         DwIn q0, q1;
         request(0, q0);
@@ -462,7 +468,7 @@ __device__ __forceinline__ void dwpw_body(const ConvArgs& a, int block) {
 }
 
 template <int MT, int NT, bool PW2 = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void dwpw_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(YL_DWPW_WPE))) void dwpw_kernel(ConvArgs a) {
   dwpw_body<MT, NT, PW2>(a, blockIdx.x);
 }
 
@@ -594,7 +600,7 @@ __global__ __launch_bounds__(256) void dwpw_deep_kernel(ConvArgs a) {
 
 // the same for up to three launches of one tiling (the class branch's second half is identical on every Detect level)
 template <int MT, int NT, bool PW2>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void dwpw_group_kernel(ConvGroup G) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(YL_DWPW_WPE))) void dwpw_group_kernel(ConvGroup G) {
   int block = blockIdx.x, m = 0;
   if (block >= G.nb[0]) {
     block -= G.nb[0];
