@@ -599,6 +599,29 @@ def main():
         extra["value_sync_per_iteration"] = round(B / lat, 1)
         extra["sync_per_iteration_note"] = (f"{n_sync} iterations, one batch in flight, hipStreamSynchronize after every "
                                             "iteration (SURVEY 8(d)); `value` pipelines the same step over the streams")
+        if args.dtype == "bf16" and os.environ.get("YL_BENCH_ONE_BATCH_PROFILE", "1") == "1":
+            # the program a caller that runs ONE batch at a time gets (lower(one_batch=True): what YOLOLite.predict() per call
+            # uses -- two workgroups per image in the resident C3k blocks, SPPF / PSABlock as separate launches): same kernels,
+            # same bits, tuned for latency instead of chip time
+            from yololite_amd.nn.engine import HipEngine as _HE
+
+            eng1 = _HE.from_model(specs, sd, B, H, W, dev, one_batch=True)
+            with torch.cuda.stream(st0):
+                for _ in range(5):
+                    o1, c1 = eng1.detect(x8, conf, iou, max_det=max_det, graph=True, slot=0)
+                st0.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(n_sync):
+                    eng1.detect(x8, conf, iou, max_det=max_det, graph=True, slot=0)
+                    st0.synchronize()
+                lat1 = (time.perf_counter() - t1) / n_sync
+                o0, c0 = eng.detect(x8, conf, iou, max_det=max_det, graph=True, slot=0)
+                st0.synchronize()
+            extra["one_batch_profile"] = {"value_sync_per_iteration": round(B / lat1, 1), "latency_ms": round(lat1 * 1e3, 4),
+                                          "program_ops": len(eng1.prog.ops),
+                                          "bit_identical_to_throughput_profile": bool(torch.equal(o1, o0) and torch.equal(c1, c0)),
+                                          "note": "lower(one_batch=True): the program YOLOLite.predict() per call runs"}
+            del eng1
     else:
         # BASELINE.json config 4: rank 0 owns the uint8 global batches (resident in its HBM before the timed region);
         # per step: RCCL scatter of the 32-image slices (S steps ahead) -> one graph launch per rank -> RCCL gather of

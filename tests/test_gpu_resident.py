@@ -98,6 +98,21 @@ def test_c3k_resident_vs_chain_and_torch(gpu_device, B, H, W):
     assert float((err > 1e-6).float().mean()) < 0.2
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 20, 20), (3, 12, 20), (1, 10, 10), (2, 16, 16), (2, 16, 20), (1, 19, 19), (1, 11, 13)])
+def test_c3k_resident_two_workgroups_per_image(gpu_device, monkeypatch, B, H, W):
+    """YL_C3K_SPLIT=2: each workgroup runs the block on its half of the rows + a halo of four (the rows next to the cut are
+    computed with zeros for their missing neighbours and never stored): the same bits as one workgroup per image.  Odd heights,
+    windows that overlap by more than the halo."""
+    gen = torch.Generator().manual_seed(1000 * H + W + 1)
+    blk = _rand_block(gen)
+    x = bf16_round(torch.randn(B, 128, H, W, generator=gen))
+    monkeypatch.setenv("YL_C3K_SPLIT", "1")
+    one = _run_resident(gpu_device, x, blk)
+    monkeypatch.setenv("YL_C3K_SPLIT", "2")
+    two = _run_resident(gpu_device, x, blk)
+    assert torch.equal(one, two), f"max |d| {float((one - two).abs().max())}"
+
+
 @pytest.mark.parametrize("h,w,b", [(640, 640, 8), (384, 640, 8), (320, 320, 9), (640, 640, 32)])
 def test_network_with_resident_c3k_is_bit_identical(gpu_device, monkeypatch, h, w, b):
     """YOLO11n with layers 8 and 22 as ONE launch each against the program with their six launches: level maps and decoded

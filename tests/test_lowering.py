@@ -247,5 +247,8 @@ def test_lowering_uses_resident_c3k_from_batch_8(monkeypatch):
     nopsa = lower(specs, sd, 32, 640, 640)
     assert [len(o["extra_weight"]) for o in nopsa.ops if o["kind"] == OP_SPPF] == [2] and len(nopsa.ops) == len(big.ops) + 5
     monkeypatch.delenv("YL_FUSE_PSA")
+    lat = lower(specs, sd, 32, 640, 640, one_batch=True)  # the latency profile: resident C3k with two workgroups per image, SPPF / PSA unfused
+    assert [o["split"] for o in lat.ops if o["kind"] == OP_C3K] == [2, 2] and all(o["split"] == 0 for o in big.ops if o["kind"] == OP_C3K)
+    assert not [o for o in lat.ops if o["kind"] in (OP_PSA, OP_SPPF)] and len(lat.ops) == len(big.ops) + 3 + 5
     s_scale = lower(arch.parse_model(arch.yolo11_dict("s"))[0], synth_state_dict("s", 0), 32, 640, 640)
     assert not [o for o in s_scale.ops if o["kind"] == OP_C3K]   # inner width 128: the maps do not fit

@@ -1119,6 +1119,7 @@ static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s, c
         q.w[k] = r.d_xw[k];
         q.bias[k] = r.d_xb[k];
       }
+      q.split = o.reserved3;  // (workgroups per image asked for by the program: 2, or 0 / 1)
       return c3k_resident_launch(q, s);
     }
     case YL_OP_SPPF: {
@@ -1429,7 +1430,17 @@ static int forward_impl(yl_engine* e, const void* input, int in_dtype, void* wor
     const int lane = r.op.lane;
     if (lane == 0) {
       int consumed = 1;
+      static const bool trace = getenv("YL_TRACE_OPS") != nullptr;  // development: name every eager launch and wait for it
+      if (trace) fprintf(stderr, "[yl] op %zu kind %d (%s)\n", oi, (int)r.op.kind, r.name);
       if (int rc = run_at(e, oi, ws, s, input, in_dtype, &consumed, sink)) return rc;
+      if (trace) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(s, &cs);
+        if (cs == hipStreamCaptureStatusNone) {
+          YL_HIP(hipStreamSynchronize(s));
+          fprintf(stderr, "[yl] op %zu done\n", oi);
+        }
+      }
     } else {
       hipEvent_t ev = ss.events[nev++];
       YL_HIP(hipEventRecord(ev, s));

@@ -17,6 +17,20 @@ namespace yl {
 
 constexpr int NSUB = PF_NSUB;
 
+// Counters are cleared by a KERNEL, not by hipMemsetAsync: a memset captured into a hipGraph (the hot path's candidate counters)
+// was found to stop clearing once other work ran eagerly in the process -- another engine's first run, a detect(graph=False) -- on
+// the legacy null stream: the replayed graphs then ACCUMULATED candidates from call to call (counts 50 -> 86 -> 101 per image) or
+// ended in a GPU memory fault (tests/test_gpu_streams.py after the allocator's layout changed; ROCm 7.2; NOTEBOOK section 13).
+// A kernel node carries its own arguments.
+__global__ void zero_i32_kernel(int32_t* __restrict__ p, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0;
+}
+static inline hipError_t zero_i32(int32_t* p, size_t n, hipStream_t s) {
+  hipLaunchKernelGGL(zero_i32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, (int)n);
+  return hipGetLastError();
+}
+
 struct NmsWs {
   int32_t* count;       // [B]
   // fused decode path: anchors that passed the logit pre-filter, in NSUB sub-lists per image (same-address
@@ -485,7 +499,7 @@ extern "C" int yl_nms(const float* pred, int batch, int nc, int anchors, float c
   nms_layout(batch, anchors, max_cand, (char*)work, &w);
   if (w.M > 64 * 64 * SCAN_T) return fail(-3, "yl_nms: max_cand above 32768 is not supported");
   hipStream_t s = (hipStream_t)stream;
-  YL_HIP(hipMemsetAsync(w.count, 0, 4 * (size_t)batch, s));
+  YL_HIP(zero_i32(w.count, (size_t)batch, s));
   hipLaunchKernelGGL(nms_candidates_kernel, dim3((anchors + 255) / 256, batch), dim3(256), 0, s, pred, nc, anchors,
                      conf_thres, classes, classes ? n_classes : 0, w);
   hipLaunchKernelGGL(nms_sort_kernel, dim3(batch), dim3(1024), 0, s, pred, nc, anchors, agnostic, max_wh, w);
@@ -514,7 +528,7 @@ extern "C" int yl_nms_ml(const float* pred, int batch, int nc, int anchors, floa
   if (w.M > 64 * 64 * SCAN_T) return fail(-3, "yl_nms_ml: max_cand above 32768 is not supported");
   w.ml_nc = nc > 1 ? nc : 0;  // ops.py:208: multi_label &= nc > 1
   hipStream_t s = (hipStream_t)stream;
-  YL_HIP(hipMemsetAsync(w.count, 0, 4 * (size_t)batch, s));
+  YL_HIP(zero_i32(w.count, (size_t)batch, s));
   if (w.ml_nc)
     hipLaunchKernelGGL(nms_candidates_ml_kernel, dim3((anchors + 255) / 256, batch), dim3(256), 0, s, pred, nc, anchors,
                        conf_thres, classes, classes ? n_classes : 0, w);
@@ -910,7 +924,7 @@ int yl::decode_nms_stages(const void* workspace, const yl_level* levels, int n_l
   hipStream_t s = (hipStream_t)stream;
   if (prefiltered && !sparse) return fail(-1, "yl_decode_nms: the fused pre-filter exists for the sparse decode path only");
   if (ev) (void)hipEventRecord(ev[0], s);
-  if (!prefiltered) YL_HIP(hipMemsetAsync(w.count, 0, 4 * (size_t)batch * (1 + NSUB), s));  // count + pre_count
+  if (!prefiltered) YL_HIP(zero_i32(w.count, (size_t)batch * (1 + NSUB), s));  // count + pre_count
   const dim3 grid((unsigned)((A + 255) / 256), batch);
   if (sparse) {
     w.fused = 1;
@@ -954,7 +968,7 @@ int yl::prefilter_sink_prepare(const yl_level* levels, int n_levels, int batch, 
   for (int i = 0; i < n_levels; ++i) A += levels[i].H * levels[i].W;
   NmsWs w;
   nms_layout(batch, A, max_cand, (char*)work, &w);
-  YL_HIP(hipMemsetAsync(w.count, 0, 4 * (size_t)batch * (1 + NSUB), (hipStream_t)stream));  // count + pre_count
+  YL_HIP(zero_i32(w.count, (size_t)batch * (1 + NSUB), (hipStream_t)stream));  // count + pre_count
   sink->pre_count = w.pre_count;
   sink->pre_list = w.pre_list;
   sink->sub_cap = w.sub_cap;

@@ -38,6 +38,8 @@ constexpr int RC_WAVES = RC_THREADS / 64;
 
 struct PixMap {
   int H, W, W1, HW;
+  int o0, o1;  // rows of this map the workgroup stores (the whole map unless the image is split between workgroups)
+  int goff;    // pixels between the map's first row and the image's first row in the HBM plane (row offset * W1)
 };
 // dense pixel index -> guarded index inside one image's plane (0 = the pixel above-left of (0, 0)); clamped for i >= HW
 __device__ __forceinline__ int guarded_index(const PixMap& m, int i, bool& valid) {
@@ -166,8 +168,11 @@ __device__ __forceinline__ void step_out(const C3kArgs& a, const PixMap& pm, con
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     bool ok;
-    const int gi = guarded_index(pm, (t0 + nt) * 16 + n, ok);
-    opix[nt] = ok ? (unsigned)(b * a.img + gi) * 16u : OOB_LANE;  // (g0 of the HBM layout == W1 + 1 == the LDS map's origin)
+    const int pi = (t0 + nt) * 16 + n;
+    const int gi = guarded_index(pm, pi, ok);
+    const int py = pi / pm.W;
+    ok = ok && py >= pm.o0 && py < pm.o1;
+    opix[nt] = ok ? (unsigned)(b * a.img + pm.goff + gi) * 16u : OOB_LANE;  // (g0 of the HBM layout == W1 + 1 == the LDS map's origin)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) xa[ks][nt] = *reinterpret_cast<const bf16x8*>(lds + a.r1 + (ks * 4 + g) * a.apl + gi * 16);
   }
@@ -220,8 +225,14 @@ __global__ __launch_bounds__(RC_THREADS) void c3k_resident_kernel(C3kArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, g = lane >> 4;
-  const int b = blockIdx.x;
-  PixMap pm{a.H, a.W, a.W1, a.H * a.W};
+  // a.split workgroups per image: each runs the block on a.Hs rows of it -- its share of the output rows + a halo of four (four
+  // chained 3x3 convs; the rows nearer to the cut than their conv's depth see zeros for their missing neighbours and are never
+  // stored) -- as if those rows were the image.  Same arithmetic per stored pixel: bit-identical to one workgroup per image.
+  const int b = blockIdx.x / a.split, part = blockIdx.x - b * a.split;
+  const int half = (a.H + 1) / 2;
+  const int ys = a.split == 1 ? 0 : (part == 0 ? 0 : a.H - a.Hs);
+  PixMap pm{a.Hs, a.W, a.W1, a.Hs * a.W, a.split == 1 ? 0 : (part == 0 ? 0 : half - ys), a.split == 1 ? a.Hs : (part == 0 ? half : a.Hs),
+            ys * a.W1};
   const int HWp = a.ntiles * 16;
 #define RC_STAMP(id) YL_STAMP(a.stamps, RC_WAVES, wave, lane, id)
   RC_STAMP(0);
@@ -246,7 +257,7 @@ __global__ __launch_bounds__(RC_THREADS) void c3k_resident_kernel(C3kArgs a) {
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, (short)0, a.x_bytes, 0x00020000);
     bool ok;
     const int gi = guarded_index(pm, tid, ok);
-    const unsigned src = ok ? (unsigned)(b * a.img + gi) * 16u : OOB_LANE;
+    const unsigned src = ok ? (unsigned)(b * a.img + pm.goff + gi) * 16u : OOB_LANE;
     bf16x8 v[16];
 #pragma unroll
     for (int p = 0; p < 16; ++p)
@@ -878,14 +889,21 @@ template <int NTQ>
 static int c3k_launch_t(const C3kArgs& a, size_t lds, hipStream_t s) {
   auto kern = c3k_resident_kernel<NTQ>;
   if (int rc = allow_big_lds(reinterpret_cast<const void*>(kern), 160 * 1024)) return rc;
-  hipLaunchKernelGGL(kern, dim3((unsigned)a.B), dim3(RC_THREADS), lds, s, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(a.B * a.split)), dim3(RC_THREADS), lds, s, a);
   YL_HIP(hipGetLastError());
   return 0;
 }
 
 int c3k_resident_launch(C3kArgs a, hipStream_t s) {
   if (!c3k_resident_fits(64, a.H, a.W)) return fail(-3, "c3k_resident: the map does not fit one workgroup's LDS");
-  const size_t lds = c3k_resident_lds(a.H, a.W, &a.xpl, &a.apl, &a.r1, &a.ntiles);
+  // Workgroups per image (YL_C3K_SPLIT, read per launch: the tests switch it).  Two: each takes half of the rows + a halo of four
+  // = 0.7 of the map on a 20x20 image: 0.83 of the latency (47.4 -> 39.4 us) for 1.4 x the chip time.  The program asks for it
+  // (yl_op.reserved3 = 2: nn/lower.py one_batch=True, the predictor's one-batch-at-a-time path); with 20 batches in flight it costs
+  // 1.5 % of the throughput.
+  const int want = getenv("YL_C3K_SPLIT") ? atoi(getenv("YL_C3K_SPLIT")) : a.split;
+  a.split = (want == 2 && (a.H + 1) / 2 + 4 < a.H) ? 2 : 1;
+  a.Hs = a.split == 2 ? (a.H + 1) / 2 + 4 : a.H;
+  const size_t lds = c3k_resident_lds(a.Hs, a.W, &a.xpl, &a.apl, &a.r1, &a.ntiles);
   a.stamps = g_stamp_buf;
   a.scratch = a.r1 + 8 * a.apl;
   static const int dbg = getenv("YL_RES_DBG") ? atoi(getenv("YL_RES_DBG")) : 0;  // development: 1 = no filter warm-up

@@ -315,6 +315,7 @@ struct C3kArgs {
   int r1;                     // LDS byte offset of region 1
   int scratch;                // LDS byte offset of a 64-byte scratch area (target of the filter warm-up loads)
   int dbg;                    // development switches (YL_RES_DBG), 0 in production
+  int split, Hs;              // workgroups per image and the rows each works on (filled by c3k_resident_launch)
   unsigned long long* stamps; // diagnostic builds (-DYL_STAMPS): [workgroup][wave][32] x {s_memtime, s_memrealtime}; else unused
 };
 bool c3k_resident_fits(int c_, int H, int W);

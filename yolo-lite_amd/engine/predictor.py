@@ -156,7 +156,10 @@ class DetectionPredictor:
         no host synchronisation.  ``after``: an event that already orders the input in front of this batch (then the batch's
         stream waits for it instead of for the current stream's tail)."""
         b, _, h, w = im.shape
-        eng = self.model.engine_for(b, h, w, calib=im.contiguous())
+        # (the one-batch-at-a-time path takes the latency profile of the program, the pipelined path the throughput profile:
+        # nn/lower.py one_batch; YL_PREDICT_ONE_BATCH_PROFILE=0: one engine for both)
+        eng = self.model.engine_for(b, h, w, calib=im.contiguous(),
+                                    one_batch=stream is None and os.environ.get("YL_PREDICT_ONE_BATCH_PROFILE", "1") != "0")
         shapes, imgs, scale = self._shapes_and_scale(im, orig_imgs, b, im.device)
         # ONE hipGraph launch per batch (reference model.py:89-99 -> predictor.py:149-229 is ~320 module calls): the
         # input and the scale table are staged into engine-owned buffers whose addresses the graph baked in

@@ -75,13 +75,18 @@ class AutoBackend:
     def eval(self):
         return self
 
-    def engine_for(self, b: int, h: int, w: int, calib: "torch.Tensor | None" = None) -> HipEngine:
+    def engine_for(self, b: int, h: int, w: int, calib: "torch.Tensor | None" = None, one_batch: bool = False) -> HipEngine:
         """The engine for this input shape (built on first use).  ``YL_DTYPE=fp8`` selects the e4m3 mode (dense 3x3 convs
         on the fp8 matrix pipe); its activation scales are calibrated on ``calib``, the first batch
         of that shape the predictor sees."""
-        key = (b, h, w, self.model._version)
+        # (one_batch: the predictor's per-call path runs ONE batch at a time and takes the latency profile of the program,
+        # its pipelined path the throughput profile; same kernels, same bits)
+        key = (b, h, w, self.model._version, bool(one_batch))
         eng = self._engines.get(key)
         if eng is None:
+            if os.environ.get("YL_ENGINE_ONE_PROFILE", "1") == "1":  # one profile of a shape alive at a time
+                self._engines.pop((b, h, w, self.model._version, not one_batch), None)
+                torch.cuda.empty_cache()
             if self.device.type != "cuda":
                 raise RuntimeError("the YOLO11 network runs on the GPU only (HIP kernels; no CPU fallback): "
                                    "pass device=0 / 'cuda:0'")
@@ -89,7 +94,7 @@ class AutoBackend:
             if fp8 and calib is None:
                 raise RuntimeError("YL_DTYPE=fp8 needs a calibration batch: call forward() / predict() with real inputs")
             eng = HipEngine.from_model(self.model.specs, self.model.state_dict(), b, h, w, self.device,
-                                       strides=self.model.stride.tolist(), fp8_calib=calib if fp8 else None)
+                                       strides=self.model.stride.tolist(), fp8_calib=calib if fp8 else None, one_batch=one_batch)
             self._engines[key] = eng
             while len(self._engines) > self.MAX_ENGINES:
                 self._engines.popitem(last=False)

@@ -76,6 +76,7 @@ class HipEngine:
                 pb = (C.c_void_p * len(xb))(*[b.ctypes.data for b in xb])
                 self._keep += xw + xb + [pw, pb]
                 c.n_extra, c.extra_weight, c.extra_bias = len(xw), C.cast(pw, C.c_void_p), C.cast(pb, C.c_void_p)
+            c.reserved3 = int(o.get("split", 0))  # YL_OP_C3K: workgroups per image (0 = the engine's choice)
             if "post_weight" in o:
                 w2 = np.ascontiguousarray(o["post_weight"], dtype=np.float32).reshape(o["post_weight"].shape[0], -1)
                 b2 = np.ascontiguousarray(o["post_bias"], dtype=np.float32)
@@ -116,21 +117,23 @@ class HipEngine:
     def from_model(cls, specs: Sequence[LayerSpec], state_dict: Dict[str, torch.Tensor], batch: int, in_h: int,
                    in_w: int, device: torch.device, strides: Sequence[float] = (8.0, 16.0, 32.0),
                    keep_layers: bool = False, fp8_calib: Optional[torch.Tensor] = None,
-                   fp8_headroom: float = 2.0) -> "HipEngine":
+                   fp8_headroom: float = 2.0, one_batch: bool = False) -> "HipEngine":
         """``keep_layers=True`` (debug: ``layer_output`` of every layer) disables the fusions that make
         intermediate tensors disappear; pass False for the production program.
 
         ``fp8_calib`` (a representative input batch) selects the e4m3 mode of BASELINE.json config 5: the bf16 program
         runs once on it, every dense 3x3 conv's input range is measured (``calibrate_fp8``), and the program is
-        lowered again with those convs on the fp8 matrix pipe (``lower.apply_fp8``)."""
-        prog = lower(specs, state_dict, batch, in_h, in_w, strides, fuse_post=not keep_layers)
+        lowered again with those convs on the fp8 matrix pipe (``lower.apply_fp8``).
+
+        ``one_batch=True``: the latency profile (``lower(one_batch=True)``) for callers that run one batch at a time."""
+        prog = lower(specs, state_dict, batch, in_h, in_w, strides, fuse_post=not keep_layers, one_batch=one_batch)
         if fp8_calib is None:
             return cls(prog, device)
         e16 = cls(prog, device)
         scales = e16.calibrate_fp8(fp8_calib, fp8_headroom)
         del e16
         torch.cuda.empty_cache()
-        return cls(lower(specs, state_dict, batch, in_h, in_w, strides, fuse_post=not keep_layers, fp8_scales=scales), device)
+        return cls(lower(specs, state_dict, batch, in_h, in_w, strides, fuse_post=not keep_layers, fp8_scales=scales, one_batch=one_batch), device)
 
     def calibrate_fp8(self, im: torch.Tensor, headroom: float = 2.0) -> Dict[str, float]:
         """{conv name: input scale} for every conv the fp8 pass may take: absmax of the conv's input after a forward of

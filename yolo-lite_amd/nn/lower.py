@@ -649,7 +649,10 @@ def group_detect_levels(ops: List[dict], det_prefix: str, nlv: int, keep_first_b
 
 def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, in_h: int, in_w: int,
           strides: Sequence[float] = (8.0, 16.0, 32.0), side_lanes: bool = True, fuse_post: bool = True,
-          fused_stem: bool = True, fp8_scales: Optional[Dict[str, float]] = None) -> Program:
+          fused_stem: bool = True, fp8_scales: Optional[Dict[str, float]] = None, one_batch: bool = False) -> Program:
+    """``one_batch=True``: the program of a caller that runs ONE batch at a time (``predict()`` per call): the resident C3k blocks take two
+    workgroups per image (0.83 of the latency for 1.4 x the chip time; with batches in flight it costs 1.5 % of the throughput), and
+    SPPF / the PSABlock stay separate launches (their one-launch forms win chip time, not latency)."""
     det = specs[-1]
     assert det.kind == "Detect"
     prog = Program(batch, in_h, in_w, det.nc, strides=tuple(float(s) for s in strides))
@@ -736,7 +739,7 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
             xw.append(w3.reshape(w3.shape[0], -1))
             xb.append(b3)
             names.append(p + ".cv3")
-            ops.append(dict(kind=OP_C3K, name=p, act=1, inp=x, out=y, res=None,
+            ops.append(dict(kind=OP_C3K, name=p, act=1, inp=x, out=y, res=None, split=2 if one_batch else 0,
                             weight=np.concatenate([w1, w2], 0).reshape(2 * c_, -1), bias=np.concatenate([b1, b2], 0),
                             extra_weight=xw, extra_bias=xb, fused_names=names))
             return
@@ -877,7 +880,8 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
             only_reader = (nxt is not None and nxt.kind == "C2PSA" and nxt.f == -1 and sp.i not in dest and sp.i not in level_of
                            and not any(sp.i in (q.f if isinstance(q.f, (list, tuple)) else [q.f]) for q in specs))
             tail_c = 2 * int(nxt.c1 * 0.5) if only_reader else 0
-            if (fuse_post and os.environ.get("YL_FUSE_SPPF", "1") != "0" and not fp8_scales
+            # (not in the one-batch profile: 55.6 us against 52.5 us in sequence -- it pays in chip time, not in latency)
+            if (fuse_post and os.environ.get("YL_FUSE_SPPF", "1") != "0" and not fp8_scales and not one_batch
                     and batch >= int(os.environ.get("YL_FUSE_C3K_MIN_BATCH", "8"))
                     and (sppf_resident_fits(sp.c1, sp.c2, tail_c, src.H, src.W) or sppf_resident_fits(sp.c1, sp.c2, 0, src.H, src.W))):
                 if not sppf_resident_fits(sp.c1, sp.c2, tail_c, src.H, src.W):
@@ -918,7 +922,8 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
                 q = f"{p}.m.{j}"
                 # the whole PSABlock in ONE launch, one workgroup per image (csrc/resident.hip psa_resident_kernel: 6 launches ->
                 # 1, bit-identical); small batches keep the six launches, like the resident C3k block
-                if (fuse_post and os.environ.get("YL_FUSE_PSA", "1") != "0" and psa_resident_fits(c, nh, kd, hd, src.H, src.W)
+                # (not in the one-batch profile: 71 us against 68 us in sequence)
+                if (fuse_post and os.environ.get("YL_FUSE_PSA", "1") != "0" and not one_batch and psa_resident_fits(c, nh, kd, hd, src.H, src.W)
                         and batch >= int(os.environ.get("YL_FUSE_C3K_MIN_BATCH", "8")) and not fp8_scales):
                     wq, bq = fold_conv_bn(sd, q + ".attn.qkv")
                     names, xw, xb = [q + ".attn.qkv", q + ".attn"], [], []
