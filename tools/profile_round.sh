@@ -22,12 +22,11 @@ timeout -k 10 ${LIMIT:-300} rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O
 # independent read-side count (round 3): L2 misses x 128-byte lines, and the fabric read requests with their 32-byte share
 echo "pass TCC_MISS_sum $(date +%T)"
 timeout -k 10 ${LIMIT:-300} rocprofv3 --pmc TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --output-format csv -d $OUT/pmc_miss -- python3 $R/bench.py $BA --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs > $OUT/pmc_miss.log 2>&1
-# matrix-pipe occupancy per kernel: busy cycles summed over the 1024 SIMDs / (1024 x kernel cycles).  Counter collection
-# serialises the dispatches, so GRBM_GUI_ACTIVE of a dispatch is that kernel's own duration whatever the stream count; rounds 2-3
-# ran this pass with --streams 1, which in round 4 ended in a memory fault / segfault inside the profiled process in 4 of 6
-# attempts (the passes with the default 20 streams never did): dropped
+# matrix-pipe occupancy per kernel: busy cycles summed over the 1024 SIMDs / (1024 x kernel cycles); one batch at a time
+# (--streams 1) so that GRBM_GUI_ACTIVE of a dispatch is that kernel's own duration.  (Round 4: this pass crashed the profiled process
+# in 4 of 6 attempts until the hot path's captured hipMemsetAsync was replaced by a kernel -- csrc/nms.hip zero_i32 -- and ran clean since.)
 echo "pass SQ_VALU_MFMA_BUSY_CYCLES $(date +%T)"
-timeout -k 10 ${LIMIT:-300} rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -- python3 $R/bench.py $BA --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs > $OUT/pmc_mfma.log 2>&1
+timeout -k 10 ${LIMIT:-300} rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_mfma -- python3 $R/bench.py $BA --steps 5 --warmup 2 --streams 1 --no-cpu-baseline --no-other-configs > $OUT/pmc_mfma.log 2>&1
 # (every pass under its own time limit and announced on stdout: a pass that hangs -- one did, after a profiler-side memory fault two
 # seconds into the process -- must not take the call with it)
 # keep only the small CSVs
