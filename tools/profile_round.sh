@@ -13,8 +13,10 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 echo "bench $(date +%T)"
 timeout -k 10 ${LIMIT:-500} python3 $R/bench.py $BA --profile-out $OUT/per_op.json > $OUT/bench.json 2> $OUT/bench.err
+# (one batch in flight: a kernel's duration is its own -- with 20 batches in flight, all started within 0.2 ms by the issue threads,
+# the same kernels' wall durations stretch 3 x (conv1x1: 13 -> 44 us) while the throughput is unchanged)
 echo "pass --stats $(date +%T)"
-timeout -k 10 ${LIMIT:-300} rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py $BA --steps 20 --warmup 5 --no-cpu-baseline --no-other-configs > $OUT/trace.log 2>&1
+timeout -k 10 ${LIMIT:-300} rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py $BA --steps 20 --warmup 5 --streams 1 --no-cpu-baseline --no-other-configs > $OUT/trace.log 2>&1
 echo "pass FETCH_SIZE $(date +%T)"
 timeout -k 10 ${LIMIT:-300} rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py $BA --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs > $OUT/pmc_fetch.log 2>&1
 echo "pass WRITE_SIZE $(date +%T)"

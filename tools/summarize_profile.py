@@ -109,7 +109,7 @@ def main():
         (dst / f"{tag}_bench.json").write_text(json.dumps(bench, indent=1))
     if (src / "per_op.json").exists():
         shutil.copy(src / "per_op.json", dst / f"{tag}_per_op.json")
-    lines = [f"# {tag}: rocprofv3 --kernel-trace --stats of `python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline`", ""]
+    lines = [f"# {tag}: rocprofv3 --kernel-trace --stats of `python3 bench.py --steps 20 --warmup 5 --streams 1 --no-cpu-baseline` (one batch in flight: kernel-only durations)", ""]
     if bench:
         lines += [f"bench (un-profiled run): **{bench['value']} {bench['unit']}**, {bench['ms_per_step']} ms/step, "
                   f"roofline {json.dumps(bench.get('roofline'))}", ""]
