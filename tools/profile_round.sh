@@ -13,6 +13,9 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 echo "bench $(date +%T)"
 timeout -k 10 ${LIMIT:-500} python3 $R/bench.py $BA --profile-out $OUT/per_op.json > $OUT/bench.json 2> $OUT/bench.err
+# the profiled passes run the THROUGHPUT profile of the program only (the latency profile's extra launches -- the predictor's per-call
+# engine, the bench's one_batch_profile engine -- would mix another population into the per-kernel averages)
+export YL_BENCH_ONE_BATCH_PROFILE=0 YL_PREDICT_ONE_BATCH_PROFILE=0
 # (one batch in flight: a kernel's duration is its own -- with 20 batches in flight, all started within 0.2 ms by the issue threads,
 # the same kernels' wall durations stretch 3 x (conv1x1: 13 -> 44 us) while the throughput is unchanged)
 echo "pass --stats $(date +%T)"
