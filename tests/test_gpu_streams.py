@@ -109,3 +109,42 @@ def test_native_multi_step_launch_equals_detect(gpu_device):
                 total += n
                 assert torch.equal(outs[j][0][i, :n], ro[i, :n]), (rnd, j, i)
         assert total > 0
+
+
+def test_prepared_graphs_survive_eager_work_of_another_engine(gpu_device):
+    """Regression (round 4): the hot path's graphs used to clear their candidate counters with a captured hipMemsetAsync; after
+    EAGER engine work elsewhere in the process -- here a second engine, created after the graphs, running detect(graph=False) on the
+    default stream -- the replays stopped clearing them: counts grew from round to round, or the process died with a GPU memory
+    fault.  The counters are cleared by a kernel now (csrc/nms.hip zero_i32): every replay must equal the other engine's answer."""
+    from yololite_amd.nn import arch
+    from yololite_amd.nn.engine import HipEngine
+    from yololite_amd.nn.synth import synth_state_dict
+
+    specs, _ = arch.parse_model(arch.yolo11_dict("n"))
+    sd = synth_state_dict("n", 3, cls_bias=[-3.0, -3.0, -3.0], cls_gain=6.0)
+    eng = HipEngine.from_model(specs, sd, 2, 96, 128, gpu_device)
+    g = torch.Generator().manual_seed(21)
+    S = 3
+    xs = [torch.randint(0, 256, (2, 3, 96, 128), generator=g, dtype=torch.uint8).to(gpu_device) for _ in range(S)]
+    streams = [torch.cuda.Stream(device=gpu_device) for _ in range(S)]
+    outs, handles = [], []
+    for j in range(S):
+        with torch.cuda.stream(streams[j]):
+            o, c, h = eng.prepare_detect(xs[j], 0.25, 0.7, slot=j)
+        outs.append((o, c))
+        handles.append(h)
+    torch.cuda.synchronize()
+    other = HipEngine.from_model(specs, sd, 2, 96, 128, gpu_device)  # created AFTER the graphs
+    for rnd in range(3):
+        for j in range(S):
+            xs[j].copy_(torch.randint(0, 256, (2, 3, 96, 128), generator=g, dtype=torch.uint8))
+        torch.cuda.synchronize()
+        eng.launch_many([handles[k % S] for k in range(2 * S)], [streams[k % S] for k in range(2 * S)])
+        torch.cuda.synchronize()
+        for j in range(S):
+            ro, rc = other.detect(xs[j], 0.25, 0.7, graph=False, slot=0)  # eager, on the default stream
+            torch.cuda.synchronize()
+            assert torch.equal(outs[j][1], rc), (rnd, j, outs[j][1].tolist(), rc.tolist())
+            for i in range(2):
+                n = int(rc[i])
+                assert torch.equal(outs[j][0][i, :n], ro[i, :n]), (rnd, j, i)
