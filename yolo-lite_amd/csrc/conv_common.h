@@ -22,7 +22,7 @@ __device__ __forceinline__ float silu_f(float v) {
 // Four SiLUs with the three full-rate steps as PACKED fp32 instructions (v_pk_mul_f32 / v_pk_add_f32: two values per lane and
 // instruction; hipcc leaves adjacent scalar silu_f calls unpacked): 6 + 8 instructions per four values instead of 12 + 8, the
 // same IEEE operations on the same operands -- bit-identical to silu_f.  The fused small-channel kernels are bound by
-// instruction issue and SiLU is 45-58 % of their slots (NOTEBOOK section 13).
+// instruction issue (NOTEBOOK section 13).
 typedef __attribute__((ext_vector_type(4))) float silu_f32x4;
 __device__ __forceinline__ silu_f32x4 silu4(silu_f32x4 v) {
 #ifdef YL_ABL_NO_SILU
