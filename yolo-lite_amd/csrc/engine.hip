@@ -1172,6 +1172,7 @@ static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s, c
       q.b_ffn0 = r.d_xb[3];
       q.b_ffn1 = r.d_xb[4];
       q.w_pe = r.d_w;
+      q.split = o.reserved3;  // (workgroups per image asked for by the program; 0: psa_resident_launch's choice)
       return psa_resident_launch(q, s);
     }
     case YL_OP_C3K2S: {

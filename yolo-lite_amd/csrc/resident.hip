@@ -846,7 +846,7 @@ int psa_resident_launch(const PsaArgs& a0, hipStream_t s) {
   // Workgroups per image.  One workgroup per image is the cheapest in chip time (the key / value conv runs once), but a batch
   // of 32 then occupies 32 of the 256 CUs for ~90 us; two halve that time for ~10 % more work (YL_PSA_SPLIT overrides).
   const int split_env = getenv("YL_PSA_SPLIT") ? atoi(getenv("YL_PSA_SPLIT")) : 0;  // (read per launch: the tests switch it)
-  int split = split_env > 0 ? split_env : (ntiles > 16 ? 2 : 1);
+  int split = split_env > 0 ? split_env : a0.split > 0 ? a0.split : (ntiles > 16 ? 2 : 1);  // (a0.split: asked for by the program, yl_op.reserved3)
   if (split > ntiles) split = ntiles;
   if (split < 1 || split > 4) split = 1;
   while (split < 4 && ((ntiles + split - 1) / split + 7) / 8 > 2) ++split;  // the own share: at most two tiles per wave

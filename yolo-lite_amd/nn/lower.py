@@ -652,7 +652,8 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
           fused_stem: bool = True, fp8_scales: Optional[Dict[str, float]] = None, one_batch: bool = False) -> Program:
     """``one_batch=True``: the program of a caller that runs ONE batch at a time (``predict()`` per call): the resident C3k blocks take two
     workgroups per image (0.83 of the latency for 1.4 x the chip time; with batches in flight it costs 1.5 % of the throughput), and
-    SPPF / the PSABlock stay separate launches (their one-launch forms win chip time, not latency)."""
+    SPPF / the PSABlock stay separate launches (their one-launch forms win chip time, not latency), and the Detect levels' box and
+    class branch launches are joined (YL_GROUP_LEVELS=3)."""
     det = specs[-1]
     assert det.kind == "Detect"
     prog = Program(batch, in_h, in_w, det.nc, strides=tuple(float(s) for s in strides))
@@ -922,8 +923,10 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
                 q = f"{p}.m.{j}"
                 # the whole PSABlock in ONE launch, one workgroup per image (csrc/resident.hip psa_resident_kernel: 6 launches ->
                 # 1, bit-identical); small batches keep the six launches, like the resident C3k block
-                # (not in the one-batch profile: 71 us against 68 us in sequence)
-                if (fuse_post and os.environ.get("YL_FUSE_PSA", "1") != "0" and not one_batch and psa_resident_fits(c, nh, kd, hd, src.H, src.W)
+                # (the one-batch profile keeps the six launches: 69.8 us in sequence against 71 us; with FOUR workgroups per image --
+                # YL_LAT_PSA=1 -- the one-launch form measures the same there, 34.4 against 34.5 k one batch at a time)
+                if (fuse_post and os.environ.get("YL_FUSE_PSA", "1") != "0" and not (one_batch and os.environ.get("YL_LAT_PSA", "0") != "1")
+                        and psa_resident_fits(c, nh, kd, hd, src.H, src.W)
                         and batch >= int(os.environ.get("YL_FUSE_C3K_MIN_BATCH", "8")) and not fp8_scales):
                     wq, bq = fold_conv_bn(sd, q + ".attn.qkv")
                     names, xw, xb = [q + ".attn.qkv", q + ".attn"], [], []
@@ -934,7 +937,7 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
                         names.append(q + part)
                     # (in -> out, never in place: cat(a, b) of this block's input buffer becomes cat(a, b') in a fresh one)
                     u2 = ar.alloc(src.H, src.W, 2 * c)
-                    ops.append(dict(kind=OP_PSA, name=q, act=0, heads=nh, key_dim=kd, head_dim=hd, scale=float(kd ** -0.5),
+                    ops.append(dict(kind=OP_PSA, name=q, act=0, heads=nh, key_dim=kd, head_dim=hd, scale=float(kd ** -0.5), split=4 if one_batch else 0,
                                     inp=u, out=u2, res=None, weight=wq.reshape(wq.shape[0], -1), bias=bq, extra_weight=xw,
                                     extra_bias=xb, fused_names=names))
                     u = u2
@@ -980,7 +983,9 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
             # The Detect levels' copies of one conv in one launch (round 2): 69 -> 64 launches, one batch at a time 1.106 ->
             # 1.06 ms.  YL_GROUP_LEVELS=2 (default) leaves level 0's first box conv on its own kernel (conv3_reg_kernel);
             # =1 groups it too (one launch fewer, -1 % with 20 batches in flight); =0 separate launches.
-            gl = os.environ.get("YL_GROUP_LEVELS", "2")
+            # (the latency profile joins the box and class branch launches of the levels too, =3: 42 -> 38 launches, one batch at a
+            # time +2.4 %, with batches in flight -2.7 %)
+            gl = os.environ.get("YL_GROUP_LEVELS", "3" if one_batch else "2")
             if gl in ("1", "2", "3", "4") and not fp8_scales:
                 ops[:] = group_detect_levels(ops, dp, nlv, keep_first_box_conv=gl == "2", join_branches=gl in ("3", "4"),
                                              join_first_only=gl == "4")
