@@ -84,9 +84,12 @@ class AutoBackend:
         key = (b, h, w, self.model._version, bool(one_batch))
         eng = self._engines.get(key)
         if eng is None:
-            if os.environ.get("YL_ENGINE_ONE_PROFILE", "1") == "1":  # one profile of a shape alive at a time
-                self._engines.pop((b, h, w, self.model._version, not one_batch), None)
-                torch.cuda.empty_cache()
+            # one profile of a shape alive at a time: with both resident, predict(stream=True) fell from 52 k to 46 k images/s (an
+            # idle engine's streams, graphs and 2-42 GB of workspaces are not free on this runtime); a caller that alternates
+            # modes on one shape pays a rebuild (~0.5 s) per switch
+            if os.environ.get("YL_ENGINE_ONE_PROFILE", "1") == "1":
+                if self._engines.pop((b, h, w, self.model._version, not one_batch), None) is not None:
+                    torch.cuda.empty_cache()
             if self.device.type != "cuda":
                 raise RuntimeError("the YOLO11 network runs on the GPU only (HIP kernels; no CPU fallback): "
                                    "pass device=0 / 'cuda:0'")
