@@ -261,9 +261,13 @@ __device__ __forceinline__ void dwpw_body(const ConvArgs& a, int block) {
   const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.out, (short)0, a.out_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc((void*)nullptr, (short)0, 0, 0x00020000);
 
+#define DW_STAMP(id) YL_STAMP(a.stamps, 4, wave, lane, id)
+  DW_STAMP(0);
   copy_slab(reinterpret_cast<const bf16x8*>(a.wpk), slab, a.ksteps * MT * 64, tid);
   if constexpr (PW2) copy_slab(reinterpret_cast<const bf16x8*>(a.wpk2), slab2, a.ksteps2 * MT * 64, tid);
+  DW_STAMP(1);
   __syncthreads();
+  DW_STAMP(2);
 
   // ---- depthwise 3x3 + bias + SiLU on the MATRIX pipe, each wave for the 16 * NT pixels its GEMM will consume.
   // A depthwise conv of 16 channels (two planes) is the GEMM out[16][px] = A[16][K] * B[K][px] with K = 2 planes x 9 taps
@@ -363,7 +367,9 @@ __device__ __forceinline__ void dwpw_body(const ConvArgs& a, int block) {
       }
     }
   }
+  DW_STAMP(3);
   __syncthreads();
+  DW_STAMP(4);
 
   // ---- 1x1 GEMM from LDS
   if (!PW2 && !live) return;
@@ -384,9 +390,11 @@ __device__ __forceinline__ void dwpw_body(const ConvArgs& a, int block) {
     for (int nt = 0; nt < NT; ++nt) xb[nt] = k8 < a.cg ? tile[k8 * P + wave * 16 * NT + nt * 16 + n] : zero;
     mma_step<MT, NT>(wa, xb, acc);
   }
+  DW_STAMP(5);
   if constexpr (!PW2) {
     if (a.dbg & 8) return;
     epilogue<MT, NT>(a, rout, rres, 0, g, Pp.opix, acc);
+    DW_STAMP(9);
   } else {
     // pointwise result (SiLU, bf16: exactly what the unfused kernel stores) -> the tile, as planes of 8 channels:
     // rows of tile mt are channels chan_in_block(MT, mt, g, 0..3), i.e. half a 16-byte pixel of one plane
@@ -408,7 +416,9 @@ __device__ __forceinline__ void dwpw_body(const ConvArgs& a, int block) {
         }
       }
     }
+    DW_STAMP(6);
     __syncthreads();
+    DW_STAMP(7);
     if (!live) return;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -463,8 +473,11 @@ __device__ __forceinline__ void dwpw_body(const ConvArgs& a, int block) {
         }
       }
     }
+    DW_STAMP(8);
     epilogue<MT, NT>(a2, rout, rres, 0, g, Pp.opix, acc);
+    DW_STAMP(9);
   }
+#undef DW_STAMP
 }
 
 template <int MT, int NT, bool PW2 = false>
@@ -947,6 +960,7 @@ static int dwpw_prepare(ConvConfig& cfg, ConvArgs& a, int batch, size_t* lds_out
   a.nblocks = (cfg.npatches + 3) / 4;
   static const int dwpw_dbg = getenv("YL_DWPW_DBG") ? atoi(getenv("YL_DWPW_DBG")) : 0;  // timing ablations (wrong results)
   a.dbg = dwpw_dbg;
+  a.stamps = g_stamp_buf;
   const int planes = a.wpk2 && a.cg2 > cfg.cg ? a.cg2 : cfg.cg;
   *lds_out = (size_t)cfg.ksteps * cfg.MT * 1024 + (size_t)planes * 64 * cfg.NT * 16 +
              (a.wpk2 ? (size_t)a.ksteps2 * cfg.MT * 1024 : 0);

@@ -124,6 +124,7 @@ struct ConvArgs {
   unsigned in_bytes, out_bytes, res_bytes;  // buffer-descriptor sizes (bytes past the base pointers)
   int nblocks;
   int dbg;  // development ablation flags (YL_CONV_DBG), 0 in production
+  unsigned long long* stamps;  // diagnostic builds (-DYL_STAMPS): dwpw_body's phase stamps
   // conv3_tile_kernel (3x3, stride 1, input tile in LDS): tile geometry in guarded-pixel units
   int t_px, t_PL, t_ppp, t_ntiles, t_plane_px, t_H, t_W, t_B;  // pixels staged / LDS plane pitch / DMA pieces per plane
   unsigned magic_ppp, magic_img, magic_w1;
