@@ -263,10 +263,22 @@ __device__ __forceinline__ void dwpw_body(const ConvArgs& a, int block) {
 
 #define DW_STAMP(id) YL_STAMP(a.stamps, 4, wave, lane, id)
   DW_STAMP(0);
-  copy_slab(reinterpret_cast<const bf16x8*>(a.wpk), slab, a.ksteps * MT * 64, tid);
-  if constexpr (PW2) copy_slab(reinterpret_cast<const bf16x8*>(a.wpk2), slab2, a.ksteps2 * MT * 64, tid);
+  // The pointwise filters are not needed before the depthwise phase is over: they travel to LDS by LDS-DMA (no registers, nobody
+  // waits) while that phase runs, and are waited for in front of the barrier that ends it.  (Copied through registers with a barrier
+  // of their own in front of the depthwise phase they were 2.0 of a workgroup's 15.9 us: tools/dwpw_stamps.py.)
+  {
+    typedef __attribute__((address_space(3))) void lds_void_d;
+    const int n1 = a.ksteps * MT, n2 = PW2 ? a.ksteps2 * MT : 0;  // 1-KiB pieces
+    const __amdgpu_buffer_rsrc_t rw1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, (short)0, (unsigned)n1 * 1024u, 0x00020000);
+    for (int pc = wave; pc < n1; pc += 4)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw1, (lds_void_d*)(reinterpret_cast<unsigned char*>(slab) + pc * 1024), 16, pc * 1024 + lane * 16, 0, 0, 0);
+    if constexpr (PW2) {
+      const __amdgpu_buffer_rsrc_t rw2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk2, (short)0, (unsigned)n2 * 1024u, 0x00020000);
+      for (int pc = wave; pc < n2; pc += 4)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw2, (lds_void_d*)(reinterpret_cast<unsigned char*>(slab2) + pc * 1024), 16, pc * 1024 + lane * 16, 0, 0, 0);
+    }
+  }
   DW_STAMP(1);
-  __syncthreads();
   DW_STAMP(2);
 
   // ---- depthwise 3x3 + bias + SiLU on the MATRIX pipe, each wave for the 16 * NT pixels its GEMM will consume.
@@ -368,6 +380,7 @@ __device__ __forceinline__ void dwpw_body(const ConvArgs& a, int block) {
     }
   }
   DW_STAMP(3);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (this wave's pieces of the filter slabs)
   __syncthreads();
   DW_STAMP(4);
 
