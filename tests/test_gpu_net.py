@@ -586,13 +586,16 @@ def test_level_group_launches_are_bit_identical(gpu_device, monkeypatch, h, w, m
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("switch,bias", [("YL_FUSE_PREFILTER", -3.0), ("YL_NMS_FUSED", -3.0), ("YL_NMS_FUSED", 0.5)])
+@pytest.mark.parametrize("switch,bias", [("YL_FUSE_PREFILTER", -3.0), ("YL_NMS_FUSED", -3.0), ("YL_NMS_FUSED", 0.5),
+                                         ("YL_NMS_LDS", -3.0), ("YL_NMS_LDS", -1.5), ("YL_NMS_LDS", 0.5)])
 def test_prefilter_in_the_class_launch_epilogue_is_bit_identical(gpu_device, switch, bias):
     """The NMS candidate pre-filter in the epilogue of the launches that write the class logits (ConvArgs::pf_*, default)
     against the separate pre-filter kernel (YL_FUSE_PREFILTER=0, read once per process -> a child process): same detections,
     bit for bit, eager and graph, at a low and at the default confidence threshold.
     YL_NMS_FUSED: exact decode + sort + mask + scan in ONE launch (decode_nms_fused_kernel, one workgroup per image, default)
-    against the four launches; bias 0.5 makes thousands of anchors per image candidates (the scan's general path, > 512 rows)."""
+    against the four launches; bias 0.5 makes thousands of anchors per image candidates (the scan's general path, > 512 rows).
+    YL_NMS_LDS: that kernel's all-in-LDS path for images with <= 512 pre-filtered anchors (default) against its general path
+    (intermediates through the NMS workspace), inside the one-launch form; with `classes` given as well."""
     import os
     import subprocess
     import sys
@@ -616,6 +619,8 @@ for conf in (0.25, 0.06):
     for graph in (False, True):
         o, c = eng.detect(x, conf, 0.7, max_det=300, graph=graph)
         res[(conf, graph)] = (o.cpu().clone(), c.cpu().clone())
+o, c = eng.detect(x, 0.25, 0.5, max_det=20, classes=[0, 3, 5, 17, 40, 79], agnostic=True)
+res["classes"] = (o.cpu().clone(), c.cpu().clone())
 torch.save(res, sys.argv[1])
 """ % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), bias)
     outs = []
@@ -623,6 +628,8 @@ torch.save(res, sys.argv[1])
         for flag in ("1", "0"):
             f = os.path.join(td, f"r{flag}.pt")
             env = dict(os.environ, **{switch: flag})
+            if switch == "YL_NMS_LDS":
+                env["YL_NMS_FUSED"] = "1"  # (batch 2: the one-launch form is the default from batch 16)
             subprocess.run([sys.executable, "-c", code, f], check=True, env=env, timeout=300)
             outs.append(torch.load(f))
     fused, plain = outs

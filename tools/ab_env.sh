@@ -8,7 +8,7 @@ for rep in $(seq $REPS); do
 import json,sys
 d=json.loads(sys.stdin.read())
 post={r:v for r,v in d['kernels'].items() if r.startswith(('decode','nms','dw3x3'))}
-print('$VAR=$v', d['value'], 'img/s', 'sync', d.get('value_sync_per_iteration'), 'lat_ms', d.get('latency_ms_single_stream'), 'launches', d.get('launches_per_step'), {k:(round(x['ms']*1e3,1),x['launches']) for k,x in post.items()})
+print('$VAR=$v', d['value'], 'img/s', 'sync', d.get('value_sync_per_iteration'), 'lat_ms', d.get('latency_ms_single_stream'), 'one_batch_profile_ms', (d.get('one_batch_profile') or {}).get('latency_ms'), 'launches', d.get('launches_per_step'), {k:(round(x['ms']*1e3,1),x['launches']) for k,x in post.items()})
 "
   done
 done

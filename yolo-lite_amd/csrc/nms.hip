@@ -300,12 +300,15 @@ __global__ __launch_bounds__(1024) void nms_sort_kernel(const float* __restrict_
 }
 
 // ---- 3. suppression mask: one wavefront per row i, one ballot per 64 columns j > i
-__device__ __forceinline__ bool iou_gt(const float4 a, float area_a, const float4 b, float thr) {
-  const float area_b = __fmul_rn(__fsub_rn(b.z, b.x), __fsub_rn(b.w, b.y));
+// (two halves so that a caller can skip the second one for pairs that do not intersect)
+__device__ __forceinline__ float iou_inter(const float4 a, const float4 b) {
   const float xx1 = fmaxf(a.x, b.x), yy1 = fmaxf(a.y, b.y);
   const float xx2 = fminf(a.z, b.z), yy2 = fminf(a.w, b.w);
   const float iw = fmaxf(0.0f, __fsub_rn(xx2, xx1)), ih = fmaxf(0.0f, __fsub_rn(yy2, yy1));
-  const float inter = __fmul_rn(iw, ih);
+  return __fmul_rn(iw, ih);
+}
+__device__ __forceinline__ bool iou_gt_of(float inter, float area_a, const float4 b, float thr) {
+  const float area_b = __fmul_rn(__fsub_rn(b.z, b.x), __fsub_rn(b.w, b.y));
   const float uni = __fsub_rn(__fadd_rn(area_a, area_b), inter);
   return __fdiv_rn(inter, uni) > thr;
 }
@@ -321,9 +324,18 @@ __device__ __forceinline__ void nms_mask_body(float iou_thres, int n, const floa
     unsigned long long* row = mask + (long long)i * MW;
     for (int wd = i >> 6; wd < nwords; ++wd) {
       const int j = wd * 64 + lane;
-      bool sup = false;
-      if (j < n && j > i) sup = iou_gt(bi, area_i, bo[j], iou_thres);
-      const unsigned long long bits = __ballot(sup);
+      // inter is +0 (or NaN) for a pair that does not intersect, and then inter / union cannot exceed a threshold in [0, 1]:
+      // the division is evaluated only where some lane of the word has an intersection (most words of a real image have none
+      // -- boxes of different classes never meet, max_wh apart); the bits are those of the plain test
+      float4 bj = bi;
+      float inter = 0.0f;
+      if (j < n && j > i) {
+        bj = bo[j];
+        inter = iou_inter(bi, bj);
+      }
+      const bool meets = inter > 0.0f;
+      unsigned long long bits = 0ull;
+      if (__ballot(meets)) bits = __ballot(meets && iou_gt_of(inter, area_i, bj, iou_thres));
       if (lane == 0) row[wd] = bits;
     }
   }
@@ -339,10 +351,21 @@ __global__ __launch_bounds__(256) void nms_mask_kernel(float iou_thres, NmsWs w)
 constexpr int SCAN_T = 8;  // words per lane -> up to 64*64*8 = 32768 candidates
 
 // one kept detection -> out[b][slot] (ops.py:66-98 scale_boxes + ops.py:276-295 clip_boxes when scaled)
-__device__ __forceinline__ void scan_emit(const NmsWs& w, int b, int i, int slot, int max_det, bool scaled, float padx,
+// the image's sorted candidates as the scan reads them: global workspace rows, or the one-launch kernel's LDS arrays
+struct ScanSrc {
+  const float4* box_raw;
+  const float* conf;
+  const int32_t* cls;
+  int n;
+};
+__device__ __forceinline__ ScanSrc scan_src_of(const NmsWs& w, int b) {
+  const long long o = (long long)b * w.M;
+  return ScanSrc{w.box_raw + o, w.conf + o, w.cls + o, w.nfinal[b]};
+}
+
+__device__ __forceinline__ void scan_emit(const ScanSrc& src, int b, int i, int slot, int max_det, bool scaled, float padx,
                                           float pady, float gain, float w0, float h0, float* out) {
-  const long long o = (long long)b * w.M + i;
-  float4 bx = w.box_raw[o];
+  float4 bx = src.box_raw[i];
   if (scaled) {
     bx.x = __fdiv_rn(__fsub_rn(bx.x, padx), gain);
     bx.y = __fdiv_rn(__fsub_rn(bx.y, pady), gain);
@@ -358,25 +381,26 @@ __device__ __forceinline__ void scan_emit(const NmsWs& w, int b, int i, int slot
   op[1] = bx.y;
   op[2] = bx.z;
   op[3] = bx.w;
-  op[4] = w.conf[o];
-  op[5] = (float)w.cls[o];
+  op[4] = src.conf[i];
+  op[5] = (float)src.cls[i];
 }
 
-__device__ __forceinline__ void nms_scan_body(int max_det, const float* __restrict__ scale, float* out, int32_t* out_count,
-                                              const NmsWs& w, int b, int lane, const unsigned long long* mask, int MW) {
-  const int n = w.nfinal[b];
+// a value every lane of the wave holds alike, as a scalar
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+// (scaled, padx .. h0: the image's scale record -- scale_boxes' arguments; scaled = false: boxes stay in network coordinates)
+__device__ __forceinline__ void nms_scan_body(int max_det, bool scaled, float padx, float pady, float gain, float w0, float h0,
+                                              float* out, int32_t* out_count, const ScanSrc& src, int b, int lane,
+                                              const unsigned long long* mask, int MW) {
+  const int n = src.n;
   const int nwords = (n + 63) >> 6;
   unsigned long long rem[SCAN_T];
 #pragma unroll
   for (int t = 0; t < SCAN_T; ++t) rem[t] = 0ull;
-  float padx = 0.f, pady = 0.f, gain = 1.f, w0 = 0.f, h0 = 0.f;
-  if (scale) {
-    padx = scale[b * 5 + 0];
-    pady = scale[b * 5 + 1];
-    gain = scale[b * 5 + 2];
-    w0 = scale[b * 5 + 3];
-    h0 = scale[b * 5 + 4];
-  }
   int total = 0;
   if (nwords <= SCAN_T) {
     // Fast path (up to 512 candidates -- every realistic conf >= 0.05 case): the pending-suppression
@@ -400,18 +424,24 @@ __device__ __forceinline__ void nms_scan_body(int max_det, const float* __restri
         }
       const int nvalid = n - blk * 64;
       const unsigned long long vmask = nvalid >= 64 ? ~0ull : ((1ull << nvalid) - 1ull);
-      unsigned long long alive = ~cur & vmask;
-      unsigned long long kept = 0ull;
-      int room = max_det - total;
-      while (alive && room > 0) {
-        const int bit = __builtin_amdgcn_readfirstlane(__builtin_ctzll(alive));
-        kept |= 1ull << bit;
-        --room;
+      // greedy pass over the block in score order.  Only candidates whose row has a bit inside the block (`hot`) can change
+      // anything, and rows hold bits j > i only: visiting the hot survivors in order leaves exactly the sequential scan's
+      // survivors (a candidate's fate is settled by the kept hot ones before it), in as many steps as there are overlapping
+      // boxes instead of one per kept box
+      unsigned long long alive = uniform64(~cur & vmask);
+      unsigned long long todo = alive & __ballot(dcur != 0ull);
+      while (todo) {
+        const int bit = __builtin_ctzll(todo);
         const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)dcur, bit);
         const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(dcur >> 32), bit);
-        alive &= ~(((unsigned long long)hi << 32) | lo);
-        alive &= ~(1ull << bit);
+        const unsigned long long gone = (((unsigned long long)hi << 32) | lo);
+        alive &= ~gone;
+        todo &= ~gone & ~(1ull << bit);
       }
+      // max_det (ops.py:265): the first `room` survivors; what the dropped ones would have suppressed lies behind them
+      const int room = max_det - total;
+      while (__popcll(alive) > room) alive &= ~(1ull << (63 - __clzll(alive)));
+      const unsigned long long kept = alive;
       const bool mine = (kept >> lane) & 1ull;
 #pragma unroll
       for (int t = 0; t < SCAN_T; ++t)
@@ -424,7 +454,7 @@ __device__ __forceinline__ void nms_scan_body(int max_det, const float* __restri
           }
           remw[t] |= ((unsigned long long)hi << 32) | lo;
         }
-      if (mine) scan_emit(w, b, i, total + __popcll(kept & ((1ull << lane) - 1ull)), max_det, scale != nullptr, padx, pady,
+      if (mine) scan_emit(src, b, i, total + __popcll(kept & ((1ull << lane) - 1ull)), max_det, scaled, padx, pady,
                           gain, w0, h0, out);
       total += __popcll(kept);
     }
@@ -466,16 +496,31 @@ __device__ __forceinline__ void nms_scan_body(int max_det, const float* __restri
     }
     // emit: lane `bit` writes its own detection at rank order
     if ((kept >> lane) & 1ull)
-      scan_emit(w, b, i, total + __popcll(kept & ((1ull << lane) - 1ull)), max_det, scale != nullptr, padx, pady, gain, w0,
+      scan_emit(src, b, i, total + __popcll(kept & ((1ull << lane) - 1ull)), max_det, scaled, padx, pady, gain, w0,
                 h0, out);
     total += __popcll(kept);
   }
   if (lane == 0) out_count[b] = total;
 }
 
+// the same with the scale record read from memory here
+__device__ __forceinline__ void nms_scan_body(int max_det, const float* __restrict__ scale, float* out, int32_t* out_count,
+                                              const ScanSrc& src, int b, int lane, const unsigned long long* mask, int MW) {
+  float padx = 0.f, pady = 0.f, gain = 1.f, w0 = 0.f, h0 = 0.f;
+  if (scale) {
+    padx = scale[b * 5 + 0];
+    pady = scale[b * 5 + 1];
+    gain = scale[b * 5 + 2];
+    w0 = scale[b * 5 + 3];
+    h0 = scale[b * 5 + 4];
+  }
+  nms_scan_body(max_det, scale != nullptr, padx, pady, gain, w0, h0, out, out_count, src, b, lane, mask, MW);
+}
+
 __global__ __launch_bounds__(64) void nms_scan_kernel(int max_det, const float* __restrict__ scale, float* out,
                                                        int32_t* out_count, NmsWs w) {
-  nms_scan_body(max_det, scale, out, out_count, w, blockIdx.x, threadIdx.x, w.mask + (long long)blockIdx.x * w.M * w.MW, w.MW);
+  nms_scan_body(max_det, scale, out, out_count, scan_src_of(w, blockIdx.x), blockIdx.x, threadIdx.x,
+                w.mask + (long long)blockIdx.x * w.M * w.MW, w.MW);
 }
 
 }  // namespace yl
@@ -560,13 +605,39 @@ struct DcAnchor {
   DecodeLevel L;
   int b, p, px, py, pix;  // level-local anchor index, its coordinates, guarded pixel index
 };
+// NLV: an upper bound of a.n_levels the caller knows (3: the select below touches three level records instead of eight)
+template <int NLV = 8>
 __device__ __forceinline__ DcAnchor dc_anchor(const DecCandArgs& a, int b, int an) {
   DcAnchor d;
-  int l = 0;
+  if constexpr (NLV <= 4) {
+    // the record by field-wise selects between the NLV records (scalars): an indexed copy is a per-lane LOAD from the kernel
+    // argument segment -- one more dependent memory round trip (~1 us in the one-launch kernel's chain)
+    d.L = a.lv[0];
 #pragma unroll
-  for (int i = 1; i < 8; ++i)
-    if (i < a.n_levels && an >= a.lv[i].a0) l = i;
-  d.L = a.lv[l];  // (a per-lane, field-by-field select of the record instead of this indexed copy was measured slower: 42 against 30 us)
+    for (int i = 1; i < NLV; ++i) {
+      const bool in = i < a.n_levels && an >= a.lv[i].a0;
+      d.L.box.base = in ? a.lv[i].box.base : d.L.box.base;
+      d.L.box.plane = in ? a.lv[i].box.plane : d.L.box.plane;
+      d.L.box.W1 = in ? a.lv[i].box.W1 : d.L.box.W1;
+      d.L.box.img = in ? a.lv[i].box.img : d.L.box.img;
+      d.L.box.g0 = in ? a.lv[i].box.g0 : d.L.box.g0;
+      d.L.cls.base = in ? a.lv[i].cls.base : d.L.cls.base;
+      d.L.cls.plane = in ? a.lv[i].cls.plane : d.L.cls.plane;
+      d.L.cls.W1 = in ? a.lv[i].cls.W1 : d.L.cls.W1;
+      d.L.cls.img = in ? a.lv[i].cls.img : d.L.cls.img;
+      d.L.cls.g0 = in ? a.lv[i].cls.g0 : d.L.cls.g0;
+      d.L.H = in ? a.lv[i].H : d.L.H;
+      d.L.W = in ? a.lv[i].W : d.L.W;
+      d.L.a0 = in ? a.lv[i].a0 : d.L.a0;
+      d.L.stride = in ? a.lv[i].stride : d.L.stride;
+    }
+  } else {
+    int l = 0;
+#pragma unroll
+    for (int i = 1; i < NLV; ++i)
+      if (i < a.n_levels && an >= a.lv[i].a0) l = i;
+    d.L = a.lv[l];  // (with eight records the field-by-field select was measured slower than this indexed copy: 42 against 30 us)
+  }
   d.b = b;
   d.p = an - d.L.a0;
   d.py = d.p / d.L.W;
@@ -575,18 +646,23 @@ __device__ __forceinline__ DcAnchor dc_anchor(const DecCandArgs& a, int b, int a
   return d;
 }
 
-// the reference's candidate test and bookkeeping for one anchor (ops.py:203,243-248).
-// key_slot < 0: append with an atomic (dense kernel); else the key goes to that slot of keys[b][] and a
-// rejected anchor leaves the sentinel ~0 there (sparse path: no atomics).
-__device__ __forceinline__ void dc_emit(const DecCandArgs& a, const NmsWs& w, const DcAnchor& d, float best, int bi,
-                                        float dl, float dt, float dr, float db, int key_slot = -1) {
+// the reference's candidate test (ops.py:203,243-248: score above conf_thres, class in `classes` when given)
+__device__ __forceinline__ bool dc_keep(const DecCandArgs& a, float best, int bi) {
   bool keep = best > a.conf_thres;
   if (keep && a.classes) {
     bool ok = false;
     for (int i = 0; i < a.n_classes; ++i) ok |= (a.classes[i] == bi);
     keep = ok;
   }
-  if (!keep) {
+  return keep;
+}
+
+// the candidate test and bookkeeping for one anchor.
+// key_slot < 0: append with an atomic (dense kernel); else the key goes to that slot of keys[b][] and a
+// rejected anchor leaves the sentinel ~0 there (sparse path: no atomics).
+__device__ __forceinline__ void dc_emit(const DecCandArgs& a, const NmsWs& w, const DcAnchor& d, float best, int bi,
+                                        float dl, float dt, float dr, float db, int key_slot = -1) {
+  if (!dc_keep(a, best, bi)) {
     if (key_slot >= 0) w.keys[(long long)d.b * w.KP + key_slot] = ~0ull;
     return;
   }
@@ -646,9 +722,25 @@ __device__ __forceinline__ void decode_anchor_thread(const DecCandArgs& a, const
 //     Should the window itself round to the best score (saturated scores), every class is evaluated as the reference does.
 //   * dfl_expect is the same function on the same 16 values.
 // `valid` lanes only; all four lanes of a group must be active or inactive together.
-__device__ __forceinline__ void decode_anchor_quad(const DecCandArgs& a, const NmsWs& w, int b, int an, int key_slot, int side) {
-  const DcAnchor d = dc_anchor(a, b, an);
+// what the four lanes of a quad know about their anchor after the evaluation (every lane holds the same values)
+struct DcQuad {
+  float best, dl, dt, dr, db;
+  int bi;
+};
+// (stamps: diagnostic builds, the one-launch kernel's phase stamps 7-10; every outstanding load is waited for before a stamp)
+#ifdef YL_STAMPS
+#define DQ_STAMP(id)                                                   \
+  do {                                                                 \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");        \
+    YL_STAMP(stamps, 16, (int)(threadIdx.x >> 6), (int)(threadIdx.x & 63u), id); \
+  } while (0)
+#else
+#define DQ_STAMP(id) do { } while (0)
+#endif
+__device__ __forceinline__ DcQuad decode_anchor_quad_eval(const DecCandArgs& a, const DcAnchor& d, int side,
+                                                          unsigned long long* stamps = nullptr) {
   const int nplanes = (a.nc + 7) >> 3;
+  DQ_STAMP(7);
   // every load of the lane is requested up front -- its class planes (side, side + 4, ...: up to QP of them are kept in
   // registers for both passes) and its two DFL planes -- so that the quad pays ONE memory round trip instead of three (first
   // class pass, second class pass, box planes); the arithmetic is unchanged
@@ -661,6 +753,7 @@ __device__ __forceinline__ void decode_anchor_quad(const DecCandArgs& a, const N
   }
   level_load8(d.L.box, 2 * side, d.pix, l8);
   level_load8(d.L.box, 2 * side + 1, d.pix, h8);
+  DQ_STAMP(8);
   float m = -__builtin_huge_valf();
 #pragma unroll
   for (int q = 0; q < QP; ++q) {
@@ -717,6 +810,7 @@ __device__ __forceinline__ void decode_anchor_quad(const DecCandArgs& a, const N
       bi = i2;
     }
   }
+  DQ_STAMP(9);
   float dist = 0.f;
   if (best > a.conf_thres) {  // (uniform over the four lanes)
     float v[16];
@@ -728,13 +822,24 @@ __device__ __forceinline__ void decode_anchor_quad(const DecCandArgs& a, const N
     dist = dfl_expect(v);
   }
   const int l0 = (int)(threadIdx.x & 63u) & ~3;
-  const float dl = __shfl(dist, l0), dt = __shfl(dist, l0 + 1), dr = __shfl(dist, l0 + 2), db = __shfl(dist, l0 + 3);
+  DcQuad q;
+  q.best = best;
+  q.bi = bi;
+  q.dl = __shfl(dist, l0), q.dt = __shfl(dist, l0 + 1), q.dr = __shfl(dist, l0 + 2), q.db = __shfl(dist, l0 + 3);
+  DQ_STAMP(10);
+  return q;
+}
+
+template <int NLV = 8>
+__device__ __forceinline__ void decode_anchor_quad(const DecCandArgs& a, const NmsWs& w, int b, int an, int key_slot, int side) {
+  const DcAnchor d = dc_anchor<NLV>(a, b, an);
+  const DcQuad q = decode_anchor_quad_eval(a, d, side);
   if (side != 0) return;
-  if (!(best > a.conf_thres)) {
+  if (!(q.best > a.conf_thres)) {
     if (key_slot >= 0) w.keys[(long long)b * w.KP + key_slot] = ~0ull;
     return;
   }
-  dc_emit(a, w, d, best, bi, dl, dt, dr, db, key_slot);
+  dc_emit(a, w, d, q.best, q.bi, q.dl, q.dt, q.dr, q.db, key_slot);
 }
 
 __global__ __launch_bounds__(256) void decode_candidates_dense_kernel(DecCandArgs a, NmsWs w) {
@@ -829,26 +934,59 @@ __global__ __launch_bounds__(256) void decode_exact_kernel(DecCandArgs a, NmsWs 
 // 12 us -- a 32-workgroup launch is a chain of memory round trips whatever its arithmetic costs (four lanes per anchor
 // instead of one thread: 36 -> 30 us).  Same latency, three launches fewer (63 -> 60 per step), +0.5 % images/s with 20
 // batches in flight; the <= 25 us the round-2 review asked for is NOT reached.
+#define NMS_STAMP(id) YL_STAMP(stamps, 16, wave, lane, id)
+
+// Up to this many pre-filtered anchors per image the one-launch kernel keeps every intermediate of the image in LDS.
+constexpr int FUSED_LDS_MAX = 512;
+
+// NLV: see dc_anchor
+template <int NLV>
 __global__ __launch_bounds__(1024) void decode_nms_fused_kernel(DecCandArgs a, NmsWs w, float iou_thres, int max_det,
                                                                  int agnostic, float max_wh, const float* __restrict__ scale,
-                                                                 float* out, int32_t* out_count, int stop_after) {
+                                                                 float* out, int32_t* out_count, int stop_after, int lds_path,
+                                                                 unsigned long long* stamps) {
   __shared__ unsigned long long sk[SORT_LDS_KEYS];
   __shared__ int s_nvalid;
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // exact decode of the pre-filtered anchors by FOUR LANES each (decode_anchor_quad: decode_candidates_dense_kernel's arithmetic,
-  // which decode_exact_kernel reproduces bit for bit).  Measured alternatives: a wavefront per anchor, as the four-launch form
-  // has it, leaves each of the 16 waves a chain of ~13 dependent memory round trips (115 us for the launch); one thread per
-  // anchor evaluates nc precise sigmoids + 64 exponentials serially (30 us for this phase).
-  {
-    int pre[NSUB + 1];  // the NSUB sub-lists as one list: all candidates of the image in flight at once
-    pre[0] = 0;
+  NMS_STAMP(0);
+  int pre[NSUB + 1];  // the NSUB sub-lists as one list: all candidates of the image in flight at once
+  pre[0] = 0;
 #pragma unroll
-    for (int q = 0; q < NSUB; ++q) pre[q + 1] = pre[q] + min(max(w.pre_count[b * NSUB + q], 0), w.sub_cap);
-    // four lanes per candidate: rounds of 256 candidates; a whole quad is active or idle together (shuffles inside)
-    const int side = tid & 3;
-    for (int i0 = 0; i0 < pre[NSUB]; i0 += 256) {
+  for (int q = 0; q < NSUB; ++q) pre[q + 1] = pre[q] + min(max(w.pre_count[b * NSUB + q], 0), w.sub_cap);
+  const int side = tid & 3;
+  NMS_STAMP(1);
+  if (lds_path && pre[NSUB] <= FUSED_LDS_MAX) {
+    // ---- the usual case (conf 0.25: ~1-2 % of the anchors): nothing but the pre-filter's lists and the level maps is read
+    // from memory and nothing but the detections written -- keys, classes, boxes, the sorted rows and the mask live in LDS
+    // (the general path below hands them from phase to phase through the NMS workspace: eight dependent round trips to L2
+    // per image on top of the three every path has -- counts, list, maps).  The same device functions in the same order
+    // on the same values: bit-identical to the general path and to the four-launch form.
+    //   [0, 14 KiB)  candidates in list order: key u64[512] | class i32[512] | (cx, cy, w, h) float4[512]
+    //   [0, 32 KiB)  ... overlaid, once sorted, by the suppression mask u64[512][8]
+    //   [32, 52 KiB) sorted rows: box_raw float4[512] | box_off float4[512] | conf f32[512] | class i32[512]
+    const int n = pre[NSUB];
+    unsigned long long* ckey = sk;
+    int32_t* ccls = reinterpret_cast<int32_t*>(sk + FUSED_LDS_MAX);
+    float4* cbox = reinterpret_cast<float4*>(sk + FUSED_LDS_MAX + FUSED_LDS_MAX / 2);
+    unsigned long long* lmask = sk;
+    float4* s_raw = reinterpret_cast<float4*>(sk + 4096);
+    float4* s_off = s_raw + FUSED_LDS_MAX;
+    float* s_conf = reinterpret_cast<float*>(s_off + FUSED_LDS_MAX);
+    int32_t* s_cls = reinterpret_cast<int32_t*>(s_conf + FUSED_LDS_MAX);
+    static_assert(SORT_LDS_KEYS >= 4096 + (2 * 16 + 4 + 4) * FUSED_LDS_MAX / 8, "sorted rows behind the mask");
+    static_assert((8 + 4 + 16) * FUSED_LDS_MAX <= 4096 * 8 && FUSED_LDS_MAX * 8 * 8 <= 4096 * 8,
+                  "candidates / mask below the sorted rows");
+    float padx = 0.f, pady = 0.f, gain = 1.f, w0 = 0.f, h0 = 0.f;  // (requested now, used by the scan)
+    if (scale && wave == 0) {
+      padx = scale[b * 5 + 0];
+      pady = scale[b * 5 + 1];
+      gain = scale[b * 5 + 2];
+      w0 = scale[b * 5 + 3];
+      h0 = scale[b * 5 + 4];
+    }
+    for (int i0 = 0; i0 < n; i0 += 256) {
       const int i = i0 + (tid >> 2);
-      if (i < pre[NSUB]) {
+      if (i < n) {
         int sub = 0;
 #pragma unroll
         for (int t = 1; t < NSUB; ++t) sub += (i >= pre[t]);
@@ -856,31 +994,96 @@ __global__ __launch_bounds__(1024) void decode_nms_fused_kernel(DecCandArgs a, N
 #pragma unroll
         for (int t = 1; t < NSUB; ++t) j = (t == sub) ? i - pre[t] : j;
         const int an = min(max(w.pre_list[(long long)(b * NSUB + sub) * w.sub_cap + j], 0), a.A - 1);
-        decode_anchor_quad(a, w, b, an, sub * w.sub_cap + j, side);
+        DQ_STAMP(6);
+        const DcAnchor d = dc_anchor<NLV>(a, b, an);
+        const DcQuad q = decode_anchor_quad_eval(a, d, side, stamps);
+        if (side == 0) {
+          const bool keep = dc_keep(a, q.best, q.bi);
+          ckey[i] = keep ? (((unsigned long long)(~__float_as_uint(q.best)) << 32) | (unsigned)an) : ~0ull;
+          ccls[i] = q.bi;
+          cbox[i] = box_xywh((float)d.px + 0.5f, (float)d.py + 0.5f, q.dl, q.dt, q.dr, q.db, d.L.stride);
+        }
       }
     }
+    NMS_STAMP(2);
+    if (stop_after == 1) return;
+    __syncthreads();
+    // sort by rank (rank_sort's order: every real key is unique) and build the sorted rows straight from the candidate's own
+    // slot -- nms_sort_body's gather arithmetic (ops.py:254-258, 386)
+    bool valid = false;
+    if (tid < n) {
+      const unsigned long long x = ckey[tid];
+      valid = x != ~0ull;
+      if (valid) {
+        int r = 0;
+        for (int j = 0; j < n; ++j) r += ckey[j] < x ? 1 : 0;
+        if (r < w.M) {  // keep the top max_cand by score
+          const float score = __uint_as_float(~(unsigned)(x >> 32));
+          const int cls = ccls[tid];
+          const float4 t = cbox[tid];
+          const float hw = __fdiv_rn(t.z, 2.0f), hh = __fdiv_rn(t.w, 2.0f);
+          const float x1 = __fsub_rn(t.x, hw), y1 = __fsub_rn(t.y, hh), x2 = __fadd_rn(t.x, hw), y2 = __fadd_rn(t.y, hh);
+          const float c = __fmul_rn((float)cls, agnostic ? 0.0f : max_wh);
+          s_raw[r] = make_float4(x1, y1, x2, y2);
+          s_off[r] = make_float4(__fadd_rn(x1, c), __fadd_rn(y1, c), __fadd_rn(x2, c), __fadd_rn(y2, c));
+          s_conf[r] = score;
+          s_cls[r] = cls;
+        }
+      }
+    }
+    const int nvalid = __syncthreads_count(valid);  // (also the barrier between the candidates and the mask that overlays them)
+    const int nf = nvalid < w.M ? nvalid : w.M;
+    NMS_STAMP(3);
+    if (stop_after == 2) return;
+    nms_mask_body(iou_thres, nf, s_off, lmask, 8, wave, 16, lane);
+    NMS_STAMP(4);
+    if (stop_after == 3) return;
+    __syncthreads();
+    if (wave == 0) {
+      const ScanSrc src{s_raw, s_conf, s_cls, nf};
+      nms_scan_body(max_det, scale != nullptr, padx, pady, gain, w0, h0, out, out_count, src, b, lane, lmask, 8);
+    }
+    NMS_STAMP(5);
+    return;
   }
+  // ---- general path: exact decode of the pre-filtered anchors by FOUR LANES each (decode_anchor_quad:
+  // decode_candidates_dense_kernel's arithmetic, which decode_exact_kernel reproduces bit for bit).  Measured alternatives: a
+  // wavefront per anchor, as the four-launch form has it, leaves each of the 16 waves a chain of ~13 dependent memory round
+  // trips (115 us for the launch); one thread per anchor evaluates nc precise sigmoids + 64 exponentials serially (30 us for
+  // this phase).  Rounds of 256 candidates; a whole quad is active or idle together (shuffles inside).
+  for (int i0 = 0; i0 < pre[NSUB]; i0 += 256) {
+    const int i = i0 + (tid >> 2);
+    if (i < pre[NSUB]) {
+      int sub = 0;
+#pragma unroll
+      for (int t = 1; t < NSUB; ++t) sub += (i >= pre[t]);
+      int j = i;
+#pragma unroll
+      for (int t = 1; t < NSUB; ++t) j = (t == sub) ? i - pre[t] : j;
+      const int an = min(max(w.pre_list[(long long)(b * NSUB + sub) * w.sub_cap + j], 0), a.A - 1);
+      decode_anchor_quad<NLV>(a, w, b, an, sub * w.sub_cap + j, side);
+    }
+  }
+  NMS_STAMP(2);
   if (stop_after == 1) return;  // (development: timing ablation, YL_NMS_DBG)
   __syncthreads();
   nms_sort_body(nullptr, a.nc, a.A, agnostic, max_wh, w, b, tid, sk, s_nvalid);
+  NMS_STAMP(3);
   if (stop_after == 2) return;
   __syncthreads();
-  // The mask phase is a serial chain of ~16 rows per wave: with the boxes in LDS (the sort's key array is free now) a row
-  // costs LDS latency, not a memory round trip; up to 512 rows the mask itself stays in LDS too (8 words per row).
+  // (boxes and mask rows in the workspace, never in LDS: a pointer that may be either becomes a FLAT access, and the compiler
+  // then folds this call and the LDS path's into one body of flat loads -- measured there: 6.5 us for a mask phase whose
+  // LDS form takes a third of that)
   const int n = w.nfinal[b];
-  float4* lbox = reinterpret_cast<float4*>(sk);                       // [<= 1024] 16 KiB
-  unsigned long long* lmask = sk + 2048;                              // [512][8]  32 KiB
-  const bool box_lds = n <= 1024, mask_lds = n <= 512;
-  if (box_lds)
-    for (int i = tid; i < n; i += 1024) lbox[i] = w.box_off[(long long)b * w.M + i];
-  __syncthreads();
-  const float4* bo = box_lds ? lbox : w.box_off + (long long)b * w.M;
-  unsigned long long* mk = mask_lds ? lmask : w.mask + (long long)b * w.M * w.MW;
-  const int mw = mask_lds ? 8 : w.MW;
+  const float4* bo = w.box_off + (long long)b * w.M;
+  unsigned long long* mk = w.mask + (long long)b * w.M * w.MW;
+  const int mw = w.MW;
   nms_mask_body(iou_thres, n, bo, mk, mw, wave, 16, lane);
+  NMS_STAMP(4);
   if (stop_after == 3) return;
   __syncthreads();
-  if (wave == 0) nms_scan_body(max_det, scale, out, out_count, w, b, lane, mk, mw);
+  if (wave == 0) nms_scan_body(max_det, scale, out, out_count, scan_src_of(w, b), b, lane, mk, mw);
+  NMS_STAMP(5);
 }
 }  // namespace yl
 
@@ -936,8 +1139,10 @@ int yl::decode_nms_stages(const void* workspace, const yl_level* levels, int n_l
     const bool one_launch = one_launch_env >= 0 ? one_launch_env != 0 : batch >= 16;
     if (one_launch) {  // exact decode + sort + mask + scan in one launch, one workgroup per image
       static const int stop_after = getenv("YL_NMS_DBG") ? atoi(getenv("YL_NMS_DBG")) : 0;
-      hipLaunchKernelGGL(decode_nms_fused_kernel, dim3(batch), dim3(1024), 0, s, a, w, iou_thres, max_det, agnostic, max_wh,
-                         scale, out, out_count, stop_after);
+      static const int lds_path = getenv("YL_NMS_LDS") ? atoi(getenv("YL_NMS_LDS")) : 1;  // (0: the general path for every image)
+      auto kern = n_levels <= 3 ? decode_nms_fused_kernel<3> : decode_nms_fused_kernel<8>;
+      hipLaunchKernelGGL(kern, dim3(batch), dim3(1024), 0, s, a, w, iou_thres, max_det, agnostic, max_wh, scale, out, out_count,
+                         stop_after, lds_path, g_stamp_buf);
       if (ev)
         for (int q = 2; q <= 5; ++q) (void)hipEventRecord(ev[q], s);  // stages 3-5 are part of that launch: zero time
       YL_HIP(hipGetLastError());
