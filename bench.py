@@ -779,7 +779,10 @@ def main():
             roof, kernels = roofline_from_profile(rows, B, cfg_key)
             res["roofline"] = roof
             res["kernels"] = kernels
-            res["launches_per_step"] = len(rows) + 1  # + the memset node in front of the candidate pre-filter
+            # + the launch that clears the NMS candidate counters, unless the network's first launch is the fused stem, which
+            # clears them on its way (csrc/engine.hip detect_eager, Stem2Args::zero_ptr)
+            zero_in_stem = rows[0]["kernel"].startswith("stem+") and os.environ.get("YL_ZERO_IN_STEM", "1") != "0"
+            res["launches_per_step"] = len(rows) + (0 if zero_in_stem else 1)
             fused_bytes = sum(r["bytes"] for r in rows)
             res["program_bytes_per_step"] = round(fused_bytes)
             res["e2e_hbm_frac_fused_program"] = round(fused_bytes / (ms_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 5)

@@ -1039,6 +1039,10 @@ static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s, c
         const long long ob = (long long)((o.out.C + 7) / 8) * plane_bytes(geo_of(B, o.out.H, o.out.W));
         if (ob > (1LL << 30)) return fail(-3, "stem2: the output slice exceeds 1 GiB; lower the batch size");
         q.out_bytes = (unsigned)ob;
+        if (sink && sink->zero_ptr) {  // (detect_eager: this launch clears the step's NMS candidate counters on its way)
+          q.zero_ptr = sink->zero_ptr;
+          q.zero_n = sink->zero_n;
+        }
         return stem2_launch(q, r.cfg.MT, in_dtype, s);
       }
       ConvArgs a{};
@@ -1506,9 +1510,13 @@ static int detect_eager(yl_engine* e, const void* input, int in_dtype, void* wor
   // front, the network fills the lists, and the decode starts at its second stage.
   PrefilterSink sink{};
   int fused = 0;
+  // (the counters are cleared by the network's first launch where that is the fused stem -- it precedes every class-logit
+  // launch in stream order; otherwise by a launch of their own)
+  static const bool zero_in_stem = !getenv("YL_ZERO_IN_STEM") || atoi(getenv("YL_ZERO_IN_STEM")) != 0;
+  const bool defer = zero_in_stem && !e->ops.empty() && e->ops[0].d_w0 && e->ops[0].op.lane == 0 && e->ops[0].group_n >= 0;
   if (e->cls_tails)
     if (int rc = prefilter_sink_prepare(e->levels.data(), (int)e->levels.size(), e->batch, max_cand, conf_thres, work, stream, &sink,
-                                        &fused))
+                                        &fused, defer))
       return rc;
   if (int rc = forward_impl(e, input, in_dtype, workspace, nullptr, stream, fused ? &sink : nullptr)) return rc;
   return decode_nms_stages(workspace, e->levels.data(), (int)e->levels.size(), e->batch, e->nc, conf_thres, iou_thres, max_det,

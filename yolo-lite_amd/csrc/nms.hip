@@ -1165,7 +1165,7 @@ int yl::decode_nms_stages(const void* workspace, const yl_level* levels, int n_l
 }
 
 int yl::prefilter_sink_prepare(const yl_level* levels, int n_levels, int batch, int max_cand, float conf_thres, void* work,
-                               void* stream, PrefilterSink* sink, int* active) {
+                               void* stream, PrefilterSink* sink, int* active, bool defer_zero) {
   *active = 0;
   if (!levels || !work || !sink || n_levels <= 0 || n_levels > 8 || batch <= 0 || max_cand <= 0) return fail(-1, "prefilter sink: bad arguments");
   if (!(conf_thres >= 0.05f) || !(conf_thres <= 1.f)) return 0;  // dense decode path (or an invalid threshold: yl_decode_nms reports it)
@@ -1173,7 +1173,14 @@ int yl::prefilter_sink_prepare(const yl_level* levels, int n_levels, int batch, 
   for (int i = 0; i < n_levels; ++i) A += levels[i].H * levels[i].W;
   NmsWs w;
   nms_layout(batch, A, max_cand, (char*)work, &w);
-  YL_HIP(zero_i32(w.count, (size_t)batch * (1 + NSUB), (hipStream_t)stream));  // count + pre_count
+  sink->zero_ptr = nullptr;
+  sink->zero_n = 0;
+  if (defer_zero) {
+    sink->zero_ptr = w.count;  // count + pre_count, adjacent
+    sink->zero_n = batch * (1 + NSUB);
+  } else {
+    YL_HIP(zero_i32(w.count, (size_t)batch * (1 + NSUB), (hipStream_t)stream));
+  }
   sink->pre_count = w.pre_count;
   sink->pre_list = w.pre_list;
   sink->sub_cap = w.sub_cap;

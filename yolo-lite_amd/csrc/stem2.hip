@@ -58,6 +58,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
   const int y0 = ty * S2_TR, x0 = tx * S2_TC;
 #define S2_STAMP(id) YL_STAMP(a.stamps, 4, wave, lane, id)
   S2_STAMP(0);
+  if (a.zero_n && blockIdx.x == 0)  // the step's NMS candidate counters (Stem2Args::zero_ptr)
+    for (int i = tid; i < a.zero_n; i += 256) a.zero_ptr[i] = 0;
 
   // ---- 1. input window -> LDS (bf16).  Local (ir, ic) <-> image (4*y0 - 3 + ir, 4*x0 - 4 + ic).
   {

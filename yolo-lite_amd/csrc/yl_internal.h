@@ -266,6 +266,8 @@ struct Stem2Args {
   PView out;
   unsigned out_bytes;
   int tiles_x, tiles_y;
+  int32_t* zero_ptr;           // zero_n words the first workgroup clears (the NMS candidate counters of this step:
+  int zero_n;                  // PrefilterSink::zero_ptr -- one launch less in front of the network); 0: none
   unsigned long long* stamps;  // diagnostic builds (-DYL_STAMPS)
 };
 int stem2_launch(const Stem2Args& a, int MT, int in_dtype, hipStream_t s);
@@ -426,11 +428,15 @@ struct PrefilterSink {
   int32_t* pre_list;   // [B][PF_NSUB][sub_cap]
   int sub_cap;
   float logit_lo;
+  int32_t* zero_ptr;   // defer_zero: zero_n counters the network's FIRST launch has to clear (nullptr: already cleared)
+  int zero_n;
 };
 // Lays out `work` as yl_decode_nms does, zeroes the counters on `stream` and fills `sink`; *active = 0 when the dense
 // decode path applies (conf < 0.05): nothing is done then and the caller must not skip the pre-filter.
+// defer_zero: no zeroing launch -- sink->zero_ptr / zero_n name the counters, and the caller promises that a launch in front
+// of every class-logit launch clears them (stem2_kernel does: Stem2Args::zero_ptr).
 int prefilter_sink_prepare(const yl_level* levels, int n_levels, int batch, int max_cand, float conf_thres, void* work,
-                           void* stream, PrefilterSink* sink, int* active);
+                           void* stream, PrefilterSink* sink, int* active, bool defer_zero = false);
 // nms.hip: yl_decode_nms with optional stage events (profiling); prefiltered != 0: the counters were zeroed and the
 // candidate lists filled by the network's own launches (prefilter_sink_prepare + ConvArgs::pf_*)
 int decode_nms_stages(const void* workspace, const yl_level* levels, int n_levels, int batch, int nc, float conf_thres,
