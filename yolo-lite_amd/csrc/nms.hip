@@ -315,11 +315,21 @@ __device__ __forceinline__ bool iou_gt_of(float inter, float area_a, const float
 
 // rows row0, row0 + nrows_step, ... of image b, one wavefront per row
 // (bo: the image's n class-offset boxes; mask / MW: its mask rows and their pitch in words -- global or LDS)
-__device__ __forceinline__ void nms_mask_body(float iou_thres, int n, const float4* bo, unsigned long long* mask, int MW,
+// (BoxPtr: const float4* in the workspace, or lds_f4_ptr -- a pointer TYPED as LDS: a pointer that may be either becomes a FLAT
+// access, and the compiler then folds differently fed calls of this body into one of flat loads, three times slower)
+typedef float nms_f32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(3))) nms_f32x4* lds_f4_ptr;
+__device__ __forceinline__ float4 ld_box(const float4* p, int i) { return p[i]; }
+__device__ __forceinline__ float4 ld_box(lds_f4_ptr p, int i) {
+  const nms_f32x4 v = p[i];
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+template <class BoxPtr>
+__device__ __forceinline__ void nms_mask_body(float iou_thres, int n, BoxPtr bo, unsigned long long* mask, int MW,
                                               int row0, int nrows_step, int lane) {
   const int nwords = (n + 63) >> 6;
   for (int i = row0; i < n; i += nrows_step) {
-    const float4 bi = bo[i];
+    const float4 bi = ld_box(bo, i);
     const float area_i = __fmul_rn(__fsub_rn(bi.z, bi.x), __fsub_rn(bi.w, bi.y));
     unsigned long long* row = mask + (long long)i * MW;
     for (int wd = i >> 6; wd < nwords; ++wd) {
@@ -330,7 +340,7 @@ __device__ __forceinline__ void nms_mask_body(float iou_thres, int n, const floa
       float4 bj = bi;
       float inter = 0.0f;
       if (j < n && j > i) {
-        bj = bo[j];
+        bj = ld_box(bo, j);
         inter = iou_inter(bi, bj);
       }
       const bool meets = inter > 0.0f;
@@ -1035,7 +1045,7 @@ __global__ __launch_bounds__(1024) void decode_nms_fused_kernel(DecCandArgs a, N
     const int nf = nvalid < w.M ? nvalid : w.M;
     NMS_STAMP(3);
     if (stop_after == 2) return;
-    nms_mask_body(iou_thres, nf, s_off, lmask, 8, wave, 16, lane);
+    nms_mask_body(iou_thres, nf, (lds_f4_ptr)(void*)s_off, lmask, 8, wave, 16, lane);
     NMS_STAMP(4);
     if (stop_after == 3) return;
     __syncthreads();
@@ -1071,14 +1081,19 @@ __global__ __launch_bounds__(1024) void decode_nms_fused_kernel(DecCandArgs a, N
   NMS_STAMP(3);
   if (stop_after == 2) return;
   __syncthreads();
-  // (boxes and mask rows in the workspace, never in LDS: a pointer that may be either becomes a FLAT access, and the compiler
-  // then folds this call and the LDS path's into one body of flat loads -- measured there: 6.5 us for a mask phase whose
-  // LDS form takes a third of that)
+  // the mask phase is a serial chain of n / 16 rows per wave: with the boxes in LDS (the sort's key array is free now, 4096
+  // boxes fit) a row costs LDS latency, not a memory round trip; the mask rows go to the workspace (stores: nobody waits)
   const int n = w.nfinal[b];
-  const float4* bo = w.box_off + (long long)b * w.M;
   unsigned long long* mk = w.mask + (long long)b * w.M * w.MW;
   const int mw = w.MW;
-  nms_mask_body(iou_thres, n, bo, mk, mw, wave, 16, lane);
+  if (n <= SORT_LDS_KEYS / 2) {
+    float4* lbox = reinterpret_cast<float4*>(sk);
+    for (int i = tid; i < n; i += 1024) lbox[i] = w.box_off[(long long)b * w.M + i];
+    __syncthreads();
+    nms_mask_body(iou_thres, n, (lds_f4_ptr)(void*)lbox, mk, mw, wave, 16, lane);
+  } else {
+    nms_mask_body(iou_thres, n, (const float4*)(w.box_off + (long long)b * w.M), mk, mw, wave, 16, lane);
+  }
   NMS_STAMP(4);
   if (stop_after == 3) return;
   __syncthreads();
