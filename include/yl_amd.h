@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define YL_ABI_VERSION 18
+#define YL_ABI_VERSION 19
 
 /* element types */
 enum { YL_BF16 = 0, YL_F32 = 1, YL_F16 = 2, YL_U8 = 3, YL_FP8 = 4 /* OCP e4m3 */ };
@@ -67,6 +67,13 @@ enum {
                            s = SiLU(cv2(cat(x, y5, y9, y13))) (extra_weight[0] [256][512]); out = s, or with n_extra = 2
                            out = SiLU(conv1x1(s)) (extra_weight[1] [256][256]) and s is never stored.  x and the pooled maps live in
                            LDS; bit-identical to the YL_OP_CONV, YL_OP_SPPF_POOL, YL_OP_CONV [, YL_OP_CONV] ops it replaces.        */
+  YL_OP_PSA_TAIL = 13,/* the pointwise tail of a C2PSA layer with ONE PSABlock of width c = 128 and 256 output channels (layer 10 of
+                           YOLO11n; nn/modules/block.py:919-953, 1035-1038): in = o, the attention's output + pe (128 channels);
+                           res = cat(a, b), C2PSA.cv1's output (256 channels, read only); out = the layer's output:
+                           b += conv1x1(o) (weight / bias [128][128], `proj`); b += conv1x1(SiLU(conv1x1(b))) (extra_weight[0]
+                           [256][128], extra_weight[1] [128][256], `ffn`); out = act(conv1x1(cat(a, b))) (extra_weight[2] [256][256],
+                           C2PSA.cv2).  Pixels of the whole batch as one list, nothing between the convs is stored; bit-identical
+                           to the four YL_OP_CONV ops it replaces.                                                          */
   YL_OP_C3K2S = 7     /* body of a narrow C3k2 block in one launch (nn/modules/block.py:220-235, 330-343), half width
                          c = 16 or 32: `in` = the block's concat buffer [a | b | ...] (a, b = halves of C3k2.cv1's output,
                          c channels each); c_out = b + SiLU(cv2(SiLU(cv1(b)))) with the Bottleneck's two 3x3 convs

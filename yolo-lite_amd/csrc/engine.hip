@@ -684,6 +684,51 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
         r.name = "psa_resident_mfma";
         break;
       }
+      case YL_OP_PSA_TAIL: {
+        const int c = o.in.C;
+        if (!o.weight || !o.bias || o.n_extra != 3 || !o.extra_weight || !o.extra_bias)
+          return fail(-1, tag + ": psa tail needs the proj filter and three extra filters (ffn.0, ffn.1, cv2)");
+        for (int q = 0; q < 3; ++q)
+          if (!o.extra_weight[q] || !o.extra_bias[q]) return fail(-1, tag + ": psa tail: null extra filter");
+        if (o.res.offset < 0) return fail(-1, tag + ": psa tail: res = cat(a, b), C2PSA.cv1's output");
+        if (int rc = check_view(o.res, batch, workspace_bytes, (tag + " res").c_str())) return rc;
+        if (o.in.dtype != YL_BF16 || o.out.dtype != YL_BF16 || o.res.dtype != YL_BF16 || !psa_tail_fits(c, o.out.C, 1) || o.res.C != 2 * c ||
+            o.in.H != o.out.H || o.in.W != o.out.W || o.res.H != o.out.H || o.res.W != o.out.W || o.lane != 0)
+          return fail(-3, tag + ": psa tail: o of 128 channels, cat(a, b) and the output of 256 channels, one map size");
+        auto pack = [&](const float* w, int cout, int cin, std::vector<uint16_t>* pk) {
+          ConvConfig cc{};
+          cc.MT = 4;
+          cc.ncb = cout / 64;
+          cc.cg = cin / 8;
+          cc.ntaps = 1;
+          cc.ksteps = cin / 32;
+          cc.wpk_elems = (size_t)cc.ncb * cc.ksteps * cc.MT * 64 * 8;
+          conv_pack_weights(w, cout, cin, 1, cc, pk);
+        };
+        {
+          std::vector<uint16_t> tail, part;
+          const float* ws4[4] = {o.weight, o.extra_weight[0], o.extra_weight[1], o.extra_weight[2]};
+          const int co4[4] = {c, 2 * c, c, 2 * c}, ci4[4] = {c, c, 2 * c, 2 * c};
+          for (int q = 0; q < 4; ++q) {
+            pack(ws4[q], co4[q], ci4[q], &part);
+            tail.insert(tail.end(), part.begin(), part.end());
+          }
+          if (tail.size() * 2 != 288 * 1024) return fail(-3, tag + ": psa tail: unexpected filter size");
+          uint16_t* d = nullptr;
+          if (int rc = dev_upload(e.get(), tail, &d)) return rc;
+          r.d_xw[1] = reinterpret_cast<__bf16*>(d);
+          const float* bs[4] = {o.bias, o.extra_bias[0], o.extra_bias[1], o.extra_bias[2]};
+          for (int q = 0; q < 4; ++q) {
+            std::vector<float> bias((size_t)co4[q] + 16, 0.f);
+            for (int ch = 0; ch < co4[q]; ++ch) bias[ch] = bs[q][ch];
+            if (int rc = dev_upload(e.get(), bias, &r.d_xb[q])) return rc;
+          }
+        }
+        r.flops = 2.0 * px_out * (c * c + 2.0 * c * c * 2 + 4.0 * c * c);
+        r.bytes = px_out * 2.0 * (c + 2 * c + 2 * c) + 2.0 * 9.0 * c * c;
+        r.name = "psa_tail_mfma";
+        break;
+      }
       case YL_OP_C3K2S: {
         if (!o.weight || !o.bias || !o.post_weight || !o.post_bias || !o.stem_weight || !o.stem_bias)
           return fail(-1, tag + ": c3k2 needs the three convs' weights and biases");
@@ -1178,6 +1223,31 @@ static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s, c
       q.w_pe = r.d_w;
       q.split = o.reserved3;  // (workgroups per image asked for by the program; 0: psa_resident_launch's choice)
       return psa_resident_launch(q, s);
+    }
+    case YL_OP_PSA_TAIL: {
+      PsaTailArgs q{};
+      const Geo gq = geo_of(B, o.in.H, o.in.W);
+      const long long pb = plane_bytes(gq);
+      if (32 * pb > (1LL << 30)) return fail(-3, "psa tail: a tensor slice exceeds 1 GiB; lower the batch size");
+      q.o = pview(ws, o.in, B).base;
+      q.u = pview(ws, o.res, B).base;
+      q.y = pview(ws, o.out, B).base;
+      q.o_plane = q.u_plane = q.y_plane = (unsigned)pb;
+      q.o_bytes = (unsigned)(16 * pb);
+      q.u_bytes = q.y_bytes = (unsigned)(32 * pb);
+      q.B = B;
+      q.H = o.in.H;
+      q.W = o.in.W;
+      q.W1 = gq.W1;
+      q.img = gq.img;
+      q.g0 = gq.g0;
+      q.w_tail = r.d_xw[1];
+      q.b_proj = r.d_xb[0];
+      q.b_ffn0 = r.d_xb[1];
+      q.b_ffn1 = r.d_xb[2];
+      q.b_cv2 = r.d_xb[3];
+      q.act = o.act;
+      return psa_tail_launch(q, s);
     }
     case YL_OP_C3K2S: {
       C3k2sArgs q{};

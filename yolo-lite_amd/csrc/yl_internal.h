@@ -369,6 +369,25 @@ struct PsaArgs {
 bool psa_resident_fits(int c, int heads, int key_dim, int head_dim, int H, int W);
 int psa_resident_launch(const PsaArgs& a, hipStream_t s);
 
+// psa_tail.hip: the pointwise tail of a C2PSA layer (proj, ffn.0, ffn.1 of its PSABlock, then C2PSA.cv2) in one launch, pixels of
+// the whole batch as one list
+struct PsaTailArgs {
+  const __bf16* o;          // first plane of the attention's output + pe (128 channels)
+  const __bf16* u;          // first plane of cat(a, b) = C2PSA.cv1's output (256 channels; b = planes 16 .. 31)
+  __bf16* y;                // first plane of the layer's output (256 channels)
+  unsigned o_plane, u_plane, y_plane, o_bytes, u_bytes, y_bytes;
+  int B, H, W, W1, img, g0;
+  const __bf16* w_tail;     // proj (32 KiB) | ffn.0 (64) | ffn.1 (64) | cv2 (128), each packed in 64-channel blocks
+  const float* b_proj;
+  const float* b_ffn0;
+  const float* b_ffn1;
+  const float* b_cv2;
+  int act;                  // cv2's activation (SiLU)
+  unsigned long long* stamps;  // diagnostic builds (-DYL_STAMPS)
+};
+bool psa_tail_fits(int c, int c2, int n_blocks);
+int psa_tail_launch(const PsaTailArgs& a, hipStream_t s);
+
 // sppf_resident.hip: an SPPF layer (256 -> 128, pools, 512 -> 256) and optionally the 1x1 conv 256 -> 256 that alone consumes its
 // output, in one launch, one or two workgroups per image
 struct SppfArgs {
