@@ -27,7 +27,7 @@ def test_header_symbols_exported():
         assert hasattr(L, n), f"{n} declared in include/yl_amd_diag.h but not exported"
     assert set(diag) == set(_lib.DIAG_EXPORTS), "diagnostic binding list and header drifted apart"
     assert not set(diag) & set(names), "a diagnostic entry point leaked into the product header"
-    assert L.yl_abi_version() == 18
+    assert L.yl_abi_version() == 19
 
 
 def test_struct_layouts_match_header():

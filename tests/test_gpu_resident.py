@@ -219,6 +219,7 @@ def test_network_with_resident_psa_is_bit_identical(gpu_device, monkeypatch, h, 
     y = eng.forward(x).clone()
     lv = [t.clone() for t in eng.raw_levels()]
     monkeypatch.setenv("YL_FUSE_PSA", "0")
+    monkeypatch.setenv("YL_FUSE_PSA_TAIL", "0")  # (the six launches, not the one-launch tail either)
     ref = HipEngine.from_model(specs, sd, b, h, w, gpu_device)
     assert "psa_resident_mfma" not in [ref.op_kernel(i) for i in range(len(ref.prog.ops))]
     assert len(ref.prog.ops) == len(eng.prog.ops) + 5
@@ -307,3 +308,31 @@ def test_network_with_resident_sppf_is_bit_identical(gpu_device, monkeypatch, h,
     assert torch.equal(y, ref.forward(x))
     for p, q in zip(lv, ref.raw_levels()):
         assert torch.equal(p, q)
+
+
+@pytest.mark.parametrize("h,w,b,one_batch", [(640, 640, 32, True), (640, 640, 3, False), (384, 640, 5, True), (320, 320, 9, True), (96, 160, 2, False),
+                                             (224, 352, 7, True), (32, 32, 1, False)])
+def test_network_with_psa_tail_is_bit_identical(gpu_device, monkeypatch, h, w, b, one_batch):
+    """YOLO11n with the pointwise tail of layer 10 (proj, ffn.0, ffn.1, C2PSA.cv2) as ONE launch over the pixels of the whole batch
+    (csrc/psa_tail.hip: the latency profile, and batches too small for the one-launch PSABlock) against the four launches: level
+    maps and decoded predictions, every bit; tiles that straddle rows and images, a last workgroup with idle waves."""
+    sd = synth_state_dict("n", 12, cls_bias=[-2.0, -2.0, -2.0], cls_gain=4.0)
+    x = torch.randint(0, 256, (b, 3, h, w), generator=torch.Generator().manual_seed(h + 5 * w + b), dtype=torch.uint8).to(gpu_device)
+    specs, _ = arch.parse_model(arch.yolo11_dict("n"))
+    monkeypatch.setenv("YL_FUSE_PSA_TAIL", "1")
+    eng = HipEngine.from_model(specs, sd, b, h, w, gpu_device, one_batch=one_batch)
+    names = [eng.op_kernel(i) for i in range(len(eng.prog.ops))]
+    assert names.count("psa_tail_mfma") == 1 and "psa_resident_mfma" not in names
+    y = eng.forward(x).clone()
+    lv = [t.clone() for t in eng.raw_levels()]
+    out, cnt = eng.detect(x, 0.25, 0.7, graph=True)
+    out, cnt = out.clone(), cnt.clone()
+    monkeypatch.setenv("YL_FUSE_PSA_TAIL", "0")
+    ref = HipEngine.from_model(specs, sd, b, h, w, gpu_device, one_batch=one_batch)
+    assert "psa_tail_mfma" not in [ref.op_kernel(i) for i in range(len(ref.prog.ops))]
+    assert len(ref.prog.ops) == len(eng.prog.ops) + 3
+    assert torch.equal(y, ref.forward(x))
+    for p, q in zip(lv, ref.raw_levels()):
+        assert torch.equal(p, q)
+    o2, c2 = ref.detect(x, 0.25, 0.7, graph=False)
+    assert torch.equal(cnt, c2) and all(torch.equal(out[i, :n], o2[i, :n]) for i, n in enumerate(cnt.tolist()))

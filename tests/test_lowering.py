@@ -2,7 +2,8 @@
 import pytest
 
 from yololite_amd.nn import arch
-from yololite_amd.nn.lower import OP_BNECK2, OP_C3K2S, OP_ATTENTION, OP_CONV, OP_DWCONV3, OP_SPPF_POOL, OP_STEM, OP_UPSAMPLE, lower, plane_pixels, view_bytes
+from yololite_amd.nn.lower import (OP_BNECK2, OP_C3K2S, OP_ATTENTION, OP_CONV, OP_DWCONV3, OP_PSA_TAIL, OP_SPPF_POOL, OP_STEM, OP_UPSAMPLE, lower,
+                                   plane_pixels, view_bytes)
 from yololite_amd.nn.synth import synth_state_dict
 
 
@@ -20,6 +21,9 @@ def _conv_gflop(prog):
         if o["kind"] == OP_C3K2S:  # Bottleneck.cv1, Bottleneck.cv2 and C3k2.cv2 in one op
             for w in (o["weight"], o["post_weight"], o["stem_weight"]):
                 f += 2.0 * o["out"].H * o["out"].W * w.shape[0] * w.shape[1] * w.shape[2] * w.shape[3]
+        if o["kind"] == OP_PSA_TAIL:  # proj, ffn.0, ffn.1 and C2PSA.cv2 in one op (all 1x1)
+            for w in [o["weight"]] + list(o["extra_weight"]):
+                f += 2.0 * o["out"].H * o["out"].W * w.shape[0] * w.shape[1]
         if o["kind"] in (OP_CONV, OP_DWCONV3, OP_STEM):
             w = o["weight"]
             f += 2.0 * o["out"].H * o["out"].W * w.shape[0] * w.shape[1] * w.shape[2] * w.shape[3]
@@ -41,8 +45,8 @@ def test_algorithmic_flops_match_survey(scale, gflop, nconv):
     got = _conv_gflop(p) + 2 * 16 * 4 * p.anchors / 1e9
     assert abs(got - gflop) < 2e-3 * gflop
     # C3k cv1+cv2 pairs are merged into one launch: count reference Conv2d calls
-    calls = sum((2 if o.get("name", "").endswith("cv1+cv2") else 1) + len(o.get("fused_names", []))
-                for o in p.ops if o["kind"] in (OP_CONV, OP_DWCONV3, OP_STEM, OP_C3K2S, OP_BNECK2))
+    calls = sum((0 if o["kind"] == OP_PSA_TAIL else 2 if o.get("name", "").endswith("cv1+cv2") else 1) + len(o.get("fused_names", []))
+                for o in p.ops if o["kind"] in (OP_CONV, OP_DWCONV3, OP_STEM, OP_C3K2S, OP_BNECK2, OP_PSA_TAIL))
     assert calls + 1 == nconv  # + the DFL conv
 
 
@@ -226,11 +230,13 @@ def test_sppf_resident_limits():
 
 def test_lowering_uses_resident_c3k_from_batch_8(monkeypatch):
     from yololite_amd.nn import arch
-    from yololite_amd.nn.lower import OP_C3K, OP_PSA, OP_SPPF, lower
+    from yololite_amd.nn.lower import OP_C3K, OP_PSA, OP_PSA_TAIL, OP_SPPF, lower, psa_tail_fits
     from yololite_amd.nn.synth import synth_state_dict
 
     monkeypatch.delenv("YL_FUSE_C3K", raising=False)
     monkeypatch.delenv("YL_FUSE_SPPF", raising=False)
+    monkeypatch.delenv("YL_FUSE_PSA_TAIL", raising=False)
+    assert psa_tail_fits(128, 256, 1) and not psa_tail_fits(256, 512, 1) and not psa_tail_fits(128, 256, 2)
     specs, _ = arch.parse_model(arch.yolo11_dict("n"))
     sd = synth_state_dict("n", 0)
     big = lower(specs, sd, 32, 640, 640)
@@ -242,13 +248,24 @@ def test_lowering_uses_resident_c3k_from_batch_8(monkeypatch):
     assert sppf[0]["out"] == [o for o in big.ops if o["kind"] == OP_PSA][0]["inp"]
     assert not [o for o in big.ops if o["name"] == "model.10.cv1"]
     small = lower(specs, sd, 1, 640, 640)
-    assert not [o for o in small.ops if o["kind"] in (OP_C3K, OP_PSA, OP_SPPF)] and len(small.ops) == len(big.ops) + 18
+    # (without the one-launch PSABlock the layer is qkv, attention, pe and ONE launch for its pointwise tail -- proj, ffn.0, ffn.1 and
+    # C2PSA.cv2: four ops where the resident form has two, PSABlock + cv2)
+    assert not [o for o in small.ops if o["kind"] in (OP_C3K, OP_PSA, OP_SPPF)] and len(small.ops) == len(big.ops) + 15
     monkeypatch.setenv("YL_FUSE_PSA", "0")  # without the resident PSABlock the SPPF launch still carries C2PSA.cv1
     nopsa = lower(specs, sd, 32, 640, 640)
-    assert [len(o["extra_weight"]) for o in nopsa.ops if o["kind"] == OP_SPPF] == [2] and len(nopsa.ops) == len(big.ops) + 5
+    assert [len(o["extra_weight"]) for o in nopsa.ops if o["kind"] == OP_SPPF] == [2] and len(nopsa.ops) == len(big.ops) + 2
+    tail = [o for o in nopsa.ops if o["kind"] == OP_PSA_TAIL]
+    assert [o["name"] for o in tail] == ["model.10.m.0.tail"]
+    assert tail[0]["fused_names"] == ["model.10.m.0.attn.proj", "model.10.m.0.ffn.0", "model.10.m.0.ffn.1", "model.10.cv2"]
+    assert tail[0]["res"].C == 256 and tail[0]["inp"].C == 128 and tail[0]["out"].C == 256
+    assert not [o for o in nopsa.ops if o["name"] in ("model.10.cv2", "model.10.m.0.ffn.0")]
+    monkeypatch.setenv("YL_FUSE_PSA_TAIL", "0")
+    assert len(lower(specs, sd, 32, 640, 640).ops) == len(big.ops) + 5
+    monkeypatch.delenv("YL_FUSE_PSA_TAIL")
     monkeypatch.delenv("YL_FUSE_PSA")
     lat = lower(specs, sd, 32, 640, 640, one_batch=True)  # the latency profile: resident C3k with two workgroups per image, SPPF / PSA unfused
     assert [o["split"] for o in lat.ops if o["kind"] == OP_C3K] == [2, 2] and all(o["split"] == 0 for o in big.ops if o["kind"] == OP_C3K)
-    assert not [o for o in lat.ops if o["kind"] in (OP_PSA, OP_SPPF)] and len(lat.ops) == len(big.ops) + 3 + 5
+    assert not [o for o in lat.ops if o["kind"] in (OP_PSA, OP_SPPF)] and len(lat.ops) == len(big.ops) + 3 + 2
+    assert len([o for o in lat.ops if o["kind"] == OP_PSA_TAIL]) == 1
     s_scale = lower(arch.parse_model(arch.yolo11_dict("s"))[0], synth_state_dict("s", 0), 32, 640, 640)
     assert not [o for o in s_scale.ops if o["kind"] == OP_C3K]   # inner width 128: the maps do not fit

@@ -240,7 +240,7 @@ def lib() -> C.CDLL:
     L.yl_diag_set_stamps.argtypes = [vp]
     L.yl_engine_prefilter_fused.restype = i32
     L.yl_engine_prefilter_fused.argtypes = [vp, f32]
-    if L.yl_abi_version() != 18:
+    if L.yl_abi_version() != 19:
         raise RuntimeError("libyl_amd.so ABI version mismatch; rebuild it")
     _lib = L
     return L

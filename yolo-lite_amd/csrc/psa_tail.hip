@@ -10,8 +10,11 @@
 // workgroup to an image: the pixels of the whole batch are one list, a wave owns two 16-pixel tiles of it from the first load
 // to the last store, and the tensors between the convs never leave its registers (the accumulator layout of one conv IS the
 // B-fragment layout of the next: conv_kernel's POST trick, as in psa_resident_kernel, whose proj / ffn code this is).  A
-// workgroup = four waves = 128 pixels; the filters come through LDS: proj | ffn.0 | ffn.1 (160 KB, the whole LDS) by LDS-DMA
-// at the start, cv2's 128 KB over them once every wave is through ffn.1.  b after ffn.1 is only cv2's input and is not stored.
+// workgroup = four waves = 128 pixels (64 while that leaves CUs idle: one tile per wave); the filters come through LDS: proj |
+// ffn.0 | ffn.1 (160 KB, the whole LDS) by LDS-DMA at the start, cv2's 128 KB over them once every wave is through ffn.1.  b after
+// ffn.1 is only cv2's input and is not stored.  Measured (batch 32, 20x20 maps, in-kernel stamps): 18.2 us kernel span with one
+// tile per wave on 200 workgroups (22.5 us with two on 100) -- filters staged 3.4, proj 1.1, ffn 5.8 (64 SiLUs per lane: VALU),
+// cv2's filter 2.9, cv2 + stores 4.5 -- 23.5 us in sequence against 41.8 us for the four launches.
 // Arithmetic is conv_kernel's (packed filters in 64-channel blocks, k order, fp32 chain from the bias, one rounding to bf16 per
 // layer, silu_f / silu4): BIT-IDENTICAL to the four launches (tests/test_gpu_resident.py).  The program's latency profile
 // (nn/lower.py lower(one_batch=True)) uses it; with batches in flight the one-launch PSABlock (psa_resident_kernel) is cheaper.
@@ -23,13 +26,13 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 
 constexpr int PT_THREADS = 256;
 constexpr int PT_WAVES = PT_THREADS / 64;
-constexpr int PT_NT = 2;                     // 16-pixel tiles per wave
 constexpr int PT_LDS = 160 * 1024;
 
+// NT: 16-pixel tiles per wave (2: a filter fragment read from LDS feeds two MFMAs; 1: twice the workgroups)
+template <int NT>
 __global__ __launch_bounds__(PT_THREADS) void psa_tail_kernel(PsaTailArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ptm[];
   unsigned char* const lds = ptm;
-  constexpr int NT = PT_NT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int g = lane >> 4, n = lane & 15;
 #define PT_STAMP(id) YL_STAMP(a.stamps, PT_WAVES, wave, lane, id)
@@ -245,8 +248,11 @@ int psa_tail_launch(const PsaTailArgs& a0, hipStream_t s) {
   a.stamps = g_stamp_buf;
   const long long P = (long long)a.B * a.H * a.W;
   if (P <= 0 || P > (1LL << 28)) return fail(-3, "psa_tail: bad map size");
-  const int per_wg = PT_WAVES * PT_NT * 16;
-  auto kern = psa_tail_kernel;
+  // one tile per wave while that still leaves CUs idle (a workgroup holds the whole LDS of its CU)
+  static const int nt_env = getenv("YL_PSA_TAIL_NT") ? atoi(getenv("YL_PSA_TAIL_NT")) : 0;
+  const int nt = nt_env == 1 || nt_env == 2 ? nt_env : (P <= (long long)device_cu_count() * PT_WAVES * 16 ? 1 : 2);
+  const int per_wg = PT_WAVES * nt * 16;
+  auto kern = nt == 1 ? psa_tail_kernel<1> : psa_tail_kernel<2>;
   if (int rc = allow_big_lds(reinterpret_cast<const void*>(kern), PT_LDS)) return rc;
   hipLaunchKernelGGL(kern, dim3((unsigned)((P + per_wg - 1) / per_wg)), dim3(PT_THREADS), PT_LDS, s, a);
   YL_HIP(hipGetLastError());

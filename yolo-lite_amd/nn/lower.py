@@ -23,6 +23,7 @@ from .arch import LayerSpec, detect_mid_channels
 BN_EPS = 1e-3
 BF16, F32, FP8 = 0, 1, 4  # yl_amd.h element types (FP8 = OCP e4m3, planes of 16 channels)
 OP_CONV, OP_DWCONV3, OP_SPPF_POOL, OP_UPSAMPLE, OP_ATTENTION, OP_STEM, OP_C3K2S, OP_BNECK2, OP_QUANT, OP_C3K, OP_PSA, OP_SPPF = 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12
+OP_PSA_TAIL = 13
 
 
 @dataclass
@@ -106,6 +107,12 @@ def c3k_resident_fits(c_: int, H: int, W: int) -> bool:
 def psa_resident_fits(c: int, nh: int, kd: int, hd: int, H: int, W: int) -> bool:
     """Mirror of ``psa_resident_fits`` (csrc/resident.hip): the PSABlock of YOLO11n's C2PSA on a map of at most 400 pixels."""
     return c == 128 and nh == 2 and kd == 32 and hd == 64 and 8 <= H * W <= 400
+
+
+def psa_tail_fits(c: int, c2: int, n_blocks: int) -> bool:
+    """Mirror of ``psa_tail_fits`` (csrc/psa_tail.hip): the pointwise tail of a C2PSA layer with one PSABlock of width 128 and
+    256 output channels (YOLO11n's layer 10); any map size -- the pixels of the batch are one list."""
+    return c == 128 and c2 == 256 and n_blocks == 1
 
 
 def sppf_resident_fits(c1: int, c2: int, tail: int, H: int, W: int) -> bool:
@@ -919,6 +926,7 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
                 u = ar.alloc(src.H, src.W, 2 * c)
                 conv(p + ".cv1", src, u, 1, 1)
             b = u.slice(c, c)
+            psa_tail_done = False
             for j in range(sp.n):
                 q = f"{p}.m.{j}"
                 # the whole PSABlock in ONE launch, one workgroup per image (csrc/resident.hip psa_resident_kernel: 6 launches ->
@@ -950,11 +958,28 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
                                 scale=float(kd ** -0.5), inp=qkv, out=o, res=None))
                 dwconv(q + ".attn.pe", qkv, o, act=False, accumulate=True, grp=hd, grp_stride=2 * kd + hd,
                        grp_off=2 * kd)
+                # everything behind the attention is pointwise: proj, ffn.0, ffn.1 and C2PSA.cv2 in ONE launch over the pixels
+                # of the whole batch (csrc/psa_tail.hip, bit-identical), where the one-launch PSABlock is not taken -- i.e. in the
+                # one-batch profile: four launch skeletons (42 us in sequence at batch 32) for 0.9 us of matrix work
+                if (fuse_post and os.environ.get("YL_FUSE_PSA_TAIL", "1") != "0" and psa_tail_fits(c, y.C, sp.n)
+                        and u.coff == 0 and not fp8_scales):
+                    names, xw, xb = [q + ".attn.proj"], [], []
+                    wp, bpj = fold_conv_bn(sd, q + ".attn.proj")
+                    for full in (q + ".ffn.0", q + ".ffn.1", p + ".cv2"):
+                        wj, bj = fold_conv_bn(sd, full)
+                        xw.append(wj.reshape(wj.shape[0], -1))
+                        xb.append(bj)
+                        names.append(full)
+                    ops.append(dict(kind=OP_PSA_TAIL, name=q + ".tail", act=1, inp=o, out=y, res=u, weight=wp.reshape(wp.shape[0], -1),
+                                    bias=bpj, extra_weight=xw, extra_bias=xb, fused_names=names))
+                    psa_tail_done = True
+                    continue
                 conv(q + ".attn.proj", o, b, 1, 1, act=False, res=b)
                 f1 = ar.alloc(src.H, src.W, 2 * c)
                 conv(q + ".ffn.0", b, f1, 1, 1)
                 conv(q + ".ffn.1", f1, b, 1, 1, act=False, res=b)
-            conv(p + ".cv2", u, y, 1, 1)
+            if not psa_tail_done:
+                conv(p + ".cv2", u, y, 1, 1)
         elif sp.kind == "Upsample":
             y = out_view(sp.i)
             ops.append(dict(kind=OP_UPSAMPLE, name=p, stride=2, inp=src, out=y, res=None))
