@@ -172,8 +172,12 @@ class DetectionPredictor:
         stage = "rebind" if graph and os.environ.get("YL_PREDICT_REBIND", "1") != "0" and not getattr(self, "_no_rebind", False) else graph
 
         def go():
+            # (one batch per call: the counts land in pinned host memory straight from the last kernel -- the harvest
+            # synchronises the stream and reads them, no device-to-host copy; YL_PREDICT_HOST_COUNTS=0: the .tolist() of a
+            # device tensor instead)
+            host_counts = graph and stream is None and os.environ.get("YL_PREDICT_HOST_COUNTS", "1") != "0"
             kw = dict(max_det=self.args.max_det, classes=self.args.classes, agnostic=self.args.agnostic_nms, scale=scale,
-                      graph=graph, slot=slot)
+                      graph=graph, slot=slot, count_host=host_counts, scale_static=True)
             try:
                 out, cnt = eng.detect(imc, self.args.conf, self.args.iou, stage=stage, **kw)
             except RuntimeError as e:
@@ -187,6 +191,8 @@ class DetectionPredictor:
             # ordered behind this batch on its stream
             if not graph:
                 return out, cnt
+            if host_counts:
+                return out, cnt  # (cloned by the harvest, behind the synchronisation: not on the path the caller waits for)
             if stream is None:
                 return out.clone(), cnt
             # the per-image counts travel to PINNED host memory on the batch's own stream: the harvest then waits for the
@@ -212,7 +218,8 @@ class DetectionPredictor:
                 ev = torch.cuda.Event()
                 ev.record(stream)
             imc.record_stream(stream)
-        return dict(out=out, cnt=cnt, ev=ev, shapes=shapes, imgs=imgs, paths=self.batch[0], n=b, input=imc)
+        return dict(out=out, cnt=cnt, ev=ev, shapes=shapes, imgs=imgs, paths=self.batch[0], n=b, input=imc,
+                    host_counts=stream is None and not cnt.is_cuda)
 
     def _harvest_fused(self, job):
         if job["ev"] is not None:
@@ -220,7 +227,12 @@ class DetectionPredictor:
             # the records were cloned on the batch's side stream and are consumed on the caller's stream from here on:
             # tell the caching allocator, so the block is not handed out again under a pending reader
             job["out"].record_stream(torch.cuda.current_stream(job["out"].device))
-        counts = job["cnt"].tolist()  # the one host sync of the batch
+        if job.get("host_counts"):
+            torch.cuda.current_stream(job["out"].device).synchronize()  # the one host sync of the batch
+            counts = job["cnt"].tolist()
+            job["out"] = job["out"].clone()  # engine-owned buffers are overwritten by the slot's next batch
+        else:
+            counts = job["cnt"].tolist()  # the one host sync of the batch
         self.last_preds = None
         names, out, shapes, imgs, paths = self.model.names, job["out"], job["shapes"], job["imgs"], job["paths"]
         recs = out.unbind(0)  # one call: the per-image (max_det, 6) records; rows are cut to the count on first use

@@ -195,7 +195,8 @@ class HipEngine:
 
     def detect(self, im: torch.Tensor, conf: float = 0.25, iou: float = 0.7, max_det: int = 300,
                classes=None, agnostic: bool = False, max_nms: int = 30000, max_wh: float = 7680.0,
-               scale: Optional[torch.Tensor] = None, graph: bool = True, slot: int = 0, stage: bool = False, rec_key=0):
+               scale: Optional[torch.Tensor] = None, graph: bool = True, slot: int = 0, stage: bool = False, rec_key=0,
+               count_host: bool = False, scale_static: bool = False):
         """Network + fused Detect decode + NMS; returns padded (out[B, max_det, 6], count[B]).
 
         Bit-identical to ``forward`` followed by ``utils.ops.nms_padded`` but the (B, 4+nc, A) tensor
@@ -211,7 +212,10 @@ class HipEngine:
         has at most one batch per slot pending.
         ``rec_key`` (graph mode): which of the slot's engine-owned output records to write -- a slot may own several
         (``dist.ShardedRunner`` alternates two per slot so that the gather of one step can still read its record while
-        the slot's next step runs); each (input address, record) pair is its own captured graph."""
+        the slot's next step runs); each (input address, record) pair is its own captured graph.
+        ``count_host`` (graph mode): the per-image counts are written by the last kernel straight into PINNED HOST memory
+        (the returned ``cnt`` is that host tensor: valid once the stream has been synchronised, no device-to-host copy) --
+        what a caller that waits for every batch wants; the packed record's count words are not written then."""
         self._check_input(im)
         rebind = graph and stage == "rebind"  # (no staging copy: the captured graph's input-reading nodes take im's address)
         if graph and stage and not rebind:
@@ -242,6 +246,11 @@ class HipEngine:
                 st[("rec", max_det, rec_key)] = rec
                 st[ok] = pack_views(rec, self.batch, max_det)
             out, cnt = st[ok]
+            if count_host:
+                hk = ("cnt_host", max_det, rec_key)
+                if hk not in st:  # (hipHostMalloc'ed memory is device-accessible at its host address)
+                    st[hk] = torch.zeros(self.batch, dtype=torch.int32, pin_memory=True)
+                cnt = st[hk]
         else:
             out = torch.empty((self.batch, max_det, 6), dtype=torch.float32, device=self.device)
             cnt = torch.empty((self.batch,), dtype=torch.int32, device=self.device)
@@ -254,7 +263,11 @@ class HipEngine:
         if scale is not None and graph:
             if "scale" not in st:
                 st["scale"] = torch.empty((self.batch, 5), dtype=torch.float32, device=self.device)
-            st["scale"].copy_(scale.reshape(self.batch, 5))
+            # (scale_static: the caller promises never to modify this tensor -- the predictor hands over ONE cached table per
+            # shape tuple -- so the same object is not copied again: a device-to-device copy in front of every launch otherwise)
+            if not (scale_static and st.get("scale_src") is scale):
+                st["scale"].copy_(scale.reshape(self.batch, 5))
+                st["scale_src"] = scale if scale_static else None
             scale = st["scale"]
         args = (float(conf), float(iou), int(max_det), int(bool(agnostic)),
                 cls_t.data_ptr() if cls_t is not None else None, int(cls_t.numel()) if cls_t is not None else 0,
