@@ -586,21 +586,28 @@ def test_level_group_launches_are_bit_identical(gpu_device, monkeypatch, h, w, m
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("switch,bias", [("YL_FUSE_PREFILTER", -3.0), ("YL_NMS_FUSED", -3.0), ("YL_NMS_FUSED", 0.5),
-                                         ("YL_NMS_LDS", -3.0), ("YL_NMS_LDS", -1.5), ("YL_NMS_LDS", 0.5)])
-def test_prefilter_in_the_class_launch_epilogue_is_bit_identical(gpu_device, switch, bias):
+@pytest.mark.parametrize("switch,bias,hw", [("YL_FUSE_PREFILTER", -3.0, (320, 448)), ("YL_NMS_FUSED", -3.0, (320, 448)),
+                                            ("YL_NMS_FUSED", 0.5, (320, 448)), ("YL_NMS_FUSED", 0.5, (640, 640)),
+                                            ("YL_NMS_LDS", -3.0, (320, 448)), ("YL_NMS_LDS", -1.5, (320, 448)),
+                                            ("YL_NMS_LDS", 0.5, (320, 448)), ("YL_FUSE_PREFILTER_CONV", -3.0, (320, 448)),
+                                            ("YL_FUSE_PREFILTER_CONV", -1.0, (160, 96))])
+def test_prefilter_in_the_class_launch_epilogue_is_bit_identical(gpu_device, switch, bias, hw):
     """The NMS candidate pre-filter in the epilogue of the launches that write the class logits (ConvArgs::pf_*, default)
     against the separate pre-filter kernel (YL_FUSE_PREFILTER=0, read once per process -> a child process): same detections,
     bit for bit, eager and graph, at a low and at the default confidence threshold.
     YL_NMS_FUSED: exact decode + sort + mask + scan in ONE launch (decode_nms_fused_kernel, one workgroup per image, default)
-    against the four launches; bias 0.5 makes thousands of anchors per image candidates (the scan's general path, > 512 rows).
+    against the four launches; bias 0.5 makes thousands of anchors per image candidates (the scan's general path, > 512 rows;
+    at 320x448 the image's <= 2 940 boxes sit in LDS for the mask phase, at 640x640 -- up to 8 400 -- in the workspace).
     YL_NMS_LDS: that kernel's all-in-LDS path for images with <= 512 pre-filtered anchors (default) against its general path
-    (intermediates through the NMS workspace), inside the one-launch form; with `classes` given as well."""
+    (intermediates through the NMS workspace), inside the one-launch form; with `classes` given as well.
+    YL_FUSE_PREFILTER_CONV (YOLO11s: the class branch is too wide for the fused tail launch and ends in a plain 1x1 conv): the
+    pre-filter in THAT conv's epilogue (conv_kernel's PF instantiation, default) against the separate pre-filter kernel."""
     import os
     import subprocess
     import sys
     import tempfile
 
+    scale = "s" if switch == "YL_FUSE_PREFILTER_CONV" else "n"
     code = """
 import sys, torch
 sys.path.insert(0, %r)
@@ -609,11 +616,11 @@ _lib.apply_runtime_knobs()
 from yololite_amd.nn import arch
 from yololite_amd.nn.engine import HipEngine
 from yololite_amd.nn.synth import synth_state_dict
-specs, _ = arch.parse_model(arch.yolo11_dict("n"))
-sd = synth_state_dict("n", 9, cls_bias=[%r] * 3, cls_gain=6.0)
+specs, _ = arch.parse_model(arch.yolo11_dict(%r))
+sd = synth_state_dict(%r, 9, cls_bias=[%r] * 3, cls_gain=6.0)
 dev = torch.device("cuda:0")
-eng = HipEngine.from_model(specs, sd, 2, 320, 448, dev)
-x = torch.randint(0, 256, (2, 3, 320, 448), generator=torch.Generator().manual_seed(11), dtype=torch.uint8).to(dev)
+eng = HipEngine.from_model(specs, sd, 2, %d, %d, dev)
+x = torch.randint(0, 256, (2, 3, %d, %d), generator=torch.Generator().manual_seed(11), dtype=torch.uint8).to(dev)
 res = {}
 for conf in (0.25, 0.06):
     for graph in (False, True):
@@ -621,8 +628,9 @@ for conf in (0.25, 0.06):
         res[(conf, graph)] = (o.cpu().clone(), c.cpu().clone())
 o, c = eng.detect(x, 0.25, 0.5, max_det=20, classes=[0, 3, 5, 17, 40, 79], agnostic=True)
 res["classes"] = (o.cpu().clone(), c.cpu().clone())
+res["fused_pf"] = bool(eng.lib.yl_engine_prefilter_fused(eng._h, 0.25))
 torch.save(res, sys.argv[1])
-""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), bias)
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), scale, scale, bias, hw[0], hw[1], hw[0], hw[1])
     outs = []
     with tempfile.TemporaryDirectory() as td:
         for flag in ("1", "0"):
@@ -634,8 +642,12 @@ torch.save(res, sys.argv[1])
             outs.append(torch.load(f))
     fused, plain = outs
     assert fused.keys() == plain.keys()
+    if switch in ("YL_FUSE_PREFILTER", "YL_FUSE_PREFILTER_CONV"):
+        assert fused["fused_pf"] and not plain["fused_pf"]
     total = 0
     for k in fused:
+        if k == "fused_pf":
+            continue
         assert torch.equal(fused[k][1], plain[k][1]), k
         for i, n in enumerate(fused[k][1].tolist()):
             assert torch.equal(fused[k][0][i, :n], plain[k][0][i, :n]), (k, i)

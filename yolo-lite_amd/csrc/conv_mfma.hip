@@ -80,13 +80,46 @@ __device__ __forceinline__ void run_ksteps(const ConvArgs& a, __amdgpu_buffer_rs
   }
 }
 
+// The NMS candidate pre-filter (nms.hip decode_candidates_sparse_kernel) in the epilogue of the launch that produces a Detect
+// level's class logits: an anchor whose best STORED logit (bf16, as the level map holds it) could clear the confidence
+// threshold is appended to its image's sub-list -- the class planes (43 MB per batch of 32 for YOLO11n) are then never re-read
+// for it.  acc: the final logits of `patch` (all `cout` class channels in this wave: ncb == 1); lane (n, g) holds 4 rows of
+// each of the MT channel tiles of pixel n.
+template <int MT, int NT>
+__device__ __forceinline__ void pf_sink(const ConvArgs& a, const f32x4 (&acc)[MT][NT], int patch, int g, int n, int cout) {
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    float m = -__builtin_huge_valf();
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (chan_in_block(MT, mt, g, r) < cout) m = fmaxf(m, (float)(__bf16)acc[mt][nt][r]);
+      }
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+    const int gp = patch * (16 * NT) + nt * 16 + n;  // pixel index over the batch (patch_setup's order)
+    if (g == 0 && gp < a.npix && m > a.pf_logit_lo) {
+      const int hw = a.Ho * a.Wo;
+      const int b = gp / hw;
+      const int an = a.pf_anchor0 + (gp - b * hw);
+      const int sub = b * PF_NSUB + ((an >> 6) & (PF_NSUB - 1));
+      const int slot = atomicAdd(&a.pf_count[sub], 1);
+      if (slot < a.pf_sub_cap) a.pf_list[(long long)sub * a.pf_sub_cap + slot] = an;
+    }
+  }
+}
+
 // POST (MT even, all MT*16 channels of the first conv in this wave, i.e. ncb == 1): a 1x1 conv that
 // consumes ONLY this conv's output is applied in the epilogue.  After bias + SiLU + bf16 rounding the
 // accumulators of tile pair p ARE the B fragment of k-step p of that 1x1 conv (same channel permutation
 // that makes the stores 16 bytes wide), so the intermediate tensor is never written or read.
 // O8: the epilogue also stores the e4m3 copy of the output (yl_op.out8, fp8 mode only; a separate instantiation so that the bf16
 // programs run exactly the code they ran before the copy existed).
-template <int KS, int MT, int NT, bool UNIFORM, bool POST, bool UP = false, bool O8 = false>
+// PF: this conv writes a Detect level's class logits (act == 0, ncb == 1) and feeds the NMS candidate pre-filter on its way out
+// (pf_sink; the networks whose class branch ends in a plain 1x1 launch: YOLO11s / m / l / x, where the branch is too wide for
+// dwpw_kernel); a separate instantiation for the same reason.
+template <int KS, int MT, int NT, bool UNIFORM, bool POST, bool UP = false, bool O8 = false, bool PF = false>
 __device__ __forceinline__ void conv_body(const ConvArgs& a, int block) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -156,6 +189,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, int block) {
     int opix[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) opix[nt] = P.opix[nt];
+    const int patch_done = patch;
     patch += 4;
     live = (pp + 1 < a.ppw) && patch < a.npatches;
     if (live) {
@@ -204,14 +238,17 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, int block) {
       a2.act = a.post_act;
       epilogue<MT, NT>(a2, rout, rres, cb, g, opix, acc);
     } else {
+      if constexpr (PF) {
+        if (a.pf_count) pf_sink<MT, NT>(a, acc, patch_done, g, n, a.Cout);
+      }
       epilogue<MT, NT, O8>(a, rout, rres, cb, g, opix, acc);
     }
   }
 }
 
-template <int KS, int MT, int NT, bool UNIFORM, bool POST, bool UP = false, bool O8 = false>
+template <int KS, int MT, int NT, bool UNIFORM, bool POST, bool UP = false, bool O8 = false, bool PF = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(YL_CONV_WPE))) void conv_kernel(ConvArgs a) {
-  conv_body<KS, MT, NT, UNIFORM, POST, UP, O8>(a, blockIdx.x);
+  conv_body<KS, MT, NT, UNIFORM, POST, UP, O8, PF>(a, blockIdx.x);
 }
 
 // Up to three convs of ONE tiling in one launch ("horizontal" fusion): the three Detect levels run the same box / class
@@ -459,33 +496,7 @@ __device__ __forceinline__ void dwpw_body(const ConvArgs& a, int block) {
           acc[mt][nt] = silu4(acc[mt][nt]);
       a2.act = 0;
     }
-    if (a.pf_count) {
-      // The NMS candidate pre-filter (nms.hip decode_candidates_sparse_kernel) in the epilogue of the launch that
-      // produces a Detect level's class logits: an anchor whose best STORED logit (bf16, as the level map holds it)
-      // could clear the confidence threshold is appended to its image's sub-list -- the 43 MB of class planes per batch
-      // are then never re-read for it.  Lane (n, g) holds 4 rows of each of the MT channel tiles of pixel n.
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        float m = -__builtin_huge_valf();
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            if (chan_in_block(MT, mt, g, r) < a.post_cout) m = fmaxf(m, (float)(__bf16)acc[mt][nt][r]);
-          }
-        m = fmaxf(m, __shfl_xor(m, 16));
-        m = fmaxf(m, __shfl_xor(m, 32));
-        const int gp = patch * (16 * NT) + nt * 16 + n;  // pixel index over the batch (patch_setup's order)
-        if (g == 0 && gp < a.npix && m > a.pf_logit_lo) {
-          const int hw = a.Ho * a.Wo;
-          const int b = gp / hw;
-          const int an = a.pf_anchor0 + (gp - b * hw);
-          const int sub = b * PF_NSUB + ((an >> 6) & (PF_NSUB - 1));
-          const int slot = atomicAdd(&a.pf_count[sub], 1);
-          if (slot < a.pf_sub_cap) a.pf_list[(long long)sub * a.pf_sub_cap + slot] = an;
-        }
-      }
-    }
+    if (a.pf_count) pf_sink<MT, NT>(a, acc, patch, g, n, a.post_cout);
     DW_STAMP(8);
     epilogue<MT, NT>(a2, rout, rres, 0, g, Pp.opix, acc);
     DW_STAMP(9);
@@ -842,6 +853,12 @@ void conv_pack_weights(const float* w, int Cout, int Cin_w, int k, const ConvCon
         }
 }
 
+// Whether conv_kernel can carry the NMS candidate pre-filter for a conv of this tiling (launch_pf: 80 classes = five channel
+// tiles in one wave, plain 1x1, not on the GEMM kernel)
+bool conv_pf_supported(const ConvConfig& cfg) {
+  return cfg.ntaps == 1 && cfg.MT == 5 && cfg.ncb == 1 && cfg.uniform && !cfg.post && !cfg.gemm && (cfg.NT == 1 || cfg.NT == 2);
+}
+
 template <int KS, int MT, int NT, bool U, bool POST, bool O8 = false>
 static int launch_p(const ConvConfig& cfg, const ConvArgs& a, hipStream_t s) {
   if constexpr (!O8 && !POST && (MT == 2 || MT == 4 || MT == 6 || MT == 8)) {
@@ -850,6 +867,23 @@ static int launch_p(const ConvConfig& cfg, const ConvArgs& a, hipStream_t s) {
   if (a.out8 && !O8) return fail(-3, "conv: an e4m3 copy of the output needs 2, 4 or 6 channel tiles per wave and no fused follow-up conv");
   auto kern = conv_kernel<KS, MT, NT, U, POST, false, O8>;
   static size_t attr = 0;  // per instantiation: largest dynamic LDS size enabled so far
+  if (cfg.lds_bytes > attr) {
+    YL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)LDS_MAX));
+    attr = LDS_MAX;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.nblocks), dim3(256), cfg.lds_bytes, s, a);
+  YL_HIP(hipGetLastError());
+  return 0;
+}
+
+// a 1x1 conv that writes a Detect level's class logits and feeds the NMS candidate pre-filter (conv_pf_supported)
+template <int MT, int NT>
+static int launch_pf(const ConvConfig& cfg, const ConvArgs& a, hipStream_t s) {
+  if (!conv_pf_supported(cfg) || a.in2 || a.out8 || a.wpk2 || a.act || a.out_f32)
+    return fail(-3, "conv: the pre-filter sink needs a plain 1x1 conv without activation, all output channels in one wave");
+  auto kern = conv_kernel<1, MT, NT, true, false, false, false, true>;
+  static size_t attr = 0;
   if (cfg.lds_bytes > attr) {
     YL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                (int)LDS_MAX));
@@ -912,7 +946,11 @@ static int launch_m(const ConvConfig& cfg, const ConvArgs& a, hipStream_t s) {
     case 2: return launch_n<KS, 2>(cfg, a, s);
     case 3: return launch_n<KS, 3>(cfg, a, s);
     case 4: return launch_n<KS, 4>(cfg, a, s);
-    case 5: return cfg.NT == 1 ? launch_u<KS, 5, 1>(cfg, a, s) : launch_u<KS, 5, 2>(cfg, a, s);
+    case 5:
+      if constexpr (KS == 1) {
+        if (a.pf_count) return cfg.NT == 1 ? launch_pf<5, 1>(cfg, a, s) : launch_pf<5, 2>(cfg, a, s);
+      }
+      return cfg.NT == 1 ? launch_u<KS, 5, 1>(cfg, a, s) : launch_u<KS, 5, 2>(cfg, a, s);
     case 8:
       if (cfg.uniform && !cfg.post && cfg.NT == 2) return launch_t<KS, 8, 2, true>(cfg, a, s);
       break;

@@ -819,8 +819,15 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
   // ---- which launches produce the class logits of the Detect levels (the NMS candidate pre-filter rides in their epilogue)
   {
     size_t found = 0;
+    static const int conv_pf = getenv("YL_FUSE_PREFILTER_CONV") ? atoi(getenv("YL_FUSE_PREFILTER_CONV")) : 1;
     for (OpRec& r : e->ops) {
-      if (r.op.kind != YL_OP_DWCONV3 || !r.d_wpk || !r.d_wpk3 || r.op.lane != 0 || r.op.out.coff != 0) continue;
+      // the fused depthwise + pointwise + 1x1 launch of the class branch (YOLO11n), or -- where the branch is too wide for it --
+      // the plain 1x1 conv that ends it (conv_kernel's PF instantiation)
+      const bool tail = r.op.kind == YL_OP_DWCONV3 && r.d_wpk && r.d_wpk3;
+      const bool last = conv_pf && r.op.kind == YL_OP_CONV && r.op.k == 1 && r.op.stride == 1 && !r.op.act && !r.f8 && !r.d_w0 && !r.d_wpk2 &&
+                        r.op.res.offset < 0 && r.op.in2.offset < 0 && r.op.out8.offset < 0 && r.op.in.dtype == YL_BF16 &&
+                        r.op.out.dtype == YL_BF16 && conv_pf_supported(r.cfg);  // (1x1 convs never join a group launch)
+      if (!(tail || last) || r.op.lane != 0 || r.op.out.coff != 0) continue;
       for (size_t li = 0; li < e->levels.size(); ++li) {
         const yl_level& L = e->levels[li];
         if (r.op.out.offset == L.offset_cls && r.op.out.C == L.nc8 && r.op.out.H == L.H && r.op.out.W == L.W) {
@@ -1124,6 +1131,15 @@ static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s, c
         return conv_f8_launch(r.cfg, a, B, s);
       }
       build_conv_args(e, r, ws, a);
+      if (sink && r.cls_level >= 0) {  // a plain 1x1 launch that writes a level's class logits: pre-filter them on the way out
+        int a0 = 0;
+        for (int li = 0; li < r.cls_level; ++li) a0 += e->levels[li].H * e->levels[li].W;
+        a.pf_count = sink->pre_count;
+        a.pf_list = sink->pre_list;
+        a.pf_sub_cap = sink->sub_cap;
+        a.pf_logit_lo = sink->logit_lo;
+        a.pf_anchor0 = a0;
+      }
       return conv_launch(r.cfg, a, B, s);
     }
     case YL_OP_QUANT: {

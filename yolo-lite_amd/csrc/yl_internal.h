@@ -438,6 +438,7 @@ __device__ __forceinline__ void level_load8(const PView& v, int c8, int pix, flo
 #pragma unroll
   for (int j = 0; j < 8; ++j) o[j] = (float)t[j];
 }
+bool conv_pf_supported(const ConvConfig& cfg);  // conv_mfma.hip: conv_kernel can feed the NMS pre-filter from this conv's epilogue
 int decode_launch(const DecodeLevel* lv, int n_levels, int batch, int nc, int A, float* y, hipStream_t s);
 // nms.hip: where the class branch's last launch appends the anchors whose best class logit could clear the threshold
 // (the first stage of yl_decode_nms, decode_candidates_sparse_kernel, done in the producing kernel's epilogue)
