@@ -336,3 +336,33 @@ def test_network_with_psa_tail_is_bit_identical(gpu_device, monkeypatch, h, w, b
         assert torch.equal(p, q)
     o2, c2 = ref.detect(x, 0.25, 0.7, graph=False)
     assert torch.equal(cnt, c2) and all(torch.equal(out[i, :n], o2[i, :n]) for i, n in enumerate(cnt.tolist()))
+
+
+def test_latency_and_throughput_profiles_agree_on_random_shapes(gpu_device):
+    """The two profiles of the program (nn/lower.py lower(one_batch=...): other launches, same arithmetic) on a dozen random
+    (map size, batch, head, threshold) cases: counts and detections bit for bit, eager against captured graph against its replay
+    (the fused stem clears the NMS candidate counters of every replay), level maps bit for bit between the profiles."""
+    import random
+
+    rng = random.Random(4)
+    specs, _ = arch.parse_model(arch.yolo11_dict("n"))
+    for it in range(12):
+        h, w, b = 32 * rng.randint(1, 20), 32 * rng.randint(1, 20), rng.choice([1, 2, 3, 8, 9, 16, 17])
+        b = max(1, min(b, 640 * 640 * 16 // (h * w)))
+        sd = synth_state_dict("n", 100 + it, cls_bias=[rng.choice([-6.0, -4.5, -3.5, -2.0])] * 3, cls_gain=rng.choice([4.0, 6.0]))
+        x = torch.randint(0, 256, (b, 3, h, w), generator=torch.Generator().manual_seed(it), dtype=torch.uint8).to(gpu_device)
+        conf = rng.choice([0.25, 0.1, 0.5])
+        res = []
+        for one_batch in (False, True):
+            eng = HipEngine.from_model(specs, sd, b, h, w, gpu_device, one_batch=one_batch)
+            o1, c1 = eng.detect(x, conf, 0.7, graph=False)
+            o1, c1 = o1.clone(), c1.clone()
+            eng.detect(x, conf, 0.7, graph=True)
+            o3, c3 = eng.detect(x, conf, 0.7, graph=True)
+            assert torch.equal(c1, c3), (it, h, w, b, one_batch)
+            assert all(torch.equal(o1[i, :n], o3[i, :n]) for i, n in enumerate(c1.tolist())), (it, h, w, b, one_batch)
+            res.append((o1, c1, [t.clone() for t in eng.raw_levels()]))
+            del eng
+        assert torch.equal(res[0][1], res[1][1]), (it, h, w, b)
+        assert all(torch.equal(res[0][0][i, :n], res[1][0][i, :n]) for i, n in enumerate(res[0][1].tolist())), (it, h, w, b)
+        assert all(torch.equal(p, q) for p, q in zip(res[0][2], res[1][2])), (it, h, w, b)
