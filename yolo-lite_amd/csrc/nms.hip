@@ -944,6 +944,67 @@ __global__ __launch_bounds__(256) void decode_exact_kernel(DecCandArgs a, NmsWs 
 // 12 us -- a 32-workgroup launch is a chain of memory round trips whatever its arithmetic costs (four lanes per anchor
 // instead of one thread: 36 -> 30 us).  Same latency, three launches fewer (63 -> 60 per step), +0.5 % images/s with 20
 // batches in flight; the <= 25 us the round-2 review asked for is NOT reached.
+// Greedy suppression WITHOUT the mask: one workgroup of 16 waves walks the image's sorted candidates; a candidate that is still
+// alive is kept, its row -- IoU against every later candidate, 64 per wave and step -- is evaluated right then and OR-ed into
+// the `gone` bitmap (LDS, one word per 64 candidates, each word owned by one wave), the next alive candidate is looked up.
+// Only the rows of KEPT candidates are ever needed (at most max_det of them): max_det x n pairs instead of n^2 / 2 -- for the
+// dense images the one-launch kernel's general path exists for (thousands of candidates, 300 kept) an order of magnitude less
+// work than mask + scan, and it stops at max_det.  Same IoU test, same order: the kept set and the output are those of
+// nms_mask_body + nms_scan_body.  Two barriers per kept candidate.
+template <class BoxPtr>
+__device__ __forceinline__ void nms_greedy_body(float iou_thres, int max_det, const float* __restrict__ scale, float* out,
+                                                int32_t* out_count, const ScanSrc& src, BoxPtr bo, unsigned long long* gone,
+                                                int& s_cur, int b, int tid) {
+  const int n = src.n, nwords = (n + 63) >> 6, lane = tid & 63, wave = tid >> 6;
+  float padx = 0.f, pady = 0.f, gain = 1.f, w0 = 0.f, h0 = 0.f;
+  if (scale) {
+    padx = scale[b * 5 + 0];
+    pady = scale[b * 5 + 1];
+    gain = scale[b * 5 + 2];
+    w0 = scale[b * 5 + 3];
+    h0 = scale[b * 5 + 4];
+  }
+  for (int wd = tid; wd < nwords; wd += 1024) gone[wd] = 0ull;
+  __syncthreads();
+  int total = 0, pos = 0;
+  while (true) {
+    if (wave == 0) {  // the next candidate nobody suppressed, from `pos` on (every lane computes the same)
+      int i = -1;
+      for (int wd = pos >> 6; wd < nwords && i < 0; ++wd) {
+        const int nv = n - wd * 64;
+        unsigned long long alive = ~gone[wd] & (nv >= 64 ? ~0ull : ((1ull << nv) - 1ull));
+        if (wd == (pos >> 6)) alive &= ~0ull << (pos & 63);
+        if (alive) i = wd * 64 + __builtin_ctzll(alive);
+      }
+      if (lane == 0) s_cur = i;
+    }
+    __syncthreads();
+    const int i = s_cur;
+    if (i < 0) break;
+    if (tid == 0) scan_emit(src, b, i, total, max_det, scale != nullptr, padx, pady, gain, w0, h0, out);
+    ++total;
+    if (total >= max_det) break;
+    const float4 bi = ld_box(bo, i);
+    const float area_i = __fmul_rn(__fsub_rn(bi.z, bi.x), __fsub_rn(bi.w, bi.y));
+    for (int wd = (i >> 6) + wave; wd < nwords; wd += 16) {
+      const int j = wd * 64 + lane;
+      float4 bj = bi;
+      float inter = 0.0f;
+      if (j < n && j > i) {
+        bj = ld_box(bo, j);
+        inter = iou_inter(bi, bj);
+      }
+      const bool meets = inter > 0.0f;
+      unsigned long long bits = 0ull;
+      if (__ballot(meets)) bits = __ballot(meets && iou_gt_of(inter, area_i, bj, iou_thres));
+      if (lane == 0 && bits) gone[wd] |= bits;
+    }
+    pos = i + 1;
+    __syncthreads();
+  }
+  if (tid == 0) out_count[b] = total;
+}
+
 #define NMS_STAMP(id) YL_STAMP(stamps, 16, wave, lane, id)
 
 // Up to this many pre-filtered anchors per image the one-launch kernel keeps every intermediate of the image in LDS.
@@ -1081,23 +1142,22 @@ __global__ __launch_bounds__(1024) void decode_nms_fused_kernel(DecCandArgs a, N
   NMS_STAMP(3);
   if (stop_after == 2) return;
   __syncthreads();
-  // the mask phase is a serial chain of n / 16 rows per wave: with the boxes in LDS (the sort's key array is free now, 4096
-  // boxes fit) a row costs LDS latency, not a memory round trip; the mask rows go to the workspace (stores: nobody waits)
-  const int n = w.nfinal[b];
-  unsigned long long* mk = w.mask + (long long)b * w.M * w.MW;
-  const int mw = w.MW;
-  if (n <= SORT_LDS_KEYS / 2) {
-    float4* lbox = reinterpret_cast<float4*>(sk);
-    for (int i = tid; i < n; i += 1024) lbox[i] = w.box_off[(long long)b * w.M + i];
-    __syncthreads();
-    nms_mask_body(iou_thres, n, (lds_f4_ptr)(void*)lbox, mk, mw, wave, 16, lane);
+  // mask + scan would evaluate n^2 / 2 pairs on this one CU (10 ms for 6 000 candidates); only the kept candidates' rows are
+  // needed: nms_greedy_body.  The `gone` bitmap (one bit per candidate) and, up to 3 840 of them, the boxes sit in LDS (the sort's
+  // key array is free now); more boxes are read from the workspace.
+  const ScanSrc src = scan_src_of(w, b);
+  unsigned long long* gone = sk;                            // [512] words = 32 768 candidates
+  static_assert(64 * 64 * SCAN_T <= 512 * 64, "one bit per candidate");
+  constexpr int LDS_BOXES = (SORT_LDS_KEYS - 512) / 2;
+  if (src.n <= LDS_BOXES) {
+    float4* lbox = reinterpret_cast<float4*>(sk + 512);
+    for (int i = tid; i < src.n; i += 1024) lbox[i] = w.box_off[(long long)b * w.M + i];
+    nms_greedy_body(iou_thres, max_det, scale, out, out_count, src, (lds_f4_ptr)(void*)lbox, gone, s_nvalid, b, tid);
   } else {
-    nms_mask_body(iou_thres, n, (const float4*)(w.box_off + (long long)b * w.M), mk, mw, wave, 16, lane);
+    nms_greedy_body(iou_thres, max_det, scale, out, out_count, src, (const float4*)(w.box_off + (long long)b * w.M), gone, s_nvalid, b,
+                    tid);
   }
   NMS_STAMP(4);
-  if (stop_after == 3) return;
-  __syncthreads();
-  if (wave == 0) nms_scan_body(max_det, scale, out, out_count, scan_src_of(w, b), b, lane, mk, mw);
   NMS_STAMP(5);
 }
 }  // namespace yl
