@@ -65,7 +65,8 @@ class LoadTensor(_SingleBatch):
 
     def __init__(self, im0) -> None:
         t = self.checked(im0)
-        self._accept(t, _names(t))
+        # (a tensor's images carry no file names: image<i>.jpg each -- without walking the tensor, which unbinds it into B views)
+        self._accept(t, [f"image{i}.jpg" for i in range(t.shape[0])])
 
     @classmethod
     def checked(cls, t: torch.Tensor) -> torch.Tensor:

@@ -358,11 +358,12 @@ class DetectionPredictor:
     def _emit(self, paths, im0s, s, im, profilers, t_pre):
         """Per-image bookkeeping of one finished batch (speed, sinks, log line); returns its Results."""
         n = len(im0s)
-        for i in range(n):
-            self.seen += 1
-            self.results[i].speed = {"preprocess": t_pre * 1e3 / n, "inference": profilers[1].dt * 1e3 / n,
-                                     "postprocess": profilers[2].dt * 1e3 / n}
-            if self.args.verbose or self.args.save_txt or self.args.save or self.args.save_crop:
+        speed = {"preprocess": t_pre * 1e3 / n, "inference": profilers[1].dt * 1e3 / n, "postprocess": profilers[2].dt * 1e3 / n}
+        sinks = self.args.verbose or self.args.save_txt or self.args.save or self.args.save_crop
+        self.seen += n
+        for i, r in enumerate(self.results[:n]):
+            r.speed = dict(speed)  # (one dict per Results, as in the reference: callers may annotate theirs)
+            if sinks:
                 s[i] += self.write_results(i, Path(paths[i]), im, s)
         if self.args.verbose:
             LOGGER.info("\n".join(s))
