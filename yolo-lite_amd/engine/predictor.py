@@ -175,7 +175,7 @@ class DetectionPredictor:
             # (one batch per call: the counts land in pinned host memory straight from the last kernel -- the harvest
             # synchronises the stream and reads them, no device-to-host copy; YL_PREDICT_HOST_COUNTS=0: the .tolist() of a
             # device tensor instead)
-            host_counts = graph and stream is None and os.environ.get("YL_PREDICT_HOST_COUNTS", "1") != "0"
+            host_counts = graph and os.environ.get("YL_PREDICT_HOST_COUNTS", "1") != "0"
             kw = dict(max_det=self.args.max_det, classes=self.args.classes, agnostic=self.args.agnostic_nms, scale=scale,
                       graph=graph, slot=slot, count_host=host_counts, scale_static=True)
             try:
@@ -191,8 +191,10 @@ class DetectionPredictor:
             # ordered behind this batch on its stream
             if not graph:
                 return out, cnt
-            if host_counts:
+            if host_counts and stream is None:
                 return out, cnt  # (cloned by the harvest, behind the synchronisation: not on the path the caller waits for)
+            if host_counts:
+                return out.clone(), cnt  # (pipelined: the slot's pinned counts are read once the batch's event has fired)
             if stream is None:
                 return out.clone(), cnt
             # the per-image counts travel to PINNED host memory on the batch's own stream: the harvest then waits for the
