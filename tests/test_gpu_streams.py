@@ -148,3 +148,29 @@ def test_prepared_graphs_survive_eager_work_of_another_engine(gpu_device):
             for i in range(2):
                 n = int(rc[i])
                 assert torch.equal(outs[j][0][i, :n], ro[i, :n]), (rnd, j, i)
+
+
+@pytest.mark.parametrize("batch", [2, 17])
+def test_counts_in_pinned_host_memory_equal_the_device_counts(gpu_device, batch):
+    """detect(count_host=True): the last kernel of the graph writes the per-image counts straight into pinned host memory (what
+    YOLOLite.predict reads after its one synchronisation) -- equal to the device counts of the plain call, over replays with new
+    inputs, with the cached scale table of the predictor (scale_static); batch 17 takes the one-launch NMS, batch 2 the four launches."""
+    from yololite_amd.nn import arch
+    from yololite_amd.nn.engine import HipEngine
+    from yololite_amd.nn.synth import synth_state_dict
+
+    specs, _ = arch.parse_model(arch.yolo11_dict("n"))
+    sd = synth_state_dict("n", 5, cls_bias=[-3.0, -3.0, -3.0], cls_gain=6.0)
+    eng = HipEngine.from_model(specs, sd, batch, 96, 160, gpu_device)
+    g = torch.Generator().manual_seed(batch)
+    scale = torch.tensor([[0.0, 0.0, 1.0, 160.0, 96.0]] * batch, dtype=torch.float32, device=gpu_device)
+    x = torch.randint(0, 256, (batch, 3, 96, 160), generator=g, dtype=torch.uint8).to(gpu_device)
+    for rnd in range(3):
+        x.copy_(torch.randint(0, 256, (batch, 3, 96, 160), generator=g, dtype=torch.uint8))
+        o_ref, c_ref = eng.detect(x, 0.25, 0.7, scale=scale, graph=False)
+        o_ref, c_ref = o_ref.clone(), c_ref.cpu()
+        out, cnt = eng.detect(x, 0.25, 0.7, scale=scale, graph=True, stage="rebind", count_host=True, scale_static=True)
+        assert not cnt.is_cuda and cnt.is_pinned()
+        torch.cuda.current_stream(gpu_device).synchronize()
+        assert torch.equal(cnt, c_ref), rnd
+        assert all(torch.equal(out[i, :n], o_ref[i, :n]) for i, n in enumerate(c_ref.tolist())) and int(c_ref.sum()) > 0
