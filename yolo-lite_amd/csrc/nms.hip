@@ -934,16 +934,18 @@ __global__ __launch_bounds__(256) void decode_exact_kernel(DecCandArgs a, NmsWs 
   decode_exact_body(a, w, blockIdx.z, blockIdx.y, blockIdx.x * 4 + (threadIdx.x >> 6), DX_BLOCKS * 4, threadIdx.x & 63);
 }
 
-// ---- the hot path's post-processing in ONE launch: one workgroup (16 wavefronts) per image runs the exact decode of the
-// pre-filtered anchors, the sort + gather, the suppression mask and the greedy scan + scale_boxes one after the other --
-// the very device functions of the four kernels above, so the results are bit-identical -- with workgroup barriers where
-// the four-launch form has kernel boundaries.  The intermediates (keys, boxes, mask rows: a few KB per image) stay in the
-// NMS workspace, i.e. in L2 (boxes and, up to 512 rows, the mask in LDS); a workgroup only ever reads what it wrote itself.
-// Measured (YOLO11n batch 32, ~130 candidates per image, in-sequence HIP events incl. ~5 us of event overhead per row): 58 us
-// for the one launch against 17 + 14 + 7 + 18 = 56 us for the four; phases (YL_NMS_DBG): decode 30, sort 9, mask 9, scan
-// 12 us -- a 32-workgroup launch is a chain of memory round trips whatever its arithmetic costs (four lanes per anchor
-// instead of one thread: 36 -> 30 us).  Same latency, three launches fewer (63 -> 60 per step), +0.5 % images/s with 20
-// batches in flight; the <= 25 us the round-2 review asked for is NOT reached.
+// ---- the hot path's post-processing in ONE launch (decode_nms_fused_kernel, below): one workgroup (16 wavefronts) per image
+// runs the exact decode of the pre-filtered anchors, the sort + gather, the suppression and the greedy scan + scale_boxes one after
+// the other -- the device functions of the four kernels above, so the results are bit-identical -- with workgroup barriers where the
+// four-launch form has kernel boundaries.  Three regimes by the image's candidate count:
+//   <= 512   everything in LDS (keys, classes, boxes, sorted rows, mask): nothing but the pre-filter's lists and the level maps is
+//            read, nothing but the detections written.  YOLO11n batch 32, ~126 candidates per image: 32 us kernel span (round 3's
+//            form, every hand-over through the NMS workspace: 41.7 us; the four launches 56 us in sequence).  Phases by in-kernel
+//            stamps (tools/nms_stamps.py): decode 9-11 (three dependent round trips: counts -> list -> level maps), sort 3.3,
+//            mask 6.5, scan 3.2.
+//   <= 1536  intermediates through the workspace, boxes in LDS, full mask + scan.
+//   above    the greedy loop over the kept candidates' rows only (nms_greedy_body): ~6 000 candidates, 300 kept per image: 3.15 ms
+//            per batch of 32 (the full mask on one CU: 13.1 ms; the four launches: 3.66 ms).
 // Greedy suppression WITHOUT the mask: one workgroup of 16 waves walks the image's sorted candidates; a candidate that is still
 // alive is kept, its row -- IoU against every later candidate, 64 per wave and step -- is evaluated right then and OR-ed into
 // the `gone` bitmap (LDS, one word per 64 candidates, each word owned by one wave), the next alive candidate is looked up.
