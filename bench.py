@@ -638,7 +638,20 @@ def main():
         def compute(im, slot, lane):
             return eng.detect_record(im, conf, iou, max_det=max_det, slot=slot, rec_key=lane)
 
+        # transport of the two exchanges: torch.distributed's "nccl" backend (default) or the yl_comm_* group of the C ABI
+        # (YL_BENCH_COMM=native: grouped RCCL send / recv issued by libyl_amd.so on two exchange streams of its own)
+        native_comm = None
+        if os.environ.get("YL_BENCH_COMM", "torch") == "native":
+            from yololite_amd.dist import NativeComm, NativeShardedRunner
+
+            native_comm = NativeComm(rank, world, NativeComm.id_via_torch(), device=dev)
+        extra["transport"] = ("yl_comm_* (include/yl_amd.h): RCCL send / recv issued by libyl_amd.so" if native_comm is not None
+                              else "torch.distributed, backend nccl (= RCCL)")
+
         def make_runner(n):
+            if native_comm is not None:
+                return NativeShardedRunner(native_comm, compute, B, (3, H, W), torch.uint8, dev, record_floats(B, max_det), slots=n,
+                                           streams=streams[:n])
             return ShardedRunner(compute, B, (3, H, W), torch.uint8, dev, record_floats(B, max_det), slots=n, streams=streams[:n])
 
         if len(cands) > 1:  # untimed trial of the stream counts; every rank takes the same decision (MAX over ranks)

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define YL_ABI_VERSION 19
+#define YL_ABI_VERSION 20
 
 /* element types */
 enum { YL_BF16 = 0, YL_F32 = 1, YL_F16 = 2, YL_U8 = 3, YL_FP8 = 4 /* OCP e4m3 */ };
@@ -326,6 +326,34 @@ int yl_preprocess_u8(const uint8_t* bgr_hwc, int batch, int h, int w, float* out
 int yl_letterbox_u8(const uint8_t* src_bgr_hwc, int src_h, int src_w, int src_pitch, uint8_t* dst_chw, int H,
                     int W, int top, int left, int new_h, int new_w, const int32_t* xtab, const int32_t* ytab,
                     void* stream);
+
+/* ---- multi-GPU exchange of the sharded path (BASELINE.json config 4) ---------------------------------
+ * One process per GPU, weights replicated, images sharded; the ONLY exchanges are root -> ranks input slices and ranks ->
+ * root packed result records (`b * max_det * 6` fp32 box words + `b` int32 counts per rank and step).  RCCL over xGMI, grouped
+ * send / recv (the root's sends leave on all its links at once); no reduction anywhere.  Replaces nothing in the reference:
+ * it has no distributed inference (utils/torch_utils.py:142-159 select_device ends on cuda:0 for predict; the per-image
+ * independence the sharding rests on is utils/ops.py:219, the loop over images in non_max_suppression).  RCCL is loaded on the
+ * first yl_comm_* call (librccl.so.1; YL_RCCL_LIB overrides the path); without it these calls fail, nothing else does.
+ * A communicator belongs to the HIP device that was current in yl_comm_create; calls on one communicator must be issued in
+ * the same order on every rank (RCCL's rule) and are not thread-safe.  `stream` is a hipStream_t: the exchange is enqueued
+ * there and ordered with the engine launches on that stream like any kernel. */
+#define YL_COMM_ID_BYTES 128
+typedef struct yl_comm yl_comm;
+/* One rank (any) creates the 128-byte id and hands it to the others by its own means (a file, a socket, MPI, a
+ * torch.distributed store): the rendezvous itself is the binder's business. */
+int yl_comm_get_unique_id(void* id_out);
+int yl_comm_create(const void* id, int rank, int world, yl_comm** out);
+void yl_comm_destroy(yl_comm* c);
+int yl_comm_rank(const yl_comm* c);
+int yl_comm_world(const yl_comm* c);
+/* root: `send` = world slices of `bytes` (device memory, rank order); every rank receives its slice into `recv` (the root by
+ * a device copy; recv may alias the root's own slice).  `send` is ignored on the other ranks. */
+int yl_comm_scatter(yl_comm* c, const void* send, void* recv, int64_t bytes, int root, void* stream);
+/* every rank sends `bytes` from `send`; the root receives world slices into `recv`, rank order.  `recv` is ignored elsewhere. */
+int yl_comm_gather(yl_comm* c, const void* send, void* recv, int64_t bytes, int root, void* stream);
+/* Everything enqueued on `stream` before the call has completed on EVERY rank when it returns (a one-word gather to rank 0
+ * and a one-word scatter back, then a host wait on the stream): the bracket of a timed region. */
+int yl_comm_barrier(yl_comm* c, void* stream);
 
 #ifdef __cplusplus
 }

@@ -27,7 +27,7 @@ def test_header_symbols_exported():
         assert hasattr(L, n), f"{n} declared in include/yl_amd_diag.h but not exported"
     assert set(diag) == set(_lib.DIAG_EXPORTS), "diagnostic binding list and header drifted apart"
     assert not set(diag) & set(names), "a diagnostic entry point leaked into the product header"
-    assert L.yl_abi_version() == 19
+    assert L.yl_abi_version() == 20
 
 
 def test_struct_layouts_match_header():
@@ -53,6 +53,30 @@ def test_no_gpu_calls_fail_loudly():
         YOLOLite("yolo11n.yaml").predict(torch.rand(1, 3, 64, 64), device="cpu", save=False, verbose=False)
     with pytest.raises(RuntimeError):
         ops.non_max_suppression(torch.rand(1, 84, 100), 0.25, 0.7)
+
+
+def test_comm_group_fails_loudly_without_gpu():
+    """yl_comm_*: the sharded path's exchanges have no CPU transport; without a HIP device communicator creation reports it."""
+    import torch
+
+    if torch.cuda.is_available():
+        import pytest
+
+        pytest.skip("GPU present")
+    from yololite_amd import _lib
+
+    L = _lib.lib()
+    ident = ctypes.create_string_buffer(_lib.COMM_ID_BYTES)
+    h = ctypes.c_void_p()
+    rc = L.yl_comm_get_unique_id(ident)
+    if rc == 0:
+        rc = L.yl_comm_create(ident, 0, 1, ctypes.byref(h))
+    assert rc < 0 and not h.value
+    assert L.yl_last_error()  # a message, not a silent code
+    assert L.yl_comm_rank(None) == -1 and L.yl_comm_world(None) == -1
+    assert L.yl_comm_scatter(None, None, None, 16, 0, None) < 0
+    assert L.yl_comm_gather(None, None, None, 16, 0, None) < 0
+    assert L.yl_comm_barrier(None, None) < 0
 
 
 def test_product_never_imports_oracle():

@@ -75,3 +75,72 @@ def test_scatter_detect_gather_equals_plain_detect(gpu_device, golden, nccl_worl
         seen.append(k)
     assert len(set(seen)) == 2  # the two runs ended on different batches
     assert len(runner.bufs) == 2 * slots  # two input buffers (and records, and graphs) per slot
+
+
+def test_native_comm_world1_scatter_gather_barrier(gpu_device, tmp_path):
+    """The yl_comm_* group of the C ABI with a world of one: real RCCL calls (communicator, grouped send / recv, the
+    one-word barrier), the root's own slice by a device copy, every exchange on a stream the caller names."""
+    from yololite_amd.dist import NativeComm
+
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(gpu_device)
+    comm = NativeComm(0, 1, NativeComm.id_via_file(str(tmp_path / "id")), device=gpu_device)
+    assert (comm.rank, comm.world) == (0, 1)
+    st = torch.cuda.Stream(device=gpu_device)
+    g = torch.randint(0, 256, (4, 3, 32, 32), dtype=torch.uint8, device=gpu_device)
+    local = torch.zeros_like(g)
+    into = torch.zeros((1, 7), dtype=torch.float32, device=gpu_device)
+    rec = torch.arange(7, dtype=torch.float32, device=gpu_device)
+    torch.cuda.synchronize()
+    comm.scatter(g, local, stream=st)
+    comm.gather(rec, into, stream=st)
+    comm.barrier(stream=st)  # returns with everything on `st` finished
+    assert torch.equal(local, g) and torch.equal(into[0], rec)
+    with pytest.raises(ValueError):
+        comm.scatter(g[:, :, :, :16], local, stream=st)  # root must pass the full contiguous batch
+    with pytest.raises(ValueError):
+        comm.gather(rec, torch.zeros(3, device=gpu_device), stream=st)
+    comm.close()
+    comm.close()  # idempotent
+
+
+@pytest.mark.parametrize("slots,steps", [(2, 5), (5, 12)])
+def test_native_runner_equals_plain_detect(gpu_device, golden, tmp_path, slots, steps):
+    """NativeShardedRunner (exchanges enqueued by libyl_amd.so on their own HIP streams) against plain detect, bit for bit:
+    the same check the torch.distributed runner passes above."""
+    from yololite_amd.dist import NativeComm, NativeShardedRunner, record_floats, unpack_record
+
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(gpu_device)
+    B, H, W, max_det = 2, 96, 128, 300
+    sd = synth_state_dict("n", 1, cls_bias=list(golden["net_n_96x128_bias"]), cls_gain=8.0)
+    specs, _ = arch.parse_model(arch.yolo11_dict("n"))
+    eng = HipEngine.from_model(specs, sd, B, H, W, gpu_device)
+    g = torch.Generator().manual_seed(5)
+    x0 = (torch.from_numpy(golden["net_n_96x128_x"]) * 255).to(torch.uint8)
+    batches = [x0.to(gpu_device)] + [torch.randint(0, 256, (B, 3, H, W), generator=g, dtype=torch.uint8).to(gpu_device)
+                                     for _ in range(2)]
+    ref = []
+    for xb in batches:
+        o, c = eng.detect(xb, 0.25, 0.7, max_det=max_det, graph=False)
+        ref.append((o.clone(), c.clone()))
+    torch.cuda.synchronize()
+    comm = NativeComm(0, 1, NativeComm.id_via_file(str(tmp_path / "id")), device=gpu_device)
+    streams = [torch.cuda.Stream(device=gpu_device) for _ in range(slots)]
+
+    def compute(im, slot, lane):
+        return eng.detect_record(im, 0.25, 0.7, max_det=max_det, slot=slot, rec_key=lane)
+
+    runner = NativeShardedRunner(comm, compute, B, (3, H, W), torch.uint8, gpu_device, record_floats(B, max_det), slots=slots,
+                                 streams=streams)
+    for n in (steps, steps + 1):
+        last = runner.run(batches, n)
+        comm.barrier(stream=streams[(n - 1) % slots])
+        torch.cuda.synchronize()
+        outs, cnts = unpack_record(last, B, max_det)
+        k = (n - 1) % len(batches)
+        assert len(outs) == 1 and torch.equal(cnts[0], ref[k][1])
+        for i in range(B):
+            m = int(ref[k][1][i])
+            assert torch.equal(outs[0][i, :m], ref[k][0][i, :m])
+    comm.close()

@@ -112,7 +112,10 @@ EXPORTS = (  # include/yl_amd.h: the product ABI
     "yl_engine_op_info", "yl_engine_detect_graph", "yl_detect_decode", "yl_nms_workspace_bytes", "yl_nms", "yl_decode_nms",
     "yl_preprocess_u8", "yl_letterbox_u8", "yl_nms_ml_workspace_bytes", "yl_nms_ml", "yl_engine_profile_detect",
     "yl_engine_prefilter_fused", "yl_engine_detect_graph_prepare", "yl_graph_launch_many", "yl_engine_detect_graph_rebind",
+    "yl_comm_get_unique_id", "yl_comm_create", "yl_comm_destroy", "yl_comm_rank", "yl_comm_world", "yl_comm_scatter",
+    "yl_comm_gather", "yl_comm_barrier",
 )
+COMM_ID_BYTES = 128  # YL_COMM_ID_BYTES
 DIAG_EXPORTS = (  # include/yl_amd_diag.h: probes for tools/ and the runtime self-checks, not part of the product ABI
     "yl_graph_branch_probe", "yl_stream_create_masked", "yl_stream_destroy", "yl_xcc_census", "yl_diag_set_stamps",
 )
@@ -240,7 +243,23 @@ def lib() -> C.CDLL:
     L.yl_diag_set_stamps.argtypes = [vp]
     L.yl_engine_prefilter_fused.restype = i32
     L.yl_engine_prefilter_fused.argtypes = [vp, f32]
-    if L.yl_abi_version() != 19:
+    L.yl_comm_get_unique_id.restype = i32
+    L.yl_comm_get_unique_id.argtypes = [vp]
+    L.yl_comm_create.restype = i32
+    L.yl_comm_create.argtypes = [vp, i32, i32, C.POINTER(vp)]
+    L.yl_comm_destroy.restype = None
+    L.yl_comm_destroy.argtypes = [vp]
+    for name in ("yl_comm_rank", "yl_comm_world"):
+        f = getattr(L, name)
+        f.restype = i32
+        f.argtypes = [vp]
+    for name in ("yl_comm_scatter", "yl_comm_gather"):
+        f = getattr(L, name)
+        f.restype = i32
+        f.argtypes = [vp, vp, vp, i64, i32, vp]
+    L.yl_comm_barrier.restype = i32
+    L.yl_comm_barrier.argtypes = [vp, vp]
+    if L.yl_abi_version() != 20:
         raise RuntimeError("libyl_amd.so ABI version mismatch; rebuild it")
     _lib = L
     return L

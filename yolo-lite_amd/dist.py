@@ -10,6 +10,10 @@ xGMI is point-to-point: the root's scatter uses its 7 links concurrently, so its
 153 GB/s (uint8 32x3x640x640 = 39 MB -> ~0.26 ms) and is hidden behind the compute of the batches already in
 flight by issuing it ``slots`` steps ahead (``ShardedRunner.run``).
 
+Two transports carry those exchanges: ``torch.distributed`` (the default of ``ShardedRunner``; "nccl" = RCCL on the GPU
+box, "gloo" in the CPU tests) and ``NativeComm`` -- the ``yl_comm_*`` group of the C ABI (include/yl_amd.h), RCCL send / recv
+enqueued on the caller's HIP stream with no torch type in sight, which is what a non-Python binder of libyl_amd.so uses.
+
 Result records: one step of one rank returns ONE packed tensor of ``record_floats(b, max_det)`` fp32 words --
 ``b * max_det * 6`` box words ``[x1, y1, x2, y2, conf, cls]`` followed by the ``b`` per-image counts stored as
 int32 bit patterns -- so a step costs one gather, not two (``pack_views`` / ``unpack_record``).
@@ -96,6 +100,181 @@ def run_resident(compute: Callable[[torch.Tensor], Tuple[torch.Tensor, torch.Ten
     if finish is not None:
         finish()
     return gather_results(out, cnt, dst)
+
+
+class NativeComm:
+    """The ``yl_comm_*`` group of libyl_amd.so (include/yl_amd.h): scatter / gather / barrier as grouped RCCL send / recv on a
+    HIP stream the caller names.  No CPU transport: construction fails without RCCL or a GPU.
+
+    ``exchange(payload)`` hands rank 0's 128-byte id to every rank: it is called with the id on rank 0 and with None
+    elsewhere and returns the id everywhere -- ``id_via_torch`` (any initialised ``torch.distributed`` group, gloo will do)
+    and ``id_via_file`` are the two stock ways; a C binder would use its own rendezvous."""
+
+    def __init__(self, rank: int, world: int, exchange: Callable[[Optional[bytes]], bytes], device: Optional[torch.device] = None):
+        import ctypes as C
+
+        from . import _lib
+
+        self._L = _lib.lib()
+        self._h = None
+        self.rank, self.world = int(rank), int(world)
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        ident = None
+        if self.rank == 0:
+            buf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+            _lib.check(self._L.yl_comm_get_unique_id(buf), "yl_comm_get_unique_id")
+            ident = buf.raw
+        ident = exchange(ident)
+        if not isinstance(ident, (bytes, bytearray)) or len(ident) != _lib.COMM_ID_BYTES:
+            raise ValueError("the id exchange must return rank 0's 128-byte id on every rank")
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _lib.check(self._L.yl_comm_create(C.create_string_buffer(bytes(ident), _lib.COMM_ID_BYTES), self.rank, self.world,
+                                              C.byref(h)), "yl_comm_create")
+        self._h = h
+
+    @staticmethod
+    def id_via_torch(group=None, src: int = 0) -> Callable[[Optional[bytes]], bytes]:
+        def exchange(ident):
+            box = [ident]
+            dist.broadcast_object_list(box, src=src, group=group)
+            return box[0]
+
+        return exchange
+
+    @staticmethod
+    def id_via_file(path: str, timeout_s: float = 120.0) -> Callable[[Optional[bytes]], bytes]:
+        def exchange(ident):
+            import os
+            import time
+
+            if ident is not None:
+                tmp = f"{path}.tmp{os.getpid()}"
+                with open(tmp, "wb") as f:
+                    f.write(ident)
+                os.replace(tmp, path)  # readers never see a partial id
+                return ident
+            t0 = time.monotonic()
+            while not os.path.exists(path):
+                if time.monotonic() - t0 > timeout_s:
+                    raise TimeoutError(f"no communicator id at {path} after {timeout_s} s")
+                time.sleep(0.01)
+            with open(path, "rb") as f:
+                return f.read()
+
+        return exchange
+
+    def _stream(self, stream) -> int:
+        return (stream if stream is not None else torch.cuda.current_stream(self.device)).cuda_stream
+
+    def scatter(self, global_batch: Optional[torch.Tensor], local: torch.Tensor, src: int = 0, stream=None) -> None:
+        """Root: ``global_batch`` = (world * b, ...) contiguous; every rank receives its (b, ...) slice into ``local``."""
+        from . import _lib
+
+        if not local.is_contiguous():
+            raise ValueError("scatter target must be contiguous")
+        nbytes = local.numel() * local.element_size()
+        send = 0
+        if self.rank == src:
+            if (global_batch is None or not global_batch.is_contiguous() or global_batch.dtype != local.dtype
+                    or global_batch.numel() != self.world * local.numel()):
+                raise ValueError("root must pass the full contiguous batch")
+            send = global_batch.data_ptr()
+        _lib.check(self._L.yl_comm_scatter(self._h, send, local.data_ptr(), nbytes, src, self._stream(stream)), "yl_comm_scatter")
+
+    def gather(self, rec: torch.Tensor, into: Optional[torch.Tensor], dst: int = 0, stream=None) -> None:
+        """Every rank sends ``rec``; the root receives into ``into`` = (world, rec.numel()) contiguous, rank order."""
+        from . import _lib
+
+        if not rec.is_contiguous():
+            raise ValueError("gather source must be contiguous")
+        nbytes = rec.numel() * rec.element_size()
+        recv = 0
+        if self.rank == dst:
+            if into is None or not into.is_contiguous() or into.dtype != rec.dtype or into.numel() != self.world * rec.numel():
+                raise ValueError("root must pass a (world, record) contiguous tensor")
+            recv = into.data_ptr()
+        _lib.check(self._L.yl_comm_gather(self._h, rec.data_ptr(), recv, nbytes, dst, self._stream(stream)), "yl_comm_gather")
+
+    def barrier(self, stream=None) -> None:
+        from . import _lib
+
+        _lib.check(self._L.yl_comm_barrier(self._h, self._stream(stream)), "yl_comm_barrier")
+
+    def close(self) -> None:
+        if self._h:
+            self._L.yl_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class NativeShardedRunner:
+    """``ShardedRunner``'s schedule on the ``yl_comm_*`` transport: the same lanes (``depth`` input buffers and records per
+    slot, so a lane's exchanges are two of its slot's steps away from the compute that needs them), but scatter and gather
+    are enqueued by libyl_amd.so on HIP streams of their own -- ONE exchange stream per direction, ordered against the slot
+    streams with events -- instead of torch.distributed's internal stream.  Records land in ONE (world, words) tensor per
+    lane on the root.  Same contract as ``ShardedRunner.run``."""
+
+    def __init__(self, comm: NativeComm, compute: Callable[[torch.Tensor, int, int], torch.Tensor], per_rank: int,
+                 shape: Tuple[int, int, int], dtype: torch.dtype, device: torch.device, record_words: int,
+                 slots: int = 2, src: int = 0, streams: Optional[Sequence] = None, depth: int = 2):
+        if streams is None or len(streams) != slots:
+            raise ValueError("one HIP stream per slot")
+        self.comm, self.compute, self.src = comm, compute, src
+        self.slots, self.lanes = slots, depth * slots
+        self.streams = list(streams)
+        self.rank, self.world = comm.rank, comm.world
+        self.device = device
+        self.bufs = [torch.empty((per_rank, *shape), dtype=dtype, device=device) for _ in range(self.lanes)]
+        self.gathered = [torch.empty((self.world, record_words), dtype=torch.float32, device=device)
+                         if self.rank == src else None for _ in range(self.lanes)]
+        self.s_scatter = torch.cuda.Stream(device=device)
+        self.s_gather = torch.cuda.Stream(device=device)
+
+    def run(self, batches: List[Optional[torch.Tensor]], steps: int) -> Optional[List[torch.Tensor]]:
+        nb, S, V = len(batches), self.slots, self.lanes
+        landed = [None] * V   # event: the scatter into lane v has completed
+        read = [None] * V     # event: the compute that read lane v's buffer (and wrote its record) has completed
+        sent = [None] * V     # event: the gather of lane v's record has completed
+        recs = [None] * V
+        for st in self.streams:  # an earlier run's readers of the lane buffers
+            self.s_scatter.wait_stream(st)
+
+        def scatter(k: int):
+            v = k % V
+            if read[v] is not None:
+                self.s_scatter.wait_event(read[v])  # the buffer's last reader
+            self.comm.scatter(batches[k % nb], self.bufs[v], self.src, stream=self.s_scatter)
+            landed[v] = self.s_scatter.record_event()
+
+        for k in range(min(V, steps)):
+            scatter(k)
+        last = None
+        for k in range(steps):
+            j, v = k % S, k % V
+            st = self.streams[j]
+            st.wait_event(landed[v])
+            if sent[v] is not None:  # the gather of step k - V still reads the record this step overwrites
+                st.wait_event(sent[v])
+            with torch.cuda.stream(st):
+                recs[v] = self.compute(self.bufs[v], j, v)
+            read[v] = st.record_event()
+            self.s_gather.wait_event(read[v])
+            self.comm.gather(recs[v], self.gathered[v], self.src, stream=self.s_gather)
+            sent[v] = self.s_gather.record_event()
+            if k + V < steps:
+                scatter(k + V)
+            last = v
+        for st in self.streams:  # a caller that synchronises its slot streams has the gathered records too
+            st.wait_stream(self.s_gather)
+        if last is None or self.rank != self.src:
+            return None
+        return list(self.gathered[last].unbind(0))
 
 
 class ShardedRunner:
