@@ -366,3 +366,34 @@ def test_latency_and_throughput_profiles_agree_on_random_shapes(gpu_device):
         assert torch.equal(res[0][1], res[1][1]), (it, h, w, b)
         assert all(torch.equal(res[0][0][i, :n], res[1][0][i, :n]) for i, n in enumerate(res[0][1].tolist())), (it, h, w, b)
         assert all(torch.equal(p, q) for p, q in zip(res[0][2], res[1][2])), (it, h, w, b)
+
+
+@pytest.mark.parametrize("side", [1, 2])
+def test_side_lane_graphs_bit_identical_and_rebindable(gpu_device, monkeypatch, side):
+    """lower(one_batch=True) with YL_ONE_BATCH_SIDE: the first levels' Detect branches on side lane 1, the program run as ONE GRAPH
+    PER SEGMENT on a stream per lane (csrc/engine.hip detect_lanes; a single captured graph's branches are serialised by this
+    runtime).  Same detections bit for bit as the program without lanes: eager, segment graphs, their replay, and the replay
+    on a FRESH input tensor (the plan rewrites the stem node's input address); the single-handle form refuses such a program."""
+    specs, _ = arch.parse_model(arch.yolo11_dict("n"))
+    b, h, w = 4, 320, 352
+    sd = synth_state_dict("n", 7, cls_bias=[-3.5] * 3, cls_gain=6.0)
+    xs = [torch.randint(0, 256, (b, 3, h, w), generator=torch.Generator().manual_seed(s), dtype=torch.uint8).to(gpu_device) for s in (1, 2, 3)]
+    ref = HipEngine.from_model(specs, sd, b, h, w, gpu_device, one_batch=True)
+    assert not any(o.get("lane", 0) for o in ref.prog.ops)
+    want = []
+    for x in xs:
+        o, c = ref.detect(x, 0.25, 0.7, graph=False)
+        want.append((o.clone(), c.clone()))
+    assert int(want[0][1].sum()) > 0
+    monkeypatch.setenv("YL_ONE_BATCH_SIDE", str(side))
+    eng = HipEngine.from_model(specs, sd, b, h, w, gpu_device, one_batch=True)
+    lanes = [o.get("lane", 0) for o in eng.prog.ops]
+    assert sum(lanes) == 4 * side and lanes[0] == 0
+    for mode in (dict(graph=False), dict(graph=True), dict(graph=True), dict(graph=True, stage="rebind")):
+        for x, (o0, c0) in zip(xs, want):
+            o, c = eng.detect(x, 0.25, 0.7, **mode)
+            torch.cuda.synchronize()
+            assert torch.equal(c, c0), mode
+            assert all(torch.equal(o[i, :n], o0[i, :n]) for i, n in enumerate(c0.tolist())), mode
+    with pytest.raises((RuntimeError, NotImplementedError)):
+        eng.prepare_detect(xs[0], 0.25, 0.7, max_det=300, slot=0)

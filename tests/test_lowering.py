@@ -269,3 +269,31 @@ def test_lowering_uses_resident_c3k_from_batch_8(monkeypatch):
     assert len([o for o in lat.ops if o["kind"] == OP_PSA_TAIL]) == 1
     s_scale = lower(arch.parse_model(arch.yolo11_dict("s"))[0], synth_state_dict("s", 0), 32, 640, 640)
     assert not [o for o in s_scale.ops if o["kind"] == OP_C3K]   # inner width 128: the maps do not fit
+
+
+def test_side_lane_head_placement(monkeypatch):
+    """YL_ONE_BATCH_SIDE=n (opt-in): the Detect branches of the first n levels follow the layer that feeds them on lane 1, the
+    other levels' copies stay behind the network (grouped when there are two of them); op 0 stays on the main lane."""
+    from yololite_amd.nn import arch
+    from yololite_amd.nn.lower import lower
+    from yololite_amd.nn.synth import synth_state_dict
+
+    specs, _ = arch.parse_model(arch.yolo11_dict("n"))
+    sd = synth_state_dict("n", 0, cls_bias=[0.0, 0.0, 0.0])
+    base = lower(specs, sd, 32, 640, 640, one_batch=True)
+    assert not any(o.get("lane", 0) for o in base.ops)
+    for side in (1, 2):
+        monkeypatch.setenv("YL_ONE_BATCH_SIDE", str(side))
+        prog = lower(specs, sd, 32, 640, 640, one_batch=True)
+        assert sorted(o["name"] for o in prog.ops) == sorted(o["name"] for o in base.ops)
+        names = [o["name"] for o in prog.ops]
+        for lvl, feed in ((0, 16), (1, 19))[:side]:
+            first = names.index(f"model.23.cv3.{lvl}.0.0+pw")
+            assert names[first - 1].startswith(f"model.{feed}.") and not names[first + 4].startswith("model.23.")
+            assert [o.get("lane", 0) for o in prog.ops[first:first + 4]] == [1, 1, 1, 1]
+        assert prog.ops[0].get("lane", 0) == 0 and sum(o.get("lane", 0) for o in prog.ops) == 4 * side
+        tail = [o for o in prog.ops if o["name"].startswith("model.23.") and not o.get("lane", 0)]
+        assert len(tail) == 4 * (3 - side) and names[-1].startswith("model.23.")
+        assert (len({o.get("group", 0) for o in tail} - {0}) == 2) == (side == 1)
+    # a throughput program never gets lanes
+    assert not any(o.get("lane", 0) for o in lower(specs, sd, 32, 640, 640).ops)

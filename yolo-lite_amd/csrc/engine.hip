@@ -171,6 +171,33 @@ struct yl_engine {
   };
   std::map<void*, StreamSet> sets;
   int max_lane = 0;
+  // Side lanes as SEPARATE graphs (lane_graphs; the one-batch profile of the program): this HIP runtime replays the parallel
+  // branches of one captured graph one after the other (yl_graph_branch_probe), so a program with side lanes is cut into
+  // SEGMENTS -- maximal runs of ops of one lane -- each captured as a graph of its own: main segments are launched on the
+  // caller's stream in program order, a side segment on its lane's stream behind an event recorded after the main segment in
+  // front of it, every lane is joined before the decode + NMS graph.  Ops of one lane keep their program order.
+  bool lane_graphs = false;
+  struct Segment {
+    int lane;
+    size_t begin, end;  // ops [begin, end)
+  };
+  std::vector<Segment> segments;
+  struct LanePlan {
+    std::vector<hipGraphExec_t> seg;  // one executable per segment
+    hipGraphExec_t post = nullptr;    // decode + NMS
+    hipGraph_t g0 = nullptr;          // source graph of segment 0: its node handles address seg[0]'s nodes (input rebinding)
+    std::vector<hipGraphNode_t> in_nodes;
+    const void* cur = nullptr;
+    uint64_t used = 0;
+  };
+  static void destroy_plan(LanePlan& p) {
+    for (hipGraphExec_t x : p.seg)
+      if (x) (void)hipGraphExecDestroy(x);
+    if (p.post) (void)hipGraphExecDestroy(p.post);
+    if (p.g0) (void)hipGraphDestroy(p.g0);
+    p = LanePlan{};
+  }
+  std::map<DetectKey, LanePlan> lplans;  // keyed without the input address (always rebindable), bounded like rgraphs
   std::vector<void*> zeroed;  // workspaces whose guard pixels this engine has already cleared
 };
 
@@ -256,6 +283,8 @@ extern "C" void yl_engine_destroy(yl_engine* e) {
     if (kv.second.g) (void)hipGraphDestroy(kv.second.g);
   }
   e->rgraphs.clear();
+  for (auto& kv : e->lplans) yl_engine::destroy_plan(kv.second);
+  e->lplans.clear();
   for (auto& kv : e->sets) {
     if (kv.second.cap) (void)hipStreamDestroy(kv.second.cap);
     for (hipStream_t st : kv.second.lanes)
@@ -816,6 +845,20 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
     if (o.lane > e->max_lane) e->max_lane = o.lane;
     e->ops.push_back(r);
   }
+  // ---- side lanes as separate graphs (see yl_engine::lane_graphs): segments = maximal runs of ops of one lane; the first one
+  // must be a main-lane segment (it holds the network's first launch)
+  {
+    static const int lg = getenv("YL_LANE_GRAPHS") ? atoi(getenv("YL_LANE_GRAPHS")) : 1;
+    e->lane_graphs = lg != 0 && e->max_lane > 0 && !e->ops.empty() && e->ops[0].op.lane == 0;
+    if (e->lane_graphs) {
+      for (size_t i = 0; i < e->ops.size();) {
+        size_t j = i + 1;
+        while (j < e->ops.size() && e->ops[j].op.lane == e->ops[i].op.lane) ++j;
+        e->segments.push_back(yl_engine::Segment{e->ops[i].op.lane, i, j});
+        i = j;
+      }
+    }
+  }
   // ---- which launches produce the class logits of the Detect levels (the NMS candidate pre-filter rides in their epilogue)
   {
     size_t found = 0;
@@ -827,7 +870,7 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
       const bool last = conv_pf && r.op.kind == YL_OP_CONV && r.op.k == 1 && r.op.stride == 1 && !r.op.act && !r.f8 && !r.d_w0 && !r.d_wpk2 &&
                         r.op.res.offset < 0 && r.op.in2.offset < 0 && r.op.out8.offset < 0 && r.op.in.dtype == YL_BF16 &&
                         r.op.out.dtype == YL_BF16 && conv_pf_supported(r.cfg);  // (1x1 convs never join a group launch)
-      if (!(tail || last) || r.op.lane != 0 || r.op.out.coff != 0) continue;
+      if (!(tail || last) || (r.op.lane != 0 && !e->lane_graphs) || r.op.out.coff != 0) continue;
       for (size_t li = 0; li < e->levels.size(); ++li) {
         const yl_level& L = e->levels[li];
         if (r.op.out.offset == L.offset_cls && r.op.out.C == L.nc8 && r.op.out.H == L.H && r.op.out.W == L.W) {
@@ -837,7 +880,7 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
       }
     }
     static const int fuse_pf = getenv("YL_FUSE_PREFILTER") ? atoi(getenv("YL_FUSE_PREFILTER")) : 1;
-    e->cls_tails = fuse_pf && !e->levels.empty() && found == e->levels.size() && e->max_lane == 0;
+    e->cls_tails = fuse_pf && !e->levels.empty() && found == e->levels.size() && (e->max_lane == 0 || e->lane_graphs);
   }
   // ---- group launches: runs of consecutive ops with the same yl_op.group > 0 (the lowering puts the Detect levels'
   // copies of one conv side by side): up to three convs, then up to three depthwise + pointwise launches, each kind of
@@ -1470,6 +1513,8 @@ static int run_decode(const yl_engine* e, const char* ws, float* y, hipStream_t 
 // they become fork/join edges of the graph.
 static int lane_resources(yl_engine* e, yl_engine::StreamSet& ss, size_t n_events) {
   while ((int)ss.lanes.size() <= e->max_lane) ss.lanes.push_back(nullptr);
+  // (measured, round 5: neither the lowest stream priority nor a CU mask on the side lanes keeps the neck's small launches from
+  // slowing down beside the large Detect branches -- priority changes nothing, a CU-masked stream serialises with the caller's)
   for (int k = 1; k <= e->max_lane; ++k)
     if (!ss.lanes[k]) YL_HIP(hipStreamCreateWithFlags(&ss.lanes[k], hipStreamNonBlocking));
   while (ss.events.size() < n_events) {
@@ -1536,7 +1581,8 @@ static int forward_impl(yl_engine* e, const void* input, int in_dtype, void* wor
       hipEvent_t ev = ss.events[nev++];
       YL_HIP(hipEventRecord(ev, s));
       YL_HIP(hipStreamWaitEvent(ss.lanes[lane], ev, 0));
-      if (int rc = run_op(e, r, ws, ss.lanes[lane])) return rc;
+      // (side ops never read the network input; with lane graphs the class branch of a level may run here and feed the sink)
+      if (int rc = run_op(e, r, ws, ss.lanes[lane], nullptr, in_dtype, e->lane_graphs ? sink : nullptr)) return rc;
       used[lane] = 1;
     }
   }
@@ -1609,6 +1655,157 @@ static int detect_eager(yl_engine* e, const void* input, int in_dtype, void* wor
                            agnostic, classes, n_classes, max_cand, max_wh, scale, out, out_count, work, stream, nullptr, fused);
 }
 
+// ---- side lanes as separate graphs (yl_engine::lane_graphs) ------------------------------------------------------------
+// One step = seg[0] on the caller's stream, then in program order: a main segment on the caller's stream; a side segment on
+// its lane's stream behind an event recorded on the caller's stream at that point (= after every earlier main-lane op, which
+// covers its data dependencies exactly as forward_impl's fork does); finally every used lane is joined and the decode + NMS
+// graph follows.  Four to six graph launches and a few events per step instead of one launch -- for a caller that runs ONE
+// batch at a time the 80x80 Detect branches then overlap the 40x40 / 20x20 neck instead of queueing behind it.
+// The plan is keyed without the input address: the kernel nodes of segment 0 that read the input get a new address written
+// into their parameters when it changes (yl_engine_detect_graph_rebind's mechanism), so one plan serves both entry points.
+static int run_range(yl_engine* e, size_t begin, size_t end, char* ws, hipStream_t s, const void* input, int in_dtype,
+                     const PrefilterSink* sink) {
+  for (size_t oi = begin; oi < end; ++oi) {
+    if (e->ops[oi].group_n < 0) continue;  // launched with the first member of its group
+    int consumed = 1;
+    if (int rc = run_at(e, oi, ws, s, input, in_dtype, &consumed, sink)) return rc;
+  }
+  return 0;
+}
+
+static int end_capture(hipStream_t cap, int rc, hipGraph_t* g_out, hipGraphExec_t* x_out) {
+  hipGraph_t g = nullptr;
+  hipError_t ce = hipStreamEndCapture(cap, &g);
+  if (rc) {
+    if (g) (void)hipGraphDestroy(g);
+    return rc;
+  }
+  if (ce != hipSuccess) return fail(-2, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
+  hipError_t ie = hipGraphInstantiate(x_out, g, nullptr, nullptr, 0);
+  if (ie != hipSuccess) {
+    (void)hipGraphDestroy(g);
+    return fail(-2, std::string("hipGraphInstantiate: ") + hipGetErrorString(ie));
+  }
+  if (g_out) *g_out = g;
+  else (void)hipGraphDestroy(g);
+  return 0;
+}
+
+static int detect_lanes(yl_engine* e, const void* input, int in_dtype, void* workspace, float conf_thres, float iou_thres,
+                        int max_det, int agnostic, const int32_t* classes, int n_classes, int max_cand, float max_wh,
+                        const float* scale, float* out, int32_t* out_count, void* work, void* stream) {
+  if (!e || !input || !workspace || !out || !out_count || !work) return fail(-1, "yl_engine_detect_graph: null pointer");
+  if (e->levels.empty()) return fail(-1, "yl_engine_detect_graph: engine has no Detect levels");
+  hipStream_t s = (hipStream_t)stream;
+  char* ws = (char*)workspace;
+  yl_engine::DetectKey key(nullptr, in_dtype, workspace, conf_thres, iou_thres, max_det, agnostic, classes, n_classes, max_cand,
+                           max_wh, scale, out, out_count, work);
+  auto it = e->lplans.find(key);
+  if (it == e->lplans.end()) {
+    // eager first (real streams and events for the lanes): argument checks, workspace preparation, lazy function attributes
+    if (int rc = detect_eager(e, input, in_dtype, workspace, conf_thres, iou_thres, max_det, agnostic, classes, n_classes, max_cand,
+                              max_wh, scale, out, out_count, work, stream))
+      return rc;
+    YL_HIP(hipStreamSynchronize(s));
+    hipStream_t cap = nullptr;
+    if (int rc = capture_stream(e, workspace, &cap)) return rc;
+    yl_engine::LanePlan P;
+    struct Guard {
+      yl_engine::LanePlan* p;
+      ~Guard() {
+        if (p) yl_engine::destroy_plan(*p);
+      }
+    } guard{&P};
+    PrefilterSink sink{};
+    int fused = 0;
+    static const bool zero_in_stem = !getenv("YL_ZERO_IN_STEM") || atoi(getenv("YL_ZERO_IN_STEM")) != 0;
+    const bool defer = zero_in_stem && e->ops[0].d_w0 && e->ops[0].group_n >= 0;
+    const bool stem = e->ops[0].op.kind == YL_OP_STEM || e->ops[0].d_w0;
+    for (size_t k = 0; k < e->segments.size(); ++k) {
+      const yl_engine::Segment& sg = e->segments[k];
+      YL_HIP(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
+      int rc = 0;
+      if (k == 0) {  // (what detect_eager puts in front of the network)
+        if (e->cls_tails)
+          rc = prefilter_sink_prepare(e->levels.data(), (int)e->levels.size(), e->batch, max_cand, conf_thres, work, (void*)cap, &sink,
+                                      &fused, defer);
+        if (!rc && !stem) rc = run_convert(e, input, in_dtype, ws, cap);
+      }
+      if (!rc) rc = run_range(e, sg.begin, sg.end, ws, cap, input, in_dtype, fused ? &sink : nullptr);
+      hipGraphExec_t x = nullptr;
+      if (int rc2 = end_capture(cap, rc, k == 0 ? &P.g0 : nullptr, &x)) return rc2;
+      P.seg.push_back(x);
+    }
+    YL_HIP(hipStreamBeginCapture(cap, hipStreamCaptureModeThreadLocal));
+    int rc = decode_nms_stages(workspace, e->levels.data(), (int)e->levels.size(), e->batch, e->nc, conf_thres, iou_thres, max_det,
+                               agnostic, classes, n_classes, max_cand, max_wh, scale, out, out_count, work, (void*)cap, nullptr, fused);
+    if (int rc2 = end_capture(cap, rc, nullptr, &P.post)) return rc2;
+    // the kernel nodes of segment 0 that take the input address as their first parameter
+    size_t nn = 0;
+    YL_HIP(hipGraphGetNodes(P.g0, nullptr, &nn));
+    std::vector<hipGraphNode_t> all(nn);
+    if (nn) YL_HIP(hipGraphGetNodes(P.g0, all.data(), &nn));
+    for (hipGraphNode_t nd : all) {
+      hipGraphNodeType ty;
+      YL_HIP(hipGraphNodeGetType(nd, &ty));
+      if (ty != hipGraphNodeTypeKernel) continue;
+      hipKernelNodeParams kp{};
+      YL_HIP(hipGraphKernelNodeGetParams(nd, &kp));
+      if (!kp.kernelParams || !kp.kernelParams[0]) continue;
+      const void* first = nullptr;
+      memcpy(&first, kp.kernelParams[0], sizeof(first));
+      if (first == input) P.in_nodes.push_back(nd);
+    }
+    if (P.in_nodes.empty()) return fail(-3, "lane graphs: no kernel node of the first segment reads the input address");
+    P.cur = input;
+    if (e->lplans.size() >= e->rcap) {  // evict the least recently launched tuple
+      auto lru = e->lplans.begin();
+      for (auto jt = e->lplans.begin(); jt != e->lplans.end(); ++jt)
+        if (jt->second.used < lru->second.used) lru = jt;
+      (void)hipDeviceSynchronize();
+      yl_engine::destroy_plan(lru->second);
+      e->lplans.erase(lru);
+    }
+    guard.p = nullptr;
+    it = e->lplans.emplace(key, P).first;
+  }
+  yl_engine::LanePlan& P = it->second;
+  P.used = ++e->rtick;
+  if (P.cur != input) {
+    for (hipGraphNode_t nd : P.in_nodes) {
+      hipKernelNodeParams kp{};
+      YL_HIP(hipGraphKernelNodeGetParams(nd, &kp));
+      memcpy(kp.kernelParams[0], &input, sizeof(input));
+      YL_HIP(hipGraphExecKernelNodeSetParams(P.seg[0], nd, &kp));
+    }
+    P.cur = input;
+  }
+  yl_engine::StreamSet& ss = e->sets[workspace];
+  if (int rc = lane_resources(e, ss, e->segments.size() + (size_t)e->max_lane + 1)) return rc;
+  size_t nev = 0;
+  std::vector<char> used((size_t)e->max_lane + 1, 0);
+  for (size_t k = 0; k < e->segments.size(); ++k) {
+    const int lane = e->segments[k].lane;
+    if (lane == 0) {
+      YL_HIP(hipGraphLaunch(P.seg[k], s));
+    } else {
+      hipEvent_t ev = ss.events[nev++];
+      YL_HIP(hipEventRecord(ev, s));
+      YL_HIP(hipStreamWaitEvent(ss.lanes[lane], ev, 0));
+      YL_HIP(hipGraphLaunch(P.seg[k], ss.lanes[lane]));
+      used[lane] = 1;
+    }
+  }
+  for (int k = 1; k <= e->max_lane; ++k)
+    if (used[k]) {
+      hipEvent_t ev = ss.events[nev++];
+      YL_HIP(hipEventRecord(ev, ss.lanes[k]));
+      YL_HIP(hipStreamWaitEvent(s, ev, 0));
+    }
+  YL_HIP(hipGraphLaunch(P.post, s));
+  return 0;
+}
+
 // the captured graph of one argument tuple (captured on first use); launch != 0: also launched on `stream`
 static int detect_graph_get(yl_engine* e, const void* input, int in_dtype, void* workspace, float conf_thres, float iou_thres,
                             int max_det, int agnostic, const int32_t* classes, int n_classes, int max_cand, float max_wh,
@@ -1655,6 +1852,9 @@ extern "C" int yl_engine_detect_graph(yl_engine* e, const void* input, int in_dt
                                       float conf_thres, float iou_thres, int max_det, int agnostic,
                                       const int32_t* classes, int n_classes, int max_cand, float max_wh,
                                       const float* scale, float* out, int32_t* out_count, void* work, void* stream) {
+  if (e && e->lane_graphs)  // a program with side lanes: one graph per segment (detect_lanes)
+    return detect_lanes(e, input, in_dtype, workspace, conf_thres, iou_thres, max_det, agnostic, classes, n_classes, max_cand, max_wh,
+                        scale, out, out_count, work, stream);
   return detect_graph_get(e, input, in_dtype, workspace, conf_thres, iou_thres, max_det, agnostic, classes, n_classes, max_cand,
                           max_wh, scale, out, out_count, work, stream, 1, nullptr);
 }
@@ -1667,6 +1867,9 @@ extern "C" int yl_engine_detect_graph_prepare(yl_engine* e, const void* input, i
                                               const float* scale, float* out, int32_t* out_count, void* work, void* stream,
                                               void** graph_out) {
   if (!graph_out) return fail(-1, "yl_engine_detect_graph_prepare: null pointer");
+  if (e && e->lane_graphs)
+    return fail(-3, "yl_engine_detect_graph_prepare: a program with side lanes runs as several graphs on several streams (one batch at "
+                    "a time); the single-handle form needs a program without lanes");
   hipGraphExec_t ex = nullptr;
   const int rc = detect_graph_get(e, input, in_dtype, workspace, conf_thres, iou_thres, max_det, agnostic, classes, n_classes,
                                   max_cand, max_wh, scale, out, out_count, work, stream, 0, &ex, /*pin=*/true);
@@ -1685,6 +1888,9 @@ extern "C" int yl_engine_detect_graph_rebind(yl_engine* e, const void* input, in
   if (!e || !input || !workspace || !out || !out_count || !work)
     return fail(-1, "yl_engine_detect_graph_rebind: null pointer");
   if (e->levels.empty()) return fail(-1, "yl_engine_detect_graph_rebind: engine has no Detect levels");
+  if (e->lane_graphs)
+    return detect_lanes(e, input, in_dtype, workspace, conf_thres, iou_thres, max_det, agnostic, classes, n_classes, max_cand, max_wh,
+                        scale, out, out_count, work, stream);
   hipStream_t s = (hipStream_t)stream;
   yl_engine::DetectKey key(nullptr, in_dtype, workspace, conf_thres, iou_thres, max_det, agnostic, classes, n_classes,
                            max_cand, max_wh, scale, out, out_count, work);

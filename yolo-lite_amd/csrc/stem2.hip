@@ -25,7 +25,10 @@
 #endif
 namespace yl {
 
-constexpr int S2_TR = 5, S2_TC = 32;                 // layer-1 output tile (round 4: 2 x 80 before -- the squarer tile recomputes
+#ifndef YL_S2_TR
+#define YL_S2_TR 5  // development build switch: rows of the layer-1 output tile
+#endif
+constexpr int S2_TR = YL_S2_TR, S2_TC = 32;                 // layer-1 output tile (round 4: 2 x 80 before -- the squarer tile recomputes
                                                      // 715 stem pixels per 160 outputs instead of 805, and a window row is four
                                                      // 16-pixel tiles + one column: one tile column per wave)
 constexpr int S2_SR = 2 * S2_TR + 1;                 // stem rows (11)

@@ -593,6 +593,55 @@ def fold_conv_bn(sd: Dict[str, torch.Tensor], name: str, bn: bool = True) -> Tup
     return np.ascontiguousarray(w.numpy(), dtype=np.float32), np.ascontiguousarray(bias.numpy(), dtype=np.float32)
 
 
+def side_lane_head(ops: List[dict], det_prefix: str, feeds: Sequence[int], side_levels: int) -> List[dict]:
+    """The one-batch profile's head placement (``lower(one_batch=True)``): the Detect branches of the first ``side_levels``
+    levels go on SIDE LANE 1 right behind the layer that feeds them (``feeds[lvl]`` = its layer index), so that a caller who
+    runs one batch at a time has the chip-filling 80x80 branches overlap the 40x40 / 20x20 neck, whose launches cannot fill
+    256 CUs (head.py:59-62: the levels are independent; yolo11.yaml:33-46: the neck goes on from layer 16 while level 0's
+    branches only need layer 16).  The engine runs a program with lanes as one graph per segment on a stream per lane
+    (csrc/engine.hip detect_lanes).  The remaining levels' copies of each conv are grouped as ``group_detect_levels`` does
+    and run behind the network.  Same kernels per conv as ungrouped launches: bit-identical."""
+    head = [o for o in ops if o.get("name", "").startswith(det_prefix + ".")]
+    nlv = len(feeds)
+    if len(head) != 4 * nlv or any(o.get("lane", 0) for o in head) or not 0 < side_levels < nlv:
+        return ops
+
+    def level_ops(lvl: int) -> Optional[List[dict]]:
+        names = (f"{det_prefix}.cv3.{lvl}.0.0+pw", f"{det_prefix}.cv3.{lvl}.1.0+pw+2", f"{det_prefix}.cv2.{lvl}.0", f"{det_prefix}.cv2.{lvl}.1+2")
+        got = [o for nm in names for o in head if o["name"] == nm]
+        return got if len(got) == 4 else None
+
+    per_level = [level_ops(lvl) for lvl in range(nlv)]
+    if any(v is None for v in per_level):
+        return ops
+    rest = [o for o in ops if not o.get("name", "").startswith(det_prefix + ".")]
+    out: List[dict] = list(rest)
+    for lvl in range(side_levels):
+        pref = f"model.{feeds[lvl]}."
+        last = max((i for i, o in enumerate(out) if o.get("name", "").startswith(pref) and o.get("lane", 0) == 0), default=None)
+        if last is None:
+            return ops
+        for o in per_level[lvl]:
+            o["lane"] = 1
+        out[last + 1:last + 1] = per_level[lvl]
+    tail_lv = list(range(side_levels, nlv))
+    if len(tail_lv) >= 2:
+        first_cls = [per_level[lvl][0] for lvl in tail_lv]
+        box0 = [per_level[lvl][2] for lvl in tail_lv]
+        box1 = [per_level[lvl][3] for lvl in tail_lv]
+        cls1 = [per_level[lvl][1] for lvl in tail_lv]
+        for o in box0:
+            o["group"] = 1
+        for o in box1 + cls1:
+            o["group"] = 2
+        out += first_cls + box0 + box1 + cls1
+    else:
+        for lvl in tail_lv:
+            cl0, cl1, b0, b1 = per_level[lvl]
+            out += [cl0, b0, b1, cl1]
+    return out
+
+
 def _out_hw(h: int, w: int, k: int, s: int) -> Tuple[int, int]:
     p = k // 2
     return (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
@@ -1011,6 +1060,18 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
             # (the latency profile joins the box and class branch launches of the levels too, =3: 42 -> 38 launches, one batch at a
             # time +2.4 %, with batches in flight -2.7 %)
             gl = os.environ.get("YL_GROUP_LEVELS", "3" if one_batch else "2")
+            # (one batch at a time: the first levels' branches on a side lane, see side_lane_head; YL_ONE_BATCH_SIDE = levels
+            # that go there, 0 = none: the joined group launches of round 4)
+            # MEASURED (round 5, NOTEBOOK section 15) and OFF by default: the branches do overlap the neck (kernel trace), but the
+            # neck's small launches slow down 1.8 x beside them and the remaining levels lose the three-level group launches:
+            # 907-913 us per batch against 895-901 us.
+            side_n = int(os.environ.get("YL_ONE_BATCH_SIDE", "0")) if one_batch and not fp8_scales else 0
+            if side_n > 0 and "YL_GROUP_LEVELS" not in os.environ:
+                n_before = len(ops)
+                ops[:] = side_lane_head(ops, dp, list(det.f), side_n)
+                assert len(ops) == n_before
+                if any(o.get("lane", 0) for o in ops):
+                    gl = "done"
             if gl in ("1", "2", "3", "4") and not fp8_scales:
                 ops[:] = group_detect_levels(ops, dp, nlv, keep_first_box_conv=gl == "2", join_branches=gl in ("3", "4"),
                                              join_first_only=gl == "4")
