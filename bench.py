@@ -551,6 +551,23 @@ def main():
             eng.launch_many(step_h[:S], step_s[:S])  # (builds the argument arrays' cache entry for the slice; untimed)
             eng.launch_many(step_h, step_s)
         sync_all()
+        # Warm-up to the steady state.  The W steps the caller asks for are a minimum: after the engine build the first rounds of
+        # S batches run 4-5 % below the rate the same loop settles at (tools/round_timeline.py --reps 40 on one box: 54.7, 55.1,
+        # 56.2, 56.6, 56.9, 57.1 k images/s for rounds 1-6, then 56.5-57.4 k: clocks and caches), and a K = 20 run IS one such
+        # round.  WARM_ROUNDS more untimed rounds of the same native loop (~0.1 s) put the timed K steps on the plateau.
+        warm_rounds = int(os.environ.get("YL_BENCH_WARM_ROUNDS", "10"))
+        # (one round per call, synchronised: behind ONE call with thousands of launches the runtime recycles its command objects
+        # during the next launches -- the timed K steps then take 0.8-2 ms to issue instead of 0.25)
+        for _ in range(warm_rounds):
+            if native:
+                eng.launch_many(step_h[:S], step_s[:S])
+            else:
+                for k in range(S):
+                    hot_path(xs[k % S])
+            sync_all()
+        extra["warmup_steps_run"] = max(args.warmup, 2 * S) + S + args.steps + warm_rounds * S
+        extra["warmup_note"] = (f"--warmup {args.warmup} is the minimum: {extra['warmup_steps_run']} untimed steps ran before the timed region "
+                                f"(the last {warm_rounds * S} of them = {warm_rounds} rounds of the same native loop, until the rate stops rising)")
         step_no[0] = 0
         t0 = time.perf_counter()
         if native:
@@ -671,7 +688,9 @@ def main():
             S = max(tried, key=tried.get)
             torch.cuda.empty_cache()
         runner = make_runner(S)
-        runner.run(batches, max(args.warmup, 2 * runner.lanes))
+        n_warm = max(args.warmup, 2 * runner.lanes, int(os.environ.get("YL_BENCH_WARM_ROUNDS", "10")) * S)  # (to the steady state, as at N = 1)
+        runner.run(batches, n_warm)
+        extra["warmup_steps_run"] = n_warm
         sync_all()
         t0 = time.perf_counter()
         last = runner.run(batches, args.steps)

@@ -144,3 +144,48 @@ def test_native_runner_equals_plain_detect(gpu_device, golden, tmp_path, slots, 
             m = int(ref[k][1][i])
             assert torch.equal(outs[0][i, :m], ref[k][0][i, :m])
     comm.close()
+
+
+def test_config4_eight_shards_of_the_global_batch(gpu_device):
+    """BASELINE.json config 4 at its own size on ONE GPU: the global batch of 256 images at 640x640, cut by ``dist.shard_bounds``
+    into the eight contiguous 32-image shards the ranks of an 8-GPU job receive.  Every shard goes through the batch-32 engine
+    a rank runs -- the captured graph writing the packed record a rank sends (``detect_record``) -- and must equal the plain
+    eager ``detect`` of the same images bit for bit (per-shard results identical to the one-GPU run with the same
+    kernels; images are independent through network and NMS, ops.py:219); the root's view of the eight records
+    (``unpack_record``) is the global result in rank order.  The transport is covered above (world of one, RCCL) and on the CPU
+    (gloo, world of two).  (A batch-256 engine is NOT the yardstick: kernel selection depends on the batch -- GEMM route, K
+    order of the stride-2 convs -- so its low bits differ; against the reference both sit inside the same format tolerance.)"""
+    from yololite_amd.dist import record_floats, shard_bounds, unpack_record
+    from yololite_amd.nn.synth import calibrate_cls_bias
+
+    world, per, H, W, max_det = 8, 32, 640, 640, 300
+    specs, _ = arch.parse_model(arch.yolo11_dict("n"))
+    g = torch.Generator().manual_seed(404)
+    xg = torch.randint(0, 256, (world * per, 3, H, W), generator=g, dtype=torch.uint8).to(gpu_device)
+    e0 = HipEngine.from_model(specs, synth_state_dict("n", 0, cls_bias=[0.0, 0.0, 0.0]), per, H, W, gpu_device)
+    e0.forward(xg[:per], decode=False)
+    bias = calibrate_cls_bias([r[:, 64:].amax(1).float().cpu() for r in e0.raw_levels()], 0.015)
+    del e0
+    torch.cuda.empty_cache()
+    eng = HipEngine.from_model(specs, synth_state_dict("n", 0, cls_bias=bias), per, H, W, gpu_device)
+    recs, want = [], []
+    for rank in range(world):
+        lo, hi = shard_bounds(world * per, world, rank)
+        assert (lo, hi) == (rank * per, (rank + 1) * per)
+        shard = xg[lo:hi]
+        o, c = eng.detect(shard, 0.25, 0.7, max_det=max_det, graph=False)
+        want.append((o.clone(), c.clone()))
+        rec = eng.detect_record(shard, 0.25, 0.7, max_det=max_det, slot=rank % 3, rec_key=rank % 2)
+        assert rec.numel() == record_floats(per, max_det)
+        recs.append(rec.clone())  # (what the gather delivers to the root)
+    torch.cuda.synchronize()
+    assert sum(int(c.sum()) for _, c in want) > 5 * world * per
+    outs, cnts = unpack_record(recs, per, max_det)
+    assert len(outs) == world
+    for rank in range(world):
+        assert torch.equal(cnts[rank], want[rank][1]), rank
+        for i in range(per):
+            n = int(cnts[rank][i])
+            assert torch.equal(outs[rank][i, :n], want[rank][0][i, :n]), (rank, i)
+    with pytest.raises(ValueError):
+        shard_bounds(world * per + 1, world, 0)
