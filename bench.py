@@ -579,6 +579,14 @@ def main():
         sync_all()
         dt = time.perf_counter() - t0
         extra["issue_ms"] = round(t_issue * 1e3, 4)  # host time to issue the K steps (inside the timed region)
+        if native and int(os.environ.get("YL_BENCH_REPEAT", "0")) > 0:  # development: the same timed region again, N times
+            reps = []
+            for _ in range(int(os.environ["YL_BENCH_REPEAT"])):
+                tr0 = time.perf_counter()
+                eng.launch_many(step_h, step_s)
+                sync_all()
+                reps.append(round(B * args.steps / (time.perf_counter() - tr0), 1))
+            extra["debug_repeats_images_per_sec"] = reps
         extra["step_issue"] = "native: yl_graph_launch_many, one call for the K steps" if native else "python loop"
         out, cnt = slot_res[(args.steps - 1) % S]
         ndet = cnt.float().mean().item()
@@ -908,7 +916,18 @@ def main():
 
                     api1 = YOLOLite(f"yolo11{args.scale}.yaml")
                     api1.model.load_state_dict(sd)
+                    # the frame: the reference's own example image, decoded once on the host (tests/golden/boats.jpg -- a data file of
+                    # the reference, 1080 x 1920; BASELINE.json configs[0] names it); white noise of that size when PIL is missing
+                    frame_src = "white noise"
                     frame = np.random.default_rng(1).integers(0, 256, (1080, 1920, 3), dtype=np.uint8)
+                    try:
+                        from PIL import Image
+
+                        fp = ROOT / "tests" / "golden" / "boats.jpg"
+                        frame = np.ascontiguousarray(np.asarray(Image.open(fp).convert("RGB"))[:, :, ::-1])  # BGR, as the loaders decode
+                        frame_src = "boats.jpg"
+                    except Exception:
+                        pass
                     kw1 = dict(conf=conf, iou=iou, max_det=max_det, device=str(dev), save=False, verbose=False, imgsz=640)
                     for _ in range(3):
                         api1.predict(frame, **kw1)
@@ -918,8 +937,8 @@ def main():
                         r1 = api1.predict(frame, **kw1)
                     torch.cuda.synchronize(dev)
                     lat = (time.perf_counter() - t5) / 20
-                    res["other_configs"].append({"workload": f"YOLO11{args.scale} bf16, one 1080x1920 frame -> 384x640, batch=1 through YOLOLite.predict "
-                                                             "(host array in, upload + device letterbox + network + NMS + Results)",
+                    res["other_configs"].append({"workload": f"YOLO11{args.scale} bf16, one {frame.shape[0]}x{frame.shape[1]} frame ({frame_src}) -> 384x640, batch=1 "
+                                                             "through YOLOLite.predict (host array in, upload + device letterbox + network + NMS + Results)",
                                                  "latency_ms": round(lat * 1e3, 3), "value": round(1.0 / lat, 1), "unit": "images/sec",
                                                  "detections": int(len(r1[0].boxes))})
                     del api1

@@ -3,6 +3,8 @@
 YOLOLite.predict(path, imgsz=640) -> LetterBox(auto) to 384 x 640, batch 1 -> network -> NMS -> scale_boxes back to
 1080 x 1920 -> Results.  Checked against the oracle run on the same decoded pixels letterboxed by the independent float
 definition of INTER_LINEAR (oracle/letterbox_oracle.py), with the post-NMS gate of oracle/parity_gate.py."""
+from pathlib import Path
+
 import numpy as np
 import pytest
 import torch
@@ -29,12 +31,20 @@ def _scene(h=1080, w=1920, seed=11):
     return np.clip(img + g.normal(0, 6, img.shape), 0, 255).astype(np.uint8)
 
 
-def test_predict_jpeg_file_1080x1920(gpu_device, golden, tmp_path):
+BOATS = Path(__file__).resolve().parent / "golden" / "boats.jpg"  # the reference's own example image (a data file, 1080 x 1920)
+
+
+@pytest.mark.parametrize("source", ["synthetic_scene", "boats.jpg"])
+def test_predict_jpeg_file_1080x1920(gpu_device, golden, tmp_path, source):
     from yololite_amd import YOLOLite
     from yololite_amd.nn.synth import calibrate_cls_bias, synth_state_dict
 
-    path = tmp_path / "boats_like.jpg"
-    Image.fromarray(_scene()).save(path, quality=92)
+    if source == "boats.jpg":  # BASELINE.json configs[0] names this file (reference main.py / README: predict on boats.jpg)
+        path = tmp_path / "boats.jpg"
+        path.write_bytes(BOATS.read_bytes())
+    else:
+        path = tmp_path / "boats_like.jpg"
+        Image.fromarray(_scene()).save(path, quality=92)
     bgr = np.ascontiguousarray(np.asarray(Image.open(path).convert("RGB"))[:, :, ::-1])  # what the loader decodes
     assert bgr.shape == (1080, 1920, 3)
     x8 = lbo.letterbox_batch_u8([bgr], (640, 640), auto=True)  # predictor.py:106-107: auto = same shapes and pt
