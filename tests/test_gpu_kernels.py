@@ -76,6 +76,9 @@ GEMM_CASES = [
     (768, 384, 11, 13, True, True),     # 24 K-slices, ragged map
     (512, 256, 12, 12, True, False),    # SPPF cv2: 256-channel blocks, ring of three 32-channel slices
     (128, 384, 33, 17, False, True),
+    (256, 64, 24, 20, True, False),     # 64-channel blocks (round 5: two tiles per wave, ring of three 64-channel slices)
+    (160, 64, 17, 23, True, True),      # ... K not a multiple of 64 (four slices of 32), residual, ragged map
+    (128, 64, 20, 20, False, False),    # ... two K-slices = exactly the ring's lead
 ]
 
 
@@ -99,6 +102,7 @@ def test_conv_gemm_vs_torch_and_conv_kernel(gpu_device, monkeypatch, cin, cout, 
         r = _rand(g, *ref.shape)
         ref = ref + r
     monkeypatch.setenv("YL_CONV_GEMM_BLOCKS", "1")
+    monkeypatch.setenv("YL_CONV_GEMM_M64_PX", "1")  # (64-channel blocks whatever the map size)
     got = run_conv(gpu_device, x, wt, b, 1, 1, act, r, expect_kernel="conv1x1_gemm_mfma")
     _assert_close_bf16(got, ref, f"gemm conv {cin}->{cout}")
     monkeypatch.setenv("YL_CONV_GEMM", "0")
@@ -223,7 +227,7 @@ def test_conv_reads_through_upsample_concat(gpu_device):
 
 
 @pytest.mark.parametrize("clo,cskip,cout,h,w,w8", [(128, 64, 128, 10, 14, "0"), (256, 128, 384, 12, 22, "0"), (128, 128, 256, 12, 22, "1"),
-                                                    (64, 192, 256, 9, 15, "-1")])
+                                                    (64, 192, 256, 9, 15, "-1"), (128, 128, 64, 11, 13, "0"), (64, 96, 64, 8, 10, "0")])
 def test_conv_gemm_reads_through_upsample_concat(gpu_device, monkeypatch, clo, cskip, cout, h, w, w8):
     """conv_gemm_kernel with an upsampled second input (yl_op.in2: the LDS-DMA source address is per lane, pixel (y / 2, x / 2) of
     the low-resolution map): against torch and bit-identical to conv_kernel's read-through."""
@@ -237,6 +241,7 @@ def test_conv_gemm_reads_through_upsample_concat(gpu_device, monkeypatch, clo, c
     for mode, kern in (("1", "conv1x1_gemm_mfma"), ("0", "conv1x1_mfma")):
         monkeypatch.setenv("YL_CONV_GEMM", mode)
         monkeypatch.setenv("YL_CONV_GEMM_BLOCKS", "1")
+        monkeypatch.setenv("YL_CONV_GEMM_M64_PX", "1")
         monkeypatch.setenv("YL_CONV_GEMM_W8", w8)
         m = Mini(B, gpu_device)
         vlo, cat, out = m.buf(h, w, clo), m.buf(2 * h, 2 * w, clo + cskip), m.buf(2 * h, 2 * w, cout)

@@ -43,8 +43,21 @@ typedef __attribute__((address_space(3))) void lds_void_g;
 // channels (64 / 80 KiB; fewer barriers: 384 -> 384 @320x320 x 8: 664 against 597 TFLOP/s with four slices of 32),
 // 256-channel blocks three slices of 32 (72 KiB); a K that is not a multiple of 64 takes four slices of 32.
 // Eight waves (2 x 4, BN = 256 pixels), one workgroup per CU: 1.3-1.5 x the MACs per staged byte.
-constexpr int gm_ks(int MTW, int NWN, bool even) { return NWN == 4 ? (MTW == 6 ? 2 : 1) : ((MTW == 8 || !even) ? 1 : 2); }
-constexpr int gm_ns(int MTW, int NWN, bool even) { return NWN == 4 ? (MTW == 6 ? 2 : 3) : (MTW == 8 ? 3 : (even ? 2 : 4)); }
+// 64-channel blocks (MTW = 2, round 5: layers that are all activation traffic -- 256 -> 64 @80x80 behind Upsample + Concat is
+// 92 MB for 6.7 GFLOP): a slice is 24 KiB (8 KiB of filter, 16 KiB of activations) and a ring of three of them keeps 48 KiB per
+// workgroup in flight; a K that is not a multiple of 64 takes four slices of 32.
+#ifndef YL_GM2_KS
+#define YL_GM2_KS 2  // development build switches: ring shape of the 64-channel blocks (even K)
+#endif
+#ifndef YL_GM2_NS
+#define YL_GM2_NS 3
+#endif
+constexpr int gm_ks(int MTW, int NWN, bool even) {
+  return NWN == 4 ? (MTW == 6 ? 2 : 1) : (MTW == 2 && even ? YL_GM2_KS : ((MTW == 8 || !even) ? 1 : 2));
+}
+constexpr int gm_ns(int MTW, int NWN, bool even) {
+  return NWN == 4 ? (MTW == 6 ? 2 : 3) : (MTW == 8 ? 3 : (even ? (MTW == 2 ? YL_GM2_NS : 2) : 4));
+}
 size_t conv_gemm_lds_bytes(int MTW, int NWN, bool even) {
   return (size_t)gm_ns(MTW, NWN, even) * gm_ks(MTW, NWN, even) * ((size_t)MTW * 2048 + (size_t)4 * 64 * NWN * 16);
 }
@@ -284,11 +297,25 @@ __global__ __launch_bounds__(128 * NWN) __attribute__((amdgpu_waves_per_eu(2))) 
     constexpr bool ENTER = decltype(enter_tag)::value;
     const unsigned char* ab = abase + ((gs0 + i) % NS) * STAGE + ks * (MT * 1024);
     const unsigned char* bb = bbase + ((gs0 + i) % NS) * STAGE + ks * BSTEP;
-    if constexpr ((YL_GEMM_ABL & 4) != 0) {  // (timing ablation: no fragment reads, the MFMAs re-use the registers)
+    if constexpr (MTW == 2) {
+      // two tiles per wave: eight MFMAs per k-step, too few to thread the six fragment reads through -- the next k-step's
+      // fragments go into a second register set (24 registers; this instance has them to spare) while this one's MFMAs run
+      if constexpr (ENTER) enter(i);
+      Frags nf;
+      if constexpr ((YL_GEMM_ABL & 4) == 0) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) nf.xb[nt] = *reinterpret_cast<const bf16x8*>(bb + nt * 256);
+#pragma unroll
+        for (int mt = 0; mt < MTW; ++mt) nf.wa[mt] = *reinterpret_cast<const bf16x8*>(ab + mt * 1024);
+      } else {
+        nf = f;
+      }
+      mma(f);
+      f = nf;
+    } else if constexpr ((YL_GEMM_ABL & 4) != 0) {  // (timing ablation: no fragment reads, the MFMAs re-use the registers)
       if constexpr (ENTER) enter(i);
       mma(f);
-      return;
-    }
+    } else {
     row(f, 0);
     row(f, 1);
     __builtin_amdgcn_sched_barrier(0);
@@ -319,6 +346,7 @@ __global__ __launch_bounds__(128 * NWN) __attribute__((amdgpu_waves_per_eu(2))) 
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
     }
     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    }
   };
   Frags F;
   enter(0);
@@ -400,9 +428,16 @@ void conv_gemm_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, i
   // 3x3 convs (stride 1 or 2; YL_CONV_GEMM3=0 turns them off): K = 9 x Cin, so 64 input channels are deep enough
   const int enable3 = getenv("YL_CONV_GEMM3") ? atoi(getenv("YL_CONV_GEMM3")) : 1;
   const bool k3 = k == 3 && enable3 && (stride == 1 || stride == 2) && !cin2 && Cin >= 64;
-  if (!enable || !(k3 || (k == 1 && stride == 1 && Cin >= min_c)) || Cin % 32 || Cout < min_c) return;
+  // 64 output channels (round 5, YL_CONV_GEMM_M64=0: off): 1x1 convs with at least 128 input channels on maps of at least
+  // m64_px pixels per batch -- traffic-bound layers, where LDS-DMA keeps more bytes in flight than conv_kernel's register ring
+  const int m64 = getenv("YL_CONV_GEMM_M64") ? atoi(getenv("YL_CONV_GEMM_M64")) : 1;
+  const long long m64_px = getenv("YL_CONV_GEMM_M64_PX") ? atoll(getenv("YL_CONV_GEMM_M64_PX")) : 100000;
+  const bool c64 = m64 && Cout == 64 && Cin % 32 == 0 && (long long)batch * Ho * Wo >= m64_px &&
+                   ((k == 1 && stride == 1 && Cin >= min_c) || (m64 >= 2 && k3));
+  if (!enable || !(k3 || (k == 1 && stride == 1 && Cin >= min_c)) || Cin % 32 || (Cout < min_c && !c64)) return;
   int MTW = 0;
-  if (Cout % 256 == 0) MTW = 8;
+  if (c64) MTW = 2;
+  else if (Cout % 256 == 0) MTW = 8;
   else if (Cout % 192 == 0) MTW = 6;
   else if (Cout % 128 == 0) MTW = 4;
   else return;
@@ -419,7 +454,7 @@ void conv_gemm_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, i
   int NWN = 2;
   const long long b8 = (npos + 255) / 256 * ncb;
   if (w8_blocks > 0 && MTW == 8 && b8 >= w8_blocks) NWN = 4;
-  if (w8_blocks < 0 && b8 >= -w8_blocks && (MTW != 6 || c->ksteps % 2 == 0)) NWN = 4;
+  if (w8_blocks < 0 && b8 >= -w8_blocks && (MTW != 6 || c->ksteps % 2 == 0) && MTW != 2) NWN = 4;  // (64-channel blocks: four waves only)
   const int BN = 64 * NWN;
   if (cin2) {  // upsampled second input: whole ring slices on either side of the split, one image wrap per pixel tile
     const bool even = c->ksteps % 2 == 0;
@@ -469,7 +504,8 @@ static int launch_gemm(const ConvArgs& a, size_t lds, hipStream_t s) {
   if (a.ksteps / gm_ks(MTW, NWN, EVEN) < gm_ns(MTW, NWN, EVEN) - 1) return fail(-3, "conv_gemm: too few K-slices for the ring");
   // persistent: as many workgroups as stay resident (every CU x two 4-wave or one 8-wave workgroup), each walks its tiles
   static const int persist = getenv("YL_CONV_GEMM_PERSIST") ? atoi(getenv("YL_CONV_GEMM_PERSIST")) : 1;
-  const int resident = device_cu_count() * (NWN == 2 ? 2 : 1);
+  static const int m64_wpc = getenv("YL_CONV_GEMM_M64_WPC") ? atoi(getenv("YL_CONV_GEMM_M64_WPC")) : 2;  // development: workgroups per CU of the 64-channel blocks
+  const int resident = device_cu_count() * (MTW == 2 ? m64_wpc : (NWN == 2 ? 2 : 1));
   const int grid = persist && a.nblocks > resident ? resident : a.nblocks;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * NWN), lds, s, a);
   YL_HIP(hipGetLastError());
@@ -479,7 +515,7 @@ static int launch_gemm(const ConvArgs& a, size_t lds, hipStream_t s) {
 int conv_gemm_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s) {
   const int MTW = cfg.gemm;
   const bool k3 = cfg.ntaps == 9;
-  if ((MTW != 4 && MTW != 6 && MTW != 8) || (cfg.ntaps != 1 && !k3) || (a.stride != 1 && !(k3 && a.stride == 2)) || a.out_f32 ||
+  if ((MTW != 2 && MTW != 4 && MTW != 6 && MTW != 8) || (cfg.ntaps != 1 && !k3) || (a.stride != 1 && !(k3 && a.stride == 2)) || a.out_f32 ||
       a.wpk2 || !cfg.uniform || (k3 && cfg.kord != 2) || a.out_w1 != a.Wo + 1 || a.Cout != cfg.ncb * 32 * MTW ||
       (a.stride == 1 && (a.in_w1 != a.out_w1 || a.in_img != a.out_img || a.in_g0 != a.out_g0)))
     return fail(-3, "conv_gemm: needs a plain bf16 1x1 or 3x3 conv, Cin % 32 == 0, Cout a multiple of the channel block");
@@ -514,6 +550,7 @@ int conv_gemm_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s
                             : (a.act ? launch_gemm<M, W, E, false, true>(a, lds, s) : launch_gemm<M, W, E, false, false>(a, lds, s)))
   if (NWN == 4) return MTW == 4 ? YL_GM3(4, 4, true) : MTW == 6 ? YL_GM3(6, 4, true) : YL_GM3(8, 4, true);
   if (MTW == 8) return YL_GM3(8, 2, true);
+  if (MTW == 2) return even ? YL_GM3(2, 2, true) : YL_GM3(2, 2, false);
   if (MTW == 4) return even ? YL_GM3(4, 2, true) : YL_GM3(4, 2, false);
   return even ? YL_GM3(6, 2, true) : YL_GM3(6, 2, false);
 #undef YL_GM3
