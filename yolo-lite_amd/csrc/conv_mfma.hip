@@ -27,6 +27,12 @@
                        // 4 (209-254 registers, still two waves per SIMD): layer 3 58.8 -> 54.8 us, but 48.3-48.9 k against
                        // 49.2-49.7 k images/s with 20 batches in flight
 #endif
+#ifndef YL_RING_NT2
+#define YL_RING_NT2 4  // ... at 32 / 16 pixels per wave (round 5: 8 / 16 measured, no launch changes by more than its noise)
+#endif
+#ifndef YL_RING_NT1
+#define YL_RING_NT1 8
+#endif
 #ifndef YL_CONV_WPE
 #define YL_CONV_WPE 2  // conv_kernel: at least this many waves per SIMD (caps its registers at 512 / YL_CONV_WPE).  3 (the
                        // 64-pixel tiles then spill from 177-203 to 168 registers): 47.0-47.1 k images/s against 48.2-48.9 k
@@ -135,7 +141,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, int block) {
       __builtin_amdgcn_make_buffer_rsrc((void*)a.res, (short)0, a.res ? a.res_bytes : 0, 0x00020000);
   const __amdgpu_buffer_rsrc_t rin2 =
       __builtin_amdgcn_make_buffer_rsrc((void*)a.in2, (short)0, UP ? a.in2_bytes : 0, 0x00020000);
-  constexpr int D = NT >= 4 ? YL_RING_NT4 : (NT == 2 ? 4 : 8);
+  constexpr int D = NT >= 4 ? YL_RING_NT4 : (NT == 2 ? YL_RING_NT2 : YL_RING_NT1);
   bf16x8 xr[D][NT];
   Patch<NT> P;
   const unsigned lane_off = UNIFORM ? (unsigned)g * a.in_plane : 0u;
@@ -171,6 +177,43 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, int block) {
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = bias_r[mt];
+    if (multi && a.slab2) {
+      // A filter larger than the slab budget, restaged in chunks of kchunk k-steps -- ASYNCHRONOUSLY (round 5): two chunk
+      // buffers, the next chunk travels to LDS by LDS-DMA (no registers, nobody waits) while this one is computed, ONE raw
+      // barrier per chunk.  (Copied through registers behind a barrier of its own, with a second barrier behind it, every
+      // restage stood still for a memory round trip: a 128 -> 128 stride-2 conv on a 20x20 map -- 36 k-steps, five chunks --
+      // spent more time restaging than computing.)  The DMA pieces of chunk c + 1 are this wave's OLDEST vector-memory
+      // operations when chunk c ends: the D x NT ring loads of the next k-steps are younger, so a counted wait that leaves
+      // exactly those in flight covers the pieces; a wave without a patch drains everything.
+      typedef __attribute__((address_space(3))) void lds_void_s;
+      const int chunk_bytes = a.kchunk * MT * 1024;
+      const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)wsrc, (short)0, (a.dbg & 4) ? 0u : (unsigned)a.ksteps * MT * 1024u, 0x00020000);
+      auto dma_chunk = [&](int kc, int buf) __attribute__((always_inline)) {
+        const int np = min(a.kchunk, a.ksteps - kc) * MT;  // 1 KiB pieces
+        for (int pc = wave; pc < np; pc += 4)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_s*)(smem + buf * chunk_bytes + pc * 1024), 16,
+                                                   (kc * MT + pc) * 1024 + lane * 16, 0, 0, 0);
+      };
+      dma_chunk(0, 0);
+      if (POST)  // the follow-up 1x1's filter: MT/2 k-steps x MT tiles, behind the two chunk buffers
+        copy_slab(reinterpret_cast<const bf16x8*>(a.wpk2), reinterpret_cast<bf16x8*>(smem + 2 * chunk_bytes), (MT / 2) * MT * 64, tid);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // (once per workgroup: the first chunk, and the first ring fill)
+      __builtin_amdgcn_s_barrier();
+      int c = 0;
+      for (int kc = 0; kc < a.ksteps; kc += a.kchunk, ++c) {
+        const int nk = min(a.kchunk, a.ksteps - kc);
+        const bool more = kc + a.kchunk < a.ksteps;
+        if (more) dma_chunk(kc + a.kchunk, (c + 1) & 1);  // (its buffer was last read in chunk c - 1: everybody has passed that barrier)
+        if (live) run_ksteps<KS, MT, NT, UNIFORM, D, UP>(a, rin, g, P, wl + (c & 1) * (chunk_bytes / 16), kc, nk, xr, acc, rin2);
+        if (more) {
+          if (live) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(D * NT) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+        }
+      }
+      first = false;
+    } else
     for (int kc = 0; kc < a.ksteps; kc += a.kchunk) {
       const int nk = min(a.kchunk, a.ksteps - kc);
       if (multi || first) {
@@ -217,7 +260,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, int block) {
 #pragma unroll
           for (int r = 0; r < 8; ++r) xb2[p][nt][r] = (__bf16)v[r];
         }
-      const bf16x8* wl2 = wl + min(a.kchunk, a.ksteps) * MT * 64;
+      const bf16x8* wl2 = wl + ((multi && a.slab2) ? 2 * a.kchunk : min(a.kchunk, a.ksteps)) * MT * 64;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const f32x4 b2 = *reinterpret_cast<const f32x4*>(a.bias2 + chan_in_block(MT, mt, g, 0));
@@ -765,7 +808,23 @@ int conv_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo,
   c->uniform = (cg % 4 == 0);
   c->ksteps = ksteps;
   c->kchunk = kchunk;
-  c->lds_bytes = (size_t)(kchunk < ksteps ? kchunk : ksteps) * MT * 1024;
+  // A chunked filter alternates between TWO chunk buffers filled by LDS-DMA (conv_body; YL_CONV_SLAB2: 1 = two buffers inside the
+  // same budget -- chunks of half the k-steps --, 2 = two buffers of the old chunk size, 0 = one buffer restaged through
+  // registers between two barriers, the form of rounds 1-4).  Chunks stay multiples of 4 k-steps: the activation ring of 32- and
+  // 64-pixel tiles is 4 / 2 k-steps deep (16-pixel tiles, ring of 8, keep the synchronous form).
+  c->slab2 = 0;
+  {
+    const int mode = getenv("YL_CONV_SLAB2") ? atoi(getenv("YL_CONV_SLAB2")) : 1;
+    if (mode > 0 && kchunk < ksteps && NT >= 2 && YL_RING_NT4 <= 4 && YL_RING_NT2 <= 4) {
+      if (mode == 1) {
+        kchunk = (kchunk / 2) & ~3;
+        if (kchunk < 4) kchunk = 4;
+      }
+      c->kchunk = kchunk;
+      c->slab2 = 1;
+    }
+  }
+  c->lds_bytes = (size_t)(kchunk < ksteps ? (c->slab2 ? 2 * kchunk : kchunk) : ksteps) * MT * 1024;
   c->post = post;
   if (post) {
     // follow-up 1x1 in the epilogue: this wave must hold every channel of the first conv
@@ -1097,6 +1156,7 @@ static int conv_prepare(const ConvConfig& cfg, ConvArgs& a, int batch) {
   a.cg = cfg.cg;
   a.ksteps = cfg.ksteps;
   a.kchunk = cfg.kchunk;
+  a.slab2 = cfg.slab2;
   a.ntaps = cfg.ntaps;
   a.kord = cfg.kord;
   a.kkn = cfg.cg >> 2;

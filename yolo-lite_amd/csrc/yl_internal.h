@@ -116,6 +116,7 @@ struct ConvArgs {
   int out_pitch, out_coff;                  // fp32 NHWC output only
   int Cin, Cout, stride, act, out_f32;
   int ncb, cg, ksteps, kchunk, ntaps;       // k-steps in total / per LDS slab
+  int slab2;                                // 1: a chunked filter (kchunk < ksteps) is restaged asynchronously through TWO chunk buffers (conv_body)
   int kord;                                 // 1: plane-major K order (3x3 only; per-lane tap / plane, the non-UNIFORM fetch)
   int npatches, ppw;                        // wave patches in total / patches per wave
   int kkn;                                  // k-steps per tap (uniform case)
@@ -146,6 +147,7 @@ struct ConvConfig {
   int reg;           // > 0: conv3_reg_kernel (filter in registers) with this many 16-pixel column tiles per wave
   int pair;          // > 0: conv3_pair_kernel (64 -> 64: filter halves in the registers of two waves per SIMD)
   int cs;            // 1: conv3_cs_kernel (64 -> 64 3x3: filter in registers, output channels split between wave pairs)
+  int slab2;         // 1: kchunk < ksteps and the chunks alternate between two LDS buffers, filled by LDS-DMA (conv_kernel, round 5)
   int kord;          // 1: K runs plane-major (k-group = plane * 9 + tap) instead of tap-major (tap * planes + plane), see conv_choose
   int gemm;          // > 0: conv_gemm_kernel (wide 1x1: both operands staged through LDS) with this many 16-channel tiles per wave
   int gemm_nwn;      // ... and this many waves along the pixels (2: 128-pixel tiles, 4: 256-pixel tiles)
