@@ -165,15 +165,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int kc = 0; kc < a.ksteps; kc += a.kchunk) {
+    // (a.slab2, round 5: a chunked filter alternates between two chunk buffers filled by LDS-DMA -- conv_mfma.hip conv_body: one raw
+    // barrier per chunk behind a counted wait that leaves the activation ring, D k-steps x 2 NT loads, in flight; one k-loop call site)
+    typedef __attribute__((address_space(3))) void lds_void_8;
+    const bool async = multi && a.slab2;
+    const int chunk_bytes = a.kchunk * MT * 2048;
+    auto dma_chunk = [&](int kc, int buf) __attribute__((always_inline)) {
+      const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)wsrc, (short)0, (unsigned)a.ksteps * MT * 2048u, 0x00020000);
+      const int np = min(a.kchunk, a.ksteps - kc) * MT * 2;  // 1 KiB pieces
+      for (int pc = wave; pc < np; pc += 4)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_8*)(smem8 + buf * chunk_bytes + pc * 1024), 16,
+                                                 (kc * MT * 2 + pc) * 1024 + lane * 16, 0, 0, 0);
+    };
+    int c = 0;
+    for (int kc = 0; kc < a.ksteps; kc += a.kchunk, ++c) {
       const int nk = min(a.kchunk, a.ksteps - kc);
-      if (multi || first) {
+      const bool more = kc + a.kchunk < a.ksteps;
+      if (async) {
+        if (first) {
+          dma_chunk(0, 0);
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          first = false;
+        }
+        if (more) dma_chunk(kc + a.kchunk, (c + 1) & 1);
+      } else if (multi || first) {
         if (!first) __syncthreads();
         copy_slab(wsrc + (size_t)kc * MT * 128, reinterpret_cast<bf16x8*>(smem8), nk * MT * 128, tid);
         __syncthreads();
         first = false;
       }
-      if (live) run_ksteps8<KS, MT, NT, UNIFORM, D>(a, rin, g, P, wl, kc, nk, xr, acc);
+      if (live) run_ksteps8<KS, MT, NT, UNIFORM, D>(a, rin, g, P, wl + ((async && (c & 1)) ? chunk_bytes / 16 : 0), kc, nk, xr, acc);
+      if (async && more) {
+        if (live) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(D * 2 * NT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
     }
     if (!live) break;
     int opix[NT];
@@ -301,8 +328,21 @@ int conv_f8_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int 
   c->gemm = 0;
   c->reg = c->pair = c->cs = 0;
   c->ksteps = ksteps;
+  // (YL_F8_SLAB2: 1 = a chunked filter alternates between two buffers of half the k-steps, filled by LDS-DMA; 2 = two buffers of the
+  // old chunk size; 0 = restaged through registers between two barriers)
+  c->slab2 = 0;
+  {
+    const int mode = getenv("YL_F8_SLAB2") ? atoi(getenv("YL_F8_SLAB2")) : 1;
+    if (mode > 0 && kchunk < ksteps) {
+      if (mode == 1) {
+        kchunk = (kchunk / 2) & ~1;
+        if (kchunk < 2) kchunk = 2;
+      }
+      c->slab2 = 1;
+    }
+  }
   c->kchunk = kchunk;
-  c->lds_bytes = (size_t)kchunk * step_bytes;
+  c->lds_bytes = (size_t)(c->slab2 ? 2 * kchunk : kchunk) * step_bytes;
   c->post = 0;
   c->tile = 0;
   c->wpk_elems = (size_t)ncb * ksteps * MT * 2048;  // bytes
@@ -384,6 +424,7 @@ int conv_f8_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s) 
   a.cg = cfg.cg;
   a.ksteps = cfg.ksteps;
   a.kchunk = cfg.kchunk;
+  a.slab2 = cfg.slab2;
   a.ntaps = cfg.ntaps;
   a.kord = cfg.kord;
   a.kkn = cfg.cg >> 3;

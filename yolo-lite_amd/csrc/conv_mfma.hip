@@ -177,46 +177,39 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, int block) {
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = bias_r[mt];
-    if (multi && a.slab2) {
-      // A filter larger than the slab budget, restaged in chunks of kchunk k-steps -- ASYNCHRONOUSLY (round 5): two chunk
-      // buffers, the next chunk travels to LDS by LDS-DMA (no registers, nobody waits) while this one is computed, ONE raw
-      // barrier per chunk.  (Copied through registers behind a barrier of its own, with a second barrier behind it, every
-      // restage stood still for a memory round trip: a 128 -> 128 stride-2 conv on a 20x20 map -- 36 k-steps, five chunks --
-      // spent more time restaging than computing.)  The DMA pieces of chunk c + 1 are this wave's OLDEST vector-memory
-      // operations when chunk c ends: the D x NT ring loads of the next k-steps are younger, so a counted wait that leaves
-      // exactly those in flight covers the pieces; a wave without a patch drains everything.
-      typedef __attribute__((address_space(3))) void lds_void_s;
-      const int chunk_bytes = a.kchunk * MT * 1024;
+    // A filter larger than the slab budget is restaged in chunks of kchunk k-steps.  a.slab2 (round 5): ASYNCHRONOUSLY -- two chunk
+    // buffers, the next chunk travels to LDS by LDS-DMA (no registers, nobody waits) while this one is computed, ONE raw barrier
+    // per chunk.  (Copied through registers behind a barrier of its own, with a second barrier behind it, every restage stood
+    // still for a memory round trip.)  The DMA pieces of chunk c + 1 are this wave's OLDEST vector-memory operations when chunk
+    // c ends: the D x NT ring loads of the next k-steps are younger, so a counted wait that leaves exactly those in flight
+    // covers the pieces; a wave without a patch drains everything.  One k-loop call site serves both forms (two inlined copies
+    // of it cost every instantiation ~36 registers).
+    typedef __attribute__((address_space(3))) void lds_void_s;
+    const bool async = multi && a.slab2;
+    const int chunk_bytes = a.kchunk * MT * 1024;
+    auto dma_chunk = [&](int kc, int buf) __attribute__((always_inline)) {
       const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
           (void*)wsrc, (short)0, (a.dbg & 4) ? 0u : (unsigned)a.ksteps * MT * 1024u, 0x00020000);
-      auto dma_chunk = [&](int kc, int buf) __attribute__((always_inline)) {
-        const int np = min(a.kchunk, a.ksteps - kc) * MT;  // 1 KiB pieces
-        for (int pc = wave; pc < np; pc += 4)
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_s*)(smem + buf * chunk_bytes + pc * 1024), 16,
-                                                   (kc * MT + pc) * 1024 + lane * 16, 0, 0, 0);
-      };
-      dma_chunk(0, 0);
-      if (POST)  // the follow-up 1x1's filter: MT/2 k-steps x MT tiles, behind the two chunk buffers
-        copy_slab(reinterpret_cast<const bf16x8*>(a.wpk2), reinterpret_cast<bf16x8*>(smem + 2 * chunk_bytes), (MT / 2) * MT * 64, tid);
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // (once per workgroup: the first chunk, and the first ring fill)
-      __builtin_amdgcn_s_barrier();
-      int c = 0;
-      for (int kc = 0; kc < a.ksteps; kc += a.kchunk, ++c) {
-        const int nk = min(a.kchunk, a.ksteps - kc);
-        const bool more = kc + a.kchunk < a.ksteps;
-        if (more) dma_chunk(kc + a.kchunk, (c + 1) & 1);  // (its buffer was last read in chunk c - 1: everybody has passed that barrier)
-        if (live) run_ksteps<KS, MT, NT, UNIFORM, D, UP>(a, rin, g, P, wl + (c & 1) * (chunk_bytes / 16), kc, nk, xr, acc, rin2);
-        if (more) {
-          if (live) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(D * NT) : "memory");
-          else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_s_barrier();
-        }
-      }
-      first = false;
-    } else
-    for (int kc = 0; kc < a.ksteps; kc += a.kchunk) {
+      const int np = min(a.kchunk, a.ksteps - kc) * MT;  // 1 KiB pieces
+      for (int pc = wave; pc < np; pc += 4)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_s*)(smem + buf * chunk_bytes + pc * 1024), 16,
+                                                 (kc * MT + pc) * 1024 + lane * 16, 0, 0, 0);
+    };
+    int c = 0;
+    for (int kc = 0; kc < a.ksteps; kc += a.kchunk, ++c) {
       const int nk = min(a.kchunk, a.ksteps - kc);
-      if (multi || first) {
+      const bool more = kc + a.kchunk < a.ksteps;
+      if (async) {
+        if (first) {  // (once per workgroup: the first chunk, and the follow-up 1x1's filter behind the two chunk buffers)
+          dma_chunk(0, 0);
+          if (POST)
+            copy_slab(reinterpret_cast<const bf16x8*>(a.wpk2), reinterpret_cast<bf16x8*>(smem + 2 * chunk_bytes), (MT / 2) * MT * 64, tid);
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          first = false;
+        }
+        if (more) dma_chunk(kc + a.kchunk, (c + 1) & 1);  // (its buffer was last read in chunk c - 1: everybody has passed that barrier)
+      } else if (multi || first) {
         if (!first) __syncthreads();  // every wave is done with the previous slab
         if (!(a.dbg & 4)) copy_slab(wsrc + (size_t)kc * MT * 64, reinterpret_cast<bf16x8*>(smem), nk * MT * 64, tid);
         if (POST && first)  // the follow-up 1x1's filter: MT/2 k-steps x MT tiles, right behind the slab
@@ -225,7 +218,12 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, int block) {
         __syncthreads();
         first = false;
       }
-      if (live) run_ksteps<KS, MT, NT, UNIFORM, D, UP>(a, rin, g, P, wl, kc, nk, xr, acc, rin2);
+      if (live) run_ksteps<KS, MT, NT, UNIFORM, D, UP>(a, rin, g, P, wl + ((async && (c & 1)) ? chunk_bytes / 16 : 0), kc, nk, xr, acc, rin2);
+      if (async && more) {
+        if (live) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(D * NT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
     }
     if (!live) break;
     // next patch: addresses + first ring fill go out before this patch's stores
