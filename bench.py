@@ -814,6 +814,15 @@ def main():
         except Exception as e:  # the probe must never cost the bench line
             probe = {"error": repr(e)}
         res["runtime"] = {"knobs": KNOBS, "graph_branch_probe": probe}
+        if sharded:
+            # N > 1: the per-GPU program is the one of N = 1 (replicas): its roofline block is measured on rank 0 the same way (the
+            # other ranks wait at the closing barrier); `cpu_baseline` is an N = 1 object
+            try:
+                rows = eng.profile_detect((x * 255).to(torch.uint8), conf, iou, max_det=max_det, iters=10)
+                res["roofline"], res["kernels"] = roofline_from_profile(rows, B, cfg_key)
+                res["roofline"]["note"] = "per-GPU program, measured on rank 0 after the timed region (every rank runs the same kernels on its shard)"
+            except Exception as e:  # never at the cost of the line
+                res["roofline"] = {"error": repr(e)}
         if not sharded:
             rows = eng.profile_detect(x8, conf, iou, max_det=max_det, iters=20)
             roof, kernels = roofline_from_profile(rows, B, cfg_key)

@@ -16,6 +16,8 @@ timeout -k 10 ${LIMIT:-500} python3 $R/bench.py $BA --profile-out $OUT/per_op.js
 # the profiled passes run the THROUGHPUT profile of the program only (the latency profile's extra launches -- the predictor's per-call
 # engine, the bench's one_batch_profile engine -- would mix another population into the per-kernel averages)
 export YL_BENCH_ONE_BATCH_PROFILE=0 YL_PREDICT_ONE_BATCH_PROFILE=0
+# (no extra warm-up rounds under the profiler: every dispatch is a row of the counter CSVs, and gpurun copies back 64 MiB at most)
+export YL_BENCH_WARM_ROUNDS=0
 # (one batch in flight: a kernel's duration is its own -- with 20 batches in flight, all started within 0.2 ms by the issue threads,
 # the same kernels' wall durations stretch 3 x (conv1x1: 13 -> 44 us) while the throughput is unchanged)
 echo "pass --stats $(date +%T)"

@@ -8,6 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+export YL_BENCH_WARM_ROUNDS=0  # (every dispatch is a row of the profiler CSVs; gpurun copies back 64 MiB at most)
 ( while true; do sleep 60; echo "heartbeat $(date +%T)"; done ) &
 HB=$!
 timeout -k 10 ${LIMIT:-400} rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py $BA --steps 10 --warmup 2 --no-cpu-baseline > $OUT/trace.log 2>&1
