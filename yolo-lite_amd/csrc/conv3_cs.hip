@@ -19,9 +19,35 @@
 //   pieces are issued -> epilogue of this tile (its stores and the DMA's flight overlap).
 #include "conv_common.h"
 
+#ifndef YL_CS_DPP
+#define YL_CS_DPP 0  // build switch (round 5 experiment): 1 = column taps by DPP shifts of ONE row fragment, 0 = every tap its own LDS read.
+                     // MEASURED SLOWER: 64 -> 64 @80x80 batch 32 34.1 us against 27.5 us (12.5 against 10.5 us @40x40), bit-identical --
+                     // the k-loop is LDS-bound (0.5 fragment reads per MFMA), and 384 DPP moves per 144 MFMAs in the same wave cost
+                     // more issue time than the 42 LDS reads they replace: vector work between a wave's own MFMAs does not hide
+                     // behind them here (the same finding as conv3_reg's interleaved epilogue, NOTEBOOK section 4)
+#endif
 namespace yl {
 
 typedef __attribute__((address_space(3))) void lds_void_c;
+
+// A B fragment (16 positions x 4 k-groups: lane = (position n, k-group g), one 16-lane row per k-group) shifted by S positions:
+// lane n takes position n + S of `lo` (row_shl:S), the last S lanes of a row the first S positions of `hi`, the next 16
+// positions (row_shr:16-S).  Two DPP moves per register instead of an LDS read: in the guarded layout the three column taps
+// of a row are ONE run of positions, and the k-loop of this kernel is bound by the LDS array (two 32-channel waves read every
+// fragment once each: 0.5 reads per MFMA), not by the vector ALU, which idles while it runs.
+template <int S>
+__device__ __forceinline__ bf16x8 frag_shift(const bf16x8& lo, const bf16x8& hi) {
+  static_assert(S == 1 || S == 2, "column taps");
+  const u32x4 a = __builtin_bit_cast(u32x4, lo), b = __builtin_bit_cast(u32x4, hi);
+  u32x4 r;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    // (bound_ctrl off: a lane whose source lies outside its row keeps `old`)
+    const int edge = __builtin_amdgcn_update_dpp(0, (int)b[q], 0x110 + (16 - S), 0xf, 0xf, false);   // row_shr:16-S
+    r[q] = (unsigned)__builtin_amdgcn_update_dpp(edge, (int)a[q], 0x100 + S, 0xf, 0xf, false);        // row_shl:S
+  }
+  return __builtin_bit_cast(bf16x8, r);
+}
 
 constexpr int CS_L = 128;  // positions per tile (two 64-position columns)
 
@@ -84,6 +110,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = bias_r[mt];
+#if YL_CS_DPP
+    // Two passes over two 16-position tiles each (the filter sits in registers: a pass costs no operand traffic).  Per row of taps
+    // and channel half THREE fragments are read -- the run of 48 positions that starts one position left of the tiles -- and the
+    // column taps dx = 1, 2 are its shifts: 6 LDS reads and 64 DPP moves per 24 MFMAs (0.25 reads per MFMA; 0.5 before).  The
+    // MFMAs keep conv_kernel's k order (tap-major, channel half inside): bit-identical.
+    if (!(a.dbg & 4))
+#pragma unroll
+    for (int hp = 0; hp < NT / 2; ++hp)
+#pragma unroll
+      for (int dy = 0; dy < 3; ++dy) {
+        bf16x8 F[2][3];
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+            F[ch][j] = *reinterpret_cast<const bf16x8*>(tb + ch * half_bytes + dy * row_bytes + (2 * hp + j) * 256);
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+#pragma unroll
+          for (int ch = 0; ch < 2; ++ch) {
+            const int ks = 2 * (3 * dy + dx) + ch;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const bf16x8 xf = dx == 0 ? F[ch][u] : (dx == 1 ? frag_shift<1>(F[ch][u], F[ch][u + 1]) : frag_shift<2>(F[ch][u], F[ch][u + 1]));
+#pragma unroll
+              for (int mt = 0; mt < 2; ++mt)
+                acc[mt][2 * hp + u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][mt], xf, acc[mt][2 * hp + u], 0, 0, 0);
+            }
+          }
+      }
+#else
     if (!(a.dbg & 4))
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -98,6 +155,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
         for (int nt = 0; nt < NT; ++nt)
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][mt], xb[nt], acc[mt][nt], 0, 0, 0);
     }
+#endif
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // everybody has read the tile: the buffer may be refilled
     if (i + 1 < nmine && !(a.dbg & 1)) stage(t + G);
