@@ -534,6 +534,46 @@ def test_conv3_cs_vs_torch_and_direct(gpu_device, monkeypatch, h, w, act, res):
     assert torch.equal(got, direct), f"cs vs direct kernel: max diff {float((got - direct).abs().max())}"
 
 
+SW_CASES = [
+    # H, W, act, res     conv3_sw_kernel (64 -> 64: a wave walks down a 16-pixel strip, fragments of three rows as a rolling window)
+    (80, 80, True, False),        # the layer it is for (Detect box branch, level 0): 5 strips x 8 band pairs per image
+    (10, 16, True, False),        # one tile per image
+    (20, 48, False, False),       # no activation
+    (160, 32, True, False),       # tall and narrow
+    (40, 64, True, True),         # a residual: stays on the linear-tile kernel (conv3_cs), same bits
+]
+
+
+@pytest.mark.parametrize("h,w,act,res", SW_CASES)
+def test_conv3_sw_vs_torch_and_direct(gpu_device, monkeypatch, h, w, act, res):
+    """The strip-walk kernel (csrc/conv3_sw.hip: output channels split between wave pairs like conv3_cs, the activation fragments
+    of three rows reused while a wave walks down its strip, double-buffered LDS-DMA staging with per-lane source addresses)
+    against torch, and against conv_kernel: same operands, k order and accumulation chain -> bit-identical.  Batch 7 with an
+    odd tile count exercises the persistent loop's last, partly filled round."""
+    g = torch.Generator().manual_seed(9100 + h + w)
+    B = 7
+    x = _rand(g, B, 64, h, w)
+    wt = _rand(g, 64, 64, 3, 3, scale=1.0 / math.sqrt(64 * 9))
+    b = torch.randn(64, generator=g) * 0.5
+    ref = F.conv2d(x, wt, b, 1, 1)
+    if act:
+        ref = F.silu(ref)
+    r = None
+    if res:
+        r = _rand(g, *ref.shape)
+        ref = ref + r
+    monkeypatch.setenv("YL_CONV_SW", "1")
+    monkeypatch.setenv("YL_CONV_SW_MIN", "1")
+    monkeypatch.setenv("YL_CONV_CS_MIN", "1")
+    got = run_conv(gpu_device, x, wt, b, 3, 1, act, r, expect_kernel="conv3x3_sw_mfma")
+    _assert_close_bf16(got, ref, f"sw conv {h}x{w}")
+    monkeypatch.setenv("YL_CONV_SW", "0")
+    monkeypatch.setenv("YL_CONV_CS", "0")
+    monkeypatch.setenv("YL_CONV_REG", "0")
+    direct = run_conv(gpu_device, x, wt, b, 3, 1, act, r, expect_kernel="conv3x3_mfma")
+    assert torch.equal(got, direct), f"sw vs direct kernel: max diff {float((got - direct).abs().max())}"
+
+
 PAIR_CASES = [
     # H, W, act, res     conv3_pair_kernel (64 -> 64: filter halves in the registers of two waves per SIMD), forced onto small maps
     (20, 20, True, False),

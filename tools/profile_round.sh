@@ -27,8 +27,10 @@ timeout -k 10 ${LIMIT:-300} rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O
 echo "pass WRITE_SIZE $(date +%T)"
 timeout -k 10 ${LIMIT:-300} rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py $BA --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs > $OUT/pmc_write.log 2>&1
 # independent read-side count (round 3): L2 misses x 128-byte lines, and the fabric read requests with their 32-byte share
-echo "pass TCC_MISS_sum $(date +%T)"
-timeout -k 10 ${LIMIT:-300} rocprofv3 --pmc TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --output-format csv -d $OUT/pmc_miss -- python3 $R/bench.py $BA --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs > $OUT/pmc_miss.log 2>&1
+# (SKIP_MISS=1: without this cross-check pass -- its CSV is three counters wide, and gpurun copies back 64 MiB at most: the
+# batch-64 / 1280x1280 configurations do not fit with it)
+[ "${SKIP_MISS:-0}" = "1" ] || echo "pass TCC_MISS_sum $(date +%T)"
+[ "${SKIP_MISS:-0}" = "1" ] || timeout -k 10 ${LIMIT:-300} rocprofv3 --pmc TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum --output-format csv -d $OUT/pmc_miss -- python3 $R/bench.py $BA --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs > $OUT/pmc_miss.log 2>&1
 # matrix-pipe occupancy per kernel: busy cycles summed over the 1024 SIMDs / (1024 x kernel cycles); one batch at a time
 # (--streams 1) so that GRBM_GUI_ACTIVE of a dispatch is that kernel's own duration.  (Round 4: this pass crashed the profiled process
 # in 4 of 6 attempts until the hot path's captured hipMemsetAsync was replaced by a kernel -- csrc/nms.hip zero_i32 -- and ran clean since.)

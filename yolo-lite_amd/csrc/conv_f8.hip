@@ -326,7 +326,7 @@ int conv_f8_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int 
   c->kord = (kord_px > 0 && k == 3 && (long long)Ho * Wo >= kord_px) ? 1 : 0;
   if (c->kord) c->uniform = 0;
   c->gemm = 0;
-  c->reg = c->pair = c->cs = 0;
+  c->reg = c->pair = c->cs = c->sw = 0;
   c->ksteps = ksteps;
   // (YL_F8_SLAB2: 1 = a chunked filter alternates between two buffers of half the k-steps, filled by LDS-DMA; 2 = two buffers of the
   // old chunk size; 0 = restaged through registers between two barriers)

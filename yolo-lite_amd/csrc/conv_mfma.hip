@@ -844,6 +844,7 @@ int conv_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo,
   c->name = k == 3 ? (stride == 2 ? "conv3x3s2_mfma" : "conv3x3_mfma") : "conv1x1_mfma";
   c->gemm = 0;
   c->cs = 0;
+  c->sw = 0;
   // K order of the stride-2 3x3 convs with >= 64 input channels (layers 3, 5, 7, 17, 20): PLANE-major.  In tap-major order a
   // workgroup sweeps its whole input footprint (8-32 planes) once per tap, nine times in all, with a reuse distance far beyond
   // L1 and -- 64 workgroups per XCD -- beyond the 4 MB L2: rocprofv3 (profiles/r03_summary.md) shows model.3 fetching 225 MB for
@@ -858,7 +859,8 @@ int conv_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo,
   conv3_reg_choose(batch, Cin, Cout, k, stride, Ho, Wo, post, c);   // ... or with the filter in registers
   conv3_pair_choose(batch, Cin, Cout, k, stride, Ho, Wo, post, c);  // ... 64 -> 64: filter halves in two waves per SIMD
   conv3_cs_choose(batch, Cin, Cout, k, stride, Ho, Wo, post, c);    // ... 64 -> 64: output channels split, two workgroups per CU
-  if (c->kord && (c->reg || c->tile || c->pair || c->cs)) {  // those kernels read the filter tap-major
+  conv3_sw_choose(batch, Cin, Cout, k, stride, Ho, Wo, post, c);    // ... on maps of whole 16-pixel strips: fragments reused across rows
+  if (c->kord && (c->reg || c->tile || c->pair || c->cs || c->sw)) {  // those kernels read the filter tap-major
     c->kord = 0;
     c->uniform = (cg % 4 == 0);
   }
@@ -1198,7 +1200,8 @@ int conv_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s) {
   const bool plain = a.stride == 1 && !a.out_f32 && !a.in2 && !a.wpk2 && !a.out8 && a.in_w1 == a.out_w1 &&
                      a.in_img == a.out_img && a.in_g0 == a.out_g0 && a.in_w1 == a.Wo + 1;
   if (cfg.gemm) return conv_gemm_launch(cfg, a, batch, s);  // chosen by the engine with the views known: no fallback needed
-  if (cfg.cs && plain) return conv3_cs_launch(cfg, a, batch, s);
+  if (cfg.sw && plain && !a.res) return conv3_sw_launch(cfg, a, batch, s);
+  if ((cfg.cs || cfg.sw) && plain) return conv3_cs_launch(cfg, a, batch, s);  // (sw with a residual: the linear-tile form)
   if (cfg.pair && plain) return conv3_pair_launch(cfg, a, batch, s);
   if (cfg.reg && plain) return conv3_reg_launch(cfg, a, batch, s);
   if (cfg.tile && a.act && plain) return conv3_tile_launch(cfg, a, batch, s);  // (a conv without SiLU stays on conv_kernel)
@@ -1209,7 +1212,7 @@ int conv_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s) {
 // The tiling of a conv that joins a group launch: plain conv_kernel (no register / tile variants), NT forced to the
 // group's common pixel-tile count, one patch per wave.
 void conv_retile_for_group(ConvConfig* c, int NT, int batch, int Ho, int Wo) {
-  c->reg = c->tile = c->pair = c->cs = 0;
+  c->reg = c->tile = c->pair = c->cs = c->sw = 0;
   c->NT = NT;
   c->npatches = (int)(((long long)batch * Ho * Wo + 16 * NT - 1) / (16 * NT));
   c->ppw = 1;
@@ -1222,7 +1225,7 @@ bool conv_group_compatible(const ConvConfig* cfg, const ConvArgs* a, int n) {
   for (int i = 0; i < n; ++i) {
     if (cfg[i].ntaps != 9 || cfg[i].MT != 4 || cfg[i].uniform != cfg[0].uniform || cfg[i].post != cfg[0].post || cfg[i].NT != cfg[0].NT ||
         (cfg[i].NT != 2 && cfg[i].NT != 4) || a[i].in2 || a[i].out8 || a[i].out_f32 || a[i].res || a[i].stride != 1 ||
-        cfg[i].reg || cfg[i].tile || cfg[i].pair || cfg[i].cs)
+        cfg[i].reg || cfg[i].tile || cfg[i].pair || cfg[i].cs || cfg[i].sw)
       return false;
   }
   return true;

@@ -487,7 +487,7 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
             r.cfg.npatches = (int)(((long long)batch * o.out.H * o.out.W + 31) / 32);
             r.cfg.wpk_elems = (size_t)r.cfg.ksteps * 8 * 64 * 8;
             r.cfg.lds_bytes = (size_t)r.cfg.ksteps * 8 * 1024;
-            r.cfg.tile = r.cfg.reg = r.cfg.pair = r.cfg.cs = r.cfg.kord = 0;
+            r.cfg.tile = r.cfg.reg = r.cfg.pair = r.cfg.cs = r.cfg.sw = r.cfg.kord = 0;
           }
           if (r.cfg.NT > 2) {
             r.cfg.NT = 2;

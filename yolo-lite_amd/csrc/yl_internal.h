@@ -147,6 +147,7 @@ struct ConvConfig {
   int reg;           // > 0: conv3_reg_kernel (filter in registers) with this many 16-pixel column tiles per wave
   int pair;          // > 0: conv3_pair_kernel (64 -> 64: filter halves in the registers of two waves per SIMD)
   int cs;            // 1: conv3_cs_kernel (64 -> 64 3x3: filter in registers, output channels split between wave pairs)
+  int sw;            // 1: conv3_sw_kernel (the same split, a wave walks down a 16-pixel strip and reuses the fragments of three rows)
   int slab2;         // 1: kchunk < ksteps and the chunks alternate between two LDS buffers, filled by LDS-DMA (conv_kernel, round 5)
   int kord;          // 1: K runs plane-major (k-group = plane * 9 + tap) instead of tap-major (tap * planes + plane), see conv_choose
   int gemm;          // > 0: conv_gemm_kernel (wide 1x1: both operands staged through LDS) with this many 16-channel tiles per wave
@@ -172,6 +173,9 @@ int conv3_reg_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s
 // conv3_cs.hip: 3x3 stride-1 64 -> 64 convs, output channels split between wave pairs, two workgroups per CU
 void conv3_cs_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, int post, ConvConfig* cfg);
 int conv3_cs_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s);
+// conv3_sw.hip: ... and the activation fragments reused across rows (strip walk); maps of whole strips, no residual
+void conv3_sw_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, int post, ConvConfig* cfg);
+int conv3_sw_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s);
 // conv3_pair.hip: 3x3 stride-1 64 -> 64 convs, K split between the two waves of a SIMD
 void conv3_pair_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, int post, ConvConfig* cfg);
 int conv3_pair_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s);
