@@ -103,7 +103,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
 
   for (int i = 0; i < nmine; ++i) {
     const int t = wg + i * G;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces of this tile (and the previous tile's stores)
+    // my pieces of this tile have landed: they are OLDER than the previous tile's NT epilogue stores (issued behind them), so a
+    // counted wait covers them and leaves the stores in flight (vmcnt(0) stood still for the stores' round trip once per tile)
+#ifndef YL_CS_WAIT_ALL
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NT) : "memory");
+#else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     __builtin_amdgcn_s_barrier();
     f32x4 acc[2][NT];
 #pragma unroll

@@ -100,7 +100,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
 
   for (int i = 0; i < nmine; ++i) {
     const int t = wg + i * G;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // my pieces of this tile (and the previous tile's stores)
+    // my pieces of this tile (issued before the previous tile was computed: older than its SW_R epilogue stores, which stay in flight)
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SW_R) : "memory");
     __builtin_amdgcn_s_barrier();                     // the tile has landed; everybody has left the other buffer
     if (i + 1 < nmine) stage(t + G, (i + 1) & 1);
     int img, y0, x0;
