@@ -241,6 +241,10 @@ __device__ __forceinline__ void cs2_tile(const ConvArgs& a, const bf16x8 (&wf)[1
   YL_STAMP(a.stamps, (int)(blockDim.x >> 6), wave, lane, stamp_id);
   mid();
   if (a.dbg & 2) return;
+  // (Round 5, measured and NOT kept: the (row, column) of fragments 1.. by carrying from fragment 0's instead of two magic
+  // divisions each, and silu8's packed multiplies / adds -- 100 of ~445 issue cycles per fragment fewer, and 28.9-29.3 us against
+  // 27.0-27.5 us stand-alone (each change alone ~+1 us): the epilogue is bound by its dependency chains, not by issue; the
+  // independent per-fragment form gives the scheduler more to interleave)
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int r = r0 + nt * 16 + n;  // position relative to g0
