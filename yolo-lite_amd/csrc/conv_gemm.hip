@@ -33,7 +33,8 @@
 #include "conv_common.h"
 
 #ifndef YL_GEMM_ABL
-#define YL_GEMM_ABL 0  // development build switch: timing ablations of the main loop (wrong results)
+#define YL_GEMM_ABL 0  // development build switch: timing ablations of the main loop (wrong results): 2 no operand traffic, 4 no fragment
+                       // reads, 8 nothing stored, 16 activations always from the first 8192 positions (L2 hits)
 #endif
 namespace yl {
 
@@ -52,10 +53,24 @@ typedef __attribute__((address_space(3))) void lds_void_g;
 #ifndef YL_GM2_NS
 #define YL_GM2_NS 3
 #endif
+#ifndef YL_GM6_KS
+#define YL_GM6_KS 2  // development build switches: ring shapes of the 192-channel blocks (even K), four waves / eight waves
+#endif
+#ifndef YL_GM6_NS
+#define YL_GM6_NS 2
+#endif
+#ifndef YL_GM6W_KS
+#define YL_GM6W_KS 2
+#endif
+#ifndef YL_GM6W_NS
+#define YL_GM6W_NS 2
+#endif
 constexpr int gm_ks(int MTW, int NWN, bool even) {
+  if (MTW == 6 && even) return NWN == 4 ? YL_GM6W_KS : YL_GM6_KS;
   return NWN == 4 ? (MTW == 6 ? 2 : 1) : (MTW == 2 && even ? YL_GM2_KS : ((MTW == 8 || !even) ? 1 : 2));
 }
 constexpr int gm_ns(int MTW, int NWN, bool even) {
+  if (MTW == 6 && even) return NWN == 4 ? YL_GM6W_NS : YL_GM6_NS;
   return NWN == 4 ? (MTW == 6 ? 2 : 3) : (MTW == 8 ? 3 : (even ? (MTW == 2 ? YL_GM2_NS : 2) : 4));
 }
 size_t conv_gemm_lds_bytes(int MTW, int NWN, bool even) {
@@ -190,7 +205,8 @@ __global__ __launch_bounds__(128 * NWN) __attribute__((amdgpu_waves_per_eu(2))) 
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rin2, (lds_void_g*)(gsm + sbase + ASTAGE + (unsigned)jb * 1024u), 16,
                                                    (int)(x.off2 + (unsigned)gp * a.in2_plane + past), 0, 0, 0);
         } else {
-          const unsigned src = (unsigned)(gp - split_planes) * a.in_plane + (unsigned)(x.q0 + h * 64) * 16u;
+          // (ABL 16: timing ablation, every pixel tile reads the first 8192 positions' activations -- all L2 hits)
+          const unsigned src = (unsigned)(gp - split_planes) * a.in_plane + (unsigned)(((YL_GEMM_ABL & 16) ? (x.q0 & 0x1fff) : x.q0) + h * 64) * 16u;
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void_g*)(gsm + sbase + ASTAGE + (unsigned)jb * 1024u), 16,
                                                    (int)(lane16 + src + past), 0, 0, 0);
         }
@@ -253,6 +269,9 @@ __global__ __launch_bounds__(128 * NWN) __attribute__((amdgpu_waves_per_eu(2))) 
   // slices stay in flight; epilogue stores of the previous tile that are still on their way only make the wait stricter),
   // all my LDS reads done, barrier -- now everybody's pieces of slice i have landed and nobody reads the slice before it
   // any more -- and that slice's buffer is refilled with slice i + NS - 1: of this tile, or of the next one.
+  // (Round 5, measured and not kept: a tile's first wait as vmcnt((NS - 2) * PW + the previous epilogue's stores) -- its pieces are
+  // older than those stores -- changed nothing: 365.7 against 368.0 us on 384 -> 384 @320x320 x 8; the stores' cost, 50-70 us of that
+  // launch by ablation, is not the drain at the tile boundary.)
   auto enter = [&](int i) __attribute__((always_inline)) {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * PW) : "memory");
     __builtin_amdgcn_s_barrier();
@@ -505,7 +524,7 @@ static int launch_gemm(const ConvArgs& a, size_t lds, hipStream_t s) {
   // persistent: as many workgroups as stay resident (every CU x two 4-wave or one 8-wave workgroup), each walks its tiles
   static const int persist = getenv("YL_CONV_GEMM_PERSIST") ? atoi(getenv("YL_CONV_GEMM_PERSIST")) : 1;
   static const int m64_wpc = getenv("YL_CONV_GEMM_M64_WPC") ? atoi(getenv("YL_CONV_GEMM_M64_WPC")) : 2;  // development: workgroups per CU of the 64-channel blocks
-  const int resident = device_cu_count() * (MTW == 2 ? m64_wpc : (NWN == 2 ? 2 : 1));
+  const int resident = device_cu_count() * (MTW == 2 ? m64_wpc : (NWN == 2 && lds <= 80 * 1024 ? 2 : 1));
   const int grid = persist && a.nblocks > resident ? resident : a.nblocks;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * NWN), lds, s, a);
   YL_HIP(hipGetLastError());
