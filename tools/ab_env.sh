@@ -1,14 +1,18 @@
 #!/bin/bash
-# Alternating A/B of one environment switch on the default bench (same box): tools/ab_env.sh VAR A B [reps] [bench args...]
+# A/B of environment switches across the three bench configurations on ONE box (one device, one clock), two rounds:
+#   bash tools/ab_env.sh "YL_ST_NT=0" "YL_ST_NT=-1" "YL_ST_NT=1"        (CFGS="2 3 5" selects the configurations)
 cd "$(dirname "$0")/.."
-VAR=$1; A=$2; B=$3; REPS=${4:-2}; shift 4
-for rep in $(seq $REPS); do
-  for v in $A $B; do
-    env $VAR=$v python bench.py --no-cpu-baseline --no-other-configs "$@" 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read())
-post={r:v for r,v in d['kernels'].items() if r.startswith(('decode','nms','dw3x3'))}
-print('$VAR=$v', d['value'], 'img/s', 'sync', d.get('value_sync_per_iteration'), 'lat_ms', d.get('latency_ms_single_stream'), 'one_batch_profile_ms', (d.get('one_batch_profile') or {}).get('latency_ms'), 'launches', d.get('launches_per_step'), {k:(round(x['ms']*1e3,1),x['launches']) for k,x in post.items()})
-"
+mkdir -p gpurun_out
+for rep in 1 2; do
+  for envs in "$@"; do
+    for c in ${CFGS:-2 3 5}; do
+      case $c in 2) cfg="";; 3) cfg="--scale s --batch 64";; 5) cfg="--scale x --imgsz 1280 --batch 8 --dtype fp8";; esac
+      env $envs python bench.py $cfg --no-cpu-baseline --no-other-configs > gpurun_out/ab.json 2> gpurun_out/ab.err
+      python - "$envs" "config $c" <<'PY'
+import json, sys
+d = json.loads(open("gpurun_out/ab.json").read().strip().splitlines()[-1])
+print(f"{sys.argv[1]:28s} {sys.argv[2]:10s} value {d['value']:9.1f}  sync/iter {d.get('value_sync_per_iteration', 0):9.1f}", flush=True)
+PY
+    done
   done
 done

@@ -193,9 +193,8 @@ __global__ __launch_bounds__(BN_THREADS) __attribute__((amdgpu_waves_per_eu(2)))
             v[q] = s0[q] + (float)rx[q];
             v[4 + q] = s1[q] + (float)rx[4 + q];
           }
-          __builtin_amdgcn_raw_buffer_store_b128(
-              u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])},
-              rout, (unsigned)(p * 4 + g) * out_plane + po, 0, 0);
+          store_b128_nt(u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])},
+                        rout, (unsigned)(p * 4 + g) * out_plane + po, a.st_nt);
         }
       }
     }
@@ -215,6 +214,7 @@ static int bneck2_launch_t(const Bneck2Args& a, hipStream_t s) {
 
 int bneck2_launch(const Bneck2Args& a0, hipStream_t s) {
   Bneck2Args a = a0;
+  a.st_nt = st_nt_policy(a.out_bytes);
   a.tiles_x = (a.W + BN_TC - 1) / BN_TC;
   a.tiles_y = (a.H + BN_TR - 1) / BN_TR;
   if (a.c == 32) return bneck2_launch_t<4>(a, s);

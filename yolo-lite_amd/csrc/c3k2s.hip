@@ -254,9 +254,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
             v[r] = s0[r];
             v[4 + r] = s1[r];
           }
-          __builtin_amdgcn_raw_buffer_store_b128(
-              u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])},
-              rout, (unsigned)(cb * 8 + p * 4 + g) * out_plane + po, 0, 0);
+          store_b128_nt(u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])},
+                        rout, (unsigned)(cb * 8 + p * 4 + g) * out_plane + po, a.st_nt);
         }
       }
       if (cb + 1 < NCB) {
@@ -279,6 +278,7 @@ static int c3k2s_launch_t(const C3k2sArgs& a, hipStream_t s) {
 
 int c3k2s_launch(const C3k2sArgs& a0, hipStream_t s) {
   C3k2sArgs a = a0;
+  a.st_nt = st_nt_policy(a.out_bytes);
   a.tiles_x = (a.W + C3_TC - 1) / C3_TC;
   a.tiles_y = (a.H + C3_TR - 1) / C3_TR;
   switch (a.c * 1000 + a.cout) {

@@ -173,9 +173,8 @@ __device__ __forceinline__ void band_compute(const BandArgs& a, unsigned char* l
       v[r] = s0[r];
       v[4 + r] = s1[r];
     }
-    __builtin_amdgcn_raw_buffer_store_b128(
-        u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])}, rout,
-        opix[nt] == OOB_LANE ? OOB_LANE : (unsigned)(mh * 4 + g) * a.y_plane + opix[nt], 0, 0);
+    store_b128_nt(u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])},
+                  rout, opix[nt] == OOB_LANE ? OOB_LANE : (unsigned)(mh * 4 + g) * a.y_plane + opix[nt], a.st_nt);
   }
 }
 
@@ -314,6 +313,7 @@ int conv3_band_launch(const BandArgs* args, int n, int batch, hipStream_t s) {
   for (int i = 0; i < n; ++i) {
     G.m[i] = args[i];
     G.m[i].stamps = g_stamp_buf;
+    G.m[i].st_nt = st_nt_policy(args[i].y_bytes);
     if (!conv3_band_plan(args[i].Cin, 64, args[i].H, args[i].W, &G.m[i], false)) return fail(-3, "conv3_band: member does not fit the band tiling");
     kk[i] = args[i].Cin / 32;
     nq[i] = (G.m[i].ntiles + 3) / 4;
@@ -347,6 +347,7 @@ int conv3_band64_launch(const BandArgs* args, int n, int batch, int post, hipStr
   for (int i = 0; i < n; ++i) {
     G.m[i] = args[i];
     G.m[i].stamps = g_stamp_buf;
+    G.m[i].st_nt = st_nt_policy(args[i].y_bytes);
     if (args[i].Cin != 64 || !conv3_band_plan(64, 64, args[i].H, args[i].W, &G.m[i], post != 0))
       return fail(-3, "conv3_band64: member does not fit the band tiling");
     if (post && (!args[i].w2 || !args[i].bias2)) return fail(-1, "conv3_band64: follow-up filter missing");

@@ -192,9 +192,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] += (float)rv[q];
       }
-      __builtin_amdgcn_raw_buffer_store_b128(
-          u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])}, rout,
-          po == OOB_LANE ? OOB_LANE : oplane * a.out_plane + po, 0, 0);
+      store_b128_nt(u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])},
+                    rout, po == OOB_LANE ? OOB_LANE : oplane * a.out_plane + po, a.st_nt);
     }
   }
 }
@@ -269,9 +268,8 @@ __device__ __forceinline__ void cs2_tile(const ConvArgs& a, const bf16x8 (&wf)[1
 #pragma unroll
       for (int q = 0; q < 8; ++q) v[q] += (float)rv[q];
     }
-    __builtin_amdgcn_raw_buffer_store_b128(
-        u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])}, rout,
-        po == OOB_LANE ? OOB_LANE : oplane * a.out_plane + po, 0, 0);
+    store_b128_nt(u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])},
+                  rout, po == OOB_LANE ? OOB_LANE : oplane * a.out_plane + po, a.st_nt);
   }
 }
 

@@ -66,9 +66,8 @@ __device__ __forceinline__ void reg_epilogue(const ConvArgs& a, __amdgpu_buffer_
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] += (float)rv[p][nt][r];
       }
-      __builtin_amdgcn_raw_buffer_store_b128(
-          u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])},
-          rout, (unsigned)(p * 4 + g) * a.out_plane + po[nt], 0, 0);
+      store_b128_nt(u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])},
+                    rout, (unsigned)(p * 4 + g) * a.out_plane + po[nt], a.st_nt);
     }
 }
 
@@ -241,8 +240,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     } else {
       e_cvt(e.d[pair], e.t[j0], e.t[j1]);
       if (pair == 3 && !(a.dbg & 64))
-        __builtin_amdgcn_raw_buffer_store_b128(u32x4{e.d[0], e.d[1], e.d[2], e.d[3]}, rout,
-                                               (unsigned)(p * 4 + g) * a.out_plane + po[nt], 0, 0);
+        store_b128_nt(u32x4{e.d[0], e.d[1], e.d[2], e.d[3]}, rout, (unsigned)(p * 4 + g) * a.out_plane + po[nt], a.st_nt);
     }
   };
 

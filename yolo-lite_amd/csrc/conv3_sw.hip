@@ -144,8 +144,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
           v[4 + q] = acc[1][q];
         }
         if constexpr (ACT) silu8(v);
-        __builtin_amdgcn_raw_buffer_store_b128(
-            u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])}, rout, opos, 0, 0);
+        store_b128_nt(u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])},
+                      rout, opos, a.st_nt);
       }
       opos += (unsigned)a.out_w1 * 16u;
     }

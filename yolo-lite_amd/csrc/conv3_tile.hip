@@ -103,9 +103,8 @@ __device__ __forceinline__ void epilogue_planar(const ConvArgs& a, __amdgpu_buff
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] += (float)rv[p][nt][r];
       }
-      __builtin_amdgcn_raw_buffer_store_b128(
-          u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])},
-          rout, (unsigned)(p * 4 + g) * a.out_plane + po[nt], 0, 0);
+      store_b128_nt(u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])},
+                    rout, (unsigned)(p * 4 + g) * a.out_plane + po[nt], a.st_nt);
     }
 }
 

@@ -64,6 +64,16 @@ __host__ __device__ inline int chan_in_block(int MT, int mt, int g, int r) {
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+// A 16-byte (8-byte) buffer store with or without the non-temporal hint (the cache-policy operand is an immediate: a wave-uniform
+// branch picks the instruction).
+__device__ __forceinline__ void store_b128_nt(u32x4 d, __amdgpu_buffer_rsrc_t r, unsigned off, int nt) {
+  if (nt) __builtin_amdgcn_raw_buffer_store_b128(d, r, off, 0, 2);
+  else __builtin_amdgcn_raw_buffer_store_b128(d, r, off, 0, 0);
+}
+__device__ __forceinline__ void store_b64_nt(u32x2 d, __amdgpu_buffer_rsrc_t r, unsigned off, int nt) {
+  if (nt) __builtin_amdgcn_raw_buffer_store_b64(d, r, off, 0, 2);
+  else __builtin_amdgcn_raw_buffer_store_b64(d, r, off, 0, 0);
+}
 // Buffer addressing (raw_buffer_load/store with a 32-bit byte offset): an offset beyond the
 // descriptor's size makes a load return zeros and a store vanish, so ragged patches and k tails need
 // no branches.  Views are limited to 2^30 bytes (host-checked) so that the sums below can never wrap
@@ -267,9 +277,8 @@ __device__ __forceinline__ void epilogue(const ConvArgs& a, __amdgpu_buffer_rsrc
         for (int r = 0; r < 8; ++r) v[r] += (float)rv[r];
       }
       const unsigned vo = ok ? (unsigned)(co >> 3) * a.out_plane + (unsigned)opix[nt] * 16u : OOB_LANE;
-      __builtin_amdgcn_raw_buffer_store_b128(
-          u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])},
-          rout, vo, 0, 0);
+      store_b128_nt(u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])},
+                    rout, vo, a.st_nt);
       if constexpr (O8) {  // e4m3 copy for an fp8 conv downstream (conv_f8.hip): this lane's 8 channels = half a 16-byte pixel
         const __amdgpu_buffer_rsrc_t r8 = __builtin_amdgcn_make_buffer_rsrc(a.out8, (short)0, a.out8_bytes, 0x00020000);
         const int c = co - a.out8_c0;

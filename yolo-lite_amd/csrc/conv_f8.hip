@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
           __builtin_amdgcn_raw_buffer_store_b32(pack_f8x4(v[0] * is, v[1] * is, v[2] * is, v[3] * is), rout, vo, 0, 0);
         } else {
           const unsigned vo = ok ? (unsigned)(co >> 3) * a.out_plane + (unsigned)opix[nt] * 16u + (unsigned)(co & 7) * 2u : OOB_LANE;
-          __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])}, rout, vo, 0, 0);
+          store_b64_nt(u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])}, rout, vo, a.st_nt);
           if (a.out8) {  // e4m3 copy of the bf16 result for the next fp8 conv
             const __amdgpu_buffer_rsrc_t r8 = __builtin_amdgcn_make_buffer_rsrc(a.out8, (short)0, a.out8_bytes, 0x00020000);
             const int c = co - a.out8_c0;
@@ -447,6 +447,7 @@ int conv_f8_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s) 
   a.res_bytes = (unsigned)resb;
   a.nblocks = cfg.gws * cfg.ncb;
   a.dbg = 0;
+  a.st_nt = st_nt_policy(outb);
   return cfg.ntaps == 9 ? launch8_m<3>(cfg, a, s) : launch8_m<1>(cfg, a, s);
 }
 

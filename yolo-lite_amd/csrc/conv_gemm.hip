@@ -410,9 +410,8 @@ __global__ __launch_bounds__(128 * NWN) __attribute__((amdgpu_waves_per_eu(2))) 
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] += (float)rv[nt][r];
       }
-      __builtin_amdgcn_raw_buffer_store_b128(
-          u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])}, rout,
-          po[nt] == OOB_LANE ? OOB_LANE : (plane0 + 4u * p) * a.out_plane + po[nt], 0, 0);
+      store_b128_nt(u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])}, rout,
+                    po[nt] == OOB_LANE ? OOB_LANE : (plane0 + 4u * p) * a.out_plane + po[nt], a.st_nt);
       if constexpr (O8) {  // this lane's 8 channels = half a 16-byte pixel of an e4m3 plane (16 channels)
         const __amdgpu_buffer_rsrc_t r8 = __builtin_amdgcn_make_buffer_rsrc(a.out8, (short)0, a.out8_bytes, 0x00020000);
         const int c = (int)(plane0 + 4u * p) * 8 - a.out8_c0;
@@ -561,6 +560,7 @@ int conv_gemm_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s
   a.res_bytes = (unsigned)resb;
   a.nblocks = cfg.gws * cfg.ncb;
   a.dbg = 0;
+  a.st_nt = st_nt_policy(outb);
   const bool even = cfg.ksteps % 2 == 0;
   const int NWN = cfg.gemm_nwn;
   if ((NWN != 2 && NWN != 4) || (NWN == 4 && MTW == 6 && !even)) return fail(-3, "conv_gemm: unsupported wave grid");

@@ -1067,6 +1067,7 @@ static int dwpw_prepare(ConvConfig& cfg, ConvArgs& a, int batch, size_t* lds_out
   if (inb > lim || outb > lim) return fail(-3, "dwpw: a tensor slice exceeds 1 GiB; lower the batch size");
   a.in_bytes = (unsigned)inb;
   a.out_bytes = (unsigned)outb;
+  a.st_nt = st_nt_policy(outb);
   a.nblocks = (cfg.npatches + 3) / 4;
   static const int dwpw_dbg = getenv("YL_DWPW_DBG") ? atoi(getenv("YL_DWPW_DBG")) : 0;  // timing ablations (wrong results)
   a.dbg = dwpw_dbg;
@@ -1183,6 +1184,7 @@ static int conv_prepare(const ConvConfig& cfg, ConvArgs& a, int batch) {
     a.in_bytes = (unsigned)inb;
     a.out_bytes = (unsigned)outb;
     a.res_bytes = (unsigned)resb;
+    a.st_nt = a.out_f32 ? 0 : st_nt_policy(outb);
   }
   a.nblocks = cfg.gws * cfg.ncb;
   {

@@ -25,6 +25,13 @@ int fail(int code, const std::string& s) {
 }
 
 unsigned long long* g_stamp_buf = nullptr;
+int st_nt_policy(long long out_bytes) {
+  // (read at every engine build, not cached: tests and tools switch them)
+  const int mode = getenv("YL_ST_NT") ? atoi(getenv("YL_ST_NT")) : 1;  // (-1: by size, YL_ST_NT_BYTES)
+  if (mode >= 0) return mode ? 1 : 0;
+  const long long thr = getenv("YL_ST_NT_BYTES") ? atoll(getenv("YL_ST_NT_BYTES")) : 48LL << 20;
+  return out_bytes >= thr ? 1 : 0;
+}
 
 int allow_big_lds(const void* kernel, int bytes) {
   static std::mutex mu;

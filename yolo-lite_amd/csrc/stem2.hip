@@ -348,9 +348,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
         }
       }
       const int co = (p * 4 + g) * 8;
-      __builtin_amdgcn_raw_buffer_store_b128(
-          u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])},
-          rout, co < cout_last ? (unsigned)(p * 4 + g) * out_plane + po : OOB_LANE, 0, 0);
+      store_b128_nt(u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])},
+                    rout, co < cout_last ? (unsigned)(p * 4 + g) * out_plane + po : OOB_LANE, a.st_nt);
     }
   }
   S2_STAMP(6);
@@ -383,6 +382,7 @@ static int stem2_launch_t(const Stem2Args& a, int MT, size_t lds, hipStream_t s)
 int stem2_launch(const Stem2Args& a0, int MT, int in_dtype, hipStream_t s) {
   Stem2Args a = a0;
   a.stamps = g_stamp_buf;
+  a.st_nt = st_nt_policy(a.out_bytes);
   if ((a.C0 != 16 && a.C0 != 32) || a.ksteps != (9 * (a.C0 / 8) + 3) / 4)
     return fail(-3, "stem2: the stem must have 16 or 32 output channels");
   const int esz = in_dtype == YL_F32 ? 4 : in_dtype == YL_F16 ? 2 : 1;

@@ -27,6 +27,12 @@ int device_cu_count();
 // In-kernel phase stamps of a DIAGNOSTIC build (make EXTRA=-DYL_STAMPS; include/yl_amd_diag.h yl_diag_set_stamps): lane 0 of
 // every wave stores {shader clock, 100 MHz clock} at phase boundaries into a buffer no other code reads.  The production
 // build compiles the macro away.
+// Non-temporal epilogue stores (round 5): YL_ST_NT=1 (default) always, 0 never, -1 when the stored tensor has at least YL_ST_NT_BYTES
+// bytes (default 48 MB).  Measured on conv_gemm_kernel: 384 -> 384 @320x320 x 8 365 -> 353 us, 128 -> 128 @80x80 x 64 52.1 -> 49.4 us
+// stand-alone; on the conv / GEMM / e4m3 epilogues end to end (one box, two rounds): YOLO11s batch 64 25.7 -> 26.1 k, YOLO11x 1280 fp8
+// 1 092 -> 1 112, YOLO11n batch 32 56.0 -> 57.5 k (one batch at a time 32.3 -> 32.9 k) -- with twenty batches in flight no cache holds a
+// layer's output until its reader runs, and a store that does not allocate leaves the caches to the operands that are re-read.
+int st_nt_policy(long long out_bytes);
 extern unsigned long long* g_stamp_buf;
 #ifdef YL_STAMPS
 #define YL_STAMP(buf, waves, wave, lane, id)                                                             \
@@ -125,6 +131,7 @@ struct ConvArgs {
   unsigned in_bytes, out_bytes, res_bytes;  // buffer-descriptor sizes (bytes past the base pointers)
   int nblocks;
   int dbg;  // development ablation flags (YL_CONV_DBG), 0 in production
+  int st_nt;  // 1: the epilogue's stores carry the non-temporal hint (large outputs that no cache holds until their reader runs)
   unsigned long long* stamps;  // diagnostic builds (-DYL_STAMPS): dwpw_body's phase stamps
   // conv3_tile_kernel (3x3, stride 1, input tile in LDS): tile geometry in guarded-pixel units
   int t_px, t_PL, t_ppp, t_ntiles, t_plane_px, t_H, t_W, t_B;  // pixels staged / LDS plane pitch / DMA pieces per plane
@@ -271,6 +278,7 @@ struct Stem2Args {
   int post_cout, post_act;
   PView out;
   unsigned out_bytes;
+  int st_nt;             // non-temporal stores (st_nt_policy), filled by stem2_launch
   int tiles_x, tiles_y;
   int32_t* zero_ptr;           // zero_n words the first workgroup clears (the NMS candidate counters of this step:
   int zero_n;                  // PrefilterSink::zero_ptr -- one launch less in front of the network); 0: none
@@ -291,6 +299,7 @@ struct C3k2sArgs {
   const __bf16* wC;      // C3k2.cv2 (48 -> 64, 1x1), MT = 4, 2 k-steps
   const float* bC;
   unsigned in_bytes, out_bytes;
+  int st_nt;             // non-temporal stores (st_nt_policy), filled by c3k2s_launch
   long long plane_px;    // pixels per input plane
   int tiles_x, tiles_y;
 };
@@ -305,6 +314,7 @@ struct Bneck2Args {
   const __bf16* w2;
   const float* b2;
   unsigned in_bytes, out_bytes;
+  int st_nt;             // non-temporal stores (st_nt_policy), filled by bneck2_launch
   long long plane_px;
   int tiles_x, tiles_y;
 };
@@ -341,6 +351,7 @@ struct BandArgs {
   const __bf16* w;        // conv_pack_weights order, one block of four tiles: [k-step][4][64 lanes][8]
   const float* bias;      // padded to 64
   int TR, nbands, ntiles, tpl;  // filled by conv3_band_launch: rows per band, bands per image, 16-pixel tiles per band, LDS bytes per plane
+  int st_nt;                    // non-temporal stores (st_nt_policy), filled by the launchers
   unsigned long long* stamps;   // diagnostic builds (-DYL_STAMPS)
   // conv3_band64_kernel with a fused follow-up 1x1 conv 64 -> 64 (conv_kernel's POST): its filter ([2 k-steps][4 tiles][64 lanes][8]),
   // bias (padded to 64) and activation flag; `y` is then the follow-up conv's output
