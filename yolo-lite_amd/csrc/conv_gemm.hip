@@ -36,6 +36,9 @@
 #define YL_GEMM_ABL 0  // development build switch: timing ablations of the main loop (wrong results): 2 no operand traffic, 4 no fragment
                        // reads, 8 nothing stored, 16 activations always from the first 8192 positions (L2 hits)
 #endif
+#ifndef YL_GEMM_LD_AUX
+#define YL_GEMM_LD_AUX 0
+#endif
 namespace yl {
 
 typedef __attribute__((address_space(3))) void lds_void_g;
@@ -207,6 +210,12 @@ __global__ __launch_bounds__(128 * NWN) __attribute__((amdgpu_waves_per_eu(2))) 
         } else {
           // (ABL 16: timing ablation, every pixel tile reads the first 8192 positions' activations -- all L2 hits)
           const unsigned src = (unsigned)(gp - split_planes) * a.in_plane + (unsigned)(((YL_GEMM_ABL & 16) ? (x.q0 & 0x1fff) : x.q0) + h * 64) * 16u;
+          // (YL_GEMM_LD_AUX, development build switch: cache-policy bits of the activation pieces when one channel block covers the
+          // layer -- every activation byte is then read exactly once)
+          if (YL_GEMM_LD_AUX && a.ncb == 1)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void_g*)(gsm + sbase + ASTAGE + (unsigned)jb * 1024u), 16,
+                                                     (int)(lane16 + src + past), 0, 0, YL_GEMM_LD_AUX);
+          else
           __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void_g*)(gsm + sbase + ASTAGE + (unsigned)jb * 1024u), 16,
                                                    (int)(lane16 + src + past), 0, 0, 0);
         }
