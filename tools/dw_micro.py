@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Stand-alone timing of the depthwise 3x3 conv (ops_misc.hip): usage  python tools/dw_micro.py C H W [batch]
-(YL_DW_WAVE_MINW=0: the per-thread form dwconv3_kernel; default: the wave-row form from 32 columns up)."""
+(YL_DW_PX = columns per thread: 1, 2 (default) or 4; YL_MICRO_ACT=0: no SiLU)."""
 import os
 import sys
 from pathlib import Path
@@ -28,7 +28,7 @@ for r in range(NREP):
     xin, out = m.buf(H, W, C), m.buf(H, W, C)
     if r == 0:
         m.fill(xin, bf16_round(torch.randn(B, C, H, W, generator=g)))
-    m.op(kind=OP_DWCONV3, name=f"dw{r}", k=3, stride=1, act=1, inp=xin, out=out, weight=wt, bias=np.zeros(C, np.float32))
+    m.op(kind=OP_DWCONV3, name=f"dw{r}", k=3, stride=1, act=int(os.environ.get("YL_MICRO_ACT", "1")), inp=xin, out=out, weight=wt, bias=np.zeros(C, np.float32))
 m.run()
 im = torch.zeros(B, 3, 32, 32, device=dev)
 for _ in range(3):
@@ -43,4 +43,4 @@ e1.record()
 torch.cuda.synchronize()
 us = e0.elapsed_time(e1) / (N * NREP) * 1e3
 byt = 2.0 * B * H * W * C * 2
-print(f"dw3x3 {C} ch @{H}x{W} x {B} (YL_DW_WAVE_MINW={os.environ.get('YL_DW_WAVE_MINW', 'default')}): {us:7.1f} us  {byt / us / 1e6:5.2f} TB/s")
+print(f"dw3x3 {C} ch @{H}x{W} x {B} (YL_DW_PX={os.environ.get('YL_DW_PX', '2')}): {us:7.1f} us  {byt / us / 1e6:5.2f} TB/s")
