@@ -68,6 +68,52 @@ def test_conv_f8_vs_torch(gpu_device, B, Cin, Cout, H, W, k, s, kern, mode):
         assert (y == bf16_round(ref)).float().mean().item() > 0.97
 
 
+F8T_CASES = [
+    # B, H, W     conv3_f8t_kernel (48 -> 48 3x3: input tile in LDS, filter in registers), forced onto small maps too
+    (3, 40, 40),
+    (2, 33, 150),     # wide rows: a tile is less than two rows
+    (5, 7, 9),        # images much smaller than a tile
+    (6, 160, 160),    # more than one round of 512 workgroups: full tiles behind the short first round
+]
+
+
+@pytest.mark.parametrize("B,H,W", F8T_CASES)
+@pytest.mark.parametrize("mode", ["bf16", "bf16+res", "fp8", "fp8+res8"])
+@pytest.mark.parametrize("kord", ["1", "0"])
+def test_conv3_f8_tile_kernel_vs_torch_and_direct(gpu_device, monkeypatch, B, H, W, mode, kord):
+    """csrc/conv3_f8t.hip against torch on the same quantised operands (tolerances of test_conv_f8_vs_torch) and against
+    conv_f8_kernel: same packed filters, same k-steps in the same order (plane-major and tap-major) -> bit-identical."""
+    g = torch.Generator().manual_seed(B * 1000 + H + W)
+    Cin = Cout = 48
+    in_scale = 0.037
+    xq = e4m3_round(torch.randn(B, Cin, H, W, generator=g) * 30)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
+    b = torch.randn(Cout, generator=g) * 0.3
+    res, res_scale, out_scale = None, 0.0, 0.0
+    if mode == "bf16+res":
+        res = bf16_round(torch.randn(B, Cout, H, W, generator=g))
+    if mode == "fp8+res8":
+        res, res_scale = e4m3_round(torch.randn(B, Cout, H, W, generator=g) * 40), 0.02
+    if mode.startswith("fp8"):
+        out_scale = 0.05
+    monkeypatch.setenv("YL_F8_KORD", "1" if kord == "1" else "0")   # plane-major K order from 1 pixel per image up / never
+    monkeypatch.setenv("YL_F8_TILE_MIN", "1")
+    y = run_conv_f8(gpu_device, xq, in_scale, w, b, 3, 1, True, res, res_scale, out_scale, expect_kernel="conv3x3_f8t_mfma")
+    ref = _ref(xq, in_scale, w, b, 3, 1, True, res, res_scale)
+    if out_scale > 0:
+        want = e4m3_round(ref / out_scale)
+        assert (y == want).float().mean().item() > 0.99
+        mag = torch.maximum(y.abs(), want.abs()).clamp_min(2.0 ** -6)
+        step = torch.exp2(torch.floor(torch.log2(mag)) - 3)
+        assert bool(((y - want).abs() <= step).all())
+    else:
+        err = (y - ref).abs()
+        assert bool((err <= 2 ** -7 * ref.abs() + 1e-3).all()), err.max()
+    monkeypatch.setenv("YL_F8_TILE", "0")
+    direct = run_conv_f8(gpu_device, xq, in_scale, w, b, 3, 1, True, res, res_scale, out_scale, expect_kernel="conv3x3_f8_mfma")
+    assert torch.equal(y, direct), f"tile kernel vs conv_f8_kernel: max diff {float((y - direct).abs().max())}"
+
+
 def test_conv_f8_no_act_and_identity_filter(gpu_device):
     """A = I with an asymmetric B: a 1x1 conv whose filter is the identity copies its input channel for channel
     (catches a swapped row / column or a permuted k order that random data could hide behind tolerances)."""

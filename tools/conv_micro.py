@@ -46,4 +46,5 @@ us = e0.elapsed_time(e1) / (N * NREP) * 1e3
 byt = B * (H * W * cin * (1 if f8 else 2) + Ho * Wo * cout * 2)
 torch.cuda.synchronize()
 fl = 2.0 * B * Ho * Wo * cout * cin * k * k
+print(eng.op_kernel(0), end="  ")
 print(f"{'fp8 ' if f8 else ''}dbg={os.environ.get('YL_CONV_DBG', '0'):>2s} {cin}->{cout} k{k} s{s} @{H}x{W}: {us:7.1f} us  {byt / us / 1e6:6.2f} TB/s  {fl / us / 1e6:7.1f} TF/s")

@@ -1,0 +1,284 @@
+// e4m3 3x3 stride-1 Conv 48 -> 48 (three planes of 16 channels) with the INPUT TILE IN LDS and the FILTER IN REGISTERS (round 5).
+//
+// Reference semantics and quantisation exactly as conv_f8.hip (nn/modules/conv.py:35-53 with the BN folded, Bottleneck add
+// nn/modules/block.py:341-343; BASELINE.json config 5): same packed filters (conv_f8_pack_weights order), same k-steps of eight
+// 16-channel groups in the same order (tap-major or plane-major, ConvArgs::kord), same fp32 accumulation chain, same epilogue --
+// results are bit-identical to conv_f8_kernel's.  What changes is the operand delivery.  conv_f8_kernel fetches every B fragment
+// from the planes (two 16-byte loads per lane, pixel tile and k-step, two k-steps ahead): on the 48-channel Bottleneck convs of
+// YOLO11x @1280 (320x320 maps, 34 GFLOP, 79-197 MB each) that is 62-125 us a launch = 0.27-0.55 PFLOP/s -- four k-steps per
+// pixel patch are too short a loop to hide an L2 round trip behind, whatever the prefetch depth (NOTEBOOK section 12).  Here a
+// workgroup stages a run of 256 + 2 (W + 1) + 2 guarded positions of the three input planes by LDS-DMA (the whole tile is ONE
+// round trip, requested while the previous tile's epilogue runs), every wave keeps the whole 48 x 432 filter in 96 registers, and
+// the k-loop reads its fragments from LDS: 48 MFMAs (16x16x128) per wave and tile behind 32 ds_read_b128.
+//
+// Tiles, staging, counted wait, barriers and the balanced short first round as conv3_cs1b_kernel (conv3_cs.hip): four waves = four
+// columns of up to four 16-position fragments.  In the guarded layout a tap is a constant offset of the linear position; a
+// k-group (tap, plane) is therefore one constant LDS offset per lane and k-step, computed once per kernel.
+#include "conv_common.h"
+
+namespace yl {
+
+typedef int f8t_v8i __attribute__((ext_vector_type(8)));
+typedef int f8t_v4i __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void_t8;
+
+constexpr int F8T_L = 256;  // positions of a full tile (four columns of 64)
+
+static __host__ __device__ inline int f8t_PL(int W1) { return (F8T_L + 2 * W1 + 2 + 63) & ~63; }  // staged positions per plane
+
+// One tile of NT fragments per wave: k-loop from LDS, `mid()` (free the buffer, request the next tile), epilogue (conv_f8_kernel's).
+template <int CG, int NT, typename Mid>
+__device__ __forceinline__ void f8t_tile(const ConvArgs& a, const f8t_v8i (&wf)[(9 * CG + 7) / 8][CG], const int (&koff)[(9 * CG + 7) / 8][2],
+                                         const unsigned char* tb, int r0, int n, int g, const __amdgpu_buffer_rsrc_t& rout,
+                                         const __amdgpu_buffer_rsrc_t& rres, Mid mid) {
+  constexpr int KSN = (9 * CG + 7) / 8, MT = CG;
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < KSN; ++ks) {
+    f8t_v8i xb[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const f8t_v4i lo = *reinterpret_cast<const f8t_v4i*>(tb + nt * 256 + koff[ks][0]);
+      const f8t_v4i hi = *reinterpret_cast<const f8t_v4i*>(tb + nt * 256 + koff[ks][1]);
+      xb[nt] = f8t_v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[ks][mt], xb[nt], acc[mt][nt], 0, 0, 0, 0, 0, 0);
+  }
+  mid();
+  // ---- epilogue: dequantise, bias, SiLU, residual, store (valid positions only: guards are computed, never stored)
+  int opix[NT];
+  const int nqv = a.t_B * a.in_img;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int r = r0 + nt * 16 + n;  // position relative to g0
+    // (row of the whole batch first: r / W1 is exact by magic number as long as positions x W1 < 2^32 -- r / img is not on 320x320 maps)
+    const int R = (int)__umulhi((unsigned)r, a.magic_w1);
+    const int x = r - R * a.in_w1;
+    const int b = (int)__umulhi((unsigned)R, a.magic_img);  // magic of H + 1 (rows per image incl. the guard row)
+    const int y = R - b * (a.t_H + 1);
+    opix[nt] = (r < nqv && y < a.t_H && x < a.t_W) ? a.in_g0 + r : -1;
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int co = mt * 16 + g * 4;
+    const f32x4 alpha_r = *reinterpret_cast<const f32x4*>(a.alpha + co);
+    const f32x4 bias_r = *reinterpret_cast<const f32x4*>(a.bias + co);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const bool ok = opix[nt] >= 0;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = __builtin_fmaf(acc[mt][nt][r], alpha_r[r], bias_r[r]);
+        if (a.act) v[r] = silu_f(v[r]);
+      }
+      if (a.res) {
+        if (a.res_f8) {
+          const unsigned ro = ok ? (unsigned)(co >> 4) * a.res_plane + (unsigned)opix[nt] * 16u + (unsigned)(co & 15) : OOB_LANE;
+          const int rv = (int)__builtin_amdgcn_raw_buffer_load_b32(rres, ro, 0, 0);
+          v[0] += a.res_scale * __builtin_amdgcn_cvt_f32_fp8(rv, 0);
+          v[1] += a.res_scale * __builtin_amdgcn_cvt_f32_fp8(rv, 1);
+          v[2] += a.res_scale * __builtin_amdgcn_cvt_f32_fp8(rv, 2);
+          v[3] += a.res_scale * __builtin_amdgcn_cvt_f32_fp8(rv, 3);
+        } else {
+          const unsigned ro = ok ? (unsigned)(co >> 3) * a.res_plane + (unsigned)opix[nt] * 16u + (unsigned)(co & 7) * 2u : OOB_LANE;
+          const bf16x4 rv = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rres, ro, 0, 0));
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+        }
+      }
+      if (a.out_f8) {
+        const unsigned vo = ok ? (unsigned)(co >> 4) * a.out_plane + (unsigned)opix[nt] * 16u + (unsigned)(co & 15) : OOB_LANE;
+        const float is = a.out_inv_scale;
+        __builtin_amdgcn_raw_buffer_store_b32(pack_f8x4(v[0] * is, v[1] * is, v[2] * is, v[3] * is), rout, vo, 0, 0);
+      } else {
+        const unsigned vo = ok ? (unsigned)(co >> 3) * a.out_plane + (unsigned)opix[nt] * 16u + (unsigned)(co & 7) * 2u : OOB_LANE;
+        store_b64_nt(u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])}, rout, vo, a.st_nt);
+        if (a.out8) {  // e4m3 copy of the bf16 result for the next fp8 conv
+          const __amdgpu_buffer_rsrc_t r8 = __builtin_amdgcn_make_buffer_rsrc(a.out8, (short)0, a.out8_bytes, 0x00020000);
+          const int c = co - a.out8_c0;
+          const bool ok8 = ok && c >= 0 && c < a.out8_n;
+          const float is = a.out8_inv_scale;
+          const unsigned v8 = ok8 ? (unsigned)(c >> 4) * a.out8_plane + (unsigned)opix[nt] * 16u + (unsigned)(c & 15) : OOB_LANE;
+          __builtin_amdgcn_raw_buffer_store_b32(pack_f8x4(v[0] * is, v[1] * is, v[2] * is, v[3] * is), r8, v8, 0, 0);
+        }
+      }
+    }
+  }
+}
+
+template <int CG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv3_f8t_kernel(ConvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char tsm[];
+  constexpr int KSN = (9 * CG + 7) / 8, MT = CG;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // = column of the tile
+  const int g = lane >> 4, n = lane & 15;
+  const int G = gridDim.x;
+  const int wg = xcd_remap(blockIdx.x, G);
+  const int PL = a.t_PL, PLB = PL * 16;
+  const int Lr = a.t_px, nsmall = a.t_ppp, S = nsmall * Lr;  // the short round: tiles of Lr positions, nsmall of them, S positions in all
+  const int has_small = wg < nsmall ? 1 : 0;
+  const int nfull = a.t_ntiles > wg ? (a.t_ntiles - wg + G - 1) / G : 0;  // this workgroup's 256-position tiles
+  const int ntl = has_small + nfull;
+  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, (short)0, a.in_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.out, (short)0, a.out_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rres =
+      __builtin_amdgcn_make_buffer_rsrc((void*)a.res, (short)0, a.res ? a.res_bytes : 0, 0x00020000);
+  const unsigned lane16 = (unsigned)lane * 16u;
+  // tile i of this workgroup: first position (relative to g0) and fragments per wave
+  auto tile_of = [&](int i, int& nt) __attribute__((always_inline)) -> int {
+    if (has_small) {
+      if (i == 0) {
+        nt = Lr >> 6;
+        return wg * Lr;
+      }
+      --i;
+    }
+    nt = 4;
+    return S + (wg + i * G) * F8T_L;
+  };
+  // a tile -> LDS: the CG x np pieces of 1 KiB (64 positions of one plane) go round the four waves; a run past the slice reads zeros
+  // (pieces j = wave, wave + 4, .. of every plane)
+  auto stage = [&](int pos, int nt) __attribute__((always_inline)) {
+    const int src0 = (a.in_g0 + pos - a.in_w1 - 1) * 16;  // first staged guarded position (>= 0)
+    const int np = (64 * nt + 2 * a.in_w1 + 2 + 63) >> 6;
+#pragma unroll
+    for (int plane = 0; plane < CG; ++plane)
+      for (int j = wave; j < np; j += 4)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void_t8*)(tsm + plane * PLB + j * 1024), 16,
+                                                 (int)(lane16 + (unsigned)(plane * (int)a.in_plane + src0 + j * 1024)), 0, 0, 0);
+  };
+  int nt_cur = 4, pos_cur = 0;
+  if (ntl > 0) {
+    pos_cur = tile_of(0, nt_cur);
+    stage(pos_cur, nt_cur);
+  }
+  // the whole filter (cb = 0), conv_f8_pack_weights order [k-step][MT][half][64 lanes] x 16 bytes
+  f8t_v8i wf[KSN][MT];
+  {
+    const f8t_v4i* wsrc = reinterpret_cast<const f8t_v4i*>(a.wpk) + lane;
+#pragma unroll
+    for (int ks = 0; ks < KSN; ++ks)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const f8t_v4i lo = wsrc[((ks * MT + mt) * 2) * 64], hi = wsrc[((ks * MT + mt) * 2 + 1) * 64];
+        wf[ks][mt] = f8t_v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      }
+  }
+  // LDS byte offset of this lane's two k-groups of every k-step, relative to its position in plane 0 (a group past the end of K
+  // has zero filters: it may read any staged bytes -- the centre tap of plane 0)
+  int koff[KSN][2];
+#pragma unroll
+  for (int ks = 0; ks < KSN; ++ks)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int q = ks * 8 + 2 * g + h;
+      int tap, c16;
+      if (a.kord) {  // plane-major: k-group = plane * 9 + tap
+        c16 = (int)__umulhi((unsigned)q, 477218589u);  // q / 9
+        tap = q - 9 * c16;
+      } else {
+        tap = q / CG;
+        c16 = q - tap * CG;
+      }
+      const bool real = q < 9 * CG;
+      const int kh = (tap * 11) >> 5;
+      koff[ks][h] = real ? c16 * PLB + ((kh - 1) * a.in_w1 + (tap - 3 * kh - 1)) * 16 : 0;
+    }
+  // the lane's position 0 of plane 0 inside the staged run: the run starts W1 + 1 positions in front of the tile
+  const unsigned char* const tb0 = tsm + (a.in_w1 + 1 + n) * 16;
+  int nt_prev = 0;
+  for (int i = 0; i < ntl; ++i) {
+    // my pieces of this tile are OLDER than the previous tile's epilogue stores (at most 2 MT nt_prev of them, fewer without the e4m3
+    // copy; a residual's loads have been consumed): a counted wait covers the pieces and leaves the plain stores in flight
+    switch (nt_prev) {
+      case 4: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * MT) : "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * MT) : "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * MT) : "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * MT) : "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+    __builtin_amdgcn_s_barrier();
+    int nt_next = 4, pos_next = 0;
+    const bool more = i + 1 < ntl;
+    if (more) pos_next = tile_of(i + 1, nt_next);
+    auto mid = [&]() __attribute__((always_inline)) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // everybody has read the tile: the buffer may be refilled
+      if (more) stage(pos_next, nt_next);
+    };
+    const unsigned char* const tb = tb0 + wave * 16 * nt_cur * 16;
+    const int r0 = pos_cur + wave * 16 * nt_cur;
+    switch (nt_cur) {
+      case 4: f8t_tile<CG, 4>(a, wf, koff, tb, r0, n, g, rout, rres, mid); break;
+      case 3: f8t_tile<CG, 3>(a, wf, koff, tb, r0, n, g, rout, rres, mid); break;
+      case 2: f8t_tile<CG, 2>(a, wf, koff, tb, r0, n, g, rout, rres, mid); break;
+      default: f8t_tile<CG, 1>(a, wf, koff, tb, r0, n, g, rout, rres, mid); break;
+    }
+    nt_prev = nt_cur;
+    nt_cur = nt_next;
+    pos_cur = pos_next;
+  }
+}
+
+// ------------------------------------------------------------------------------------ host
+static unsigned f8t_magic(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull / (unsigned)d) + 1ull); }
+
+// may this conv take the tile kernel?  (3x3 stride 1, 48 -> 48, one channel block, enough positions, the tile fits the LDS twice per CU)
+bool conv3_f8t_fits(const ConvConfig& cfg, int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo) {
+  const int enable = getenv("YL_F8_TILE") ? atoi(getenv("YL_F8_TILE")) : 1;
+  if (!enable || k != 3 || stride != 1 || Cin != 48 || Cout != 48 || cfg.ncb != 1 || cfg.MT != 3 || cfg.cg != 3) return false;
+  const long long img = (long long)(Ho + 1) * (Wo + 1), nq = (long long)batch * img;
+  const long long rows = (long long)batch * (Ho + 1);
+  if ((nq + 512) * (Wo + 1) >= (1LL << 32) || rows * (Ho + 1) >= (1LL << 32) || nq >= (1LL << 30)) return false;  // exactness of the magic divisions
+  const long long min_pos = getenv("YL_F8_TILE_MIN") ? atoll(getenv("YL_F8_TILE_MIN")) : 65536;
+  if (nq < min_pos) return false;
+  return (size_t)3 * f8t_PL(Wo + 1) * 16 <= 80 * 1024;
+}
+
+int conv3_f8t_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s) {
+  if (a.stride != 1 || a.in_w1 != a.out_w1 || a.in_img != a.out_img || a.in_g0 != a.out_g0 || a.in_w1 != a.Wo + 1 || a.Cin != 48 ||
+      a.Cout != 48 || cfg.ntaps != 9)
+    return fail(-3, "conv3_f8t: needs a 48 -> 48 3x3 stride-1 conv between planar tensors of one geometry");
+  constexpr int CG = 3;
+  a.t_B = batch;
+  a.t_H = a.Ho;
+  a.t_W = a.Wo;
+  a.t_PL = f8t_PL(a.in_w1);
+  a.magic_img = f8t_magic(a.Ho + 1);  // (rows per image: the kernel divides position -> batch row -> image)
+  a.magic_w1 = f8t_magic(a.in_w1);
+  const long long nq = (long long)batch * a.in_img;
+  const long long nq64 = (nq + 63) & ~63LL;
+  const int resident = 2 * device_cu_count();  // two persistent workgroups per CU
+  const long long per_round = (long long)resident * F8T_L;
+  const long long rounds = nq64 / per_round, rem = nq64 - rounds * per_round;
+  int Lr = rem > 0 ? (int)(((rem + resident - 1) / resident + 63) & ~63LL) : 0;
+  int nsmall = 0;
+  if (Lr >= F8T_L) Lr = 0;  // the remainder fills whole tiles: no short round
+  if (Lr > 0) nsmall = (int)((rem + Lr - 1) / Lr);
+  const long long S = (long long)nsmall * Lr;
+  const int nfull_tiles = nq64 > S ? (int)((nq64 - S + F8T_L - 1) / F8T_L) : 0;
+  a.t_px = Lr;
+  a.t_ppp = nsmall;
+  a.t_ntiles = nfull_tiles;
+  int grid = nsmall > nfull_tiles ? nsmall : nfull_tiles;
+  if (grid > resident) grid = resident;
+  if (grid < 1) grid = 1;
+  const size_t lds = (size_t)CG * a.t_PL * 16;
+  auto kern = conv3_f8t_kernel<CG>;
+  if (int rc = allow_big_lds(reinterpret_cast<const void*>(kern), (int)(160 * 1024))) return rc;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
+  YL_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace yl

@@ -322,7 +322,7 @@ int conv_f8_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int 
   // 80-160 MB of input and `model.23.cv2.0.0` 402 MB for 79 MB.  Same cure as conv_mfma.hip's: one plane's nine taps back to
   // back (the per-lane tap / plane arithmetic of the non-UNIFORM fetch).  YL_F8_KORD = smallest map (pixels per image) that
   // takes it; 0: never.
-  static const int kord_px = getenv("YL_F8_KORD") ? atoi(getenv("YL_F8_KORD")) : 1600;
+  const int kord_px = getenv("YL_F8_KORD") ? atoi(getenv("YL_F8_KORD")) : 1600;  // (read at every engine build: the tests switch it)
   c->kord = (kord_px > 0 && k == 3 && (long long)Ho * Wo >= kord_px) ? 1 : 0;
   if (c->kord) c->uniform = 0;
   c->gemm = 0;
@@ -360,6 +360,8 @@ int conv_f8_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int 
   c->ppw = ppw;
   c->gws = (int)(((long long)c->npatches + 4 * ppw - 1) / (4 * ppw));
   c->name = k == 3 ? (stride == 2 ? "conv3x3s2_f8_mfma" : "conv3x3_f8_mfma") : "conv1x1_f8_mfma";
+  c->f8t = conv3_f8t_fits(*c, batch, Cin, Cout, k, stride, Ho, Wo) ? 1 : 0;
+  if (c->f8t) c->name = "conv3x3_f8t_mfma";
   return 0;
 }
 
@@ -448,6 +450,7 @@ int conv_f8_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s) 
   a.nblocks = cfg.gws * cfg.ncb;
   a.dbg = 0;
   a.st_nt = st_nt_policy(outb);
+  if (cfg.f8t) return conv3_f8t_launch(cfg, a, batch, s);
   return cfg.ntaps == 9 ? launch8_m<3>(cfg, a, s) : launch8_m<1>(cfg, a, s);
 }
 

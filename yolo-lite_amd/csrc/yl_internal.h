@@ -150,6 +150,7 @@ struct ConvArgs {
 
 struct ConvConfig {
   int MT, NT, uniform, post, ncb, cg, ksteps, kchunk, ntaps, npatches, gws, ppw;
+  int f8t;           // 1: conv3_f8t_kernel (e4m3 48 -> 48 3x3: input tile in LDS, filter in registers) instead of conv_f8_kernel
   int tile;          // > 0: conv3_tile_kernel with this many 16-pixel column tiles per wave (else conv_kernel)
   int reg;           // > 0: conv3_reg_kernel (filter in registers) with this many 16-pixel column tiles per wave
   int pair;          // > 0: conv3_pair_kernel (64 -> 64: filter halves in the registers of two waves per SIMD)
@@ -204,6 +205,9 @@ int conv_f8_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int 
 void conv_f8_pack_weights(const float* w_oihw, int Cout, int Cin, int k, const ConvConfig& cfg, std::vector<uint8_t>* out,
                           std::vector<float>* wscale);
 int conv_f8_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s);
+// conv3_f8t.hip: the LDS-tile form of the 48 -> 48 e4m3 3x3 conv (same packed filters, bit-identical to conv_f8_kernel)
+bool conv3_f8t_fits(const ConvConfig& cfg, int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo);
+int conv3_f8t_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s);
 uint8_t f32_to_e4m3(float f);
 
 // ------------------------------------------------------------------------ elementwise-ish
