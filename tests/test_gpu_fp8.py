@@ -69,22 +69,26 @@ def test_conv_f8_vs_torch(gpu_device, B, Cin, Cout, H, W, k, s, kern, mode):
 
 
 F8T_CASES = [
-    # B, H, W     conv3_f8t_kernel (48 -> 48 3x3: input tile in LDS, filter in registers), forced onto small maps too
-    (3, 40, 40),
-    (2, 33, 150),     # wide rows: a tile is less than two rows
-    (5, 7, 9),        # images much smaller than a tile
-    (6, 160, 160),    # more than one round of 512 workgroups: full tiles behind the short first round
+    # C, B, H, W     conv3_f8t_kernel (48 -> 48 / 96 -> 96 3x3: input tile in LDS, filter in registers), forced onto small maps too
+    (48, 3, 40, 40),
+    (48, 2, 33, 150),     # wide rows: a tile is less than two rows
+    (48, 5, 7, 9),        # images much smaller than a tile
+    (48, 6, 160, 160),    # more than one round of 512 workgroups: full tiles behind the short first round
+    (96, 3, 40, 40),      # eight waves: two channel blocks x four columns
+    (96, 2, 21, 150),
+    (96, 4, 5, 6),
+    (96, 2, 160, 160),    # more than one round of 256 workgroups
 ]
 
 
-@pytest.mark.parametrize("B,H,W", F8T_CASES)
+@pytest.mark.parametrize("C,B,H,W", F8T_CASES)
 @pytest.mark.parametrize("mode", ["bf16", "bf16+res", "fp8", "fp8+res8"])
 @pytest.mark.parametrize("kord", ["1", "0"])
-def test_conv3_f8_tile_kernel_vs_torch_and_direct(gpu_device, monkeypatch, B, H, W, mode, kord):
+def test_conv3_f8_tile_kernel_vs_torch_and_direct(gpu_device, monkeypatch, C, B, H, W, mode, kord):
     """csrc/conv3_f8t.hip against torch on the same quantised operands (tolerances of test_conv_f8_vs_torch) and against
     conv_f8_kernel: same packed filters, same k-steps in the same order (plane-major and tap-major) -> bit-identical."""
-    g = torch.Generator().manual_seed(B * 1000 + H + W)
-    Cin = Cout = 48
+    g = torch.Generator().manual_seed(B * 1000 + H + W + C)
+    Cin = Cout = C
     in_scale = 0.037
     xq = e4m3_round(torch.randn(B, Cin, H, W, generator=g) * 30)
     w = torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5
@@ -98,7 +102,8 @@ def test_conv3_f8_tile_kernel_vs_torch_and_direct(gpu_device, monkeypatch, B, H,
         out_scale = 0.05
     monkeypatch.setenv("YL_F8_KORD", "1" if kord == "1" else "0")   # plane-major K order from 1 pixel per image up / never
     monkeypatch.setenv("YL_F8_TILE_MIN", "1")
-    y = run_conv_f8(gpu_device, xq, in_scale, w, b, 3, 1, True, res, res_scale, out_scale, expect_kernel="conv3x3_f8t_mfma")
+    monkeypatch.setenv("YL_F8_TILE", "2")   # the 96-channel form is opt-in
+    y = run_conv_f8(gpu_device, xq, in_scale, w, b, 3, 1, True, res, res_scale, out_scale, expect_kernel="conv3x3_f8_tile_mfma")
     ref = _ref(xq, in_scale, w, b, 3, 1, True, res, res_scale)
     if out_scale > 0:
         want = e4m3_round(ref / out_scale)

@@ -1,4 +1,5 @@
-// e4m3 3x3 stride-1 Conv 48 -> 48 (three planes of 16 channels) with the INPUT TILE IN LDS and the FILTER IN REGISTERS (round 5).
+// e4m3 3x3 stride-1 Conv 48 -> 48 / 96 -> 96 (three / six planes of 16 channels) with the INPUT TILE IN LDS and the FILTER IN REGISTERS
+// (round 5).
 //
 // Reference semantics and quantisation exactly as conv_f8.hip (nn/modules/conv.py:35-53 with the BN folded, Bottleneck add
 // nn/modules/block.py:341-343; BASELINE.json config 5): same packed filters (conv_f8_pack_weights order), same k-steps of eight
@@ -11,9 +12,11 @@
 // round trip, requested while the previous tile's epilogue runs), every wave keeps the whole 48 x 432 filter in 96 registers, and
 // the k-loop reads its fragments from LDS: 48 MFMAs (16x16x128) per wave and tile behind 32 ds_read_b128.
 //
-// Tiles, staging, counted wait, barriers and the balanced short first round as conv3_cs1b_kernel (conv3_cs.hip): four waves = four
-// columns of up to four 16-position fragments.  In the guarded layout a tap is a constant offset of the linear position; a
-// k-group (tap, plane) is therefore one constant LDS offset per lane and k-step, computed once per kernel.
+// Tiles, staging, counted wait, barriers and the balanced short first round as conv3_cs1b_kernel (conv3_cs.hip).  48 -> 48: four waves =
+// four columns of up to four 16-position fragments (tiles of 256 positions, two workgroups per CU).  96 -> 96 (864 x 96 filter): eight
+// waves = two channel blocks of 48 x four columns of up to two fragments (tiles of 128 positions, one workgroup per CU); a wave holds its
+// block's 48 x 864 filter in 168 registers.  In the guarded layout a tap is a constant offset of the linear position; a k-group
+// (tap, plane) is therefore one constant LDS offset per lane and k-step, computed once per kernel.
 #include "conv_common.h"
 
 namespace yl {
@@ -22,16 +25,18 @@ typedef int f8t_v8i __attribute__((ext_vector_type(8)));
 typedef int f8t_v4i __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void_t8;
 
-constexpr int F8T_L = 256;  // positions of a full tile (four columns of 64)
+constexpr int F8T_NCOL = 4;  // columns of a tile = waves per channel block
+constexpr int f8t_ntm(int CG) { return CG == 3 ? 4 : 2; }            // fragments per wave of a full tile
+constexpr int f8t_L(int CG) { return F8T_NCOL * f8t_ntm(CG) * 16; }  // positions of a full tile (256 / 128)
 
-static __host__ __device__ inline int f8t_PL(int W1) { return (F8T_L + 2 * W1 + 2 + 63) & ~63; }  // staged positions per plane
+static __host__ __device__ inline int f8t_PL(int L, int W1) { return (L + 2 * W1 + 2 + 63) & ~63; }  // staged positions per plane
 
 // One tile of NT fragments per wave: k-loop from LDS, `mid()` (free the buffer, request the next tile), epilogue (conv_f8_kernel's).
 template <int CG, int NT, typename Mid>
-__device__ __forceinline__ void f8t_tile(const ConvArgs& a, const f8t_v8i (&wf)[(9 * CG + 7) / 8][CG], const int (&koff)[(9 * CG + 7) / 8][2],
-                                         const unsigned char* tb, int r0, int n, int g, const __amdgpu_buffer_rsrc_t& rout,
+__device__ __forceinline__ void f8t_tile(const ConvArgs& a, const f8t_v8i (&wf)[(9 * CG + 7) / 8][3], const unsigned (&koff)[(9 * CG + 7) / 8],
+                                         const unsigned char* tb, int r0, int n, int g, int cb, const __amdgpu_buffer_rsrc_t& rout,
                                          const __amdgpu_buffer_rsrc_t& rres, Mid mid) {
-  constexpr int KSN = (9 * CG + 7) / 8, MT = CG;
+  constexpr int KSN = (9 * CG + 7) / 8, MT = 3;  // a wave's channel block: 48 output channels
   f32x4 acc[MT][NT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
@@ -42,8 +47,8 @@ __device__ __forceinline__ void f8t_tile(const ConvArgs& a, const f8t_v8i (&wf)[
     f8t_v8i xb[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const f8t_v4i lo = *reinterpret_cast<const f8t_v4i*>(tb + nt * 256 + koff[ks][0]);
-      const f8t_v4i hi = *reinterpret_cast<const f8t_v4i*>(tb + nt * 256 + koff[ks][1]);
+      const f8t_v4i lo = *reinterpret_cast<const f8t_v4i*>(tb + nt * 256 + (koff[ks] & 0xffffu));
+      const f8t_v4i hi = *reinterpret_cast<const f8t_v4i*>(tb + nt * 256 + (koff[ks] >> 16));
       xb[nt] = f8t_v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     }
 #pragma unroll
@@ -68,7 +73,7 @@ __device__ __forceinline__ void f8t_tile(const ConvArgs& a, const f8t_v8i (&wf)[
   }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
-    const int co = mt * 16 + g * 4;
+    const int co = cb * 48 + mt * 16 + g * 4;
     const f32x4 alpha_r = *reinterpret_cast<const f32x4*>(a.alpha + co);
     const f32x4 bias_r = *reinterpret_cast<const f32x4*>(a.bias + co);
 #pragma unroll
@@ -116,18 +121,19 @@ __device__ __forceinline__ void f8t_tile(const ConvArgs& a, const f8t_v8i (&wf)[
 }
 
 template <int CG>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv3_f8t_kernel(ConvArgs a) {
+__global__ __launch_bounds__(64 * F8T_NCOL * (CG / 3)) __attribute__((amdgpu_waves_per_eu(2))) void conv3_f8t_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tsm[];
-  constexpr int KSN = (9 * CG + 7) / 8, MT = CG;
+  constexpr int KSN = (9 * CG + 7) / 8, MT = 3, NCB = CG / 3, NW = NCB * F8T_NCOL, NTM = f8t_ntm(CG), L = f8t_L(CG);
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // = column of the tile
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int cb = wave / F8T_NCOL, col = wave % F8T_NCOL;  // channel block, column of the tile
   const int g = lane >> 4, n = lane & 15;
   const int G = gridDim.x;
   const int wg = xcd_remap(blockIdx.x, G);
   const int PL = a.t_PL, PLB = PL * 16;
   const int Lr = a.t_px, nsmall = a.t_ppp, S = nsmall * Lr;  // the short round: tiles of Lr positions, nsmall of them, S positions in all
   const int has_small = wg < nsmall ? 1 : 0;
-  const int nfull = a.t_ntiles > wg ? (a.t_ntiles - wg + G - 1) / G : 0;  // this workgroup's 256-position tiles
+  const int nfull = a.t_ntiles > wg ? (a.t_ntiles - wg + G - 1) / G : 0;  // this workgroup's full tiles
   const int ntl = has_small + nfull;
   const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, (short)0, a.in_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.out, (short)0, a.out_bytes, 0x00020000);
@@ -138,34 +144,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
   auto tile_of = [&](int i, int& nt) __attribute__((always_inline)) -> int {
     if (has_small) {
       if (i == 0) {
-        nt = Lr >> 6;
+        nt = Lr / (16 * F8T_NCOL);
         return wg * Lr;
       }
       --i;
     }
-    nt = 4;
-    return S + (wg + i * G) * F8T_L;
+    nt = NTM;
+    return S + (wg + i * G) * L;
   };
-  // a tile -> LDS: the CG x np pieces of 1 KiB (64 positions of one plane) go round the four waves; a run past the slice reads zeros
-  // (pieces j = wave, wave + 4, .. of every plane)
+  // a tile -> LDS: pieces of 1 KiB (64 positions of one plane), j = wave, wave + NW, .. of every plane; a run past the slice reads zeros
   auto stage = [&](int pos, int nt) __attribute__((always_inline)) {
     const int src0 = (a.in_g0 + pos - a.in_w1 - 1) * 16;  // first staged guarded position (>= 0)
-    const int np = (64 * nt + 2 * a.in_w1 + 2 + 63) >> 6;
+    const int np = (16 * F8T_NCOL * nt + 2 * a.in_w1 + 2 + 63) >> 6;
 #pragma unroll
     for (int plane = 0; plane < CG; ++plane)
-      for (int j = wave; j < np; j += 4)
+      for (int j = wave; j < np; j += NW)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void_t8*)(tsm + plane * PLB + j * 1024), 16,
                                                  (int)(lane16 + (unsigned)(plane * (int)a.in_plane + src0 + j * 1024)), 0, 0, 0);
   };
-  int nt_cur = 4, pos_cur = 0;
+  int nt_cur = NTM, pos_cur = 0;
   if (ntl > 0) {
     pos_cur = tile_of(0, nt_cur);
     stage(pos_cur, nt_cur);
   }
-  // the whole filter (cb = 0), conv_f8_pack_weights order [k-step][MT][half][64 lanes] x 16 bytes
+  // this wave's channel block of the filter, conv_f8_pack_weights order [cb][k-step][MT][half][64 lanes] x 16 bytes
   f8t_v8i wf[KSN][MT];
   {
-    const f8t_v4i* wsrc = reinterpret_cast<const f8t_v4i*>(a.wpk) + lane;
+    const f8t_v4i* wsrc = reinterpret_cast<const f8t_v4i*>(a.wpk) + (size_t)cb * KSN * MT * 128 + lane;
 #pragma unroll
     for (int ks = 0; ks < KSN; ++ks)
 #pragma unroll
@@ -174,11 +179,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
         wf[ks][mt] = f8t_v8i{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
       }
   }
-  // LDS byte offset of this lane's two k-groups of every k-step, relative to its position in plane 0 (a group past the end of K
-  // has zero filters: it may read any staged bytes -- the centre tap of plane 0)
-  int koff[KSN][2];
+  // LDS byte offset of this lane's two k-groups of every k-step, relative to the FIRST staged position of its column in plane 0 (tap
+  // (kh, kw) = kh rows + kw positions further), two 16-bit halves of one register (host: the tile is at most 64 KB).  A group past the
+  // end of K has zero filters: it may read any staged bytes (offset 0).
+  unsigned koff[KSN];
 #pragma unroll
-  for (int ks = 0; ks < KSN; ++ks)
+  for (int ks = 0; ks < KSN; ++ks) {
+    unsigned two[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int q = ks * 8 + 2 * g + h;
@@ -192,10 +199,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
       }
       const bool real = q < 9 * CG;
       const int kh = (tap * 11) >> 5;
-      koff[ks][h] = real ? c16 * PLB + ((kh - 1) * a.in_w1 + (tap - 3 * kh - 1)) * 16 : 0;
+      two[h] = real ? (unsigned)(c16 * PLB + (kh * a.in_w1 + (tap - 3 * kh)) * 16) : 0u;
     }
-  // the lane's position 0 of plane 0 inside the staged run: the run starts W1 + 1 positions in front of the tile
-  const unsigned char* const tb0 = tsm + (a.in_w1 + 1 + n) * 16;
+    koff[ks] = two[0] | (two[1] << 16);
+  }
+  // the lane's position inside the staged run: the run starts W1 + 1 positions in front of the tile (tap (0, 0) of the tile's position 0)
+  const unsigned char* const tb0 = tsm + n * 16;
   int nt_prev = 0;
   for (int i = 0; i < ntl; ++i) {
     // my pieces of this tile are OLDER than the previous tile's epilogue stores (at most 2 MT nt_prev of them, fewer without the e4m3
@@ -208,7 +217,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
       default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
     __builtin_amdgcn_s_barrier();
-    int nt_next = 4, pos_next = 0;
+    int nt_next = NTM, pos_next = 0;
     const bool more = i + 1 < ntl;
     if (more) pos_next = tile_of(i + 1, nt_next);
     auto mid = [&]() __attribute__((always_inline)) {
@@ -216,13 +225,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
       __builtin_amdgcn_s_barrier();  // everybody has read the tile: the buffer may be refilled
       if (more) stage(pos_next, nt_next);
     };
-    const unsigned char* const tb = tb0 + wave * 16 * nt_cur * 16;
-    const int r0 = pos_cur + wave * 16 * nt_cur;
-    switch (nt_cur) {
-      case 4: f8t_tile<CG, 4>(a, wf, koff, tb, r0, n, g, rout, rres, mid); break;
-      case 3: f8t_tile<CG, 3>(a, wf, koff, tb, r0, n, g, rout, rres, mid); break;
-      case 2: f8t_tile<CG, 2>(a, wf, koff, tb, r0, n, g, rout, rres, mid); break;
-      default: f8t_tile<CG, 1>(a, wf, koff, tb, r0, n, g, rout, rres, mid); break;
+    const unsigned char* const tb = tb0 + col * 16 * nt_cur * 16;
+    const int r0 = pos_cur + col * 16 * nt_cur;
+    if constexpr (NTM == 4) {
+      switch (nt_cur) {
+        case 4: f8t_tile<CG, 4>(a, wf, koff, tb, r0, n, g, cb, rout, rres, mid); break;
+        case 3: f8t_tile<CG, 3>(a, wf, koff, tb, r0, n, g, cb, rout, rres, mid); break;
+        case 2: f8t_tile<CG, 2>(a, wf, koff, tb, r0, n, g, cb, rout, rres, mid); break;
+        default: f8t_tile<CG, 1>(a, wf, koff, tb, r0, n, g, cb, rout, rres, mid); break;
+      }
+    } else {
+      if (nt_cur == 2) f8t_tile<CG, 2>(a, wf, koff, tb, r0, n, g, cb, rout, rres, mid);
+      else f8t_tile<CG, 1>(a, wf, koff, tb, r0, n, g, cb, rout, rres, mid);
     }
     nt_prev = nt_cur;
     nt_cur = nt_next;
@@ -233,40 +247,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
 // ------------------------------------------------------------------------------------ host
 static unsigned f8t_magic(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull / (unsigned)d) + 1ull); }
 
-// may this conv take the tile kernel?  (3x3 stride 1, 48 -> 48, one channel block, enough positions, the tile fits the LDS twice per CU)
+// may this conv take the tile kernel?  (3x3 stride 1, 48 -> 48 or 96 -> 96 in channel blocks of 48, enough positions, the tile fits the LDS)
 bool conv3_f8t_fits(const ConvConfig& cfg, int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo) {
+  // YL_F8_TILE: 0 never, 1 (default) the 48-channel form, 2 the 96-channel form too.  Config 5, A / B on one box: 48 only 1 117 -> 1 129
+  // images/s (+1 %); with the 96-channel form 1 095 (-2 %: its eight 256-register waves take a whole CU per workgroup, which costs the
+  // other batches in flight more than its 8 % shorter launch, 38.5 against 41.7 us, gives back); one batch at a time both +2.5 %.
   const int enable = getenv("YL_F8_TILE") ? atoi(getenv("YL_F8_TILE")) : 1;
-  if (!enable || k != 3 || stride != 1 || Cin != 48 || Cout != 48 || cfg.ncb != 1 || cfg.MT != 3 || cfg.cg != 3) return false;
+  if (!enable || k != 3 || stride != 1 || Cin != Cout || (Cin != 48 && !(Cin == 96 && enable >= 2)) || cfg.MT != 3 || cfg.ncb != Cout / 48 ||
+      cfg.cg != Cin / 16)
+    return false;
   const long long img = (long long)(Ho + 1) * (Wo + 1), nq = (long long)batch * img;
   const long long rows = (long long)batch * (Ho + 1);
   if ((nq + 512) * (Wo + 1) >= (1LL << 32) || rows * (Ho + 1) >= (1LL << 32) || nq >= (1LL << 30)) return false;  // exactness of the magic divisions
   const long long min_pos = getenv("YL_F8_TILE_MIN") ? atoll(getenv("YL_F8_TILE_MIN")) : 65536;
   if (nq < min_pos) return false;
-  return (size_t)3 * f8t_PL(Wo + 1) * 16 <= 80 * 1024;
+  const int CG = Cin / 16;
+  return (size_t)CG * f8t_PL(CG == 3 ? f8t_L(3) : f8t_L(6), Wo + 1) * 16 <= 64 * 1024 - 64;  // (16-bit tap offsets)
 }
 
-int conv3_f8t_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s) {
-  if (a.stride != 1 || a.in_w1 != a.out_w1 || a.in_img != a.out_img || a.in_g0 != a.out_g0 || a.in_w1 != a.Wo + 1 || a.Cin != 48 ||
-      a.Cout != 48 || cfg.ntaps != 9)
-    return fail(-3, "conv3_f8t: needs a 48 -> 48 3x3 stride-1 conv between planar tensors of one geometry");
-  constexpr int CG = 3;
-  a.t_B = batch;
-  a.t_H = a.Ho;
-  a.t_W = a.Wo;
-  a.t_PL = f8t_PL(a.in_w1);
-  a.magic_img = f8t_magic(a.Ho + 1);  // (rows per image: the kernel divides position -> batch row -> image)
-  a.magic_w1 = f8t_magic(a.in_w1);
+template <int CG>
+static int f8t_launch_t(ConvArgs a, int batch, hipStream_t s) {
+  constexpr int L = f8t_L(CG), U = 16 * F8T_NCOL;  // full tile, unit of the short round
+  a.t_PL = f8t_PL(L, a.in_w1);
   const long long nq = (long long)batch * a.in_img;
-  const long long nq64 = (nq + 63) & ~63LL;
-  const int resident = 2 * device_cu_count();  // two persistent workgroups per CU
-  const long long per_round = (long long)resident * F8T_L;
-  const long long rounds = nq64 / per_round, rem = nq64 - rounds * per_round;
-  int Lr = rem > 0 ? (int)(((rem + resident - 1) / resident + 63) & ~63LL) : 0;
+  const long long nqu = (nq + U - 1) / U * U;
+  const int resident = (CG == 3 ? 2 : 1) * device_cu_count();  // persistent workgroups: two of four waves / one of eight per CU
+  const long long per_round = (long long)resident * L;
+  const long long rounds = nqu / per_round, rem = nqu - rounds * per_round;
+  int Lr = rem > 0 ? (int)(((rem + resident - 1) / resident + U - 1) / U * U) : 0;
   int nsmall = 0;
-  if (Lr >= F8T_L) Lr = 0;  // the remainder fills whole tiles: no short round
+  if (Lr >= L) Lr = 0;  // the remainder fills whole tiles: no short round
   if (Lr > 0) nsmall = (int)((rem + Lr - 1) / Lr);
   const long long S = (long long)nsmall * Lr;
-  const int nfull_tiles = nq64 > S ? (int)((nq64 - S + F8T_L - 1) / F8T_L) : 0;
+  const int nfull_tiles = nqu > S ? (int)((nqu - S + L - 1) / L) : 0;
   a.t_px = Lr;
   a.t_ppp = nsmall;
   a.t_ntiles = nfull_tiles;
@@ -276,9 +289,21 @@ int conv3_f8t_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s
   const size_t lds = (size_t)CG * a.t_PL * 16;
   auto kern = conv3_f8t_kernel<CG>;
   if (int rc = allow_big_lds(reinterpret_cast<const void*>(kern), (int)(160 * 1024))) return rc;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * F8T_NCOL * (CG / 3)), lds, s, a);
   YL_HIP(hipGetLastError());
   return 0;
+}
+
+int conv3_f8t_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s) {
+  if (a.stride != 1 || a.in_w1 != a.out_w1 || a.in_img != a.out_img || a.in_g0 != a.out_g0 || a.in_w1 != a.Wo + 1 || a.Cin != a.Cout ||
+      (a.Cin != 48 && a.Cin != 96) || cfg.ntaps != 9)
+    return fail(-3, "conv3_f8t: needs a 48 -> 48 or 96 -> 96 3x3 stride-1 conv between planar tensors of one geometry");
+  a.t_B = batch;
+  a.t_H = a.Ho;
+  a.t_W = a.Wo;
+  a.magic_img = f8t_magic(a.Ho + 1);  // (rows per image: the kernel divides position -> batch row -> image)
+  a.magic_w1 = f8t_magic(a.in_w1);
+  return a.Cin == 48 ? f8t_launch_t<3>(a, batch, s) : f8t_launch_t<6>(a, batch, s);
 }
 
 }  // namespace yl

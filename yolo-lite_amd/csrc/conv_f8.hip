@@ -361,7 +361,7 @@ int conv_f8_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int 
   c->gws = (int)(((long long)c->npatches + 4 * ppw - 1) / (4 * ppw));
   c->name = k == 3 ? (stride == 2 ? "conv3x3s2_f8_mfma" : "conv3x3_f8_mfma") : "conv1x1_f8_mfma";
   c->f8t = conv3_f8t_fits(*c, batch, Cin, Cout, k, stride, Ho, Wo) ? 1 : 0;
-  if (c->f8t) c->name = "conv3x3_f8t_mfma";
+  if (c->f8t) c->name = "conv3x3_f8_tile_mfma";
   return 0;
 }
 
