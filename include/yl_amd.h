@@ -169,7 +169,10 @@ typedef struct yl_op {
   /* ops made of more than three convs (YL_OP_C3K): n_extra further BN-folded fp32 filters / biases, arrays of HOST pointers
      (read by yl_engine_create only, like weight / bias) */
   int32_t n_extra, reserved3;        /* reserved3: YL_OP_C3K: workgroups per image (2: each takes half of the rows + a halo of four -- the
-                                        latency profile of a caller that runs one batch at a time; 0 / 1: one) */
+                                        latency profile of a caller that runs one batch at a time; 0 / 1: one).
+                                        YL_OP_CONV with stem_weight and YL_OP_C3K2S: bit 8 (0x100) = keep the output cacheable --
+                                        no non-temporal hint on its stores: its reader is the next launch of a caller that runs
+                                        one batch at a time (the latency profile); results are the same either way */
   const float* const* extra_weight;
   const float* const* extra_bias;
   /* YL_OP_DWCONV3 with post_weight (depthwise 3x3 -> pointwise 1x1 in one launch) AND stem_weight: a further 1x1

@@ -1141,6 +1141,7 @@ static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s, c
         const long long ob = (long long)((o.out.C + 7) / 8) * plane_bytes(geo_of(B, o.out.H, o.out.W));
         if (ob > (1LL << 30)) return fail(-3, "stem2: the output slice exceeds 1 GiB; lower the batch size");
         q.out_bytes = (unsigned)ob;
+        q.cacheable = (o.reserved3 & 0x100) ? 1 : 0;
         if (sink && sink->zero_ptr) {  // (detect_eager: this launch clears the step's NMS candidate counters on its way)
           q.zero_ptr = sink->zero_ptr;
           q.zero_n = sink->zero_n;
@@ -1335,6 +1336,7 @@ static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s, c
       if (ib > (1LL << 30) || ob > (1LL << 30)) return fail(-3, "c3k2: a tensor slice exceeds 1 GiB; lower the batch size");
       q.in_bytes = (unsigned)ib;
       q.out_bytes = (unsigned)ob;
+      q.cacheable = (o.reserved3 & 0x100) ? 1 : 0;
       q.plane_px = gq.plane_px;
       return c3k2s_launch(q, s);
     }

@@ -283,6 +283,7 @@ struct Stem2Args {
   PView out;
   unsigned out_bytes;
   int st_nt;             // non-temporal stores (st_nt_policy), filled by stem2_launch
+  int cacheable;         // 1: never (yl_op.reserved3 bit 8: the latency profile's reader runs next)
   int tiles_x, tiles_y;
   int32_t* zero_ptr;           // zero_n words the first workgroup clears (the NMS candidate counters of this step:
   int zero_n;                  // PrefilterSink::zero_ptr -- one launch less in front of the network); 0: none
@@ -304,6 +305,7 @@ struct C3k2sArgs {
   const float* bC;
   unsigned in_bytes, out_bytes;
   int st_nt;             // non-temporal stores (st_nt_policy), filled by c3k2s_launch
+  int cacheable;         // 1: never (yl_op.reserved3 bit 8)
   long long plane_px;    // pixels per input plane
   int tiles_x, tiles_y;
 };

@@ -76,7 +76,8 @@ class HipEngine:
                 pb = (C.c_void_p * len(xb))(*[b.ctypes.data for b in xb])
                 self._keep += xw + xb + [pw, pb]
                 c.n_extra, c.extra_weight, c.extra_bias = len(xw), C.cast(pw, C.c_void_p), C.cast(pb, C.c_void_p)
-            c.reserved3 = int(o.get("split", 0))  # YL_OP_C3K: workgroups per image (0 = the engine's choice)
+            # YL_OP_C3K: workgroups per image (0 = the engine's choice); fused stem / C3k2: bit 8 = keep the output cacheable
+            c.reserved3 = int(o.get("split", 0)) | (0x100 if o.get("cacheable") else 0)
             if "post_weight" in o:
                 w2 = np.ascontiguousarray(o["post_weight"], dtype=np.float32).reshape(o["post_weight"].shape[0], -1)
                 b2 = np.ascontiguousarray(o["post_bias"], dtype=np.float32)

@@ -1081,6 +1081,12 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
         ops[:] = fuse_stem_into_conv(ops, in_w)
     if fuse_post and os.environ.get("YL_FUSE_C3K2", "1") != "0":
         ops[:] = fuse_c3k2_small(ops)
+    if one_batch and os.environ.get("YL_LAT_CACHEABLE", "1") != "0":
+        # one batch at a time: the readers of the fused stem's / the narrow C3k2 blocks' outputs are the next launches -- keep those
+        # outputs cacheable (no non-temporal hint on the stores; yl_op.reserved3 bit 8): layer 2 then takes 45.5 instead of 54.1 us
+        for o in ops:
+            if o["kind"] == OP_C3K2S or (o["kind"] == OP_CONV and "stem_weight" in o):
+                o["cacheable"] = 1
     if fp8_scales:
         # opt-in: e4m3 mirrors make the 1x1 convs fp8 too (90 % of YOLO11x's conv FLOPs; 923 -> 1023 images/s at 1280x1280
         # batch 8) but the detections then leave the stated fp8 tolerance
