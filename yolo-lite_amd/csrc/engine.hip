@@ -817,6 +817,24 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
           memcpy(&wt[q], &u, 4);
         }
         if (int rc = dev_upload(e.get(), wt, &r.d_w)) return rc;
+        {
+          // the same filter in MFMA A-fragment order, bf16: [16-channel block][lane][8] -- lane (row p = lane & 15, k-group lane >> 4)
+          // holds taps k = 8 (lane >> 4) + j of output channel block * 16 + p, zero from tap 27 on: ONE 16-byte load per lane and
+          // block in stem_kernel instead of eight scattered dword loads (round 5)
+          std::vector<uint16_t> pk((size_t)(o.out.C / 16) * 64 * 8, 0);
+          for (int mb = 0; mb < o.out.C / 16; ++mb)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int j = 0; j < 8; ++j) {
+                const int k = (lane >> 4) * 8 + j;
+                if (k >= 27) continue;
+                uint32_t u;
+                memcpy(&u, &wt[(size_t)(mb * 16 + (lane & 15)) * 27 + k], 4);
+                pk[((size_t)mb * 64 + lane) * 8 + j] = (uint16_t)(u >> 16);  // (wt is bf16-rounded: the low half is zero)
+              }
+          uint16_t* d = nullptr;
+          if (int rc = dev_upload(e.get(), pk, &d)) return rc;
+          r.d_wpk = reinterpret_cast<__bf16*>(d);
+        }
         std::vector<float> bias(o.bias, o.bias + o.out.C);
         if (int rc = dev_upload(e.get(), bias, &r.d_bias)) return rc;
         r.flops = 2.0 * px_out * o.out.C * 27;
@@ -1346,6 +1364,7 @@ static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s, c
       a.in = input;
       a.out = pview(ws, o.out, B);
       a.w = r.d_w;
+      a.wpk = r.d_wpk;
       a.bias = r.d_bias;
       a.B = B;
       a.H = e->in_h;

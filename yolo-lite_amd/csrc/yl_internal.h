@@ -254,6 +254,7 @@ struct StemArgs {
   const void* in;     // NCHW [B][3][H][W]
   PView out;
   const float* w;     // [Cout][27] (bf16-rounded values)
+  const __bf16* wpk;  // the same in MFMA A-fragment order [Cout / 16][64 lanes][8] (taps 27..31 zero); nullptr: gather from w
   const float* bias;
   int B, H, W, Ho, Wo, Cout, act, nseg;
   unsigned char* out8;   // e4m3 copy of the output (planes of 16 channels, same pixel geometry), nullptr: none
