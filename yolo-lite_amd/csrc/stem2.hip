@@ -178,17 +178,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
     for (int j = 0; j < 8; ++j) rp[j] = imgb + koffb[j] + 4u * (unsigned)n + 64u * (unsigned)wave;
     const int sx0 = 2 * x0 - 1 + wave * 16;
     const bool col_in = sx0 >= 0 && sx0 + 15 < a.W0;  // scalar: no pixel of this tile column is layer 1's zero padding
-    for (int mb = 0; mb < a.C0; mb += 16) {
-      bf16x8 af;
+    // (round 5) The 16-channel blocks of the stem (one for YOLO11n, two for YOLO11s) share a tile's im2col fragment: it is gathered
+    // ONCE per tile and feeds one MFMA per block -- the gather (8 ds_read_u16 + 4 v_perm) is the larger part of a tile's instructions.
+    constexpr int NMB = CG0 / 2;
+    bf16x8 af[NMB];
+    f32x4 bv[NMB];
+    unsigned char* sbase[NMB];
+    unsigned char* wp[NMB];
+#pragma unroll
+    for (int mbi = 0; mbi < NMB; ++mbi) {
+      const int mb = 16 * mbi;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int k = g * 8 + j;
-        af[j] = (__bf16)(k < 27 ? a.w0[(mb + n) * 27 + k] : 0.f);
+        af[mbi][j] = (__bf16)(k < 27 ? a.w0[(mb + n) * 27 + k] : 0.f);
       }
-      const f32x4 bv = *reinterpret_cast<const f32x4*>(a.b0 + mb + g * 4);
+      bv[mbi] = *reinterpret_cast<const f32x4*>(a.b0 + mb + g * 4);
       const int ch = mb + g * 4;
-      unsigned char* const sbase = stile + (size_t)(ch >> 3) * S2_SR * S2_SP * 16 + (ch & 7) * 2;
-      unsigned char* const wp = sbase + (size_t)((wave * 16 + n) * 16);
+      sbase[mbi] = stile + (size_t)(ch >> 3) * S2_SR * S2_SP * 16 + (ch & 7) * 2;
+      wp[mbi] = sbase[mbi] + (size_t)((wave * 16 + n) * 16);
+    }
+    {
       // (the SiLU flag is a compile-time constant inside: left as a runtime test of a.act0, hipcc branched around every
       // single SiLU and shuttled the accumulators through AGPRs between the branches)
       auto stem_tiles = [&](auto act_tag) __attribute__((always_inline)) {
@@ -210,22 +220,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
             for (int j = 0; j < 8; ++j) bf[u][j] = *reinterpret_cast<const __bf16*>(rp[j] + r * ROWB);
 #endif
           }
-          f32x4 acc[NU];
 #pragma unroll
-          for (int u = 0; u < NU; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bf[u], bv, 0, 0, 0);
+          for (int mbi = 0; mbi < NMB; ++mbi) {
+            f32x4 acc[NU];
 #pragma unroll
-          for (int u = 0; u < NU; ++u) {
-            const int r = r0 + u;
-            if (r >= S2_SR) continue;
-            bf16x4 o;
-            const f32x4 sv = (ACT0 && !(YL_STEM2_ABL & 4)) ? silu4(acc[u]) : acc[u];
+            for (int u = 0; u < NU; ++u) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mbi], bf[u], bv[mbi], 0, 0, 0);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) o[q] = (__bf16)sv[q];
-            const bool row_in = (unsigned)(2 * y0 - 1 + r) < (unsigned)a.H0;  // scalar
-            if (!(row_in && col_in)) {  // (scalar branch) stem positions outside the stem map are layer 1's zero padding
-              if (!(row_in && (unsigned)(sx0 + n) < (unsigned)a.W0)) o = z;
+            for (int u = 0; u < NU; ++u) {
+              const int r = r0 + u;
+              if (r >= S2_SR) continue;
+              bf16x4 o;
+              const f32x4 sv = (ACT0 && !(YL_STEM2_ABL & 4)) ? silu4(acc[u]) : acc[u];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) o[q] = (__bf16)sv[q];
+              const bool row_in = (unsigned)(2 * y0 - 1 + r) < (unsigned)a.H0;  // scalar
+              if (!(row_in && col_in)) {  // (scalar branch) stem positions outside the stem map are layer 1's zero padding
+                if (!(row_in && (unsigned)(sx0 + n) < (unsigned)a.W0)) o = z;
+              }
+              *reinterpret_cast<bf16x4*>(wp[mbi] + r * (S2_SP * 16)) = o;
             }
-            *reinterpret_cast<bf16x4*>(wp + r * (S2_SP * 16)) = o;
           }
         }
         // the window's last column (c = S2_SC - 1), one lane per row: a tile of its own
@@ -235,13 +248,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
           bf16x8 bl;
 #pragma unroll
           for (int j = 0; j < 8; ++j) bl[j] = *reinterpret_cast<const __bf16*>(corner + koffb[j]);
-          const f32x4 al = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, bl, bv, 0, 0, 0);
-          bf16x4 o;
-          const f32x4 sl = (ACT0 && !(YL_STEM2_ABL & 4)) ? silu4(al) : al;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) o[q] = (__bf16)sl[q];
           const bool inside = (unsigned)(2 * y0 - 1 + r) < (unsigned)a.H0 && (unsigned)(2 * x0 - 1 + c) < (unsigned)a.W0;
-          if (n < S2_SR) *reinterpret_cast<bf16x4*>(sbase + (size_t)(r * S2_SP + c) * 16) = inside ? o : z;
+#pragma unroll
+          for (int mbi = 0; mbi < NMB; ++mbi) {
+            const f32x4 al = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mbi], bl, bv[mbi], 0, 0, 0);
+            bf16x4 o;
+            const f32x4 sl = (ACT0 && !(YL_STEM2_ABL & 4)) ? silu4(al) : al;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = (__bf16)sl[q];
+            if (n < S2_SR) *reinterpret_cast<bf16x4*>(sbase[mbi] + (size_t)(r * S2_SP + c) * 16) = inside ? o : z;
+          }
         }
       };
       if (a.act0) stem_tiles(std::true_type{});
