@@ -297,3 +297,22 @@ def test_side_lane_head_placement(monkeypatch):
         assert (len({o.get("group", 0) for o in tail} - {0}) == 2) == (side == 1)
     # a throughput program never gets lanes
     assert not any(o.get("lane", 0) for o in lower(specs, sd, 32, 640, 640).ops)
+
+
+def test_latency_profile_keeps_the_fused_stem_and_c3k2_outputs_cacheable(monkeypatch):
+    """lower(one_batch=True): the fused stem conv and the narrow C3k2 blocks carry `cacheable` (yl_op.reserved3 bit 8: no
+    non-temporal hint on their stores -- their readers are the next launches of a caller that runs one batch at a time); the
+    throughput profile marks nothing, and YL_LAT_CACHEABLE=0 turns the marking off."""
+    from yololite_amd.nn.lower import OP_C3K2S, OP_CONV
+
+    specs, _ = arch.parse_model(arch.yolo11_dict("n"))
+    sd = synth_state_dict("n", 0)
+    thr = lower(specs, sd, 32, 640, 640)
+    assert not any(o.get("cacheable") for o in thr.ops)
+    lat = lower(specs, sd, 32, 640, 640, one_batch=True)
+    marked = [o for o in lat.ops if o.get("cacheable")]
+    assert marked and all(o["kind"] == OP_C3K2S or (o["kind"] == OP_CONV and "stem_weight" in o) for o in marked)
+    assert sum(o["kind"] == OP_C3K2S for o in marked) == sum(o["kind"] == OP_C3K2S for o in lat.ops) == 3  # layers 2, 4, 16
+    assert sum(o["kind"] == OP_CONV for o in marked) == 1                        # the conv with the network's first layer fused in front
+    monkeypatch.setenv("YL_LAT_CACHEABLE", "0")
+    assert not any(o.get("cacheable") for o in lower(specs, sd, 32, 640, 640, one_batch=True).ops)
