@@ -68,11 +68,19 @@ typedef __attribute__((address_space(3))) void lds_void_g;
 #ifndef YL_GM6W_NS
 #define YL_GM6W_NS 2
 #endif
+#ifndef YL_GM4_KS
+#define YL_GM4_KS 2  // ... and of the 128-channel blocks (four waves, even K)
+#endif
+#ifndef YL_GM4_NS
+#define YL_GM4_NS 2
+#endif
 constexpr int gm_ks(int MTW, int NWN, bool even) {
+  if (MTW == 4 && NWN == 2 && even) return YL_GM4_KS;
   if (MTW == 6 && even) return NWN == 4 ? YL_GM6W_KS : YL_GM6_KS;
   return NWN == 4 ? (MTW == 6 ? 2 : 1) : (MTW == 2 && even ? YL_GM2_KS : ((MTW == 8 || !even) ? 1 : 2));
 }
 constexpr int gm_ns(int MTW, int NWN, bool even) {
+  if (MTW == 4 && NWN == 2 && even) return YL_GM4_NS;
   if (MTW == 6 && even) return NWN == 4 ? YL_GM6W_NS : YL_GM6_NS;
   return NWN == 4 ? (MTW == 6 ? 2 : 3) : (MTW == 8 ? 3 : (even ? (MTW == 2 ? YL_GM2_NS : 2) : 4));
 }
@@ -228,6 +236,12 @@ __global__ __launch_bounds__(128 * NWN) __attribute__((amdgpu_waves_per_eu(2))) 
   for (int st = 0; st < NS - 1; ++st) issue(cur, st, st);  // (host: at least NS - 1 slices per tile)
   int gs0 = 0;    // ring position of the tile's slice 0
   int round = 0;
+#ifdef YL_STAMPS
+  // diagnostic build: shader clocks a wave spends in the counted wait for its own pieces / in the barrier behind it, over the whole
+  // launch (tools/gemm_stamps.py); st_t0 = the wave's start
+  unsigned long long st_wait = 0, st_bar = 0, st_n = 0;
+  const unsigned long long st_t0 = __builtin_amdgcn_s_memtime();
+#endif
 
   const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.out, (short)0, a.out_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rres =
@@ -282,8 +296,19 @@ __global__ __launch_bounds__(128 * NWN) __attribute__((amdgpu_waves_per_eu(2))) 
   // older than those stores -- changed nothing: 365.7 against 368.0 us on 384 -> 384 @320x320 x 8; the stores' cost, 50-70 us of that
   // launch by ablation, is not the drain at the tile boundary.)
   auto enter = [&](int i) __attribute__((always_inline)) {
+#ifdef YL_STAMPS
+    const unsigned long long e0 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * PW) : "memory");
+    const unsigned long long e1 = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_barrier();
+    const unsigned long long e2 = __builtin_amdgcn_s_memtime();
+    st_wait += e1 - e0;
+    st_bar += e2 - e1;
+    st_n += 1;
+#else
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NS - 2) * PW) : "memory");
     __builtin_amdgcn_s_barrier();
+#endif
     const int sl = i + NS - 1;
     const bool here = sl < nk;  // (wave-uniform: scalar selects)
     Src x;
@@ -437,6 +462,16 @@ __global__ __launch_bounds__(128 * NWN) __attribute__((amdgpu_waves_per_eu(2))) 
   cur = nxt;
   gs0 = (gs0 + nk) % NS;
   }  // tiles
+#ifdef YL_STAMPS
+  if (a.stamps && lane == 0) {
+    unsigned long long* p = a.stamps + ((size_t)blockIdx.x * NW + wave) * 8;
+    p[0] = st_wait;
+    p[1] = st_bar;
+    p[2] = st_n;
+    p[3] = __builtin_amdgcn_s_memtime() - st_t0;
+    p[4] = (unsigned long long)round;
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------ host
@@ -569,6 +604,7 @@ int conv_gemm_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s
   a.res_bytes = (unsigned)resb;
   a.nblocks = cfg.gws * cfg.ncb;
   a.dbg = 0;
+  a.stamps = g_stamp_buf;
   a.st_nt = st_nt_policy(outb);
   const bool even = cfg.ksteps % 2 == 0;
   const int NWN = cfg.gemm_nwn;
