@@ -114,6 +114,10 @@ def test_conv3_f8_tile_kernel_vs_torch_and_direct(gpu_device, monkeypatch, C, B,
     else:
         err = (y - ref).abs()
         assert bool((err <= 2 ** -7 * ref.abs() + 1e-3).all()), err.max()
+    if C == 96:  # the eight-wave form (one workgroup per CU) beside the default pair of four-wave workgroups
+        monkeypatch.setenv("YL_F8_TILE_W8", "1")
+        y8 = run_conv_f8(gpu_device, xq, in_scale, w, b, 3, 1, True, res, res_scale, out_scale, expect_kernel="conv3x3_f8_tile_mfma")
+        assert torch.equal(y, y8), f"four-wave vs eight-wave tile kernel: max diff {float((y - y8).abs().max())}"
     monkeypatch.setenv("YL_F8_TILE", "0")
     direct = run_conv_f8(gpu_device, xq, in_scale, w, b, 3, 1, True, res, res_scale, out_scale, expect_kernel="conv3x3_f8_mfma")
     assert torch.equal(y, direct), f"tile kernel vs conv_f8_kernel: max diff {float((y - direct).abs().max())}"

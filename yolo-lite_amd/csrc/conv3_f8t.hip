@@ -120,16 +120,22 @@ __device__ __forceinline__ void f8t_tile(const ConvArgs& a, const f8t_v8i (&wf)[
   }
 }
 
-template <int CG>
-__global__ __launch_bounds__(64 * F8T_NCOL * (CG / 3)) __attribute__((amdgpu_waves_per_eu(2))) void conv3_f8t_kernel(ConvArgs a) {
+// NCBW: channel blocks (of 48 output channels) per workgroup = CG / 3 (one workgroup holds the whole conv: eight waves at 96 channels) or
+// 1 (96 channels: TWO four-wave workgroups walk the same tiles, one per channel block, each staging the tile for itself -- half a CU
+// per workgroup, which is what twenty batches in flight want)
+template <int CG, int NCBW>
+__global__ __launch_bounds__(64 * F8T_NCOL * NCBW) __attribute__((amdgpu_waves_per_eu(2))) void conv3_f8t_kernel(ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char tsm[];
-  constexpr int KSN = (9 * CG + 7) / 8, MT = 3, NCB = CG / 3, NW = NCB * F8T_NCOL, NTM = f8t_ntm(CG), L = f8t_L(CG);
+  constexpr int KSN = (9 * CG + 7) / 8, MT = 3, NCB = CG / 3, NW = NCBW * F8T_NCOL, NTM = f8t_ntm(CG), L = f8t_L(CG);
+  constexpr int NSPLIT = NCB / NCBW;  // workgroups per tile walk
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int cb = wave / F8T_NCOL, col = wave % F8T_NCOL;  // channel block, column of the tile
+  const int col = wave % F8T_NCOL;  // column of the tile
   const int g = lane >> 4, n = lane & 15;
-  const int G = gridDim.x;
-  const int wg = xcd_remap(blockIdx.x, G);
+  const int G = gridDim.x / NSPLIT;
+  const int wgraw = xcd_remap(blockIdx.x, gridDim.x);
+  const int wg = wgraw / NSPLIT;
+  const int cb = wave / F8T_NCOL + (wgraw % NSPLIT) * NCBW;  // channel block of this wave
   const int PL = a.t_PL, PLB = PL * 16;
   const int Lr = a.t_px, nsmall = a.t_ppp, S = nsmall * Lr;  // the short round: tiles of Lr positions, nsmall of them, S positions in all
   const int has_small = wg < nsmall ? 1 : 0;
@@ -249,9 +255,11 @@ static unsigned f8t_magic(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000u
 
 // may this conv take the tile kernel?  (3x3 stride 1, 48 -> 48 or 96 -> 96 in channel blocks of 48, enough positions, the tile fits the LDS)
 bool conv3_f8t_fits(const ConvConfig& cfg, int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo) {
-  // YL_F8_TILE: 0 never, 1 (default) the 48-channel form, 2 the 96-channel form too.  Config 5, A / B on one box: 48 only 1 117 -> 1 129
-  // images/s (+1 %); with the 96-channel form 1 095 (-2 %: its eight 256-register waves take a whole CU per workgroup, which costs the
-  // other batches in flight more than its 8 % shorter launch, 38.5 against 41.7 us, gives back); one batch at a time both +2.5 %.
+  // YL_F8_TILE: 0 never, 1 (default) the 48-channel form, 2 the 96-channel form too (a pair of four-wave workgroups per tile walk;
+  // YL_F8_TILE_W8=1: one eight-wave workgroup).  Config 5, A / B on one box: 48 only 1 117 -> 1 129 images/s (+1 %); with the
+  // 96-channel form 1 095-1 105 (-2..-2.7 %, eight-wave and four-wave form alike, although the launch alone is 8-13 % shorter: 38.9 /
+  // 36.9 against 42.6 us) -- twenty batches in flight prefer conv_f8_kernel's many short workgroups on these layers; one batch at a
+  // time both forms +2.5 %.
   const int enable = getenv("YL_F8_TILE") ? atoi(getenv("YL_F8_TILE")) : 1;
   if (!enable || k != 3 || stride != 1 || Cin != Cout || (Cin != 48 && !(Cin == 96 && enable >= 2)) || cfg.MT != 3 || cfg.ncb != Cout / 48 ||
       cfg.cg != Cin / 16)
@@ -265,13 +273,15 @@ bool conv3_f8t_fits(const ConvConfig& cfg, int batch, int Cin, int Cout, int k, 
   return (size_t)CG * f8t_PL(CG == 3 ? f8t_L(3) : f8t_L(6), Wo + 1) * 16 <= 64 * 1024 - 64;  // (16-bit tap offsets)
 }
 
-template <int CG>
+template <int CG, int NCBW>
 static int f8t_launch_t(ConvArgs a, int batch, hipStream_t s) {
   constexpr int L = f8t_L(CG), U = 16 * F8T_NCOL;  // full tile, unit of the short round
+  constexpr int NSPLIT = (CG / 3) / NCBW;          // workgroups per tile walk
   a.t_PL = f8t_PL(L, a.in_w1);
   const long long nq = (long long)batch * a.in_img;
   const long long nqu = (nq + U - 1) / U * U;
-  const int resident = (CG == 3 ? 2 : 1) * device_cu_count();  // persistent workgroups: two of four waves / one of eight per CU
+  // tile walks that stay resident: two four-wave workgroups or one eight-wave workgroup per CU
+  const int resident = (NCBW * F8T_NCOL == 4 ? 2 : 1) * device_cu_count() / NSPLIT;
   const long long per_round = (long long)resident * L;
   const long long rounds = nqu / per_round, rem = nqu - rounds * per_round;
   int Lr = rem > 0 ? (int)(((rem + resident - 1) / resident + U - 1) / U * U) : 0;
@@ -287,9 +297,9 @@ static int f8t_launch_t(ConvArgs a, int batch, hipStream_t s) {
   if (grid > resident) grid = resident;
   if (grid < 1) grid = 1;
   const size_t lds = (size_t)CG * a.t_PL * 16;
-  auto kern = conv3_f8t_kernel<CG>;
+  auto kern = conv3_f8t_kernel<CG, NCBW>;
   if (int rc = allow_big_lds(reinterpret_cast<const void*>(kern), (int)(160 * 1024))) return rc;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * F8T_NCOL * (CG / 3)), lds, s, a);
+  hipLaunchKernelGGL(kern, dim3(grid * NSPLIT), dim3(64 * F8T_NCOL * NCBW), lds, s, a);
   YL_HIP(hipGetLastError());
   return 0;
 }
@@ -303,7 +313,9 @@ int conv3_f8t_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s
   a.t_W = a.Wo;
   a.magic_img = f8t_magic(a.Ho + 1);  // (rows per image: the kernel divides position -> batch row -> image)
   a.magic_w1 = f8t_magic(a.in_w1);
-  return a.Cin == 48 ? f8t_launch_t<3>(a, batch, s) : f8t_launch_t<6>(a, batch, s);
+  if (a.Cin == 48) return f8t_launch_t<3, 1>(a, batch, s);
+  const int wide = getenv("YL_F8_TILE_W8") ? atoi(getenv("YL_F8_TILE_W8")) : 0;  // 1: the eight-wave form (one workgroup per CU)
+  return wide ? f8t_launch_t<6, 2>(a, batch, s) : f8t_launch_t<6, 1>(a, batch, s);
 }
 
 }  // namespace yl
