@@ -103,7 +103,7 @@ __device__ __forceinline__ void f8t_tile(const ConvArgs& a, const f8t_v8i (&wf)[
       if (a.out_f8) {
         const unsigned vo = ok ? (unsigned)(co >> 4) * a.out_plane + (unsigned)opix[nt] * 16u + (unsigned)(co & 15) : OOB_LANE;
         const float is = a.out_inv_scale;
-        __builtin_amdgcn_raw_buffer_store_b32(pack_f8x4(v[0] * is, v[1] * is, v[2] * is, v[3] * is), rout, vo, 0, 0);
+        store_b32_nt(pack_f8x4(v[0] * is, v[1] * is, v[2] * is, v[3] * is), rout, vo, a.st_nt & 2);
       } else {
         const unsigned vo = ok ? (unsigned)(co >> 3) * a.out_plane + (unsigned)opix[nt] * 16u + (unsigned)(co & 7) * 2u : OOB_LANE;
         store_b64_nt(u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])}, rout, vo, a.st_nt);
@@ -113,7 +113,7 @@ __device__ __forceinline__ void f8t_tile(const ConvArgs& a, const f8t_v8i (&wf)[
           const bool ok8 = ok && c >= 0 && c < a.out8_n;
           const float is = a.out8_inv_scale;
           const unsigned v8 = ok8 ? (unsigned)(c >> 4) * a.out8_plane + (unsigned)opix[nt] * 16u + (unsigned)(c & 15) : OOB_LANE;
-          __builtin_amdgcn_raw_buffer_store_b32(pack_f8x4(v[0] * is, v[1] * is, v[2] * is, v[3] * is), r8, v8, 0, 0);
+          store_b32_nt(pack_f8x4(v[0] * is, v[1] * is, v[2] * is, v[3] * is), r8, v8, a.st_nt & 2);
         }
       }
     }

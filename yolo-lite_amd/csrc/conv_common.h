@@ -64,11 +64,16 @@ __host__ __device__ inline int chan_in_block(int MT, int mt, int g, int r) {
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+// (st_nt: bit 0 = the bf16 stores carry the hint, bit 1 = the e4m3 stores -- fp8 outputs and the e4m3 copies of bf16 outputs -- too)
 // A 16-byte (8-byte) buffer store with or without the non-temporal hint (the cache-policy operand is an immediate: a wave-uniform
 // branch picks the instruction).
 __device__ __forceinline__ void store_b128_nt(u32x4 d, __amdgpu_buffer_rsrc_t r, unsigned off, int nt) {
   if (nt) __builtin_amdgcn_raw_buffer_store_b128(d, r, off, 0, 2);
   else __builtin_amdgcn_raw_buffer_store_b128(d, r, off, 0, 0);
+}
+__device__ __forceinline__ void store_b32_nt(unsigned d, __amdgpu_buffer_rsrc_t r, unsigned off, int nt) {
+  if (nt) __builtin_amdgcn_raw_buffer_store_b32(d, r, off, 0, 2);
+  else __builtin_amdgcn_raw_buffer_store_b32(d, r, off, 0, 0);
 }
 __device__ __forceinline__ void store_b64_nt(u32x2 d, __amdgpu_buffer_rsrc_t r, unsigned off, int nt) {
   if (nt) __builtin_amdgcn_raw_buffer_store_b64(d, r, off, 0, 2);
@@ -285,9 +290,8 @@ __device__ __forceinline__ void epilogue(const ConvArgs& a, __amdgpu_buffer_rsrc
         const bool ok8 = ok && c >= 0 && c < a.out8_n;
         const float is = a.out8_inv_scale;
         const unsigned v8 = ok8 ? (unsigned)(c >> 4) * a.out8_plane + (unsigned)opix[nt] * 16u + (unsigned)(c & 15) : OOB_LANE;
-        __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack_f8x4(v[0] * is, v[1] * is, v[2] * is, v[3] * is),
-                                                    pack_f8x4(v[4] * is, v[5] * is, v[6] * is, v[7] * is)},
-                                              r8, v8, 0, 0);
+        store_b64_nt(u32x2{pack_f8x4(v[0] * is, v[1] * is, v[2] * is, v[3] * is), pack_f8x4(v[4] * is, v[5] * is, v[6] * is, v[7] * is)}, r8, v8,
+                     a.st_nt & 2);
       }
     }
   }

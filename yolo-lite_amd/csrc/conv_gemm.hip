@@ -452,9 +452,8 @@ __global__ __launch_bounds__(128 * NWN) __attribute__((amdgpu_waves_per_eu(2))) 
         const bool ok8 = po[nt] != OOB_LANE && c >= 0 && c < a.out8_n;
         const float is = a.out8_inv_scale;
         const unsigned v8 = ok8 ? (unsigned)(c >> 4) * a.out8_plane + po[nt] + (unsigned)(c & 15) : OOB_LANE;
-        __builtin_amdgcn_raw_buffer_store_b64(u32x2{pack_f8x4(v[0] * is, v[1] * is, v[2] * is, v[3] * is),
-                                                    pack_f8x4(v[4] * is, v[5] * is, v[6] * is, v[7] * is)},
-                                              r8, v8, 0, 0);
+        store_b64_nt(u32x2{pack_f8x4(v[0] * is, v[1] * is, v[2] * is, v[3] * is), pack_f8x4(v[4] * is, v[5] * is, v[6] * is, v[7] * is)}, r8, v8,
+                     a.st_nt & 2);
       }
     }
   }
