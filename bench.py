@@ -148,7 +148,7 @@ def build_model(scale, device, batch, h, w, x_calib, target_frac=0.015, fp8=Fals
     eng = HipEngine.from_model(specs, sd0, batch, h, w, device)
     eng.forward(x_calib)
     torch.cuda.synchronize()
-    mx = [r[:, 64:].amax(1).float().cpu() for r in eng.raw_levels()]
+    mx = [r.amax(1).float().cpu() for r in eng.raw_cls_levels()]
     bias = calibrate_cls_bias(mx, target_frac)
     del eng
     sd = synth_state_dict(scale, 0, cls_bias=bias)
@@ -889,7 +889,7 @@ def main():
                 from yololite_amd.nn.engine import HipEngine
 
                 o8, c8 = eng.detect(x8, conf, iou, max_det=max_det, graph=False)
-                l8 = [t.clone() for t in eng.raw_levels()] if B * H * W <= 32 * 640 * 640 else None
+                l8 = [t.clone() for t in eng.head_outputs()] if B * H * W <= 32 * 640 * 640 else None
                 e16 = HipEngine.from_model(specs, sd, B, H, W, dev)
                 o16, c16 = e16.detect(x8, conf, iou, max_det=max_det, graph=False)
                 torch.cuda.synchronize(dev)
@@ -898,7 +898,7 @@ def main():
                                                  [o8[i, : int(c8[i])].cpu() for i in range(nb8)], conf, iou, band=0.15,
                                                  min_matched_frac=0.85, max_explained_share=0.35)
                 if l8 is not None:
-                    l16 = e16.raw_levels()
+                    l16 = e16.head_outputs()  # (class logits, then decoded boxes, level by level)
                     res["fp8_vs_bf16"]["level_rel_l2"] = [round(float((a - b).norm() / b.norm()), 4) for a, b in zip(l8, l16)]
                 n8 = sum(1 for r in rows if "_f8_" in r["kernel"])
                 res["fp8_vs_bf16"]["fp8_conv_launches"] = n8

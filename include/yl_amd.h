@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define YL_ABI_VERSION 20
+#define YL_ABI_VERSION 21
 
 /* element types */
 enum { YL_BF16 = 0, YL_F32 = 1, YL_F16 = 2, YL_U8 = 3, YL_FP8 = 4 /* OCP e4m3 */ };
@@ -175,6 +175,13 @@ typedef struct yl_op {
                                         one batch at a time (the latency profile); results are the same either way */
   const float* const* extra_weight;
   const float* const* extra_bias;
+  /* YL_OP_CONV that produces the 64 DFL logits of a Detect level (a 1x1 conv with out.C == 64, alone or as the fused follow-up
+     `post_weight` of the 3x3 conv in front of it; head.py:36-40 cv2[i][2]): dfl_level = 1 + index of that level in the engine's
+     `levels` (0 = off).  The epilogue then runs the level's box decode -- DFL (block.py:51-69: softmax over the 16 bins of each
+     side, expectation) and dist2bbox(xywh) * stride (tal.py:341-350, head.py:105-106) -- ON THE fp32 ACCUMULATORS and stores
+     (cx, cy, w, h) fp32 at yl_level.offset_xywh; the 64 logits are rounded to bf16 and stored at `out` only with dfl_keep != 0
+     (debug / parity tests), otherwise `out` is not written.  ABI v21. */
+  int32_t dfl_level, dfl_keep;
   /* YL_OP_DWCONV3 with post_weight (depthwise 3x3 -> pointwise 1x1 in one launch) AND stem_weight: a further 1x1
      conv behind the pointwise one (the nn.Conv2d(c3, nc, 1) that ends Detect's class branch, head.py:47), also in
      that launch: reserved2 = output channels of the pointwise conv (post_weight [reserved2][in.C]), stem_weight
@@ -191,6 +198,11 @@ typedef struct yl_level {
   int32_t H, W;
   float stride;
   int32_t nc8;
+  /* ABI v21: >= 0: the level's boxes arrive DECODED -- fp32 [B][H * W][4] = (cx, cy, w, h) in input pixels (head.py:105-106
+     dbox * strides), written by the epilogue of the conv that computes the DFL logits (yl_op.dfl_level) from its fp32
+     accumulators; decode and NMS read 16 bytes per anchor instead of 64 bf16 logits, and the box error of bf16-stored logits
+     (up to 0.3 stride) is gone.  `offset` may then be < 0 (no logits stored).  < 0: logits at `offset`, decoded by the readers. */
+  int64_t offset_xywh;
 } yl_level;
 
 typedef struct yl_engine yl_engine;

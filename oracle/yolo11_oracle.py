@@ -32,7 +32,9 @@ bf16-storage mode (``forward(..., storage="bf16")``)
 ----------------------------------------------------
 The SAME restatement with every tensor that the HIP path keeps in HBM / LDS as bf16 rounded to bf16 at the point
 where the HIP path rounds it (the network input, BN-folded filters, every conv / depthwise / attention output after
-bias + activation + residual, the softmax probabilities entering the P.V product, the Detect level maps); all
+bias + activation + residual, the softmax probabilities entering the P.V product, the Detect levels' class logits -- and, with
+``box_logits="bf16"`` only, their 64 DFL logits: the product of rounds 1-5 stored those as bf16, since round 6 it decodes the boxes
+from the fp32 accumulators of the conv that computes them, which ``box_logits="fp32"``, the default, mirrors); all
 arithmetic stays fp32.  It splits the HIP path's distance from the fp32 reference into (a) the error of the number
 format, a CPU-only property measured in ``tests/test_oracle_golden.py`` against the reference-pinned fp32 mode, and
 (b) the kernels' own deviation (accumulation order, hardware exp / rcp), which the GPU tests bound tightly against
@@ -141,6 +143,7 @@ def plan(scale: str, nc: int = 80, ch: int = 3) -> List[dict]:
 # --------------------------------------------------------------------------- modules
 _STORAGE = ["fp32"]  # "fp32" (the pinned restatement) or "bf16" (storage emulation, see the module docstring)
 _FP8_SCALES: Dict[str, float] = {}  # bf16 mode only: convs emulated in e4m3 (name -> calibrated input scale)
+_BOX_LOGITS = ["fp32"]  # bf16 mode only: "bf16" also rounds the Detect levels' DFL logits (the stored-logits product of rounds 1-5)
 E4M3_MAX = 448.0
 
 
@@ -182,10 +185,12 @@ def conv_bn_act(sd: Dict[str, torch.Tensor], p: str, x: torch.Tensor, k: int = 1
     return y if res is None else res + y
 
 
-def plain_conv(sd, p, x):
-    """nn.Conv2d with bias, no BN / activation (the last conv of each Detect branch, head.py:38-48)."""
+def plain_conv(sd, p, x, store: bool = True):
+    """nn.Conv2d with bias, no BN / activation (the last conv of each Detect branch, head.py:38-48).  ``store=False``: the result
+    is consumed from the fp32 accumulators (bf16-storage mode does not round it)."""
     w = sd[p + ".weight"]
-    return q_store(F.conv2d(x, w.bfloat16().float() if _STORAGE[0] == "bf16" else w, sd[p + ".bias"]))
+    y = F.conv2d(x, w.bfloat16().float() if _STORAGE[0] == "bf16" else w, sd[p + ".bias"])
+    return q_store(y) if store else y
 
 
 def bottleneck(sd, p, x, c1, c2, shortcut=True, k=(3, 3), e=0.5):
@@ -298,7 +303,7 @@ def detect_heads(sd, p, feats: List[torch.Tensor], nc: int = 80) -> List[torch.T
     for i, x in enumerate(feats):
         b = conv_bn_act(sd, f"{p}.cv2.{i}.0", x, 3, 1)
         b = conv_bn_act(sd, f"{p}.cv2.{i}.1", b, 3, 1)
-        b = plain_conv(sd, f"{p}.cv2.{i}.2", b)
+        b = plain_conv(sd, f"{p}.cv2.{i}.2", b, store=_BOX_LOGITS[0] == "bf16")
         c = conv_bn_act(sd, f"{p}.cv3.{i}.0.0", x, 3, 1, x.shape[1], dw_taps_bf16=True)
         c = conv_bn_act(sd, f"{p}.cv3.{i}.0.1", c, 1, 1)
         c = conv_bn_act(sd, f"{p}.cv3.{i}.1.0", c, 3, 1, c.shape[1], dw_taps_bf16=True)
@@ -322,25 +327,29 @@ def detect_decode(raw: List[torch.Tensor], strides: Sequence[float], nc: int = 8
 
 def forward(sd: Dict[str, torch.Tensor], x: torch.Tensor, scale: str = "n", nc: int = 80,
             strides: Sequence[float] = (8.0, 16.0, 32.0), return_layers: bool = False, storage: str = "fp32",
-            fp8_scales: Optional[Dict[str, float]] = None):
+            fp8_scales: Optional[Dict[str, float]] = None, box_logits: str = "fp32"):
     """nn/tasks.py:118-145 BaseModel._predict_once over the 24 layers of yolo11.yaml.
 
     Returns (y[B, 4+nc, A], [raw level maps (B, 64+nc, H, W)]) like Detect.forward (head.py:59-69).
     ``storage="bf16"``: the bf16-storage emulation described in the module docstring; with ``fp8_scales`` the named convs are
-    emulated in e4m3 on top of it.
+    emulated in e4m3 on top of it; ``box_logits="bf16"`` additionally rounds the levels' DFL logits (see the module docstring).
     """
     if storage not in ("fp32", "bf16"):
         raise ValueError(storage)
     if fp8_scales and storage != "bf16":
         raise ValueError("the e4m3 emulation sits on top of the bf16-storage mode")
-    prev, prev8 = _STORAGE[0], dict(_FP8_SCALES)
+    if box_logits not in ("fp32", "bf16"):
+        raise ValueError(box_logits)
+    prev, prev8, prevb = _STORAGE[0], dict(_FP8_SCALES), _BOX_LOGITS[0]
     _STORAGE[0] = storage
+    _BOX_LOGITS[0] = box_logits
     _FP8_SCALES.clear()
     _FP8_SCALES.update(fp8_scales or {})
     try:
         return _forward(sd, q_store(x), scale, nc, strides, return_layers)
     finally:
         _STORAGE[0] = prev
+        _BOX_LOGITS[0] = prevb
         _FP8_SCALES.clear()
         _FP8_SCALES.update(prev8)
 

@@ -27,16 +27,47 @@ def test_header_symbols_exported():
         assert hasattr(L, n), f"{n} declared in include/yl_amd_diag.h but not exported"
     assert set(diag) == set(_lib.DIAG_EXPORTS), "diagnostic binding list and header drifted apart"
     assert not set(diag) & set(names), "a diagnostic entry point leaked into the product header"
-    assert L.yl_abi_version() == 20
+    assert L.yl_abi_version() == 21
 
 
 def test_struct_layouts_match_header():
     from yololite_amd import _lib
 
     assert ctypes.sizeof(_lib.View) == 32       # int64 + 6 x int32
-    assert ctypes.sizeof(_lib.Level) == 32
+    assert ctypes.sizeof(_lib.Level) == 40      # ABI v21: + offset_xywh
     # yl_op: 13 x int32/float (52) + pad to 8 (56) + 3 views (96) + 2 pointers (16)
-    assert ctypes.sizeof(_lib.Op) == 56 + 96 + 16 + 8 + 16 + 32 + 8 + 16 + 8 + 16 + 40 + 24  # + post_*, in2, up, reserved, stem_*, fp8 scales, out8, extra filters
+    assert ctypes.sizeof(_lib.Op) == 56 + 96 + 16 + 8 + 16 + 32 + 8 + 16 + 8 + 16 + 40 + 24 + 8  # + post_*, in2, up, reserved, stem_*, fp8 scales, out8, extra filters, dfl_*
+
+
+def test_struct_layouts_match_the_compiled_header(tmp_path):
+    """The ctypes mirrors against the header ITSELF: a C program that includes include/yl_amd.h prints sizeof and every field's
+    offsetof for yl_view / yl_level / yl_op; the ctypes structures must agree field by field (names differ where a C name is a
+    Python keyword or was shortened: in -> inp, in2 -> inp2)."""
+    import shutil
+    import subprocess
+
+    from yololite_amd import _lib
+
+    if shutil.which("gcc") is None:
+        import pytest
+
+        pytest.skip("no C compiler")
+    cname = {"inp": "in", "inp2": "in2"}
+    structs = {"yl_view": _lib.View, "yl_level": _lib.Level, "yl_op": _lib.Op}
+    lines = []
+    for cn, cls in structs.items():
+        lines.append(f'printf("{cn} %zu\\n", sizeof({cn}));')
+        for f, _t in cls._fields_:
+            lines.append(f'printf("{cn}.{f} %zu\\n", offsetof({cn}, {cname.get(f, f)}));')
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "yl_amd.h"\nint main(void) {\n' + "\n".join(lines) + "\nreturn 0;\n}\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", str(ROOT / "include"), str(src), "-o", str(exe)], check=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cn, cls in structs.items():
+        assert int(got[cn]) == ctypes.sizeof(cls), cn
+        for f, _t in cls._fields_:
+            assert int(got[f"{cn}.{f}"]) == getattr(cls, f).offset, f"{cn}.{f}"
 
 
 def test_no_gpu_calls_fail_loudly():

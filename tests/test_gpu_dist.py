@@ -164,7 +164,7 @@ def test_config4_eight_shards_of_the_global_batch(gpu_device):
     xg = torch.randint(0, 256, (world * per, 3, H, W), generator=g, dtype=torch.uint8).to(gpu_device)
     e0 = HipEngine.from_model(specs, synth_state_dict("n", 0, cls_bias=[0.0, 0.0, 0.0]), per, H, W, gpu_device)
     e0.forward(xg[:per], decode=False)
-    bias = calibrate_cls_bias([r[:, 64:].amax(1).float().cpu() for r in e0.raw_levels()], 0.015)
+    bias = calibrate_cls_bias([r.amax(1).float().cpu() for r in e0.raw_cls_levels()], 0.015)
     del e0
     torch.cuda.empty_cache()
     eng = HipEngine.from_model(specs, synth_state_dict("n", 0, cls_bias=bias), per, H, W, gpu_device)

@@ -160,7 +160,7 @@ def test_fp8_network_close_to_bf16(gpu_device, monkeypatch, scale, h, w, mode):
     specs, _ = arch.parse_model(arch.yolo11_dict(scale))
     sd = synth_state_dict(scale, 3, cls_bias=[-2.0, -2.0, -2.0], cls_gain=4.0)
     x = torch.randint(0, 256, (2, 3, h, w), generator=torch.Generator().manual_seed(5), dtype=torch.uint8).to(gpu_device)
-    e16 = HipEngine.from_model(specs, sd, 2, h, w, gpu_device)
+    e16 = HipEngine.from_model(specs, sd, 2, h, w, gpu_device, keep_logits=True)
     e16.forward(x)
     l16 = [t.clone() for t in e16.raw_levels()]
     # "3x3": the default (dense 3x3 convs, e4m3 copies from the producers' epilogues); "passes": separate quantize passes
@@ -168,7 +168,7 @@ def test_fp8_network_close_to_bf16(gpu_device, monkeypatch, scale, h, w, mode):
     monkeypatch.setenv("YL_FP8_DUAL", "0" if mode == "passes" else "1")
     monkeypatch.setenv("YL_FP8_MIRROR", "1" if mode == "mirror" else "0")
     monkeypatch.setenv("YL_FP8_1X1_GF", "0")  # mirror mode here: every eligible 1x1 conv
-    e8 = HipEngine.from_model(specs, sd, 2, h, w, gpu_device, fp8_calib=x)
+    e8 = HipEngine.from_model(specs, sd, 2, h, w, gpu_device, fp8_calib=x, keep_logits=True)
     kernels = [e8.op_kernel(i) for i in range(len(e8.prog.ops))]
     assert sum("_f8_" in k for k in kernels) >= (35 if mode == "mirror" else 15)
     assert ("quantize_f8" in kernels) == (mode == "passes" or scale != "x")
@@ -321,12 +321,12 @@ def test_fp8_full_size_x1280_batch8_properties(gpu_device):
     sd = synth_state_dict("x", 0, cls_bias=[-3.0, -3.0, -3.0], cls_gain=4.0)
     g = torch.Generator().manual_seed(8)
     x = torch.randint(0, 256, (B, 3, H, W), generator=g, dtype=torch.uint8).to(gpu_device)
-    e16 = HipEngine.from_model(specs, sd, B, H, W, gpu_device)
+    e16 = HipEngine.from_model(specs, sd, B, H, W, gpu_device, keep_logits=True)
     e16.forward(x, decode=False)
     l16 = [t.clone() for t in e16.raw_levels()]
     del e16
     torch.cuda.empty_cache()
-    eng = HipEngine.from_model(specs, sd, B, H, W, gpu_device, fp8_calib=x)
+    eng = HipEngine.from_model(specs, sd, B, H, W, gpu_device, fp8_calib=x, keep_logits=True)
     assert sum("_f8_" in eng.op_kernel(i) for i in range(len(eng.prog.ops))) >= 70
     out, cnt = (t.clone() for t in eng.detect(x, 0.25, 0.7, graph=False))
     errs = [float((a - b).norm() / b.norm()) for a, b in zip(eng.raw_levels(), l16)]

@@ -208,6 +208,61 @@ def test_conv_with_fused_follow_up_1x1(gpu_device, cin, cmid, cout, k, s, h, w, 
     assert bool(((got - ref).abs() <= tol).all()), float(((got - ref).abs() - tol).max())
 
 
+@pytest.mark.parametrize("form,cin,B,h,w,stride,keep", [("post", 64, 2, 20, 24, 8.0, False), ("post", 64, 3, 7, 9, 16.0, True),
+                                                        ("post", 128, 2, 13, 5, 32.0, False), ("plain", 64, 2, 20, 20, 8.0, True),
+                                                        ("plain", 96, 2, 12, 20, 16.0, False), ("plain", 64, 33, 2, 2, 32.0, False)])
+def test_dfl_epilogue_vs_torch(gpu_device, form, cin, B, h, w, stride, keep):
+    """Detect's box decode in the epilogue of the conv that computes a level's 64 DFL logits (yl_op.dfl_level, csrc/conv_common.h
+    dfl_epilogue; reference head.py:95-126, block.py:51-69, tal.py:341-350): the 1x1 conv alone ("plain": YOLO11x, whose 96-channel
+    box branch cannot fuse it) or fused behind a 3x3 conv ("post": cv2[i][1] + cv2[i][2] of YOLO11n / s) against torch fp32 -- the
+    logits from the same bf16-rounded operands, then softmax expectation and dist2bbox(xywh) * stride in fp32.  The logits never
+    pass through bf16, so the boxes agree to fp32 accumulation order: |d| <= 2e-4 * stride + 1e-5 * |value|.  keep: the bf16
+    logits are stored as well (the parity tests' program) and equal the rounded torch logits."""
+    from oracle import yolo11_oracle as oracle
+
+    g = torch.Generator().manual_seed(cin + h + w)
+    x = _rand(g, B, cin, h, w)
+    w2 = _rand(g, 64, 64 if form == "post" else cin, 1, 1, scale=2.0 / math.sqrt(64))
+    b2 = torch.randn(64, generator=g)
+    m = Mini(B, gpu_device)
+    xin, yo, cls = m.buf(h, w, cin), m.buf(h, w, 64), m.buf(h, w, 80)
+    off = m.ar.alloc_bytes(B * h * w * 16)
+    m.prog.levels.append(dict(offset=yo.offset if keep else -1, offset_cls=cls.offset, offset_xywh=off, nc8=80, H=h, W=w, stride=stride))
+    m.prog.anchors = h * w
+    m.fill(xin, x)
+    if form == "post":
+        w1 = _rand(g, 64, cin, 3, 3, scale=1.0 / math.sqrt(cin * 9))
+        b1 = torch.randn(64, generator=g) * 0.5
+        mid = bf16_round(F.silu(F.conv2d(x, w1, b1, 1, 1)))
+        logits = F.conv2d(mid, w2, b2)
+        m.op(kind=OP_CONV, name="t", k=3, stride=1, act=1, inp=xin, out=yo, weight=np.ascontiguousarray(w1.numpy()),
+             bias=np.ascontiguousarray(b1.numpy()), post_weight=np.ascontiguousarray(w2.numpy().reshape(64, 64)),
+             post_bias=np.ascontiguousarray(b2.numpy()), post_act=0, dfl_level=1, dfl_keep=int(keep))
+    else:
+        logits = F.conv2d(x, w2, b2)
+        m.op(kind=OP_CONV, name="t", k=1, stride=1, act=0, inp=xin, out=yo, weight=np.ascontiguousarray(w2.numpy()),
+             bias=np.ascontiguousarray(b2.numpy()), dfl_level=1, dfl_keep=int(keep))
+    m.run()
+    anchors, _ = oracle.make_anchors([(h, w)], [stride])
+    ref = oracle.dist2bbox_xywh(oracle.dfl(logits.reshape(B, 64, h * w)), anchors.transpose(0, 1).unsqueeze(0)) * stride
+    got = m.eng.level_boxes()[0].cpu()
+    assert got.shape == ref.shape == (B, 4, h * w)
+    tol = 2e-4 * stride + 1e-5 * ref.abs()
+    if form == "post":  # (the intermediate's bf16 rounding can flip by one ulp with the accumulation order: a logit moves by
+        tol = tol + 0.02 * stride  # |w2| 2^-8 |mid|, the expectation by a few hundredths of a bin)
+    err = (got - ref).abs()
+    assert bool((err <= tol).all()), f"max box error {float(err.max()):.5f} px (stride {stride})"
+    if keep:
+        _assert_close_bf16(m.read(yo), logits, "kept DFL logits")
+        # ... and the readers decode from the boxes, not from the kept logits: yl_detect_decode returns them
+        y = torch.empty(B, 84, h * w, device=gpu_device)
+        from yololite_amd import _lib
+        _lib.check(m.eng.lib.yl_detect_decode(m.eng.workspace.data_ptr(), m.eng._levels, 1, B, 80, y.data_ptr(),
+                                              torch.cuda.current_stream().cuda_stream), "yl_detect_decode")
+        torch.cuda.synchronize()
+        assert torch.equal(y[:, :4].cpu(), got)
+
+
 def test_conv_reads_through_upsample_concat(gpu_device):
     """1x1 conv over cat(upsample(lo), skip): the conv reads `lo` itself (yl_op.in2); bit-identical to the
     conv over a materialised concat buffer."""

@@ -29,9 +29,9 @@ BOX_ATOL_STRIDES = 0.35  # box coordinate error allowed, in units of the level s
 FMT_RATIO = 1.5
 
 
-def _engine(scale, sd, b, h, w, dev, keep_layers=False):
+def _engine(scale, sd, b, h, w, dev, keep_layers=False, keep_logits=False, dfl_epilogue=True):
     specs, _ = arch.parse_model(arch.yolo11_dict(scale))
-    return HipEngine.from_model(specs, sd, b, h, w, dev, keep_layers=keep_layers)
+    return HipEngine.from_model(specs, sd, b, h, w, dev, keep_layers=keep_layers, keep_logits=keep_logits, dfl_epilogue=dfl_epilogue)
 
 
 def _stride_per_anchor(h, w):
@@ -64,7 +64,7 @@ def test_net_output_vs_golden(gpu_device, golden, scale, h, w, seed):
     tag = f"net_{scale}_{h}x{w}"
     sd = synth_state_dict(scale, seed, cls_bias=list(golden[tag + "_bias"]), cls_gain=8.0)
     x = torch.from_numpy(golden[tag + "_x"])
-    eng = _engine(scale, sd, x.shape[0], h, w, gpu_device)
+    eng = _engine(scale, sd, x.shape[0], h, w, gpu_device, keep_logits=True)  # (the DFL logits too: compared with the goldens' below)
     y = eng.forward(x.to(gpu_device)).cpu()
     ref = torch.from_numpy(golden[tag + "_y"])
     assert y.shape == ref.shape
@@ -193,7 +193,7 @@ def test_decode_vs_oracle(gpu_device):
     raw = [(torch.randn(2, 144, h, w, generator=g) * 3).bfloat16().float() for h, w in ((12, 16), (6, 8), (3, 4))]
     ref = oracle.detect_decode(raw, (8.0, 16.0, 32.0))
     sd = synth_state_dict("n", 0)
-    eng = _engine("n", sd, 2, 96, 128, gpu_device)
+    eng = _engine("n", sd, 2, 96, 128, gpu_device, dfl_epilogue=False)  # (the stored-logits form: the readers run the DFL)
     for i, r in enumerate(raw):  # level maps = two bf16 planar buffers (64 box logits, 80 class logits)
         vb, vc = eng.level_views(i)
         eng.write_view(vb, r[:, :64])
@@ -286,7 +286,7 @@ def test_error_has_the_size_of_the_format_error(gpu_device, golden, scale, h, w,
     oracle's bf16-storage mode vs the same goldens (CPU, no kernel involved)."""
     sd = synth_state_dict(scale, seed, cls_bias=list(golden[key + "_bias"]), cls_gain=8.0)
     x = torch.from_numpy(golden[key + "_x"])
-    eng = _engine(scale, sd, x.shape[0], h, w, gpu_device)
+    eng = _engine(scale, sd, x.shape[0], h, w, gpu_device, keep_logits=True)
     y = eng.forward(x.to(gpu_device)).cpu()
     lv = [t.cpu() for t in eng.raw_levels()]
     with torch.inference_mode():
@@ -340,7 +340,7 @@ def test_end_to_end_640_yolo11s_vs_oracle(gpu_device):
     # class bias calibrated on the device so that ~1.5 % of the anchors pass the threshold (bench.py's build_model)
     e0 = _engine("s", synth_state_dict("s", 0, cls_bias=[0.0, 0.0, 0.0]), 3, 640, 640, gpu_device)
     e0.forward(xd)
-    bias = calibrate_cls_bias([r[:, 64:].amax(1).float().cpu() for r in e0.raw_levels()], 0.015)
+    bias = calibrate_cls_bias([r.amax(1).float().cpu() for r in e0.raw_cls_levels()], 0.015)
     del e0
     sd = synth_state_dict("s", 0, cls_bias=bias)
     eng = _engine("s", sd, 3, 640, 640, gpu_device)
@@ -501,7 +501,7 @@ def test_fused_stem_conv_is_bit_identical(gpu_device, monkeypatch, scale, h, w, 
     assert ref_eng.op_kernel(0) == "stem_conv3x3s2"
     y_ref = ref_eng.forward(x.to(gpu_device))
     assert torch.equal(y, y_ref)
-    for a, b in zip(eng.raw_levels(), ref_eng.raw_levels()):
+    for a, b in zip(eng.head_outputs(), ref_eng.head_outputs()):
         assert torch.equal(a, b)
 
 
@@ -526,7 +526,7 @@ def test_fused_c3k2_block_is_bit_identical(gpu_device, monkeypatch, h, w, dtype)
     assert ref_eng.op_kernel(1).startswith("conv3x3")
     y_ref = ref_eng.forward(x.to(gpu_device))
     assert torch.equal(y, y_ref)
-    for a, b in zip(eng.raw_levels(), ref_eng.raw_levels()):
+    for a, b in zip(eng.head_outputs(), ref_eng.head_outputs()):
         assert torch.equal(a, b)
 
 
@@ -547,7 +547,7 @@ def test_fused_class_branch_tail_is_bit_identical(gpu_device, monkeypatch, h, w)
     assert not any(ref_eng.op_kernel(i) == "dw3x3+pw1x1+1x1_mfma" for i in range(len(ref_eng.prog.ops)))
     y_ref = ref_eng.forward(x.to(gpu_device))
     assert torch.equal(y, y_ref)
-    for a, b in zip(eng.raw_levels(), ref_eng.raw_levels()):
+    for a, b in zip(eng.head_outputs(), ref_eng.head_outputs()):
         assert torch.equal(a, b)
 
 
@@ -572,7 +572,7 @@ def test_level_group_launches_are_bit_identical(gpu_device, monkeypatch, h, w, m
         assert first & set(names) and second & set(names) and "dw3x3+pw1x1+1x1_mfma[x3]" in names
     out, cnt = eng.detect(x, 0.25, 0.7, max_det=300)
     out, cnt = out.clone(), cnt.clone()
-    lv = [t.clone() for t in eng.raw_levels()]
+    lv = [t.clone() for t in eng.head_outputs()]
     out_g, cnt_g = eng.detect(x, 0.25, 0.7, max_det=300, graph=True)
     assert torch.equal(cnt_g, cnt)
     monkeypatch.setenv("YL_GROUP_LEVELS", "0")
@@ -582,7 +582,7 @@ def test_level_group_launches_are_bit_identical(gpu_device, monkeypatch, h, w, m
     assert torch.equal(cnt, c2)
     for i, n in enumerate(cnt.tolist()):
         assert torch.equal(out[i, :n], o2[i, :n]) and torch.equal(out_g[i, :n], o2[i, :n])
-    for a, b in zip(lv, ref.raw_levels()):
+    for a, b in zip(lv, ref.head_outputs()):
         assert torch.equal(a, b)
 
 
@@ -666,12 +666,12 @@ def test_lds_staged_class_branch_is_bit_identical(gpu_device, monkeypatch):
     monkeypatch.setenv("YL_GROUP_LEVELS", "0")
     eng = _engine("n", sd, 2, 96, 128, gpu_device)
     y = eng.forward(x.to(gpu_device)).clone()
-    lv = [t.clone() for t in eng.raw_levels()]
+    lv = [t.clone() for t in eng.head_outputs()]
     monkeypatch.setenv("YL_DWPW_TILE", "0")
     monkeypatch.delenv("YL_GROUP_LEVELS")
     ref_eng = _engine("n", sd, 2, 96, 128, gpu_device)
     assert torch.equal(y, ref_eng.forward(x.to(gpu_device)))
-    for a, b in zip(lv, ref_eng.raw_levels()):
+    for a, b in zip(lv, ref_eng.head_outputs()):
         assert torch.equal(a, b)
 
 
@@ -682,13 +682,13 @@ def test_cross_layer_fusions_bit_identical_at_640(gpu_device, monkeypatch):
     x = torch.randint(0, 256, (2, 3, 640, 640), generator=torch.Generator().manual_seed(640), dtype=torch.uint8).to(gpu_device)
     eng = _engine("n", sd, 2, 640, 640, gpu_device)
     out, cnt = eng.detect(x, 0.25, 0.7, graph=False)
-    lv = [t.clone() for t in eng.raw_levels()]
+    lv = [t.clone() for t in eng.head_outputs()]
     monkeypatch.setenv("YL_FUSE_STEM", "0")
     monkeypatch.setenv("YL_FUSE_C3K2", "0")
     ref = _engine("n", sd, 2, 640, 640, gpu_device)
     assert len(ref.prog.ops) == len(eng.prog.ops) + 1 + 3 * 2
     out_r, cnt_r = ref.detect(x, 0.25, 0.7, graph=False)
-    for a, b in zip(lv, ref.raw_levels()):
+    for a, b in zip(lv, ref.head_outputs()):
         assert torch.equal(a, b)
     assert torch.equal(cnt, cnt_r) and int(cnt.sum()) > 0
     for i in range(2):
@@ -707,12 +707,12 @@ def test_fused_bottlenecks_are_bit_identical(gpu_device, monkeypatch, scale, h, 
     fused = [i for i in range(len(eng.prog.ops)) if eng.op_kernel(i) == "bottleneck_fused_mfma"]
     assert len(fused) >= 2, fused
     y = eng.forward(x).clone()
-    lv = [t.clone() for t in eng.raw_levels()]
+    lv = [t.clone() for t in eng.head_outputs()]
     monkeypatch.setenv("YL_FUSE_BNECK", "0")
     ref = _engine(scale, sd, 2, h, w, gpu_device)
     assert not any(ref.op_kernel(i) == "bottleneck_fused_mfma" for i in range(len(ref.prog.ops)))
     assert torch.equal(y, ref.forward(x))
-    for a, b in zip(lv, ref.raw_levels()):
+    for a, b in zip(lv, ref.head_outputs()):
         assert torch.equal(a, b)
 
 
@@ -730,7 +730,7 @@ def test_full_size_properties(gpu_device, scale, B):
     x = torch.randint(0, 256, (B, 3, H, W), generator=g, dtype=torch.uint8).to(gpu_device)
     e0 = _engine(scale, synth_state_dict(scale, 0, cls_bias=[0.0, 0.0, 0.0]), B, H, W, gpu_device)
     e0.forward(x, decode=False)
-    bias = calibrate_cls_bias([r[:, 64:].amax(1).float().cpu() for r in e0.raw_levels()], 0.015)  # ~1.5 % of anchors pass conf
+    bias = calibrate_cls_bias([r.amax(1).float().cpu() for r in e0.raw_cls_levels()], 0.015)  # ~1.5 % of anchors pass conf
     del e0
     torch.cuda.empty_cache()
     sd = synth_state_dict(scale, 0, cls_bias=bias)
@@ -786,3 +786,41 @@ def test_pre_nms_at_realistic_logit_scale_vs_reference_golden(gpu_device):
     print("cls_gain 1: HIP vs reference golden: max |dscore|", dscore, "max box error (strides)", dbox)
     assert dscore <= 0.02, dscore
     assert dbox <= BOX_ATOL_STRIDES, dbox
+
+
+@pytest.mark.parametrize("scale,h,w", [("n", 96, 128), ("n", 640, 640), ("s", 160, 96), ("x", 64, 96)])
+def test_dfl_epilogue_program_forms(gpu_device, scale, h, w):
+    """Detect's box decode in the epilogue of the conv that computes the DFL logits (lower(dfl_epilogue=True), the product) against
+    (a) the same program that ALSO stores the bf16 logits (keep_logits: the parity tests' form): class logits, decoded boxes,
+    the (B, 84, A) tensor and the detections bit for bit -- the extra stores change nothing; (b) the stored-logits program of
+    rounds 1-5 (dfl_epilogue=False): class logits and scores bit for bit (the class branch is untouched), boxes within that form's
+    stated format band of 0.35 stride (its 64 logits per side pass through bf16, this one's do not)."""
+    specs, _ = arch.parse_model(arch.yolo11_dict(scale))
+    sd = synth_state_dict(scale, 12, cls_bias=[-3.0, -3.0, -3.0], cls_gain=6.0)
+    x = torch.randint(0, 256, (2, 3, h, w), generator=torch.Generator().manual_seed(h + w), dtype=torch.uint8).to(gpu_device)
+    prod = HipEngine.from_model(specs, sd, 2, h, w, gpu_device)
+    assert all(L["offset"] == -1 and L["offset_xywh"] >= 0 for L in prod.prog.levels)
+    names = [o.get("name", "") for o in prod.prog.ops if o.get("dfl_level")]
+    assert len(names) == 3 and all(".cv2." in n for n in names), names
+    y = prod.forward(x).clone()
+    out, cnt = (t.clone() for t in prod.detect(x, 0.25, 0.7, graph=False))
+    outg, cntg = (t.clone() for t in prod.detect(x, 0.25, 0.7, graph=True))
+    assert torch.equal(cnt, cntg) and torch.equal(out, outg)
+    keep = HipEngine.from_model(specs, sd, 2, h, w, gpu_device, keep_logits=True)
+    yk = keep.forward(x)
+    assert torch.equal(y, yk)
+    for a, b in zip(prod.level_boxes() + prod.raw_cls_levels(), keep.level_boxes() + keep.raw_cls_levels()):
+        assert torch.equal(a, b)
+    outk, cntk = keep.detect(x, 0.25, 0.7, graph=False)
+    assert torch.equal(cnt, cntk) and all(torch.equal(out[i, : int(cnt[i])], outk[i, : int(cnt[i])]) for i in range(2))
+    old = HipEngine.from_model(specs, sd, 2, h, w, gpu_device, dfl_epilogue=False)
+    assert all(L["offset"] >= 0 and L["offset_xywh"] == -1 for L in old.prog.levels)
+    yo = old.forward(x)
+    assert torch.equal(y[:, 4:], yo[:, 4:])
+    st = _stride_per_anchor(h, w).to(gpu_device)
+    d = ((y[:, :4] - yo[:, :4]).abs() / st).max()
+    print(f"{scale} {h}x{w}: decoded-in-epilogue vs stored-logits boxes, max |d| = {float(d):.4f} strides")
+    assert float(d) < BOX_ATOL_STRIDES
+    # the kept bf16 logits are the stored-logits program's (same accumulators, same rounding)
+    for a, b in zip(keep.raw_levels(), old.raw_levels()):
+        assert torch.equal(a, b)

@@ -125,13 +125,13 @@ def test_network_with_resident_c3k_is_bit_identical(gpu_device, monkeypatch, h, 
     names = [eng.op_kernel(i) for i in range(len(eng.prog.ops))]
     assert names.count("c3k_resident_mfma") == 2, names
     y = eng.forward(x).clone()
-    lv = [t.clone() for t in eng.raw_levels()]
+    lv = [t.clone() for t in eng.head_outputs()]
     monkeypatch.setenv("YL_FUSE_C3K", "0")
     ref = HipEngine.from_model(specs, sd, b, h, w, gpu_device)
     assert "c3k_resident_mfma" not in [ref.op_kernel(i) for i in range(len(ref.prog.ops))]
     assert len(ref.prog.ops) == len(eng.prog.ops) + 10
     assert torch.equal(y, ref.forward(x))
-    for p, q in zip(lv, ref.raw_levels()):
+    for p, q in zip(lv, ref.head_outputs()):
         assert torch.equal(p, q)
 
 
@@ -217,14 +217,14 @@ def test_network_with_resident_psa_is_bit_identical(gpu_device, monkeypatch, h, 
     eng = HipEngine.from_model(specs, sd, b, h, w, gpu_device)
     assert [eng.op_kernel(i) for i in range(len(eng.prog.ops))].count("psa_resident_mfma") == 1
     y = eng.forward(x).clone()
-    lv = [t.clone() for t in eng.raw_levels()]
+    lv = [t.clone() for t in eng.head_outputs()]
     monkeypatch.setenv("YL_FUSE_PSA", "0")
     monkeypatch.setenv("YL_FUSE_PSA_TAIL", "0")  # (the six launches, not the one-launch tail either)
     ref = HipEngine.from_model(specs, sd, b, h, w, gpu_device)
     assert "psa_resident_mfma" not in [ref.op_kernel(i) for i in range(len(ref.prog.ops))]
     assert len(ref.prog.ops) == len(eng.prog.ops) + 5
     assert torch.equal(y, ref.forward(x))
-    for p, q in zip(lv, ref.raw_levels()):
+    for p, q in zip(lv, ref.head_outputs()):
         assert torch.equal(p, q)
 
 
@@ -300,13 +300,13 @@ def test_network_with_resident_sppf_is_bit_identical(gpu_device, monkeypatch, h,
     eng = HipEngine.from_model(specs, sd, b, h, w, gpu_device)
     assert [eng.op_kernel(i) for i in range(len(eng.prog.ops))].count("sppf_resident_mfma") == 1
     y = eng.forward(x).clone()
-    lv = [t.clone() for t in eng.raw_levels()]
+    lv = [t.clone() for t in eng.head_outputs()]
     monkeypatch.setenv("YL_FUSE_SPPF", "0")
     ref = HipEngine.from_model(specs, sd, b, h, w, gpu_device)
     assert "sppf_resident_mfma" not in [ref.op_kernel(i) for i in range(len(ref.prog.ops))]
     assert len(ref.prog.ops) == len(eng.prog.ops) + 3
     assert torch.equal(y, ref.forward(x))
-    for p, q in zip(lv, ref.raw_levels()):
+    for p, q in zip(lv, ref.head_outputs()):
         assert torch.equal(p, q)
 
 
@@ -324,7 +324,7 @@ def test_network_with_psa_tail_is_bit_identical(gpu_device, monkeypatch, h, w, b
     names = [eng.op_kernel(i) for i in range(len(eng.prog.ops))]
     assert names.count("psa_tail_mfma") == 1 and "psa_resident_mfma" not in names
     y = eng.forward(x).clone()
-    lv = [t.clone() for t in eng.raw_levels()]
+    lv = [t.clone() for t in eng.head_outputs()]
     out, cnt = eng.detect(x, 0.25, 0.7, graph=True)
     out, cnt = out.clone(), cnt.clone()
     monkeypatch.setenv("YL_FUSE_PSA_TAIL", "0")
@@ -332,7 +332,7 @@ def test_network_with_psa_tail_is_bit_identical(gpu_device, monkeypatch, h, w, b
     assert "psa_tail_mfma" not in [ref.op_kernel(i) for i in range(len(ref.prog.ops))]
     assert len(ref.prog.ops) == len(eng.prog.ops) + 3
     assert torch.equal(y, ref.forward(x))
-    for p, q in zip(lv, ref.raw_levels()):
+    for p, q in zip(lv, ref.head_outputs()):
         assert torch.equal(p, q)
     o2, c2 = ref.detect(x, 0.25, 0.7, graph=False)
     assert torch.equal(cnt, c2) and all(torch.equal(out[i, :n], o2[i, :n]) for i, n in enumerate(cnt.tolist()))
@@ -361,7 +361,7 @@ def test_latency_and_throughput_profiles_agree_on_random_shapes(gpu_device):
             o3, c3 = eng.detect(x, conf, 0.7, graph=True)
             assert torch.equal(c1, c3), (it, h, w, b, one_batch)
             assert all(torch.equal(o1[i, :n], o3[i, :n]) for i, n in enumerate(c1.tolist())), (it, h, w, b, one_batch)
-            res.append((o1, c1, [t.clone() for t in eng.raw_levels()]))
+            res.append((o1, c1, [t.clone() for t in eng.head_outputs()]))
             del eng
         assert torch.equal(res[0][1], res[1][1]), (it, h, w, b)
         assert all(torch.equal(res[0][0][i, :n], res[1][0][i, :n]) for i, n in enumerate(res[0][1].tolist())), (it, h, w, b)

@@ -92,8 +92,18 @@ def test_buffers_never_overlap(scale):
             v = o.get(key)
             if v is not None:
                 spans[v.offset] = max(spans.get(v.offset, 0), view_bytes(p.batch, v))
-    for L in p.levels:  # a level = two ordinary planar buffers: 64 box logits, nc8 class logits
-        assert L["offset"] in spans and L["offset_cls"] in spans and L["nc8"] % 8 == 0 and L["nc8"] >= p.nc
+    for L in p.levels:  # a level = the nc8 class logits (a planar buffer) + the decoded boxes, fp32 (cx, cy, w, h) per anchor
+        assert L["offset"] == -1 and L["offset_cls"] in spans and L["nc8"] % 8 == 0 and L["nc8"] >= p.nc
+        assert L["offset_xywh"] >= 0 and L["offset_xywh"] not in spans
+        spans[L["offset_xywh"]] = p.batch * L["H"] * L["W"] * 16
+    dfl = [o for o in p.ops if o.get("dfl_level")]
+    assert sorted(o["dfl_level"] for o in dfl) == [1, 2, 3] and all(o["out"].C == 64 and not o["dfl_keep"] for o in dfl)
+    # (the rounds 1-5 form: 64 bf16 DFL logits per anchor, stored and decoded by their readers)
+    specs, _ = arch.parse_model(arch.yolo11_dict(scale))
+    q = lower(specs, synth_state_dict(scale, 0), 2, 96, 128, dfl_epilogue=False)
+    assert all(L["offset"] >= 0 and L["offset_xywh"] == -1 for L in q.levels) and not any(o.get("dfl_level") for o in q.ops)
+    k = lower(specs, synth_state_dict(scale, 0), 2, 96, 128, keep_logits=True)
+    assert all(L["offset"] >= 0 and L["offset_xywh"] >= 0 for L in k.levels) and all(o["dfl_keep"] for o in k.ops if o.get("dfl_level"))
     t = sorted(spans.items())
     for (o1, s1), (o2, _) in zip(t, t[1:]):
         assert o1 + s1 <= o2

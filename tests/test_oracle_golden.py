@@ -135,7 +135,13 @@ def test_bf16_storage_format_error(golden):
             worst["rel"] = max(worst["rel"], float((r - gref).norm() / gref.norm()))
         # the roundings must actually be there: bf16 mode differs from the fp32 golden, and its level maps are bf16 values
         assert not torch.equal(y16, ref)
-        assert all(torch.equal(r, r.bfloat16().float()) for r in raw16)
+        # (class logits are stored as bf16; the DFL logits are consumed from fp32 accumulators since round 6 -- box_logits="bf16"
+        # is the stored-logits form of rounds 1-5)
+        assert all(torch.equal(r[:, 64:], r[:, 64:].bfloat16().float()) and not torch.equal(r[:, :64], r[:, :64].bfloat16().float())
+                   for r in raw16)
+        with torch.inference_mode():
+            _, raw_old = oracle.forward(sd, x, scale, storage="bf16", box_logits="bf16")
+        assert all(torch.equal(r, r.bfloat16().float()) for r in raw_old)
     print("bf16-storage format error vs reference goldens:", worst)
     assert worst["score"] < 0.08 and worst["box"] < 0.35 and worst["rel"] < 0.015
     assert worst["score"] > 0.005, "suspiciously small: is the emulation rounding anything?"

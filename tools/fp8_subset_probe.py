@@ -22,7 +22,7 @@ x = torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(0)).to(dev)
 x8 = (x * 255).to(torch.uint8)
 specs, sd, e16 = bench.build_model("x", dev, B, S, S, x, target_frac=bench.config5_target_frac(S), fp8=False)
 o16, c16 = e16.detect(x8, 0.25, 0.7, graph=False)
-l16 = [t.clone() for t in e16.raw_levels()]
+l16 = [t.clone() for t in e16.raw_cls_levels()]
 scales = e16.calibrate_fp8(x, 2.0)
 torch.cuda.synchronize()
 
@@ -62,7 +62,7 @@ for tag, sub in subsets.items():
     eng = HipEngine(lower(specs, sd, B, S, S, fp8_scales=sc), dev)
     o, c = eng.detect(x8, 0.25, 0.7, graph=False)
     torch.cuda.synchronize()
-    errs = [float((a[:, 64:] - b[:, 64:]).norm() / b[:, 64:].norm()) for a, b in zip(eng.raw_levels(), l16)]
+    errs = [float((a - b).norm() / b.norm()) for a, b in zip(eng.raw_cls_levels(), l16)]
     nf8 = sum("_f8_" in eng.op_kernel(i) for i in range(len(eng.prog.ops)))
     g = parity_gate(ref16, [o[i, : int(c[i])].cpu() for i in range(B)], 0.25, 0.7, band=0.12, min_matched_frac=0.85, max_explained_share=0.35)
     print(f"{tag:18s} convs {len(sub):3d} (f8 launches {nf8:3d})  boxes {c.tolist()}  class-map rel-L2 {[round(e, 4) for e in errs]}  {timeit(eng):.2f} ms"

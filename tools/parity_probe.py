@@ -41,7 +41,7 @@ def main(tag="r02"):
         else:
             x = torch.from_numpy(g[key + "_x"])
         specs, _ = arch.parse_model(arch.yolo11_dict(scale))
-        eng = HipEngine.from_model(specs, sd, x.shape[0], h, w, dev)
+        eng = HipEngine.from_model(specs, sd, x.shape[0], h, w, dev, keep_logits=True)
         y = eng.forward(x.to(dev)).cpu()
         lv = [t.cpu() for t in eng.raw_levels()]
         det = [d.cpu() for d in hops.non_max_suppression(y.to(dev), 0.25, 0.7)]

@@ -19,7 +19,7 @@ for kind in ("noise", "structured"):
     x8 = (x * 255).to(torch.uint8)
     specs, sd, e16 = bench.build_model(scale, dev, B, S, S, x, target_frac=bench.config5_target_frac(S))
     e16.forward(x8)
-    mx = torch.cat([r[:, 64:].amax(1).float().flatten(1) for r in e16.raw_levels()], 1)
+    mx = torch.cat([r.amax(1).float().flatten(1) for r in e16.raw_cls_levels()], 1)
     o16, c16 = e16.detect(x8, 0.25, 0.7, graph=False)
     e8 = HipEngine.from_model(specs, sd, B, S, S, dev, fp8_calib=x)
     o8, c8 = e8.detect(x8, 0.25, 0.7, graph=False)

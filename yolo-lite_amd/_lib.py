@@ -141,12 +141,13 @@ class Op(C.Structure):
                 ("stem_act", C.c_int32), ("reserved2", C.c_int32),
                 ("in_scale", C.c_float), ("out_scale", C.c_float), ("res_scale", C.c_float), ("out8_c0", C.c_int32),
                 ("out8", View), ("out8_scale", C.c_float), ("out8_only", C.c_int32),
-                ("n_extra", C.c_int32), ("reserved3", C.c_int32), ("extra_weight", C.c_void_p), ("extra_bias", C.c_void_p)]
+                ("n_extra", C.c_int32), ("reserved3", C.c_int32), ("extra_weight", C.c_void_p), ("extra_bias", C.c_void_p),
+                ("dfl_level", C.c_int32), ("dfl_keep", C.c_int32)]
 
 
 class Level(C.Structure):
     _fields_ = [("offset", C.c_int64), ("offset_cls", C.c_int64), ("H", C.c_int32), ("W", C.c_int32),
-                ("stride", C.c_float), ("nc8", C.c_int32)]
+                ("stride", C.c_float), ("nc8", C.c_int32), ("offset_xywh", C.c_int64)]
 
 
 _lib = None
@@ -259,7 +260,7 @@ def lib() -> C.CDLL:
         f.argtypes = [vp, vp, vp, i64, i32, vp]
     L.yl_comm_barrier.restype = i32
     L.yl_comm_barrier.argtypes = [vp, vp]
-    if L.yl_abi_version() != 20:
+    if L.yl_abi_version() != 21:
         raise RuntimeError("libyl_amd.so ABI version mismatch; rebuild it")
     _lib = L
     return L

@@ -322,4 +322,54 @@ __device__ __forceinline__ void epilogue(const ConvArgs& a, __amdgpu_buffer_rsrc
   }
 }
 
+// Detect's box decode in the epilogue of the conv that computes a level's 64 DFL logits (ConvArgs::dfl_out; reference
+// nn/modules/head.py:95-126 _inference, block.py:51-69 DFL.forward, utils/tal.py:341-350 dist2bbox(xywh=True), head.py:105-106
+// `dbox * strides`) -- on the fp32 ACCUMULATORS: the logits never pass through bf16, which was the whole 0.2-0.3 stride box error
+// of the stored-logits form.  `acc` = one block of four channel tiles (64 channels, bias included) x NT pixel tiles.  By
+// chan_in_block a lane (pixel n, quad g) holds in tile pair p the 8 consecutive channels (4 p + g) * 8 ..: side 2 p + (g >> 1)
+// (l, t, r, b = 0..3; channel = side * 16 + bin), bins 8 (g & 1) .. + 7.  The lane pair (g, g ^ 1) shares a side: maximum over the
+// 16 bins by one exchange, each lane exponentiates its 8 bins, the two partial sums / weighted sums are exchanged and added as
+// (bins 0..7) + (bins 8..15) in both lanes.  Lanes g = 0, 1 then hold (l, r), lanes g = 2, 3 (t, b): centre and extent per axis
+// with box_xywh's arithmetic, one exchange across 32 lanes, and lane g = 0 stores the anchor's 16 bytes; 16 lanes = 256 contiguous
+// bytes.  first = index (over the batch, patch_setup's order = b * Ho * Wo + y * Wo + x) of the wave's first pixel.
+template <int NT>
+__device__ __forceinline__ void dfl_epilogue(const ConvArgs& a, int first, int g, int n, const f32x4 (&acc)[4][NT]) {
+  const int hw = a.Ho * a.Wo;
+  const float j0 = (float)((g & 1) * 8);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    float d[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[2 * p][nt][r];
+        v[4 + r] = acc[2 * p + 1][nt][r];
+      }
+      float m = v[0];
+#pragma unroll
+      for (int j = 1; j < 8; ++j) m = fmaxf(m, v[j]);
+      m = fmaxf(m, __shfl_xor(m, 16));
+      float sum = 0.f, ws = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float e = expf(v[j] - m);
+        sum += e;
+        ws += e * (j0 + (float)j);
+      }
+      const float sum2 = __shfl_xor(sum, 16), ws2 = __shfl_xor(ws, 16);
+      const bool hi = (g & 1) != 0;
+      d[p] = ((hi ? ws2 : ws) + (hi ? ws : ws2)) / ((hi ? sum2 : sum) + (hi ? sum : sum2));
+    }
+    const int gp = first + nt * 16 + n;
+    const int r = gp - (gp / hw) * hw, oy = r / a.Wo, ox = r - oy * a.Wo;
+    const float ac = (float)((g >> 1) ? oy : ox) + 0.5f;  // tal.py:326-338 make_anchors: (x + 0.5, y + 0.5)
+    const float lo = ac - d[0], hi2 = ac + d[1];
+    const float ctr = ((lo + hi2) / 2.0f) * a.dfl_stride, ext = (hi2 - lo) * a.dfl_stride;
+    const float cy = __shfl_xor(ctr, 32), eh = __shfl_xor(ext, 32);
+    if (g == 0 && gp < a.npix) *reinterpret_cast<float4*>(a.dfl_out + 4LL * gp) = make_float4(ctr, cy, ext, eh);
+  }
+}
+
 }  // namespace yl

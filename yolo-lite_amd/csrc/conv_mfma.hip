@@ -125,7 +125,9 @@ __device__ __forceinline__ void pf_sink(const ConvArgs& a, const f32x4 (&acc)[MT
 // PF: this conv writes a Detect level's class logits (act == 0, ncb == 1) and feeds the NMS candidate pre-filter on its way out
 // (pf_sink; the networks whose class branch ends in a plain 1x1 launch: YOLO11s / m / l / x, where the branch is too wide for
 // dwpw_kernel); a separate instantiation for the same reason.
-template <int KS, int MT, int NT, bool UNIFORM, bool POST, bool UP = false, bool O8 = false, bool PF = false>
+// DFL: this conv (its fused follow-up 1x1 with POST) computes a Detect level's 64 DFL logits: the box decode runs on the fp32
+// accumulators (dfl_epilogue, conv_common.h) and the bf16 logits are stored only with a.dfl_keep; separate instantiations again.
+template <int KS, int MT, int NT, bool UNIFORM, bool POST, bool UP = false, bool O8 = false, bool PF = false, bool DFL = false>
 __device__ __forceinline__ void conv_body(const ConvArgs& a, int block) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -277,19 +279,31 @@ __device__ __forceinline__ void conv_body(const ConvArgs& a, int block) {
       ConvArgs a2 = a;
       a2.Cout = a.post_cout;
       a2.act = a.post_act;
-      epilogue<MT, NT>(a2, rout, rres, cb, g, opix, acc);
+      if constexpr (DFL) {
+        static_assert(!DFL || MT == 4, "the DFL epilogue takes one block of 64 channels");
+        dfl_epilogue<NT>(a, patch_done * (16 * NT), g, n, acc);
+        if (a.dfl_keep) epilogue<MT, NT>(a2, rout, rres, cb, g, opix, acc);
+      } else {
+        epilogue<MT, NT>(a2, rout, rres, cb, g, opix, acc);
+      }
     } else {
       if constexpr (PF) {
         if (a.pf_count) pf_sink<MT, NT>(a, acc, patch_done, g, n, a.Cout);
       }
-      epilogue<MT, NT, O8>(a, rout, rres, cb, g, opix, acc);
+      if constexpr (DFL) {
+        static_assert(!DFL || MT == 4, "the DFL epilogue takes one block of 64 channels");
+        dfl_epilogue<NT>(a, patch_done * (16 * NT), g, n, acc);
+        if (a.dfl_keep) epilogue<MT, NT, O8>(a, rout, rres, cb, g, opix, acc);
+      } else {
+        epilogue<MT, NT, O8>(a, rout, rres, cb, g, opix, acc);
+      }
     }
   }
 }
 
-template <int KS, int MT, int NT, bool UNIFORM, bool POST, bool UP = false, bool O8 = false, bool PF = false>
+template <int KS, int MT, int NT, bool UNIFORM, bool POST, bool UP = false, bool O8 = false, bool PF = false, bool DFL = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(YL_CONV_WPE))) void conv_kernel(ConvArgs a) {
-  conv_body<KS, MT, NT, UNIFORM, POST, UP, O8, PF>(a, blockIdx.x);
+  conv_body<KS, MT, NT, UNIFORM, POST, UP, O8, PF, DFL>(a, blockIdx.x);
 }
 
 // Up to three convs of ONE tiling in one launch ("horizontal" fusion): the three Detect levels run the same box / class
@@ -301,7 +315,7 @@ struct ConvGroup {
   int nb[3];  // workgroups of each member (unused members: 0)
 };
 
-template <int KS, int MT, int NT, bool UNIFORM, bool POST>
+template <int KS, int MT, int NT, bool UNIFORM, bool POST, bool DFL = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(YL_CONV_WPE))) void conv_group_kernel(ConvGroup G) {
   int block = blockIdx.x, m = 0;
   if (block >= G.nb[0]) {
@@ -312,7 +326,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(YL_CONV_WPE
       m = 2;
     }
   }
-  conv_body<KS, MT, NT, UNIFORM, POST>(G.a[m], block);
+  conv_body<KS, MT, NT, UNIFORM, POST, false, false, false, DFL>(G.a[m], block);
 }
 
 // ------------------------------------------------------- depthwise 3x3 -> pointwise 1x1 in one launch
@@ -695,7 +709,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(YL_DWPW_WPE
 // independent of each other (head.py:61: cat(cv2[i](x), cv3[i](x))), so their launches can share the chip as well as
 // the levels do.  Workgroups [0, n_conv) run conv_body on the members of GC, the rest dwpw_body on the members of GD.
 // The register budget is the larger of the two bodies' (the conv's), the LDS size the larger of the members'.
-template <int NTC, bool POST, int NTD, bool PW2>
+template <int NTC, bool POST, int NTD, bool PW2, bool DFL = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void head_group_kernel(ConvGroup GC, ConvGroup GD, int n_conv) {
   int block = blockIdx.x;
   if (block < n_conv) {
@@ -708,7 +722,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void h
         m = 2;
       }
     }
-    conv_body<3, 4, NTC, true, POST>(GC.a[m], block);
+    conv_body<3, 4, NTC, true, POST, false, false, false, DFL>(GC.a[m], block);
   } else {
     block -= n_conv;
     int m = 0;
@@ -918,8 +932,28 @@ bool conv_pf_supported(const ConvConfig& cfg) {
   return cfg.ntaps == 1 && cfg.MT == 5 && cfg.ncb == 1 && cfg.uniform && !cfg.post && !cfg.gemm && (cfg.NT == 1 || cfg.NT == 2);
 }
 
+// a conv that computes a Detect level's DFL logits (ConvArgs::dfl_out): the 1x1 itself, or the 3x3 in front of it with the 1x1 fused
+template <int KS, int NT, bool U, bool POST>
+static int launch_dfl(const ConvConfig& cfg, const ConvArgs& a, hipStream_t s) {
+  if (a.out8 || a.in2 || a.res || a.out_f32 || a.pf_count || cfg.ncb != 1 || (POST ? a.post_cout : a.Cout) != 64)
+    return fail(-3, "conv: the DFL epilogue needs a plain conv whose 64 output channels sit in one wave");
+  auto kern = conv_kernel<KS, 4, NT, U, POST, false, false, false, true>;
+  static size_t attr = 0;
+  if (cfg.lds_bytes > attr) {
+    YL_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX));
+    attr = LDS_MAX;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.nblocks), dim3(256), cfg.lds_bytes, s, a);
+  YL_HIP(hipGetLastError());
+  return 0;
+}
+
 template <int KS, int MT, int NT, bool U, bool POST, bool O8 = false>
 static int launch_p(const ConvConfig& cfg, const ConvArgs& a, hipStream_t s) {
+  if (a.dfl_out) {
+    if constexpr (MT == 4 && !O8 && (POST || KS == 1)) return launch_dfl<KS, NT, U, POST>(cfg, a, s);
+    return fail(-3, "conv: the DFL epilogue needs a 1x1 conv (alone or fused behind a 3x3) with four channel tiles per wave");
+  }
   if constexpr (!O8 && !POST && (MT == 2 || MT == 4 || MT == 6 || MT == 8)) {
     if (a.out8) return launch_p<KS, MT, NT, U, POST, true>(cfg, a, s);
   }
@@ -1227,15 +1261,20 @@ bool conv_group_compatible(const ConvConfig* cfg, const ConvArgs* a, int n) {
   for (int i = 0; i < n; ++i) {
     if (cfg[i].ntaps != 9 || cfg[i].MT != 4 || cfg[i].uniform != cfg[0].uniform || cfg[i].post != cfg[0].post || cfg[i].NT != cfg[0].NT ||
         (cfg[i].NT != 2 && cfg[i].NT != 4) || a[i].in2 || a[i].out8 || a[i].out_f32 || a[i].res || a[i].stride != 1 ||
+        (a[i].dfl_out != nullptr) != (a[0].dfl_out != nullptr) || (a[i].dfl_out && (!cfg[i].post || a[i].post_cout != 64)) ||
         cfg[i].reg || cfg[i].tile || cfg[i].pair || cfg[i].cs || cfg[i].sw)
       return false;
   }
   return true;
 }
 
-template <int NT, bool POST, bool U = true>
+template <int NT, bool POST, bool U = true, bool DFL = false>
 static int launch_group_r(const ConvGroup& G, int grid, size_t lds, hipStream_t s) {
-  auto kern = conv_group_kernel<3, 4, NT, U, POST>;
+  if constexpr (POST && !DFL) {
+    if (G.a[0].dfl_out) return launch_group_r<NT, POST, U, true>(G, grid, lds, s);  // (all members or none: conv_group_compatible)
+  }
+  if (G.a[0].dfl_out && !DFL) return fail(-3, "conv group: the DFL epilogue rides on the fused follow-up 1x1");
+  auto kern = conv_group_kernel<3, 4, NT, U, POST, DFL>;
   if (int rc = allow_big_lds(reinterpret_cast<const void*>(kern), (int)((int)LDS_MAX))) return rc;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, G);
   YL_HIP(hipGetLastError());
@@ -1264,9 +1303,13 @@ int conv_group_launch(const ConvConfig* cfg, const ConvArgs* args, int n, int ba
   return post ? launch_group_r<2, true>(G, grid, lds, s) : launch_group_r<2, false>(G, grid, lds, s);
 }
 
-template <int NTC, bool POST, int NTD>
+template <int NTC, bool POST, int NTD, bool DFL = false>
 static int launch_head_group(const ConvGroup& GC, const ConvGroup& GD, int n_conv, int grid, size_t lds, hipStream_t s) {
-  auto kern = head_group_kernel<NTC, POST, NTD, POST>;
+  if constexpr (POST && !DFL) {
+    if (GC.a[0].dfl_out) return launch_head_group<NTC, POST, NTD, true>(GC, GD, n_conv, grid, lds, s);
+  }
+  if (GC.a[0].dfl_out && !DFL) return fail(-3, "head group: the DFL epilogue rides on the fused follow-up 1x1");
+  auto kern = head_group_kernel<NTC, POST, NTD, POST, DFL>;
   if (int rc = allow_big_lds(reinterpret_cast<const void*>(kern), (int)((int)LDS_MAX))) return rc;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, GC, GD, n_conv);
   YL_HIP(hipGetLastError());

@@ -326,9 +326,13 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
     const yl_level& L = levels[i];
     const int64_t pb = plane_bytes(geo_of(batch, L.H, L.W));
     if (L.nc8 < nc || L.nc8 % 8) return fail(-1, "level nc8 must be nc rounded up to a multiple of 8");
-    if (L.offset < 0 || L.offset % 16 || L.offset + 8 * pb > workspace_bytes || L.offset_cls < 0 || L.offset_cls % 16 ||
-        L.offset_cls + (L.nc8 / 8) * pb > workspace_bytes)
+    if (L.offset_cls < 0 || L.offset_cls % 16 || L.offset_cls + (L.nc8 / 8) * pb > workspace_bytes)
       return fail(-1, "level view exceeds the workspace");
+    // the boxes: 64 bf16 DFL logits at `offset` and / or the decoded (cx, cy, w, h) fp32 at `offset_xywh` (ABI v21)
+    if (L.offset < 0 && L.offset_xywh < 0) return fail(-1, "level needs its DFL logits (offset) or its decoded boxes (offset_xywh)");
+    if (L.offset >= 0 && (L.offset % 16 || L.offset + 8 * pb > workspace_bytes)) return fail(-1, "level view exceeds the workspace");
+    if (L.offset_xywh >= 0 && (L.offset_xywh % 16 || L.offset_xywh + (int64_t)batch * L.H * L.W * 16 > workspace_bytes))
+      return fail(-1, "level boxes (offset_xywh) exceed the workspace");
     e->levels.push_back(L);
     a0 += L.H * L.W;
   }
@@ -350,7 +354,7 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
         const int Ho = (o.in.H + 2 * pad - o.k) / o.stride + 1, Wo = (o.in.W + 2 * pad - o.k) / o.stride + 1;
         if (Ho != o.out.H || Wo != o.out.W) return fail(-1, tag + ": conv output dims mismatch");
         if (o.in.dtype == YL_FP8) {  // e4m3 x e4m3 on the block-scaled matrix pipe (conv_f8.hip)
-          if (o.post_weight || o.in2.offset >= 0 || o.stem_weight || o.cin_weight || o.out.dtype == YL_F32)
+          if (o.post_weight || o.in2.offset >= 0 || o.stem_weight || o.cin_weight || o.out.dtype == YL_F32 || o.dfl_level)
             return fail(-1, tag + ": an fp8 conv is a plain conv (no fused follow-up / upsampled input / stem, bf16 or fp8 output)");
           if (!(o.in_scale > 0.f) || (o.out.dtype == YL_FP8 && !(o.out_scale > 0.f)))
             return fail(-1, tag + ": fp8 conv needs positive in_scale (and out_scale for fp8 output)");
@@ -399,6 +403,16 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
         const int cin_w = o.cin_weight > 0 ? o.cin_weight : cin_total;
         const bool post = o.post_weight != nullptr;
         const int cout1 = post ? o.post_cin : o.out.C;  // channels the main GEMM produces
+        if (o.dfl_level) {  // this conv computes a Detect level's DFL logits: the box decode runs in its epilogue (dfl_epilogue)
+          if (o.dfl_level < 0 || o.dfl_level > n_levels) return fail(-1, tag + ": dfl_level names no level");
+          const yl_level& L = levels[o.dfl_level - 1];
+          if (L.offset_xywh < 0 || L.H != o.out.H || L.W != o.out.W || o.out.C != 64 || o.out.dtype != YL_BF16 || cout1 != 64 ||
+              (!post && o.k != 1) || up || o.res.offset >= 0 || o.out8.offset >= 0 || o.stem_weight || o.cin_weight || (post ? o.post_act : o.act))
+            return fail(-1, tag + ": the DFL epilogue needs a plain 1x1 conv 64 <- c without activation (or such a conv fused behind a "
+                              "conv of 64 channels) on a level with offset_xywh");
+          if (!o.dfl_keep && L.offset >= 0 && L.offset == o.out.offset)
+            return fail(-1, tag + ": the level announces stored DFL logits (offset) but the conv does not keep them (dfl_keep)");
+        }
         if (post && (!o.post_bias || o.res.offset >= 0 || o.out.C > o.post_cin))
           return fail(-1, tag + ": fused follow-up conv needs a bias, no residual and out.C <= post_cin");
         if (int rc = conv_choose(batch, cin_total, cout1, o.k, o.stride, Ho, Wo, post, &r.cfg)) return rc;
@@ -406,7 +420,7 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
         // it has its own filter packing (BM / 16 tiles).  Its 3x3 route cannot write an e4m3 copy (out8): such a conv
         // stays on conv_kernel.
         if (!post && !o.stem_weight && !o.cin_weight && o.out.dtype == YL_BF16 && !(up && o.res.offset >= 0) &&
-            !(o.k == 3 && o.out8.offset >= 0))
+            !(o.k == 3 && o.out8.offset >= 0) && !o.dfl_level)
           conv_gemm_choose(batch, cin_total, cout1, o.k, o.stride, Ho, Wo, &r.cfg, up ? o.in2.C : 0);
         if (o.out8.offset >= 0) {
           if (int rc = check_out8(o, batch, workspace_bytes, tag)) return rc;
@@ -459,8 +473,12 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
           std::vector<float> b0(o.stem_bias, o.stem_bias + o.in.C);
           if (int rc = dev_upload(e.get(), b0, &r.d_b0)) return rc;
         }
+        if (o.dfl_level && (r.cfg.MT != 4 || r.cfg.ncb != 1))
+          return fail(-3, tag + ": the DFL epilogue needs the conv's 64 channels as four tiles of one wave");
         r.flops = 2.0 * px_out * cout1 * cin_w * o.k * o.k + (post ? 2.0 * px_out * o.out.C * o.post_cin : 0.0);
-        r.bytes = px_in * o.in.C * 2 + (up ? px_in / 4 * o.in2.C * 2 : 0.0) + px_out * o.out.C * view_elem_size(o.out) +
+        // (a DFL conv stores 16 bytes of decoded box per pixel; the 64 bf16 logits only with dfl_keep)
+        const double out_b = o.dfl_level ? px_out * (16.0 + (o.dfl_keep ? 128.0 : 0.0)) : px_out * o.out.C * view_elem_size(o.out);
+        r.bytes = px_in * o.in.C * 2 + (up ? px_in / 4 * o.in2.C * 2 : 0.0) + out_b +
                   (o.res.offset >= 0 ? px_out * o.out.C * 2 : 0) + (double)cout1 * cin_w * o.k * o.k * 2;
         r.name = r.cfg.name;
         if (o.stem_weight) {
@@ -927,7 +945,7 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
         ok = o.lane == 0 && !r.f8 && !r.d_w0 && o.in.dtype == YL_BF16 && o.out.dtype == YL_BF16 && o.out8.offset < 0;
         if (o.kind == YL_OP_CONV) {
           ok = ok && nd == 0 && o.k == 3 && o.stride == 1 && o.res.offset < 0 && o.in2.offset < 0 && r.cfg.MT == 4 && r.cfg.uniform &&
-               r.cfg.ncb == 1 && (r.cfg.post != 0) == (e->ops[i].cfg.post != 0);
+               r.cfg.ncb == 1 && (r.cfg.post != 0) == (e->ops[i].cfg.post != 0) && (o.dfl_level != 0) == (e->ops[i].op.dfl_level != 0);
           ++nc;
         } else if (o.kind == YL_OP_DWCONV3) {
           const OpRec& d0 = e->ops[i + nc];
@@ -967,7 +985,7 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
       // with 20 batches in flight -- with 18 k-steps a band's k-loop (4.6 us) is shorter than what surrounds it (input
       // staging 2.8 us, epilogue + 1x1 + stores 2.5 us), and a 152 KB workgroup owns its CU, so nothing overlaps those phases.
       const int band64_on = getenv("YL_CONV_BAND64") ? atoi(getenv("YL_CONV_BAND64")) : 0;
-      bool band64 = ok && band_on && band64_on && nc >= 2 && nd == 0 && e->ops[i].cfg.post;
+      bool band64 = ok && band_on && band64_on && nc >= 2 && nd == 0 && e->ops[i].cfg.post && !e->ops[i].op.dfl_level;
       for (size_t k = i; k < j && band64; ++k) {
         const OpRec& r = e->ops[k];
         band64 = r.cfg.MT == 4 && r.cfg.ncb == 1 && !r.cfg.kord && r.op.in.C == 64 && r.op.post_cin == 64 && r.op.out.C == 64 && r.d_wpk2 &&
@@ -1075,6 +1093,12 @@ static void build_conv_args(const yl_engine* e, const OpRec& r, char* ws, ConvAr
   a.Cout = r.d_wpk2 ? o.post_cin : o.out.C;
   a.stride = o.stride;
   a.act = o.act;
+  if (o.dfl_level) {
+    const yl_level& L = e->levels[o.dfl_level - 1];
+    a.dfl_out = reinterpret_cast<float*>(ws + L.offset_xywh);
+    a.dfl_stride = L.stride;
+    a.dfl_keep = o.dfl_keep;
+  }
   fill_out8(a, o, ws, B);
 }
 

@@ -626,6 +626,7 @@ __device__ __forceinline__ DcAnchor dc_anchor(const DecCandArgs& a, int b, int a
 #pragma unroll
     for (int i = 1; i < NLV; ++i) {
       const bool in = i < a.n_levels && an >= a.lv[i].a0;
+      d.L.xywh = in ? a.lv[i].xywh : d.L.xywh;
       d.L.box.base = in ? a.lv[i].box.base : d.L.box.base;
       d.L.box.plane = in ? a.lv[i].box.plane : d.L.box.plane;
       d.L.box.W1 = in ? a.lv[i].box.W1 : d.L.box.W1;
@@ -670,14 +671,17 @@ __device__ __forceinline__ bool dc_keep(const DecCandArgs& a, float best, int bi
 // the candidate test and bookkeeping for one anchor.
 // key_slot < 0: append with an atomic (dense kernel); else the key goes to that slot of keys[b][] and a
 // rejected anchor leaves the sentinel ~0 there (sparse path: no atomics).
+// (bx = the anchor's (cx, cy, w, h): dc_box of its four DFL distances, or the level's decoded box, DecodeLevel::xywh)
+__device__ __forceinline__ float4 dc_box(const DcAnchor& d, float dl, float dt, float dr, float db) {
+  return box_xywh((float)d.px + 0.5f, (float)d.py + 0.5f, dl, dt, dr, db, d.L.stride);
+}
 __device__ __forceinline__ void dc_emit(const DecCandArgs& a, const NmsWs& w, const DcAnchor& d, float best, int bi,
-                                        float dl, float dt, float dr, float db, int key_slot = -1) {
+                                        float4 bx, int key_slot = -1) {
   if (!dc_keep(a, best, bi)) {
     if (key_slot >= 0) w.keys[(long long)d.b * w.KP + key_slot] = ~0ull;
     return;
   }
   const int an = d.L.a0 + d.p;
-  const float4 bx = box_xywh((float)d.px + 0.5f, (float)d.py + 0.5f, dl, dt, dr, db, d.L.stride);
   const int slot = key_slot >= 0 ? key_slot : atomicAdd(&w.count[d.b], 1);
   w.keys[(long long)d.b * w.KP + slot] = ((unsigned long long)(~__float_as_uint(best)) << 32) | (unsigned)an;
   w.cls_of[(long long)d.b * a.A + an] = bi;
@@ -708,6 +712,10 @@ __device__ __forceinline__ void decode_anchor_thread(const DecCandArgs& a, const
     if (key_slot >= 0) w.keys[(long long)b * w.KP + key_slot] = ~0ull;  // sparse path: the slot holds a rejected anchor
     return;
   }
+  if (d.L.xywh) {  // the producing conv's epilogue decoded the box from its fp32 accumulators
+    dc_emit(a, w, d, best, bi, level_xywh(d.L, b, d.p), key_slot);
+    return;
+  }
   float dist[4];
 #pragma unroll
   for (int side = 0; side < 4; ++side) {
@@ -721,7 +729,7 @@ __device__ __forceinline__ void decode_anchor_thread(const DecCandArgs& a, const
     }
     dist[side] = dfl_expect(v);
   }
-  dc_emit(a, w, d, best, bi, dist[0], dist[1], dist[2], dist[3], key_slot);
+  dc_emit(a, w, d, best, bi, dc_box(d, dist[0], dist[1], dist[2], dist[3]), key_slot);
 }
 
 // The same decode by FOUR adjacent lanes per anchor (lane & 3 = box side): each lane runs the DFL of its side (16 of the 64
@@ -734,7 +742,8 @@ __device__ __forceinline__ void decode_anchor_thread(const DecCandArgs& a, const
 // `valid` lanes only; all four lanes of a group must be active or inactive together.
 // what the four lanes of a quad know about their anchor after the evaluation (every lane holds the same values)
 struct DcQuad {
-  float best, dl, dt, dr, db;
+  float best;
+  float4 bx;  // (cx, cy, w, h)
   int bi;
 };
 // (stamps: diagnostic builds, the one-launch kernel's phase stamps 7-10; every outstanding load is waited for before a stamp)
@@ -761,8 +770,14 @@ __device__ __forceinline__ DcQuad decode_anchor_quad_eval(const DecCandArgs& a, 
     const int c8 = side + 4 * q;
     if (c8 < nplanes) level_load8(d.L.cls, c8, d.pix, cv[q]);
   }
-  level_load8(d.L.box, 2 * side, d.pix, l8);
-  level_load8(d.L.box, 2 * side + 1, d.pix, h8);
+  const bool dec = d.L.xywh != nullptr;  // the box arrives decoded (DecodeLevel::xywh): 16 bytes instead of the lane's two DFL planes
+  float4 bx = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (dec) {
+    bx = level_xywh(d.L, d.b, d.p);
+  } else {
+    level_load8(d.L.box, 2 * side, d.pix, l8);
+    level_load8(d.L.box, 2 * side + 1, d.pix, h8);
+  }
   DQ_STAMP(8);
   float m = -__builtin_huge_valf();
 #pragma unroll
@@ -822,7 +837,7 @@ __device__ __forceinline__ DcQuad decode_anchor_quad_eval(const DecCandArgs& a, 
   }
   DQ_STAMP(9);
   float dist = 0.f;
-  if (best > a.conf_thres) {  // (uniform over the four lanes)
+  if (!dec && best > a.conf_thres) {  // (uniform over the four lanes)
     float v[16];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -835,7 +850,8 @@ __device__ __forceinline__ DcQuad decode_anchor_quad_eval(const DecCandArgs& a, 
   DcQuad q;
   q.best = best;
   q.bi = bi;
-  q.dl = __shfl(dist, l0), q.dt = __shfl(dist, l0 + 1), q.dr = __shfl(dist, l0 + 2), q.db = __shfl(dist, l0 + 3);
+  const float dl = __shfl(dist, l0), dt = __shfl(dist, l0 + 1), dr = __shfl(dist, l0 + 2), db = __shfl(dist, l0 + 3);
+  q.bx = dec ? bx : dc_box(d, dl, dt, dr, db);
   DQ_STAMP(10);
   return q;
 }
@@ -849,7 +865,7 @@ __device__ __forceinline__ void decode_anchor_quad(const DecCandArgs& a, const N
     if (key_slot >= 0) w.keys[(long long)b * w.KP + key_slot] = ~0ull;
     return;
   }
-  dc_emit(a, w, d, q.best, q.bi, q.dl, q.dt, q.dr, q.db, key_slot);
+  dc_emit(a, w, d, q.best, q.bi, q.bx, key_slot);
 }
 
 __global__ __launch_bounds__(256) void decode_candidates_dense_kernel(DecCandArgs a, NmsWs w) {
@@ -892,7 +908,8 @@ __device__ __forceinline__ void decode_exact_body(const DecCandArgs& a, const Nm
     const int an = min(max(w.pre_list[(long long)(b * NSUB + sub) * w.sub_cap + j], 0), a.A - 1);
     const DcAnchor d = dc_anchor(a, b, an);
     // lane = box channel lane: plane lane >> 3, element lane & 7
-    const float v = (float)d.L.box.base[(long long)(lane >> 3) * d.L.box.plane + (long long)d.pix * 8 + (lane & 7)];
+    const bool dec = d.L.xywh != nullptr;  // (wave-uniform: one anchor per wavefront) the level's boxes arrive decoded
+    const float v = dec ? 0.f : (float)d.L.box.base[(long long)(lane >> 3) * d.L.box.plane + (long long)d.pix * 8 + (lane & 7)];
     float mx = v;
 #pragma unroll
     for (int off = 8; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
@@ -926,7 +943,7 @@ __device__ __forceinline__ void decode_exact_body(const DecCandArgs& a, const Nm
     }
     const float dist = ws / sum;
     const float dl = __shfl(dist, 0), dt = __shfl(dist, 16), dr = __shfl(dist, 32), db = __shfl(dist, 48);
-    if (lane == 0) dc_emit(a, w, d, best, bi, dl, dt, dr, db, sub * w.sub_cap + j);
+    if (lane == 0) dc_emit(a, w, d, best, bi, dec ? level_xywh(d.L, b, d.p) : dc_box(d, dl, dt, dr, db), sub * w.sub_cap + j);
   }
 }
 
@@ -1074,7 +1091,7 @@ __global__ __launch_bounds__(1024) void decode_nms_fused_kernel(DecCandArgs a, N
           const bool keep = dc_keep(a, q.best, q.bi);
           ckey[i] = keep ? (((unsigned long long)(~__float_as_uint(q.best)) << 32) | (unsigned)an) : ~0ull;
           ccls[i] = q.bi;
-          cbox[i] = box_xywh((float)d.px + 0.5f, (float)d.py + 0.5f, q.dl, q.dt, q.dr, q.db, d.L.stride);
+          cbox[i] = q.bx;
         }
       }
     }

@@ -728,21 +728,26 @@ __global__ __launch_bounds__(256) void decode_kernel(DecodeArgs a) {
   const DecodeLevel L = a.lv[l];
   const int p = an - L.a0, py = p / L.W, px = p - py * L.W;
   const int pix = pv_pix(L.box, b, py, px);
-  float dist[4];
+  float4 bx;
+  if (L.xywh) {  // decoded by the epilogue of the conv that computed the DFL logits (yl_level.offset_xywh)
+    bx = level_xywh(L, b, p);
+  } else {
+    float dist[4];
 #pragma unroll
-  for (int side = 0; side < 4; ++side) {
-    float v[16];
-    float lo[8], hi[8];
-    level_load8(L.box, 2 * side, pix, lo);
-    level_load8(L.box, 2 * side + 1, pix, hi);
+    for (int side = 0; side < 4; ++side) {
+      float v[16];
+      float lo[8], hi[8];
+      level_load8(L.box, 2 * side, pix, lo);
+      level_load8(L.box, 2 * side + 1, pix, hi);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      v[j] = lo[j];
-      v[8 + j] = hi[j];
+      for (int j = 0; j < 8; ++j) {
+        v[j] = lo[j];
+        v[8 + j] = hi[j];
+      }
+      dist[side] = dfl_expect(v);
     }
-    dist[side] = dfl_expect(v);
+    bx = box_xywh((float)px + 0.5f, (float)py + 0.5f, dist[0], dist[1], dist[2], dist[3], L.stride);
   }
-  const float4 bx = box_xywh((float)px + 0.5f, (float)py + 0.5f, dist[0], dist[1], dist[2], dist[3], L.stride);
   float* yb = a.y + (long long)b * (4 + a.nc) * a.A + an;
   yb[0] = bx.x;
   yb[(long long)a.A] = bx.y;

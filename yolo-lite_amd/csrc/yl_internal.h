@@ -132,6 +132,12 @@ struct ConvArgs {
   int nblocks;
   int dbg;  // development ablation flags (YL_CONV_DBG), 0 in production
   int st_nt;  // 1: the epilogue's stores carry the non-temporal hint (large outputs that no cache holds until their reader runs)
+  // The conv that produces a Detect level's 64 DFL logits (yl_op.dfl_level): dfl_out = the level's decoded boxes, fp32
+  // [npix][4] = (cx, cy, w, h) * stride, written by dfl_epilogue (conv_common.h) from the fp32 accumulators; the bf16 logits go
+  // to `out` only with dfl_keep.  nullptr: an ordinary conv.
+  float* dfl_out;
+  float dfl_stride;
+  int dfl_keep;
   unsigned long long* stamps;  // diagnostic builds (-DYL_STAMPS): dwpw_body's phase stamps
   // conv3_tile_kernel (3x3, stride 1, input tile in LDS): tile geometry in guarded-pixel units
   int t_px, t_PL, t_ppp, t_ntiles, t_plane_px, t_H, t_W, t_B;  // pixels staged / LDS plane pitch / DMA pieces per plane
@@ -431,6 +437,7 @@ bool sppf_resident_fits(int c1, int c2, int tail, int H, int W);
 int sppf_resident_launch(const SppfArgs& a, hipStream_t s);
 
 struct DecodeLevel {
+  const float4* xywh;  // != nullptr: the level's boxes decoded by the producing conv's epilogue (yl_level.offset_xywh), [B][H * W]; `box` unused
   PView box;     // 8 planes: DFL logits (head.py:64 cv2)
   PView cls;     // nc8 / 8 planes: class logits (cv3); padding channels hold large negative values
   int H, W, a0;  // a0: first anchor index of this level
@@ -448,7 +455,8 @@ inline PView level_view(const void* workspace, int64_t offset, int batch, int H,
 }
 inline DecodeLevel decode_level(const void* workspace, const yl_level& L, int batch, int a0) {
   DecodeLevel d;
-  d.box = level_view(workspace, L.offset, batch, L.H, L.W);
+  d.xywh = L.offset_xywh >= 0 ? reinterpret_cast<const float4*>((const char*)workspace + L.offset_xywh) : nullptr;
+  d.box = level_view(workspace, L.offset >= 0 ? L.offset : L.offset_cls, batch, L.H, L.W);  // (geometry is shared with `cls`)
   d.cls = level_view(workspace, L.offset_cls, batch, L.H, L.W);
   d.H = L.H;
   d.W = L.W;
@@ -544,5 +552,9 @@ __device__ __forceinline__ float4 box_xywh(float ax, float ay, float dl, float d
                      (y2 - y1) * stride);
 }
 __device__ __forceinline__ float sigmoid_score(float logit) { return 1.0f / (1.0f + expf(-logit)); }
+// (cx, cy, w, h) of level-local anchor p of image b from the level's decoded boxes (DecodeLevel::xywh)
+__device__ __forceinline__ float4 level_xywh(const DecodeLevel& L, int b, int p) {
+  return L.xywh[(long long)b * (L.H * L.W) + p];
+}
 
 }  // namespace yl

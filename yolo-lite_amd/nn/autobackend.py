@@ -106,8 +106,8 @@ class AutoBackend:
         return eng
 
     def forward(self, im: torch.Tensor, augment=False, visualize=False, embed=None, graph: bool = False):
-        """(B,3,H,W) in [0,1] -> [y (B, 4+nc, A) fp32, [raw level maps (B, 64+nc, H_l, W_l)]]
-        like ``Detect.forward`` in eval mode (reference head.py:59-69, autobackend.py:126-151)."""
+        """(B,3,H,W) in [0,1] -> [y (B, 4+nc, A) fp32, [per-level class-logit maps (B, nc, H_l, W_l)]]
+        like ``Detect.forward`` in eval mode (reference head.py:59-69, autobackend.py:126-151; see the note at the return)."""
         if augment or visualize or embed:
             raise NotImplementedError("augment / visualize / embed are outside the accelerated predict path")
         if im.device != self.device:
@@ -118,7 +118,10 @@ class AutoBackend:
         b, _, h, w = im.shape
         eng = self.engine_for(b, h, w, calib=im)
         y = eng.forward(im, graph=graph)
-        return [y, eng.raw_levels()]
+        # The second element: the reference returns the raw level maps (B, 64 + nc, H_l, W_l) (head.py:69).  This program decodes
+        # the boxes in the epilogue of the conv that computes the 64 DFL logits and never stores them: the levels' class logits
+        # (B, nc, H_l, W_l) are returned in their place (nothing on the predict path reads it, predictor.py:99 takes preds[0]).
+        return [y, eng.raw_cls_levels()]
 
     __call__ = forward
 

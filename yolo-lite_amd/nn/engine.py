@@ -53,6 +53,7 @@ class HipEngine:
             c.cin_weight = o.get("cin_weight", 0)
             c.lane = o.get("lane", 0)
             c.group = int(o.get("group", 0))
+            c.dfl_level, c.dfl_keep = int(o.get("dfl_level", 0)), int(o.get("dfl_keep", 0))
             c.inp, c.out, c.res = _cview(o["inp"]), _cview(o["out"]), _cview(o.get("res"))
             c.inp2, c.up = _cview(o.get("inp2")), int(o.get("up", 0))
             c.in_scale, c.out_scale, c.res_scale = (float(o.get(k, 0.0)) for k in ("in_scale", "out_scale", "res_scale"))
@@ -86,7 +87,7 @@ class HipEngine:
                 c.post_cin, c.post_act = int(w2.shape[1]), int(o.get("post_act", 0))
         lv = (_lib.Level * len(self.prog.levels))()
         for i, L in enumerate(self.prog.levels):
-            lv[i] = _lib.Level(L["offset"], L["offset_cls"], L["H"], L["W"], L["stride"], L["nc8"])
+            lv[i] = _lib.Level(L["offset"], L["offset_cls"], L["H"], L["W"], L["stride"], L["nc8"], L.get("offset_xywh", -1))
         self._levels = lv
         iv = _cview(self.prog.input_view)
         handle = C.c_void_p()
@@ -118,7 +119,8 @@ class HipEngine:
     def from_model(cls, specs: Sequence[LayerSpec], state_dict: Dict[str, torch.Tensor], batch: int, in_h: int,
                    in_w: int, device: torch.device, strides: Sequence[float] = (8.0, 16.0, 32.0),
                    keep_layers: bool = False, fp8_calib: Optional[torch.Tensor] = None,
-                   fp8_headroom: float = 2.0, one_batch: bool = False) -> "HipEngine":
+                   fp8_headroom: float = 2.0, one_batch: bool = False, dfl_epilogue: bool = True,
+                   keep_logits: bool = False) -> "HipEngine":
         """``keep_layers=True`` (debug: ``layer_output`` of every layer) disables the fusions that make
         intermediate tensors disappear; pass False for the production program.
 
@@ -126,15 +128,21 @@ class HipEngine:
         runs once on it, every dense 3x3 conv's input range is measured (``calibrate_fp8``), and the program is
         lowered again with those convs on the fp8 matrix pipe (``lower.apply_fp8``).
 
-        ``one_batch=True``: the latency profile (``lower(one_batch=True)``) for callers that run one batch at a time."""
-        prog = lower(specs, state_dict, batch, in_h, in_w, strides, fuse_post=not keep_layers, one_batch=one_batch)
+        ``one_batch=True``: the latency profile (``lower(one_batch=True)``) for callers that run one batch at a time.
+
+        ``dfl_epilogue`` (default): the Detect levels' boxes are decoded from the fp32 accumulators of the conv that computes the DFL
+        logits (``level_boxes()``); ``keep_logits=True`` ALSO stores the 64 bf16 logits per anchor (``raw_levels()``: parity tests);
+        ``dfl_epilogue=False`` is the form of rounds 1-5: logits stored in bf16 and decoded by their readers."""
+        prog = lower(specs, state_dict, batch, in_h, in_w, strides, fuse_post=not keep_layers, one_batch=one_batch,
+                     dfl_epilogue=dfl_epilogue, keep_logits=keep_logits)
         if fp8_calib is None:
             return cls(prog, device)
         e16 = cls(prog, device)
         scales = e16.calibrate_fp8(fp8_calib, fp8_headroom)
         del e16
         torch.cuda.empty_cache()
-        return cls(lower(specs, state_dict, batch, in_h, in_w, strides, fuse_post=not keep_layers, fp8_scales=scales, one_batch=one_batch), device)
+        return cls(lower(specs, state_dict, batch, in_h, in_w, strides, fuse_post=not keep_layers, fp8_scales=scales, one_batch=one_batch,
+                         dfl_epilogue=dfl_epilogue, keep_logits=keep_logits), device)
 
     def calibrate_fp8(self, im: torch.Tensor, headroom: float = 2.0) -> Dict[str, float]:
         """{conv name: input scale} for every conv the fp8 pass may take: absmax of the conv's input after a forward of
@@ -332,11 +340,44 @@ class HipEngine:
                 TView(L["offset_cls"], L["H"], L["W"], L["nc8"], L["nc8"], 0, BF16))
 
     def raw_levels(self) -> List[torch.Tensor]:
-        """(B, 64+nc, H, W) fp32 copies of the Detect level maps (reference head.py:64-65 ``cat(cv2, cv3)``)."""
+        """(B, 64+nc, H, W) fp32 copies of the Detect level maps (reference head.py:64-65 ``cat(cv2, cv3)``).  The 64 DFL logits
+        exist only in a program lowered with ``keep_logits=True`` (the production program decodes the boxes in the epilogue of the
+        conv that computes them and stores ``level_boxes()`` instead)."""
         out = []
         for i in range(len(self.prog.levels)):
+            if self.prog.levels[i]["offset"] < 0:
+                raise RuntimeError("this program does not store the DFL logits (lower(..., keep_logits=True) does); "
+                                   "see level_boxes() / raw_cls_levels()")
             vb, vc = self.level_views(i)
             out.append(torch.cat([self.view_tensor(vb), self.view_tensor(vc)[:, : self.nc]], 1))
+        return out
+
+    def raw_cls_levels(self) -> List[torch.Tensor]:
+        """(B, nc, H, W) fp32 copies of the Detect levels' class logits (cv3, head.py:64)."""
+        return [self.view_tensor(self.level_views(i)[1])[:, : self.nc] for i in range(len(self.prog.levels))]
+
+    def head_outputs(self) -> List[torch.Tensor]:
+        """Everything the Detect head of this program stores, level by level (class logits; the DFL logits where kept; the decoded
+        boxes where the epilogue produces them): what two variants of a program must agree on bit for bit (tests)."""
+        out = self.raw_cls_levels()
+        for i, L in enumerate(self.prog.levels):
+            if L["offset"] >= 0:
+                out.append(self.view_tensor(self.level_views(i)[0]))
+        if all(L.get("offset_xywh", -1) >= 0 for L in self.prog.levels):
+            out += self.level_boxes()
+        return out
+
+    def level_boxes(self) -> List[torch.Tensor]:
+        """(B, 4, H * W) fp32 per level: (cx, cy, w, h) in input pixels as the epilogue of the level's last box conv decoded them
+        from its fp32 accumulators (``yl_level.offset_xywh``; reference head.py:105-106 ``dbox * strides``, per level)."""
+        out = []
+        for L in self.prog.levels:
+            off = L.get("offset_xywh", -1)
+            if off < 0:
+                raise RuntimeError("this program stores DFL logits, not decoded boxes (lower(..., dfl_epilogue=False))")
+            n = self.batch * L["H"] * L["W"]
+            t = self.workspace[off: off + 16 * n].view(torch.float32).view(self.batch, L["H"] * L["W"], 4)
+            out.append(t.permute(0, 2, 1).contiguous())
         return out
 
     def _planes(self, v: TView) -> torch.Tensor:

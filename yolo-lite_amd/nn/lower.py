@@ -92,6 +92,12 @@ class _Arena:
         self.top += (view_bytes(self.batch, v) + 255) // 256 * 256
         return v
 
+    def alloc_bytes(self, n: int) -> int:
+        """A raw buffer of n bytes (no planar geometry): its offset."""
+        off = self.top
+        self.top += (n + 255) // 256 * 256
+        return off
+
 
 def c3k_resident_fits(c_: int, H: int, W: int) -> bool:
     """Mirror of ``c3k_resident_fits`` (csrc/resident.hip): a C3k block of inner width 64 whose map fits one workgroup's
@@ -166,6 +172,8 @@ def fuse_follow_up_convs(ops: List[dict]) -> List[dict]:
         a["post_bias"] = b["bias"]
         a["post_act"] = b.get("act", 0)
         a["out"] = b["out"]
+        if b.get("dfl_level", 0):  # (the fused 1x1 computes a Detect level's DFL logits: the box decode moves with it)
+            a["dfl_level"], a["dfl_keep"] = b["dfl_level"], b.get("dfl_keep", 0)
         a["name"] = f"{a.get('name', '')}+{b.get('name', '').split('.')[-1] if '.' in b.get('name', '') else b.get('name', '')}"
         a["fused_names"] = [b.get("name", "")]
         drop.add(j)
@@ -379,7 +387,7 @@ def fp8_candidate(o: dict, min_cin: int = 32, allow_1x1: bool = False) -> bool:
     x, y = o.get("inp"), o.get("out")
     if o["kind"] != OP_CONV or not (o.get("k") == 3 or (allow_1x1 and o.get("k") == 1 and x.C >= 64)):
         return False
-    return ("post_weight" not in o and o.get("inp2") is None
+    return ("post_weight" not in o and o.get("inp2") is None and not o.get("dfl_level", 0)
             and "stem_weight" not in o and not o.get("cin_weight", 0) and x.dtype == BF16 and y.dtype == BF16
             and x.C % 16 == 0 and x.C >= min_cin and (y.C % 32 == 0 or y.C % 48 == 0))
 
@@ -705,8 +713,15 @@ def group_detect_levels(ops: List[dict], det_prefix: str, nlv: int, keep_first_b
 
 def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, in_h: int, in_w: int,
           strides: Sequence[float] = (8.0, 16.0, 32.0), side_lanes: bool = True, fuse_post: bool = True,
-          fused_stem: bool = True, fp8_scales: Optional[Dict[str, float]] = None, one_batch: bool = False) -> Program:
-    """``one_batch=True``: the program of a caller that runs ONE batch at a time (``predict()`` per call): the resident C3k blocks take two
+          fused_stem: bool = True, fp8_scales: Optional[Dict[str, float]] = None, one_batch: bool = False,
+          dfl_epilogue: bool = True, keep_logits: bool = False) -> Program:
+    """``dfl_epilogue`` (default on): Detect's box decode -- DFL + dist2bbox * stride (head.py:95-126, block.py:51-69, tal.py:341-350) --
+    runs in the epilogue of the conv that computes a level's 64 DFL logits (cv2[i][2], alone or fused behind cv2[i][1]) on its fp32
+    accumulators and stores (cx, cy, w, h) fp32 per anchor (``Program.levels[i]["offset_xywh"]``); the logits are stored as bf16
+    planes too only with ``keep_logits`` (parity tests; ``levels[i]["offset"]`` is -1 otherwise).  ``dfl_epilogue=False``: the form of
+    rounds 1-5 -- bf16 logits stored, decoded by the NMS / decode kernels (box error up to 0.3 stride from the bf16 rounding).
+
+    ``one_batch=True``: the program of a caller that runs ONE batch at a time (``predict()`` per call): the resident C3k blocks take two
     workgroups per image (0.83 of the latency for 1.4 x the chip time; with batches in flight it costs 1.5 % of the throughput), and
     SPPF / the PSABlock stay separate launches (their one-launch forms win chip time, not latency), and the Detect levels' box and
     class branch launches are joined (YL_GROUP_LEVELS=3)."""
@@ -877,6 +892,10 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
         conv(f"{dp}.cv2.{lvl}.0", xin, t1, 3, 1)
         conv(f"{dp}.cv2.{lvl}.1", t1, t2, 3, 1)
         conv(f"{dp}.cv2.{lvl}.2", t2, head_box, 1, 1, act=False, bn=False)
+        off_xywh = -1
+        if dfl_epilogue:
+            off_xywh = ar.alloc_bytes(batch * h * w * 16)  # fp32 (cx, cy, w, h) per anchor, [B][H * W][4]
+            ops[-1]["dfl_level"], ops[-1]["dfl_keep"] = lvl + 1, int(keep_logits)
         for o in ops[n0:]:
             o["lane"] = box_lane(lvl)
         if lvl in defer_box:  # run this box branch after the rest of the network (see below)
@@ -896,8 +915,8 @@ def lower(specs: Sequence[LayerSpec], sd: Dict[str, torch.Tensor], batch: int, i
         conv(f"{dp}.cv3.{lvl}.2", e2, head_cls, 1, 1, act=False, wb=(wc, bc))
         for o in ops[n1:]:
             o["lane"] = cls_lane(lvl)
-        level_rec[lvl] = dict(offset=head_box.offset, offset_cls=head_cls.offset, nc8=nc8, H=h, W=w,
-                              stride=float(strides[lvl]))
+        level_rec[lvl] = dict(offset=head_box.offset if (keep_logits or not dfl_epilogue) else -1, offset_cls=head_cls.offset,
+                              offset_xywh=off_xywh, nc8=nc8, H=h, W=w, stride=float(strides[lvl]))
 
     views: Dict[int, TView] = {}
     sppf_tail: Dict[int, TView] = {}  # C2PSA layer -> its cat(a, b) buffer, when the SPPF launch in front of it ran its cv1
