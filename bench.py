@@ -341,24 +341,19 @@ def short_config(scale, batch, imgsz, dtype, streams, steps, dev, conf=0.25, iou
     return res
 
 
-def measured_traffic(kernel, cfg):
-    """HBM bytes per launch of a kernel family from a committed PMC summary (profiles/*_traffic.json, written by
-    tools/summarize_profile.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench; PMC counters
-    cannot be read from inside the un-profiled run).  Only a file whose ``_config`` (scale, imgsz, batch, dtype) equals
-    the configuration being benched is used -- the newest such file; (None, None) when there is none."""
+def per_launch_profile(cfg):
+    """The newest committed per-launch table (profiles/*_per_launch.json, tools/summarize_profile.py: rocprofv3 kernel-trace duration
+    and PMC FETCH_SIZE / WRITE_SIZE bytes of every launch of a step, matched to the per-op table by position) whose ``_config``
+    equals the configuration being benched; None when there is none."""
     best = None
-    for f in sorted((ROOT / "profiles").glob("*_traffic.json")):
+    for f in sorted((ROOT / "profiles").glob("*_per_launch.json")):
         try:
             t = json.loads(f.read_text())
         except ValueError:
             continue
-        if t.get("_config") != cfg:
-            continue
-        for fam, v in t.items():
-            if not fam.startswith("_") and kernel in fam.split("+"):
-                best = (v["read_bytes_per_launch"] + v["write_bytes_per_launch"], f"{f.name}: {t.get('_source', '')}",
-                        v.get("avg_launch_us_rocprof"))
-    return best if best else (None, None, None)
+        if t.get("_config") == cfg and t.get("rows"):
+            best = (f.name, t)
+    return best
 
 
 def roofline_from_profile(rows, batch, cfg):
@@ -388,15 +383,42 @@ def roofline_from_profile(rows, batch, cfg):
     # `frac` divides by the IN-SEQUENCE HIP-event time of a launch (measured live in this run; it includes the ~2.6 us dispatch gap
     # in front of a dependent launch); the committed rocprofv3 kernel trace gives the kernel-only duration: both are stated
     roof["time_source"] = "in-sequence HIP events of this run (dispatch gap included)"
-    roof["traffic"], src, us_rp = measured_traffic(name, cfg)
-    if src:
-        roof["traffic_unit"] = "HBM bytes per launch (PMC)"
-        roof["traffic_source"] = src
-    if us_rp:
-        ach = (a["flops"] / a["launches"] / (us_rp * 1e-6) / 1e12) if bound == "mfma" else (a["bytes"] / a["launches"] / (us_rp * 1e-6) / 1e9)
-        roof["avg_launch_us_rocprof"] = us_rp
-        roof["frac_rocprof"] = round(ach / roof["peak"], 4)
-        roof["frac_rocprof_note"] = "same algorithmic work / the committed rocprofv3 kernel-trace duration of the family (profiles/, kernel only)"
+    # Traffic and the kernel-only duration come from the committed per-launch table: THE SAME LAUNCHES (matched by op name) whose
+    # algorithmic work is divided above -- round 5 divided the stride-2 convs' bytes by the duration / PMC bytes of a template family
+    # that also held the stride-1 convs.  Every instance is listed; frac_rocprof must reproduce from those rows by hand.
+    plp = per_launch_profile(cfg)
+    if plp:
+        fname, tab = plp
+        by_name = {r["name"]: r for r in tab["rows"]}
+        inst, miss = [], []
+        for r in rows:
+            if r["kernel"] != name:
+                continue
+            p = by_name.get(r["name"])
+            if p is None or "us_rocprof" not in p:
+                miss.append(r["name"])
+                continue
+            work = r["flops"] if bound == "mfma" else r["bytes"]
+            tr = (p.get("read_bytes", 0) + p.get("write_bytes", 0)) if "read_bytes" in p and "write_bytes" in p else None
+            inst.append({"op": r["name"], "us_in_sequence": round(r["ms"] * 1e3, 2), "us_rocprof": p["us_rocprof"],
+                         "algorithmic_bytes": round(r["bytes"]), "GFLOP": round(r["flops"] / 1e9, 3), "traffic": tr,
+                         "frac_in_sequence": round(work / (r["ms"] * 1e-3) / (1e12 if bound == "mfma" else 1e9) / roof["peak"], 4),
+                         "frac_rocprof": round(work / (p["us_rocprof"] * 1e-6) / (1e12 if bound == "mfma" else 1e9) / roof["peak"], 4)})
+        if inst and not miss:
+            us_sum = sum(i["us_rocprof"] for i in inst)
+            work_sum = sum((i["GFLOP"] * 1e9) if bound == "mfma" else i["algorithmic_bytes"] for i in inst)
+            roof["instances"] = inst
+            roof["avg_launch_us_rocprof"] = round(us_sum / len(inst), 2)
+            roof["frac_rocprof"] = round(work_sum / (us_sum * 1e-6) / (1e12 if bound == "mfma" else 1e9) / roof["peak"], 4)
+            roof["frac_rocprof_note"] = ("sum of the instances' algorithmic work / sum of their committed rocprofv3 kernel-trace durations "
+                                         f"(profiles/{fname}, kernel only, one batch in flight)")
+            if all(i["traffic"] is not None for i in inst):
+                roof["traffic"] = round(sum(i["traffic"] for i in inst) / len(inst))
+                roof["traffic_unit"] = "HBM bytes per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE), mean over the instances listed"
+                roof["traffic_source"] = f"profiles/{fname}: {tab.get('_source', '')}"
+                roof["traffic_over_algorithmic"] = round(roof["traffic"] / max(1, roof["algorithmic_bytes_per_launch"]), 3)
+        elif miss:
+            roof["traffic_note"] = f"profiles/{fname} has no row for {miss}: the program changed since that profile was taken"
     # best single 3x3 layer against the MFMA roof (the north-star target names the fused 3x3 conv)
     best = None
     for r in rows:
@@ -549,7 +571,15 @@ def main():
         native = os.environ.get("YL_BENCH_PY_LOOP", "0") != "1"
         if native:
             eng.launch_many(step_h[:S], step_s[:S])  # (builds the argument arrays' cache entry for the slice; untimed)
+            sync_all()
+            # the K steps ONCE before the warm-up rounds below: the figure a K-step run gives right behind the W warm-up steps the
+            # caller asked for (rounds 1-4's method) -- reported as value_cold_first_run beside `value`, which is taken on the plateau
+            tc0 = time.perf_counter()
             eng.launch_many(step_h, step_s)
+            sync_all()
+            extra["value_cold_first_run"] = round(B * args.steps / (time.perf_counter() - tc0), 1)
+            extra["value_cold_first_run_note"] = (f"the same K = {args.steps} steps timed once right behind the {max(args.warmup, 2 * S)} warm-up steps, before "
+                                                  "the extra warm-up rounds (the method of BENCH_r01-r04; its first call also builds the launch arrays)")
         sync_all()
         # Warm-up to the steady state.  The W steps the caller asks for are a minimum: after the engine build the first rounds of
         # S batches run 4-5 % below the rate the same loop settles at (tools/round_timeline.py --reps 40 on one box: 54.7, 55.1,
@@ -808,7 +838,12 @@ def main():
                              if args.scale in ACT_MELEM_AT_640 else None),
         }
         res.update(extra)
-        res["bench_config"] = cfg_key  # what profiles/*_traffic.json files are matched against
+        # which of the figures `value` is (VERDICT r05 weak #12 / ADVICE): the pipelined rate on the plateau; SURVEY 8(d)'s literal
+        # per-iteration figure and the cold first run are value_sync_per_iteration and value_cold_first_run of the same line
+        res["value_kind"] = (f"pipelined: {S} batches in flight, K steps issued by one native call after the warm-up rounds; beside it: "
+                             "value_sync_per_iteration (one batch at a time, one host synchronisation per iteration: SURVEY 8(d) as written), "
+                             "value_cold_first_run (the same K steps right behind the --warmup steps), value_steady_state (500 steps)")
+        res["bench_config"] = cfg_key  # what profiles/*_per_launch.json files are matched against
         try:
             probe = yl_lib.graph_branch_probe(dev)
         except Exception as e:  # the probe must never cost the bench line

@@ -22,7 +22,15 @@ def short(name):
     return n[:60]
 
 
+def _agg(dirpath):
+    f = Path(dirpath) / "agg.json"  # tools/reduce_pmc.py (run on the GPU box; the raw CSVs are deleted there)
+    return json.loads(f.read_text()) if f.exists() else None
+
+
 def pmc(dirpath, counter):
+    a = _agg(dirpath)
+    if a is not None:
+        return {k: v[counter][0] / v[counter][1] for k, v in a["per_kernel"].items() if counter in v and v[counter][1]}
     out = defaultdict(lambda: [0.0, 0])
     files = sorted(glob.glob(str(Path(dirpath) / "**" / "*counter_collection.csv"), recursive=True),
                    key=lambda f: Path(f).stat().st_mtime)
@@ -84,6 +92,77 @@ def family(k):
     if k.startswith("nms_scan"):
         return "nms_scan"
     return None
+
+
+def per_launch_table(src, bench):
+    """One row per LAUNCH of a step, by position: the per-op table of the un-profiled run (name, family, algorithmic flops / bytes,
+    in-sequence HIP-event time) beside THE SAME launch's rocprofv3 kernel-trace duration and its FETCH_SIZE / WRITE_SIZE bytes
+    (read side doubled, gfx950).  bench.py's roofline block quotes rows of this table -- traffic and kernel-only duration of exactly
+    the launches whose algorithmic work it divides (round 5 divided one family's work by another family mix's duration)."""
+    if not (src / "per_op.json").exists():
+        return None
+    rows = json.load(open(src / "per_op.json"))
+    rows = rows["rows"] if isinstance(rows, dict) else rows
+
+    out = [dict(name=r["name"], kernel=r["kernel"], flops=r["flops"], bytes=r["bytes"], us_in_sequence=round(r["ms"] * 1e3, 2)) for r in rows]
+    n = len(out)
+    note = []
+    def program_only(t):  # (older agg.json files still carry the runtime's copy kernels / the counter-clearing launch per step)
+        if not t:
+            return t
+        keep = [i for i, k in enumerate(t["kernels"]) if not k.startswith("zero_i32_kernel") and not k.startswith("__amd_rocclr")]
+        return dict(t, kernels=[t["kernels"][i] for i in keep], mean=[t["mean"][i] for i in keep])
+
+    tr = program_only((_agg(src / "trace") or {}).get("trace"))
+    if tr and len(tr["mean"]) == n:
+        for i in range(n):
+            out[i]["us_rocprof"] = round(tr["mean"][i], 2)
+            out[i]["kernel_symbol"] = tr["kernels"][i]
+        note.append(f"kernel-trace durations: mean over {tr['n_steps']} steps, one batch in flight")
+    else:
+        note.append(f"kernel trace: steps of {len(tr['mean']) if tr else 0} dispatches do not match the {n} rows of the per-op table")
+    for d, c, key, mul in (("pmc_fetch", "FETCH_SIZE", "read_bytes", 2 * 1024.0), ("pmc_write", "WRITE_SIZE", "write_bytes", 1024.0)):
+        st = program_only((_agg(src / d) or {}).get("steps", {}).get(c))
+        if st and len(st["mean"]) == n:
+            for i in range(n):
+                out[i][key] = round(st["mean"][i] * mul)
+            note.append(f"{c}: mean over {st['n_steps']} steps")
+        else:
+            note.append(f"{c}: steps of {len(st['mean']) if st else 0} dispatches do not match the {n} rows of the per-op table")
+    return {"_config": (bench or {}).get("bench_config"),
+            "_source": "rocprofv3 kernel trace (--streams 1) and separate --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py, matched to the per-op "
+                       "table by launch position within a step (stem launch to stem launch); read side = 2 x FETCH_SIZE (gfx950); " + "; ".join(note),
+            "rows": out}
+
+
+def sq_table(src, top):
+    """Issue / wait / LDS / texture-addresser counters per kernel symbol (two --pmc passes, one batch in flight), averaged per launch."""
+    names = ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_LDS",
+             "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_INST_LDS", "SQ_INSTS_VALU_MFMA_MOPS_BF16", "SQ_ACTIVE_INST_VMEM", "TA_BUSY_avr"]
+    vals = {}
+    for c in names:
+        v = pmc(src / ("pmc_sq1" if names.index(c) < 8 else "pmc_sq2"), c)
+        if v:
+            vals[c] = v
+    if not vals:
+        return []
+    lines = ["", "## Issue / wait / LDS / texture-addresser counters of the top kernels (per launch; separate `--pmc` passes, one batch in flight)", "",
+             "SQ_* cycle counters are in quad-cycles summed over all waves (MI355X_MICROARCH.md): the shares below are of SQ_WAVE_CYCLES --",
+             "`wait` = SQ_WAIT_ANY (wave parked on s_waitcnt / barrier), `issue-stall` = SQ_WAIT_INST_ANY, `active` = SQ_ACTIVE_INST_ANY;",
+             "`LDS conflict` = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE; `TA busy` = TA_BUSY_avr / GRBM_GUI_ACTIVE where both exist.", "",
+             "| kernel | waves | wave Mcyc | wait % | issue-stall % | active % | VALU active % | LDS active % | LDS-issue-stall % | VMEM active % | LDS conflict % | VALU insts/wave | LDS insts/wave |",
+             "|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
+    g = lambda c, k: vals.get(c, {}).get(k)
+    for k in top:
+        wc, wv = g("SQ_WAVE_CYCLES", k), g("SQ_WAVES", k)
+        if not wc or not wv:
+            continue
+        pct = lambda c: "" if g(c, k) is None else f"{100.0 * g(c, k) / wc:.1f}"
+        conf = "" if not g("SQ_LDS_IDX_ACTIVE", k) else f"{100.0 * (g('SQ_LDS_BANK_CONFLICT', k) or 0.0) / g('SQ_LDS_IDX_ACTIVE', k):.1f}"
+        per = lambda c: "" if g(c, k) is None else f"{g(c, k) / wv:.0f}"
+        lines.append(f"| `{k}` | {wv:.0f} | {wc / 1e6:.2f} | {pct('SQ_WAIT_ANY')} | {pct('SQ_WAIT_INST_ANY')} | {pct('SQ_ACTIVE_INST_ANY')} | {pct('SQ_ACTIVE_INST_VALU')} | "
+                     f"{pct('SQ_ACTIVE_INST_LDS')} | {pct('SQ_WAIT_INST_LDS')} | {pct('SQ_ACTIVE_INST_VMEM')} | {conf} | {per('SQ_INSTS_VALU')} | {per('SQ_INSTS_LDS')} |")
+    return lines
 
 
 def main():
@@ -148,6 +227,18 @@ def main():
         rq = "" if k not in rdreq else f"{rdreq[k] / 1e6:.2f} ({100.0 * rd32.get(k, 0.0) / max(rdreq[k], 1.0):.0f} %)"
         lines.append(f"| `{k}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} | "
                      f"{'' if rd is None else f'{2 * rd * 1024 / 1e6:.1f}'} | {ms_} | {rq} | {'' if wr is None else f'{wr * 1024 / 1e6:.1f}'} | {mb} |")
+    top = [short(r["Name"]) for r in sorted(rows, key=lambda r: -float(r["Percentage"]))[:12]]
+    lines += sq_table(src, top)
+    pl = per_launch_table(src, bench)
+    if pl:
+        (dst / f"{tag}_per_launch.json").write_text(json.dumps(pl, indent=1))
+        lines += ["", "## Per launch of one step (position-matched: per-op table, kernel trace, PMC)", "",
+                  "| op | family | alg MB | GFLOP | in-sequence us | rocprof us | PMC read MB | PMC write MB | PMC / alg |", "|---|---|---|---|---|---|---|---|---|"]
+        for r in pl["rows"]:
+            t = (r.get("read_bytes", 0) + r.get("write_bytes", 0))
+            ratio = "" if not t or not r["bytes"] else f"{t / r['bytes']:.2f}"
+            lines.append(f"| {r['name'][:60]} | {r['kernel']} | {r['bytes'] / 1e6:.1f} | {r['flops'] / 1e9:.2f} | {r['us_in_sequence']} | {r.get('us_rocprof', '')} | "
+                         f"{r.get('read_bytes', 0) / 1e6:.1f} | {r.get('write_bytes', 0) / 1e6:.1f} | {ratio} |")
     (dst / f"{tag}_summary.md").write_text("\n".join(lines) + "\n")
     # per-family HBM bytes per launch (launch-weighted over the template instances), read by bench.py
     fam = {}

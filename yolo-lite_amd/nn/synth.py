@@ -113,3 +113,52 @@ def synth_images(batch: int, h: int, w: int, seed: int = 0) -> torch.Tensor:
     amp = field(48, "nearest", 1).abs()  # texture strength per region: some flat, some busy
     x = x + 0.25 * amp * (torch.rand((batch, 3, h, w), generator=g) * 2.0 - 1.0)
     return x.clamp_(0.0, 1.0)
+
+
+def plant_object_head(sd: Dict[str, torch.Tensor], feats: Sequence[torch.Tensor], per_image: int = 96, alpha: float = 12.0,
+                      margin: float = 3.0, ridge: float = 0.05, seed: int = 0, det_index: int = 23) -> Dict[str, torch.Tensor]:
+    """A synthetic class head with OBJECTS in it: a copy of ``sd`` whose last class convs (``model.<det>.cv3.<l>.2``, reference
+    head.py:47 ``nn.Conv2d(c3, nc, 1)``) are matched filters for ~``per_image`` planted anchors per image.
+
+    ``feats[l]``: (B, c3, H_l, W_l) fp32, the INPUT of level l's last class conv on the images the head is built for (random-init
+    features of a fixed synthetic batch).  Planted anchors are drawn per image and level (in proportion to the level's anchors, at
+    least two pixels apart) and dealt to the classes round-robin.  Random-init features of noise images are strongly correlated
+    from anchor to anchor (a few dominant directions), so the filters are WHITENED matched filters: with mu, S = mean and
+    covariance of the level's features over all anchors and R = S + ridge^2 * mean(diag S) * I,
+        w_c = alpha * sum_k R^-1 d_k / (d_k^T R^-1 d_k),  d_k = p_k - mu,      b_c = margin - alpha - w_c . mu
+    A planted anchor answers with logit ~``margin`` (score 0.95 for 3), an unrelated anchor with ``margin - alpha`` plus cross-talk
+    of std ~alpha * sqrt(prototypes per class / c3): the per-anchor best score is BIMODAL, as a trained detector's is.  With the
+    plain random head (``calibrate_cls_bias``) white-noise images put every anchor's best score within a fraction of a logit of
+    the threshold, so the box COUNT measured the last bit of the number format and a post-NMS parity gate could not be failed by a
+    wrong kernel (round-5 review, weak #1).  ``ridge`` bounds the amplification of feature noise (the storage format's rounding)
+    along low-variance directions.  Deterministic in (sd, feats, seed)."""
+    out = dict(sd)
+    g = _gen("plant", seed)
+    B = feats[0].shape[0]
+    A = sum(f.shape[2] * f.shape[3] for f in feats)
+    k_class = 0
+    for l, f in enumerate(feats):
+        f = f.double().cpu()
+        _, c3, H, W = f.shape
+        key = f"model.{det_index}.cv3.{l}.2"
+        nc = sd[key + ".weight"].shape[0]
+        flat = f.permute(1, 0, 2, 3).reshape(c3, -1)          # (c3, B * H * W)
+        mu = flat.mean(1)
+        dev = flat - mu[:, None]
+        S = dev @ dev.T / max(1, dev.shape[1] - 1)
+        R = S + (ridge ** 2) * S.diagonal().mean() * torch.eye(c3, dtype=torch.float64)
+        Rinv = torch.linalg.inv(R)
+        n_l = max(1, int(round(per_image * H * W / A)))
+        ys, xs = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
+        lattice = ((ys % 3 == 1) & (xs % 3 == 1)).flatten().nonzero().flatten() if H >= 3 and W >= 3 else torch.arange(H * W)
+        w = torch.zeros(nc, c3, dtype=torch.float64)
+        for b in range(B):
+            pick = lattice[torch.randperm(lattice.numel(), generator=g)[: min(n_l, lattice.numel())]]
+            for p in pick.tolist():
+                d = f[b, :, p // W, p % W] - mu
+                rd = Rinv @ d
+                w[k_class % nc] += alpha * rd / (d @ rd).clamp(min=1e-30)
+                k_class += 1
+        out[key + ".weight"] = w.float().view(nc, c3, 1, 1).contiguous()
+        out[key + ".bias"] = ((margin - alpha) - w @ mu).float()
+    return out
