@@ -33,3 +33,35 @@ def test_self_launch_two_ranks_fails_loudly_without_gpus():
 def test_mismatched_world_size_is_rejected():
     r = _run("--gpus", "4", env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stderr + r.stdout)
+
+
+def test_rank_dying_mid_run_ends_the_job_non_zero():
+    """A rank that dies MID-RUN (here: rank 5 of 8 exits with status 3 after the others have entered a long wait, as ranks stuck in
+    a collective would): the launcher ends the other ranks, returns that status promptly and relays no result line."""
+    import importlib.util
+    import time
+
+    spec = importlib.util.spec_from_file_location("_yl_launch", str(ROOT / "yolo-lite_amd" / "launch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    child = ("import os, sys, time\n"
+             "r = int(os.environ['RANK']); assert os.environ['WORLD_SIZE'] == '8' and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+             "print('started', r, flush=True)\n"
+             "time.sleep(0.5)\n"
+             "if r == 5: sys.exit(3)\n"
+             "time.sleep(120)\n"
+             "print('{\"value\": 1}', flush=True)\n")
+    t0 = time.monotonic()
+    rc, lines = mod.launch_ranks(8, [sys.executable, "-c", child])
+    assert rc == 3 and time.monotonic() - t0 < 30
+    assert not any(ln.lstrip().startswith("{") for ln in lines), lines  # rank 0 never got to print a record
+
+
+def test_all_ranks_succeeding_returns_rank0_stdout():
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("_yl_launch", str(ROOT / "yolo-lite_amd" / "launch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rc, lines = mod.launch_ranks(3, [sys.executable, "-c", "import os; print('{\"rank\": %s}' % os.environ['RANK'])"])
+    assert rc == 0 and [ln.strip() for ln in lines] == ['{"rank": 0}']

@@ -122,3 +122,83 @@ def test_shard_bounds_errors():
     assert shard_bounds(256, 8, 3) == (96, 128)
     with pytest.raises(ValueError):
         shard_bounds(30, 8, 0)
+
+
+# ------------------------------------------------------------------ BASELINE.json config 4's own shapes, eight ranks (gloo)
+C4_PER, C4_DET, C4_HW = 32, 300, 640
+
+
+def _record_compute(im):
+    """(32, 3, 640, 640) uint8 -> a REAL-sized result record's contents (out[32, 300, 6], cnt[32]) as a pure function of the
+    images: per image a count in 0..300 and that many rows derived from the pixels, score-descending like the engine's."""
+    b = im.shape[0]
+    cnt = (im[:, 0, 0, :8].to(torch.int32).sum(1) % (C4_DET + 1)).to(torch.int32)
+    out = torch.zeros(b, C4_DET, 6)
+    base = im[:, :, ::80, ::80].float().flatten(1)[:, :6]                      # six pixel samples per image
+    rows = torch.arange(C4_DET, dtype=torch.float32).view(1, C4_DET, 1)
+    full = base.view(b, 1, 6) + rows                                           # row r = samples + r
+    full[:, :, 4] = 1.0 - rows[:, :, 0] / C4_DET                               # descending "confidence"
+    mask = (torch.arange(C4_DET).view(1, C4_DET) < cnt.view(b, 1)).view(b, C4_DET, 1)
+    out = torch.where(mask, full, out)
+    return out, cnt
+
+
+def _worker_c4(rank, world, port, steps, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from yololite_amd.dist import ShardedRunner, pack_views, record_floats, unpack_record
+
+        slots, words = 2, record_floats(C4_PER, C4_DET)
+        assert words == C4_PER * C4_DET * 6 + C4_PER == 57632  # 230 528 bytes per rank and step (SURVEY 8(e))
+        batches = [None, None]
+        if rank == 0:  # the root owns the uint8 global batches: 256 x 3 x 640 x 640 = 315 MB each
+            g = torch.Generator().manual_seed(4)
+            batches = [torch.randint(0, 256, (world * C4_PER, 3, C4_HW, C4_HW), generator=g, dtype=torch.uint8) for _ in range(2)]
+        recs = [torch.empty(words) for _ in range(2 * slots)]
+
+        def compute(im, slot, lane):
+            assert tuple(im.shape) == (C4_PER, 3, C4_HW, C4_HW) and im.dtype == torch.uint8
+            out, cnt = _record_compute(im)
+            o, c = pack_views(recs[lane], C4_PER, C4_DET)
+            o.copy_(out)
+            c.copy_(cnt)
+            return recs[lane]
+
+        runner = ShardedRunner(compute, C4_PER, (3, C4_HW, C4_HW), torch.uint8, torch.device("cpu"), words, slots=slots)
+        last = runner.run(batches, steps)
+        if rank == 0:
+            assert len(last) == world and all(t.numel() == words for t in last)
+            outs, cnts = unpack_record(last, C4_PER, C4_DET)
+            ref_out, ref_cnt = _record_compute(batches[(steps - 1) % 2])  # the 1-process answer on the whole global batch
+            assert torch.equal(torch.cat(cnts), ref_cnt) and torch.equal(torch.cat(outs), ref_out)
+            assert int(ref_cnt.max()) > 200 and int(ref_cnt.min()) < 100  # (records of very different fill, all 300 rows travel)
+        else:
+            assert last is None
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+
+        q.put((rank, repr(e) + traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_runner_world8_config4_shapes():
+    """BASELINE.json config 4 at its own size with eight ranks on gloo: the root scatters a 256 x 3 x 640 x 640 uint8 global batch
+    as eight 32-image slices (39 MB per peer), every rank fills a full ``record_floats(32, 300)`` record (230 KB), the root gathers
+    eight of them per step; the gathered records equal the one-process answer on the whole batch, in rank order, after three
+    steps on two slots (four lanes: a lane buffer is reused once).  The per-GPU compute is a stand-in (no GPU here); the
+    transport, the lane schedule and the record layout are the ones bench.py --gpus 8 runs."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_c4, args=(r, world, port, 3, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(r, "ok") for r in range(world)], res

@@ -84,7 +84,7 @@ def test_native_comm_world1_scatter_gather_barrier(gpu_device, tmp_path):
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(gpu_device)
-    comm = NativeComm(0, 1, NativeComm.id_via_file(str(tmp_path / "id")), device=gpu_device)
+    comm = NativeComm(0, 1, NativeComm.id_via_file(str(tmp_path / "id"), token="job-1"), device=gpu_device)
     assert (comm.rank, comm.world) == (0, 1)
     st = torch.cuda.Stream(device=gpu_device)
     g = torch.randint(0, 256, (4, 3, 32, 32), dtype=torch.uint8, device=gpu_device)
@@ -104,8 +104,8 @@ def test_native_comm_world1_scatter_gather_barrier(gpu_device, tmp_path):
     comm.close()  # idempotent
 
 
-@pytest.mark.parametrize("slots,steps", [(2, 5), (5, 12)])
-def test_native_runner_equals_plain_detect(gpu_device, golden, tmp_path, slots, steps):
+@pytest.mark.parametrize("slots,steps,two_comms,in_place", [(2, 5, False, True), (5, 12, True, True), (3, 7, True, False)])
+def test_native_runner_equals_plain_detect(gpu_device, golden, tmp_path, slots, steps, two_comms, in_place):
     """NativeShardedRunner (exchanges enqueued by libyl_amd.so on their own HIP streams) against plain detect, bit for bit:
     the same check the torch.distributed runner passes above."""
     from yololite_amd.dist import NativeComm, NativeShardedRunner, record_floats, unpack_record
@@ -125,14 +125,18 @@ def test_native_runner_equals_plain_detect(gpu_device, golden, tmp_path, slots, 
         o, c = eng.detect(xb, 0.25, 0.7, max_det=max_det, graph=False)
         ref.append((o.clone(), c.clone()))
     torch.cuda.synchronize()
-    comm = NativeComm(0, 1, NativeComm.id_via_file(str(tmp_path / "id")), device=gpu_device)
+    comm = NativeComm(0, 1, NativeComm.id_via_file(str(tmp_path / "id"), token="job-1"), device=gpu_device)
     streams = [torch.cuda.Stream(device=gpu_device) for _ in range(slots)]
 
     def compute(im, slot, lane):
         return eng.detect_record(im, 0.25, 0.7, max_det=max_det, slot=slot, rec_key=lane)
 
+    # one communicator (both directions on one exchange stream) and two (a gather communicator and stream of its own); the root's
+    # slice read in place or copied into the lane buffer: the same records
+    comm_g = NativeComm(0, 1, NativeComm.id_via_file(str(tmp_path / "id_g"), token="job-1"), device=gpu_device) if two_comms else None
     runner = NativeShardedRunner(comm, compute, B, (3, H, W), torch.uint8, gpu_device, record_floats(B, max_det), slots=slots,
-                                 streams=streams)
+                                 streams=streams, comm_gather=comm_g, root_in_place=in_place)
+    assert (runner.s_gather is runner.s_scatter) == (not two_comms)
     for n in (steps, steps + 1):
         last = runner.run(batches, n)
         comm.barrier(stream=streams[(n - 1) % slots])
@@ -144,6 +148,92 @@ def test_native_runner_equals_plain_detect(gpu_device, golden, tmp_path, slots, 
             m = int(ref[k][1][i])
             assert torch.equal(outs[0][i, :m], ref[k][0][i, :m])
     comm.close()
+    if comm_g is not None:
+        comm_g.close()
+    assert not (tmp_path / "id").exists() and not (tmp_path / "id_g").exists()  # rank 0 removed the id files after the create barrier
+
+
+def _native_two_rank_worker(rank, world, idfile, token, q):
+    """One rank of the two-GPU test of the yl_comm_* transport (spawned; its own process and GPU)."""
+    try:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import numpy as np
+        from yololite_amd import _lib
+        from yololite_amd.dist import NativeComm, NativeShardedRunner, record_floats, unpack_record
+
+        _lib.apply_runtime_knobs()
+        dev = torch.device(f"cuda:{rank}")
+        torch.cuda.set_device(dev)
+        comm = NativeComm(rank, world, NativeComm.id_via_file(idfile, token), device=dev)
+        comm_g = NativeComm(rank, world, NativeComm.id_via_file(idfile + "_g", token), device=dev)
+        st = torch.cuda.Stream(device=dev)
+        # scatter / gather / barrier with the link in the path
+        g = torch.Generator().manual_seed(3)
+        full = torch.randint(0, 256, (world * 4, 3, 32, 32), generator=g, dtype=torch.uint8)
+        local = torch.zeros((4, 3, 32, 32), dtype=torch.uint8, device=dev)
+        comm.scatter(full.to(dev) if rank == 0 else None, local, stream=st)
+        rec = torch.full((5,), float(rank + 1), device=dev)
+        into = torch.zeros((world, 5), device=dev) if rank == 0 else None
+        comm.gather(rec, into, stream=st)
+        comm.barrier(stream=st)
+        assert torch.equal(local.cpu(), full[rank * 4: (rank + 1) * 4])
+        if rank == 0:
+            assert into.cpu().tolist() == [[float(r + 1)] * 5 for r in range(world)]
+        # the sharded runner against plain detect of the same images, on every rank's own engine (identical replicas)
+        B, H, W, max_det, slots = 2, 96, 128, 300, 3
+        gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_v1.npz"))
+        sd = synth_state_dict("n", 1, cls_bias=list(gold["net_n_96x128_bias"]), cls_gain=8.0)
+        specs, _ = arch.parse_model(arch.yolo11_dict("n"))
+        eng = HipEngine.from_model(specs, sd, B, H, W, dev)
+        gb = torch.Generator().manual_seed(9)
+        batches_cpu = [torch.randint(0, 256, (world * B, 3, H, W), generator=gb, dtype=torch.uint8) for _ in range(3)]
+        batches = [b.to(dev) for b in batches_cpu] if rank == 0 else [None] * 3
+        streams = [torch.cuda.Stream(device=dev) for _ in range(slots)]
+
+        def compute(im, slot, lane):
+            return eng.detect_record(im, 0.25, 0.7, max_det=max_det, slot=slot, rec_key=lane)
+
+        runner = NativeShardedRunner(comm, compute, B, (3, H, W), torch.uint8, dev, record_floats(B, max_det), slots=slots,
+                                     streams=streams, comm_gather=comm_g)
+        for n in (7, 8):
+            last = runner.run(batches, n)
+            comm.barrier(stream=streams[(n - 1) % slots])
+            torch.cuda.synchronize()
+            if rank == 0:
+                outs, cnts = unpack_record(last, B, max_det)
+                k = (n - 1) % 3
+                for r in range(world):
+                    o, c = eng.detect(batches_cpu[k][r * B: (r + 1) * B].to(dev), 0.25, 0.7, max_det=max_det, graph=False)
+                    assert torch.equal(cnts[r], c)
+                    for i in range(B):
+                        assert torch.equal(outs[r][i, : int(c[i])], o[i, : int(c[i])])
+        comm.close()
+        comm_g.close()
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+
+        q.put((rank, repr(e) + traceback.format_exc()))
+
+
+def test_native_comm_two_ranks_over_the_link(tmp_path):
+    """The yl_comm_* transport with a peer on the other end of an xGMI link (two processes, two GPUs): grouped ncclSend / ncclRecv,
+    the barrier's gather and scatter words, and NativeShardedRunner (one communicator per direction) against plain detect of every
+    rank's shard.  Skipped below two devices -- which is every box this build has had: the test exists so that the first
+    multi-GPU run exercises the p2p code before anything quotes a number from it (round-5 advisor, medium)."""
+    import torch.multiprocessing as mp
+
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_native_two_rank_worker, args=(r, 2, str(tmp_path / "id"), "job-2", q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
 
 
 def test_config4_eight_shards_of_the_global_batch(gpu_device):

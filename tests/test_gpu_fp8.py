@@ -343,20 +343,24 @@ def test_fp8_full_size_x1280_batch8_properties(gpu_device):
 
 def test_fp8_x_1280_vs_fp32_oracle(gpu_device):
     """BASELINE.json config 5's OWN model -- YOLO11x at 1280x1280, e4m3 dense 3x3 convs -- against the fp32 oracle (reference
-    arithmetic: nn/modules/block.py:720-739, head.py:95-126, utils/ops.py:138-273) through the post-NMS gate: boxes paired one to
-    one by IoU >= 0.9, classes of paired boxes bit-exact, |dconf| inside the stated e4m3 band, every one-sided box explained,
-    at least 85 % of the reference's boxes paired.  The head is calibrated as bench.py calibrates config 5 (no image cut at
-    max_det).  One-sided boxes: the e4m3 FORMAT itself -- the oracle with the same convs emulated in e4m3 on the CPU, no
-    kernel involved -- keeps more boxes than fp32 on this head (count bias); the HIP program's share of one-sided boxes must
-    stay at the format's own (oracle.parity_gate.format_yardstick_ok), and both are printed."""
+    arithmetic: nn/modules/block.py:720-739, head.py:95-126, utils/ops.py:138-273) through the FIXED post-NMS gate of bench.py
+    (C5_GATE): boxes paired one to one by IoU >= 0.9, classes of paired boxes bit-exact, nothing unexplained, >= 90 % of the
+    reference's boxes paired, one-sided share <= 0.35, |det / ref - 1| <= 0.25, |dconf| p99 <= 0.2 and max <= 0.6 (score bands
+    stated from the HIP measurement on this head, see bench.py).
+
+    The head carries PLANTED OBJECTS (nn/synth.py plant_object_head, ~96 per image): the per-anchor best score is bimodal, so
+    the gate is falsifiable -- a kernel that loses or shifts features loses objects or moves their scores.  Round 5's version of
+    this test ran the calibrated random head, whose best scores all sit at the threshold: e4m3 kept 2.2 x the reference's boxes
+    there and only a yardstick against this repo's own CPU emulation could pass (review, weak #1).  The emulation is still
+    run and printed -- as a diagnostic, not as the criterion."""
     import bench
     from oracle import yolo11_oracle as oracle
-    from oracle.parity_gate import format_yardstick_ok, parity_gate
+    from oracle.parity_gate import parity_gate
 
     B, S, conf, iou = 2, 1280, 0.25, 0.7
     x = bench.config5_images(B, S).to(gpu_device)
     x8 = (x * 255).to(torch.uint8)
-    specs, sd, eng = bench.build_model("x", gpu_device, B, S, S, x, target_frac=bench.config5_target_frac(S), fp8=True)
+    specs, sd, eng = bench.build_model("x", gpu_device, B, S, S, x, fp8=True, planted=bench.c5_planted(B))
     assert sum("_f8_" in eng.op_kernel(i) for i in range(len(eng.prog.ops))) >= 70
     o, c = eng.detect(x8, conf, iou, max_det=300, graph=False)
     y8 = eng.forward(x8, graph=False).float().cpu()
@@ -370,15 +374,55 @@ def test_fp8_x_1280_vs_fp32_oracle(gpu_device):
         ref = oracle.non_max_suppression(y32, conf, iou, max_det=300)
         y8e, _ = oracle.forward(sd, xin, "x", storage="bf16", fp8_scales=eng.fp8_conv_scales())
         det8e = oracle.non_max_suppression(y8e, conf, iou, max_det=300)
-    kw = dict(band=FP8_SCORE_ATOL, min_matched_frac=0.85, max_explained_share=0.35, ref_y=y32)
-    g = parity_gate(ref, [o[i, : counts[i]].cpu() for i in range(B)], conf, iou, got_y=y8, **kw)
-    fmt = parity_gate(ref, det8e, conf, iou, got_y=y8e, **kw)
-    yard = format_yardstick_ok(g, fmt, FP8_SCORE_ATOL)
-    keys = ("ref", "det", "matched", "matched_frac", "class_mismatch", "unexplained", "max_dconf", "explained_share", "count_bias",
-            "near_threshold", "nms_flip")
-    print("fp8 x 1280, HIP e4m3 vs fp32 oracle:   ", {k: g[k] for k in keys})
-    print("fp8 x 1280, e4m3 emulation vs fp32:    ", {k: fmt[k] for k in keys})
-    print("yardstick:", yard)
-    assert g["class_mismatch"] == 0 and g["unexplained"] == 0
-    assert g["matched_frac"] >= 0.85 and g["max_dconf"] <= FP8_SCORE_ATOL, g
-    assert yard["ok"], yard
+    # the head IS bimodal on the reference side: few anchors between 0.05 and 0.6, ~96 objects per image above the threshold
+    mx = y32[:, 4:].amax(1)
+    mid = int(((mx > 0.05) & (mx < 0.6)).sum())
+    over = (mx > conf).sum(1).tolist()
+    print("fp32 reference: anchors with a best score in (0.05, 0.6):", mid, "of", mx.numel(), "; over the threshold per image:", over)
+    assert mid < 0.01 * mx.numel() and all(60 <= n <= 200 for n in over), (mid, over)
+    g = parity_gate(ref, [o[i, : counts[i]].cpu() for i in range(B)], conf, iou, ref_y=y32, got_y=y8, **bench.C5_GATE)
+    fmt = parity_gate(ref, det8e, conf, iou, ref_y=y32, got_y=y8e, **bench.C5_GATE)
+    keys = ("ref", "det", "matched", "matched_frac", "class_mismatch", "unexplained", "max_dconf", "p99_dconf", "explained_share",
+            "count_bias", "near_threshold", "nms_flip", "ok")
+    print("fp8 x 1280, HIP e4m3 vs fp32 oracle:                ", {k: g.get(k) for k in keys})
+    print("fp8 x 1280, e4m3 emulation vs fp32 (diagnostic):    ", {k: fmt.get(k) for k in keys})
+    assert g["ok"], g
+    # the same program without e4m3 (bf16 storage) through the same gate with the bf16 score bands: tighter, same head
+    from yololite_amd.nn.engine import HipEngine
+
+    e16 = HipEngine.from_model(specs, sd, B, S, S, gpu_device)
+    o16, c16 = e16.detect(x8, conf, iou, max_det=300, graph=False)
+    y16 = e16.forward(x8, graph=False).float().cpu()
+    g16 = parity_gate(ref, [o16[i, : int(c16[i])].cpu() for i in range(B)], conf, iou, ref_y=y32, got_y=y16,
+                      **dict(bench.C5_GATE, band=0.25, p99_band=0.1))
+    print("bf16 x 1280, HIP bf16 vs fp32 oracle:               ", {k: g16.get(k) for k in keys})
+    assert g16["ok"], g16
+
+
+FP8_GAIN1_SCORE_ATOL = 0.05  # e4m3 dense 3x3 convs against the reference at a trained head's logit scale (measured below)
+
+
+def test_fp8_pre_nms_at_realistic_logit_scale_vs_reference_golden(gpu_device):
+    """The e4m3 program against the REFERENCE's own pre-NMS tensor (tests/golden/golden_gain1_v2.npz, x_192x256: YOLO11x, class
+    logits at cls_gain = 1): the score band of the e4m3 mode is stated here from the HIP measurement, against reference-made numbers
+    -- not against this repo's emulation.  The bf16 program on the same vector is inside SURVEY 8(d)'s 0.02
+    (tests/test_gpu_net.py::test_pre_nms_at_realistic_logit_scale_vs_reference_goldens_v2)."""
+    import numpy as np
+    from pathlib import Path
+    from yololite_amd.nn import arch
+    from yololite_amd.nn.engine import HipEngine
+    from yololite_amd.nn.synth import synth_state_dict
+
+    G = np.load(Path(__file__).resolve().parent / "golden" / "golden_gain1_v2.npz")
+    tag, scale = "x_192x256", "x"
+    h, w, seed, sub = (int(v) for v in G[tag + "_meta"])
+    sd = synth_state_dict(scale, seed, cls_bias=list(G[tag + "_bias"]), cls_gain=1.0)
+    x8 = torch.from_numpy(G[tag + "_x8"]).to(gpu_device)
+    ref = torch.from_numpy(G[tag + "_y"])
+    specs, _ = arch.parse_model(arch.yolo11_dict(scale))
+    eng = HipEngine.from_model(specs, sd, 1, h, w, gpu_device, fp8_calib=x8)
+    assert sum("_f8_" in eng.op_kernel(i) for i in range(len(eng.prog.ops))) >= 70
+    y = eng.forward(x8).cpu()
+    d = (y[:, 4:] - ref[:, 4:]).abs()
+    print(f"{tag}: HIP e4m3 vs reference golden: max |dscore| {float(d.max()):.4f}, rms {float(d.pow(2).mean().sqrt()):.5f}")
+    assert float(d.max()) <= FP8_GAIN1_SCORE_ATOL, float(d.max())

@@ -824,3 +824,38 @@ def test_dfl_epilogue_program_forms(gpu_device, scale, h, w):
     # the kept bf16 logits are the stored-logits program's (same accumulators, same rounding)
     for a, b in zip(keep.raw_levels(), old.raw_levels()):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("tag,scale", [("x_192x256", "x"), ("s_320", "s"), ("n_640", "n")])
+def test_pre_nms_at_realistic_logit_scale_vs_reference_goldens_v2(gpu_device, tag, scale):
+    """SURVEY 8(d)'s pre-NMS score tolerance -- |dscore| <= 0.02 -- against the REFERENCE's own outputs on the other configurations'
+    models and sizes (tests/golden/golden_gain1_v2.npz, made by importing the reference: YOLO11x with its six-head, two-block C2PSA
+    on 48 tokens, YOLO11s at 320 x 320, YOLO11n at config 2's 640 x 640; synthetic head at cls_gain = 1, i.e. class logits of std
+    0.2-0.7 as a trained head has them).  Boxes: absolute pixels, printed per level; the bound is the bf16 STORAGE of the
+    activations upstream of the head (tools/box_error_attribution.py: an fp32 box branch on bf16 features keeps the same error),
+    not the decode, which runs on fp32 accumulators."""
+    import numpy as np
+    from pathlib import Path
+
+    G = np.load(Path(__file__).resolve().parent / "golden" / "golden_gain1_v2.npz")
+    h, w, seed, sub = (int(v) for v in G[tag + "_meta"])
+    sd = synth_state_dict(scale, seed, cls_bias=list(G[tag + "_bias"]), cls_gain=1.0)
+    x8 = torch.from_numpy(G[tag + "_x8"]).to(gpu_device)
+    ref = torch.from_numpy(G[tag + "_y"])
+    eng = _engine(scale, sd, 1, h, w, gpu_device)
+    y = eng.forward(x8).cpu()[:, :, ::sub]
+    st = _stride_per_anchor(h, w)[::sub]
+    dscore = float((y[:, 4:] - ref[:, 4:]).abs().max())
+    dpx = (y[:, :4] - ref[:, :4]).abs()
+    per_level = [round(float(dpx[:, :, st == s].max()), 3) for s in (8.0, 16.0, 32.0)]
+    print(f"{tag}: HIP bf16 vs reference golden: max |dscore| {dscore:.4f}; max box error per level {per_level} px "
+          f"= {float((dpx / st).max()):.3f} strides")
+    assert dscore <= 0.02, dscore
+    # boxes: the yardstick is what the bf16 STORAGE FORMAT costs on this very vector (the oracle's bf16-storage mode: fp32 arithmetic
+    # on the CPU, tensors rounded where the HIP path stores bf16, fp32 DFL logits like the product) -- 2.5-3.8 px on these
+    # random-init networks, a property of bf16 activations upstream of the head
+    with torch.inference_mode():
+        y16, _ = oracle.forward(sd, x8.float().cpu() / 255.0, scale, storage="bf16")
+    fpx = (y16[:, :, ::sub][:, :4] - ref[:, :4]).abs()
+    print(f"{tag}: bf16-storage emulation vs reference golden: max box error {float(fpx.max()):.3f} px = {float((fpx / st).max()):.3f} strides")
+    assert float((dpx / st).max()) <= FMT_RATIO * float((fpx / st).max()) + 0.02, (float((dpx / st).max()), float((fpx / st).max()))

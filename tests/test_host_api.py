@@ -322,3 +322,34 @@ def test_image_file_loader_walks_files_dirs_globs_and_lists(tmp_path):
     (tmp_path / "bad.png").write_bytes(b"not an image")
     with pytest.raises(FileNotFoundError):
         list(LoadImagesAndVideos(str(tmp_path / "bad.png")))
+
+
+def test_comm_id_file_ignores_another_jobs_id(tmp_path):
+    """NativeComm.id_via_file: a file left behind by an earlier job (or written by another job's faster rank 0) carries another job
+    token and is never taken for this job's id; this job's id is found once its rank 0 has written it; rank 0 removes the file."""
+    import threading
+    import time
+
+    from yololite_amd.dist import NativeComm
+
+    path = str(tmp_path / "id")
+    stale = NativeComm.id_via_file(path, token="job-A")
+    assert stale(b"A" * 128) == b"A" * 128            # an earlier job's rank 0 wrote its id and never cleaned up
+    reader = NativeComm.id_via_file(path, token="job-B", timeout_s=0.3)
+    with pytest.raises(TimeoutError):
+        reader(None)                                   # the stale id is NOT returned
+    reader = NativeComm.id_via_file(path, token="job-B", timeout_s=10.0)
+    got = []
+    t = threading.Thread(target=lambda: got.append(reader(None)))
+    t.start()
+    time.sleep(0.2)
+    writer = NativeComm.id_via_file(path, token="job-B")
+    writer(b"B" * 128)
+    t.join(10)
+    assert got == [b"B" * 128]
+    writer.done(1)
+    assert (tmp_path / "id").exists()                  # only rank 0 removes it
+    writer.done(0)
+    assert not (tmp_path / "id").exists()
+    with pytest.raises(ValueError):
+        NativeComm.id_via_file(path, token="")

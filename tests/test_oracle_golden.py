@@ -176,3 +176,38 @@ def test_realistic_logit_scale_golden_and_format_error():
     dbox = float(((y16[:, :4] - ref[:, :4]).abs() / st).max())
     print("cls_gain 1: bf16-storage format error vs reference golden: score", dscore, "box (strides)", dbox)
     assert dscore < 0.01 and dbox < 0.35
+
+
+GAIN1_V2_CASES = (("x_192x256", "x"), ("s_320", "s"), ("n_640", "n"))
+
+
+def _gain1_v2():
+    import numpy as np
+    from pathlib import Path
+
+    return np.load(Path(__file__).resolve().parent / "golden" / "golden_gain1_v2.npz")
+
+
+@pytest.mark.parametrize("tag,scale", GAIN1_V2_CASES)
+def test_gain1_v2_goldens_pin_the_oracle_and_the_format_error(tag, scale):
+    """tests/golden/golden_gain1_v2.npz (made by importing the reference, make_golden_gain1_v2.py): YOLO11x at 192 x 256 (its C2PSA
+    with 48 tokens, two PSABlocks, six heads), YOLO11s at 320 x 320 and YOLO11n at 640 x 640, synthetic head at cls_gain = 1.  The
+    fp32 oracle reproduces the reference's pre-NMS tensor; the bf16 STORAGE FORMAT (CPU emulation, no kernel) costs < 0.01 in
+    score on every one of them; the e4m3 emulation of the dense 3x3 convs is printed beside it (the GPU tests state the HIP bands)."""
+    from yololite_amd.nn.synth import synth_state_dict
+
+    G = _gain1_v2()
+    h, w, seed, sub = (int(v) for v in G[tag + "_meta"])
+    sd = synth_state_dict(scale, seed, cls_bias=list(G[tag + "_bias"]), cls_gain=1.0)
+    x = torch.from_numpy(G[tag + "_x8"]).float() / 255.0
+    ref = torch.from_numpy(G[tag + "_y"])
+    with torch.inference_mode():
+        y32, _ = oracle.forward(sd, x, scale)
+        y16, _ = oracle.forward(sd, x, scale, storage="bf16")
+    y32, y16 = y32[:, :, ::sub], y16[:, :, ::sub]
+    assert y32.shape == ref.shape
+    assert torch.allclose(y32, ref, rtol=1e-4, atol=2e-4), float((y32 - ref).abs().max())
+    dscore = float((y16[:, 4:] - ref[:, 4:]).abs().max())
+    dbox = float((y16[:, :4] - ref[:, :4]).abs().max())
+    print(f"{tag}: bf16-storage format error vs the reference golden: score {dscore:.4f}, boxes {dbox:.3f} px")
+    assert dscore < 0.01, dscore

@@ -132,6 +132,9 @@ class NativeComm:
             _lib.check(self._L.yl_comm_create(C.create_string_buffer(bytes(ident), _lib.COMM_ID_BYTES), self.rank, self.world,
                                               C.byref(h)), "yl_comm_create")
         self._h = h
+        if hasattr(exchange, "done"):  # (id_via_file: every rank holds a communicator now -- ncclCommInitRank is collective)
+            self.barrier()
+            exchange.done(self.rank)
 
     @staticmethod
     def id_via_torch(group=None, src: int = 0) -> Callable[[Optional[bytes]], bytes]:
@@ -143,25 +146,48 @@ class NativeComm:
         return exchange
 
     @staticmethod
-    def id_via_file(path: str, timeout_s: float = 120.0) -> Callable[[Optional[bytes]], bytes]:
+    def id_via_file(path: str, token: str, timeout_s: float = 120.0) -> Callable[[Optional[bytes]], bytes]:
+        """Rank 0 writes ``token`` + its id to ``path``; the others wait for a file that starts with THEIR ``token`` -- a value every
+        rank of ONE job shares and no other job does (the launcher's MASTER_PORT + start time, a scheduler's job id).  A file left
+        behind by an earlier job, or written by a faster rank 0 of another one, carries another token and is never taken for this
+        job's id (a stale id made ncclCommInitRank hang or mismatch without a diagnostic).  ``NativeComm`` removes the file on
+        rank 0 once every rank has created its communicator (``exchange.done``)."""
+        import os
+
+        tok = token.encode()
+        if not tok or b"\n" in tok:
+            raise ValueError("the job token must be a non-empty single line")
+
         def exchange(ident):
-            import os
             import time
 
             if ident is not None:
                 tmp = f"{path}.tmp{os.getpid()}"
                 with open(tmp, "wb") as f:
-                    f.write(ident)
+                    f.write(tok + b"\n" + ident)
                 os.replace(tmp, path)  # readers never see a partial id
                 return ident
             t0 = time.monotonic()
-            while not os.path.exists(path):
+            while True:
+                try:
+                    with open(path, "rb") as f:
+                        blob = f.read()
+                    if blob.startswith(tok + b"\n"):
+                        return blob[len(tok) + 1:]
+                except FileNotFoundError:
+                    pass
                 if time.monotonic() - t0 > timeout_s:
-                    raise TimeoutError(f"no communicator id at {path} after {timeout_s} s")
+                    raise TimeoutError(f"no communicator id for job token {token!r} at {path} after {timeout_s} s")
                 time.sleep(0.01)
-            with open(path, "rb") as f:
-                return f.read()
 
+        def done(rank):
+            if rank == 0:
+                try:
+                    os.unlink(path)
+                except FileNotFoundError:
+                    pass
+
+        exchange.done = done
         return exchange
 
     def _stream(self, stream) -> int:
@@ -216,16 +242,34 @@ class NativeComm:
 class NativeShardedRunner:
     """``ShardedRunner``'s schedule on the ``yl_comm_*`` transport: the same lanes (``depth`` input buffers and records per
     slot, so a lane's exchanges are two of its slot's steps away from the compute that needs them), but scatter and gather
-    are enqueued by libyl_amd.so on HIP streams of their own -- ONE exchange stream per direction, ordered against the slot
-    streams with events -- instead of torch.distributed's internal stream.  Records land in ONE (world, words) tensor per
-    lane on the root.  Same contract as ``ShardedRunner.run``."""
+    are enqueued by libyl_amd.so on HIP streams of their own, ordered against the slot streams with events, instead of
+    torch.distributed's internal stream.  Records land in ONE (world, words) tensor per lane on the root.  Same contract as
+    ``ShardedRunner.run``.
+
+    RCCL runs the operations of ONE communicator in the order the host issued them, whatever stream they name: with a single
+    communicator, scatter(k + V) queues behind gather(k), which waits for compute k -- two exchange streams on one communicator
+    overlap nothing, and the result depends on every rank issuing the same interleaving (round-5 advisor).  So: ``comm_gather``,
+    a SECOND communicator, carries the gathers on a stream of its own and the two directions really are independent; without it
+    both directions share ONE exchange stream and run in issue order, which this schedule makes identical on every rank.
+
+    ``root_in_place`` (default): the root computes on ITS slice of the global batch where it lies (``yl_comm_scatter`` with
+    ``recv`` = that slice copies nothing) instead of a device-to-device copy of 39 MB per step into the lane buffer; the input
+    address of a root lane then cycles through ``len(batches)`` values, each its own captured graph.
+
+    NOT YET RUN ON MORE THAN ONE GPU (no multi-GPU box was available to this build: tests/test_gpu_dist.py holds a two-process
+    test that is skipped below two devices); ``ShardedRunner`` on torch.distributed is the default transport of bench.py."""
 
     def __init__(self, comm: NativeComm, compute: Callable[[torch.Tensor, int, int], torch.Tensor], per_rank: int,
                  shape: Tuple[int, int, int], dtype: torch.dtype, device: torch.device, record_words: int,
-                 slots: int = 2, src: int = 0, streams: Optional[Sequence] = None, depth: int = 2):
+                 slots: int = 2, src: int = 0, streams: Optional[Sequence] = None, depth: int = 2,
+                 comm_gather: Optional[NativeComm] = None, root_in_place: bool = True):
         if streams is None or len(streams) != slots:
             raise ValueError("one HIP stream per slot")
+        if comm_gather is not None and (comm_gather.rank, comm_gather.world) != (comm.rank, comm.world):
+            raise ValueError("the gather communicator must span the same ranks")
         self.comm, self.compute, self.src = comm, compute, src
+        self.comm_g = comm_gather if comm_gather is not None else comm
+        self.per_rank, self.root_in_place = per_rank, bool(root_in_place)
         self.slots, self.lanes = slots, depth * slots
         self.streams = list(streams)
         self.rank, self.world = comm.rank, comm.world
@@ -234,7 +278,8 @@ class NativeShardedRunner:
         self.gathered = [torch.empty((self.world, record_words), dtype=torch.float32, device=device)
                          if self.rank == src else None for _ in range(self.lanes)]
         self.s_scatter = torch.cuda.Stream(device=device)
-        self.s_gather = torch.cuda.Stream(device=device)
+        # (one communicator = one exchange stream for both directions, see the class docstring)
+        self.s_gather = torch.cuda.Stream(device=device) if comm_gather is not None else self.s_scatter
 
     def run(self, batches: List[Optional[torch.Tensor]], steps: int) -> Optional[List[torch.Tensor]]:
         nb, S, V = len(batches), self.slots, self.lanes
@@ -245,11 +290,18 @@ class NativeShardedRunner:
         for st in self.streams:  # an earlier run's readers of the lane buffers
             self.s_scatter.wait_stream(st)
 
+        inputs = [None] * V   # what step k's compute reads: the lane buffer, or (root, in place) its slice of the global batch
+
         def scatter(k: int):
             v = k % V
             if read[v] is not None:
                 self.s_scatter.wait_event(read[v])  # the buffer's last reader
-            self.comm.scatter(batches[k % nb], self.bufs[v], self.src, stream=self.s_scatter)
+            gb = batches[k % nb]
+            if self.root_in_place and self.rank == self.src:
+                inputs[v] = gb[self.src * self.per_rank: (self.src + 1) * self.per_rank]  # (recv == the root's own slice: no copy)
+            else:
+                inputs[v] = self.bufs[v]
+            self.comm.scatter(gb, inputs[v], self.src, stream=self.s_scatter)
             landed[v] = self.s_scatter.record_event()
 
         for k in range(min(V, steps)):
@@ -262,10 +314,10 @@ class NativeShardedRunner:
             if sent[v] is not None:  # the gather of step k - V still reads the record this step overwrites
                 st.wait_event(sent[v])
             with torch.cuda.stream(st):
-                recs[v] = self.compute(self.bufs[v], j, v)
+                recs[v] = self.compute(inputs[v], j, v)
             read[v] = st.record_event()
             self.s_gather.wait_event(read[v])
-            self.comm.gather(recs[v], self.gathered[v], self.src, stream=self.s_gather)
+            self.comm_g.gather(recs[v], self.gathered[v], self.src, stream=self.s_gather)
             sent[v] = self.s_gather.record_event()
             if k + V < steps:
                 scatter(k + V)

@@ -116,7 +116,8 @@ def synth_images(batch: int, h: int, w: int, seed: int = 0) -> torch.Tensor:
 
 
 def plant_object_head(sd: Dict[str, torch.Tensor], feats: Sequence[torch.Tensor], per_image: int = 96, alpha: float = 12.0,
-                      margin: float = 3.0, ridge: float = 0.05, seed: int = 0, det_index: int = 23) -> Dict[str, torch.Tensor]:
+                      margin: float = 3.0, ridge: float = 0.05, ridge_samples: float = 0.25, seed: int = 0,
+                      det_index: int = 23) -> Dict[str, torch.Tensor]:
     """A synthetic class head with OBJECTS in it: a copy of ``sd`` whose last class convs (``model.<det>.cv3.<l>.2``, reference
     head.py:47 ``nn.Conv2d(c3, nc, 1)``) are matched filters for ~``per_image`` planted anchors per image.
 
@@ -124,7 +125,7 @@ def plant_object_head(sd: Dict[str, torch.Tensor], feats: Sequence[torch.Tensor]
     features of a fixed synthetic batch).  Planted anchors are drawn per image and level (in proportion to the level's anchors, at
     least two pixels apart) and dealt to the classes round-robin.  Random-init features of noise images are strongly correlated
     from anchor to anchor (a few dominant directions), so the filters are WHITENED matched filters: with mu, S = mean and
-    covariance of the level's features over all anchors and R = S + ridge^2 * mean(diag S) * I,
+    covariance of the level's features over all anchors and R = S + r^2 * mean(diag S) * I, r = max(ridge, ridge_samples * sqrt(c3 / anchors)),
         w_c = alpha * sum_k R^-1 d_k / (d_k^T R^-1 d_k),  d_k = p_k - mu,      b_c = margin - alpha - w_c . mu
     A planted anchor answers with logit ~``margin`` (score 0.95 for 3), an unrelated anchor with ``margin - alpha`` plus cross-talk
     of std ~alpha * sqrt(prototypes per class / c3): the per-anchor best score is BIMODAL, as a trained detector's is.  With the
@@ -146,7 +147,10 @@ def plant_object_head(sd: Dict[str, torch.Tensor], feats: Sequence[torch.Tensor]
         mu = flat.mean(1)
         dev = flat - mu[:, None]
         S = dev @ dev.T / max(1, dev.shape[1] - 1)
-        R = S + (ridge ** 2) * S.diagonal().mean() * torch.eye(c3, dtype=torch.float64)
+        # (a level with few anchors per feature dimension -- P5 of a small batch -- gets a stronger ridge: its sample covariance
+        # is poorly conditioned and the filter would amplify the format's rounding noise along directions it merely under-sampled)
+        rl = max(ridge, ridge_samples * math.sqrt(c3 / max(1, dev.shape[1])))
+        R = S + (rl ** 2) * S.diagonal().mean() * torch.eye(c3, dtype=torch.float64)
         Rinv = torch.linalg.inv(R)
         n_l = max(1, int(round(per_image * H * W / A)))
         ys, xs = torch.meshgrid(torch.arange(H), torch.arange(W), indexing="ij")
