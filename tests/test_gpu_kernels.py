@@ -472,45 +472,6 @@ def test_attention_vs_torch(gpu_device, nh, h, w):
     assert not (err > tol).any(), f"attention: max err {float(err.max()):.4g}, worst ratio {float((err / tol).max()):.2f}"
 
 
-TILE_CASES = [
-    # Cin, Cout, H, W, act, res, NT     conv3_tile_kernel (input tile in LDS), forced onto small maps
-    (64, 64, 20, 20, True, True, 4),
-    (64, 64, 20, 20, True, False, 1),
-    (64, 64, 7, 9, True, False, 2),
-    (32, 32, 40, 40, True, True, 4),
-    (64, 32, 13, 17, True, False, 2),
-    (32, 64, 24, 40, False, False, 4),
-    (64, 64, 80, 80, True, False, 4),
-]
-
-
-@pytest.mark.parametrize("cin,cout,h,w,act,res,nt", TILE_CASES)
-def test_conv3_tile_vs_torch_and_direct(gpu_device, monkeypatch, cin, cout, h, w, act, res, nt):
-    """The LDS-tile 3x3 kernel against torch, and against the direct kernel (the k order differs, so the two
-    agree to one bf16 ulp, not bit for bit)."""
-    g = torch.Generator().manual_seed(cin * 100 + cout + h + nt)
-    B = 3
-    x = _rand(g, B, cin, h, w)
-    wt = _rand(g, cout, cin, 3, 3, scale=1.0 / math.sqrt(cin * 9))
-    b = torch.randn(cout, generator=g) * 0.5
-    ref = F.conv2d(x, wt, b, 1, 1)
-    if act:
-        ref = F.silu(ref)
-    r = None
-    if res:
-        r = _rand(g, *ref.shape)
-        ref = ref + r
-    monkeypatch.setenv("YL_CONV_TILE", "1")
-    monkeypatch.setenv("YL_CONV_TILE_MIN", "1")
-    monkeypatch.setenv("YL_CONV_TILE_NT", str(nt))
-    got = run_conv(gpu_device, x, wt, b, 3, 1, act, r, expect_kernel="conv3x3_tile_mfma")
-    _assert_close_bf16(got, ref, f"tile conv {cin}->{cout} NT={nt}")
-    monkeypatch.setenv("YL_CONV_TILE", "0")
-    direct = run_conv(gpu_device, x, wt, b, 3, 1, act, r, expect_kernel="conv3x3_mfma")
-    # both are within half a bf16 ulp of the exact sum, so they differ by at most one ulp (2^-7 relative)
-    assert ((got - direct).abs() <= 2.0 ** -7 * direct.abs().clamp(min=1e-2) + 1e-3).all(), "tile vs direct kernel"
-
-
 REG_CASES = [
     # Cin, Cout, H, W, act, res, NT     conv3_reg_kernel (filter in registers, input tile in LDS), forced onto small maps
     (64, 64, 20, 20, True, True, 4),
@@ -524,9 +485,8 @@ REG_CASES = [
 ]
 
 
-@pytest.mark.parametrize("pipe", [0, 1])
 @pytest.mark.parametrize("cin,cout,h,w,act,res,nt", REG_CASES)
-def test_conv3_reg_vs_torch_and_direct(gpu_device, monkeypatch, cin, cout, h, w, act, res, nt, pipe):
+def test_conv3_reg_vs_torch_and_direct(gpu_device, monkeypatch, cin, cout, h, w, act, res, nt):
     """The filter-in-registers 3x3 kernel against torch, and against the direct kernel: same k order, same MFMA
     accumulation chain starting from the bias -> bit-identical."""
     g = torch.Generator().manual_seed(cin * 100 + cout + h + nt + 7)
@@ -544,7 +504,6 @@ def test_conv3_reg_vs_torch_and_direct(gpu_device, monkeypatch, cin, cout, h, w,
     monkeypatch.setenv("YL_CONV_REG", "1")
     monkeypatch.setenv("YL_CONV_REG_MIN", "1")
     monkeypatch.setenv("YL_CONV_REG_NT", str(nt))
-    monkeypatch.setenv("YL_CONV_REG_PIPE", str(pipe))  # 1: the previous tile's epilogue interleaved with the MFMAs
     got = run_conv(gpu_device, x, wt, b, 3, 1, act, r, expect_kernel="conv3x3_reg_mfma")
     _assert_close_bf16(got, ref, f"reg conv {cin}->{cout} NT={nt}")
     monkeypatch.setenv("YL_CONV_REG", "0")
@@ -602,84 +561,6 @@ def test_conv3_cs_vs_torch_and_direct(gpu_device, monkeypatch, h, w, act, res, B
     assert torch.equal(got, direct), f"cs vs direct kernel: max diff {float((got - direct).abs().max())}"
 
 
-SW_CASES = [
-    # H, W, act, res     conv3_sw_kernel (64 -> 64: a wave walks down a 16-pixel strip, fragments of three rows as a rolling window)
-    (80, 80, True, False),        # the layer it is for (Detect box branch, level 0): 5 strips x 8 band pairs per image
-    (10, 16, True, False),        # one tile per image
-    (20, 48, False, False),       # no activation
-    (160, 32, True, False),       # tall and narrow
-    (40, 64, True, True),         # a residual: stays on the linear-tile kernel (conv3_cs), same bits
-]
-
-
-@pytest.mark.parametrize("h,w,act,res", SW_CASES)
-def test_conv3_sw_vs_torch_and_direct(gpu_device, monkeypatch, h, w, act, res):
-    """The strip-walk kernel (csrc/conv3_sw.hip: output channels split between wave pairs like conv3_cs, the activation fragments
-    of three rows reused while a wave walks down its strip, double-buffered LDS-DMA staging with per-lane source addresses)
-    against torch, and against conv_kernel: same operands, k order and accumulation chain -> bit-identical.  Batch 7 with an
-    odd tile count exercises the persistent loop's last, partly filled round."""
-    g = torch.Generator().manual_seed(9100 + h + w)
-    B = 7
-    x = _rand(g, B, 64, h, w)
-    wt = _rand(g, 64, 64, 3, 3, scale=1.0 / math.sqrt(64 * 9))
-    b = torch.randn(64, generator=g) * 0.5
-    ref = F.conv2d(x, wt, b, 1, 1)
-    if act:
-        ref = F.silu(ref)
-    r = None
-    if res:
-        r = _rand(g, *ref.shape)
-        ref = ref + r
-    monkeypatch.setenv("YL_CONV_SW", "1")
-    monkeypatch.setenv("YL_CONV_SW_MIN", "1")
-    monkeypatch.setenv("YL_CONV_CS_MIN", "1")
-    got = run_conv(gpu_device, x, wt, b, 3, 1, act, r, expect_kernel="conv3x3_sw_mfma")
-    _assert_close_bf16(got, ref, f"sw conv {h}x{w}")
-    monkeypatch.setenv("YL_CONV_SW", "0")
-    monkeypatch.setenv("YL_CONV_CS", "0")
-    monkeypatch.setenv("YL_CONV_REG", "0")
-    direct = run_conv(gpu_device, x, wt, b, 3, 1, act, r, expect_kernel="conv3x3_mfma")
-    assert torch.equal(got, direct), f"sw vs direct kernel: max diff {float((got - direct).abs().max())}"
-
-
-PAIR_CASES = [
-    # H, W, act, res     conv3_pair_kernel (64 -> 64: filter halves in the registers of two waves per SIMD), forced onto small maps
-    (20, 20, True, False),
-    (20, 20, True, True),
-    (7, 9, True, False),
-    (80, 80, True, False),
-    (33, 90, False, False),    # wide rows (the LDS budget ends at W = 90)
-    (40, 40, True, True),
-]
-
-
-@pytest.mark.parametrize("h,w,act,res", PAIR_CASES)
-def test_conv3_pair_vs_torch_and_direct(gpu_device, monkeypatch, h, w, act, res):
-    """The K-split two-waves-per-SIMD 3x3 kernel against torch, and against the direct kernel: the accumulation is
-    (bias + k-steps 0..8) + (k-steps 9..17) instead of one chain, so the two agree to one bf16 ulp, not bit for bit."""
-    g = torch.Generator().manual_seed(h * 100 + w + 13)
-    B = 3
-    x = _rand(g, B, 64, h, w)
-    wt = _rand(g, 64, 64, 3, 3, scale=1.0 / math.sqrt(64 * 9))
-    b = torch.randn(64, generator=g) * 0.5
-    ref = F.conv2d(x, wt, b, 1, 1)
-    if act:
-        ref = F.silu(ref)
-    r = None
-    if res:
-        r = _rand(g, *ref.shape)
-        ref = ref + r
-    monkeypatch.setenv("YL_CONV_PAIR", "1")
-    monkeypatch.setenv("YL_CONV_PAIR_MIN", "1")
-    got = run_conv(gpu_device, x, wt, b, 3, 1, act, r, expect_kernel="conv3x3_pair_mfma")
-    _assert_close_bf16(got, ref, f"pair conv {h}x{w}")
-    monkeypatch.setenv("YL_CONV_PAIR", "0")
-    monkeypatch.setenv("YL_CONV_REG", "0")
-    direct = run_conv(gpu_device, x, wt, b, 3, 1, act, r, expect_kernel="conv3x3_mfma")
-    assert ((got - direct).abs() <= 2.0 ** -7 * direct.abs().clamp(min=1e-2) + 1e-3).all(), "pair vs direct kernel"
-    assert float((got != direct).float().mean()) < 0.02, "only a few elements may differ by that ulp"
-
-
 def test_view_above_one_gib_fails_loudly(gpu_device):
     """Maximum sizes: buffer offsets are 32 bits with out-of-range sentinels, so a tensor slice above 1 GiB must be
     refused with an error (never wrapped around or silently truncated)."""
@@ -723,39 +604,3 @@ def test_conv3_band_vs_conv_kernel(gpu_device, monkeypatch, B, H, W):
         ref = F.silu(F.conv2d(x, wt, b, padding=1))
         assert float((y - ref).abs().max()) <= 0.02 * float(ref.abs().max()) + 0.02
 
-
-@pytest.mark.parametrize("B,H,W", [(2, 80, 80), (1, 48, 80), (2, 64, 104)])
-def test_conv3_band64_with_follow_up_vs_conv_kernel(gpu_device, monkeypatch, B, H, W):
-    """conv3_band64_kernel (opt-in, YL_CONV_BAND64=1): the three Detect levels' 64 -> 64 3x3 convs with the 1x1 conv 64 -> 64
-    behind each fused into the launch (head.py:36-40 cv2[i][1], cv2[i][2]) against conv_kernel's form of the same group: every
-    bit; and against torch."""
-    monkeypatch.setenv("YL_CONV_BAND64", "1")
-    gen = torch.Generator().manual_seed(H * 7 + W)
-    dims = [(H, W), (H // 2, W // 2), (H // 4, W // 4)]
-    xs = [bf16_round(torch.randn(B, 64, h, w, generator=gen)) for h, w in dims]
-    w1 = [bf16_round(torch.randn(64, 64, 3, 3, generator=gen) / 24 * 1.5) for _ in dims]
-    b1 = [torch.randn(64, generator=gen) * 0.3 for _ in dims]
-    w2 = [bf16_round(torch.randn(64, 64, 1, 1, generator=gen) / 8) for _ in dims]
-    b2 = [torch.randn(64, generator=gen) * 0.3 for _ in dims]
-    got = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("YL_CONV_BAND", mode)
-        m = Mini(B, gpu_device)
-        outs = []
-        for (h, w), x, wa, ba, wb, bb in zip(dims, xs, w1, b1, w2, b2):
-            xin, y = m.buf(h, w, 64), m.buf(h, w, 64)
-            m.fill(xin, x)
-            m.op(kind=OP_CONV, name=f"l{h}", k=3, stride=1, act=1, inp=xin, out=y, group=2, weight=np.ascontiguousarray(wa.numpy()),
-                 bias=np.ascontiguousarray(ba.numpy()), post_weight=np.ascontiguousarray(wb.numpy().reshape(64, 64)),
-                 post_bias=np.ascontiguousarray(bb.numpy()), post_act=0)
-            outs.append(y)
-        m.run()
-        kern = m.eng.op_kernel(0)
-        assert kern == ("conv3x3+1x1_band_mfma[x3]" if mode == "1" else "conv3x3+1x1_mfma[x3]"), kern
-        got[mode] = [m.read(y) for y in outs]
-    for a, b in zip(got["1"], got["0"]):
-        assert torch.equal(a, b), float((a - b).abs().max())
-    for y, x, wa, ba, wb, bb in zip(got["1"], xs, w1, b1, w2, b2):
-        mid = bf16_round(F.silu(F.conv2d(x, wa, ba, padding=1)))
-        ref = F.conv2d(mid, wb, bb)
-        assert float((y - ref).abs().max()) <= 0.02 * float(ref.abs().max()) + 0.03

@@ -278,7 +278,7 @@ static int c3k2s_launch_t(const C3k2sArgs& a, hipStream_t s) {
 
 int c3k2s_launch(const C3k2sArgs& a0, hipStream_t s) {
   C3k2sArgs a = a0;
-  a.st_nt = (a.cacheable || (getenv("YL_ST_NT_FUSED") && !atoi(getenv("YL_ST_NT_FUSED")))) ? 0 : st_nt_policy(a.out_bytes);
+  a.st_nt = (a.cacheable || !tune_int("YL_ST_NT_FUSED", 1)) ? 0 : st_nt_policy(a.out_bytes);
   a.tiles_x = (a.W + C3_TC - 1) / C3_TC;
   a.tiles_y = (a.H + C3_TR - 1) / C3_TR;
   switch (a.c * 1000 + a.cout) {

@@ -250,26 +250,6 @@ __global__ __launch_bounds__(BD_THREADS) void conv3_band_kernel(BandGroup G) {
   else band_body<KB, NB>(G.m[1], block - G.nb0);
 }
 
-// Up to three 64 -> 64 convs (the Detect levels' copies of cv2[i][1] + cv2[i][2]) in one launch
-struct BandGroup3 {
-  BandArgs m[3];
-  int nb[3];
-};
-
-template <bool POST>
-__global__ __launch_bounds__(BD_THREADS) void conv3_band64_kernel(BandGroup3 G) {
-  int block = blockIdx.x, mi = 0;
-  if (block >= G.nb[0]) {
-    block -= G.nb[0];
-    mi = 1;
-    if (block >= G.nb[1]) {
-      block -= G.nb[1];
-      mi = 2;
-    }
-  }
-  band_body<2, 0, POST>(G.m[mi], block);
-}
-
 // Tiling of one member: the largest band (rows) whose pixel tiles fit NTQ <= 5 per wave quarter and whose input fits the LDS budget
 bool conv3_band_plan(int Cin, int Cout, int H, int W, BandArgs* a, bool post) {
   if (Cout != 64 || (Cin != 64 && Cin != 128 && Cin != 256)) return false;
@@ -336,37 +316,6 @@ int conv3_band_launch(const BandArgs* args, int n, int batch, hipStream_t s) {
 #undef YL_BAND_ROW
 #undef YL_BAND_CASE
   return fail(-3, "conv3_band: unsupported member tiling");
-}
-
-// one to three 64 -> 64 convs, each with (post != 0: all of them) or without a fused follow-up 1x1 conv 64 -> 64
-int conv3_band64_launch(const BandArgs* args, int n, int batch, int post, hipStream_t s) {
-  if (n < 1 || n > 3) return fail(-1, "conv3_band64: one to three members");
-  BandGroup3 G{};
-  size_t lds = 0;
-  int grid = 0;
-  for (int i = 0; i < n; ++i) {
-    G.m[i] = args[i];
-    G.m[i].stamps = g_stamp_buf;
-    G.m[i].st_nt = st_nt_policy(args[i].y_bytes);
-    if (args[i].Cin != 64 || !conv3_band_plan(64, 64, args[i].H, args[i].W, &G.m[i], post != 0))
-      return fail(-3, "conv3_band64: member does not fit the band tiling");
-    if (post && (!args[i].w2 || !args[i].bias2)) return fail(-1, "conv3_band64: follow-up filter missing");
-    const size_t l = (size_t)8 * G.m[i].tpl + (size_t)BD_NS * BD_SLICE + (post ? (size_t)8 * G.m[i].ntiles * 256 : 0);
-    lds = l > lds ? l : lds;
-    G.nb[i] = batch * G.m[i].nbands;
-    grid += G.nb[i];
-  }
-  if (post) {
-    auto kern = conv3_band64_kernel<true>;
-    if (int rc = allow_big_lds(reinterpret_cast<const void*>(kern), 160 * 1024)) return rc;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BD_THREADS), lds, s, G);
-  } else {
-    auto kern = conv3_band64_kernel<false>;
-    if (int rc = allow_big_lds(reinterpret_cast<const void*>(kern), 160 * 1024)) return rc;
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BD_THREADS), lds, s, G);
-  }
-  YL_HIP(hipGetLastError());
-  return 0;
 }
 
 }  // namespace yl

@@ -590,16 +590,16 @@ static unsigned cs_magic(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ul
 // sets cfg->cs for 64 -> 64 3x3 stride-1 convs with enough tiles for two persistent workgroups per CU
 void conv3_cs_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, int post, ConvConfig* c) {
   c->cs = 0;
-  const int enable = getenv("YL_CONV_CS") ? atoi(getenv("YL_CONV_CS")) : 1;
+  const int enable = env_int("YL_CONV_CS", 1);
   // (512 tiles = one per resident workgroup: YOLO11s's 64 -> 64 Bottleneck convs @40x40 batch 64 have 840, +0.5-1.1 % end to end
   // against conv3_reg_kernel; YOLO11n batch 32 has none between 512 and 1024)
-  const int min_tiles = getenv("YL_CONV_CS_MIN") ? atoi(getenv("YL_CONV_CS_MIN")) : 512;
+  const int min_tiles = env_int("YL_CONV_CS_MIN", 512);
   if (!enable || k != 3 || stride != 1 || post || Cin != 64 || Cout != 64 || c->ncb != 1 || c->MT != 4) return;
   const long long img = (long long)(Ho + 1) * (Wo + 1), nq = (long long)batch * img;
   if (nq * img >= (1LL << 32) || img * (Wo + 1) >= (1LL << 32)) return;  // exactness of the magic divisions
   if ((nq + CS_L - 1) / CS_L < min_tiles || (size_t)8 * cs_PL(Wo) * 16 > 80 * 1024) return;
   c->cs = 1;
-  c->reg = c->tile = c->pair = 0;
+  c->reg = 0;
   c->name = "conv3x3_cs_mfma";
 }
 
@@ -657,11 +657,11 @@ int conv3_cs_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s)
   a.in_bytes = (unsigned)inb;
   a.out_bytes = (unsigned)outb;
   a.res_bytes = (unsigned)resb;
-  a.dbg = getenv("YL_CONV_DBG") ? atoi(getenv("YL_CONV_DBG")) : 0;
+  a.dbg = tune_int("YL_CONV_DBG", 0);
   const int resident = 2 * device_cu_count();  // two persistent workgroups per CU
   {
     // one eight-wave workgroup per CU, the filter through LDS, the run in two halves (conv3_cs3_kernel)
-    const int v3 = getenv("YL_CS_V3") ? atoi(getenv("YL_CS_V3")) : 0;  // (measured: 24.5 us in the network against 23.5 of the tile-walking form)
+    const int v3 = tune_int("YL_CS_V3", 0);  // (measured: 24.5 us in the network against 23.5 of the tile-walking form)
     const int ncu = device_cu_count();
     const long long nq32 = (nq + 31) & ~31LL;
     const int Q = (int)(((nq32 + ncu - 1) / ncu + 63) & ~63LL);
@@ -680,7 +680,7 @@ int conv3_cs_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s)
   }
   {
     // segment form: one contiguous run per workgroup, when run + halo of two workgroups fit a CU's LDS
-    const int v2 = getenv("YL_CS_V2") ? atoi(getenv("YL_CS_V2")) : 0;  // (measured: 25.6 us in the network)
+    const int v2 = tune_int("YL_CS_V2", 0);  // (measured: 25.6 us in the network)
     const long long nq32 = (nq + 31) & ~31LL;
     const int Q = (int)(((nq32 + resident - 1) / resident + 31) & ~31LL);
     const int PL2 = (Q + 2 * a.in_w1 + 2 + 63) & ~63;
@@ -698,7 +698,7 @@ int conv3_cs_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s)
   const size_t lds = (size_t)8 * a.t_PL * 16;
   {
     // tile-walking form with a balanced (short, first) round
-    const int bal = getenv("YL_CS_BAL") ? atoi(getenv("YL_CS_BAL")) : 1;
+    const int bal = tune_int("YL_CS_BAL", 1);
     const long long nq32 = (nq + 31) & ~31LL;
     const long long per_round = (long long)resident * CS_L;
     const long long rounds = nq32 / per_round, rem = nq32 - rounds * per_round;

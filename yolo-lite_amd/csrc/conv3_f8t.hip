@@ -260,14 +260,14 @@ bool conv3_f8t_fits(const ConvConfig& cfg, int batch, int Cin, int Cout, int k, 
   // 96-channel form 1 095-1 105 (-2..-2.7 %, eight-wave and four-wave form alike, although the launch alone is 8-13 % shorter: 38.9 /
   // 36.9 against 42.6 us) -- twenty batches in flight prefer conv_f8_kernel's many short workgroups on these layers; one batch at a
   // time both forms +2.5 %.
-  const int enable = getenv("YL_F8_TILE") ? atoi(getenv("YL_F8_TILE")) : 1;
+  const int enable = env_int("YL_F8_TILE", 1);
   if (!enable || k != 3 || stride != 1 || Cin != Cout || (Cin != 48 && !(Cin == 96 && enable >= 2)) || cfg.MT != 3 || cfg.ncb != Cout / 48 ||
       cfg.cg != Cin / 16)
     return false;
   const long long img = (long long)(Ho + 1) * (Wo + 1), nq = (long long)batch * img;
   const long long rows = (long long)batch * (Ho + 1);
   if ((nq + 512) * (Wo + 1) >= (1LL << 32) || rows * (Ho + 1) >= (1LL << 32) || nq >= (1LL << 30)) return false;  // exactness of the magic divisions
-  const long long min_pos = getenv("YL_F8_TILE_MIN") ? atoll(getenv("YL_F8_TILE_MIN")) : 65536;
+  const long long min_pos = env_int("YL_F8_TILE_MIN", 65536);
   if (nq < min_pos) return false;
   const int CG = Cin / 16;
   return (size_t)CG * f8t_PL(CG == 3 ? f8t_L(3) : f8t_L(6), Wo + 1) * 16 <= 64 * 1024 - 64;  // (16-bit tap offsets)
@@ -314,7 +314,7 @@ int conv3_f8t_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s
   a.magic_img = f8t_magic(a.Ho + 1);  // (rows per image: the kernel divides position -> batch row -> image)
   a.magic_w1 = f8t_magic(a.in_w1);
   if (a.Cin == 48) return f8t_launch_t<3, 1>(a, batch, s);
-  const int wide = getenv("YL_F8_TILE_W8") ? atoi(getenv("YL_F8_TILE_W8")) : 0;  // 1: the eight-wave form (one workgroup per CU)
+  const int wide = env_int("YL_F8_TILE_W8", 0);  // 1: the eight-wave form (one workgroup per CU)
   return wide ? f8t_launch_t<6, 2>(a, batch, s) : f8t_launch_t<6, 1>(a, batch, s);
 }
 

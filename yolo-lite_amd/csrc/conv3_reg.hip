@@ -351,9 +351,9 @@ static int reg_PL(int NT, int W) { return (64 * NT + 2 * (W + 1) + 2 + 63) & ~63
 
 void conv3_reg_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, int post, ConvConfig* c) {
   c->reg = 0;
-  const int enable = getenv("YL_CONV_REG") ? atoi(getenv("YL_CONV_REG")) : 1;
-  const int min_tiles = getenv("YL_CONV_REG_MIN") ? atoi(getenv("YL_CONV_REG_MIN")) : 512;
-  const int want_nt = getenv("YL_CONV_REG_NT") ? atoi(getenv("YL_CONV_REG_NT")) : 4;
+  const int enable = env_int("YL_CONV_REG", 1);
+  const int min_tiles = env_int("YL_CONV_REG_MIN", 512);
+  const int want_nt = env_int("YL_CONV_REG_NT", 4);
   if (!enable || k != 3 || stride != 1 || post) return;
   if ((Cin != 32 && Cin != 64) || (Cout != 32 && Cout != 64) || c->ncb != 1 || Cout != c->MT * 16) return;
   const long long nq = (long long)batch * (Ho + 1) * (Wo + 1);
@@ -375,7 +375,6 @@ void conv3_reg_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, i
   }
   if (best) {
     c->reg = best;
-    c->tile = 0;
     c->name = "conv3x3_reg_mfma";
   }
 }
@@ -394,7 +393,7 @@ static int launch_reg(const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
   // (the interleaved epilogue stream exists for the common case: SiLU, no residual)
   // Opt-in (YL_CONV_REG_PIPE=1): bit-identical and measured EQUAL in time to the plain form on MI355X (64 -> 64 @80x80:
   // 26-30 us either way, box to box): VALU work placed between one wave's own MFMAs did not overlap with them here.
-  const int pipe = getenv("YL_CONV_REG_PIPE") ? atoi(getenv("YL_CONV_REG_PIPE")) : 0;
+  const int pipe = tune_int("YL_CONV_REG_PIPE", 0);
   if (a.res) return launch_reg_r<MT, NT, NPH, true, false>(a, grid, lds, s);
   return (a.act && pipe) ? launch_reg_r<MT, NT, NPH, false, true>(a, grid, lds, s)
                          : launch_reg_r<MT, NT, NPH, false, false>(a, grid, lds, s);
@@ -429,12 +428,12 @@ int conv3_reg_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s
   a.out_bytes = (unsigned)outb;
   a.res_bytes = (unsigned)resb;
   {
-    static const int dbg = getenv("YL_CONV_DBG") ? atoi(getenv("YL_CONV_DBG")) : 0;  // ablation, dev only
+    static const int dbg = tune_int("YL_CONV_DBG", 0);  // ablation, dev only
     a.dbg = dbg;
   }
   const size_t lds = (size_t)2 * cfg.cg * a.t_PL * 16;
   if (lds > LDS_MAX_R) return fail(-3, "conv3_reg: LDS budget exceeded");
-  static const int max_grid = getenv("YL_CONV_REG_GRID") ? atoi(getenv("YL_CONV_REG_GRID")) : NUM_CU_R;
+  static const int max_grid = tune_int("YL_CONV_REG_GRID", NUM_CU_R);
   const int grid = a.t_ntiles < max_grid ? a.t_ntiles : max_grid;
   const int nph = cfg.cg / 4;
   switch (cfg.MT * 100 + NT * 10 + nph) {

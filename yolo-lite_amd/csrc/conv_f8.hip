@@ -299,7 +299,7 @@ int conv_f8_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int 
   // six tiles per wave (96 output channels) instead of four on wide layers: a third fewer re-reads of the activations
   // (YOLO11x 1280x1280: the stride-2 3x3 convs 1.56 -> 1.43 ms).  Not instead of three tiles (the 96-channel Bottleneck convs
   // get slower: 250+ VGPRs with a few spills do not pay on short k-loops).  YL_F8_MT6=0 turns it off.
-  const int mt6 = getenv("YL_F8_MT6") ? atoi(getenv("YL_F8_MT6")) : 1;
+  const int mt6 = tune_int("YL_F8_MT6", 1);
   if (mt6 && MT == 4 && cout16 % 6 == 0 && Cin >= 128) MT = 6;
   const int ntaps = k * k, cg = Cin / 16;
   const int ksteps = (ntaps * cg + 7) / 8;
@@ -308,7 +308,7 @@ int conv_f8_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int 
   if ((size_t)ksteps * step_bytes > slab_max) kchunk = (int)(slab_max / step_bytes) & ~1;  // multiple of the ring depth
   const long long npix = (long long)batch * Ho * Wo;
   const int ncb = cout16 / MT;
-  const int force_nt = getenv("YL_F8_NT") ? atoi(getenv("YL_F8_NT")) : 0;  // development: pixel tiles per wave for MT <= 4
+  const int force_nt = tune_int("YL_F8_NT", 0);  // development: pixel tiles per wave for MT <= 4
   const int NT = (force_nt == 2 || force_nt == 4) && MT != 6 ? force_nt : ((npix + 63) / 64 * ncb / 4 >= 256 || MT == 6 ? 4 : 2);
   c->MT = MT;
   c->NT = NT;
@@ -322,17 +322,17 @@ int conv_f8_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int 
   // 80-160 MB of input and `model.23.cv2.0.0` 402 MB for 79 MB.  Same cure as conv_mfma.hip's: one plane's nine taps back to
   // back (the per-lane tap / plane arithmetic of the non-UNIFORM fetch).  YL_F8_KORD = smallest map (pixels per image) that
   // takes it; 0: never.
-  const int kord_px = getenv("YL_F8_KORD") ? atoi(getenv("YL_F8_KORD")) : 1600;  // (read at every engine build: the tests switch it)
+  const int kord_px = env_int("YL_F8_KORD", 1600);  // (read at every engine build: the tests switch it)
   c->kord = (kord_px > 0 && k == 3 && (long long)Ho * Wo >= kord_px) ? 1 : 0;
   if (c->kord) c->uniform = 0;
   c->gemm = 0;
-  c->reg = c->pair = c->cs = c->sw = 0;
+  c->reg = c->cs = 0;
   c->ksteps = ksteps;
   // (YL_F8_SLAB2: 1 = a chunked filter alternates between two buffers of half the k-steps, filled by LDS-DMA; 2 = two buffers of the
   // old chunk size; 0 = restaged through registers between two barriers)
   c->slab2 = 0;
   {
-    const int mode = getenv("YL_F8_SLAB2") ? atoi(getenv("YL_F8_SLAB2")) : 1;
+    const int mode = tune_int("YL_F8_SLAB2", 1);
     if (mode > 0 && kchunk < ksteps) {
       if (mode == 1) {
         kchunk = (kchunk / 2) & ~1;
@@ -344,7 +344,6 @@ int conv_f8_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int 
   c->kchunk = kchunk;
   c->lds_bytes = (size_t)(c->slab2 ? 2 * kchunk : kchunk) * step_bytes;
   c->post = 0;
-  c->tile = 0;
   c->wpk_elems = (size_t)ncb * ksteps * MT * 2048;  // bytes
   c->npatches = (int)((npix + 16 * NT - 1) / (16 * NT));
   long long blocks1 = ((long long)c->npatches + 3) / 4 * ncb;
@@ -352,7 +351,7 @@ int conv_f8_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int 
   // k-loops are short (7-14 steps), so fewer, longer workgroups cost less of the chip per launch.  YOLO11x 1280x1280 batch 8
   // with 20 batches in flight: 8 per CU 1 042-1 053 images/s, 4: 1 058, 3: 1 072, 2: 1 066-1 070 (but one batch at a time
   // 867 -> 820), 1: 1 066.  YL_F8_PPW_DIV overrides.
-  static const int ppw_div = getenv("YL_F8_PPW_DIV") ? std::max(1, atoi(getenv("YL_F8_PPW_DIV"))) : 3;
+  static const int ppw_div = std::max(1, tune_int("YL_F8_PPW_DIV", 3));
   int ppw = (int)(blocks1 / (ppw_div * 256));
   if (ppw < 1) ppw = 1;
   if (ppw > 32) ppw = 32;

@@ -481,18 +481,18 @@ static unsigned gm_magic(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ul
 void conv_gemm_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, ConvConfig* c, int cin2) {
   c->gemm = 0;
   // (read at every engine build, not cached: the tests switch them)
-  const int enable = getenv("YL_CONV_GEMM") ? atoi(getenv("YL_CONV_GEMM")) : 1;
-  const int min_c = getenv("YL_CONV_GEMM_MINC") ? atoi(getenv("YL_CONV_GEMM_MINC")) : 128;
+  const int enable = env_int("YL_CONV_GEMM", 1);
+  const int min_c = tune_int("YL_CONV_GEMM_MINC", 128);
   // smallest grid that takes it (384 before the workgroups were persistent; 192: YOLO11s batch 64 24.3 -> 25.0 k images/s --
   // its 20x20 maps have 200-400 tiles --, YOLO11n and YOLO11x unchanged; 96: the same)
-  const int min_blocks = getenv("YL_CONV_GEMM_BLOCKS") ? atoi(getenv("YL_CONV_GEMM_BLOCKS")) : 192;
+  const int min_blocks = env_int("YL_CONV_GEMM_BLOCKS", 192);
   // 3x3 convs (stride 1 or 2; YL_CONV_GEMM3=0 turns them off): K = 9 x Cin, so 64 input channels are deep enough
-  const int enable3 = getenv("YL_CONV_GEMM3") ? atoi(getenv("YL_CONV_GEMM3")) : 1;
+  const int enable3 = env_int("YL_CONV_GEMM3", 1);
   const bool k3 = k == 3 && enable3 && (stride == 1 || stride == 2) && !cin2 && Cin >= 64;
   // 64 output channels (round 5, YL_CONV_GEMM_M64=0: off): 1x1 convs with at least 128 input channels on maps of at least
   // m64_px pixels per batch -- traffic-bound layers, where LDS-DMA keeps more bytes in flight than conv_kernel's register ring
-  const int m64 = getenv("YL_CONV_GEMM_M64") ? atoi(getenv("YL_CONV_GEMM_M64")) : 1;
-  const long long m64_px = getenv("YL_CONV_GEMM_M64_PX") ? atoll(getenv("YL_CONV_GEMM_M64_PX")) : 100000;
+  const int m64 = tune_int("YL_CONV_GEMM_M64", 1);
+  const long long m64_px = env_int("YL_CONV_GEMM_M64_PX", 100000);
   const bool c64 = m64 && Cout == 64 && Cin % 32 == 0 && (long long)batch * Ho * Wo >= m64_px &&
                    ((k == 1 && stride == 1 && Cin >= min_c) || (m64 >= 2 && k3));
   if (!enable || !(k3 || (k == 1 && stride == 1 && Cin >= min_c)) || Cin % 32 || (Cout < min_c && !c64)) return;
@@ -511,7 +511,7 @@ void conv_gemm_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, i
   // blocks (512 -> 512 @20x20 x 64: 24.7 against 27.0 us; 768 -> 768 @160x160 x 8: 909 against 877 TFLOP/s), -4-8 % on
   // 192-channel blocks, equal on 128.  YL_CONV_GEMM_W8: smallest grid (in 256-pixel workgroups) that takes it; 0: never;
   // negative: every tile size from that grid up (development).
-  const int w8_blocks = getenv("YL_CONV_GEMM_W8") ? atoi(getenv("YL_CONV_GEMM_W8")) : 128;
+  const int w8_blocks = env_int("YL_CONV_GEMM_W8", 128);
   int NWN = 2;
   const long long b8 = (npos + 255) / 256 * ncb;
   if (w8_blocks > 0 && MTW == 8 && b8 >= w8_blocks) NWN = 4;
@@ -533,7 +533,7 @@ void conv_gemm_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, i
   c->ncb = ncb;
   c->kchunk = c->ksteps;
   c->post = 0;
-  c->reg = c->tile = c->pair = c->cs = 0;
+  c->reg = c->cs = 0;
   c->ppw = 1;
   c->lds_bytes = conv_gemm_lds_bytes(MTW, NWN, c->ksteps % 2 == 0);
   c->wpk_elems = (size_t)ncb * c->ksteps * c->MT * 64 * 8;
@@ -564,8 +564,8 @@ static int launch_gemm(const ConvArgs& a, size_t lds, hipStream_t s) {
   if (int rc = allow_big_lds(reinterpret_cast<const void*>(kern), (int)(160 * 1024))) return rc;
   if (a.ksteps / gm_ks(MTW, NWN, EVEN) < gm_ns(MTW, NWN, EVEN) - 1) return fail(-3, "conv_gemm: too few K-slices for the ring");
   // persistent: as many workgroups as stay resident (every CU x two 4-wave or one 8-wave workgroup), each walks its tiles
-  static const int persist = getenv("YL_CONV_GEMM_PERSIST") ? atoi(getenv("YL_CONV_GEMM_PERSIST")) : 1;
-  static const int m64_wpc = getenv("YL_CONV_GEMM_M64_WPC") ? atoi(getenv("YL_CONV_GEMM_M64_WPC")) : 2;  // development: workgroups per CU of the 64-channel blocks
+  static const int persist = tune_int("YL_CONV_GEMM_PERSIST", 1);
+  static const int m64_wpc = tune_int("YL_CONV_GEMM_M64_WPC", 2);  // development: workgroups per CU of the 64-channel blocks
   const int resident = device_cu_count() * (MTW == 2 ? m64_wpc : (NWN == 2 && lds <= 80 * 1024 ? 2 : 1));
   const int grid = persist && a.nblocks > resident ? resident : a.nblocks;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(128 * NWN), lds, s, a);

@@ -767,10 +767,10 @@ int conv_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo,
   // slab -- bigger filters are restaged in chunks -- leaves them room: 40-56 KiB all give 47.6-49.0 k images/s against
   // 45.2-46.3 k for 64-72 KiB and 46.1-46.4 k for 100 KiB (tools/env_ab.sh, alternating runs on one box).
   static const size_t slab_max =
-      getenv("YL_CONV_SLAB_KB") ? (size_t)atoi(getenv("YL_CONV_SLAB_KB")) * 1024 : 48 * 1024;
+      (size_t)tune_int("YL_CONV_SLAB_KB", 48) * 1024;
   // output-channel tiles per wave: as many as divide the layer (B-fragment traffic goes with 1/MT).
   // YL_CONV_CHUNK=0 restores the older policy of shrinking MT until the whole filter fits the slab.
-  static const int allow_chunk = getenv("YL_CONV_CHUNK") ? atoi(getenv("YL_CONV_CHUNK")) : 1;
+  static const int allow_chunk = tune_int("YL_CONV_CHUNK", 1);
   int mts[5], nmt = 0;
   if (cout16 % 4 == 0) mts[nmt++] = 4;
   if (cout16 % 5 == 0 && !g_even_only) mts[nmt++] = 5;
@@ -780,13 +780,13 @@ int conv_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo,
   int MT = mts[0];
   // six tiles per wave (96 output channels): channel counts that are multiples of 96 but not of 64 (YOLO11x / m) would otherwise
   // fall to two tiles; YL_CONV_MT6=2 also prefers it to four tiles on wide layers (fewer re-reads of the activations)
-  const int mt6 = getenv("YL_CONV_MT6") ? atoi(getenv("YL_CONV_MT6")) : 2;
+  const int mt6 = tune_int("YL_CONV_MT6", 2);
   if (!post && cout16 % 6 == 0 && Cin % 32 == 0 && ((mt6 >= 1 && cout16 % 4 != 0) || (mt6 >= 2 && Cin >= 128))) MT = 6;
   // eight tiles x two pixel tiles per wave (128 channels x 32 pixels): half the activation re-reads of 4 x 4 at twice the filter
   // reads from LDS -- a trade that pays while the texture path, not LDS, is the busier one (YL_CONV_MT8 = smallest Cin that takes it)
-  const int mt8 = getenv("YL_CONV_MT8") ? atoi(getenv("YL_CONV_MT8")) : 128;
-  const int mt8_cout = getenv("YL_CONV_MT8_COUT") ? atoi(getenv("YL_CONV_MT8_COUT")) : 256;  // smallest Cout that takes it
-  const int mt8_blocks = getenv("YL_CONV_MT8_BLOCKS") ? atoi(getenv("YL_CONV_MT8_BLOCKS")) : 512;
+  const int mt8 = env_int("YL_CONV_MT8", 128);
+  const int mt8_cout = tune_int("YL_CONV_MT8_COUT", 256);  // smallest Cout that takes it
+  const int mt8_blocks = env_int("YL_CONV_MT8_BLOCKS", 512);
   if (mt8 > 0 && !post && cout16 % 8 == 0 && Cin % 32 == 0 && Cin >= mt8 && Cout >= mt8_cout && MT == 4 &&
       ((long long)batch * Ho * Wo + 31) / 32 / 4 * (cout16 / 8) >= mt8_blocks)  // still at least two workgroups per CU
     MT = 8;
@@ -805,8 +805,8 @@ int conv_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo,
   const long long npix = (long long)batch * Ho * Wo;
   auto npatches = [&](int nt) { return (npix + 16 * nt - 1) / (16 * nt); };
   int NT = 1;
-  static const int nt4_blocks = getenv("YL_CONV_NT4") ? atoi(getenv("YL_CONV_NT4")) : NUM_CU / 2;
-  static const int nt2_blocks = getenv("YL_CONV_NT2") ? atoi(getenv("YL_CONV_NT2")) : NUM_CU / 4;
+  static const int nt4_blocks = tune_int("YL_CONV_NT4", NUM_CU / 2);
+  static const int nt2_blocks = tune_int("YL_CONV_NT2", NUM_CU / 4);
   if (npatches(4) * ncb / 4 >= nt4_blocks) NT = 4;
   else if (npatches(2) * ncb / 4 >= nt2_blocks) NT = 2;
   if (MT == 5 && NT == 4) NT = 2;
@@ -826,7 +826,7 @@ int conv_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo,
   // 64-pixel tiles is 4 / 2 k-steps deep (16-pixel tiles, ring of 8, keep the synchronous form).
   c->slab2 = 0;
   {
-    const int mode = getenv("YL_CONV_SLAB2") ? atoi(getenv("YL_CONV_SLAB2")) : 1;
+    const int mode = tune_int("YL_CONV_SLAB2", 1);
     if (mode > 0 && kchunk < ksteps && NT >= 2 && YL_RING_NT4 <= 4 && YL_RING_NT2 <= 4) {
       if (mode == 1) {
         kchunk = (kchunk / 2) & ~3;
@@ -848,7 +848,7 @@ int conv_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo,
   c->npatches = (int)npatches(NT);
   // patches per wave: amortise the slab load while keeping >= ~8 blocks per CU in the grid
   long long blocks1 = ((long long)c->npatches + 3) / 4 * ncb;
-  static const int ppw_div = getenv("YL_CONV_BPC") ? atoi(getenv("YL_CONV_BPC")) : 32;  // target blocks per CU (8 until several batches ran in flight: +0.7 %)
+  static const int ppw_div = tune_int("YL_CONV_BPC", 32);  // target blocks per CU (8 until several batches ran in flight: +0.7 %)
   int ppw = (int)(blocks1 / (ppw_div * NUM_CU));
   if (ppw < 1) ppw = 1;
   if (ppw > 32) ppw = 32;
@@ -858,23 +858,19 @@ int conv_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo,
   c->name = k == 3 ? (stride == 2 ? "conv3x3s2_mfma" : "conv3x3_mfma") : "conv1x1_mfma";
   c->gemm = 0;
   c->cs = 0;
-  c->sw = 0;
   // K order of the stride-2 3x3 convs with >= 64 input channels (layers 3, 5, 7, 17, 20): PLANE-major.  In tap-major order a
   // workgroup sweeps its whole input footprint (8-32 planes) once per tap, nine times in all, with a reuse distance far beyond
   // L1 and -- 64 workgroups per XCD -- beyond the 4 MB L2: rocprofv3 (profiles/r03_summary.md) shows model.3 fetching 225 MB for
   // a 105 MB input.  Plane-major touches one plane's footprint with all nine taps back to back and never again.  Costs the
   // per-lane (tap, plane) arithmetic of the non-UNIFORM fetch (~10 VALU per k-step); the sum order changes (same operands).
-  static const int kord_min_cin = getenv("YL_CONV_KORD") ? atoi(getenv("YL_CONV_KORD")) : 64;  // 0: never
-  static const int kord_s1_cin = getenv("YL_CONV_KORD_S1") ? atoi(getenv("YL_CONV_KORD_S1")) : 0;  // stride 1 too, from this Cin (0: never)
+  static const int kord_min_cin = tune_int("YL_CONV_KORD", 64);  // 0: never
+  static const int kord_s1_cin = tune_int("YL_CONV_KORD_S1", 0);  // stride 1 too, from this Cin (0: never)
   c->kord = (kord_min_cin > 0 && k == 3 && stride == 2 && Cin >= kord_min_cin && MT <= 5 && !g_even_only) ? 1 : 0;
   if (kord_s1_cin > 0 && k == 3 && stride == 1 && Cin >= kord_s1_cin && MT <= 5 && !g_even_only && Cin % 8 == 0) c->kord = 1;
   if (c->kord) c->uniform = 0;
-  conv3_tile_choose(batch, Cin, Cout, k, stride, Ho, Wo, post, c);  // 3x3 s1 layers that fit: input tile in LDS
   conv3_reg_choose(batch, Cin, Cout, k, stride, Ho, Wo, post, c);   // ... or with the filter in registers
-  conv3_pair_choose(batch, Cin, Cout, k, stride, Ho, Wo, post, c);  // ... 64 -> 64: filter halves in two waves per SIMD
   conv3_cs_choose(batch, Cin, Cout, k, stride, Ho, Wo, post, c);    // ... 64 -> 64: output channels split, two workgroups per CU
-  conv3_sw_choose(batch, Cin, Cout, k, stride, Ho, Wo, post, c);    // ... on maps of whole 16-pixel strips: fragments reused across rows
-  if (c->kord && (c->reg || c->tile || c->pair || c->cs || c->sw)) {  // those kernels read the filter tap-major
+  if (c->kord && (c->reg || c->cs)) {  // those kernels read the filter tap-major
     c->kord = 0;
     c->uniform = (cg % 4 == 0);
   }
@@ -1077,7 +1073,7 @@ static int launch_dwpw(const ConvConfig& cfg, const ConvArgs& a, size_t lds, hip
 
 // dwpw_kernel's arguments and LDS size from the tiling; cfg may be retiled (development override of NT)
 static int dwpw_prepare(ConvConfig& cfg, ConvArgs& a, int batch, size_t* lds_out) {
-  static const int force_nt = getenv("YL_DWPW_NT") ? atoi(getenv("YL_DWPW_NT")) : 0;  // development: 1 or 2 positions tiles per wave
+  static const int force_nt = tune_int("YL_DWPW_NT", 0);  // development: 1 or 2 positions tiles per wave
   if (force_nt == 1 || force_nt == 2) {
     cfg.NT = force_nt;
     cfg.npatches = (int)(((long long)batch * a.Ho * a.Wo + 16 * force_nt - 1) / (16 * force_nt));
@@ -1103,7 +1099,7 @@ static int dwpw_prepare(ConvConfig& cfg, ConvArgs& a, int batch, size_t* lds_out
   a.out_bytes = (unsigned)outb;
   a.st_nt = st_nt_policy(outb);
   a.nblocks = (cfg.npatches + 3) / 4;
-  static const int dwpw_dbg = getenv("YL_DWPW_DBG") ? atoi(getenv("YL_DWPW_DBG")) : 0;  // timing ablations (wrong results)
+  static const int dwpw_dbg = tune_int("YL_DWPW_DBG", 0);  // timing ablations (wrong results)
   a.dbg = dwpw_dbg;
   a.stamps = g_stamp_buf;
   const int planes = a.wpk2 && a.cg2 > cfg.cg ? a.cg2 : cfg.cg;
@@ -1124,7 +1120,7 @@ int dwpw_launch(const ConvConfig& cfg0, ConvArgs a, int batch, hipStream_t s) {
     if (rc || handled) return rc;
   }
   {  // deep launches on small maps: one 16-pixel patch per workgroup, the waves split channels (dwpw_deep_kernel)
-    const int deep = getenv("YL_DWPW_DEEP") ? atoi(getenv("YL_DWPW_DEEP")) : 1;  // (read per launch: the tests switch it)
+    const int deep = env_int("YL_DWPW_DEEP", 1);  // (read per launch: the tests switch it)
     if (deep && cfg.NT == 1 && !a.wpk2 && cfg.cg >= 16 && !a.dbg) {
       a.nblocks = a.npatches;
       const size_t lds_deep = (size_t)cfg.cg * 256;
@@ -1222,7 +1218,7 @@ static int conv_prepare(const ConvConfig& cfg, ConvArgs& a, int batch) {
   }
   a.nblocks = cfg.gws * cfg.ncb;
   {
-    static const int dbg = getenv("YL_CONV_DBG") ? atoi(getenv("YL_CONV_DBG")) : 0;  // ablation, dev only
+    static const int dbg = tune_int("YL_CONV_DBG", 0);  // ablation, dev only
     a.dbg = dbg;
   }
   return 0;
@@ -1230,17 +1226,14 @@ static int conv_prepare(const ConvConfig& cfg, ConvArgs& a, int batch) {
 
 // `a` arrives with pointers, plane sizes, geometry, Cin/Cout/stride/act/out_f32 filled in.
 int conv_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s) {
-  // The register / pair / tile variants are chosen from (Cin, Cout, k, stride, post) alone and take only a plain stride-1
+  // The register-filter variants (conv3_reg, conv3_cs) are chosen from (Cin, Cout, k, stride, post) alone and take only a plain stride-1
   // conv between bf16 planar tensors of ONE geometry; they share conv_kernel's filter packing, so any other view (fp32 or
   // pitched output, an upsampled second input, an e4m3 copy) simply runs on conv_kernel.
   const bool plain = a.stride == 1 && !a.out_f32 && !a.in2 && !a.wpk2 && !a.out8 && a.in_w1 == a.out_w1 &&
                      a.in_img == a.out_img && a.in_g0 == a.out_g0 && a.in_w1 == a.Wo + 1;
   if (cfg.gemm) return conv_gemm_launch(cfg, a, batch, s);  // chosen by the engine with the views known: no fallback needed
-  if (cfg.sw && plain && !a.res) return conv3_sw_launch(cfg, a, batch, s);
-  if ((cfg.cs || cfg.sw) && plain) return conv3_cs_launch(cfg, a, batch, s);  // (sw with a residual: the linear-tile form)
-  if (cfg.pair && plain) return conv3_pair_launch(cfg, a, batch, s);
+  if (cfg.cs && plain) return conv3_cs_launch(cfg, a, batch, s);
   if (cfg.reg && plain) return conv3_reg_launch(cfg, a, batch, s);
-  if (cfg.tile && a.act && plain) return conv3_tile_launch(cfg, a, batch, s);  // (a conv without SiLU stays on conv_kernel)
   if (int rc = conv_prepare(cfg, a, batch)) return rc;
   return cfg.ntaps == 9 ? launch_m<3>(cfg, a, s) : launch_m<1>(cfg, a, s);
 }
@@ -1248,7 +1241,7 @@ int conv_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s) {
 // The tiling of a conv that joins a group launch: plain conv_kernel (no register / tile variants), NT forced to the
 // group's common pixel-tile count, one patch per wave.
 void conv_retile_for_group(ConvConfig* c, int NT, int batch, int Ho, int Wo) {
-  c->reg = c->tile = c->pair = c->cs = c->sw = 0;
+  c->reg = c->cs = 0;
   c->NT = NT;
   c->npatches = (int)(((long long)batch * Ho * Wo + 16 * NT - 1) / (16 * NT));
   c->ppw = 1;
@@ -1262,7 +1255,7 @@ bool conv_group_compatible(const ConvConfig* cfg, const ConvArgs* a, int n) {
     if (cfg[i].ntaps != 9 || cfg[i].MT != 4 || cfg[i].uniform != cfg[0].uniform || cfg[i].post != cfg[0].post || cfg[i].NT != cfg[0].NT ||
         (cfg[i].NT != 2 && cfg[i].NT != 4) || a[i].in2 || a[i].out8 || a[i].out_f32 || a[i].res || a[i].stride != 1 ||
         (a[i].dfl_out != nullptr) != (a[0].dfl_out != nullptr) || (a[i].dfl_out && (!cfg[i].post || a[i].post_cout != 64)) ||
-        cfg[i].reg || cfg[i].tile || cfg[i].pair || cfg[i].cs || cfg[i].sw)
+        cfg[i].reg || cfg[i].cs)
       return false;
   }
   return true;

@@ -288,9 +288,9 @@ int dwpw_tile_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s
   // positions per tile, 1 to 4 workgroups per CU).  The ring and the slabs leave room for 2-3 workgroups per CU, whose four
   // waves meet at a barrier every step; dwpw_kernel's 5-6 independent workgroups per CU hide more latency than the
   // staging saves in L1 traffic.  Kept for the record and for the timeline tool (tools/dwpw_timeline.py).
-  const int enable = getenv("YL_DWPW_TILE") ? atoi(getenv("YL_DWPW_TILE")) : 0;
-  static const int want_nt = getenv("YL_DWPW_TILE_NT") ? atoi(getenv("YL_DWPW_TILE_NT")) : 0;
-  static const int wg_per_cu = getenv("YL_DWPW_TILE_WPC") ? atoi(getenv("YL_DWPW_TILE_WPC")) : 0;
+  const int enable = env_int("YL_DWPW_TILE", 0);
+  static const int want_nt = tune_int("YL_DWPW_TILE_NT", 0);
+  static const int wg_per_cu = tune_int("YL_DWPW_TILE_WPC", 0);
   if (!enable || a.pf_count || a.in_w1 != a.Wo + 1 || a.in_w1 != a.out_w1 || a.in_img != a.out_img || a.in_g0 != a.out_g0 || a.out_f32)
     return 0;
   const long long nq = (long long)batch * a.in_img;

@@ -27,11 +27,11 @@ int fail(int code, const std::string& s) {
 unsigned long long* g_stamp_buf = nullptr;
 int st_nt_policy(long long out_bytes) {
   // (read at every engine build, not cached: tests and tools switch them)
-  const int mode = getenv("YL_ST_NT") ? atoi(getenv("YL_ST_NT")) : 1;  // (-1: by size, YL_ST_NT_BYTES)
+  const int mode = tune_int("YL_ST_NT", 1);  // (-1: by size, YL_ST_NT_BYTES)
   // bit 1: the e4m3 stores too (YL_ST_NT_F8=1; measured on config 5: 1 136 -> 1 131 images/s, off)
-  const int f8 = (getenv("YL_ST_NT_F8") ? atoi(getenv("YL_ST_NT_F8")) : 0) ? 2 : 0;
+  const int f8 = (tune_int("YL_ST_NT_F8", 0)) ? 2 : 0;
   if (mode >= 0) return mode ? (1 | f8) : 0;
-  const long long thr = getenv("YL_ST_NT_BYTES") ? atoll(getenv("YL_ST_NT_BYTES")) : 48LL << 20;
+  const long long thr = (long long)tune_int("YL_ST_NT_BYTES", 48 << 20);
   return out_bytes >= thr ? (1 | f8) : 0;
 }
 
@@ -81,7 +81,6 @@ struct OpRec {
   int cls_level = -1;  // fused depthwise + pointwise + 1x1 that writes the class logits of this Detect level (else -1)
   int group_n = 0;  // group launch (yl_op.group): 2 or 3 on the first member, -1 on the others (run with it), 0 = on its own
   bool band = false;  // (first member of a group) the group runs on conv3_band_kernel: deep-K 3x3 convs, 64 output channels
-  bool band64 = false;  // ... on conv3_band64_kernel: 64 -> 64 3x3 convs with a fused follow-up 1x1 (the levels' cv2[i][1] + cv2[i][2])
   double flops = 0, bytes = 0;
   const char* name = "";
 };
@@ -427,7 +426,6 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
           if (post || o.stem_weight) return fail(-1, tag + ": out8 needs a plain conv");
           if (r.cfg.MT & 1)  // the copy is written by tile pairs: take the best even tiling instead
             if (int rc = conv_choose_even(batch, cin_total, cout1, o.k, o.stride, Ho, Wo, &r.cfg)) return rc;
-          r.cfg.tile = 0;  // the e4m3 copy is written by conv_kernel's epilogue
         }
         std::vector<uint16_t> pk;
         conv_pack_weights(o.weight, cout1, cin_w, o.k, r.cfg, &pk);
@@ -514,7 +512,7 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
             r.cfg.npatches = (int)(((long long)batch * o.out.H * o.out.W + 31) / 32);
             r.cfg.wpk_elems = (size_t)r.cfg.ksteps * 8 * 64 * 8;
             r.cfg.lds_bytes = (size_t)r.cfg.ksteps * 8 * 1024;
-            r.cfg.tile = r.cfg.reg = r.cfg.pair = r.cfg.cs = r.cfg.sw = r.cfg.kord = 0;
+            r.cfg.reg = r.cfg.cs = r.cfg.kord = 0;
           }
           if (r.cfg.NT > 2) {
             r.cfg.NT = 2;
@@ -523,7 +521,7 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
           // A deep launch on a small map (Detect level 2: 256 channels @20x20 = 16 channel blocks one after the other in every
           // workgroup, 100 workgroups at 32 pixels per wave for batch 32): 16 pixels per wave double the workgroups and halve
           // each one's serial chain.  Launches that join a level group keep the group's tiling.
-          static const int small_nt1 = getenv("YL_DWPW_SMALL_NT1") ? atoi(getenv("YL_DWPW_SMALL_NT1")) : 1;
+          static const int small_nt1 = tune_int("YL_DWPW_SMALL_NT1", 1);
           const int small_blocks = small_nt1 > 1 ? small_nt1 : 256;  // (> 1: the workgroup count below which it applies, development)
           if (small_nt1 && o.group == 0 && r.cfg.NT == 2 && C >= 128 && (r.cfg.npatches + 3) / 4 < small_blocks) {
             r.cfg.NT = 1;
@@ -893,7 +891,7 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
   // ---- side lanes as separate graphs (see yl_engine::lane_graphs): segments = maximal runs of ops of one lane; the first one
   // must be a main-lane segment (it holds the network's first launch)
   {
-    static const int lg = getenv("YL_LANE_GRAPHS") ? atoi(getenv("YL_LANE_GRAPHS")) : 1;
+    static const int lg = tune_int("YL_LANE_GRAPHS", 1);
     e->lane_graphs = lg != 0 && e->max_lane > 0 && !e->ops.empty() && e->ops[0].op.lane == 0;
     if (e->lane_graphs) {
       for (size_t i = 0; i < e->ops.size();) {
@@ -907,7 +905,7 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
   // ---- which launches produce the class logits of the Detect levels (the NMS candidate pre-filter rides in their epilogue)
   {
     size_t found = 0;
-    static const int conv_pf = getenv("YL_FUSE_PREFILTER_CONV") ? atoi(getenv("YL_FUSE_PREFILTER_CONV")) : 1;
+    static const int conv_pf = tune_int("YL_FUSE_PREFILTER_CONV", 1);
     for (OpRec& r : e->ops) {
       // the fused depthwise + pointwise + 1x1 launch of the class branch (YOLO11n), or -- where the branch is too wide for it --
       // the plain 1x1 conv that ends it (conv_kernel's PF instantiation)
@@ -924,7 +922,7 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
         }
       }
     }
-    static const int fuse_pf = getenv("YL_FUSE_PREFILTER") ? atoi(getenv("YL_FUSE_PREFILTER")) : 1;
+    static const int fuse_pf = tune_int("YL_FUSE_PREFILTER", 1);
     e->cls_tails = fuse_pf && !e->levels.empty() && found == e->levels.size() && (e->max_lane == 0 || e->lane_graphs);
   }
   // ---- group launches: runs of consecutive ops with the same yl_op.group > 0 (the lowering puts the Detect levels'
@@ -963,7 +961,7 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
       // Two plain convs with a deep K and 64 output channels on small maps (Detect's first box convs on the 40x40 and 20x20 levels,
       // 128 -> 64 and 256 -> 64): conv3_band_kernel -- the input band in LDS, the filter streamed from L2 -- instead of
       // conv_group_kernel, which restages the 144 / 288 KB filters per 256 pixels (YL_CONV_BAND=0: off)
-      const int band_on = getenv("YL_CONV_BAND") ? atoi(getenv("YL_CONV_BAND")) : 1;  // (read at every engine build: tests switch it)
+      const int band_on = env_int("YL_CONV_BAND", 1);  // (read at every engine build: tests switch it)
       bool band = ok && band_on && nc == 2 && nd == 0 && !e->ops[i].cfg.post;
       for (size_t k = i; k < j && band; ++k) {
         const OpRec& r = e->ops[k];
@@ -977,27 +975,6 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
           r.group_n = k == i ? n : -1;
           r.band = k == i;
           r.name = k == i ? "conv3x3_band_mfma[x2]" : "(in the group launch)";
-        }
-        ok = false;  // (handled)
-      }
-      // The levels' 64 -> 64 3x3 convs with their fused follow-up 1x1 (cv2[i][1] + cv2[i][2]) on conv3_band64_kernel: OPT-IN
-      // (YL_CONV_BAND64=1).  Bit-identical, but not faster: 58.6 against 59.9 us in sequence and 53.5 k against 54.1 k images/s
-      // with 20 batches in flight -- with 18 k-steps a band's k-loop (4.6 us) is shorter than what surrounds it (input
-      // staging 2.8 us, epilogue + 1x1 + stores 2.5 us), and a 152 KB workgroup owns its CU, so nothing overlaps those phases.
-      const int band64_on = getenv("YL_CONV_BAND64") ? atoi(getenv("YL_CONV_BAND64")) : 0;
-      bool band64 = ok && band_on && band64_on && nc >= 2 && nd == 0 && e->ops[i].cfg.post && !e->ops[i].op.dfl_level;
-      for (size_t k = i; k < j && band64; ++k) {
-        const OpRec& r = e->ops[k];
-        band64 = r.cfg.MT == 4 && r.cfg.ncb == 1 && !r.cfg.kord && r.op.in.C == 64 && r.op.post_cin == 64 && r.op.out.C == 64 && r.d_wpk2 &&
-                 r.op.in.H == r.op.out.H && r.op.in.W == r.op.out.W && conv3_band_plan(64, 64, r.op.out.H, r.op.out.W, nullptr, true);
-      }
-      if (band64) {
-        static const char* const bn[3] = {"conv3x3+1x1_band_mfma[x1]", "conv3x3+1x1_band_mfma[x2]", "conv3x3+1x1_band_mfma[x3]"};
-        for (size_t k = i; k < j; ++k) {
-          OpRec& r = e->ops[k];
-          r.group_n = k == i ? n : -1;
-          r.band64 = k == i;
-          r.name = k == i ? bn[n - 1] : "(in the group launch)";
         }
         ok = false;  // (handled)
       }
@@ -1015,7 +992,7 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
           if (NT != 2 && NT != 4) NT = 2;
           // a launch shared with depthwise members: 32 pixels per wave (151-156 registers, three waves per SIMD -- the
           // depthwise bodies run at the conv's register budget; 64 pixels: 187-220 registers, -1.3 % end to end)
-          static const int head_nt = getenv("YL_HEAD_GROUP_NT") ? atoi(getenv("YL_HEAD_GROUP_NT")) : 2;
+          static const int head_nt = tune_int("YL_HEAD_GROUP_NT", 2);
           if (nd && (head_nt == 2 || head_nt == 4)) NT = head_nt;
           for (size_t k = i; k < i + nc; ++k) conv_retile_for_group(&e->ops[k].cfg, NT, batch, e->ops[k].op.out.H, e->ops[k].op.out.W);
         }
@@ -1471,7 +1448,7 @@ static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s, c
 // and / or the independent branches of the head (head.py:61), one launch for all of them (conv_group_kernel /
 // dwpw_group_kernel / head_group_kernel).
 static int run_group(const yl_engine* e, size_t i, int n, char* ws, hipStream_t s, const PrefilterSink* sink) {
-  if (e->ops[i].band || e->ops[i].band64) {
+  if (e->ops[i].band) {
     BandArgs ba[3]{};
     for (int k = 0; k < n && k < 3; ++k) {
       const OpRec& r = e->ops[i + k];
@@ -1498,7 +1475,6 @@ static int run_group(const yl_engine* e, size_t i, int n, char* ws, hipStream_t 
       q.bias2 = r.d_bias2;
       q.post_act = o.post_act;
     }
-    if (e->ops[i].band64) return conv3_band64_launch(ba, n, e->batch, 1, s);
     return conv3_band_launch(ba, n, e->batch, s);
   }
   ConvArgs ca[3]{}, da[3]{};
@@ -1698,7 +1674,7 @@ static int detect_eager(yl_engine* e, const void* input, int in_dtype, void* wor
   int fused = 0;
   // (the counters are cleared by the network's first launch where that is the fused stem -- it precedes every class-logit
   // launch in stream order; otherwise by a launch of their own)
-  static const bool zero_in_stem = !getenv("YL_ZERO_IN_STEM") || atoi(getenv("YL_ZERO_IN_STEM")) != 0;
+  static const bool zero_in_stem = env_int("YL_ZERO_IN_STEM", 1) != 0;
   const bool defer = zero_in_stem && !e->ops.empty() && e->ops[0].d_w0 && e->ops[0].op.lane == 0 && e->ops[0].group_n >= 0;
   if (e->cls_tails)
     if (int rc = prefilter_sink_prepare(e->levels.data(), (int)e->levels.size(), e->batch, max_cand, conf_thres, work, stream, &sink,
@@ -1772,7 +1748,7 @@ static int detect_lanes(yl_engine* e, const void* input, int in_dtype, void* wor
     } guard{&P};
     PrefilterSink sink{};
     int fused = 0;
-    static const bool zero_in_stem = !getenv("YL_ZERO_IN_STEM") || atoi(getenv("YL_ZERO_IN_STEM")) != 0;
+    static const bool zero_in_stem = env_int("YL_ZERO_IN_STEM", 1) != 0;
     const bool defer = zero_in_stem && e->ops[0].d_w0 && e->ops[0].group_n >= 0;
     const bool stem = e->ops[0].op.kind == YL_OP_STEM || e->ops[0].d_w0;
     for (size_t k = 0; k < e->segments.size(); ++k) {
@@ -2096,7 +2072,7 @@ extern "C" int yl_graph_launch_many(void* const* graphs, void* const* streams, i
   if (!graphs || !streams || n < 0) return fail(-1, "yl_graph_launch_many: bad arguments");
   for (int i = 0; i < n; ++i)
     if (!graphs[i]) return fail(-1, "yl_graph_launch_many: null graph");
-  static const int threads_env = getenv("YL_ISSUE_THREADS") ? atoi(getenv("YL_ISSUE_THREADS")) : 4;
+  static const int threads_env = env_int("YL_ISSUE_THREADS", 4);
   const int parts = threads_env < 1 ? 1 : threads_env > IssuePool::NW + 1 ? IssuePool::NW + 1 : threads_env;
   // distinct streams in order of first appearance; stream k goes to part k % parts
   std::vector<void*> seen;

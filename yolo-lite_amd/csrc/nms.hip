@@ -1240,11 +1240,11 @@ int yl::decode_nms_stages(const void* workspace, const yl_level* levels, int n_l
     if (ev) (void)hipEventRecord(ev[1], s);
     // (one workgroup per image: with few images in the batch the four launches, whose grids spread over the anchors and rows,
     // are quicker -- YOLO11x 1280x1280 batch 8, ~1000 candidates per image: 214 us against 320 us)
-    static const int one_launch_env = getenv("YL_NMS_FUSED") ? atoi(getenv("YL_NMS_FUSED")) : -1;
+    static const int one_launch_env = env_int("YL_NMS_FUSED", -1);
     const bool one_launch = one_launch_env >= 0 ? one_launch_env != 0 : batch >= 16;
     if (one_launch) {  // exact decode + sort + mask + scan in one launch, one workgroup per image
-      static const int stop_after = getenv("YL_NMS_DBG") ? atoi(getenv("YL_NMS_DBG")) : 0;
-      static const int lds_path = getenv("YL_NMS_LDS") ? atoi(getenv("YL_NMS_LDS")) : 1;  // (0: the general path for every image)
+      static const int stop_after = tune_int("YL_NMS_DBG", 0);
+      static const int lds_path = tune_int("YL_NMS_LDS", 1);  // (0: the general path for every image)
       auto kern = n_levels <= 3 ? decode_nms_fused_kernel<3> : decode_nms_fused_kernel<8>;
       hipLaunchKernelGGL(kern, dim3(batch), dim3(1024), 0, s, a, w, iou_thres, max_det, agnostic, max_wh, scale, out, out_count,
                          stop_after, lds_path, g_stamp_buf);

@@ -336,7 +336,7 @@ int dwconv3_launch(const DwArgs& a, hipStream_t s) {
   if (a.C % 8 || (a.grp && (a.grp % 8 || a.grp_stride % 8 || a.grp_off % 8)))
     return fail(-3, "dwconv3: channel counts must be multiples of 8");
   if ((long long)a.batch * a.H * a.W >= (1LL << 31) || a.C / 8 > 65535) return fail(-3, "dwconv3: tensor too large");
-  static const int px = getenv("YL_DW_PX") ? atoi(getenv("YL_DW_PX")) : 2;
+  static const int px = tune_int("YL_DW_PX", 2);
   if (px == 1) dw_launch_px<1>(a, s);
   else if (px == 2) dw_launch_px<2>(a, s);
   else dw_launch_px<4>(a, s);
@@ -692,7 +692,7 @@ int attention_launch(const AttnArgs& a, hipStream_t s) {
   // workgroups per (image, head): four; more only when a wave would carry more than four query tiles (every workgroup
   // stages ALL keys and values of its head: 40x40 tokens, YOLO11x batch 8: 4 workgroups 105 us per launch, 7: 150 us)
   const int nqt = (a.N + 15) / 16;
-  static const int qs_env = getenv("YL_ATTN_QSPLIT") ? atoi(getenv("YL_ATTN_QSPLIT")) : 0;  // development
+  static const int qs_env = tune_int("YL_ATTN_QSPLIT", 0);  // development
   int qsplit = qs_env > 0 ? qs_env : 4;
   auto rounds_of = [&](int qs) { return (nqt + AT_WAVES * qs - 1) / (AT_WAVES * qs); };
   while (qs_env <= 0 && rounds_of(qsplit) > 4 && qsplit < 16) ++qsplit;

@@ -249,7 +249,7 @@ int psa_tail_launch(const PsaTailArgs& a0, hipStream_t s) {
   const long long P = (long long)a.B * a.H * a.W;
   if (P <= 0 || P > (1LL << 28)) return fail(-3, "psa_tail: bad map size");
   // one tile per wave while that still leaves CUs idle (a workgroup holds the whole LDS of its CU)
-  static const int nt_env = getenv("YL_PSA_TAIL_NT") ? atoi(getenv("YL_PSA_TAIL_NT")) : 0;
+  static const int nt_env = tune_int("YL_PSA_TAIL_NT", 0);
   const int nt = nt_env == 1 || nt_env == 2 ? nt_env : (P <= (long long)device_cu_count() * PT_WAVES * 16 ? 1 : 2);
   const int per_wg = PT_WAVES * nt * 16;
   auto kern = nt == 1 ? psa_tail_kernel<1> : psa_tail_kernel<2>;

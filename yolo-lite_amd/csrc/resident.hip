@@ -845,7 +845,7 @@ int psa_resident_launch(const PsaArgs& a0, hipStream_t s) {
   const int ntiles = (a.H * a.W + 15) / 16;
   // Workgroups per image.  One workgroup per image is the cheapest in chip time (the key / value conv runs once), but a batch
   // of 32 then occupies 32 of the 256 CUs for ~90 us; two halve that time for ~10 % more work (YL_PSA_SPLIT overrides).
-  const int split_env = getenv("YL_PSA_SPLIT") ? atoi(getenv("YL_PSA_SPLIT")) : 0;  // (read per launch: the tests switch it)
+  const int split_env = tune_int("YL_PSA_SPLIT", 0);  // (read per launch: the tests switch it)
   int split = split_env > 0 ? split_env : a0.split > 0 ? a0.split : (ntiles > 16 ? 2 : 1);  // (a0.split: asked for by the program, yl_op.reserved3)
   if (split > ntiles) split = ntiles;
   if (split < 1 || split > 4) split = 1;
@@ -900,13 +900,13 @@ int c3k_resident_launch(C3kArgs a, hipStream_t s) {
   // = 0.7 of the map on a 20x20 image: 0.83 of the latency (47.4 -> 39.4 us) for 1.4 x the chip time.  The program asks for it
   // (yl_op.reserved3 = 2: nn/lower.py one_batch=True, the predictor's one-batch-at-a-time path); with 20 batches in flight it costs
   // 1.5 % of the throughput.
-  const int want = getenv("YL_C3K_SPLIT") ? atoi(getenv("YL_C3K_SPLIT")) : a.split;
+  const int want = env_int("YL_C3K_SPLIT", a.split);
   a.split = (want == 2 && (a.H + 1) / 2 + 4 < a.H) ? 2 : 1;
   a.Hs = a.split == 2 ? (a.H + 1) / 2 + 4 : a.H;
   const size_t lds = c3k_resident_lds(a.Hs, a.W, &a.xpl, &a.apl, &a.r1, &a.ntiles);
   a.stamps = g_stamp_buf;
   a.scratch = a.r1 + 8 * a.apl;
-  static const int dbg = getenv("YL_RES_DBG") ? atoi(getenv("YL_RES_DBG")) : 0;  // development: 1 = no filter warm-up
+  static const int dbg = tune_int("YL_RES_DBG", 0);  // development: 1 = no filter warm-up
   a.dbg = dbg;
   switch ((a.ntiles + 3) / 4) {
     case 1: return c3k_launch_t<1>(a, lds, s);

@@ -390,7 +390,7 @@ static int sp_launch_t(const SppfArgs& a, size_t lds, hipStream_t s) {
 int sppf_resident_launch(const SppfArgs& a0, hipStream_t s) {
   SppfArgs a = a0;
   a.stamps = g_stamp_buf;
-  static const int dbg = getenv("YL_SPPF_DBG") ? atoi(getenv("YL_SPPF_DBG")) : 0;  // development: timing ablations (wrong results)
+  static const int dbg = tune_int("YL_SPPF_DBG", 0);  // development: timing ablations (wrong results)
   a.dbg = dbg;
   if (!sppf_resident_fits(256, 256, a.w3 ? 256 : 0, a.H, a.W)) return fail(-3, "sppf_resident: the map does not fit one workgroup's LDS");
   const int ntiles = (a.H * a.W + 15) / 16;

@@ -398,7 +398,7 @@ static int stem2_launch_t(const Stem2Args& a, int MT, size_t lds, hipStream_t s)
 int stem2_launch(const Stem2Args& a0, int MT, int in_dtype, hipStream_t s) {
   Stem2Args a = a0;
   a.stamps = g_stamp_buf;
-  a.st_nt = (a.cacheable || (getenv("YL_ST_NT_FUSED") && !atoi(getenv("YL_ST_NT_FUSED")))) ? 0 : st_nt_policy(a.out_bytes);
+  a.st_nt = (a.cacheable || !tune_int("YL_ST_NT_FUSED", 1)) ? 0 : st_nt_policy(a.out_bytes);
   if ((a.C0 != 16 && a.C0 != 32) || a.ksteps != (9 * (a.C0 / 8) + 3) / 4)
     return fail(-3, "stem2: the stem must have 16 or 32 output channels");
   const int esz = in_dtype == YL_F32 ? 4 : in_dtype == YL_F16 ? 2 : 1;

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -14,6 +15,20 @@ namespace yl {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+// Switches.  env_int: a RUNTIME knob -- every one is listed in INTEGRATION.md (section 5); tests use most of them to force a
+// kernel choice on small shapes or to build the unfused twin of a fused launch.  tune_int: a DEVELOPMENT constant (tile shapes,
+// thresholds, ablation flags whose A / B is recorded in NOTEBOOK.md): the production library returns the default and never looks
+// at the environment; `make EXTRA=-DYL_TUNING` builds a library that does.
+inline int env_int(const char* name, int def) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : def;
+}
+#ifdef YL_TUNING
+inline int tune_int(const char* name, int def) { return env_int(name, def); }
+#else
+inline int tune_int(const char*, int def) { return def; }
+#endif
 
 void set_error(const std::string& s);
 int fail(int code, const std::string& s);
@@ -139,7 +154,7 @@ struct ConvArgs {
   float dfl_stride;
   int dfl_keep;
   unsigned long long* stamps;  // diagnostic builds (-DYL_STAMPS): dwpw_body's phase stamps
-  // conv3_tile_kernel (3x3, stride 1, input tile in LDS): tile geometry in guarded-pixel units
+  // the LDS-tile kernels (conv3_reg / conv3_cs / conv3_f8t / dwpw tile form): tile geometry in guarded-pixel units
   int t_px, t_PL, t_ppp, t_ntiles, t_plane_px, t_H, t_W, t_B;  // pixels staged / LDS plane pitch / DMA pieces per plane
   unsigned magic_ppp, magic_img, magic_w1;
   // conv_f8_kernel (conv_f8.hip): in / wpk are e4m3 (planes of 16 channels; cg, kkn count groups of 16 / steps of 128)
@@ -157,11 +172,8 @@ struct ConvArgs {
 struct ConvConfig {
   int MT, NT, uniform, post, ncb, cg, ksteps, kchunk, ntaps, npatches, gws, ppw;
   int f8t;           // 1: conv3_f8t_kernel (e4m3 48 -> 48 3x3: input tile in LDS, filter in registers) instead of conv_f8_kernel
-  int tile;          // > 0: conv3_tile_kernel with this many 16-pixel column tiles per wave (else conv_kernel)
   int reg;           // > 0: conv3_reg_kernel (filter in registers) with this many 16-pixel column tiles per wave
-  int pair;          // > 0: conv3_pair_kernel (64 -> 64: filter halves in the registers of two waves per SIMD)
   int cs;            // 1: conv3_cs_kernel (64 -> 64 3x3: filter in registers, output channels split between wave pairs)
-  int sw;            // 1: conv3_sw_kernel (the same split, a wave walks down a 16-pixel strip and reuses the fragments of three rows)
   int slab2;         // 1: kchunk < ksteps and the chunks alternate between two LDS buffers, filled by LDS-DMA (conv_kernel, round 5)
   int kord;          // 1: K runs plane-major (k-group = plane * 9 + tap) instead of tap-major (tap * planes + plane), see conv_choose
   int gemm;          // > 0: conv_gemm_kernel (wide 1x1: both operands staged through LDS) with this many 16-channel tiles per wave
@@ -178,21 +190,12 @@ int conv_choose_even(int batch, int Cin, int Cout, int k, int stride, int Ho, in
 void conv_pack_weights(const float* w_oihw, int Cout, int Cin_w, int k, const ConvConfig& cfg,
                        std::vector<uint16_t>* out);
 int conv_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s);
-// conv3_tile.hip: decides whether the LDS-tile kernel takes this layer (sets cfg->tile) / launches it
-void conv3_tile_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, int post, ConvConfig* cfg);
-int conv3_tile_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s);
 // conv3_reg.hip: 3x3 stride-1 convs with Cin, Cout in {32, 64}: the filter lives in the registers of every wave
 void conv3_reg_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, int post, ConvConfig* cfg);
 int conv3_reg_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s);
 // conv3_cs.hip: 3x3 stride-1 64 -> 64 convs, output channels split between wave pairs, two workgroups per CU
 void conv3_cs_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, int post, ConvConfig* cfg);
 int conv3_cs_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s);
-// conv3_sw.hip: ... and the activation fragments reused across rows (strip walk); maps of whole strips, no residual
-void conv3_sw_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, int post, ConvConfig* cfg);
-int conv3_sw_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s);
-// conv3_pair.hip: 3x3 stride-1 64 -> 64 convs, K split between the two waves of a SIMD
-void conv3_pair_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, int post, ConvConfig* cfg);
-int conv3_pair_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s);
 // conv_gemm.hip: wide 1x1 convs (Cin, Cout >= 128) as a 128/192 x 128 macro-tile GEMM, both operands through LDS by LDS-DMA
 void conv_gemm_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, ConvConfig* cfg, int cin2 = 0);
 int conv_gemm_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s);
@@ -374,7 +377,6 @@ struct BandArgs {
 };
 bool conv3_band_plan(int Cin, int Cout, int H, int W, BandArgs* a, bool post = false);
 int conv3_band_launch(const BandArgs* args, int n, int batch, hipStream_t s);
-int conv3_band64_launch(const BandArgs* args, int n, int batch, int post, hipStream_t s);
 
 // resident.hip: the PSABlock of a C2PSA layer (c = 128, two heads) in one launch, one workgroup per image
 struct PsaArgs {
