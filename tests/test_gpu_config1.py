@@ -109,3 +109,28 @@ def test_predict_jpeg_file_1080x1920(gpu_device, golden, tmp_path, source):
     ck = verdict["checks"]
     assert ck["class_exact"] and ck["nothing_unexplained"] and ck["matched_frac_vs_format"] and ck["paired_something"], verdict
     assert st_hip["max_dconf"] <= 0.12
+
+
+def test_predict_profile_true_prints_the_per_layer_table(gpu_device, caplog):
+    """``predict(profile=True)``: the reference's per-layer profiler (nn/tasks.py:155-177: time, GFLOPs, params per yaml layer, then
+    the total) on the HIP path -- every launch of the hot path timed with HIP events (yl_engine_profile_detect) and summed per
+    layer.  The table accounts for the whole network: the layers' GFLOPs add up to the architecture's known 6.48 GFLOP per
+    640 x 640 image scaled to this input, the parameters to YOLO11n's 2 624 080 (yolo11.yaml:8), and the results of
+    the call are those of a plain predict."""
+    import logging
+
+    from yololite_amd import YOLOLite
+
+    x = torch.rand(2, 3, 96, 128, generator=torch.Generator().manual_seed(3)).to(gpu_device)
+    m = YOLOLite("yolo11n.yaml")
+    plain = m.predict(x, conf=0.25, save=False, verbose=False)
+    with caplog.at_level(logging.INFO):
+        res = m.predict(x, conf=0.25, save=False, verbose=False, profile=True)
+    rows = m.predictor.layer_profile
+    assert [r["layer"] for r in rows] == list(range(24)) + ["post"]
+    assert rows[23]["module"] == "Detect" and rows[23]["launches"] >= 4 and rows[-1]["launches"] == 1
+    assert all(r["ms"] >= 0 for r in rows) and sum(r["ms"] for r in rows) > 0
+    gflops = sum(r["gflops"] for r in rows)
+    assert abs(gflops - 2 * 6.4811 * (96 * 128) / (640 * 640)) / gflops < 0.02, gflops  # two images
+    assert sum(r["params"] for r in rows) + 16 == 2624080  # (+ the DFL's frozen arange conv, block.py:60-64)
+    assert all(torch.equal(a.boxes.data, b.boxes.data) for a, b in zip(plain, res))

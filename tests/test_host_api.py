@@ -268,6 +268,17 @@ def test_result_sinks_plot_save_crop_txt_json(tmp_path):
     assert lines[0].split()[0] == "1" and len(lines[0].split()) == 6 and abs(float(lines[0].split()[1]) - 0.5) < 1e-6
     js = json.loads(r.to_json(normalize=True))
     assert js[0]["name"] == "box" and abs(js[0]["box"]["x2"] - 110 / 160) < 1e-5
+    # to_df / to_csv / to_xml / tojson (reference results.py:354-418): the summary as a table, through pandas
+    df = r.to_df()
+    assert list(df.columns) == ["name", "class", "confidence", "box"] and list(df["name"]) == ["box", "cat"]
+    assert df["box"][0] == {"x1": 50.0, "y1": 40.0, "x2": 110.0, "y2": 80.0} and abs(df["confidence"][1] - 0.4) < 1e-5
+    csv = r.to_csv(normalize=True, index=False)
+    assert csv.splitlines()[0] == "name,class,confidence,box" and csv.splitlines()[1].startswith("box,1,0.9,")
+    xml = r.to_xml()
+    assert xml.startswith("<?xml") and "<name>box</name>" in xml and "<class>1</class>" in xml
+    empty = Results(img, path="p", names={0: "a"}, boxes=torch.zeros((0, 6)))
+    assert empty.to_xml() == '<?xml version="1.0" encoding="utf-8"?>\n<root></root>' and empty.to_df().empty
+    assert json.loads(r.tojson()) == json.loads(r.to_json())  # (deprecated spelling, warns)
     with pytest.raises(ValueError):
         Results(None, path="p", names={0: "a"}, boxes=boxes[:1], orig_shape=(120, 160)).plot()
 

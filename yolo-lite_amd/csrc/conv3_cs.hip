@@ -200,14 +200,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
 
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// Round 5: the SEGMENT form.  conv3_cs_kernel's workgroups walk tiles t = wg, wg + G, ..: 1640 tiles on 512 workgroups are 3.2 per
-// workgroup -- a fifth of them does four, the launch lasts four tile periods -- , every tile re-reads its 2 (W + 1) + 2 halo positions
-// (320 staged positions for 128 computed) and its pieces are requested only once the previous tile's MFMAs have left the single
-// buffer.  Here a workgroup owns ONE contiguous run of Q positions (Q = positions / workgroups, rounded up to 32: 416 at 80x80 batch
-// 32), stages the whole run + one halo (580 positions, 74 KB: two workgroups per CU still fit) with all its LDS-DMA requests issued at
-// once, waits ONCE, and then its waves run free: no barrier between tiles, a wave's epilogue beside its neighbours' MFMAs.  The run is
-// cut into ceil(units / 4) tiles of 1..4 fragments per wave, as even as they come (13 units: 4 + 3 + 3 + 3).
-// Same operands, k order and epilogue as conv3_cs_kernel: bit-identical.
+// The tile body shared by the kernels below.  (Round 5 also built a SEGMENT form -- one contiguous run per workgroup, staged at once,
+// no barrier between tiles -- and an eight-wave form with the filter through LDS: 25.6 and 24.5 us in the network against 23.5 us for
+// the tile walk with a balanced first round; both were deleted in round 6, NOTEBOOK.md section 15 has their measurements.)
 struct CsNoMid {
   __device__ __forceinline__ void operator()() const {}
 };
@@ -375,215 +370,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
   }
 }
 
-template <bool RES, bool ACT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv3_cs2_kernel(ConvArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char csm[];
-  constexpr int KS = 18;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int h = wave >> 1, c = wave & 1;  // channel half, column of a tile
-  const int g = lane >> 4, n = lane & 15;
-  YL_STAMP(a.stamps, 4, wave, lane, 0);
-  const int seg = xcd_remap(blockIdx.x, gridDim.x);
-  const int Q = a.t_px, PL = a.t_PL, PLB = PL * 16;
-  const int p0 = seg * Q;                              // first position of the run (relative to g0)
-  const int pend = a.t_plane_px;                       // positions of the tensor, rounded up to 32
-  const int len = (p0 + Q <= pend ? Q : pend - p0);    // > 0 by the grid's size, a multiple of 32
-  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, (short)0, a.in_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.out, (short)0, a.out_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rres =
-      __builtin_amdgcn_make_buffer_rsrc((void*)a.res, (short)0, RES ? a.res_bytes : 0, 0x00020000);
-
-  // this wave's half of the filter first (it is needed first, and requests retire in order) ...
-  bf16x8 wf[KS][2];
-  if (!(a.dbg & 8)) {
-    const bf16x8* wsrc = reinterpret_cast<const bf16x8*>(a.wpk) + lane;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) wf[ks][mt] = wsrc[(ks * 4 + 2 * h + mt) * 64];
-  } else {
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt) wf[ks][mt] = bf16x8{};
-  }
-  f32x4 bias_r[2];
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt) bias_r[mt] = *reinterpret_cast<const f32x4*>(a.bias + chan_in_block(4, 2 * h + mt, g, 0));
-  // ... then the run: wave w copies planes w and w + 4, ceil((len + halo) / 64) pieces of 64 positions each; the LDS planes are
-  // PL = 64 x pieces positions apart, a piece past the slice reads zeros
-  if (!(a.dbg & 1)) {
-    const int np = (len + 2 * a.in_w1 + 2 + 63) >> 6;
-    const int src0 = (a.in_g0 + p0 - a.in_w1 - 1) * 16;  // first staged guarded position (>= 0)
-    for (int j = 0; j < np; ++j)
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int plane = wave + 4 * q;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void_c*)(csm + plane * PLB + j * 1024), 16,
-                                                 (int)((unsigned)lane * 16u + (unsigned)(plane * (int)a.in_plane + src0 + j * 1024)), 0, 0, 0);
-      }
-  }
-  const int row_bytes = a.in_w1 * 16, half_bytes = 4 * PLB;  // planes 4..7 = input channels 32..63
-  const unsigned oplane = (unsigned)(4 * h + g);              // the lane's output plane (8 channels)
-  // Each wave owns F = len / 32 fragments of 16 positions (column c: fragments c F .. c F + F - 1 of the run) and cuts them into tiles of
-  // 1..4 as even as they come.  After the one barrier the waves run free, so the two waves that share a SIMD (one of each workgroup on
-  // the CU) should not be in the same phase: a wave on an odd hardware wave slot starts with a SHORT tile (2 fragments) and reaches its
-  // first epilogue while its neighbour is still in its first MFMA phase; from there on one wave's SiLU runs beside the other's MFMAs.
-  const int F = len >> 5;
-  int phase_b = 0;
-  {
-    const int mode = a.dbg >> 4;  // (development: 1 = no de-phasing, 2 = by the workgroup's index instead of the hardware wave slot)
-    if (mode == 0) phase_b = __builtin_amdgcn_s_getreg((3 << 11) | 4) & 1;  // HW_REG_HW_ID[3:0] = wave slot of the SIMD
-    if (mode == 2) phase_b = (blockIdx.x >> 8) & 1;
-  }
-#ifdef YL_STAMPS
-  if (a.stamps && lane == 0) {  // where the wave runs: HW_ID (wave slot, SIMD, CU, SE) and the XCC
-    unsigned long long* p = a.stamps + (((size_t)blockIdx.x * 4 + wave) * 32 + 31) * 2;
-    p[0] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
-    p[1] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20);
-  }
-#endif
-  YL_STAMP(a.stamps, 4, wave, lane, 1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  YL_STAMP(a.stamps, 4, wave, lane, 2);
-  __builtin_amdgcn_s_barrier();
-  YL_STAMP(a.stamps, 4, wave, lane, 3);
-  int stamp_id = 4;
-  auto run_tile = [&](int nt, int f0) __attribute__((always_inline)) {
-    const unsigned char* const tb = csm + (g * PL + f0 * 16 + n) * 16;  // the lane's position 0 of plane g (taps add offsets)
-    const int r0 = p0 + f0 * 16;
-    switch (nt) {
-      case 4: cs2_tile<4, RES, ACT>(a, wf, bias_r, tb, r0, n, oplane, row_bytes, half_bytes, rout, rres, wave, lane, stamp_id); break;
-      case 3: cs2_tile<3, RES, ACT>(a, wf, bias_r, tb, r0, n, oplane, row_bytes, half_bytes, rout, rres, wave, lane, stamp_id); break;
-      case 2: cs2_tile<2, RES, ACT>(a, wf, bias_r, tb, r0, n, oplane, row_bytes, half_bytes, rout, rres, wave, lane, stamp_id); break;
-      default: cs2_tile<1, RES, ACT>(a, wf, bias_r, tb, r0, n, oplane, row_bytes, half_bytes, rout, rres, wave, lane, stamp_id); break;
-    }
-    YL_STAMP(a.stamps, 4, wave, lane, stamp_id + 1);
-    stamp_id += 2;
-  };
-  int done = 0;
-  if (phase_b && F > 4) {
-    run_tile(2, c * F);
-    done = 2;
-  }
-  const int rem = F - done, ntile = (rem + 3) >> 2, base = rem / ntile, extra = rem - base * ntile;
-  for (int k = 0; k < ntile; ++k) {
-    const int nt = base + (k < extra ? 1 : 0);
-    run_tile(nt, c * F + done);
-    done += nt;
-  }
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------------------------
-// Round 5, second step: ONE workgroup of eight waves per CU, the filter through LDS.  Stamps of conv3_cs2_kernel (tools/cs_stamps.py)
-// show its first 5 us as a pure load phase that the CU's vector-memory return path bounds (64 B per clock): 8 waves x 36 KB of filter
-// + 2 x 74 KB of activations = 436 KB per CU, two thirds of it the SAME 72 KB of filter eight times (4 waves per channel half).  Here
-// the CU's eight waves are one workgroup (h = channel half, c = one of four columns), the filter crosses the memory path ONCE (72 KB by
-// LDS-DMA into a region the activations overwrite later) and each wave reads its half from LDS (256 B per clock); the workgroup's run
-// of Q positions is staged as two halves with a halo each, the second half beside the filter, the first half -- whose LDS region the
-// filter occupied -- while the second is being computed.  220 KB per CU instead of 436, and only 146 KB of them in front of the first MFMA.
-// Tiles, operands, k order, epilogue: cs2_tile, bit-identical to conv_kernel.
-template <bool RES, bool ACT>
-__global__ __launch_bounds__(512) void conv3_cs3_kernel(ConvArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char csm[];
-  constexpr int KS = 18, FILTER_BYTES = KS * 4 * 1024;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int h = wave >> 2, c = wave & 3;  // channel half, column
-  const int g = lane >> 4, n = lane & 15;
-  YL_STAMP(a.stamps, 8, wave, lane, 0);
-  const int seg = xcd_remap(blockIdx.x, gridDim.x);
-  const int Q = a.t_px, Qh = Q >> 1, PL = a.t_PL, PLB = PL * 16, HB = 8 * PLB;
-  const int p0 = seg * Q;
-  const int pend = a.t_plane_px;  // positions of the tensor, rounded up to 32
-  int len[2];
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int s0 = p0 + u * Qh;
-    len[u] = s0 >= pend ? 0 : (s0 + Qh <= pend ? Qh : pend - s0);
-  }
-  const bool early = HB >= FILTER_BYTES;  // the second half's buffer lies past the filter's temporary place
-  const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void*)a.in, (short)0, a.in_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, (short)0, FILTER_BYTES, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(a.out, (short)0, a.out_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rres =
-      __builtin_amdgcn_make_buffer_rsrc((void*)a.res, (short)0, RES ? a.res_bytes : 0, 0x00020000);
-  const unsigned lane16 = (unsigned)lane * 16u;
-  // half u of the run -> its buffer: wave w copies plane w
-  auto stage = [&](int u) __attribute__((always_inline)) {
-    if (len[u] <= 0 || (a.dbg & 1)) return;
-    const int np = (len[u] + 2 * a.in_w1 + 2 + 63) >> 6;
-    const int src0 = (a.in_g0 + p0 + u * Qh - a.in_w1 - 1) * 16;  // first staged guarded position (>= 0)
-    for (int j = 0; j < np; ++j)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rin, (lds_void_c*)(csm + u * HB + wave * PLB + j * 1024), 16,
-                                               (int)(lane16 + (unsigned)(wave * (int)a.in_plane + src0 + j * 1024)), 0, 0, 0);
-  };
-  // 1. the filter (72 pieces of 1 KiB, nine per wave) and, where its buffer is free, the second half of the run
-#pragma unroll
-  for (int j = 0; j < 9; ++j)
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_void_c*)(csm + (wave * 9 + j) * 1024), 16, (int)(lane16 + (unsigned)((wave * 9 + j) * 1024)), 0, 0, 0);
-  if (early) stage(1);
-  f32x4 bias_r[2];
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt) bias_r[mt] = *reinterpret_cast<const f32x4*>(a.bias + chan_in_block(4, 2 * h + mt, g, 0));
-#ifdef YL_STAMPS
-  if (a.stamps && lane == 0) {  // where the wave runs: HW_ID (wave slot, SIMD, CU, SE) and the XCC
-    unsigned long long* p = a.stamps + (((size_t)blockIdx.x * 8 + wave) * 32 + 31) * 2;
-    p[0] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
-    p[1] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20);
-  }
-#endif
-  YL_STAMP(a.stamps, 8, wave, lane, 1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  YL_STAMP(a.stamps, 8, wave, lane, 2);
-  // 2. this wave's half of the filter, conv_pack_weights order (4 tiles per k-step): tiles 2h, 2h + 1
-  bf16x8 wf[KS][2];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) wf[ks][mt] = *reinterpret_cast<const bf16x8*>(csm + (ks * 4 + 2 * h + mt) * 1024 + lane16);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();  // everybody holds its half: the filter's place is free
-  YL_STAMP(a.stamps, 8, wave, lane, 3);
-  // 3. the first half of the run (and the second, where it could not go earlier)
-  stage(0);
-  if (!early) stage(1);
-  const int row_bytes = a.in_w1 * 16, half_bytes = 4 * PLB;  // planes 4..7 = input channels 32..63
-  const unsigned oplane = (unsigned)(4 * h + g);              // the lane's output plane (8 channels)
-  int stamp_id = 4;
-  auto run_half = [&](int u) __attribute__((always_inline)) {
-    const int F = len[u] >> 4;                     // fragments of 16 positions in this half
-    const int lo = (c * F) >> 2, hi = ((c + 1) * F) >> 2;
-    const int cnt = hi - lo;
-    if (cnt <= 0) return;
-    const int ntile = (cnt + 3) >> 2, base = cnt / ntile, extra = cnt - base * ntile;
-    int f0 = lo;
-    for (int k = 0; k < ntile; ++k) {
-      const int nt = base + (k < extra ? 1 : 0);
-      const unsigned char* const tb = csm + u * HB + (g * PL + f0 * 16 + n) * 16;  // the lane's position 0 of plane g
-      const int r0 = p0 + u * Qh + f0 * 16;
-      switch (nt) {
-        case 4: cs2_tile<4, RES, ACT>(a, wf, bias_r, tb, r0, n, oplane, row_bytes, half_bytes, rout, rres, wave, lane, stamp_id); break;
-        case 3: cs2_tile<3, RES, ACT>(a, wf, bias_r, tb, r0, n, oplane, row_bytes, half_bytes, rout, rres, wave, lane, stamp_id); break;
-        case 2: cs2_tile<2, RES, ACT>(a, wf, bias_r, tb, r0, n, oplane, row_bytes, half_bytes, rout, rres, wave, lane, stamp_id); break;
-        default: cs2_tile<1, RES, ACT>(a, wf, bias_r, tb, r0, n, oplane, row_bytes, half_bytes, rout, rres, wave, lane, stamp_id); break;
-      }
-      YL_STAMP(a.stamps, 8, wave, lane, stamp_id + 1);
-      stamp_id += 2;
-      f0 += nt;
-    }
-  };
-  if (early) run_half(1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  YL_STAMP(a.stamps, 8, wave, lane, 30);
-  run_half(0);
-  if (!early) run_half(1);
-}
-
 // ------------------------------------------------------------------------------------ host
 static unsigned cs_magic(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull / (unsigned)d) + 1ull); }
 
@@ -621,24 +407,6 @@ static int launch_cs1b(const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
   return 0;
 }
 
-template <bool RES, bool ACT>
-static int launch_cs2(const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
-  auto kern = conv3_cs2_kernel<RES, ACT>;
-  if (int rc = allow_big_lds(reinterpret_cast<const void*>(kern), (int)(160 * 1024))) return rc;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, a);
-  YL_HIP(hipGetLastError());
-  return 0;
-}
-
-template <bool RES, bool ACT>
-static int launch_cs3(const ConvArgs& a, int grid, size_t lds, hipStream_t s) {
-  auto kern = conv3_cs3_kernel<RES, ACT>;
-  if (int rc = allow_big_lds(reinterpret_cast<const void*>(kern), (int)(160 * 1024))) return rc;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, a);
-  YL_HIP(hipGetLastError());
-  return 0;
-}
-
 int conv3_cs_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s) {
   if (a.stride != 1 || a.out_f32 || a.in2 || a.wpk2 || a.out8 || a.in_w1 != a.out_w1 || a.in_img != a.out_img ||
       a.in_g0 != a.out_g0 || a.in_w1 != a.Wo + 1 || a.Cin != 64 || a.Cout != 64)
@@ -659,42 +427,6 @@ int conv3_cs_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s)
   a.res_bytes = (unsigned)resb;
   a.dbg = tune_int("YL_CONV_DBG", 0);
   const int resident = 2 * device_cu_count();  // two persistent workgroups per CU
-  {
-    // one eight-wave workgroup per CU, the filter through LDS, the run in two halves (conv3_cs3_kernel)
-    const int v3 = tune_int("YL_CS_V3", 0);  // (measured: 24.5 us in the network against 23.5 of the tile-walking form)
-    const int ncu = device_cu_count();
-    const long long nq32 = (nq + 31) & ~31LL;
-    const int Q = (int)(((nq32 + ncu - 1) / ncu + 63) & ~63LL);
-    const int PLh = (Q / 2 + 2 * a.in_w1 + 2 + 63) & ~63;
-    size_t lds3 = (size_t)2 * 8 * PLh * 16;
-    if (v3 && lds3 <= 160 * 1024) {
-      if (lds3 < 18 * 4 * 1024) lds3 = 18 * 4 * 1024;  // the filter's temporary place
-      a.t_px = Q;
-      a.t_PL = PLh;
-      a.t_plane_px = (int)nq32;
-      a.stamps = g_stamp_buf;
-      const int grid3 = (int)((nq32 + Q - 1) / Q);
-      if (a.res) return a.act ? launch_cs3<true, true>(a, grid3, lds3, s) : launch_cs3<true, false>(a, grid3, lds3, s);
-      return a.act ? launch_cs3<false, true>(a, grid3, lds3, s) : launch_cs3<false, false>(a, grid3, lds3, s);
-    }
-  }
-  {
-    // segment form: one contiguous run per workgroup, when run + halo of two workgroups fit a CU's LDS
-    const int v2 = tune_int("YL_CS_V2", 0);  // (measured: 25.6 us in the network)
-    const long long nq32 = (nq + 31) & ~31LL;
-    const int Q = (int)(((nq32 + resident - 1) / resident + 31) & ~31LL);
-    const int PL2 = (Q + 2 * a.in_w1 + 2 + 63) & ~63;
-    const size_t lds2 = (size_t)8 * PL2 * 16;
-    if (v2 && lds2 <= 80 * 1024) {
-      a.t_px = Q;
-      a.t_PL = PL2;
-      a.t_plane_px = (int)nq32;
-      a.stamps = g_stamp_buf;
-      const int grid2 = (int)((nq32 + Q - 1) / Q);
-      if (a.res) return a.act ? launch_cs2<true, true>(a, grid2, lds2, s) : launch_cs2<true, false>(a, grid2, lds2, s);
-      return a.act ? launch_cs2<false, true>(a, grid2, lds2, s) : launch_cs2<false, false>(a, grid2, lds2, s);
-    }
-  }
   const size_t lds = (size_t)8 * a.t_PL * 16;
   {
     // tile-walking form with a balanced (short, first) round

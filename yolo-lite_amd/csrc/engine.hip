@@ -905,7 +905,7 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
   // ---- which launches produce the class logits of the Detect levels (the NMS candidate pre-filter rides in their epilogue)
   {
     size_t found = 0;
-    static const int conv_pf = tune_int("YL_FUSE_PREFILTER_CONV", 1);
+    static const int conv_pf = env_int("YL_FUSE_PREFILTER_CONV", 1);
     for (OpRec& r : e->ops) {
       // the fused depthwise + pointwise + 1x1 launch of the class branch (YOLO11n), or -- where the branch is too wide for it --
       // the plain 1x1 conv that ends it (conv_kernel's PF instantiation)
@@ -922,7 +922,7 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
         }
       }
     }
-    static const int fuse_pf = tune_int("YL_FUSE_PREFILTER", 1);
+    static const int fuse_pf = env_int("YL_FUSE_PREFILTER", 1);
     e->cls_tails = fuse_pf && !e->levels.empty() && found == e->levels.size() && (e->max_lane == 0 || e->lane_graphs);
   }
   // ---- group launches: runs of consecutive ops with the same yl_op.group > 0 (the lowering puts the Detect levels'
@@ -2072,7 +2072,7 @@ extern "C" int yl_graph_launch_many(void* const* graphs, void* const* streams, i
   if (!graphs || !streams || n < 0) return fail(-1, "yl_graph_launch_many: bad arguments");
   for (int i = 0; i < n; ++i)
     if (!graphs[i]) return fail(-1, "yl_graph_launch_many: null graph");
-  static const int threads_env = env_int("YL_ISSUE_THREADS", 4);
+  static const int threads_env = tune_int("YL_ISSUE_THREADS", 4);
   const int parts = threads_env < 1 ? 1 : threads_env > IssuePool::NW + 1 ? IssuePool::NW + 1 : threads_env;
   // distinct streams in order of first appearance; stream k goes to part k % parts
   std::vector<void*> seen;

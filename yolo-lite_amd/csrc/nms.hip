@@ -1244,7 +1244,7 @@ int yl::decode_nms_stages(const void* workspace, const yl_level* levels, int n_l
     const bool one_launch = one_launch_env >= 0 ? one_launch_env != 0 : batch >= 16;
     if (one_launch) {  // exact decode + sort + mask + scan in one launch, one workgroup per image
       static const int stop_after = tune_int("YL_NMS_DBG", 0);
-      static const int lds_path = tune_int("YL_NMS_LDS", 1);  // (0: the general path for every image)
+      static const int lds_path = env_int("YL_NMS_LDS", 1);  // (0: the general path for every image)
       auto kern = n_levels <= 3 ? decode_nms_fused_kernel<3> : decode_nms_fused_kernel<8>;
       hipLaunchKernelGGL(kern, dim3(batch), dim3(1024), 0, s, a, w, iou_thres, max_det, agnostic, max_wh, scale, out, out_count,
                          stop_after, lds_path, g_stamp_buf);

@@ -331,6 +331,11 @@ class DetectionPredictor:
                 paths, im0s, s = self.batch
                 with profilers[0]:
                     im = self.preprocess(im0s)
+                if getattr(self.args, "profile", False) and not self.__dict__.get("_profiled", False):
+                    # predict(profile=True): the per-layer table of the first batch (reference nn/tasks.py:155-177 prints it from
+                    # inside the layer loop; here the launches are timed with HIP events by yl_engine_profile_detect)
+                    self._profiled = True
+                    self.layer_profile = self.model.profile_layers(im if im.dtype != torch.float64 else im.float())
                 if self._can_fuse():
                     with profilers[1]:  # network + fused decode / NMS / box rescale, one host sync
                         # (a non-contiguous tensor gets a .contiguous() copy enqueued on the CURRENT stream in

@@ -197,7 +197,35 @@ class Results(SimpleClass):
     def to_json(self, normalize=False, decimals=5):
         return json.dumps(self.summary(normalize=normalize, decimals=decimals), indent=2)
 
-    tojson = to_json
+    def tojson(self, normalize=False, decimals=5):
+        """Deprecated spelling of ``to_json`` (reference results.py:415-418 warns the same way)."""
+        from ..utils import LOGGER
+
+        LOGGER.warning("WARNING 'result.tojson()' is deprecated, replace with 'result.to_json()'.")
+        return self.to_json(normalize, decimals)
+
+    def to_df(self, normalize=False, decimals=5):
+        """``summary()`` as a pandas DataFrame: columns name, class, confidence, box (reference results.py:354-371)."""
+        import pandas as pd
+
+        return pd.DataFrame(self.summary(normalize=normalize, decimals=decimals))
+
+    def to_csv(self, normalize=False, decimals=5, *args, **kwargs):
+        """CSV text of ``to_df`` (extra arguments go to ``DataFrame.to_csv``; reference results.py:373-392)."""
+        return self.to_df(normalize=normalize, decimals=decimals).to_csv(*args, **kwargs)
+
+    def to_xml(self, normalize=False, decimals=5, *args, **kwargs):
+        """XML text of ``to_df`` (extra arguments go to ``DataFrame.to_xml``; an empty result gives the reference's empty document,
+        results.py:394-413).  The reference insists on lxml; without it pandas' built-in ``etree`` writer produces the same document."""
+        df = self.to_df(normalize=normalize, decimals=decimals)
+        if df.empty:
+            return '<?xml version="1.0" encoding="utf-8"?>\n<root></root>'
+        if "parser" not in kwargs:
+            try:
+                import lxml  # noqa: F401
+            except ImportError:
+                kwargs["parser"] = "etree"
+        return df.to_xml(*args, **kwargs)
 
     def save_txt(self, txt_file, save_conf=False):
         """Append 'cls cx cy w h [conf]' lines, normalised (reference results.py:265-290)."""
@@ -221,8 +249,6 @@ class Results(SimpleClass):
         from ..utils.plotting import Annotator, colors
 
         assert color_mode in {"instance", "class"}, f"Expected color_mode='instance' or 'class', not {color_mode}."
-        if show:
-            raise NotImplementedError("show=True needs a display (cv2.imshow); save the image instead")
         if img is None:
             img = self.orig_img
             if isinstance(img, torch.Tensor):  # (1, 3, H, W) RGB in [0, 1] -> HWC BGR uint8
@@ -236,9 +262,15 @@ class Results(SimpleClass):
                 name = self.names[c]
                 label = (f"{name} {float(d.conf):.2f}" if conf else name) if labels else None
                 ann.box_label(d.xyxy.reshape(-1), label, color=colors(c if color_mode == "class" else i))
+        if show:  # (reference results.py:205-206 annotator.show(): cv2.imshow there, the platform's image viewer through PIL here)
+            ann.im.show(title=str(self.path or "image0"))
         if save:
             ann.im.save(filename or f"results_{Path(self.path or 'image0').stem}.jpg")
         return ann.im if pil else ann.result()[..., ::-1].copy()
+
+    def show(self, *args, **kwargs):
+        """Display the annotated image (reference results.py:215-226: ``plot(show=True, ...)``)."""
+        self.plot(show=True, *args, **kwargs)
 
     def save(self, filename=None, *args, **kwargs):
         """Save the annotated image (reference results.py: save)."""

@@ -141,50 +141,54 @@ class DetectionValidator:
         return predn
 
     def match_predictions(self, pred_classes, true_classes, iou):
-        """(N, 10) bool: is detection n a true positive at IoU threshold t (validator.py:192-229, the numpy
-        branch): class-matched pairs above the threshold, best IoU first, each label and each detection once."""
-        correct = np.zeros((pred_classes.shape[0], self.niou), dtype=bool)
-        iou = (iou * (true_classes[:, None] == pred_classes)).cpu().numpy()
-        for i, thr in enumerate(self.iouv.tolist()):
-            m = np.array(np.nonzero(iou >= thr)).T  # (label, detection)
-            if m.shape[0]:
-                if m.shape[0] > 1:
-                    m = m[iou[m[:, 0], m[:, 1]].argsort()[::-1]]
-                    m = m[np.unique(m[:, 1], return_index=True)[1]]
-                    m = m[np.unique(m[:, 0], return_index=True)[1]]
-                correct[m[:, 1].astype(int), i] = True
-        return torch.tensor(correct, dtype=torch.bool, device=pred_classes.device)
+        """(N, T) bool: is detection n a true positive at IoU threshold t.  Same outcome as the reference's matching
+        (validator.py:192-229: per threshold, pairs of one class above the threshold sorted by IoU, one label per detection, then
+        one detection per label) computed for all T thresholds at once from two facts about that procedure: a detection's partner is
+        its best-overlapping label of its own class whatever the threshold (the threshold only decides whether the pair counts),
+        and a label wanted by several detections goes to the one with the LOWEST index (the reference's second ``np.unique`` runs
+        over rows already re-ordered by detection index) -- i.e. the most confident one, detections being score-sorted."""
+        n, dev = pred_classes.shape[0], pred_classes.device
+        T = self.niou
+        correct = torch.zeros((n, T), dtype=torch.bool, device=dev)
+        L = true_classes.shape[0]
+        if n == 0 or L == 0:
+            return correct
+        same = iou * (true_classes[:, None] == pred_classes[None, :]).to(iou.dtype)   # (L, n): IoU where the classes agree, else 0
+        best_iou, partner = same.max(0)                                                 # per detection
+        counts = best_iou[:, None] >= self.iouv.to(device=dev, dtype=iou.dtype)[None, :]  # (n, T): the pair counts at threshold t
+        det = torch.arange(n, device=dev)[:, None].expand(n, T)
+        claim = torch.where(counts, det, torch.full_like(det, n))
+        winner = torch.full((L, T), n, dtype=det.dtype, device=dev)
+        winner.scatter_reduce_(0, partner[:, None].expand(n, T), claim, reduce="amin")  # lowest claiming detection per (label, t)
+        return counts & (winner[partner] == det)
 
     def _process_batch(self, detections, gt_bboxes, gt_cls):
         return self.match_predictions(detections[:, 5], gt_cls, box_iou(gt_bboxes, detections[:, :4]))
 
     def update_metrics(self, preds, batch):
+        """One statistics record per image (reference validator.py:313-360): confidences, predicted classes, the (n, T) true-positive
+        table against the image's labels, the labels' classes.  An image with neither detections nor labels leaves no record."""
+        empty = torch.zeros(0, device=self.device)
         for si, pred in enumerate(preds):
             self.seen += 1
-            npr = len(pred)
-            stat = dict(conf=torch.zeros(0, device=self.device), pred_cls=torch.zeros(0, device=self.device),
-                        tp=torch.zeros(npr, self.niou, dtype=torch.bool, device=self.device))
-            pbatch = self._prepare_batch(si, batch)
-            cls, bbox = pbatch.pop("cls"), pbatch.pop("bbox")
-            stat["target_cls"] = cls
-            stat["target_img"] = cls.unique()
-            if npr == 0:
-                if len(cls):
-                    for k in self.stats:
-                        self.stats[k].append(stat[k])
+            labels = self._prepare_batch(si, batch)
+            gt_cls, gt_box = labels["cls"], labels["bbox"]
+            n = len(pred)
+            if n == 0 and len(gt_cls) == 0:
                 continue
-            if self.args.single_cls:
+            if n and self.args.single_cls:
                 pred[:, 5] = 0
-            predn = self._prepare_pred(pred, pbatch)
-            stat["conf"], stat["pred_cls"] = predn[:, 4], predn[:, 5]
-            if len(cls):
-                stat["tp"] = self._process_batch(predn, bbox, cls)
-            for k in self.stats:
-                self.stats[k].append(stat[k])
-            if self.args.save_json:
+            predn = self._prepare_pred(pred, labels) if n else pred
+            tp = self._process_batch(predn, gt_box, gt_cls) if (n and len(gt_cls)) else torch.zeros(n, self.niou, dtype=torch.bool,
+                                                                                                     device=self.device)
+            record = dict(tp=tp, conf=predn[:, 4] if n else empty, pred_cls=predn[:, 5] if n else empty, target_cls=gt_cls,
+                          target_img=gt_cls.unique())
+            for k, v in record.items():
+                self.stats[k].append(v)
+            if n and self.args.save_json:
                 self.pred_to_json(predn, batch["im_file"][si])
-            if self.args.save_txt:
-                self.save_one_txt(predn, self.args.save_conf, pbatch["ori_shape"],
+            if n and self.args.save_txt:
+                self.save_one_txt(predn, self.args.save_conf, labels["ori_shape"],
                                   self.save_dir / "labels" / f'{Path(batch["im_file"][si]).stem}.txt')
 
     def finalize_metrics(self, *args, **kwargs):

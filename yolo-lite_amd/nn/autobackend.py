@@ -125,6 +125,43 @@ class AutoBackend:
 
     __call__ = forward
 
+    def profile_layers(self, im: torch.Tensor, iters: int = 10, log: bool = True):
+        """Per-LAYER profile of one batch, the table ``BaseModel._profile_one_layer`` prints with ``predict(profile=True)`` (reference
+        nn/tasks.py:155-177: ``time (ms)  GFLOPs  params  module`` per layer of the yaml, then the total): HIP-event time of every
+        launch of the hot path (``yl_engine_profile_detect``), summed per yolo11.yaml layer.  A launch that fuses several layers (the
+        stem launch = layers 0 + 1 + the next C3k2's cv1) is charged to its first layer; ``Detect`` gets its branches' launches and
+        ``(post)`` the decode + NMS launch, which the reference times outside the model.  Returns the rows as dicts."""
+        import re
+
+        from ..utils import LOGGER
+        from .arch import conv_units
+
+        if im.device != self.device:
+            im = im.to(self.device)
+        im = im.contiguous()
+        b, _, h, w = im.shape
+        eng = self.engine_for(b, h, w, calib=im)
+        specs = self.model.specs
+        params = {sp.i: 0 for sp in specs}
+        for u in conv_units(specs):
+            li = int(u.name.split(".")[1])
+            params[li] += u.c2 * (u.c1 // u.g) * u.k * u.k + (2 * u.c2 if u.bn else u.c2)
+        per = {sp.i: dict(layer=sp.i, module=sp.kind, ms=0.0, gflops=0.0, params=params[sp.i], launches=0) for sp in specs}
+        post = dict(layer="post", module="decode + NMS (one launch)", ms=0.0, gflops=0.0, params=0, launches=0)
+        for r in eng.profile_detect(im, iters=iters):
+            m = re.match(r"model\.(\d+)", r["name"])
+            row = per[int(m.group(1))] if m else post
+            row["ms"] += r["ms"]
+            row["gflops"] += r["flops"] / 1e9
+            row["launches"] += 1
+        rows = [per[sp.i] for sp in specs] + [post]
+        if log:
+            LOGGER.info(f"{'time (ms)':>10s} {'GFLOPs':>10s} {'params':>10s}  module")
+            for r in rows:
+                LOGGER.info(f"{r['ms']:10.3f} {r['gflops']:10.2f} {r['params']:10.0f}  {r['layer']}: {r['module']} ({r['launches']} launches)")
+            LOGGER.info(f"{sum(r['ms'] for r in rows):10.3f} {'-':>10s} {'-':>10s}  Total (batch {b}, {h}x{w}, in-sequence HIP events)")
+        return rows
+
     def from_numpy(self, x):
         import numpy as np
 
