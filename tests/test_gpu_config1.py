@@ -128,7 +128,7 @@ def test_predict_profile_true_prints_the_per_layer_table(gpu_device, caplog):
         res = m.predict(x, conf=0.25, save=False, verbose=False, profile=True)
     rows = m.predictor.layer_profile
     assert [r["layer"] for r in rows] == list(range(24)) + ["post"]
-    assert rows[23]["module"] == "Detect" and rows[23]["launches"] >= 4 and rows[-1]["launches"] == 1
+    assert rows[23]["module"] == "Detect" and rows[23]["launches"] >= 4 and rows[-1]["launches"] in (1, 4)  # (one launch from batch 16 up, else decode, sort, mask, scan)
     assert all(r["ms"] >= 0 for r in rows) and sum(r["ms"] for r in rows) > 0
     gflops = sum(r["gflops"] for r in rows)
     assert abs(gflops - 2 * 6.4811 * (96 * 128) / (640 * 640)) / gflops < 0.02, gflops  # two images

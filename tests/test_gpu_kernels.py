@@ -263,6 +263,52 @@ def test_dfl_epilogue_vs_torch(gpu_device, form, cin, B, h, w, stride, keep):
         assert torch.equal(y[:, :4].cpu(), got)
 
 
+@pytest.mark.parametrize("B,h,w,stride,keep", [(2, 20, 24, 8.0, True), (3, 7, 9, 16.0, False), (32, 80, 80, 8.0, False), (5, 33, 150, 8.0, True),
+                                                (8, 79, 79, 8.0, False)])
+def test_conv3_cs_post_dfl_vs_conv_kernel(gpu_device, monkeypatch, B, h, w, stride, keep):
+    """Detect's cv2[i][1] + cv2[i][2] + box decode on the Cout-split filter-in-registers kernel (conv3_cs1b_kernel's POST form,
+    round 6: the waves exchange their t2 halves through LDS, the 1x1 filter is read from LDS, dfl_box on the fp32 accumulators)
+    against conv_kernel's POST + DFL form of the same op: boxes (and, kept, the bf16 logits) bit for bit -- same operands, same k
+    order, same accumulation chains.  The last case fills whole rounds of 128-position tiles (no short first round)."""
+    g = torch.Generator().manual_seed(B + h + w)
+    x = _rand(g, B, 64, h, w)
+    w1 = _rand(g, 64, 64, 3, 3, scale=1.0 / math.sqrt(64 * 9))
+    b1 = torch.randn(64, generator=g) * 0.5
+    w2 = _rand(g, 64, 64, 1, 1, scale=2.0 / math.sqrt(64))
+    b2 = torch.randn(64, generator=g)
+
+    def run(cs):
+        monkeypatch.setenv("YL_CONV_CS", "1" if cs else "0")
+        monkeypatch.setenv("YL_CONV_CS_MIN", "1")
+        m = Mini(B, gpu_device)
+        xin, yo, cls = m.buf(h, w, 64), m.buf(h, w, 64), m.buf(h, w, 80)
+        off = m.ar.alloc_bytes(B * h * w * 16)
+        m.prog.levels.append(dict(offset=yo.offset if keep else -1, offset_cls=cls.offset, offset_xywh=off, nc8=80, H=h, W=w, stride=stride))
+        m.prog.anchors = h * w
+        m.fill(xin, x)
+        m.op(kind=OP_CONV, name="t", k=3, stride=1, act=1, inp=xin, out=yo, weight=np.ascontiguousarray(w1.numpy()),
+             bias=np.ascontiguousarray(b1.numpy()), post_weight=np.ascontiguousarray(w2.numpy().reshape(64, 64)),
+             post_bias=np.ascontiguousarray(b2.numpy()), post_act=0, dfl_level=1, dfl_keep=int(keep))
+        m.run()
+        assert m.eng.op_kernel(0) == ("conv3x3_cs+1x1+dfl_mfma" if cs else "conv3x3_mfma"), m.eng.op_kernel(0)
+        return m.eng.level_boxes()[0].cpu(), (m.read(yo) if keep else None)
+
+    box_cs, log_cs = run(True)
+    box_ck, log_ck = run(False)
+    assert torch.equal(box_cs, box_ck), float((box_cs - box_ck).abs().max())
+    if keep:
+        assert torch.equal(log_cs, log_ck)
+    # ... and against torch (as test_dfl_epilogue_vs_torch)
+    from oracle import yolo11_oracle as oracle
+
+    mid = bf16_round(F.silu(F.conv2d(x, w1, b1, 1, 1)))
+    logits = F.conv2d(mid, w2, b2)
+    anchors, _ = oracle.make_anchors([(h, w)], [stride])
+    ref = oracle.dist2bbox_xywh(oracle.dfl(logits.reshape(B, 64, h * w)), anchors.transpose(0, 1).unsqueeze(0)) * stride
+    err = (box_cs - ref).abs()
+    assert bool((err <= 2e-4 * stride + 1e-5 * ref.abs() + 0.02 * stride).all()), float(err.max())
+
+
 def test_conv_reads_through_upsample_concat(gpu_device):
     """1x1 conv over cat(upsample(lo), skip): the conv reads `lo` itself (yl_op.in2); bit-identical to the
     conv over a materialised concat buffer."""

@@ -568,7 +568,7 @@ def test_level_group_launches_are_bit_identical(gpu_device, monkeypatch, h, w, m
     else:
         # (mode 2: levels 1 and 2 of the first box conv as a pair -- conv3_band_kernel where the maps fit its tiling)
         first = {"conv3x3_mfma[x3]"} if mode == "1" else {"conv3x3_mfma[x2]", "conv3x3_band_mfma[x2]"}
-        second = {"conv3x3+1x1_mfma[x3]", "conv3x3+1x1_band_mfma[x3]"}  # (the band kernel where the maps fit its tiling)
+        second = {"conv3x3+1x1_mfma[x3]", "conv3x3_cs+1x1+dfl_mfma[x3]"}  # (the filter-in-registers form from 512 tiles of 128 positions up)
         assert first & set(names) and second & set(names) and "dw3x3+pw1x1+1x1_mfma[x3]" in names
     out, cnt = eng.detect(x, 0.25, 0.7, max_det=300)
     out, cnt = out.clone(), cnt.clone()
@@ -859,3 +859,27 @@ def test_pre_nms_at_realistic_logit_scale_vs_reference_goldens_v2(gpu_device, ta
     fpx = (y16[:, :, ::sub][:, :4] - ref[:, :4]).abs()
     print(f"{tag}: bf16-storage emulation vs reference golden: max box error {float(fpx.max()):.3f} px = {float((fpx / st).max()):.3f} strides")
     assert float((dpx / st).max()) <= FMT_RATIO * float((fpx / st).max()) + 0.02, (float((dpx / st).max()), float((fpx / st).max()))
+
+
+@pytest.mark.parametrize("B,h,w", [(8, 640, 640), (16, 384, 640)])
+def test_box_branch_tail_on_the_cs_group_kernel_is_bit_identical(gpu_device, monkeypatch, B, h, w):
+    """The three levels' cv2[i][1] + cv2[i][2] + box decode as ONE launch of the Cout-split filter-in-registers kernel
+    (conv3_csg_kernel, round 6: the resident workgroups dealt to the levels in proportion to their tiles) against the
+    conv_group_kernel form (YL_CONV_CS=0): decoded boxes, class logits, the (B, 84, A) tensor and the detections bit for bit."""
+    sd = synth_state_dict("n", 13, cls_bias=[-3.0, -3.0, -3.0], cls_gain=6.0)
+    x = torch.randint(0, 256, (B, 3, h, w), generator=torch.Generator().manual_seed(B + h), dtype=torch.uint8).to(gpu_device)
+    eng = _engine("n", sd, B, h, w, gpu_device)
+    names = [eng.op_kernel(i) for i in range(len(eng.prog.ops))]
+    assert "conv3x3_cs+1x1+dfl_mfma[x3]" in names, names
+    y = eng.forward(x).clone()
+    out, cnt = (t.clone() for t in eng.detect(x, 0.25, 0.7, max_det=300, graph=True))
+    lv = [t.clone() for t in eng.head_outputs()]
+    monkeypatch.setenv("YL_CONV_CS", "0")
+    ref = _engine("n", sd, B, h, w, gpu_device)
+    rnames = [ref.op_kernel(i) for i in range(len(ref.prog.ops))]
+    assert "conv3x3+1x1_mfma[x3]" in rnames and not any("_cs" in k for k in rnames), rnames
+    assert torch.equal(y, ref.forward(x))
+    o2, c2 = ref.detect(x, 0.25, 0.7, max_det=300, graph=False)
+    assert torch.equal(cnt, c2) and all(torch.equal(out[i, : int(cnt[i])], o2[i, : int(cnt[i])]) for i in range(B))
+    for a, b in zip(lv, ref.head_outputs()):
+        assert torch.equal(a, b)

@@ -332,43 +332,51 @@ __device__ __forceinline__ void epilogue(const ConvArgs& a, __amdgpu_buffer_rsrc
 // (bins 0..7) + (bins 8..15) in both lanes.  Lanes g = 0, 1 then hold (l, r), lanes g = 2, 3 (t, b): centre and extent per axis
 // with box_xywh's arithmetic, one exchange across 32 lanes, and lane g = 0 stores the anchor's 16 bytes; 16 lanes = 256 contiguous
 // bytes.  first = index (over the batch, patch_setup's order = b * Ho * Wo + y * Wo + x) of the wave's first pixel.
+// (dfl_box: one 16-pixel tile -- t[mt] = the four channel tiles' accumulators of the tile; (ax, ay) = the anchor coordinates of the
+// lane's pixel, tal.py:326-338 make_anchors: (x + 0.5, y + 0.5).  The box is valid in the lanes g == 0; every lane of the wave must call.)
+__device__ __forceinline__ float4 dfl_box(const f32x4 (&t)[4], int g, float ax, float ay, float stride) {
+  const float j0 = (float)((g & 1) * 8);
+  float d[2];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    float v[8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      v[r] = t[2 * p][r];
+      v[4 + r] = t[2 * p + 1][r];
+    }
+    float m = v[0];
+#pragma unroll
+    for (int j = 1; j < 8; ++j) m = fmaxf(m, v[j]);
+    m = fmaxf(m, __shfl_xor(m, 16));
+    float sum = 0.f, ws = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float e = expf(v[j] - m);
+      sum += e;
+      ws += e * (j0 + (float)j);
+    }
+    const float sum2 = __shfl_xor(sum, 16), ws2 = __shfl_xor(ws, 16);
+    const bool hi = (g & 1) != 0;
+    d[p] = ((hi ? ws2 : ws) + (hi ? ws : ws2)) / ((hi ? sum2 : sum) + (hi ? sum : sum2));
+  }
+  const float ac = (g >> 1) ? ay : ax;
+  const float lo = ac - d[0], hi2 = ac + d[1];
+  const float ctr = ((lo + hi2) / 2.0f) * stride, ext = (hi2 - lo) * stride;
+  const float cy = __shfl_xor(ctr, 32), eh = __shfl_xor(ext, 32);
+  return make_float4(ctr, cy, ext, eh);
+}
+
 template <int NT>
 __device__ __forceinline__ void dfl_epilogue(const ConvArgs& a, int first, int g, int n, const f32x4 (&acc)[4][NT]) {
   const int hw = a.Ho * a.Wo;
-  const float j0 = (float)((g & 1) * 8);
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
-    float d[2];
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      float v[8];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        v[r] = acc[2 * p][nt][r];
-        v[4 + r] = acc[2 * p + 1][nt][r];
-      }
-      float m = v[0];
-#pragma unroll
-      for (int j = 1; j < 8; ++j) m = fmaxf(m, v[j]);
-      m = fmaxf(m, __shfl_xor(m, 16));
-      float sum = 0.f, ws = 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float e = expf(v[j] - m);
-        sum += e;
-        ws += e * (j0 + (float)j);
-      }
-      const float sum2 = __shfl_xor(sum, 16), ws2 = __shfl_xor(ws, 16);
-      const bool hi = (g & 1) != 0;
-      d[p] = ((hi ? ws2 : ws) + (hi ? ws : ws2)) / ((hi ? sum2 : sum) + (hi ? sum : sum2));
-    }
+    const f32x4 t[4] = {acc[0][nt], acc[1][nt], acc[2][nt], acc[3][nt]};
     const int gp = first + nt * 16 + n;
     const int r = gp - (gp / hw) * hw, oy = r / a.Wo, ox = r - oy * a.Wo;
-    const float ac = (float)((g >> 1) ? oy : ox) + 0.5f;  // tal.py:326-338 make_anchors: (x + 0.5, y + 0.5)
-    const float lo = ac - d[0], hi2 = ac + d[1];
-    const float ctr = ((lo + hi2) / 2.0f) * a.dfl_stride, ext = (hi2 - lo) * a.dfl_stride;
-    const float cy = __shfl_xor(ctr, 32), eh = __shfl_xor(ext, 32);
-    if (g == 0 && gp < a.npix) *reinterpret_cast<float4*>(a.dfl_out + 4LL * gp) = make_float4(ctr, cy, ext, eh);
+    const float4 bx = dfl_box(t, g, (float)ox + 0.5f, (float)oy + 0.5f, a.dfl_stride);
+    if (g == 0 && gp < a.npix) *reinterpret_cast<float4*>(a.dfl_out + 4LL * gp) = bx;
   }
 }
 

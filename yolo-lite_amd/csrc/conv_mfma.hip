@@ -1232,7 +1232,10 @@ int conv_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s) {
   const bool plain = a.stride == 1 && !a.out_f32 && !a.in2 && !a.wpk2 && !a.out8 && a.in_w1 == a.out_w1 &&
                      a.in_img == a.out_img && a.in_g0 == a.out_g0 && a.in_w1 == a.Wo + 1;
   if (cfg.gemm) return conv_gemm_launch(cfg, a, batch, s);  // chosen by the engine with the views known: no fallback needed
-  if (cfg.cs && plain) return conv3_cs_launch(cfg, a, batch, s);
+  if (cfg.cs == 1 && plain) return conv3_cs_launch(cfg, a, batch, s);
+  if (cfg.cs == 2 && a.wpk2 && a.dfl_out && a.stride == 1 && !a.out_f32 && !a.in2 && !a.out8 && a.in_w1 == a.out_w1 &&
+      a.in_img == a.out_img && a.in_g0 == a.out_g0 && a.in_w1 == a.Wo + 1)
+    return conv3_cs_launch(cfg, a, batch, s);
   if (cfg.reg && plain) return conv3_reg_launch(cfg, a, batch, s);
   if (int rc = conv_prepare(cfg, a, batch)) return rc;
   return cfg.ntaps == 9 ? launch_m<3>(cfg, a, s) : launch_m<1>(cfg, a, s);

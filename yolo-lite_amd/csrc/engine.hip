@@ -81,6 +81,7 @@ struct OpRec {
   int cls_level = -1;  // fused depthwise + pointwise + 1x1 that writes the class logits of this Detect level (else -1)
   int group_n = 0;  // group launch (yl_op.group): 2 or 3 on the first member, -1 on the others (run with it), 0 = on its own
   bool band = false;  // (first member of a group) the group runs on conv3_band_kernel: deep-K 3x3 convs, 64 output channels
+  bool csg = false;   // ... on conv3_csg_kernel: the levels' cv2[i][1] + cv2[i][2] + box decode, filter halves in registers
   double flops = 0, bytes = 0;
   const char* name = "";
 };
@@ -473,6 +474,10 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
         }
         if (o.dfl_level && (r.cfg.MT != 4 || r.cfg.ncb != 1))
           return fail(-3, tag + ": the DFL epilogue needs the conv's 64 channels as four tiles of one wave");
+        // Detect's cv2[i][1] + cv2[i][2] + decode on its own (not a member of a level group): the Cout-split filter-in-registers
+        // kernel's form of it where the map is large enough (level 0 at 640x640 from batch 8 up); same packed filters
+        if (o.dfl_level && post && o.group == 0 && o.lane == 0 && o.out.dtype == YL_BF16 && o.in.dtype == YL_BF16 && !up)
+          conv3_cs_choose_post(batch, cin_total, cout1, o.out.C, o.k, o.stride, Ho, Wo, &r.cfg);
         r.flops = 2.0 * px_out * cout1 * cin_w * o.k * o.k + (post ? 2.0 * px_out * o.out.C * o.post_cin : 0.0);
         // (a DFL conv stores 16 bytes of decoded box per pixel; the 64 bf16 logits only with dfl_keep)
         const double out_b = o.dfl_level ? px_out * (16.0 + (o.dfl_keep ? 128.0 : 0.0)) : px_out * o.out.C * view_elem_size(o.out);
@@ -978,6 +983,32 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
         }
         ok = false;  // (handled)
       }
+      // The levels' second box convs with the fused 1x1 + box decode (cv2[i][1] + cv2[i][2], 64 -> 64 -> 64 DFL logits -> boxes) on
+      // the Cout-split filter-in-registers kernel, ONE launch for the levels (conv3_csg_kernel, round 6): conv_group_kernel restages
+      // each 72 KB filter per 256 pixels and took 65 us in sequence for the three; this form 4x us (profiles/r06b_*)
+      if (ok && nc >= 2 && nd == 0 && e->ops[i].cfg.post && e->ops[i].op.dfl_level) {
+        ConvConfig cc3[3];
+        int hh[3], ww[3];
+        bool fit = nc <= 3;
+        for (int k = 0; k < nc && fit; ++k) {
+          const OpRec& r = e->ops[i + k];
+          fit = r.op.dfl_level && r.op.in.C == 64 && r.op.post_cin == 64 && r.op.out.C == 64 && r.op.k == 3 && !r.op.post_act && r.op.act &&
+                r.op.in.H == r.op.out.H && r.op.in.W == r.op.out.W;
+          cc3[k] = r.cfg;
+          hh[k] = r.op.out.H;
+          ww[k] = r.op.out.W;
+        }
+        if (fit && conv3_cs_group_fits(cc3, nc, batch, hh, ww)) {
+          static const char* const gn[3] = {"conv3x3_cs+1x1+dfl_mfma[x1]", "conv3x3_cs+1x1+dfl_mfma[x2]", "conv3x3_cs+1x1+dfl_mfma[x3]"};
+          for (size_t k = i; k < j; ++k) {
+            OpRec& r = e->ops[k];
+            r.group_n = k == i ? n : -1;
+            r.csg = k == i;
+            r.name = k == i ? gn[n - 1] : "(in the group launch)";
+          }
+          ok = false;  // (handled)
+        }
+      }
       if (ok) {
         // one pixel-tile count per kind: the largest member's choice (it has most of the workgroups)
         auto largest = [&](size_t k0, size_t k1) {
@@ -1476,6 +1507,11 @@ static int run_group(const yl_engine* e, size_t i, int n, char* ws, hipStream_t 
       q.post_act = o.post_act;
     }
     return conv3_band_launch(ba, n, e->batch, s);
+  }
+  if (e->ops[i].csg) {
+    ConvArgs ga[3]{};
+    for (int k = 0; k < n && k < 3; ++k) build_conv_args(e, e->ops[i + k], ws, ga[k]);
+    return conv3_cs_group_launch(ga, n, e->batch, s);
   }
   ConvArgs ca[3]{}, da[3]{};
   ConvConfig cc[3], dc[3];

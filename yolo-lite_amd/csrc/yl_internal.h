@@ -173,7 +173,8 @@ struct ConvConfig {
   int MT, NT, uniform, post, ncb, cg, ksteps, kchunk, ntaps, npatches, gws, ppw;
   int f8t;           // 1: conv3_f8t_kernel (e4m3 48 -> 48 3x3: input tile in LDS, filter in registers) instead of conv_f8_kernel
   int reg;           // > 0: conv3_reg_kernel (filter in registers) with this many 16-pixel column tiles per wave
-  int cs;            // 1: conv3_cs_kernel (64 -> 64 3x3: filter in registers, output channels split between wave pairs)
+  int cs;            // 1: conv3_cs_kernel (64 -> 64 3x3: filter in registers, output channels split between wave pairs); 2: ... with the
+                     //    fused 1x1 + box decode of Detect's box branch behind it (conv3_cs_choose_post)
   int slab2;         // 1: kchunk < ksteps and the chunks alternate between two LDS buffers, filled by LDS-DMA (conv_kernel, round 5)
   int kord;          // 1: K runs plane-major (k-group = plane * 9 + tap) instead of tap-major (tap * planes + plane), see conv_choose
   int gemm;          // > 0: conv_gemm_kernel (wide 1x1: both operands staged through LDS) with this many 16-channel tiles per wave
@@ -196,6 +197,11 @@ int conv3_reg_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s
 // conv3_cs.hip: 3x3 stride-1 64 -> 64 convs, output channels split between wave pairs, two workgroups per CU
 void conv3_cs_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, int post, ConvConfig* cfg);
 int conv3_cs_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s);
+// ... with Detect's cv2[i][2] (1x1) and the box decode behind it in the same launch (sets cfg->cs = 2)
+bool conv3_cs_choose_post(int batch, int Cin, int Cout1, int Cout2, int k, int stride, int Ho, int Wo, ConvConfig* cfg);
+// ... of all Detect levels in one launch (conv3_csg_kernel): whether the members fit / the launch (args as conv_group_launch's)
+bool conv3_cs_group_fits(const ConvConfig* cfg, int n, int batch, const int* Ho, const int* Wo);
+int conv3_cs_group_launch(const ConvArgs* args, int n, int batch, hipStream_t s);
 // conv_gemm.hip: wide 1x1 convs (Cin, Cout >= 128) as a 128/192 x 128 macro-tile GEMM, both operands through LDS by LDS-DMA
 void conv_gemm_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo, ConvConfig* cfg, int cin2 = 0);
 int conv_gemm_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s);

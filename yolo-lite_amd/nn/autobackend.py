@@ -147,7 +147,7 @@ class AutoBackend:
             li = int(u.name.split(".")[1])
             params[li] += u.c2 * (u.c1 // u.g) * u.k * u.k + (2 * u.c2 if u.bn else u.c2)
         per = {sp.i: dict(layer=sp.i, module=sp.kind, ms=0.0, gflops=0.0, params=params[sp.i], launches=0) for sp in specs}
-        post = dict(layer="post", module="decode + NMS (one launch)", ms=0.0, gflops=0.0, params=0, launches=0)
+        post = dict(layer="post", module="decode + NMS", ms=0.0, gflops=0.0, params=0, launches=0)
         for r in eng.profile_detect(im, iters=iters):
             m = re.match(r"model\.(\d+)", r["name"])
             row = per[int(m.group(1))] if m else post
