@@ -164,7 +164,7 @@ C5_PLANTED_TOTAL = int(os.environ.get("YL_C5_PLANTED_TOTAL", "192"))
 
 def c5_planted(batch: int) -> int:
     return max(8, min(96, C5_PLANTED_TOTAL // max(1, batch)))
-C5_GATE = dict(band=0.6, p99_band=0.2, min_matched_frac=0.9, max_explained_share=0.35, max_count_bias=0.25)
+C5_GATE = dict(band=0.2, max_band=0.6, p99_band=0.2, min_matched_frac=0.9, max_explained_share=0.35, max_count_bias=0.25)
 
 
 def config5_images(batch: int, imgsz: int, seed: int = 0):
@@ -288,8 +288,13 @@ def short_config(scale, batch, imgsz, dtype, streams, steps, dev, conf=0.25, iou
         # 0.11-0.16, max 0.19-0.57, the 0.57 at ONE of 207 boxes; the bf16 program: p99 0.06, max 0.07-0.15 -- a whitened matched
         # filter of gain 12 turns the e4m3 rounding of a few feature directions into logit errors of up to 2.7; the CPU emulation
         # of the same roundings has tails of the same size at other anchors: 0.17-0.25)
+        # (both programs' pre-NMS tensors go in: a paired box whose classes differ because two classes tie within the band at that
+        # anchor is counted as a near-tie, not as a class mismatch -- SURVEY 8(d))
+        y16_all = e16.forward(x8, graph=False).float().cpu()
+        y8_all = eng.forward(x8, graph=False).float().cpu()
         g = parity_gate([o16[i, : int(c16[i])].cpu() for i in range(batch)], [o8[i, : int(c8[i])].cpu() for i in range(batch)],
-                        conf, iou, **C5_GATE)
+                        conf, iou, ref_y=y16_all, got_y=y8_all, **C5_GATE)
+        del y16_all
         keys = ("ref", "det", "matched", "matched_frac", "class_mismatch", "unexplained", "max_dconf", "p99_dconf", "explained_share",
                 "max_explained_share", "count_bias", "max_count_bias", "ok")
         res["head"] = f"planted objects, {planted} per image (nn/synth.py plant_object_head)"
@@ -308,7 +313,7 @@ def short_config(scale, batch, imgsz, dtype, streams, steps, dev, conf=0.25, iou
         with torch.inference_mode():
             y32, _ = oracle.forward(sd, x8[:n_or].float().cpu() / 255.0, scale)
             ref = oracle.non_max_suppression(y32, conf, iou, max_det=gate_max_det)
-        y8 = eng.forward(x8, graph=False)[:n_or].float().cpu()  # the e4m3 program's own pre-NMS tensor (near-tied arg-maxes)
+        y8 = y8_all[:n_or]  # the e4m3 program's own pre-NMS tensor (near-tied arg-maxes)
         g2 = parity_gate(ref, [o8g[i, : int(c8g[i])].cpu() for i in range(n_or)], conf, iou, ref_y=y32, got_y=y8, **C5_GATE)
         res["fp8_vs_fp32_oracle"] = dict({k: g2.get(k) for k in keys}, images=n_or, oracle_seconds=round(time.time() - t_or, 1),
                                          near_threshold=g2["near_threshold"], nms_flip=g2["nms_flip"])
@@ -321,7 +326,7 @@ def short_config(scale, batch, imgsz, dtype, streams, steps, dev, conf=0.25, iou
             det8e = oracle.non_max_suppression(y8e, conf, iou, max_det=gate_max_det)
         g3 = parity_gate(ref, det8e, conf, iou, ref_y=y32, got_y=y8e, **C5_GATE)
         res["format_error_e4m3"] = dict({k: g3.get(k) for k in keys}, note="DIAGNOSTIC: the CPU emulation of the same roundings through the same gate")
-        res["format_yardstick_e4m3"] = dict(format_yardstick_ok(g2, g3, C5_GATE["band"]), note="DIAGNOSTIC, not the pass criterion (that is fp8_vs_fp32_oracle.ok)")
+        res["format_yardstick_e4m3"] = dict(format_yardstick_ok(g2, g3, C5_GATE["max_band"]), note="DIAGNOSTIC, not the pass criterion (that is fp8_vs_fp32_oracle.ok)")
         del e16
     else:
         # bf16 configurations: the HIP detections of the first two images against the fp32 oracle (one host forward, a few
@@ -944,7 +949,9 @@ def main():
                 torch.cuda.synchronize(dev)
                 nb8 = min(B, 8)
                 res["fp8_vs_bf16"] = parity_gate([o16[i, : int(c16[i])].cpu() for i in range(nb8)],
-                                                 [o8[i, : int(c8[i])].cpu() for i in range(nb8)], conf, iou, **C5_GATE)
+                                                 [o8[i, : int(c8[i])].cpu() for i in range(nb8)], conf, iou,
+                                                 ref_y=e16.forward(x8, graph=False)[:nb8].float().cpu(),
+                                                 got_y=eng.forward(x8, graph=False)[:nb8].float().cpu(), **C5_GATE)
                 if l8 is not None:
                     l16 = e16.head_outputs()  # (class logits, then decoded boxes, level by level)
                     res["fp8_vs_bf16"]["level_rel_l2"] = [round(float((a - b).norm() / b.norm()), 4) for a, b in zip(l8, l16)]

@@ -70,12 +70,15 @@ def parity_gate(ref_dets: List[torch.Tensor], got_dets: List[torch.Tensor], conf
                 iou_match: float = 0.9, iou_band: float = 0.1, min_matched_frac: float = 0.9,
                 ref_y: Optional[torch.Tensor] = None, verbose: bool = False, max_explained_share: float = 0.25,
                 got_y: Optional[torch.Tensor] = None, p99_band: Optional[float] = None,
-                max_count_bias: Optional[float] = None) -> dict:
+                max_count_bias: Optional[float] = None, max_band: Optional[float] = None) -> dict:
     """ref_dets / got_dets: per image (n, 6) [x1, y1, x2, y2, conf, cls] score-descending.  Returns the statistics
     dict with ``ok``.
 
-    ``p99_band`` / ``max_count_bias`` (round 6, the fixed gate of the e4m3 configuration): ``ok`` additionally needs the 99th
-    percentile of |dconf| over the pairs <= p99_band (``band`` keeps bounding the maximum) and |det / ref - 1| <= max_count_bias.
+    ``p99_band`` / ``max_count_bias`` / ``max_band`` (round 6, the fixed gate of the e4m3 configuration): ``ok`` additionally needs the
+    99th percentile of |dconf| over the pairs <= p99_band and |det / ref - 1| <= max_count_bias; with ``max_band`` the MAXIMUM of
+    |dconf| is bounded by it instead of by ``band``, which then only sizes the explanations (a one-sided box is near the threshold
+    when its score lies within ``band`` of it, two classes tie within ``band``) -- so a wide bound on one outlier does not widen what
+    counts as explained.
 
     One-sided boxes are classified AFTER the pairing, so that an explanation can ask whether a neighbour has a partner:
       near_threshold      score within ``band`` of ``conf`` (the other side's score fell below the threshold);
@@ -158,10 +161,12 @@ def parity_gate(ref_dets: List[torch.Tensor], got_dets: List[torch.Tensor], conf
     st["max_explained_share"] = max_explained_share
     st["count_bias"] = round(st["det"] / max(1, st["ref"]) - 1.0, 4)
     st["ok"] = bool(st["class_mismatch"] == 0 and st["unexplained"] == 0 and st["matched"] > 0
-                    and st["max_dconf"] <= band and st["matched_frac"] >= min_matched_frac
+                    and st["max_dconf"] <= (band if max_band is None else max_band) and st["matched_frac"] >= min_matched_frac
                     and st["explained_share"] <= max_explained_share
                     and (p99_band is None or st.get("p99_dconf", 0.0) <= p99_band)
                     and (max_count_bias is None or abs(st["count_bias"]) <= max_count_bias))
+    if max_band is not None:
+        st["max_band"] = max_band
     if p99_band is not None:
         st["p99_band"] = p99_band
     if max_count_bias is not None:

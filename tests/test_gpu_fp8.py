@@ -394,7 +394,7 @@ def test_fp8_x_1280_vs_fp32_oracle(gpu_device):
     o16, c16 = e16.detect(x8, conf, iou, max_det=300, graph=False)
     y16 = e16.forward(x8, graph=False).float().cpu()
     g16 = parity_gate(ref, [o16[i, : int(c16[i])].cpu() for i in range(B)], conf, iou, ref_y=y32, got_y=y16,
-                      **dict(bench.C5_GATE, band=0.25, p99_band=0.1))
+                      **dict(bench.C5_GATE, band=0.1, max_band=0.25, p99_band=0.1))
     print("bf16 x 1280, HIP bf16 vs fp32 oracle:               ", {k: g16.get(k) for k in keys})
     assert g16["ok"], g16
 

@@ -70,3 +70,31 @@ def test_format_yardstick_compares_with_the_formats_own_error():
     fmt = dict(unexplained=0, max_dconf=0.07, matched_frac=0.95, explained_share=0.1)
     assert format_yardstick_ok(got, fmt, BAND)["ok"]
     assert not format_yardstick_ok(dict(got, max_dconf=0.12), dict(fmt, max_dconf=0.03), 0.2)["ok"]  # 1.5 x the format's + 0.01
+
+
+def test_fixed_gate_keywords_p99_count_bias_and_max_band():
+    """Round 6, the fixed gate of the e4m3 configuration: ``max_band`` bounds the maximum |dconf| without widening what counts as
+    explained (``band`` keeps sizing the explanations), ``p99_band`` bounds the 99th percentile, ``max_count_bias`` |det / ref - 1|."""
+    boxes = [_b(10 + 60 * i, 10, 50 + 60 * i, 50, 0.9, 1) for i in range(10)]
+    ref = [torch.tensor(boxes)]
+    drift = [list(b) for b in boxes]
+    drift[0][4] = 0.55                                     # one outlier: |dconf| 0.35
+    det = [torch.tensor(drift)]
+    assert not parity_gate(ref, det, CONF, IOU, 0.1)["ok"]                                   # max > band
+    g = parity_gate(ref, det, CONF, IOU, 0.1, max_band=0.4, p99_band=0.4)
+    assert g["ok"] and g["max_dconf"] == 0.35 and g["max_band"] == 0.4
+    drift[1][4] = 0.6                                      # a second one: with 10 pairs the 99th percentile is the 9th smallest
+    det2 = [torch.tensor(drift)]
+    assert parity_gate(ref, det2, CONF, IOU, 0.1, max_band=0.4, p99_band=0.4)["ok"]
+    assert not parity_gate(ref, det2, CONF, IOU, 0.1, max_band=0.4, p99_band=0.2)["ok"]
+    # a confident one-sided box stays unexplained however wide max_band is: only `band` sizes "near the threshold"
+    extra = [torch.tensor(boxes + [_b(700, 10, 740, 50, 0.5, 2)])]
+    g = parity_gate(ref, extra, CONF, IOU, 0.1, max_band=0.9, max_explained_share=1.0)
+    assert g["unexplained"] == 1 and not g["ok"]
+    g = parity_gate(ref, extra, CONF, IOU, 0.3, max_explained_share=1.0)                      # (band 0.3: 0.5 <= 0.25 + 0.3)
+    assert g["near_threshold"] == 1 and g["ok"]
+    # count bias: 10 reference boxes, 14 detections of which 4 are near the threshold (explained) -> bias 0.4
+    many = [torch.tensor(boxes + [_b(700 + 60 * i, 10, 740 + 60 * i, 50, 0.27, 2) for i in range(4)])]
+    assert parity_gate(ref, many, CONF, IOU, 0.1, max_explained_share=1.0)["ok"]
+    g = parity_gate(ref, many, CONF, IOU, 0.1, max_explained_share=1.0, max_count_bias=0.25)
+    assert abs(g["count_bias"] - 0.4) < 1e-6 and not g["ok"]
