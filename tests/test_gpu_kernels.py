@@ -642,3 +642,21 @@ def test_conv3_band_vs_conv_kernel(gpu_device, monkeypatch, B, H, W):
         ref = F.silu(F.conv2d(x, wt, b, padding=1))
         assert float((y - ref).abs().max()) <= 0.02 * float(ref.abs().max()) + 0.02
 
+
+@pytest.mark.parametrize("cin,B,H,W", [(128, 2, 80, 80), (256, 4, 40, 40), (512, 11, 20, 20), (128, 3, 47, 91), (512, 16, 16, 16), (256, 2, 64, 48)])
+def test_conv3_band_single_vs_conv_kernel(gpu_device, monkeypatch, cin, B, H, W):
+    """conv3_band1_kernel (round 6): ONE deep-K 3x3 conv with 64 output channels per launch -- the first box convs of the wider
+    models (YOLO11s: 128 -> 64 @80x80, 256 -> 64 @40x40, 512 -> 64 @20x20; head.py:36-40 cv2[i][0]) -- against conv_kernel: every
+    bit; and against torch fp32.  Ragged maps, bands cut short by the image's last rows, one tile per wave quarter (512 @20x20)."""
+    gen = torch.Generator().manual_seed(cin + H * 100 + W)
+    x = bf16_round(torch.randn(B, cin, H, W, generator=gen))
+    wt = bf16_round(torch.randn(64, cin, 3, 3, generator=gen) / (cin * 9) ** 0.5 * 1.5)
+    b = torch.randn(64, generator=gen) * 0.3
+    monkeypatch.setenv("YL_CONV_BAND", "1")
+    got = run_conv(gpu_device, x, wt, b, 3, 1, True, None, expect_kernel="conv3x3_band_mfma")
+    monkeypatch.setenv("YL_CONV_BAND", "0")
+    direct = run_conv(gpu_device, x, wt, b, 3, 1, True, None, expect_kernel="conv3x3_mfma")
+    assert torch.equal(got, direct), float((got - direct).abs().max())
+    ref = F.silu(F.conv2d(x, wt, b, padding=1))
+    assert float((got - ref).abs().max()) <= 0.02 * float(ref.abs().max()) + 0.02
+

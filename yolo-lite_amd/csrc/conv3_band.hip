@@ -250,9 +250,20 @@ __global__ __launch_bounds__(BD_THREADS) void conv3_band_kernel(BandGroup G) {
   else band_body<KB, NB>(G.m[1], block - G.nb0);
 }
 
+// ONE conv per launch (round 6: the first box convs of the wider models -- YOLO11s 128 -> 64 @80x80, 256 -> 64 @40x40, 512 -> 64 @20x20,
+// reference head.py:36-40 cv2[i][0] -- which ran on conv_kernel at 0.10-0.23 of the matrix peak with 1.5 x their algorithmic traffic:
+// its tap-major sweep of a 100 MB input does not fit any cache).  The wave's tile count is dispatched at run time.
+template <int KKN>
+__global__ __launch_bounds__(BD_THREADS) void conv3_band1_kernel(BandArgs a) {
+  band_body<KKN, 0>(a, blockIdx.x);
+}
+
 // Tiling of one member: the largest band (rows) whose pixel tiles fit NTQ <= 5 per wave quarter and whose input fits the LDS budget
+// (post = true: the single-member form -- 512 input channels too, and a band may hold as little as one tile per wave quarter)
 bool conv3_band_plan(int Cin, int Cout, int H, int W, BandArgs* a, bool post) {
-  if (Cout != 64 || (Cin != 64 && Cin != 128 && Cin != 256)) return false;
+  const bool single = post;
+  post = false;
+  if (Cout != 64 || (Cin != 64 && Cin != 128 && Cin != 256 && !(single && Cin == 512))) return false;
   const int planes = Cin / 8;
   int best = 0;
   for (int TR = 1; TR <= H; ++TR) {
@@ -265,7 +276,7 @@ bool conv3_band_plan(int Cin, int Cout, int H, int W, BandArgs* a, bool post) {
   const int nbands = (H + best - 1) / best;
   const int TR = (H + nbands - 1) / nbands;
   const int ntiles = (TR * W + 15) / 16, ntq = (ntiles + 3) / 4;
-  if (ntq < 2 || ntq > 5) return false;  // (the instantiated tile counts; at least one tile per wave)
+  if ((ntq < 2 && !single) || ntq > 5) return false;  // (the instantiated tile counts; at least one tile per wave)
   if (a) {
     a->TR = TR;
     a->nbands = nbands;
@@ -316,6 +327,32 @@ int conv3_band_launch(const BandArgs* args, int n, int batch, hipStream_t s) {
 #undef YL_BAND_ROW
 #undef YL_BAND_CASE
   return fail(-3, "conv3_band: unsupported member tiling");
+}
+
+// one conv on conv3_band1_kernel (plan with `single`)
+int conv3_band1_launch(const BandArgs& arg, int batch, hipStream_t s) {
+  BandArgs a = arg;
+  a.stamps = g_stamp_buf;
+  a.st_nt = st_nt_policy(arg.y_bytes);
+  if (!conv3_band_plan(a.Cin, 64, a.H, a.W, &a, true)) return fail(-3, "conv3_band: the conv does not fit the band tiling");
+  const size_t lds = (size_t)(a.Cin / 8) * a.tpl + (size_t)BD_NS * BD_SLICE;
+  const int grid = batch * a.nbands;
+#define YL_BAND1(KK)                                                                                      \
+  case KK: {                                                                                              \
+    auto kern = conv3_band1_kernel<KK>;                                                                   \
+    if (int rc = allow_big_lds(reinterpret_cast<const void*>(kern), 160 * 1024)) return rc;             \
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(BD_THREADS), lds, s, a);                          \
+    break;                                                                                                \
+  }
+  switch (a.Cin / 32) {
+    YL_BAND1(4)
+    YL_BAND1(8)
+    YL_BAND1(16)
+    default: return fail(-3, "conv3_band: 128, 256 or 512 input channels");
+  }
+#undef YL_BAND1
+  YL_HIP(hipGetLastError());
+  return 0;
 }
 
 }  // namespace yl

@@ -81,6 +81,7 @@ struct OpRec {
   int cls_level = -1;  // fused depthwise + pointwise + 1x1 that writes the class logits of this Detect level (else -1)
   int group_n = 0;  // group launch (yl_op.group): 2 or 3 on the first member, -1 on the others (run with it), 0 = on its own
   bool band = false;  // (first member of a group) the group runs on conv3_band_kernel: deep-K 3x3 convs, 64 output channels
+  bool band1 = false; // a conv on its own on conv3_band1_kernel (the wider models' first box convs: 128 / 256 / 512 -> 64)
   bool csg = false;   // ... on conv3_csg_kernel: the levels' cv2[i][1] + cv2[i][2] + box decode, filter halves in registers
   double flops = 0, bytes = 0;
   const char* name = "";
@@ -478,6 +479,15 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
         // kernel's form of it where the map is large enough (level 0 at 640x640 from batch 8 up); same packed filters
         if (o.dfl_level && post && o.group == 0 && o.lane == 0 && o.out.dtype == YL_BF16 && o.in.dtype == YL_BF16 && !up)
           conv3_cs_choose_post(batch, cin_total, cout1, o.out.C, o.k, o.stride, Ho, Wo, &r.cfg);
+        // a deep-K 3x3 conv with 64 output channels on its own (the wider models' cv2[i][0]): the band kernel, one conv per launch
+        if (!post && !up && o.group == 0 && o.lane == 0 && o.k == 3 && o.stride == 1 && o.act && o.res.offset < 0 && o.out8.offset < 0 &&
+            !o.stem_weight && !o.cin_weight && o.out.dtype == YL_BF16 && o.in.dtype == YL_BF16 && o.out.C == 64 && !r.cfg.gemm &&
+            r.cfg.MT == 4 && r.cfg.ncb == 1 && !r.cfg.kord && (o.in.C == 128 || o.in.C == 256 || o.in.C == 512) && env_int("YL_CONV_BAND", 1) &&
+            (long long)batch * Ho * Wo >= 4096 && conv3_band_plan(o.in.C, 64, Ho, Wo, nullptr, true)) {
+          r.band1 = true;
+          r.cfg.reg = r.cfg.cs = 0;
+          r.cfg.name = "conv3x3_band_mfma";
+        }
         r.flops = 2.0 * px_out * cout1 * cin_w * o.k * o.k + (post ? 2.0 * px_out * o.out.C * o.post_cin : 0.0);
         // (a DFL conv stores 16 bytes of decoded box per pixel; the 64 bf16 logits only with dfl_keep)
         const double out_b = o.dfl_level ? px_out * (16.0 + (o.dfl_keep ? 128.0 : 0.0)) : px_out * o.out.C * view_elem_size(o.out);
@@ -1232,6 +1242,27 @@ static int run_op(const yl_engine* e, const OpRec& r, char* ws, hipStream_t s, c
         a.act = o.act;
         fill_out8(a, o, ws, B);
         return conv_f8_launch(r.cfg, a, B, s);
+      }
+      if (r.band1) {
+        const Geo gq = geo_of(B, o.out.H, o.out.W);
+        BandArgs q{};
+        q.x = pview(ws, o.in, B).base;
+        q.y = pview(ws, o.out, B).base;
+        q.x_plane = q.y_plane = (unsigned)plane_bytes(gq);
+        const long long ib = (long long)(o.in.C / 8) * plane_bytes(gq), ob = (long long)(o.out.C / 8) * plane_bytes(gq);
+        if (ib > (1LL << 30) || ob > (1LL << 30)) return fail(-3, "conv3_band: a tensor slice exceeds 1 GiB; lower the batch size");
+        q.x_bytes = (unsigned)ib;
+        q.y_bytes = (unsigned)ob;
+        q.H = o.out.H;
+        q.W = o.out.W;
+        q.W1 = gq.W1;
+        q.img = gq.img;
+        q.g0 = gq.g0;
+        q.Cin = o.in.C;
+        q.act = o.act;
+        q.w = r.d_wpk;
+        q.bias = r.d_bias;
+        return conv3_band1_launch(q, B, s);
       }
       build_conv_args(e, r, ws, a);
       if (sink && r.cls_level >= 0) {  // a plain 1x1 launch that writes a level's class logits: pre-filter them on the way out

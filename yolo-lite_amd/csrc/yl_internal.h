@@ -381,8 +381,10 @@ struct BandArgs {
   const float* bias2;
   int post_act;
 };
-bool conv3_band_plan(int Cin, int Cout, int H, int W, BandArgs* a, bool post = false);
+bool conv3_band_plan(int Cin, int Cout, int H, int W, BandArgs* a, bool single = false);  // single: the one-conv-per-launch form (512 input channels too)
 int conv3_band_launch(const BandArgs* args, int n, int batch, hipStream_t s);
+// ... one conv per launch (128 / 256 / 512 -> 64; conv3_band_plan(..., post = true) is its plan)
+int conv3_band1_launch(const BandArgs& arg, int batch, hipStream_t s);
 
 // resident.hip: the PSABlock of a C2PSA layer (c = 128, two heads) in one launch, one workgroup per image
 struct PsaArgs {
