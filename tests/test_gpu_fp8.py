@@ -399,7 +399,7 @@ def test_fp8_x_1280_vs_fp32_oracle(gpu_device):
     assert g16["ok"], g16
 
 
-FP8_GAIN1_SCORE_ATOL = 0.05  # e4m3 dense 3x3 convs against the reference at a trained head's logit scale (measured below)
+FP8_GAIN1_SCORE_ATOL = 0.02  # SURVEY 8(d)'s own band: measured 0.0056 (e4m3 dense 3x3 convs, YOLO11x) against the reference at a trained head's logit scale
 
 
 def test_fp8_pre_nms_at_realistic_logit_scale_vs_reference_golden(gpu_device):
