@@ -724,8 +724,10 @@ def main():
 
         def make_runner(n):
             if native_comm is not None:
+                o_ = os.environ.get("YL_BENCH_NATIVE_OPTS", "")  # (experiments: "copy" = no in-place root slice, "one" = one communicator)
                 return NativeShardedRunner(native_comm, compute, B, (3, H, W), torch.uint8, dev, record_floats(B, max_det), slots=n,
-                                           streams=streams[:n], comm_gather=native_comm_g)
+                                           streams=streams[:n], comm_gather=None if "one" in o_ else native_comm_g,
+                                           root_in_place="copy" not in o_)
             return ShardedRunner(compute, B, (3, H, W), torch.uint8, dev, record_floats(B, max_det), slots=n, streams=streams[:n])
 
         if len(cands) > 1:  # untimed trial of the stream counts; every rank takes the same decision (MAX over ranks)
@@ -751,8 +753,12 @@ def main():
         sync_all()
         t0 = time.perf_counter()
         last = runner.run(batches, args.steps)
+        t_issue = time.perf_counter() - t0  # (the host's share: run() returns when the last step is ENQUEUED)
         sync_all()
         dt = time.perf_counter() - t0
+        extra["host_issue_ms_per_step"] = round(t_issue * 1e3 / args.steps, 4)
+        extra["host_issue_note"] = ("time for this rank's Python loop to enqueue one step (scatter, graph launch, gather, their events); "
+                                    "close to ms_per_step = the host loop, not the GPU or a link, bounds the sharded run")
         if rank == 0:
             _, cnts = unpack_record(last, B, max_det)
             ndet = torch.cat(cnts).float().mean().item()

@@ -351,9 +351,11 @@ int yl_letterbox_u8(const uint8_t* src_bgr_hwc, int src_h, int src_w, int src_pi
  * first yl_comm_* call (librccl.so.1; YL_RCCL_LIB overrides the path); without it these calls fail, nothing else does.
  * A communicator belongs to the HIP device that was current in yl_comm_create; calls on one communicator must be issued in
  * the same order on every rank (RCCL's rule) and are not thread-safe.  `stream` is a hipStream_t: the exchange is enqueued
- * there and ordered with the engine launches on that stream like any kernel.  RCCL runs the operations of ONE communicator in
- * host issue order whatever streams they name: a binder that wants the scatters of step k + n to overlap the gathers of step k
- * creates TWO communicators, one per direction (yololite_amd/dist.py NativeShardedRunner does).
+ * there and ordered with the engine launches on that stream like any kernel.  Operations of ONE communicator EXECUTE in the
+ * order they were issued whatever streams they name (an operation that crosses a link waits for an event its predecessor on
+ * the communicator recorded: RCCL matches sends to one peer in execution order and orders nothing between streams itself), so
+ * a binder may put each exchange on the stream of the step it belongs to.  One that wants the scatters of step k + n to
+ * overlap the gathers of step k creates TWO communicators, one per direction (yololite_amd/dist.py NativeShardedRunner does).
  * STATUS: EXPERIMENTAL.  Exercised with a world of one on the GPU (tests/test_gpu_dist.py) and never yet with a peer on the
  * other end of a link -- no multi-GPU machine was available to this build; a two-process test is in place and skips itself
  * below two devices.  bench.py --gpus N uses torch.distributed (backend nccl = RCCL) unless YL_BENCH_COMM=native. */

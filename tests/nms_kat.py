@@ -87,4 +87,26 @@ def cases():
     rows = [(8, 8, 16, 16, 3, 0.75), (8, 4.5, 16, 9, 3, 0.75)]
     out.append(("equal_score_convention_lower_anchor_first", _pred(rows), dict(conf_thres=0.25, iou_thres=0.5),
                 [[0, 0, 16, 16, 0.75, 3]]))
+    # 10. zero-area boxes (no minimum size in ops.py:138-273; torchvision: IoU = inter / (area_i + area_j - inter)).  A = (0,0,16,16);
+    #     Z1 = Z2 = the vertical segment x = 8, y in [0, 16] (w = 0: x1 = x2 = 8).  IoU(A, Z) = 0 / (256 + 0 - 0) = 0, not > 0.5;
+    #     IoU(Z1, Z2) = 0 / (0 + 0 - 0) = NaN, and NaN > 0.5 is false: nothing is suppressed, all three come back in score order.
+    rows = [(8, 8, 16, 16, 3, 0.9), (8, 8, 0, 16, 3, 0.8), (8, 8, 0, 16, 3, 0.7)]
+    out.append(("zero_area_boxes_suppress_nothing", _pred(rows), dict(conf_thres=0.25, iou_thres=0.5),
+                [[0, 0, 16, 16, 0.9, 3], [8, 0, 8, 16, 0.8, 3], [8, 0, 8, 16, 0.7, 3]]))
+
+    # 11. exactly equal scores ACROSS classes: the same box at two anchors, classes 5 and 2, score 0.75 each.  Class-aware: the
+    #     offsets 5 * 7680 and 2 * 7680 separate them -> both kept; their order among equal scores is the convention of case 9
+    #     (lower anchor first; NOT a reference fact -- a caller of the reference must not rely on it either).  Agnostic: IoU 1 > 0.5
+    #     -> the first in that order suppresses the other.
+    rows = [(20, 20, 8, 8, 5, 0.75), (20, 20, 8, 8, 2, 0.75)]
+    out.append(("equal_scores_across_classes", _pred(rows), dict(conf_thres=0.25, iou_thres=0.5),
+                [[16, 16, 24, 24, 0.75, 5], [16, 16, 24, 24, 0.75, 2]]))
+    out.append(("equal_scores_across_classes_agnostic", _pred(rows), dict(conf_thres=0.25, iou_thres=0.5, agnostic=True),
+                [[16, 16, 24, 24, 0.75, 5]]))
+
+    # 12. IoU exactly equal to the threshold ACROSS the class offset (agnostic off): class 1 at both anchors, offset 7680 exactly
+    #     representable next to these coordinates (7680 + 16 etc. are integers): the shifted boxes keep IoU = 0.5 exactly -> kept.
+    rows = [(8, 8, 16, 16, 1, 0.9), (8, 4, 16, 8, 1, 0.8)]
+    out.append(("iou_equal_threshold_with_class_offset", _pred(rows), dict(conf_thres=0.25, iou_thres=0.5),
+                [[0, 0, 16, 16, 0.9, 1], [0, 0, 16, 8, 0.8, 1]]))
     return out

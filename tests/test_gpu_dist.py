@@ -106,7 +106,7 @@ def test_native_comm_world1_scatter_gather_barrier(gpu_device, tmp_path):
 
 @pytest.mark.parametrize("slots,steps,two_comms,in_place", [(2, 5, False, True), (5, 12, True, True), (3, 7, True, False)])
 def test_native_runner_equals_plain_detect(gpu_device, golden, tmp_path, slots, steps, two_comms, in_place):
-    """NativeShardedRunner (exchanges enqueued by libyl_amd.so on their own HIP streams) against plain detect, bit for bit:
+    """NativeShardedRunner (exchanges enqueued by libyl_amd.so on the slot streams, one event chain per communicator) against plain detect, bit for bit:
     the same check the torch.distributed runner passes above."""
     from yololite_amd.dist import NativeComm, NativeShardedRunner, record_floats, unpack_record
 
@@ -131,12 +131,12 @@ def test_native_runner_equals_plain_detect(gpu_device, golden, tmp_path, slots, 
     def compute(im, slot, lane):
         return eng.detect_record(im, 0.25, 0.7, max_det=max_det, slot=slot, rec_key=lane)
 
-    # one communicator (both directions on one exchange stream) and two (a gather communicator and stream of its own); the root's
+    # one communicator (both directions on one chain) and two (a gather communicator with a chain of its own); the root's
     # slice read in place or copied into the lane buffer: the same records
     comm_g = NativeComm(0, 1, NativeComm.id_via_file(str(tmp_path / "id_g"), token="job-1"), device=gpu_device) if two_comms else None
     runner = NativeShardedRunner(comm, compute, B, (3, H, W), torch.uint8, gpu_device, record_floats(B, max_det), slots=slots,
                                  streams=streams, comm_gather=comm_g, root_in_place=in_place)
-    assert (runner.s_gather is runner.s_scatter) == (not two_comms)
+    assert (runner.comm_g is runner.comm) == (not two_comms) and not hasattr(runner, "s_gather")  # (no stream beyond the slots')
     for n in (steps, steps + 1):
         last = runner.run(batches, n)
         comm.barrier(stream=streams[(n - 1) % slots])

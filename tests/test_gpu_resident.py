@@ -373,7 +373,7 @@ def test_side_lane_graphs_bit_identical_and_rebindable(gpu_device, monkeypatch, 
     """lower(one_batch=True) with YL_ONE_BATCH_SIDE: the first levels' Detect branches on side lane 1, the program run as ONE GRAPH
     PER SEGMENT on a stream per lane (csrc/engine.hip detect_lanes; a single captured graph's branches are serialised by this
     runtime).  Same detections bit for bit as the program without lanes: eager, segment graphs, their replay, and the replay
-    on a FRESH input tensor (the plan rewrites the stem node's input address); the single-handle form refuses such a program."""
+    on a FRESH input tensor (the plan rewrites the stem node's input address); the single-handle form captures the lanes as branches of one graph."""
     specs, _ = arch.parse_model(arch.yolo11_dict("n"))
     b, h, w = 4, 320, 352
     sd = synth_state_dict("n", 7, cls_bias=[-3.5] * 3, cls_gain=6.0)
@@ -395,5 +395,11 @@ def test_side_lane_graphs_bit_identical_and_rebindable(gpu_device, monkeypatch, 
             torch.cuda.synchronize()
             assert torch.equal(c, c0), mode
             assert all(torch.equal(o[i, :n], o0[i, :n]) for i, n in enumerate(c0.tolist())), mode
-    with pytest.raises((RuntimeError, NotImplementedError)):
-        eng.prepare_detect(xs[0], 0.25, 0.7, max_det=300, slot=0)
+    # the single-handle form: the lanes as branches of one captured graph (serialised by the runtime, same results)
+    o, c, hd = eng.prepare_detect(xs[1], 0.25, 0.7, max_det=300, slot=1)
+    for _ in range(2):
+        c.zero_()
+        eng.launch_many([hd], [torch.cuda.current_stream()])
+        torch.cuda.synchronize()
+        assert torch.equal(c, want[1][1])
+        assert all(torch.equal(o[i, :n], want[1][0][i, :n]) for i, n in enumerate(want[1][1].tolist()))

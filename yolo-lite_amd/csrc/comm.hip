@@ -83,7 +83,33 @@ struct yl_comm {
   ncclComm_t comm = nullptr;
   int rank = 0, world = 1, device = 0;
   int32_t* word = nullptr;  // world + 1 device words: the barrier's gather target and scatter source
+  // Order chain.  Two operations on one communicator must EXECUTE in the same order on every rank (sends to one peer are
+  // matched in execution order), and RCCL orders nothing between streams: so every operation that crosses a link waits for
+  // the event its predecessor on this communicator recorded, unless that one went to the same stream.  A binder may then
+  // name any stream per call (the slot's own: dist.NativeShardedRunner) as long as every rank issues the same sequence.
+  // (A wait takes the event's latest record at the time of the call, so a ring of a few events is plenty; one host thread
+  // per communicator.)
+  hipEvent_t tail[4] = {nullptr, nullptr, nullptr, nullptr};
+  uint64_t n_ops = 0;
+  hipStream_t last_stream = nullptr;
 };
+
+namespace yl {
+namespace {
+int chain_enter(yl_comm* c, hipStream_t s) {
+  if (c->world > 1 && c->n_ops && c->last_stream != s) YL_HIP(hipStreamWaitEvent(s, c->tail[(c->n_ops - 1) & 3], 0));
+  return 0;
+}
+int chain_exit(yl_comm* c, hipStream_t s) {
+  if (c->world > 1) {
+    YL_HIP(hipEventRecord(c->tail[c->n_ops & 3], s));
+    ++c->n_ops;
+    c->last_stream = s;
+  }
+  return 0;
+}
+}  // namespace
+}  // namespace yl
 
 static_assert(sizeof(ncclUniqueId) == YL_COMM_ID_BYTES, "yl_amd.h promises an opaque id of this size");
 
@@ -126,6 +152,11 @@ YL_API int yl_comm_create(const void* id_in, int rank, int world, yl_comm** out)
     delete c;
     return yl::fail(-2, "yl_comm_create: hipMalloc of the barrier words failed");
   }
+  for (hipEvent_t& ev : c->tail)
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+      yl_comm_destroy(c);
+      return yl::fail(-2, "yl_comm_create: hipEventCreate failed");
+    }
   *out = c;
   return 0;
 }
@@ -134,6 +165,8 @@ YL_API void yl_comm_destroy(yl_comm* c) {
   if (!c) return;
   const yl::Rccl* r = yl::rccl();
   if (c->word) (void)hipFree(c->word);
+  for (hipEvent_t ev : c->tail)
+    if (ev) (void)hipEventDestroy(ev);
   if (r && c->comm) r->CommDestroy(c->comm);
   delete c;
 }
@@ -149,18 +182,22 @@ YL_API int yl_comm_scatter(yl_comm* c, const void* send, void* recv, int64_t byt
   if (c->rank == root && !send) return yl::fail(-1, "yl_comm_scatter: the root must pass the full buffer");
   if (bytes == 0) return 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  YL_NCCL(r, r->GroupStart());
-  ncclResult_t e = ncclSuccess;
-  if (c->rank == root) {
-    const char* p = static_cast<const char*>(send);
-    for (int k = 0; k < c->world && e == ncclSuccess; ++k)
-      if (k != root) e = r->Send(p + (size_t)k * (size_t)bytes, (size_t)bytes, ncclUint8, k, c->comm, s);
-  } else {
-    e = r->Recv(recv, (size_t)bytes, ncclUint8, root, c->comm, s);
+  if (c->world > 1) {  // (one rank: nothing crosses a link, and an empty group is not free)
+    if (int rc = yl::chain_enter(c, s)) return rc;
+    YL_NCCL(r, r->GroupStart());
+    ncclResult_t e = ncclSuccess;
+    if (c->rank == root) {
+      const char* p = static_cast<const char*>(send);
+      for (int k = 0; k < c->world && e == ncclSuccess; ++k)
+        if (k != root) e = r->Send(p + (size_t)k * (size_t)bytes, (size_t)bytes, ncclUint8, k, c->comm, s);
+    } else {
+      e = r->Recv(recv, (size_t)bytes, ncclUint8, root, c->comm, s);
+    }
+    ncclResult_t e2 = r->GroupEnd();
+    YL_NCCL(r, e);
+    YL_NCCL(r, e2);
+    if (int rc = yl::chain_exit(c, s)) return rc;
   }
-  ncclResult_t e2 = r->GroupEnd();
-  YL_NCCL(r, e);
-  YL_NCCL(r, e2);
   if (c->rank == root) {  // the root's own slice never touches a link
     const char* mine = static_cast<const char*>(send) + (size_t)root * (size_t)bytes;
     if (mine != recv) YL_HIP(hipMemcpyAsync(recv, mine, (size_t)bytes, hipMemcpyDeviceToDevice, s));
@@ -176,18 +213,22 @@ YL_API int yl_comm_gather(yl_comm* c, const void* send, void* recv, int64_t byte
   if (c->rank == root && !recv) return yl::fail(-1, "yl_comm_gather: the root must pass the full buffer");
   if (bytes == 0) return 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  YL_NCCL(r, r->GroupStart());
-  ncclResult_t e = ncclSuccess;
-  if (c->rank == root) {
-    char* p = static_cast<char*>(recv);
-    for (int k = 0; k < c->world && e == ncclSuccess; ++k)
-      if (k != root) e = r->Recv(p + (size_t)k * (size_t)bytes, (size_t)bytes, ncclUint8, k, c->comm, s);
-  } else {
-    e = r->Send(send, (size_t)bytes, ncclUint8, root, c->comm, s);
+  if (c->world > 1) {
+    if (int rc = yl::chain_enter(c, s)) return rc;
+    YL_NCCL(r, r->GroupStart());
+    ncclResult_t e = ncclSuccess;
+    if (c->rank == root) {
+      char* p = static_cast<char*>(recv);
+      for (int k = 0; k < c->world && e == ncclSuccess; ++k)
+        if (k != root) e = r->Recv(p + (size_t)k * (size_t)bytes, (size_t)bytes, ncclUint8, k, c->comm, s);
+    } else {
+      e = r->Send(send, (size_t)bytes, ncclUint8, root, c->comm, s);
+    }
+    ncclResult_t e2 = r->GroupEnd();
+    YL_NCCL(r, e);
+    YL_NCCL(r, e2);
+    if (int rc = yl::chain_exit(c, s)) return rc;
   }
-  ncclResult_t e2 = r->GroupEnd();
-  YL_NCCL(r, e);
-  YL_NCCL(r, e2);
   if (c->rank == root) {
     char* mine = static_cast<char*>(recv) + (size_t)root * (size_t)bytes;
     if (mine != send) YL_HIP(hipMemcpyAsync(mine, send, (size_t)bytes, hipMemcpyDeviceToDevice, s));

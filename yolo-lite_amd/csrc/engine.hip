@@ -1964,9 +1964,9 @@ extern "C" int yl_engine_detect_graph_prepare(yl_engine* e, const void* input, i
                                               const float* scale, float* out, int32_t* out_count, void* work, void* stream,
                                               void** graph_out) {
   if (!graph_out) return fail(-1, "yl_engine_detect_graph_prepare: null pointer");
-  if (e && e->lane_graphs)
-    return fail(-3, "yl_engine_detect_graph_prepare: a program with side lanes runs as several graphs on several streams (one batch at "
-                    "a time); the single-handle form needs a program without lanes");
+  // A program with side lanes (lane_graphs) normally replays as one graph per segment on a stream per lane; a single handle
+  // cannot carry that, so here its lanes are captured as fork/join branches of ONE graph (what detect_eager records under
+  // capture): the same results, the branches serialised by this runtime -- the price of the launch_many form for such a program.
   hipGraphExec_t ex = nullptr;
   const int rc = detect_graph_get(e, input, in_dtype, workspace, conf_thres, iou_thres, max_det, agnostic, classes, n_classes,
                                   max_cand, max_wh, scale, out, out_count, work, stream, 0, &ex, /*pin=*/true);

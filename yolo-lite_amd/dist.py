@@ -240,17 +240,22 @@ class NativeComm:
 
 
 class NativeShardedRunner:
-    """``ShardedRunner``'s schedule on the ``yl_comm_*`` transport: the same lanes (``depth`` input buffers and records per
-    slot, so a lane's exchanges are two of its slot's steps away from the compute that needs them), but scatter and gather
-    are enqueued by libyl_amd.so on HIP streams of their own, ordered against the slot streams with events, instead of
-    torch.distributed's internal stream.  Records land in ONE (world, words) tensor per lane on the root.  Same contract as
-    ``ShardedRunner.run``.
+    """``ShardedRunner``'s schedule on the ``yl_comm_*`` transport, exchange for exchange: ``depth`` input buffers and records
+    per slot; gather k and scatter k + depth * slots are enqueued by libyl_amd.so on the SLOT's OWN stream right behind
+    compute k.  Step k + depth * slots runs on the same slot, so stream order alone puts its compute behind that scatter (the
+    data has landed), the scatter behind the last reader of its buffer, and the next writer of a record behind its gather: the
+    schedule needs no event for its data hazards and NO stream beyond the slots' (a rank's batch streams each want a hardware
+    queue of their own, see bench.py's notes on GPU_MAX_HW_QUEUES; round 6: with exchange streams of its own this runner read
+    46.2 k images/s at one rank beside 53.7 k resident -- and anything from 43.4 k to 50.7 k as the queue count moved --, with one
+    exchange stream 50.9 k).  Records land in ONE (world, words) tensor per lane on the root.  Same contract as ``ShardedRunner.run``.
 
-    RCCL runs the operations of ONE communicator in the order the host issued them, whatever stream they name: with a single
-    communicator, scatter(k + V) queues behind gather(k), which waits for compute k -- two exchange streams on one communicator
-    overlap nothing, and the result depends on every rank issuing the same interleaving (round-5 advisor).  So: ``comm_gather``,
-    a SECOND communicator, carries the gathers on a stream of its own and the two directions really are independent; without it
-    both directions share ONE exchange stream and run in issue order, which this schedule makes identical on every rank.
+    Order on a communicator: RCCL's operations on ONE communicator must EXECUTE in the same order on every rank (two sends to
+    the same peer are matched in execution order), and operations enqueued on different streams have no order of their own.
+    libyl_amd.so keeps that order itself (csrc/comm.hip, the communicator's order chain: an operation that crosses a link waits
+    for the event its predecessor on that communicator recorded -- nothing at a world of one); the caller's part is that every
+    rank issues the same sequence, which this schedule does.  ``comm_gather``, a SECOND communicator, gives the gathers a chain
+    of their own, independent of the scatters'; without it both directions share one chain (issue order gather k,
+    scatter k + depth * slots).
 
     ``root_in_place`` (default): the root computes on ITS slice of the global batch where it lies (``yl_comm_scatter`` with
     ``recv`` = that slice copies nothing) instead of a device-to-device copy of 39 MB per step into the lane buffer; the input
@@ -277,32 +282,20 @@ class NativeShardedRunner:
         self.bufs = [torch.empty((per_rank, *shape), dtype=dtype, device=device) for _ in range(self.lanes)]
         self.gathered = [torch.empty((self.world, record_words), dtype=torch.float32, device=device)
                          if self.rank == src else None for _ in range(self.lanes)]
-        self.s_scatter = torch.cuda.Stream(device=device)
-        # (one communicator = one exchange stream for both directions, see the class docstring)
-        self.s_gather = torch.cuda.Stream(device=device) if comm_gather is not None else self.s_scatter
 
     def run(self, batches: List[Optional[torch.Tensor]], steps: int) -> Optional[List[torch.Tensor]]:
         nb, S, V = len(batches), self.slots, self.lanes
-        landed = [None] * V   # event: the scatter into lane v has completed
-        read = [None] * V     # event: the compute that read lane v's buffer (and wrote its record) has completed
-        sent = [None] * V     # event: the gather of lane v's record has completed
         recs = [None] * V
-        for st in self.streams:  # an earlier run's readers of the lane buffers
-            self.s_scatter.wait_stream(st)
-
         inputs = [None] * V   # what step k's compute reads: the lane buffer, or (root, in place) its slice of the global batch
 
         def scatter(k: int):
-            v = k % V
-            if read[v] is not None:
-                self.s_scatter.wait_event(read[v])  # the buffer's last reader
+            v, st = k % V, self.streams[k % S]
             gb = batches[k % nb]
             if self.root_in_place and self.rank == self.src:
                 inputs[v] = gb[self.src * self.per_rank: (self.src + 1) * self.per_rank]  # (recv == the root's own slice: no copy)
             else:
                 inputs[v] = self.bufs[v]
-            self.comm.scatter(gb, inputs[v], self.src, stream=self.s_scatter)
-            landed[v] = self.s_scatter.record_event()
+            self.comm.scatter(gb, inputs[v], self.src, stream=st)
 
         for k in range(min(V, steps)):
             scatter(k)
@@ -310,20 +303,13 @@ class NativeShardedRunner:
         for k in range(steps):
             j, v = k % S, k % V
             st = self.streams[j]
-            st.wait_event(landed[v])
-            if sent[v] is not None:  # the gather of step k - V still reads the record this step overwrites
-                st.wait_event(sent[v])
             with torch.cuda.stream(st):
                 recs[v] = self.compute(inputs[v], j, v)
-            read[v] = st.record_event()
-            self.s_gather.wait_event(read[v])
-            self.comm_g.gather(recs[v], self.gathered[v], self.src, stream=self.s_gather)
-            sent[v] = self.s_gather.record_event()
+            self.comm_g.gather(recs[v], self.gathered[v], self.src, stream=st)
             if k + V < steps:
                 scatter(k + V)
             last = v
-        for st in self.streams:  # a caller that synchronises its slot streams has the gathered records too
-            st.wait_stream(self.s_gather)
+        # (a caller that synchronises its slot streams has the gathered records too: the gathers ran on them)
         if last is None or self.rank != self.src:
             return None
         return list(self.gathered[last].unbind(0))
