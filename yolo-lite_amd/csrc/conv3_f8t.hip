@@ -18,6 +18,7 @@
 // block's 48 x 864 filter in 168 registers.  In the guarded layout a tap is a constant offset of the linear position; a k-group
 // (tap, plane) is therefore one constant LDS offset per lane and k-step, computed once per kernel.
 #include "conv_common.h"
+#include "f8_epilogue.h"
 
 namespace yl {
 
@@ -34,8 +35,8 @@ static __host__ __device__ inline int f8t_PL(int L, int W1) { return (L + 2 * W1
 // One tile of NT fragments per wave: k-loop from LDS, `mid()` (free the buffer, request the next tile), epilogue (conv_f8_kernel's).
 template <int CG, int NT, typename Mid>
 __device__ __forceinline__ void f8t_tile(const ConvArgs& a, const f8t_v8i (&wf)[(9 * CG + 7) / 8][3], const unsigned (&koff)[(9 * CG + 7) / 8],
-                                         const unsigned char* tb, int r0, int n, int g, int cb, const __amdgpu_buffer_rsrc_t& rout,
-                                         const __amdgpu_buffer_rsrc_t& rres, Mid mid) {
+                                         const unsigned char* tb, int r0, int n, int g, int cb, const float* lab,
+                                         const __amdgpu_buffer_rsrc_t& rout, const __amdgpu_buffer_rsrc_t& rres, Mid mid) {
   constexpr int KSN = (9 * CG + 7) / 8, MT = 3;  // a wave's channel block: 48 output channels
   f32x4 acc[MT][NT];
 #pragma unroll
@@ -71,53 +72,7 @@ __device__ __forceinline__ void f8t_tile(const ConvArgs& a, const f8t_v8i (&wf)[
     const int y = R - b * (a.t_H + 1);
     opix[nt] = (r < nqv && y < a.t_H && x < a.t_W) ? a.in_g0 + r : -1;
   }
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int co = cb * 48 + mt * 16 + g * 4;
-    const f32x4 alpha_r = *reinterpret_cast<const f32x4*>(a.alpha + co);
-    const f32x4 bias_r = *reinterpret_cast<const f32x4*>(a.bias + co);
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const bool ok = opix[nt] >= 0;
-      float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        v[r] = __builtin_fmaf(acc[mt][nt][r], alpha_r[r], bias_r[r]);
-        if (a.act) v[r] = silu_f(v[r]);
-      }
-      if (a.res) {
-        if (a.res_f8) {
-          const unsigned ro = ok ? (unsigned)(co >> 4) * a.res_plane + (unsigned)opix[nt] * 16u + (unsigned)(co & 15) : OOB_LANE;
-          const int rv = (int)__builtin_amdgcn_raw_buffer_load_b32(rres, ro, 0, 0);
-          v[0] += a.res_scale * __builtin_amdgcn_cvt_f32_fp8(rv, 0);
-          v[1] += a.res_scale * __builtin_amdgcn_cvt_f32_fp8(rv, 1);
-          v[2] += a.res_scale * __builtin_amdgcn_cvt_f32_fp8(rv, 2);
-          v[3] += a.res_scale * __builtin_amdgcn_cvt_f32_fp8(rv, 3);
-        } else {
-          const unsigned ro = ok ? (unsigned)(co >> 3) * a.res_plane + (unsigned)opix[nt] * 16u + (unsigned)(co & 7) * 2u : OOB_LANE;
-          const bf16x4 rv = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rres, ro, 0, 0));
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
-        }
-      }
-      if (a.out_f8) {
-        const unsigned vo = ok ? (unsigned)(co >> 4) * a.out_plane + (unsigned)opix[nt] * 16u + (unsigned)(co & 15) : OOB_LANE;
-        const float is = a.out_inv_scale;
-        store_b32_nt(pack_f8x4(v[0] * is, v[1] * is, v[2] * is, v[3] * is), rout, vo, a.st_nt & 2);
-      } else {
-        const unsigned vo = ok ? (unsigned)(co >> 3) * a.out_plane + (unsigned)opix[nt] * 16u + (unsigned)(co & 7) * 2u : OOB_LANE;
-        store_b64_nt(u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])}, rout, vo, a.st_nt);
-        if (a.out8) {  // e4m3 copy of the bf16 result for the next fp8 conv
-          const __amdgpu_buffer_rsrc_t r8 = __builtin_amdgcn_make_buffer_rsrc(a.out8, (short)0, a.out8_bytes, 0x00020000);
-          const int c = co - a.out8_c0;
-          const bool ok8 = ok && c >= 0 && c < a.out8_n;
-          const float is = a.out8_inv_scale;
-          const unsigned v8 = ok8 ? (unsigned)(c >> 4) * a.out8_plane + (unsigned)opix[nt] * 16u + (unsigned)(c & 15) : OOB_LANE;
-          store_b32_nt(pack_f8x4(v[0] * is, v[1] * is, v[2] * is, v[3] * is), r8, v8, a.st_nt & 2);
-        }
-      }
-    }
-  }
+  f8_epilogue_any<MT, NT>(a, acc, opix, cb, g, lab, rres, rout);
 }
 
 // NCBW: channel blocks (of 48 output channels) per workgroup = CG / 3 (one workgroup holds the whole conv: eight waves at 96 channels) or
@@ -173,6 +128,16 @@ __global__ __launch_bounds__(64 * F8T_NCOL * NCBW) __attribute__((amdgpu_waves_p
     pos_cur = tile_of(0, nt_cur);
     stage(pos_cur, nt_cur);
   }
+  // the epilogue's alpha / bias of the workgroup's channel blocks -> LDS behind the tile (f8_epilogue.h; visible behind the first
+  // barrier of the tile loop): [block of the workgroup][alpha 48, bias 48]
+  float* const lab_all = reinterpret_cast<float*>(tsm + (size_t)CG * PLB);
+  if (tid < NCBW * 96) {
+    const int blk = tid / 96, i = tid - blk * 96;
+    const int cbq = blk + (wgraw % NSPLIT) * NCBW;
+    lab_all[tid] = (i < 48 ? a.alpha : a.bias)[cbq * 48 + (i < 48 ? i : i - 48)];
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  const float* const lab = lab_all + (wave / F8T_NCOL) * 96;
   // this wave's channel block of the filter, conv_f8_pack_weights order [cb][k-step][MT][half][64 lanes] x 16 bytes
   f8t_v8i wf[KSN][MT];
   {
@@ -235,14 +200,14 @@ __global__ __launch_bounds__(64 * F8T_NCOL * NCBW) __attribute__((amdgpu_waves_p
     const int r0 = pos_cur + col * 16 * nt_cur;
     if constexpr (NTM == 4) {
       switch (nt_cur) {
-        case 4: f8t_tile<CG, 4>(a, wf, koff, tb, r0, n, g, cb, rout, rres, mid); break;
-        case 3: f8t_tile<CG, 3>(a, wf, koff, tb, r0, n, g, cb, rout, rres, mid); break;
-        case 2: f8t_tile<CG, 2>(a, wf, koff, tb, r0, n, g, cb, rout, rres, mid); break;
-        default: f8t_tile<CG, 1>(a, wf, koff, tb, r0, n, g, cb, rout, rres, mid); break;
+        case 4: f8t_tile<CG, 4>(a, wf, koff, tb, r0, n, g, cb, lab, rout, rres, mid); break;
+        case 3: f8t_tile<CG, 3>(a, wf, koff, tb, r0, n, g, cb, lab, rout, rres, mid); break;
+        case 2: f8t_tile<CG, 2>(a, wf, koff, tb, r0, n, g, cb, lab, rout, rres, mid); break;
+        default: f8t_tile<CG, 1>(a, wf, koff, tb, r0, n, g, cb, lab, rout, rres, mid); break;
       }
     } else {
-      if (nt_cur == 2) f8t_tile<CG, 2>(a, wf, koff, tb, r0, n, g, cb, rout, rres, mid);
-      else f8t_tile<CG, 1>(a, wf, koff, tb, r0, n, g, cb, rout, rres, mid);
+      if (nt_cur == 2) f8t_tile<CG, 2>(a, wf, koff, tb, r0, n, g, cb, lab, rout, rres, mid);
+      else f8t_tile<CG, 1>(a, wf, koff, tb, r0, n, g, cb, lab, rout, rres, mid);
     }
     nt_prev = nt_cur;
     nt_cur = nt_next;
@@ -296,7 +261,7 @@ static int f8t_launch_t(ConvArgs a, int batch, hipStream_t s) {
   int grid = nsmall > nfull_tiles ? nsmall : nfull_tiles;
   if (grid > resident) grid = resident;
   if (grid < 1) grid = 1;
-  const size_t lds = (size_t)CG * a.t_PL * 16;
+  const size_t lds = (size_t)CG * a.t_PL * 16 + (size_t)NCBW * 96 * 4;  // the tile + alpha / bias of the workgroup's channel blocks
   auto kern = conv3_f8t_kernel<CG, NCBW>;
   if (int rc = allow_big_lds(reinterpret_cast<const void*>(kern), (int)(160 * 1024))) return rc;
   hipLaunchKernelGGL(kern, dim3(grid * NSPLIT), dim3(64 * F8T_NCOL * NCBW), lds, s, a);

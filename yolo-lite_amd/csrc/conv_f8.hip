@@ -21,6 +21,7 @@
 // D: lane (pixel n, group g) holds channels 16 mt + 4 g + r of tile mt: 4-byte (fp8) or 8-byte (bf16) stores, which a
 // wave still issues as 256 contiguous bytes per tile.
 #include "conv_common.h"
+#include "f8_epilogue.h"
 
 #include <cmath>
 
@@ -157,6 +158,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
   const bf16x8* wsrc = reinterpret_cast<const bf16x8*>(a.wpk) + (size_t)cb * a.ksteps * MT * 128;  // 16-byte units
   const v4i* wl = reinterpret_cast<const v4i*>(smem8) + lane;
   const bool multi = a.kchunk < a.ksteps;
+  if (tid < 2 * MT * 16) {  // the epilogue's alpha / bias of this channel block -> LDS (visible behind the first slab barrier)
+    float* lab = reinterpret_cast<float*>(smem8 + a.ab_off);
+    const int i = tid < MT * 16 ? tid : tid - MT * 16;
+    lab[tid] = (tid < MT * 16 ? a.alpha : a.bias)[cb * MT * 16 + i];
+  }
   bool first = true;
   for (int pp = 0; pp < a.ppw; ++pp) {
     if (!first && !live) break;
@@ -208,60 +214,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void c
     for (int nt = 0; nt < NT; ++nt) opix[nt] = P.opix[nt];
     patch += 4;
     live = (pp + 1 < a.ppw) && patch < a.npatches;
+    // the next patch's first fragments are requested before the epilogue; with six channel tiles only its first k-step (the
+    // accumulators, two steps of fragments and the epilogue's own registers do not fit 256: the spills' reloads each cost a
+    // vmcnt(0) in the middle of the stores), the second step behind the epilogue
+    constexpr int DPRE = MT == 6 ? 1 : D;
     if (live) {
       patch_setup<NT>(a, patch, n, lane_off, P);
 #pragma unroll
-      for (int d = 0; d < D; ++d) fetch_b8<KS, NT, UNIFORM>(a, rin, d, g, P, xr[d]);
+      for (int d = 0; d < DPRE; ++d) fetch_b8<KS, NT, UNIFORM>(a, rin, d, g, P, xr[d]);
     }
-    // ---- epilogue: dequantise, bias, SiLU, residual, store
+    // ---- epilogue (f8_epilogue.h): the hot combinations of residual / output kind are compiled as straight-line code
+    f8_epilogue_any<MT, NT>(a, acc, opix, cb, g, reinterpret_cast<const float*>(smem8 + a.ab_off), rres, rout);
+    if (DPRE < D && live) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-      const int co = cb * MT * 16 + mt * 16 + g * 4;
-      const bool cok = co < a.Cout;
-      // per-lane dequantisation factor and bias of its 4 channels of this tile (L1-resident; not held across the k-loop)
-      const f32x4 alpha_r = *reinterpret_cast<const f32x4*>(a.alpha + co);
-      const f32x4 bias_r = *reinterpret_cast<const f32x4*>(a.bias + co);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const bool ok = cok && opix[nt] >= 0;
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          v[r] = __builtin_fmaf(acc[mt][nt][r], alpha_r[r], bias_r[r]);
-          if (a.act) v[r] = silu_f(v[r]);
-        }
-        if (a.res) {
-          if (a.res_f8) {
-            const unsigned ro = ok ? (unsigned)(co >> 4) * a.res_plane + (unsigned)opix[nt] * 16u + (unsigned)(co & 15) : OOB_LANE;
-            const int rv = (int)__builtin_amdgcn_raw_buffer_load_b32(rres, ro, 0, 0);
-            v[0] += a.res_scale * __builtin_amdgcn_cvt_f32_fp8(rv, 0);
-            v[1] += a.res_scale * __builtin_amdgcn_cvt_f32_fp8(rv, 1);
-            v[2] += a.res_scale * __builtin_amdgcn_cvt_f32_fp8(rv, 2);
-            v[3] += a.res_scale * __builtin_amdgcn_cvt_f32_fp8(rv, 3);
-          } else {
-            const unsigned ro = ok ? (unsigned)(co >> 3) * a.res_plane + (unsigned)opix[nt] * 16u + (unsigned)(co & 7) * 2u : OOB_LANE;
-            const bf16x4 rv = __builtin_bit_cast(bf16x4, __builtin_amdgcn_raw_buffer_load_b64(rres, ro, 0, 0));
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
-          }
-        }
-        if (a.out_f8) {
-          const unsigned vo = ok ? (unsigned)(co >> 4) * a.out_plane + (unsigned)opix[nt] * 16u + (unsigned)(co & 15) : OOB_LANE;
-          const float is = a.out_inv_scale;
-          store_b32_nt(pack_f8x4(v[0] * is, v[1] * is, v[2] * is, v[3] * is), rout, vo, a.st_nt & 2);
-        } else {
-          const unsigned vo = ok ? (unsigned)(co >> 3) * a.out_plane + (unsigned)opix[nt] * 16u + (unsigned)(co & 7) * 2u : OOB_LANE;
-          store_b64_nt(u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])}, rout, vo, a.st_nt);
-          if (a.out8) {  // e4m3 copy of the bf16 result for the next fp8 conv
-            const __amdgpu_buffer_rsrc_t r8 = __builtin_amdgcn_make_buffer_rsrc(a.out8, (short)0, a.out8_bytes, 0x00020000);
-            const int c = co - a.out8_c0;
-            const bool ok8 = ok && c >= 0 && c < a.out8_n;
-            const float is = a.out8_inv_scale;
-            const unsigned v8 = ok8 ? (unsigned)(c >> 4) * a.out8_plane + (unsigned)opix[nt] * 16u + (unsigned)(c & 15) : OOB_LANE;
-            store_b32_nt(pack_f8x4(v[0] * is, v[1] * is, v[2] * is, v[3] * is), r8, v8, a.st_nt & 2);
-          }
-        }
-      }
+      for (int d = DPRE; d < D; ++d) fetch_b8<KS, NT, UNIFORM>(a, rin, d, g, P, xr[d]);
     }
   }
 }
@@ -342,7 +308,7 @@ int conv_f8_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int 
     }
   }
   c->kchunk = kchunk;
-  c->lds_bytes = (size_t)(c->slab2 ? 2 * kchunk : kchunk) * step_bytes;
+  c->lds_bytes = (size_t)(c->slab2 ? 2 * kchunk : kchunk) * step_bytes + (size_t)MT * 16 * 8;  // + the block's alpha / bias (conv_f8_kernel's epilogue)
   c->post = 0;
   c->wpk_elems = (size_t)ncb * ksteps * MT * 2048;  // bytes
   c->npatches = (int)((npix + 16 * NT - 1) / (16 * NT));
@@ -449,6 +415,7 @@ int conv_f8_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s) 
   a.nblocks = cfg.gws * cfg.ncb;
   a.dbg = 0;
   a.st_nt = st_nt_policy(outb);
+  a.ab_off = (int)(cfg.lds_bytes - (size_t)cfg.MT * 16 * 8);
   if (cfg.f8t) return conv3_f8t_launch(cfg, a, batch, s);
   return cfg.ntaps == 9 ? launch8_m<3>(cfg, a, s) : launch8_m<1>(cfg, a, s);
 }
