@@ -185,6 +185,30 @@ def test_fp8_network_close_to_bf16(gpu_device, monkeypatch, scale, h, w, mode):
             assert e8.guards_are_zero(o["out"])
 
 
+def test_copy_only_producer_is_bit_identical(gpu_device, monkeypatch):
+    """yl_op.out8_only on a plain conv (YOLO11x: model.2.cv2, whose only reader is the e4m3 conv model.3): the bf16 store is
+    dropped (a zero-byte descriptor), the e4m3 copy and everything downstream are the same bits as with the store; the bf16
+    buffer the store would have hit keeps its old contents."""
+    from yololite_amd.nn import arch
+    from yololite_amd.nn.engine import HipEngine
+    from yololite_amd.nn.synth import synth_state_dict
+
+    specs, _ = arch.parse_model(arch.yolo11_dict("x"))
+    sd = synth_state_dict("x", 3, cls_bias=[-2.0, -2.0, -2.0], cls_gain=4.0)
+    x = torch.randint(0, 256, (2, 3, 64, 96), generator=torch.Generator().manual_seed(5), dtype=torch.uint8).to(gpu_device)
+    outs = []
+    for only in ("0", "1"):
+        monkeypatch.setenv("YL_FP8_OUT8_ONLY", only)
+        e8 = HipEngine.from_model(specs, sd, 2, 64, 96, gpu_device, fp8_calib=x, keep_logits=True)
+        flagged = [o["name"] for o in e8.prog.ops if o.get("out8_only")]
+        assert flagged == (["model.0", "model.2.cv2"] if only == "1" else ["model.0"]), flagged
+        y = e8.forward(x).clone()
+        assert torch.equal(e8.forward(x, graph=True), y)
+        outs.append((y, [t.clone() for t in e8.raw_levels()]))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert all(torch.equal(a, b) for a, b in zip(outs[0][1], outs[1][1]))
+
+
 FP8_SCORE_ATOL = 0.12  # stated tolerance of the e4m3 mode: 1.5 x the bf16 band (measured max |dscore| below)
 
 

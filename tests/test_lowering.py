@@ -167,6 +167,18 @@ def test_fp8_pass_structure(scale, with_1x1, monkeypatch):
             wrote(v, o["out8_scale"])
     if scale == "x":  # every e4m3 tensor comes out of a producer's epilogue: no quantize pass left, the stem stores fp8 only
         assert not any(o["kind"] == OP_QUANT for o in p8.ops) and p8.ops[0].get("out8_only") == 1
+    # a copy-only producer: the copy covers the whole output and NO op of the program reads the bf16 planes it would have written
+    only = [o for o in p8.ops if o.get("out8_only")]
+    for o in only:
+        assert o["out8_c0"] == 0 and o["out8"].C == o["out"].C and o.get("res") is None
+        mine = {(o["out"].offset, pl) for pl in range(o["out"].coff // 8, (o["out"].coff + o["out"].C) // 8)}
+        for r in p8.ops:
+            for key in ("inp", "res", "inp2"):
+                v = r.get(key)
+                if v is not None and v.dtype != FP8:
+                    assert not ({(v.offset, pl) for pl in range(v.coff // 8, (v.coff + v.C) // 8)} & mine), (o["name"], r["name"], key)
+    if scale == "x" and not with_1x1:  # the stem and model.2.cv2 (read by model.3 alone)
+        assert [o["name"] for o in only] == ["model.0", "model.2.cv2"], [o["name"] for o in only]
     if with_1x1:
         assert n8 >= {"n": 35, "s": 50, "x": 130}[scale]
         assert sum(o["kind"] == OP_CONV and o["out"].dtype == FP8 for o in p8.ops) >= {"n": 15, "s": 25, "x": 80}[scale]

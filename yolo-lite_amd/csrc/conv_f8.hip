@@ -266,13 +266,16 @@ int conv_f8_choose(int batch, int Cin, int Cout, int k, int stride, int Ho, int 
   // (YOLO11x 1280x1280: the stride-2 3x3 convs 1.56 -> 1.43 ms).  Not instead of three tiles (the 96-channel Bottleneck convs
   // get slower: 250+ VGPRs with a few spills do not pay on short k-loops).  YL_F8_MT6=0 turns it off.
   const int mt6 = tune_int("YL_F8_MT6", 1);
-  if (mt6 && MT == 4 && cout16 % 6 == 0 && Cin >= 128) MT = 6;
+  const long long npix = (long long)batch * Ho * Wo;
+  // ... and not on maps so small that six tiles x 64 pixels per wave leave CUs idle (YOLO11x 1280x1280 batch 8: the 192 -> 192
+  // convs at 40x40 are 400 waves = 100 workgroups for 256 CUs): YL_F8_MT6_MINWG = fewest workgroups the six-tile form must fill
+  const long long wg6 = (npix + 63) / 64 * (cout16 / 6) / 4;
+  if (mt6 && MT == 4 && cout16 % 6 == 0 && Cin >= 128 && wg6 >= tune_int("YL_F8_MT6_MINWG", 0)) MT = 6;
   const int ntaps = k * k, cg = Cin / 16;
   const int ksteps = (ntaps * cg + 7) / 8;
   const size_t slab_max = 72 * 1024, step_bytes = (size_t)MT * 2048;
   int kchunk = ksteps;
   if ((size_t)ksteps * step_bytes > slab_max) kchunk = (int)(slab_max / step_bytes) & ~1;  // multiple of the ring depth
-  const long long npix = (long long)batch * Ho * Wo;
   const int ncb = cout16 / MT;
   const int force_nt = tune_int("YL_F8_NT", 0);  // development: pixel tiles per wave for MT <= 4
   const int NT = (force_nt == 2 || force_nt == 4) && MT != 6 ? force_nt : ((npix + 63) / 64 * ncb / 4 >= 256 || MT == 6 ? 4 : 2);
@@ -410,7 +413,7 @@ int conv_f8_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s) 
   if (inb > lim || outb > lim || resb > lim)
     return fail(-3, "fp8 conv: a tensor slice exceeds 1 GiB (32-bit buffer offsets); lower the batch size");
   a.in_bytes = (unsigned)inb;
-  a.out_bytes = (unsigned)outb;
+  a.out_bytes = a.out8 && a.out8_only ? 0u : (unsigned)outb;  // (copy only: a descriptor of zero bytes drops every bf16 store)
   a.res_bytes = (unsigned)resb;
   a.nblocks = cfg.gws * cfg.ncb;
   a.dbg = 0;

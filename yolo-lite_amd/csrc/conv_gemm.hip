@@ -599,7 +599,7 @@ int conv_gemm_launch(const ConvConfig& cfg, ConvArgs a, int batch, hipStream_t s
   if (inb > lim || outb > lim || resb > lim || (long long)cfg.ncb * cfg.ksteps * cfg.MT * 1024 > lim)
     return fail(-3, "conv_gemm: a tensor slice exceeds 1 GiB (32-bit buffer offsets); lower the batch size");
   a.in_bytes = (unsigned)inb;
-  a.out_bytes = (unsigned)outb;
+  a.out_bytes = a.out8 && a.out8_only ? 0u : (unsigned)outb;  // (copy only: a descriptor of zero bytes drops every bf16 store)
   a.res_bytes = (unsigned)resb;
   a.nblocks = cfg.gws * cfg.ncb;
   a.dbg = 0;

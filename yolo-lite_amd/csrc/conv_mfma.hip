@@ -1212,7 +1212,7 @@ static int conv_prepare(const ConvConfig& cfg, ConvArgs& a, int batch) {
       a.in2_bytes = (unsigned)in2b;
     }
     a.in_bytes = (unsigned)inb;
-    a.out_bytes = (unsigned)outb;
+    a.out_bytes = a.out8 && a.out8_only ? 0u : (unsigned)outb;  // (copy only: a descriptor of zero bytes drops every bf16 store)
     a.res_bytes = (unsigned)resb;
     a.st_nt = a.out_f32 ? 0 : st_nt_policy(outb);
   }

@@ -253,6 +253,7 @@ static int check_out8(const yl_op& o, int batch, int64_t ws_bytes, const std::st
   if (o.out8.dtype != YL_FP8 || o.out8.H != o.out.H || o.out8.W != o.out.W || o.out8_c0 < 0 || (o.out8_c0 & 7) ||
       o.out8_c0 + o.out8.C > o.out.C || !(o.out8_scale > 0.f) || o.out.dtype != YL_BF16)
     return fail(-1, tag + ": out8 must be an fp8 view of the output's dims covering a channel range of a bf16 output");
+  if (o.out8_only && (o.out8_c0 != 0 || o.out8.C != o.out.C)) return fail(-1, tag + ": out8_only needs a copy of all output channels");
   return 0;
 }
 
@@ -264,6 +265,7 @@ static void fill_out8(ConvArgs& a, const yl_op& o, char* ws, int B) {
   a.out8_inv_scale = 1.0f / o.out8_scale;
   a.out8_c0 = o.out8_c0;
   a.out8_n = o.out8.C;
+  a.out8_only = o.out8_only;
 }
 
 template <typename T>
@@ -423,6 +425,7 @@ extern "C" int yl_engine_create(const yl_op* ops, int n_ops, int batch, int in_h
         if (!post && !o.stem_weight && !o.cin_weight && o.out.dtype == YL_BF16 && !(up && o.res.offset >= 0) &&
             !(o.k == 3 && o.out8.offset >= 0) && !o.dfl_level)
           conv_gemm_choose(batch, cin_total, cout1, o.k, o.stride, Ho, Wo, &r.cfg, up ? o.in2.C : 0);
+        if (o.out8_only && o.out8.offset < 0) return fail(-1, tag + ": out8_only without out8");
         if (o.out8.offset >= 0) {
           if (int rc = check_out8(o, batch, workspace_bytes, tag)) return rc;
           if (post || o.stem_weight) return fail(-1, tag + ": out8 needs a plain conv");

@@ -167,6 +167,7 @@ struct ConvArgs {
   unsigned out8_plane, out8_bytes;
   float out8_inv_scale;
   int out8_c0, out8_n;
+  int out8_only;               // the e4m3 copy is the ONLY output (every reader is an fp8 conv): the launchers give the bf16 descriptor zero bytes, its stores vanish
   int ab_off;                  // conv_f8_kernel: byte offset in LDS of the channel block's alpha / bias (behind the filter slab)
 };
 

@@ -550,7 +550,13 @@ def apply_fp8(ops: List[dict], ar: "_Arena", scales: Dict[str, float]) -> List[d
                 p = producer(x, o.get("lane", 0)) if dual else None
                 if p is not None:  # the producer's epilogue writes the e4m3 copy next to (or instead of) its bf16 output
                     p.update(out8=q, out8_c0=x.coff - p["out"].coff, out8_scale=sc)
-                    if p["kind"] == OP_STEM and all(cand(r) and key(r["inp"]) == key(x) for r in ops if reads(r) & planes(p["out"])):
+                    # nothing but fp8 convs ever reads this buffer (conservatively: no op of the whole program, before or after):
+                    # the copy is the only output -- the stem's (model.0 -> model.1) and, round 6, a plain conv's (YOLO11x: model.2.cv2
+                    # -> model.3, 629 MB of bf16 per batch of eight 1280x1280 images that nobody read)
+                    only_ok = p["kind"] == OP_STEM or (key(x) == key(p["out"]) and p.get("res") is None and not p.get("accumulate")
+                                                       and os.environ.get("YL_FP8_OUT8_ONLY", "1") != "0")
+                    if only_ok and all(cand(r) and key(r["inp"]) == key(x) and not (planes(r.get("res")) & planes(p["out"]))
+                                       for r in ops if reads(r) & planes(p["out"])):
                         p["out8_only"] = 1
                 else:
                     out.append(dict(kind=OP_QUANT, name=o["name"] + ".q8", inp=x, out=q, res=None, out_scale=sc,
