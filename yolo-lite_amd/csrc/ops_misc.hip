@@ -218,7 +218,10 @@ __global__ __launch_bounds__(64 * STEM_MAXW) void stem_kernel(StemArgs a, const 
 int stem_launch(const StemArgs& a0, int in_dtype, hipStream_t s) {
   if (a0.Cout % 16) return fail(-3, "stem: output channels must be a multiple of 16");
   StemArgs a = a0;
-  const int waves = std::min(STEM_MAXW, (a.Wo + 63) / 64);
+  // row segments of equal size: the fewest that fit STEM_MAXW waves, then the fewest waves that cover one (640 output columns
+  // used to be 512 + 128 -- the second workgroup of every row ran six of its eight waves on nothing: 2 x 5 waves now)
+  const int nseg0 = (a.Wo + 64 * STEM_MAXW - 1) / (64 * STEM_MAXW);
+  const int waves = std::max(1, ((a.Wo + nseg0 - 1) / nseg0 + 63) / 64);
   const int nthr = 64 * waves;
   a.nseg = (a.Wo + nthr - 1) / nthr;
   const unsigned blocks = (unsigned)(a.B * a.Ho * a.nseg);
