@@ -162,7 +162,8 @@ typedef struct yl_op {
   /* YL_OP_CONV (plain, bf16 or fp8 input, bf16 output) and YL_OP_STEM: out8.offset >= 0 makes the epilogue ALSO store
      e4m3(y / out8_scale) of output channels [out8_c0, out8_c0 + out8.C) into the fp8 view out8 (same H, W) -- the copy an
      fp8 conv reads -- so no YL_OP_QUANT pass over the tensor is needed.  out8_c0 % 8 == 0, out8.C % 16 == 0.
-     YL_OP_STEM with out8_only != 0 stores nothing but that copy (every reader of the stem's output is an fp8 conv). */
+     out8_only != 0 (YL_OP_STEM, and a plain YL_OP_CONV whose copy covers all output channels): the op stores nothing but that copy --
+     every reader of its output is an fp8 conv (the lowering proves that no op of the program reads the bf16 planes). */
   yl_view out8;
   float out8_scale;
   int32_t out8_only;
