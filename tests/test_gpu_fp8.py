@@ -102,7 +102,7 @@ def test_conv3_f8_tile_kernel_vs_torch_and_direct(gpu_device, monkeypatch, C, B,
         out_scale = 0.05
     monkeypatch.setenv("YL_F8_KORD", "1" if kord == "1" else "0")   # plane-major K order from 1 pixel per image up / never
     monkeypatch.setenv("YL_F8_TILE_MIN", "1")
-    monkeypatch.setenv("YL_F8_TILE", "2")   # the 96-channel form is opt-in
+    monkeypatch.setenv("YL_F8_TILE", "2")   # (the default: 48- and 96-channel forms)
     y = run_conv_f8(gpu_device, xq, in_scale, w, b, 3, 1, True, res, res_scale, out_scale, expect_kernel="conv3x3_f8_tile_mfma")
     ref = _ref(xq, in_scale, w, b, 3, 1, True, res, res_scale)
     if out_scale > 0:

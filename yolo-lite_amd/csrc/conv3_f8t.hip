@@ -220,12 +220,11 @@ static unsigned f8t_magic(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000u
 
 // may this conv take the tile kernel?  (3x3 stride 1, 48 -> 48 or 96 -> 96 in channel blocks of 48, enough positions, the tile fits the LDS)
 bool conv3_f8t_fits(const ConvConfig& cfg, int batch, int Cin, int Cout, int k, int stride, int Ho, int Wo) {
-  // YL_F8_TILE: 0 never, 1 (default) the 48-channel form, 2 the 96-channel form too (a pair of four-wave workgroups per tile walk;
-  // YL_F8_TILE_W8=1: one eight-wave workgroup).  Config 5, A / B on one box: 48 only 1 117 -> 1 129 images/s (+1 %); with the
-  // 96-channel form 1 095-1 105 (-2..-2.7 %, eight-wave and four-wave form alike, although the launch alone is 8-13 % shorter: 38.9 /
-  // 36.9 against 42.6 us) -- twenty batches in flight prefer conv_f8_kernel's many short workgroups on these layers; one batch at a
-  // time both forms +2.5 %.
-  const int enable = env_int("YL_F8_TILE", 1);
+  // YL_F8_TILE: 0 never, 1 the 48-channel form only, 2 (default since the epilogue stopped waiting on its own stores) the 96-channel
+  // form too (a pair of four-wave workgroups per tile walk; YL_F8_TILE_W8=1: one eight-wave workgroup).  Config 5, A / B on one box.
+  // Round 5 (old epilogue): 48 only 1 117 -> 1 129 images/s (+1 %); with the 96-channel form 1 095-1 105 (-2..-2.7 %, although the
+  // launch alone was 8-13 % shorter).  Round 6 (f8_epilogue.h): 1 264-1 267 -> 1 271 (+0.5 %), one batch at a time 1 038-1 044 -> 1 050-1 058.
+  const int enable = env_int("YL_F8_TILE", 2);
   if (!enable || k != 3 || stride != 1 || Cin != Cout || (Cin != 48 && !(Cin == 96 && enable >= 2)) || cfg.MT != 3 || cfg.ncb != Cout / 48 ||
       cfg.cg != Cin / 16)
     return false;
