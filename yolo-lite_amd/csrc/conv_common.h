@@ -246,6 +246,48 @@ __device__ __forceinline__ void store_f32(const ConvArgs& a, __amdgpu_buffer_rsr
   }
 }
 
+// The residual form of the epilogue below for bf16 planes (activated accumulators in, even MT): straight-line code in which the
+// residual of tile pair p + 1 is requested before pair p's stores are issued, so the wait for it is a counted one that leaves the
+// stores in flight.  (As one run-time branch per tile the compiler put `s_waitcnt vmcnt(0)` behind every residual load -- on CDNA4
+// that also waits for every store before it: a load - wait - store round trip per tile; round 6, found in conv_f8_kernel first.)
+template <int MT, int NT>
+__device__ __forceinline__ void epilogue_res(const ConvArgs& a, __amdgpu_buffer_rsrc_t rout, __amdgpu_buffer_rsrc_t rres, int cb, int g,
+                                             const int (&opix)[NT], const f32x4 (&acc)[MT][NT]) {
+  static_assert(MT % 2 == 0, "tile pairs");
+  unsigned pix16[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) pix16[nt] = opix[nt] >= 0 ? (unsigned)opix[nt] * 16u : OOB_LANE;
+  u32x4 rnext[NT];
+  auto res_load = [&](int p) __attribute__((always_inline)) {
+    const int co = cb * MT * 16 + (p * 4 + g) * 8;
+    const unsigned row = co < a.Cout ? (unsigned)(co >> 3) * a.res_plane : OOB_K;  // (dead pixel 2^31, dead channel 2^30: no sum is in range)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) rnext[nt] = __builtin_amdgcn_raw_buffer_load_b128(rres, pix16[nt] + row, 0, 0);
+  };
+  res_load(0);
+#pragma unroll
+  for (int p = 0; p < MT / 2; ++p) {
+    u32x4 rcur[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) rcur[nt] = rnext[nt];
+    if (p + 1 < MT / 2) res_load(p + 1);
+    const int co = cb * MT * 16 + (p * 4 + g) * 8;
+    const unsigned row = co < a.Cout ? (unsigned)(co >> 3) * a.out_plane : OOB_K;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const bf16x8 rv = __builtin_bit_cast(bf16x8, rcur[nt]);
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[2 * p][nt][r] + (float)rv[r];
+        v[4 + r] = acc[2 * p + 1][nt][r] + (float)rv[4 + r];
+      }
+      store_b128_nt(u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])},
+                    rout, pix16[nt] + row, a.st_nt);
+    }
+  }
+}
+
 // Epilogue (the accumulators already contain the bias): SiLU, residual, 16-byte buffer stores.
 template <int MT, int NT, bool O8 = false>
 __device__ __forceinline__ void epilogue(const ConvArgs& a, __amdgpu_buffer_rsrc_t rout, __amdgpu_buffer_rsrc_t rres,
@@ -257,6 +299,12 @@ __device__ __forceinline__ void epilogue(const ConvArgs& a, __amdgpu_buffer_rsrc
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
         acc[mt][nt] = silu4(acc[mt][nt]);
+  }
+  if constexpr (!O8 && MT % 2 == 0) {
+    if (a.res && !a.out_f32) {
+      epilogue_res<MT, NT>(a, rout, rres, cb, g, opix, acc);
+      return;
+    }
   }
 #pragma unroll
   for (int p = 0; p < MT / 2; ++p) {
@@ -275,11 +323,13 @@ __device__ __forceinline__ void epilogue(const ConvArgs& a, __amdgpu_buffer_rsrc
         store_f32<8>(a, rout, ok, opix[nt], co, v);
         continue;
       }
-      if (a.res) {
-        const unsigned ro = ok ? (unsigned)(co >> 3) * a.res_plane + (unsigned)opix[nt] * 16u : OOB_LANE;
-        const bf16x8 rv = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rres, ro, 0, 0));
+      if constexpr (O8 || MT % 2 != 0) {  // (even MT without the e4m3 copy: epilogue_res above)
+        if (a.res) {
+          const unsigned ro = ok ? (unsigned)(co >> 3) * a.res_plane + (unsigned)opix[nt] * 16u : OOB_LANE;
+          const bf16x8 rv = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rres, ro, 0, 0));
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] += (float)rv[r];
+          for (int r = 0; r < 8; ++r) v[r] += (float)rv[r];
+        }
       }
       const unsigned vo = ok ? (unsigned)(co >> 3) * a.out_plane + (unsigned)opix[nt] * 16u : OOB_LANE;
       store_b128_nt(u32x4{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])},

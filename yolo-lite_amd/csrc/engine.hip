@@ -1763,6 +1763,9 @@ static int detect_eager(yl_engine* e, const void* input, int in_dtype, void* wor
 // batch at a time the 80x80 Detect branches then overlap the 40x40 / 20x20 neck instead of queueing behind it.
 // The plan is keyed without the input address: the kernel nodes of segment 0 that read the input get a new address written
 // into their parameters when it changes (yl_engine_detect_graph_rebind's mechanism), so one plan serves both entry points.
+// First call for a new argument tuple: the step runs ONCE EAGERLY (argument checks, workspace preparation, lazy function
+// attributes; one hipStreamSynchronize) and its segments are then captured and launched -- the network runs twice in that call, as
+// in detect_graph_get.  yl_engine_detect_graph_prepare on such a program captures the lanes as branches of ONE graph instead.
 static int run_range(yl_engine* e, size_t begin, size_t end, char* ws, hipStream_t s, const void* input, int in_dtype,
                      const PrefilterSink* sink) {
   for (size_t oi = begin; oi < end; ++oi) {
