@@ -379,60 +379,70 @@ def roofline_from_profile(rows, batch, cfg):
         a["flops"] += r["flops"]
         a["bytes"] += r["bytes"]
         a["launches"] += 1
-    dom = max(agg.items(), key=lambda kv: kv[1]["ms"])
-    name, a = dom
-    tf = a["flops"] / (a["ms"] * 1e-3) / 1e12 if a["ms"] > 0 else 0.0
-    gbs = a["bytes"] / (a["ms"] * 1e-3) / 1e9 if a["ms"] > 0 else 0.0
-    peak_tf = PEAK_FP8_TFLOPS if "_f8_" in name else PEAK_BF16_TFLOPS  # e4m3 kernels are priced against the fp8 peak
-    mfma_frac, hbm_frac = tf / peak_tf, gbs / PEAK_HBM_GBS
-    bound = "mfma" if mfma_frac >= hbm_frac else "hbm"
-    roof = {"kernel": name, "bound": bound,
-            "achieved": round(tf if bound == "mfma" else gbs, 2),
-            "peak": peak_tf if bound == "mfma" else PEAK_HBM_GBS,
-            "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
-            "frac": round(max(mfma_frac, hbm_frac), 4), "traffic": None,
-            "launches_per_step": a["launches"], "avg_launch_us": round(a["ms"] * 1e3 / a["launches"], 2),
-            "mfma_frac": round(mfma_frac, 4), "hbm_frac": round(hbm_frac, 4),
-            "algorithmic_bytes_per_launch": round(a["bytes"] / a["launches"])}
-    # `frac` divides by the IN-SEQUENCE HIP-event time of a launch (measured live in this run; it includes the ~2.6 us dispatch gap
-    # in front of a dependent launch); the committed rocprofv3 kernel trace gives the kernel-only duration: both are stated
-    roof["time_source"] = "in-sequence HIP events of this run (dispatch gap included)"
-    # Traffic and the kernel-only duration come from the committed per-launch table: THE SAME LAUNCHES (matched by op name) whose
-    # algorithmic work is divided above -- round 5 divided the stride-2 convs' bytes by the duration / PMC bytes of a template family
-    # that also held the stride-1 convs.  Every instance is listed; frac_rocprof must reproduce from those rows by hand.
     plp = per_launch_profile(cfg)
-    if plp:
-        fname, tab = plp
-        by_name = {r["name"]: r for r in tab["rows"]}
-        inst, miss = [], []
-        for r in rows:
-            if r["kernel"] != name:
-                continue
-            p = by_name.get(r["name"])
-            if p is None or "us_rocprof" not in p:
-                miss.append(r["name"])
-                continue
-            work = r["flops"] if bound == "mfma" else r["bytes"]
-            tr = (p.get("read_bytes", 0) + p.get("write_bytes", 0)) if "read_bytes" in p and "write_bytes" in p else None
-            inst.append({"op": r["name"], "us_in_sequence": round(r["ms"] * 1e3, 2), "us_rocprof": p["us_rocprof"],
-                         "algorithmic_bytes": round(r["bytes"]), "GFLOP": round(r["flops"] / 1e9, 3), "traffic": tr,
-                         "frac_in_sequence": round(work / (r["ms"] * 1e-3) / (1e12 if bound == "mfma" else 1e9) / roof["peak"], 4),
-                         "frac_rocprof": round(work / (p["us_rocprof"] * 1e-6) / (1e12 if bound == "mfma" else 1e9) / roof["peak"], 4)})
-        if inst and not miss:
-            us_sum = sum(i["us_rocprof"] for i in inst)
-            work_sum = sum((i["GFLOP"] * 1e9) if bound == "mfma" else i["algorithmic_bytes"] for i in inst)
-            roof["instances"] = inst
-            roof["avg_launch_us_rocprof"] = round(us_sum / len(inst), 2)
-            roof["frac_rocprof"] = round(work_sum / (us_sum * 1e-6) / (1e12 if bound == "mfma" else 1e9) / roof["peak"], 4)
-            roof["frac_rocprof_note"] = ("sum of the instances' algorithmic work / sum of their committed rocprofv3 kernel-trace durations "
-                                         f"(profiles/{fname}, kernel only, one batch in flight)")
-            if all(i["traffic"] is not None for i in inst):
-                roof["traffic"] = round(sum(i["traffic"] for i in inst) / len(inst))
-                roof["traffic_unit"] = "HBM bytes per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE), mean over the instances listed"
-                roof["traffic_source"] = f"profiles/{fname}: {tab.get('_source', '')}"
-                roof["traffic_over_algorithmic"] = round(roof["traffic"] / max(1, roof["algorithmic_bytes_per_launch"]), 3)
-        elif miss:
-            roof["traffic_note"] = f"profiles/{fname} has no row for {miss}: the program changed since that profile was taken"
+
+    def block(name, a):
+        tf = a["flops"] / (a["ms"] * 1e-3) / 1e12 if a["ms"] > 0 else 0.0
+        gbs = a["bytes"] / (a["ms"] * 1e-3) / 1e9 if a["ms"] > 0 else 0.0
+        peak_tf = PEAK_FP8_TFLOPS if "_f8_" in name else PEAK_BF16_TFLOPS  # e4m3 kernels are priced against the fp8 peak
+        mfma_frac, hbm_frac = tf / peak_tf, gbs / PEAK_HBM_GBS
+        bound = "mfma" if mfma_frac >= hbm_frac else "hbm"
+        roof = {"kernel": name, "bound": bound,
+                "achieved": round(tf if bound == "mfma" else gbs, 2),
+                "peak": peak_tf if bound == "mfma" else PEAK_HBM_GBS,
+                "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+                "frac": round(max(mfma_frac, hbm_frac), 4), "traffic": None,
+                "launches_per_step": a["launches"], "avg_launch_us": round(a["ms"] * 1e3 / a["launches"], 2),
+                "mfma_frac": round(mfma_frac, 4), "hbm_frac": round(hbm_frac, 4),
+                "algorithmic_bytes_per_launch": round(a["bytes"] / a["launches"])}
+        # `frac` divides by the IN-SEQUENCE HIP-event time of a launch (measured live in this run; it includes the ~2.6 us dispatch gap
+        # in front of a dependent launch); the committed rocprofv3 kernel trace gives the kernel-only duration: both are stated
+        roof["time_source"] = "in-sequence HIP events of this run (dispatch gap included)"
+        # Traffic and the kernel-only duration come from the committed per-launch table: THE SAME LAUNCHES (matched by op name) whose
+        # algorithmic work is divided above -- round 5 divided the stride-2 convs' bytes by the duration / PMC bytes of a template family
+        # that also held the stride-1 convs.  Every instance is listed; frac_rocprof must reproduce from those rows by hand.
+        if plp:
+            fname, tab = plp
+            by_name = {r["name"]: r for r in tab["rows"]}
+            inst, miss = [], []
+            for r in rows:
+                if r["kernel"] != name:
+                    continue
+                p = by_name.get(r["name"])
+                if p is None or "us_rocprof" not in p:
+                    miss.append(r["name"])
+                    continue
+                work = r["flops"] if bound == "mfma" else r["bytes"]
+                tr = (p.get("read_bytes", 0) + p.get("write_bytes", 0)) if "read_bytes" in p and "write_bytes" in p else None
+                inst.append({"op": r["name"], "us_in_sequence": round(r["ms"] * 1e3, 2), "us_rocprof": p["us_rocprof"],
+                             "algorithmic_bytes": round(r["bytes"]), "GFLOP": round(r["flops"] / 1e9, 3), "traffic": tr,
+                             "frac_in_sequence": round(work / (r["ms"] * 1e-3) / (1e12 if bound == "mfma" else 1e9) / roof["peak"], 4),
+                             "frac_rocprof": round(work / (p["us_rocprof"] * 1e-6) / (1e12 if bound == "mfma" else 1e9) / roof["peak"], 4)})
+            if inst and not miss:
+                us_sum = sum(i["us_rocprof"] for i in inst)
+                work_sum = sum((i["GFLOP"] * 1e9) if bound == "mfma" else i["algorithmic_bytes"] for i in inst)
+                roof["instances"] = inst
+                roof["avg_launch_us_rocprof"] = round(us_sum / len(inst), 2)
+                roof["frac_rocprof"] = round(work_sum / (us_sum * 1e-6) / (1e12 if bound == "mfma" else 1e9) / roof["peak"], 4)
+                roof["frac_rocprof_note"] = ("sum of the instances' algorithmic work / sum of their committed rocprofv3 kernel-trace durations "
+                                             f"(profiles/{fname}, kernel only, one batch in flight)")
+                if all(i["traffic"] is not None for i in inst):
+                    roof["traffic"] = round(sum(i["traffic"] for i in inst) / len(inst))
+                    roof["traffic_unit"] = "HBM bytes per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE), mean over the instances listed"
+                    roof["traffic_source"] = f"profiles/{fname}: {tab.get('_source', '')}"
+                    roof["traffic_over_algorithmic"] = round(roof["traffic"] / max(1, roof["algorithmic_bytes_per_launch"]), 3)
+            elif miss:
+                roof["traffic_note"] = f"profiles/{fname} has no row for {miss}: the program changed since that profile was taken"
+        return roof
+
+    ranked = sorted(agg.items(), key=lambda kv: -kv[1]["ms"])
+    roof = block(*ranked[0])
+    # Families within 5 % of the dominant one's time (YOLO11n: the three fused C3k2 launches and the four stride-2 convs are 122 us each,
+    # and which of them leads changes from run to run): their blocks ride along, so the line never depends on a coin toss
+    near = [kv for kv in ranked[1:] if kv[1]["ms"] >= 0.95 * ranked[0][1]["ms"]]
+    if near:
+        roof["also"] = [block(*kv) for kv in near]
+        roof["also_note"] = "families whose in-sequence time is within 5 % of the dominant family's: same block, same sources"
     # best single 3x3 layer against the MFMA roof (the north-star target names the fused 3x3 conv)
     best = None
     for r in rows:
