@@ -357,6 +357,8 @@ int yl_letterbox_u8(const uint8_t* src_bgr_hwc, int src_h, int src_w, int src_pi
  * the communicator recorded: RCCL matches sends to one peer in execution order and orders nothing between streams itself), so
  * a binder may put each exchange on the stream of the step it belongs to.  One that wants the scatters of step k + n to
  * overlap the gathers of step k creates TWO communicators, one per direction (yololite_amd/dist.py NativeShardedRunner does).
+ * The calls record and wait on events of their own: issue them on live streams, not inside a stream capture (the engine's graphs
+ * hold the compute; the exchanges go between graph launches).
  * STATUS: EXPERIMENTAL.  Exercised with a world of one on the GPU (tests/test_gpu_dist.py) and never yet with a peer on the
  * other end of a link -- no multi-GPU machine was available to this build; a two-process test is in place and skips itself
  * below two devices.  bench.py --gpus N uses torch.distributed (backend nccl = RCCL) unless YL_BENCH_COMM=native. */
